@@ -1,0 +1,161 @@
+/*
+ * tde_abi.h — plain-C data contract of the batched driving-env step path.
+ *
+ * Shared by the HIP library (include/tde_hip.h -> libtde_hip.so, device pointers) and by the CPU
+ * oracle (oracle/tde_oracle.c -> libtde_oracle.so, host pointers).  It is an interface description
+ * only: no algorithm lives here.  Every struct is laid out with natural alignment and explicit
+ * padding so that a ctypes.Structure (torchdriveenv_amd/_abi.py) mirrors it field for field.
+ *
+ * Vocabulary follows the reference (inverted-ai/torchdriveenv):
+ *   env      one simulator instance           (reference: one WaypointSuiteEnv, gym_env.py:303)
+ *   agent    one vehicle slot of an env; slot 0 is the ego, the rest are NPCs
+ *            (reference: npc_mask = all True except index 0, gym_env.py:269-271)
+ *   state    (x, y, psi, v) per agent         (reference: simulator.get_state() -> (B,A,4), gym_env.py:371-375)
+ *   attrs    (length, width, rear_axis_offset) (reference: agent_attributes (B,A,3), gym_env.py:241-247,261)
+ *   scenario one entry of a WaypointSuite      (reference: gym_env.py:63-68, data/validation_cases.yml)
+ *   replay   pre-recorded NPC trajectory       (reference: replay_states/replay_mask, gym_env.py:275-283)
+ *
+ * Layout: struct-of-arrays, env-major.  Agent arrays have B*A elements, element (e,a) at e*A + a.
+ * A must be a power of two, 1..64, so that an env never straddles a 64-lane wavefront.
+ */
+#ifndef TDE_ABI_H
+#define TDE_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDE_ABI_VERSION 1
+#define TDE_MAX_AGENTS 64
+
+/* feature bits of tde_config.flags */
+#define TDE_F_NPC        (1u << 0)  /* heuristic NPC controller drives slots 1..A-1 (else they coast: zero action,
+                                       which is what NPCWrapper feeds the kinematic model before teleporting) */
+#define TDE_F_REPLAY     (1u << 1)  /* replay override (gym_env.py:275-283) */
+#define TDE_F_OFFROAD    (1u << 2)  /* drivable-mesh offroad test (gym_env.py:142,415,427) */
+#define TDE_F_REWARD     (1u << 3)  /* WaypointSuite reward/advance/terminate/truncate (gym_env.py:369-437) */
+#define TDE_F_AUTORESET  (1u << 4)  /* envs that finished this step are re-spawned in place (VecEnv semantics) */
+#define TDE_F_EGO_ONLY_ATTRS (1u << 5) /* cfg.ego_only: random ego attrs at reset (gym_env.py:192-198) */
+#define TDE_F_ALL (TDE_F_NPC | TDE_F_REPLAY | TDE_F_OFFROAD | TDE_F_REWARD | TDE_F_AUTORESET)
+
+/* cell classes of the offroad grid index (HIP side only; the oracle is brute force over triangles) */
+#define TDE_CELL_EMPTY 0u  /* every point of the cell is farther than threshold from every triangle  */
+#define TDE_CELL_MIXED 1u  /* test the cell's candidate triangles                                    */
+#define TDE_CELL_FULL  2u  /* every point of the cell is within threshold of some triangle            */
+
+typedef struct tde_config {
+    /* reward constants are Python floats (float64) in the reference: EnvConfig, gym_env.py:34-54 */
+    double waypoint_bonus;      /* 100.  gym_env.py:39 */
+    double heading_penalty;     /* 25.   gym_env.py:40 */
+    double distance_bonus;      /* 1.    gym_env.py:41 */
+    double distance_cutoff;     /* 0.5   gym_env.py:42 (shipped training configs use 0.25) */
+    double reach_radius;        /* 3.    literal at gym_env.py:394 */
+    uint64_t seed;              /* EnvConfig.seed, gym_env.py:45; keys the counter-based reset RNG */
+    float dt;                   /* 0.1   KinematicBicycle default; render_fps 10, gym_env.py:75 */
+    float offroad_threshold;    /* 0.5   TorchDriveConfig default (not overridden at gym_env.py:46-49) */
+    /* heuristic NPC controller (replaces the IAI call at gym_env.py:285-294) */
+    float npc_k_steer;          /* steering gain on sin(heading error) */
+    float npc_k_speed;          /* accel gain on (v_des - v) */
+    float npc_gap_s0;           /* standstill gap [m] */
+    float npc_cone_k;           /* yield cone: corridor half width grows by this per metre ahead */
+    float npc_lane_half;        /* half width of the look-ahead corridor [m] */
+    float npc_reach;            /* NPC route waypoint switch radius [m] */
+    float npc_max_accel;        /* NPC accel/brake limit [m/s^2] (NPCs are not bound by the ego's action range) */
+    float npc_max_steer;        /* 0.3  action range gym_env.py:84 */
+    int32_t max_steps;          /* 200   gym_env.py:37 */
+    int32_t terminated_at_infraction; /* 1  gym_env.py:44 */
+    uint32_t flags;             /* TDE_F_* */
+    float npc_cone_range;       /* yield cone length [m] */
+} tde_config;
+
+/* One drivable-surface map: triangle soup + uniform grid index. */
+typedef struct tde_map {
+    float ox, oy;               /* grid origin (lower-left corner of cell (0,0)) */
+    float cell;                 /* cell edge [m] */
+    float inv_cell;             /* 1/cell */
+    int32_t nx, ny;             /* grid size */
+    int32_t cell_base;          /* first cell of this map in cell_class / cell_start */
+    int32_t tri_base;           /* first triangle of this map in tri */
+    int32_t n_tri;
+    int32_t _pad0;
+} tde_map;
+
+/* Static world tables, replicated per GPU.  All pointers live in the address space of the
+ * library they are handed to (device for libtde_hip, host for libtde_oracle). */
+typedef struct tde_world {
+    const tde_map *maps;        /* [n_maps] */
+    const float *tri;           /* [n_tri_total][6]  ax,ay,bx,by,cx,cy */
+    const int32_t *cell_start;  /* [n_cells_total + 1] CSR offsets into cell_tris (global) */
+    const int32_t *cell_tris;   /* candidate triangle ids (global triangle index) */
+    const uint8_t *cell_class;  /* [n_cells_total] TDE_CELL_* */
+    /* scenarios = WaypointSuite entries */
+    const int32_t *scn_map;     /* [S] map id                                                        */
+    const double *wp_xy;        /* [S][NW][2] ego waypoints, float64 like the YAML lists (gym_env.py:314,394) */
+    const int32_t *wp_n;        /* [S] number of waypoints                                           */
+    const float *start_heading; /* [S] stand-in for find_lanelet_directions at the start point (gym_env.py:359) */
+    const float *spawn_state;   /* [S][A][4] initial (x,y,psi,v); slot 0 is overwritten by the sampled ego start */
+    const float *spawn_attr;    /* [S][A][3] (length,width,rear_axis_offset) */
+    const float *spawn_vdes;    /* [S][A] NPC desired speed */
+    const int32_t *spawn_route; /* [S][A] NPC route id or -1 */
+    const int32_t *spawn_route_wp; /* [S][A] first route waypoint index the NPC heads for */
+    const int32_t *spawn_replay;/* [S][A] replay row id or -1 (car_sequence_suite, gym_env.py:275-283) */
+    const uint8_t *spawn_present;/* [S][A] */
+    const float *route_xy;      /* [R][RW][2] NPC route polylines */
+    const int32_t *route_n;     /* [R] */
+    const float *replay_states; /* [P][RT][4] */
+    const int32_t *replay_len;  /* [P] T of each replay row */
+    int32_t n_maps, n_scn, NW, A;
+    int32_t n_routes, RW, n_replay, RT;
+} tde_world;
+
+/* Mutable per-env / per-agent state and per-step outputs.  Caller-allocated, written in place. */
+typedef struct tde_state {
+    /* agent arrays [B*A] */
+    float *x, *y, *psi, *v;     /* kinematic state (R4) */
+    float *len, *wid, *lr;      /* attrs */
+    float *vdes;                /* NPC desired speed */
+    int32_t *route;             /* NPC route id or -1 */
+    int32_t *route_wp;          /* NPC current route waypoint index */
+    int32_t *replay;            /* replay row id or -1 */
+    uint8_t *present;           /* present mask (gym_env.py:262-263: all ones in the reference) */
+    uint8_t *collided;          /* out: compute_collision() > 0 per agent (R9) */
+    uint8_t *offroad;           /* out: compute_offroad() > 0 per agent (R10) */
+    /* env arrays [B] */
+    int32_t *scn;               /* current scenario (current_waypoint_suite_idx, gym_env.py:320) */
+    int32_t *steps;             /* environment_steps (gym_env.py:116) */
+    int32_t *target_idx;        /* current_target_idx (gym_env.py:325,379) */
+    int32_t *reached;           /* reached_waypoint_num (gym_env.py:338,406) */
+    int32_t *episode;           /* number of resets so far (RNG counter) */
+    const float *action;        /* in: [B][2] ego (accel, steer), raw units (gym_env.py:83-94) */
+    float *reward;              /* out [B] (R6) */
+    uint8_t *terminated;        /* out [B] (R8) */
+    uint8_t *truncated;         /* out [B] (R11) */
+    double *info;               /* out [B][4] psi_smoothness, speed_smoothness, psi_reward, dist_reward (R12; Python floats
+                                   in the reference, hence float64); may be NULL */
+    int32_t *info_reached;      /* out [B] reached_waypoint_num as reported by get_info (gym_env.py:425,431); may be NULL */
+    int32_t B, A;
+} tde_state;
+
+/* K-step open-loop rollout buffers (actions resident in HBM; per-step env outputs). */
+typedef struct tde_rollout {
+    const float *actions;       /* [K][B][2] */
+    float *reward;              /* [K][B] */
+    uint8_t *done;              /* [K][B] bit0 terminated, bit1 truncated, bit2 ego offroad, bit3 ego collided */
+    int32_t K;
+    int32_t _pad0;
+} tde_rollout;
+
+/* ego-centred birdview raster (R13; BASELINE config 5) */
+typedef struct tde_render {
+    uint8_t *out;               /* [B][3][H][W] uint8, channels first (obs space gym_env.py:95) */
+    int32_t H, W;               /* 64, 64 */
+    float fov;                  /* metres covered by the view edge */
+    int32_t _pad0;
+} tde_render;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDE_ABI_H */

@@ -1,0 +1,171 @@
+"""ctypes mirror of include/tde_abi.h (field for field) plus helpers to fill the structs from numpy arrays
+(host pointers, for the CPU oracle used by the tests) or torch tensors (device pointers, for libtde_hip.so).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; nothing in the C-ABI mentions torch.
+"""
+import ctypes as C
+
+import numpy as np
+
+TDE_ABI_VERSION = 1
+TDE_MAX_AGENTS = 64
+
+F_NPC = 1 << 0
+F_REPLAY = 1 << 1
+F_OFFROAD = 1 << 2
+F_REWARD = 1 << 3
+F_AUTORESET = 1 << 4
+F_EGO_ONLY_ATTRS = 1 << 5
+F_ALL = F_NPC | F_REPLAY | F_OFFROAD | F_REWARD | F_AUTORESET
+
+CELL_EMPTY, CELL_MIXED, CELL_FULL = 0, 1, 2
+
+_p = C.c_void_p
+
+
+class TdeConfig(C.Structure):
+    _fields_ = [
+        ("waypoint_bonus", C.c_double),
+        ("heading_penalty", C.c_double),
+        ("distance_bonus", C.c_double),
+        ("distance_cutoff", C.c_double),
+        ("reach_radius", C.c_double),
+        ("seed", C.c_uint64),
+        ("dt", C.c_float),
+        ("offroad_threshold", C.c_float),
+        ("npc_k_steer", C.c_float),
+        ("npc_k_speed", C.c_float),
+        ("npc_gap_s0", C.c_float),
+        ("npc_cone_k", C.c_float),
+        ("npc_lane_half", C.c_float),
+        ("npc_reach", C.c_float),
+        ("npc_max_accel", C.c_float),
+        ("npc_max_steer", C.c_float),
+        ("max_steps", C.c_int32),
+        ("terminated_at_infraction", C.c_int32),
+        ("flags", C.c_uint32),
+        ("npc_cone_range", C.c_float),
+    ]
+
+
+class TdeMap(C.Structure):
+    _fields_ = [
+        ("ox", C.c_float), ("oy", C.c_float), ("cell", C.c_float), ("inv_cell", C.c_float),
+        ("nx", C.c_int32), ("ny", C.c_int32), ("cell_base", C.c_int32), ("tri_base", C.c_int32),
+        ("n_tri", C.c_int32), ("_pad0", C.c_int32),
+    ]
+
+
+MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "f4"), ("nx", "i4"), ("ny", "i4"),
+                      ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("_pad0", "i4")])
+assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 40
+
+WORLD_PTRS = ["maps", "tri", "cell_start", "cell_tris", "cell_class", "scn_map", "wp_xy", "wp_n", "start_heading",
+              "spawn_state", "spawn_attr", "spawn_vdes", "spawn_route", "spawn_route_wp", "spawn_replay",
+              "spawn_present", "route_xy", "route_n", "replay_states", "replay_len"]
+WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT"]
+
+
+class TdeWorld(C.Structure):
+    _fields_ = [(n, _p) for n in WORLD_PTRS] + [(n, C.c_int32) for n in WORLD_INTS]
+
+
+STATE_AGENT_F32 = ["x", "y", "psi", "v", "len", "wid", "lr", "vdes"]
+STATE_AGENT_I32 = ["route", "route_wp", "replay"]
+STATE_AGENT_U8 = ["present", "collided", "offroad"]
+STATE_ENV_I32 = ["scn", "steps", "target_idx", "reached", "episode"]
+STATE_PTRS = (STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8 + STATE_ENV_I32 +
+              ["action", "reward", "terminated", "truncated", "info", "info_reached"])
+
+
+class TdeState(C.Structure):
+    _fields_ = [(n, _p) for n in STATE_PTRS] + [("B", C.c_int32), ("A", C.c_int32)]
+
+
+class TdeRollout(C.Structure):
+    _fields_ = [("actions", _p), ("reward", _p), ("done", _p), ("K", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class TdeRender(C.Structure):
+    _fields_ = [("out", _p), ("H", C.c_int32), ("W", C.c_int32), ("fov", C.c_float), ("_pad0", C.c_int32)]
+
+
+def ptr_of(a):
+    """Raw address of a contiguous numpy array or torch tensor (None -> NULL)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"], "arrays handed to the C-ABI must be contiguous"
+        return a.ctypes.data
+    # torch tensor
+    assert a.is_contiguous(), "tensors handed to the C-ABI must be contiguous"
+    return a.data_ptr()
+
+
+def default_config(**over):
+    """tde_config with the reference's defaults (EnvConfig, gym_env.py:34-54) and the NPC controller's."""
+    cfg = TdeConfig()
+    cfg.waypoint_bonus = 100.0
+    cfg.heading_penalty = 25.0
+    cfg.distance_bonus = 1.0
+    cfg.distance_cutoff = 0.5
+    cfg.reach_radius = 3.0
+    cfg.seed = 0
+    cfg.dt = 0.1
+    cfg.offroad_threshold = 0.5
+    cfg.npc_k_steer = 1.2
+    cfg.npc_k_speed = 3.0
+    cfg.npc_gap_s0 = 3.0
+    cfg.npc_cone_k = 0.5
+    cfg.npc_cone_range = 25.0
+    cfg.npc_lane_half = 1.75
+    cfg.npc_reach = 3.0
+    cfg.npc_max_accel = 3.0
+    cfg.npc_max_steer = 0.3
+    cfg.max_steps = 200
+    cfg.terminated_at_infraction = 1
+    cfg.flags = F_ALL
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(f"tde_config has no field {k!r}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+WORLD_DTYPES = {
+    "maps": MAP_DTYPE, "tri": np.float32, "cell_start": np.int32, "cell_tris": np.int32, "cell_class": np.uint8,
+    "scn_map": np.int32, "wp_xy": np.float64, "wp_n": np.int32, "start_heading": np.float32,
+    "spawn_state": np.float32, "spawn_attr": np.float32, "spawn_vdes": np.float32, "spawn_route": np.int32,
+    "spawn_route_wp": np.int32, "spawn_replay": np.int32, "spawn_present": np.uint8, "route_xy": np.float32,
+    "route_n": np.int32, "replay_states": np.float32, "replay_len": np.int32,
+}
+
+STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n in STATE_AGENT_I32},
+                **{n: np.uint8 for n in STATE_AGENT_U8}, **{n: np.int32 for n in STATE_ENV_I32},
+                "action": np.float32, "reward": np.float32, "terminated": np.uint8, "truncated": np.uint8,
+                "info": np.float64, "info_reached": np.int32}
+
+
+def state_shapes(B, A):
+    sh = {n: (B * A,) for n in STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8}
+    sh.update({n: (B,) for n in STATE_ENV_I32})
+    sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "info": (B, 4),
+               "info_reached": (B,)})
+    return sh
+
+
+def fill_world_struct(arrays, ints):
+    w = TdeWorld()
+    for n in WORLD_PTRS:
+        setattr(w, n, ptr_of(arrays[n]))
+    for n in WORLD_INTS:
+        setattr(w, n, int(ints[n]))
+    return w
+
+
+def fill_state_struct(arrays, B, A):
+    s = TdeState()
+    for n in STATE_PTRS:
+        setattr(s, n, ptr_of(arrays.get(n)))
+    s.B, s.A = int(B), int(A)
+    return s

@@ -1,0 +1,325 @@
+"""Static world tables of the batched env: drivable meshes + their grid index, scenarios (WaypointSuite entries),
+NPC routes and replay rows.  Host side (numpy); `World.to_device()` uploads them once per GPU (they are
+replicated per GPU) and returns the `tde_world` struct of device pointers the C-ABI takes.
+
+Reference anchors:
+  * drivable mesh = `map_cfg.road_mesh` handed to `Simulator(road_mesh=...)`      ref gym_env.py:184,260
+  * waypoints / car sequences / scenarios = `WaypointSuite`                         ref gym_env.py:63-68,314-316
+  * replay rows = `car_sequences` -> replay_states/replay_mask                      ref gym_env.py:275-283
+  * agent ordering: slot 0 ego, then scenario agents                                ref gym_env.py:219-228
+The real CARLA meshes/lanelets live inside torchdrivesim's package data, which is not part of the reference
+repository, so meshes here are synthetic ("Out of scope").
+"""
+import math
+
+import numpy as np
+
+from . import _abi
+
+# margin that makes the grid classification robust to fp32 evaluation and to the fp32 cell lookup
+GRID_MARGIN = 0.05
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry helpers (float64, host, build time only)
+# ------------------------------------------------------------------------------------------------
+def _seg_d2(p, a, b):
+    """squared distance of points p[...,2] to segment a-b"""
+    ab = b - a
+    ap = p - a
+    l2 = float(ab @ ab)
+    t = np.clip((ap @ ab) / l2, 0.0, 1.0) if l2 > 0 else np.zeros(p.shape[:-1])
+    q = ap - t[..., None] * ab
+    return (q * q).sum(-1)
+
+
+def point_tri_dist(p, tri):
+    """distance of points p[...,2] to triangle tri[3,2] (0 inside)"""
+    a, b, c = tri
+
+    def cross(u, v):
+        return u[..., 0] * v[..., 1] - u[..., 1] * v[..., 0]
+
+    e0 = cross(b - a, p - a)
+    e1 = cross(c - b, p - b)
+    e2 = cross(a - c, p - c)
+    inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+    d2 = np.minimum(np.minimum(_seg_d2(p, a, b), _seg_d2(p, b, c)), _seg_d2(p, c, a))
+    return np.where(inside, 0.0, np.sqrt(d2))
+
+
+def _seg_seg_dist(p1, q1, p2, q2):
+    """min distance between segments p1q1 and p2q2 (2-D), scalar float64"""
+
+    def orient(a, b, c):
+        return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+
+    o1, o2 = orient(p1, q1, p2), orient(p1, q1, q2)
+    o3, o4 = orient(p2, q2, p1), orient(p2, q2, q1)
+    if (o1 * o2 < 0) and (o3 * o4 < 0):
+        return 0.0
+    d = min(_seg_d2(p1[None], p2, q2)[0], _seg_d2(q1[None], p2, q2)[0], _seg_d2(p2[None], p1, q1)[0],
+            _seg_d2(q2[None], p1, q1)[0])
+    return math.sqrt(d)
+
+
+def rect_tri_dist(x0, y0, x1, y1, tri):
+    """distance between the axis-aligned rectangle [x0,x1]x[y0,y1] and a triangle (0 if they touch)"""
+    rc = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], dtype=np.float64)
+    # a rect corner inside the triangle or a triangle vertex inside the rect -> 0
+    if (point_tri_dist(rc, tri) == 0.0).any():
+        return 0.0
+    if ((tri[:, 0] >= x0) & (tri[:, 0] <= x1) & (tri[:, 1] >= y0) & (tri[:, 1] <= y1)).any():
+        return 0.0
+    best = math.inf
+    for i in range(4):
+        for j in range(3):
+            best = min(best, _seg_seg_dist(rc[i], rc[(i + 1) % 4], tri[j], tri[(j + 1) % 3]))
+            if best == 0.0:
+                return 0.0
+    return best
+
+
+def build_grid_index(tri, threshold=0.5, cell=2.0, margin=GRID_MARGIN, full_depth=3):
+    """Uniform-grid index over a triangle soup `tri` [n,3,2] for the offroad test.
+
+    For every cell: the list of triangles that can be within `threshold` of some point of the cell
+    (conservative by `margin`), and a class:
+      EMPTY  no such triangle  -> every corner falling in the cell is offroad,
+      FULL   every point of the cell is within threshold-margin of one triangle -> never offroad,
+      MIXED  test the candidates.
+    The HIP kernel's mask equals the brute-force mask of the oracle because both classifications are
+    conservative by `margin` >> fp32 evaluation error at |coords| <~ 1e3 m.
+    """
+    tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
+    R = threshold + margin
+    lo = tri.reshape(-1, 2).min(0) - (R + cell)
+    hi = tri.reshape(-1, 2).max(0) + (R + cell)
+    # the origin must be exactly representable in fp32 (the kernel subtracts it in fp32)
+    ox, oy = float(np.float32(math.floor(lo[0]))), float(np.float32(math.floor(lo[1])))
+    nx = int(math.ceil((hi[0] - ox) / cell))
+    ny = int(math.ceil((hi[1] - oy) / cell))
+    cand = [[] for _ in range(nx * ny)]
+    for k, t in enumerate(tri):
+        bx0, by0 = t.min(0) - R
+        bx1, by1 = t.max(0) + R
+        ix0 = max(0, int(math.floor((bx0 - ox) / cell)))
+        ix1 = min(nx - 1, int(math.floor((bx1 - ox) / cell)))
+        iy0 = max(0, int(math.floor((by0 - oy) / cell)))
+        iy1 = min(ny - 1, int(math.floor((by1 - oy) / cell)))
+        for iy in range(iy0, iy1 + 1):
+            for ix in range(ix0, ix1 + 1):
+                x0, y0 = ox + ix * cell, oy + iy * cell
+                if rect_tri_dist(x0, y0, x0 + cell, y0 + cell, t) <= R:
+                    cand[iy * nx + ix].append(k)
+
+    thr_in = threshold - margin
+
+    def covered(x0, y0, x1, y1, ks, depth):
+        rc = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], dtype=np.float64)
+        for k in ks:
+            if (point_tri_dist(rc, tri[k]) <= thr_in).all():
+                return True
+        if depth == 0:
+            return False
+        xm, ym = 0.5 * (x0 + x1), 0.5 * (y0 + y1)
+        return (covered(x0, y0, xm, ym, ks, depth - 1) and covered(xm, y0, x1, ym, ks, depth - 1) and
+                covered(x0, ym, xm, y1, ks, depth - 1) and covered(xm, ym, x1, y1, ks, depth - 1))
+
+    cls = np.zeros(nx * ny, dtype=np.uint8)
+    start = np.zeros(nx * ny + 1, dtype=np.int32)
+    flat = []
+    for c in range(nx * ny):
+        ks = cand[c]
+        if ks:
+            ix, iy = c % nx, c // nx
+            x0, y0 = ox + ix * cell, oy + iy * cell
+            # the fp32 cell lookup may be off by one ulp at a cell border: grow the rect by the margin
+            if covered(x0 - margin, y0 - margin, x0 + cell + margin, y0 + cell + margin, ks, full_depth):
+                cls[c] = _abi.CELL_FULL
+            else:
+                cls[c] = _abi.CELL_MIXED
+                flat.extend(ks)
+        start[c + 1] = len(flat)
+    return dict(ox=ox, oy=oy, cell=float(cell), nx=nx, ny=ny, cell_class=cls, cell_start=start,
+                cell_tris=np.asarray(flat, dtype=np.int32))
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic drivable meshes
+# ------------------------------------------------------------------------------------------------
+def strip_mesh(polyline, width, seg_len=5.0):
+    """Triangulated road strip of `width` metres around a polyline (list of (x,y)); quads of ~seg_len."""
+    pts = np.asarray(polyline, dtype=np.float64)
+    tris = []
+    for a, b in zip(pts[:-1], pts[1:]):
+        d = b - a
+        L = float(np.hypot(*d))
+        if L == 0:
+            continue
+        t = d / L
+        n = np.array([-t[1], t[0]]) * (0.5 * width)
+        k = max(1, int(round(L / seg_len)))
+        for i in range(k):
+            p = a + d * (i / k)
+            q = a + d * ((i + 1) / k)
+            tris.append([p - n, q - n, q + n])
+            tris.append([p - n, q + n, p + n])
+    return np.asarray(tris, dtype=np.float64)
+
+
+def disc_mesh(center, radius, n=12):
+    c = np.asarray(center, dtype=np.float64)
+    ang = np.linspace(0, 2 * math.pi, n + 1)
+    ring = c + radius * np.stack([np.cos(ang), np.sin(ang)], -1)
+    return np.asarray([[c, ring[i], ring[i + 1]] for i in range(n)], dtype=np.float64)
+
+
+def corridor_mesh(polylines, width=12.0, seg_len=6.0, joint_radius=None):
+    """Drivable corridor around a set of polylines (used to give the shipped WaypointSuite scenarios a mesh:
+    their CARLA town meshes are not in the reference repository)."""
+    parts = []
+    for pl in polylines:
+        pl = np.asarray(pl, dtype=np.float64)
+        if len(pl) >= 2:
+            parts.append(strip_mesh(pl, width, seg_len))
+        r = joint_radius if joint_radius is not None else 0.5 * width
+        for p in pl:
+            parts.append(disc_mesh(p, r, 8))
+    return np.concatenate(parts, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# World container
+# ------------------------------------------------------------------------------------------------
+class World:
+    """Host copy of every static table the step path reads (numpy, dtypes of _abi.WORLD_DTYPES)."""
+
+    def __init__(self, arrays, ints):
+        self.arrays = {k: np.ascontiguousarray(arrays[k], dtype=_abi.WORLD_DTYPES[k]) for k in _abi.WORLD_PTRS}
+        self.ints = {k: int(ints[k]) for k in _abi.WORLD_INTS}
+        # zero-length tables still need a valid pointer
+        for k, a in self.arrays.items():
+            if a.size == 0:
+                self.arrays[k] = np.zeros(max(1, 1), dtype=a.dtype)
+        self._host_struct = None
+
+    @property
+    def A(self):
+        return self.ints["A"]
+
+    @property
+    def n_scn(self):
+        return self.ints["n_scn"]
+
+    def host_struct(self):
+        """tde_world of HOST pointers (what the CPU oracle takes in the tests)."""
+        if self._host_struct is None:
+            self._host_struct = _abi.fill_world_struct(self.arrays, self.ints)
+        return self._host_struct
+
+    def to_device(self, device):
+        import torch
+
+        tens = {}
+        for k, a in self.arrays.items():
+            if a.dtype == _abi.MAP_DTYPE:
+                t = torch.from_numpy(a.view(np.uint8).copy())
+            else:
+                t = torch.from_numpy(a.copy())
+            tens[k] = t.to(device)
+        return DeviceWorld(tens, self.ints)
+
+    def map_of_scn(self):
+        return self.arrays["scn_map"]
+
+
+class DeviceWorld:
+    def __init__(self, tensors, ints):
+        self.tensors = tensors  # keeps the device memory alive
+        self.ints = dict(ints)
+        self.struct = _abi.fill_world_struct(tensors, ints)
+
+
+def assemble_world(meshes, scenarios, A, threshold=0.5, cell=2.0):
+    """meshes: list of [n,3,2] triangle arrays; scenarios: list of dicts with keys
+         map (int), waypoints [(x,y)...], start_heading (float),
+         agents: list (slots 1..) of dict(state=(x,y,psi,v), attr=(L,W,lr), vdes, route=[(x,y)..] or None,
+                                         replay=[(x,y,psi,v)...] or None)
+         ego_attr (L,W,lr)
+    """
+    assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
+    maps = np.zeros(len(meshes), dtype=_abi.MAP_DTYPE)
+    tri_all, cs_all, ct_all, cc_all = [], [np.zeros(1, np.int32)], [], []
+    tri_base = cell_base = ct_base = 0
+    for m, tri in enumerate(meshes):
+        tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
+        # the kernels see fp32 vertices: index the fp32-rounded mesh
+        tri32 = tri.astype(np.float32)
+        g = build_grid_index(tri32.astype(np.float64), threshold, cell)
+        maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
+                   tri_base, len(tri), 0)
+        tri_all.append(tri32.reshape(-1, 6))
+        cs_all.append(g["cell_start"][1:] + ct_base)
+        ct_all.append(g["cell_tris"] + tri_base)
+        cc_all.append(g["cell_class"])
+        tri_base += len(tri)
+        cell_base += g["nx"] * g["ny"]
+        ct_base += len(g["cell_tris"])
+    S = len(scenarios)
+    NW = max(2, max(len(s["waypoints"]) for s in scenarios))
+    wp_xy = np.zeros((S, NW, 2), np.float64)
+    wp_n = np.zeros(S, np.int32)
+    spawn_state = np.zeros((S, A, 4), np.float32)
+    spawn_attr = np.ones((S, A, 3), np.float32)
+    spawn_vdes = np.zeros((S, A), np.float32)
+    spawn_route = -np.ones((S, A), np.int32)
+    spawn_route_wp = np.zeros((S, A), np.int32)
+    spawn_replay = -np.ones((S, A), np.int32)
+    spawn_present = np.zeros((S, A), np.uint8)
+    routes, replays = [], []
+    for si, s in enumerate(scenarios):
+        w = np.asarray(s["waypoints"], np.float64)
+        assert len(w) >= 2, "a scenario needs at least two waypoints (gym_env.py:353-354)"
+        wp_xy[si, :len(w)] = w
+        wp_n[si] = len(w)
+        spawn_present[si, 0] = 1
+        spawn_attr[si, 0] = s.get("ego_attr", (5.0, 2.0, 1.9))
+        spawn_state[si, 0] = (w[0, 0], w[0, 1], s["start_heading"], 0.0)
+        ags = s.get("agents", [])
+        assert len(ags) <= A - 1, f"scenario {si} has {len(ags)} NPCs but only {A - 1} NPC slots"
+        for k, ag in enumerate(ags):
+            a = k + 1
+            spawn_present[si, a] = 1
+            spawn_state[si, a] = ag["state"]
+            spawn_attr[si, a] = ag["attr"]
+            spawn_vdes[si, a] = ag.get("vdes", ag["state"][3])
+            if ag.get("route") is not None and len(ag["route"]) > 0:
+                spawn_route[si, a] = len(routes)
+                routes.append(np.asarray(ag["route"], np.float32))
+                spawn_route_wp[si, a] = ag.get("route_wp", 0)
+            if ag.get("replay") is not None and len(ag["replay"]) > 0:
+                spawn_replay[si, a] = len(replays)
+                replays.append(np.asarray(ag["replay"], np.float32))
+    RW = max([len(r) for r in routes], default=1)
+    route_xy = np.zeros((max(1, len(routes)), RW, 2), np.float32)
+    route_n = np.zeros(max(1, len(routes)), np.int32)
+    for i, r in enumerate(routes):
+        route_xy[i, :len(r)] = r
+        route_n[i] = len(r)
+    RT = max([len(r) for r in replays], default=1)
+    replay_states = np.zeros((max(1, len(replays)), RT, 4), np.float32)
+    replay_len = np.zeros(max(1, len(replays)), np.int32)
+    for i, r in enumerate(replays):
+        replay_states[i, :len(r)] = r
+        replay_len[i] = len(r)
+    arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_start=np.concatenate(cs_all),
+                  cell_tris=np.concatenate(ct_all) if ct_all else np.zeros(0, np.int32),
+                  cell_class=np.concatenate(cc_all), scn_map=np.asarray([s["map"] for s in scenarios], np.int32),
+                  wp_xy=wp_xy, wp_n=wp_n,
+                  start_heading=np.asarray([s["start_heading"] for s in scenarios], np.float32),
+                  spawn_state=spawn_state, spawn_attr=spawn_attr, spawn_vdes=spawn_vdes, spawn_route=spawn_route,
+                  spawn_route_wp=spawn_route_wp, spawn_replay=spawn_replay, spawn_present=spawn_present,
+                  route_xy=route_xy, route_n=route_n, replay_states=replay_states, replay_len=replay_len)
+    ints = dict(n_maps=len(meshes), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT)
+    return World(arrays, ints)
