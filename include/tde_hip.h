@@ -1,0 +1,95 @@
+/*
+ * tde_hip.h — C-ABI of libtde_hip.so: the MI355X (gfx950) implementation of the per-timestep env step path of
+ * inverted-ai/torchdriveenv.  Plain pointers (DEVICE memory unless stated), sizes, and a HIP stream passed as
+ * void* (hipStream_t; NULL = the default stream).  No torch types.  All entry points are asynchronous on the given
+ * stream, allocate nothing, and return 0 on success or a hipError_t value (message: tde_last_error()).
+ *
+ * Each entry point names the reference interface it replaces (file:line into /root/reference/torchdriveenv/).
+ * The reference has no FFI of its own (it is pure Python over torchdrivesim); INTEGRATION.md shows the ctypes stub a
+ * maintainer would add and how GymEnv/WaypointSuiteEnv would call it.
+ *
+ * Struct arguments (tde_config, tde_world, tde_state, tde_rollout: include/tde_abi.h) are HOST structs whose pointer
+ * members are device pointers; they are copied by value into the kernel arguments at launch.
+ */
+#ifndef TDE_HIP_H
+#define TDE_HIP_H
+
+#include "tde_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDE_API __attribute__((visibility("default")))
+
+/* TDE_ABI_VERSION the library was built with. */
+TDE_API int tde_abi_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+TDE_API const char *tde_last_error(void);
+
+/* ---- operator level: the SimulatorInterface methods GymEnv calls ------------------------------------ */
+
+/* simulator.step(action) restricted to the kinematic model — KinematicBicycle.step for n agents.
+ * Replaces: gym_env.py:117 (simulator.step), model built at gym_env.py:245-247 (lr = rear_axis_offset).
+ * x,y,psi,v: in/out [n]; lr [n]; present [n] or NULL; action [n][2] = (acceleration, steering). */
+TDE_API int tde_kinematics_step(int64_t n, float *x, float *y, float *psi, float *v, const float *lr,
+                                const uint8_t *present, const float *action, float dt, void *stream);
+
+/* simulator.compute_collision() > 0 per agent: strict OBB overlap with any other present agent of the same env.
+ * Replaces: gym_env.py:143, 415, 428 (CollisionMetric.nograd, gym_env.py:48).  All arrays [B*A]; out u8 [B*A]. */
+TDE_API int tde_compute_collision(int32_t B, int32_t A, const float *x, const float *y, const float *psi,
+                                  const float *len, const float *wid, const uint8_t *present, uint8_t *out,
+                                  void *stream);
+
+/* simulator.compute_offroad() > 0 per agent: a box corner farther than `threshold` from the drivable mesh of the
+ * env's map.  Replaces: gym_env.py:142, 415, 427 (mesh: gym_env.py:184,260).  map_of_env [B]; out u8 [B*A]. */
+TDE_API int tde_compute_offroad(int32_t B, int32_t A, const float *x, const float *y, const float *psi,
+                                const float *len, const float *wid, const uint8_t *present, const tde_world *world,
+                                const int32_t *map_of_env, float threshold, uint8_t *out, void *stream);
+
+/* Fused kinematics + all-pairs collision for every agent (BASELINE.json configs[1]: "bicycle kinematics + OBB
+ * collision only").  action [B*A][2].  Replaces: gym_env.py:117 followed by :143. */
+TDE_API int tde_kin_collide_step(int32_t B, int32_t A, float *x, float *y, float *psi, float *v, const float *lr,
+                                 const float *len, const float *wid, const uint8_t *present, const float *action,
+                                 float dt, uint8_t *collided, void *stream);
+
+/* The part of the step the reference owns, batched over n envs: environment_steps += 1 (gym_env.py:116),
+ * WaypointSuiteEnv.get_reward (:396-411), check_reach_target (:391-394), is_terminated (:413-417), is_truncated
+ * (:134-135), get_info terms (:419-437), waypoint advance (:378-383).
+ * pre_* = ego state before simulator.step (last_x.. :371-375), x.. = after; flags u8 [n]; tl_violation may be NULL.
+ * wp_xy f64 [S][NW][2], wp_n [S], scn [n]; steps/target_idx/reached in/out [n];
+ * info f64 [n][4] = psi_smoothness, speed_smoothness, psi_reward, dist_reward (or NULL); info_reached [n] or NULL. */
+TDE_API int tde_waypoint_reward(const tde_config *cfg, int32_t n, const float *pre_x, const float *pre_y,
+                                const float *pre_psi, const float *pre_v, const float *x, const float *y,
+                                const float *psi, const float *v, const uint8_t *offroad, const uint8_t *collided,
+                                const uint8_t *tl_violation, const double *wp_xy, const int32_t *wp_n, int32_t NW,
+                                const int32_t *scn, int32_t *steps, int32_t *target_idx, int32_t *reached,
+                                float *reward, uint8_t *terminated, uint8_t *truncated, double *info,
+                                int32_t *info_reached, void *stream);
+
+/* ---- env level: the fused hot path ---------------------------------------------------------------------------- */
+
+/* WaypointSuiteEnv.reset for the envs selected by mask (u8 [B], NULL = all): scenario draw, start pose/speed/heading
+ * noise, spawn of NPC slots, counters.  Replaces: gym_env.py:319-367 + the initial tensors of build_simulator
+ * (:192-198, :241-247).  Network parts (IAI initialize, :236-238) are out of scope. */
+TDE_API int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state *state, const uint8_t *mask,
+                          void *stream);
+
+/* One timestep of every env in ONE kernel: SingleAgentWrapper.step -> WaypointSuiteEnv.step -> GymEnv.step
+ * (gym_env.py:453-461, 369-389, 115-120): bicycle kinematics, heuristic NPC controller (in place of the IAI call,
+ * :285-294), replay override (:275-283), all-pairs OBB collision, drivable-mesh offroad, WaypointSuite reward,
+ * termination/truncation, info, waypoint advance, and (TDE_F_AUTORESET) in-place re-spawn of finished envs.
+ * Reads state->action [B][2]; writes state in place. */
+TDE_API int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state *state, void *stream);
+
+/* K consecutive timesteps with the ego actions taken from a resident [K][B][2] buffer (open-loop / action-repeat
+ * rollouts; how bench.py drives the path without a host round trip per step).  Per-step reward [K][B] and done bits
+ * [K][B] are written to `rollout`. */
+TDE_API int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_state *state,
+                            const tde_rollout *rollout, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDE_HIP_H */

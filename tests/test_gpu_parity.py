@@ -1,0 +1,294 @@
+"""GPU parity tests: the HIP path, called through the C-ABI of libtde_hip.so, against the CPU oracle on the same
+seeded inputs.  Bar (BASELINE.json north_star): collision/offroad masks bit-exact, fp32 kinematic state within 1e-5.
+Because oracle and kernels share one floating-point contract (no contraction, own sincos), we assert the stronger
+property: EVERY array is bit-identical, including state after hundreds of steps.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from tests.golden_util import case_config, case_expected, case_inputs  # noqa: E402
+from torchdriveenv_amd import _abi, ops  # noqa: E402
+from torchdriveenv_amd.state import EnvState  # noqa: E402
+
+DEV = "cuda:0"
+STATE_TOL = 1e-5  # the tolerance the north star states for fp32 kinematic state
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def random_agents(rng, B, A, spread=12.0):
+    """clusters of boxes so that a good fraction of pairs overlap / almost touch"""
+    n = B * A
+    cx = np.repeat(rng.uniform(-200, 200, B), A)
+    cy = np.repeat(rng.uniform(-200, 200, B), A)
+    x = (cx + rng.uniform(-spread, spread, n)).astype(np.float32)
+    y = (cy + rng.uniform(-spread, spread, n)).astype(np.float32)
+    psi = rng.uniform(-np.pi, np.pi, n).astype(np.float32)
+    v = rng.uniform(0, 20, n).astype(np.float32)
+    length = np.clip(rng.normal(4.8, 0.31, n), 3.83, 6.89).astype(np.float32)
+    width = np.clip(rng.normal(2.07, 0.11, n), 1.67, 3.03).astype(np.float32)
+    lr = np.clip(rng.normal(1.83, 0.12, n), 1.46, 2.62).astype(np.float32)
+    present = (rng.uniform(size=n) < 0.9).astype(np.uint8)
+    return dict(x=x, y=y, psi=psi, v=v, length=length, width=width, lr=lr, present=present)
+
+
+def test_kinematics_bit_exact():
+    rng = np.random.default_rng(0)
+    n = 200_003  # ragged: not a multiple of the workgroup
+    ag = random_agents(rng, n, 1)
+    ag["psi"][:1000] = np.float32(np.pi) - np.float32(1e-4) * rng.uniform(size=1000).astype(np.float32)  # wrap zone
+    ag["v"][1000:2000] *= -1  # reversing is allowed in KinematicBicycle
+    action = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.3, 0.3, n)], -1).astype(np.float32)
+    d = {k: dev(val) for k, val in ag.items()}
+    h = {k: val.copy() for k, val in ag.items()}
+    for _ in range(5):
+        ops.kinematics_step(d["x"], d["y"], d["psi"], d["v"], d["lr"], dev(action), d["present"])
+        oracle.kinematics_step(h["x"], h["y"], h["psi"], h["v"], h["lr"], h["present"], action)
+    for k in ("x", "y", "psi", "v"):
+        g = d[k].cpu().numpy()
+        assert np.allclose(g, h[k], rtol=0, atol=STATE_TOL * max(1.0, np.abs(h[k]).max())), k
+        assert np.array_equal(g.view(np.uint32), h[k].view(np.uint32)), f"{k} not bit-exact"
+    assert np.all((h["psi"] >= -np.pi - 1e-6) & (h["psi"] < np.pi + 1e-6))
+
+
+@pytest.mark.parametrize("A", [1, 2, 4, 8, 16, 32, 64])
+def test_collision_mask_bit_exact(A):
+    rng = np.random.default_rng(A)
+    B = 1000 // A + 3
+    ag = random_agents(rng, B, A, spread=2.0 + A * 0.8)
+    want = oracle.compute_collision(B, A, ag["x"], ag["y"], ag["psi"], ag["length"], ag["width"], ag["present"])
+    got = ops.compute_collision(B, A, dev(ag["x"]), dev(ag["y"]), dev(ag["psi"]), dev(ag["length"]), dev(ag["width"]),
+                                dev(ag["present"])).cpu().numpy()
+    assert np.array_equal(got, want)
+    if A > 1:
+        assert 0 < want.sum() < want.size  # the case exercises both outcomes
+
+
+def test_collision_known_answers():
+    # identical boxes / edge-touching (no collision) / 45-degree corner poke / far apart   
+    def run(b0, b1):
+        x = np.array([b0[0], b1[0]], np.float32); y = np.array([b0[1], b1[1]], np.float32)
+        psi = np.array([b0[2], b1[2]], np.float32)
+        L = np.array([4.0, 4.0], np.float32); W = np.array([2.0, 2.0], np.float32)
+        p = np.ones(2, np.uint8)
+        got = ops.compute_collision(1, 2, dev(x), dev(y), dev(psi), dev(L), dev(W), dev(p)).cpu().numpy()
+        want = oracle.compute_collision(1, 2, x, y, psi, L, W, p)
+        assert np.array_equal(got, want)
+        return tuple(got)
+    assert run((0, 0, 0), (0, 0, 0)) == (1, 1)
+    assert run((0, 0, 0), (4, 0, 0)) == (0, 0)          # touching along the length: not a collision
+    assert run((0, 0, 0), (3.999, 0, 0)) == (1, 1)
+    assert run((0, 0, 0), (0, 2, 0)) == (0, 0)          # touching along the width
+    assert run((0, 0, 0), (4.0, 0, np.pi / 4)) == (1, 1)         # rotated corner pokes in (extent 2.12)
+    assert run((0, 0, 0), (4.2, 0, np.pi / 4)) == (0, 0)         # ... and just misses
+    assert run((0, 0, 0), (100, 100, 1.0)) == (0, 0)
+
+
+def test_offroad_mask_bit_exact(small_world):
+    w = small_world
+    dw = w.to_device(DEV)
+    rng = np.random.default_rng(5)
+    B, A = 600, 16
+    n = B * A
+    scn_map = w.arrays["scn_map"]
+    map_of_env = rng.integers(0, w.ints["n_maps"], B).astype(np.int32)
+    # poses along the roads with lateral offsets that straddle the road edge (3.5 m) +- threshold
+    s = rng.uniform(-130, 130, n)
+    lat = rng.choice([0.0, 1.75, 2.4, 2.9, 3.2, 3.6, 4.2, 6.0, 15.0], n) * rng.choice([-1, 1], n)
+    x = (s + rng.normal(0, 0.2, n)).astype(np.float32)
+    y = (lat + rng.normal(0, 0.15, n)).astype(np.float32)
+    swap = rng.uniform(size=n) < 0.3   # some along the side roads / anywhere
+    x[swap], y[swap] = rng.uniform(-40, 40, swap.sum()).astype(np.float32), rng.uniform(-130, 130, swap.sum()).astype(np.float32)
+    psi = rng.uniform(-np.pi, np.pi, n).astype(np.float32)
+    ag = random_agents(rng, B, A)
+    want = oracle.compute_offroad(B, A, x, y, psi, ag["length"], ag["width"], ag["present"], w, map_of_env)
+    got = ops.compute_offroad(B, A, dev(x), dev(y), dev(psi), dev(ag["length"]), dev(ag["width"]), dev(ag["present"]),
+                              dw, dev(map_of_env)).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert 0.1 < want.mean() < 0.9
+    assert scn_map.max() < w.ints["n_maps"]
+
+
+def test_reward_operator_matches_reference_golden(golden):
+    """HIP reward/termination operator against vectors captured from the reference's own gym_env.py"""
+    for case in golden["cases"]:
+        cfg = case_config(case)
+        i = case_inputs(case)
+        e = case_expected(case)
+        steps, target, reached = dev(i["steps"]), dev(i["target"]), dev(i["reached"])
+        pre = tuple(dev(i["pre"][:, k]) for k in range(4))
+        post = tuple(dev(i["post"][:, k]) for k in range(4))
+        out = ops.waypoint_reward(cfg, pre, post, dev(i["off"]), dev(i["col"]), dev(i["tl"]), dev(i["wp"]),
+                                  dev(i["wp_n"]), dev(i["scn"]), steps, target, reached)
+        name = case["name"]
+        assert np.array_equal(out["reward"].cpu().numpy().astype(np.float64), e["reward"]), name
+        assert np.array_equal(out["terminated"].cpu().numpy(), e["terminated"]), name
+        assert np.array_equal(out["truncated"].cpu().numpy(), e["truncated"]), name
+        assert np.array_equal(target.cpu().numpy(), e["target_after"]), name
+        assert np.array_equal(reached.cpu().numpy(), e["reached"]), name
+        info = out["info"].cpu().numpy()
+        assert np.array_equal(info[:, :2], e["info"][:, :2]), name          # fp32-derived smoothness terms
+        assert np.array_equal(info[:, 3], e["info"][:, 3]), name            # dist_reward
+        assert np.allclose(info[:, 2], e["info"][:, 2], rtol=1e-12, atol=1e-15), name  # psi_reward (float64 cos)
+
+
+def assert_state_equal(hs, ds, where):
+    for k, a in hs.items():
+        if k == "action":
+            continue
+        b = ds[k]
+        if a.dtype.kind == "f":
+            tol = STATE_TOL * max(1.0, float(np.abs(a).max()))
+            assert np.allclose(a, b, rtol=0, atol=tol, equal_nan=True), f"{k} differs beyond tolerance at {where}"
+            same = (a.view(np.uint32 if a.itemsize == 4 else np.uint64) ==
+                    b.view(np.uint32 if b.itemsize == 4 else np.uint64))
+            assert same.all(), f"{k}: {(~same).sum()} of {same.size} not bit-exact at {where}"
+        else:
+            assert np.array_equal(a, b), f"{k} differs at {where}"
+
+
+def _pair(world, B, A, cfg):
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    return hs, ds, dw
+
+
+def test_env_reset_bit_exact(small_world):
+    cfg = _abi.default_config(seed=11)
+    hs, ds, dw = _pair(small_world, 300, 16, cfg)
+    assert_state_equal(hs.host(), ds.host(), "reset")
+    # masked re-reset of a ragged subset advances only those envs' episode counters
+    mask = (np.arange(300) % 3 == 0).astype(np.uint8)
+    oracle.env_reset(cfg, small_world, hs, mask)
+    ops.env_reset(cfg, dw, ds, dev(mask))
+    assert_state_equal(hs.host(), ds.host(), "masked reset")
+    assert np.array_equal(hs["episode"], 1 + mask.astype(np.int32))
+    # ego_only attribute sampling (gym_env.py:194-196)
+    cfg2 = _abi.default_config(seed=12, flags=_abi.F_ALL | _abi.F_EGO_ONLY_ATTRS)
+    hs2, ds2, _ = _pair(small_world, 64, 16, cfg2)
+    assert_state_equal(hs2.host(), ds2.host(), "ego_only reset")
+    L0 = hs2["len"].reshape(64, 16)[:, 0]
+    assert np.all((L0 >= 4.8) & (L0 < 5.5))
+
+
+@pytest.mark.parametrize("flags", [_abi.F_ALL, _abi.F_ALL & ~_abi.F_AUTORESET, _abi.F_REWARD | _abi.F_OFFROAD, 0])
+def test_env_step_bit_exact_over_an_episode(small_world, flags):
+    """full fused step, 250 consecutive steps (> one 200-step episode, so truncation + auto-reset are crossed)"""
+    cfg = _abi.default_config(seed=21, flags=flags, distance_cutoff=0.25)
+    B, A = 333, 16   # ragged: last workgroup partially filled
+    hs, ds, dw = _pair(small_world, B, A, cfg)
+    rng = np.random.default_rng(3)
+    n_term = n_trunc = n_col = n_off = 0
+    for t in range(250):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        if t % 50 < 10:
+            act[:, 1] = 0.0   # let some egos survive long enough to reach waypoints
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, small_world, hs)
+        ops.env_step(cfg, dw, ds)
+        if t % 10 == 0 or t > 195:
+            assert_state_equal(hs.host(), ds.host(), f"step {t} flags {flags}")
+        n_term += int(hs["terminated"].sum()); n_trunc += int(hs["truncated"].sum())
+        n_col += int(hs["collided"].sum()); n_off += int(hs["offroad"].sum())
+    assert_state_equal(hs.host(), ds.host(), "end")
+    if flags & _abi.F_REWARD:
+        assert n_trunc > 0
+    if flags == _abi.F_ALL:
+        assert n_term > 0 and n_col > 0 and n_off > 0 and hs["episode"].max() > 1
+        assert hs["reached"].max() >= 0
+
+
+@pytest.mark.parametrize("A", [1, 4, 8, 32, 64])
+def test_env_step_other_agent_counts(A):
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=4, A=A, seed=A, n_maps=2)
+    cfg = _abi.default_config(seed=A)
+    B = 40 if A >= 32 else 130
+    hs, ds, dw = _pair(world, B, A, cfg)
+    rng = np.random.default_rng(A)
+    for t in range(60):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+    assert_state_equal(hs.host(), ds.host(), f"A={A}")
+
+
+def test_env_rollout_matches_oracle(small_world):
+    cfg = _abi.default_config(seed=5, distance_cutoff=0.25)
+    B, A, K = 200, 16, 64
+    hs, ds, dw = _pair(small_world, B, A, cfg)
+    rng = np.random.default_rng(9)
+    actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+    hr, hd = oracle.env_rollout(cfg, small_world, hs, actions)
+    dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32))
+    assert np.array_equal(dd.cpu().numpy(), hd)
+    assert_state_equal(hs.host(), ds.host(), "rollout end")
+    assert (hd & 1).sum() > 0
+
+
+def test_config2_kin_collide_1024x8():
+    """BASELINE.json configs[1]: 1024 envs x 8 agents, bicycle kinematics + OBB collision only"""
+    rng = np.random.default_rng(2)
+    B, A = 1024, 8
+    ag = random_agents(rng, B, A, spread=8.0)
+    d = {k: dev(val) for k, val in ag.items()}
+    h = {k: val.copy() for k, val in ag.items()}
+    for t in range(20):
+        action = np.stack([rng.uniform(-1, 1, B * A), rng.uniform(-0.3, 0.3, B * A)], -1).astype(np.float32)
+        got = ops.kin_collide_step(B, A, d["x"], d["y"], d["psi"], d["v"], d["lr"], d["length"], d["width"],
+                                   d["present"], dev(action)).cpu().numpy()
+        oracle.kinematics_step(h["x"], h["y"], h["psi"], h["v"], h["lr"], h["present"], action)
+        want = oracle.compute_collision(B, A, h["x"], h["y"], h["psi"], h["length"], h["width"], h["present"])
+        assert np.array_equal(got, want), t
+    for k in ("x", "y", "psi", "v"):
+        assert np.array_equal(d[k].cpu().numpy().view(np.uint32), h[k].view(np.uint32)), k
+
+
+def test_full_size_8192x16_subset_and_determinism():
+    """BASELINE.json configs[2] size.  Envs are independent and the reset RNG is keyed by env index, so envs
+    [0, 384) of the 8192-env batch must equal a 384-env oracle run bit for bit; and two GPU runs must agree."""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=16, A=16, seed=0, n_maps=2)
+    cfg = _abi.default_config(seed=77, distance_cutoff=0.25)
+    B, A, K, SUB = 8192, 16, 210, 256
+    dw = world.to_device(DEV)
+    rng = np.random.default_rng(1)
+    actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        ds = EnvState(B, A, device=DEV)
+        ops.env_reset(cfg, dw, ds)
+        r, d = ops.env_rollout(cfg, dw, ds, dev(actions))
+        runs.append((r.cpu().numpy(), d.cpu().numpy(), ds.host()))
+    assert np.array_equal(runs[0][0].view(np.uint32), runs[1][0].view(np.uint32))
+    assert np.array_equal(runs[0][1], runs[1][1])
+    hs = EnvState(SUB, A)
+    oracle.env_reset(cfg, world, hs)
+    hr, hd = oracle.env_rollout(cfg, world, hs, np.ascontiguousarray(actions[:, :SUB]))
+    assert np.array_equal(runs[0][0][:, :SUB].view(np.uint32), hr.view(np.uint32))
+    assert np.array_equal(runs[0][1][:, :SUB], hd)
+    full = runs[0][2]
+    for k, a in hs.host().items():
+        if k == "action":
+            continue
+        n = a.shape[0]
+        assert np.array_equal(np.ascontiguousarray(full[k][:n]).view(np.uint8), a.view(np.uint8)), k
+    # sanity of the batch as a whole
+    done = runs[0][1]
+    assert (done & 2).sum() > 0 and (done & 1).sum() > 0
+    assert np.isfinite(runs[0][0]).all()

@@ -1,0 +1,29 @@
+"""Builds libtde_hip.so in-tree with hipcc for gfx950 (one translation unit, ~5 s)."""
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(_PKG, "csrc", "tde_kernels.hip")]
+DEPS = SRC + [os.path.join(_PKG, "csrc", "tde_device.h"), os.path.join(_PKG, "..", "include", "tde_abi.h"),
+              os.path.join(_PKG, "..", "include", "tde_hip.h")]
+OUT = os.path.join(_PKG, "libtde_hip.so")
+
+# -ffp-contract=off / no fast-math: one IEEE rounding per written operation — the floating-point contract shared
+# with the oracle (bit-exact masks AND state).  fp32 divide/sqrt stay IEEE-correct (hipcc default).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-fvisibility=hidden"]
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    stale = not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(p) for p in DEPS)
+    if force or stale:
+        cmd = [hipcc] + FLAGS + ["-o", OUT] + SRC
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

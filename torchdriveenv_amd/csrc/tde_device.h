@@ -1,0 +1,201 @@
+// tde_device.h — device-side building blocks of the env step path (gfx950 / CDNA4, wave64).
+//
+// Every fp32 expression here is written to round exactly like the CPU oracle's (oracle/tde_oracle.c): the library is
+// compiled with -ffp-contract=off, without fast-math, with IEEE-correct fp32 divide/sqrt (hipcc default), so masks AND
+// kinematic state are bit-identical to the oracle.  Reference anchors (file:line into inverted-ai/torchdriveenv) are
+// given per function; torchdrivesim internals are restated from the published algorithm ("Oracle").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tde_abi.h"
+
+#define TDE_DEV __device__ __forceinline__
+
+namespace tde {
+
+constexpr float kPi = 3.14159265358979323846f;      // float(np.pi)
+constexpr float kTwoPi = 6.28318530717958647692f;   // float(2*np.pi)
+constexpr float k2OverPi = 0.636619772367581343f;
+constexpr float kPio2A = 1.5703125f;                // Cody-Waite split of pi/2 (k*A, k*B exact for |k| < 2^13)
+constexpr float kPio2B = 4.837512969970703125e-4f;
+constexpr float kPio2C = 7.54978995489188216e-8f;
+
+// sin and cos of an fp32 angle: plain mul/add only, so CPU and GPU agree bit for bit (<= 2 ulp vs libm).
+TDE_DEV void sincos_f32(float xin, float &s, float &c)
+{
+    float kf = __builtin_rintf(xin * k2OverPi);
+    float r = xin - kf * kPio2A;
+    r = r - kf * kPio2B;
+    r = r - kf * kPio2C;
+    float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    float sn = r + (r * z) * ps;
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    float cs = (1.0f - 0.5f * z) + (z * z) * pc;
+    int q = ((int)kf) & 3;
+    float a = (q & 1) ? cs : sn;   // q: 0 (sn,cs) 1 (cs,-sn) 2 (-sn,-cs) 3 (-cs,sn)
+    float b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+TDE_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// torch.remainder(a, b): result takes the sign of b
+TDE_DEV float pymodf(float a, float b)
+{
+    float r = fmodf(a, b);
+    if (r != 0.0f && ((r < 0.0f) != (b < 0.0f))) r += b;
+    return r;
+}
+
+// R4: KinematicBicycle.step — called through simulator.step(action), ref gym_env.py:117; model built at :245-247.
+TDE_DEV void bicycle(float &x, float &y, float &psi, float &v, float lr, float a, float beta, float dt)
+{
+    float v1 = v + a * dt;
+    float sn, cs;
+    sincos_f32(psi + beta, sn, cs);
+    float x1 = x + (v1 * cs) * dt;
+    float y1 = y + (v1 * sn) * dt;
+    float sb, cb;
+    sincos_f32(beta, sb, cb);
+    float p1 = psi + ((v1 / lr) * sb) * dt;
+    p1 = pymodf(kPi + p1, kTwoPi) - kPi;
+    x = x1; y = y1; psi = p1; v = v1;
+}
+
+// R9: strict separating-axis overlap of two oriented boxes (compute_collision() > 0, ref gym_env.py:143,415).
+TDE_DEV bool obb_overlap(float xi, float yi, float ci, float si, float hli, float hwi, float xj, float yj, float cj,
+                         float sj, float hlj, float hwj)
+{
+    float dx = xj - xi, dy = yj - yi;
+    float c = ci * cj + si * sj;
+    float s = ci * sj - si * cj;
+    float ac = fabsf(c), as = fabsf(s);
+    float p = dx * ci + dy * si;
+    bool ok = fabsf(p) < hli + (hlj * ac + hwj * as);
+    float q = dy * ci - dx * si;
+    ok = ok && (fabsf(q) < hwi + (hlj * as + hwj * ac));
+    float p2 = dx * cj + dy * sj;
+    ok = ok && (fabsf(p2) < hlj + (hli * ac + hwi * as));
+    float q2 = dy * cj - dx * sj;
+    ok = ok && (fabsf(q2) < hwj + (hli * as + hwi * ac));
+    return ok;
+}
+
+// R10 building blocks: squared distance point -> segment / triangle (0 inside).
+TDE_DEV float seg_d2(float px, float py, float ax, float ay, float bx, float by)
+{
+    float abx = bx - ax, aby = by - ay;
+    float apx = px - ax, apy = py - ay;
+    float len2 = abx * abx + aby * aby;
+    float t = 0.0f;
+    if (len2 > 0.0f) {
+        float inv = 1.0f / len2;
+        t = (apx * abx + apy * aby) * inv;
+        t = clampf(t, 0.0f, 1.0f);
+    }
+    float qx = apx - t * abx, qy = apy - t * aby;
+    return qx * qx + qy * qy;
+}
+
+TDE_DEV float point_tri_d2(float px, float py, const float *__restrict__ t)
+{
+    float ax = t[0], ay = t[1], bx = t[2], by = t[3], cx = t[4], cy = t[5];
+    float e0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+    float e1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
+    float e2 = (ax - cx) * (py - cy) - (ay - cy) * (px - cx);
+    if ((e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) || (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f)) return 0.0f;
+    float d = seg_d2(px, py, ax, ay, bx, by);
+    d = fminf(d, seg_d2(px, py, bx, by, cx, cy));
+    d = fminf(d, seg_d2(px, py, cx, cy, ax, ay));
+    return d;
+}
+
+// true if the point is farther than sqrt(thr2) from every triangle of the map; uses the grid index, which is
+// conservative by GRID_MARGIN so the answer equals the oracle's brute force (world.py: build_grid_index).
+TDE_DEV bool point_offroad(const tde_world &w, const tde_map &m, float px, float py, float thr2)
+{
+    float fx = (px - m.ox) * m.inv_cell;
+    float fy = (py - m.oy) * m.inv_cell;
+    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)m.nx && fy < (float)m.ny)) return true;
+    int cell = m.cell_base + (int)fy * m.nx + (int)fx;
+    uint32_t cls = w.cell_class[cell];
+    if (cls != TDE_CELL_MIXED) return cls == TDE_CELL_EMPTY;
+    int k0 = w.cell_start[cell], k1 = w.cell_start[cell + 1];
+    for (int k = k0; k < k1; ++k) {
+        if (point_tri_d2(px, py, w.tri + 6 * (int64_t)w.cell_tris[k]) <= thr2) return false;
+    }
+    return true;
+}
+
+// compute_offroad() > 0 for one box: any of the corners FL, FR, RR, RL off the drivable surface.
+TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, float x, float y, float c, float s, float hl, float hw,
+                         float thr2)
+{
+    float lx = hl * c, ly = hl * s, wx = hw * s, wy = hw * c;
+    bool off = point_offroad(w, m, (x + lx) - wx, (y + ly) + wy, thr2);
+    off = off || point_offroad(w, m, (x + lx) + wx, (y + ly) - wy, thr2);
+    off = off || point_offroad(w, m, (x - lx) + wx, (y - ly) - wy, thr2);
+    off = off || point_offroad(w, m, (x - lx) - wx, (y - ly) + wy, thr2);
+    return off;
+}
+
+// Philox4x32-10, key = seed, counter = (c0,c1,c2,c3) — the reset RNG (R16).
+TDE_DEV void philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4])
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+TDE_DEV double u01(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
+
+// R6/R7/R8/R11/R12 — the reference-owned reward/termination logic, ref gym_env.py:391-437 (see the oracle's
+// tde_reward_core for the line-by-line citations).  float64 math on fp32 state, as the reference's Python does.
+struct RewardOut {
+    float reward;
+    uint8_t terminated, truncated;
+    double psi_smooth, speed_smooth, psi_r, dist_r;
+};
+
+TDE_DEV RewardOut reward_core(const tde_config &cfg, const double *__restrict__ wp, int n_wp, float lx, float ly,
+                              float lpsi, float lv, float x, float y, float psi, float v, bool off, bool col, bool tl,
+                              int k, int &target_idx, int &reached)
+{
+    RewardOut o;
+    double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
+    double d = sqrt(ddx * ddx + ddy * ddy);
+    o.dist_r = (d > cfg.distance_cutoff) ? cfg.distance_bonus : 0.0;
+    float dpsi = psi - lpsi;
+    o.psi_r = (1.0 - cos((double)dpsi)) * (-cfg.heading_penalty);
+    bool reach = false;
+    int ti = target_idx;
+    if (ti < n_wp) {
+        double tx = (double)x - wp[2 * ti], ty = (double)y - wp[2 * ti + 1];
+        reach = sqrt(tx * tx + ty * ty) < cfg.reach_radius;
+    }
+    double reach_r = 0.0;
+    if (reach) { reach_r = cfg.waypoint_bonus; reached += 1; }
+    o.reward = (float)((reach_r + o.dist_r) + o.psi_r);
+    o.terminated = (uint8_t)(cfg.terminated_at_infraction && (off || col || tl));
+    o.truncated = (uint8_t)(k >= cfg.max_steps);
+    o.psi_smooth = (double)fabsf((lpsi - psi) / 0.1f);
+    o.speed_smooth = (double)fabsf((lv - v) / 0.1f);
+    if (reach) target_idx = ti + 1;
+    return o;
+}
+
+}  // namespace tde

@@ -1,0 +1,579 @@
+// tde_kernels.hip — hand-written CDNA4 (gfx950) kernels of the batched driving-env step path and the C-ABI that
+// exposes them (include/tde_hip.h).  No torch types anywhere: plain device pointers, sizes and a hipStream_t.
+//
+// Mapping (DESIGN.md "Kernels"): one lane per agent slot, env-major, so an env of A (power of two <= 64) slots is a
+// contiguous lane group inside ONE wavefront; 256-thread workgroups hold 256/A envs.  Per-env agent tiles are staged
+// in LDS for the all-pairs sweeps (NPC gap search on the pre-step tile, OBB collision on the post-step tile); env
+// termination is gathered with a wave ballot.  HBM traffic per step is the SoA state read + write; the drivable-mesh
+// grid index and the scenario tables are read-only and stay in L2 / Infinity Cache.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tde_hip.h"
+#include "tde_device.h"
+
+namespace tde {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-lane registers
+// ------------------------------------------------------------------------------------------------------------------
+struct Agent {
+    float x, y, psi, v, len, wid, lr, vdes;
+    int route, route_wp, replay;
+    bool present;
+};
+
+struct EnvRegs {   // replicated on every lane of the env
+    int scn, steps, target_idx, reached, episode;
+};
+
+struct Tiles {     // LDS, one slot per lane of the workgroup
+    float x[kBlock], y[kBlock], c[kBlock], s[kBlock], len[kBlock], wid[kBlock];
+    uint8_t present[kBlock];
+};
+
+TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
+{
+    a.x = st.x[g]; a.y = st.y[g]; a.psi = st.psi[g]; a.v = st.v[g];
+    a.len = st.len[g]; a.wid = st.wid[g]; a.lr = st.lr[g]; a.vdes = st.vdes[g];
+    a.route = st.route[g]; a.route_wp = st.route_wp[g]; a.replay = st.replay[g];
+    a.present = st.present[g] != 0;
+}
+
+TDE_DEV void store_agent_dynamic(const tde_state &st, int64_t g, const Agent &a)
+{
+    st.x[g] = a.x; st.y[g] = a.y; st.psi[g] = a.psi; st.v[g] = a.v;
+    st.route_wp[g] = a.route_wp;
+}
+
+TDE_DEV void store_agent_static(const tde_state &st, int64_t g, const Agent &a)
+{
+    st.len[g] = a.len; st.wid[g] = a.wid; st.lr[g] = a.lr; st.vdes[g] = a.vdes;
+    st.route[g] = a.route; st.replay[g] = a.replay; st.present[g] = a.present ? 1 : 0;
+}
+
+// WaypointSuiteEnv.reset + set_start_pos + build_simulator's initial tensors for one env (ref gym_env.py:319-367,
+// 192-198, 241-247); every lane of the env runs it for its own slot.  Mirrors tde_reset_env of the oracle.
+template <int A>
+TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a, Agent &ag, EnvRegs &er)
+{
+    uint32_t ep = (uint32_t)er.episode;
+    uint32_t r0[4];
+    philox(cfg.seed, (uint32_t)e, ep, 0u, 0x7DEu, r0);
+    int scn = (int)(((uint64_t)r0[0] * (uint64_t)w.n_scn) >> 32);
+    er.scn = scn;
+    er.steps = 0;
+    er.target_idx = 1;
+    er.reached = 0;
+    er.episode = (int)(ep + 1u);
+    int64_t sa = (int64_t)scn * A + a;
+    ag.x = w.spawn_state[4 * sa + 0];
+    ag.y = w.spawn_state[4 * sa + 1];
+    ag.psi = w.spawn_state[4 * sa + 2];
+    ag.v = w.spawn_state[4 * sa + 3];
+    ag.len = w.spawn_attr[3 * sa + 0];
+    ag.wid = w.spawn_attr[3 * sa + 1];
+    ag.lr = w.spawn_attr[3 * sa + 2];
+    ag.vdes = w.spawn_vdes[sa];
+    ag.route = w.spawn_route[sa];
+    ag.route_wp = w.spawn_route_wp[sa];
+    ag.replay = w.spawn_replay[sa];
+    ag.present = w.spawn_present[sa] != 0;
+    if (a == 0) {
+        uint32_t r1[4], rn[4];
+        philox(cfg.seed, (uint32_t)e, ep, 1u, 0x7DEu, r1);
+        const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
+        double f = u01(r0[1]);
+        double sx = wp[0] + f * (wp[2] - wp[0]);
+        double sy = wp[1] + f * (wp[3] - wp[1]);
+        double speed = u01(r0[2]) * 10.0;
+        double acc = 0.0;
+        for (uint32_t b = 0; b < 3; ++b) {
+            philox(cfg.seed, (uint32_t)e, ep, 2u + b, 0x7DEu, rn);
+            for (int k = 0; k < 4; ++k) acc += u01(rn[k]);
+        }
+        double psi0 = (double)w.start_heading[scn] + (acc - 6.0) * 0.1;
+        ag.x = (float)sx; ag.y = (float)sy; ag.psi = (float)psi0; ag.v = (float)speed;
+        ag.present = true; ag.route = -1; ag.replay = -1; ag.vdes = 0.0f;
+        if (cfg.flags & TDE_F_EGO_ONLY_ATTRS) {
+            ag.len = (float)(u01(r0[3]) * (5.5 - 4.8) + 4.8);
+            ag.wid = (float)(u01(r1[0]) * (2.2 - 1.8) + 1.8);
+            ag.lr = (float)(u01(r1[1]) * (0.97 - 0.82) + 0.82);
+        }
+    }
+}
+
+// heuristic NPC controller (R14 slot), mirrors tde_npc_action of the oracle; reads the PRE-step tile.
+template <int A>
+TDE_DEV void npc_action(const tde_config &cfg, const tde_world &w, const Tiles &t, int base, int i, const Agent &ag,
+                        float cp, float sp, float &acc, float &beta)
+{
+    float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
+    int rn = ag.route >= 0 ? w.route_n[ag.route] : 0;
+    if (ag.route < 0 || ag.route_wp >= rn) {
+        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
+        beta = 0.0f;
+        return;
+    }
+    const float *tg = w.route_xy + ((int64_t)ag.route * w.RW + ag.route_wp) * 2;
+    float dx = tg[0] - ag.x, dy = tg[1] - ag.y;
+    float fwd = dx * cp + dy * sp;
+    float lat = dy * cp - dx * sp;
+    float dist = sqrtf(dx * dx + dy * dy);
+    float sin_err = lat / fmaxf(dist, 1e-3f);
+    if (fwd < 0.0f) beta = copysignf(smax, lat);
+    else beta = clampf(cfg.npc_k_steer * sin_err, -smax, smax);
+    float gap = 1e30f;
+#pragma unroll 4
+    for (int j = 0; j < A; ++j) {
+        int jj = base + j;
+        if (j == i || !t.present[jj]) continue;
+        float ex = t.x[jj] - ag.x, ey = t.y[jj] - ag.y;
+        float fj = ex * cp + ey * sp;
+        float lj = ey * cp - ex * sp;
+        if (fj > 0.0f) {
+            float halfw = cfg.npc_lane_half + 0.5f * t.wid[jj];
+            float al = fabsf(lj);
+            bool inlane = al < halfw;
+            float hd = cp * t.c[jj] + sp * t.s[jj];
+            bool cone = (j < i) && (fj < cfg.npc_cone_range) && (al < halfw + cfg.npc_cone_k * fj) && (hd > -0.5f);
+            if (inlane || cone) {
+                float g = fj - 0.5f * (ag.len + t.len[jj]);
+                gap = fminf(gap, g);
+            }
+        }
+    }
+    float vd = fminf(ag.vdes, sqrtf(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
+    acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
+}
+
+struct StepOut {
+    float reward;
+    uint8_t terminated, truncated, collided, offroad;
+};
+
+// One timestep for this lane's agent slot.  WaypointSuiteEnv.step over GymEnv.step, ref gym_env.py:369-389,115-120.
+// `act_acc/act_steer` are the ego action of this lane's env (read by every lane, used by slot 0).
+// Called by all 256 lanes of the workgroup (contains barriers).
+template <int A>
+TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_state &st, Tiles &t, int e, int a,
+                          bool valid, Agent &ag, EnvRegs &er, float act_acc, float act_steer)
+{
+    const uint32_t F = cfg.flags;
+    const int tid = threadIdx.x;
+    const int base = tid - a;                       // first lane of this env inside the workgroup
+    const bool live = valid && ag.present;
+    StepOut out{0.0f, 0, 0, 0, 0};
+
+    // pre-step tile (positions, heading unit vectors, sizes) for the NPC controller
+    const float lx = ag.x, ly = ag.y, lpsi = ag.psi, lv = ag.v;   // :371-375 last_x, last_y, last_psi, last_speed
+    float sp = 0.0f, cp = 1.0f;
+    if (F & TDE_F_NPC) {
+        sincos_f32(ag.psi, sp, cp);
+        t.x[tid] = ag.x; t.y[tid] = ag.y; t.c[tid] = cp; t.s[tid] = sp;
+        t.len[tid] = ag.len; t.wid[tid] = ag.wid; t.present[tid] = live ? 1 : 0;
+        __syncthreads();
+    }
+    er.steps += 1;                                  // :116
+    const int k = er.steps;
+
+    if (live) {
+        float acc = 0.0f, beta = 0.0f;
+        if (a == 0) { acc = act_acc; beta = act_steer; }
+        else if (F & TDE_F_NPC) npc_action<A>(cfg, w, t, base, a, ag, cp, sp, acc, beta);
+        bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);          // :117
+        if ((F & TDE_F_REPLAY) && a > 0 && ag.replay >= 0 && k < w.replay_len[ag.replay]) {   // :275-283
+            const float *r = w.replay_states + ((int64_t)ag.replay * w.RT + k) * 4;
+            ag.x = r[0]; ag.y = r[1]; ag.psi = r[2]; ag.v = r[3];
+        }
+        if ((F & TDE_F_NPC) && a > 0 && ag.route >= 0 && ag.route_wp < w.route_n[ag.route]) {
+            const float *tg = w.route_xy + ((int64_t)ag.route * w.RW + ag.route_wp) * 2;
+            float dx = tg[0] - ag.x, dy = tg[1] - ag.y;
+            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) ag.route_wp += 1;
+        }
+    }
+
+    // post-step tile for the all-pairs collision sweep
+    float s1, c1;
+    sincos_f32(ag.psi, s1, c1);
+    const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
+    if (F & TDE_F_NPC) __syncthreads();             // every lane is done reading the pre-step tile
+    t.x[tid] = ag.x; t.y[tid] = ag.y; t.c[tid] = c1; t.s[tid] = s1; t.len[tid] = hl; t.wid[tid] = hw;
+    t.present[tid] = live ? 1 : 0;
+    __syncthreads();
+    bool hit = false;
+    if (live) {
+#pragma unroll 4
+        for (int j = 0; j < A; ++j) {
+            int jj = base + j;
+            if (j == a || !t.present[jj]) continue;
+            hit = hit || obb_overlap(ag.x, ag.y, c1, s1, hl, hw, t.x[jj], t.y[jj], t.c[jj], t.s[jj], t.len[jj],
+                                     t.wid[jj]);
+        }
+    }
+    bool off = false;
+    if ((F & TDE_F_OFFROAD) && live) {
+        const tde_map m = w.maps[w.scn_map[er.scn]];
+        off = box_offroad(w, m, ag.x, ag.y, c1, s1, hl, hw, cfg.offroad_threshold * cfg.offroad_threshold);
+    }
+    out.collided = hit ? 1 : 0;
+    out.offroad = off ? 1 : 0;
+
+    // reward / termination: the ego lane computes, then the env's other lanes pick the result up by shuffle
+    int done = 0;
+    if (F & TDE_F_REWARD) {
+        if (a == 0 && valid) {
+            const double *wp = w.wp_xy + (int64_t)er.scn * w.NW * 2;
+            RewardOut r = reward_core(cfg, wp, w.wp_n[er.scn], lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
+                                      false, k, er.target_idx, er.reached);
+            out.reward = r.reward;
+            out.terminated = r.terminated;
+            out.truncated = r.truncated;
+            if (st.info) {
+                double *inf = st.info + 4 * (int64_t)e;
+                inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
+            }
+            if (st.info_reached) st.info_reached[e] = er.reached;
+            done = (r.terminated | r.truncated) ? 1 : 0;
+        }
+        if (F & TDE_F_AUTORESET) {
+            // wave ballot: skip the reset path when no env of this wavefront finished
+            unsigned long long any = __ballot(done);
+            if (any) {
+                const int lane = tid & 63;
+                int env_done = (int)((any >> (lane - a)) & 1ull);   // bit of this env's ego lane
+                if (env_done && valid) reset_lane<A>(cfg, w, e, a, ag, er);
+                if (env_done) out.collided |= 0x80;   // marks "agent was re-spawned": static attrs must be stored
+            }
+        }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+template <int A>
+__global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
+                                                          const float *__restrict__ action, float *reward_k,
+                                                          uint8_t *done_k)
+{
+    __shared__ Tiles t;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int e = (int)(g / A), a = (int)(g % A);
+    const bool valid = e < st.B;
+    const int64_t gs = valid ? g : 0;
+    const int es = valid ? e : 0;
+    Agent ag;
+    load_agent(st, gs, ag);
+    if (!valid) ag.present = false;
+    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
+    const float aa = action[2 * es], as = action[2 * es + 1];
+    StepOut o = step_lane<A>(cfg, w, st, t, es, a, valid, ag, er, aa, as);
+    if (!valid) return;
+    const bool respawned = (o.collided & 0x80) != 0;
+    store_agent_dynamic(st, g, ag);
+    if (respawned) store_agent_static(st, g, ag);
+    // flags of a re-spawned agent are cleared, as tde_reset_env does
+    st.collided[g] = respawned ? 0 : (o.collided & 1);
+    st.offroad[g] = respawned ? 0 : o.offroad;
+    if (a == 0) {
+        st.steps[e] = er.steps;
+        st.target_idx[e] = er.target_idx;
+        st.reached[e] = er.reached;
+        st.reward[e] = o.reward;
+        st.terminated[e] = o.terminated;
+        st.truncated[e] = o.truncated;
+        if (respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
+        if (reward_k) reward_k[e] = o.reward;
+        if (done_k)
+            done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | ((o.collided & 1) << 3));
+    }
+}
+
+template <int A>
+__global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_world w, tde_state st,
+                                                           const uint8_t *__restrict__ mask)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int e = (int)(g / A), a = (int)(g % A);
+    if (e >= st.B) return;
+    if (mask && !mask[e]) return;
+    Agent ag;
+    EnvRegs er{0, 0, 0, 0, st.episode[e]};
+    reset_lane<A>(cfg, w, e, a, ag, er);
+    store_agent_dynamic(st, g, ag);
+    store_agent_static(st, g, ag);
+    st.collided[g] = 0;
+    st.offroad[g] = 0;
+    if (a == 0) {
+        st.scn[e] = er.scn; st.steps[e] = 0; st.target_idx[e] = 1; st.reached[e] = 0; st.episode[e] = er.episode;
+    }
+}
+
+// --- operator-level kernels (SimulatorInterface methods) ------------------------------------------------
+__global__ __launch_bounds__(kBlock) void kinematics_kernel(int64_t n, float *x, float *y, float *psi, float *v,
+                                                            const float *__restrict__ lr,
+                                                            const uint8_t *__restrict__ present,
+                                                            const float *__restrict__ action, float dt)
+{
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (present && !present[i]) return;
+    float2 act = reinterpret_cast<const float2 *>(action)[i];
+    float X = x[i], Y = y[i], P = psi[i], V = v[i];
+    bicycle(X, Y, P, V, lr[i], act.x, act.y, dt);
+    x[i] = X; y[i] = Y; psi[i] = P; v[i] = V;
+}
+
+// kinematics (optional) + all-pairs collision; BASELINE config 2 when KIN
+template <int A, bool KIN>
+__global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float *y, float *psi, float *v,
+                                                         const float *__restrict__ lr, const float *__restrict__ len,
+                                                         const float *__restrict__ wid,
+                                                         const uint8_t *__restrict__ present,
+                                                         const float *__restrict__ action, float dt,
+                                                         uint8_t *__restrict__ out)
+{
+    __shared__ Tiles t;
+    const int tid = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + tid;
+    const int a = (int)(g % A);
+    const bool valid = (g / A) < B;
+    const int64_t gs = valid ? g : 0;
+    float X = x[gs], Y = y[gs], P = psi[gs];
+    const bool live = valid && present[gs] != 0;
+    if (KIN && live) {
+        float V = v[gs];
+        float2 act = reinterpret_cast<const float2 *>(action)[gs];
+        bicycle(X, Y, P, V, lr[gs], act.x, act.y, dt);
+        x[g] = X; y[g] = Y; psi[g] = P; v[g] = V;
+    }
+    float s1, c1;
+    sincos_f32(P, s1, c1);
+    const float hl = 0.5f * len[gs], hw = 0.5f * wid[gs];
+    t.x[tid] = X; t.y[tid] = Y; t.c[tid] = c1; t.s[tid] = s1; t.len[tid] = hl; t.wid[tid] = hw;
+    t.present[tid] = live ? 1 : 0;
+    __syncthreads();
+    bool hit = false;
+    const int base = tid - a;
+    if (live) {
+#pragma unroll 4
+        for (int j = 0; j < A; ++j) {
+            int jj = base + j;
+            if (j == a || !t.present[jj]) continue;
+            hit = hit || obb_overlap(X, Y, c1, s1, hl, hw, t.x[jj], t.y[jj], t.c[jj], t.s[jj], t.len[jj], t.wid[jj]);
+        }
+    }
+    if (valid) out[g] = hit ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void offroad_kernel(int B, int A, const float *__restrict__ x,
+                                                         const float *__restrict__ y, const float *__restrict__ psi,
+                                                         const float *__restrict__ len, const float *__restrict__ wid,
+                                                         const uint8_t *__restrict__ present, tde_world w,
+                                                         const int32_t *__restrict__ map_of_env, float thr,
+                                                         uint8_t *__restrict__ out)
+{
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= (int64_t)B * A) return;
+    uint8_t off = 0;
+    if (present[g]) {
+        float s1, c1;
+        sincos_f32(psi[g], s1, c1);
+        const tde_map m = w.maps[map_of_env[g / A]];
+        off = box_offroad(w, m, x[g], y[g], c1, s1, 0.5f * len[g], 0.5f * wid[g], thr * thr) ? 1 : 0;
+    }
+    out[g] = off;
+}
+
+__global__ __launch_bounds__(kBlock) void reward_kernel(
+    tde_config cfg, int n, const float *__restrict__ pre_x, const float *__restrict__ pre_y,
+    const float *__restrict__ pre_psi, const float *__restrict__ pre_v, const float *__restrict__ x,
+    const float *__restrict__ y, const float *__restrict__ psi, const float *__restrict__ v,
+    const uint8_t *__restrict__ offroad, const uint8_t *__restrict__ collided, const uint8_t *__restrict__ tl,
+    const double *__restrict__ wp_xy, const int32_t *__restrict__ wp_n, int NW, const int32_t *__restrict__ scn,
+    int32_t *steps, int32_t *target_idx, int32_t *reached, float *reward, uint8_t *terminated, uint8_t *truncated,
+    double *info, int32_t *info_reached)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int k = steps[i] + 1;
+    steps[i] = k;
+    int ti = target_idx[i], rc = reached[i];
+    const int s = scn[i];
+    RewardOut r = reward_core(cfg, wp_xy + (int64_t)s * NW * 2, wp_n[s], pre_x[i], pre_y[i], pre_psi[i], pre_v[i], x[i],
+                              y[i], psi[i], v[i], offroad[i] != 0, collided[i] != 0, tl ? tl[i] != 0 : false, k, ti, rc);
+    target_idx[i] = ti;
+    reached[i] = rc;
+    reward[i] = r.reward;
+    terminated[i] = r.terminated;
+    truncated[i] = r.truncated;
+    if (info) {
+        double *inf = info + 4 * (int64_t)i;
+        inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
+    }
+    if (info_reached) info_reached[i] = rc;
+}
+
+}  // namespace tde
+
+// ------------------------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+
+static int fail(const char *what, hipError_t e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+static int bad(const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return (int)hipErrorInvalidValue;
+}
+
+static bool pow2_le64(int A) { return A >= 1 && A <= TDE_MAX_AGENTS && (A & (A - 1)) == 0; }
+
+#define TDE_DISPATCH_A(A, ...)                                  \
+    switch (A) {                                                \
+        case 1: { constexpr int kA = 1; __VA_ARGS__; } break;   \
+        case 2: { constexpr int kA = 2; __VA_ARGS__; } break;   \
+        case 4: { constexpr int kA = 4; __VA_ARGS__; } break;   \
+        case 8: { constexpr int kA = 8; __VA_ARGS__; } break;   \
+        case 16: { constexpr int kA = 16; __VA_ARGS__; } break; \
+        case 32: { constexpr int kA = 32; __VA_ARGS__; } break; \
+        case 64: { constexpr int kA = 64; __VA_ARGS__; } break; \
+    }
+
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + tde::kBlock - 1) / tde::kBlock); }
+
+extern "C" {
+
+int tde_abi_version(void) { return TDE_ABI_VERSION; }
+
+const char *tde_last_error(void) { return g_err; }
+
+int tde_kinematics_step(int64_t n, float *x, float *y, float *psi, float *v, const float *lr, const uint8_t *present,
+                        const float *action, float dt, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(tde::kinematics_kernel, dim3(blocks_for(n)), dim3(tde::kBlock), 0, (hipStream_t)stream, n, x, y,
+                       psi, v, lr, present, action, dt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_kinematics_step", e);
+}
+
+int tde_compute_collision(int32_t B, int32_t A, const float *x, const float *y, const float *psi, const float *len,
+                          const float *wid, const uint8_t *present, uint8_t *out, void *stream)
+{
+    if (!pow2_le64(A)) return bad("tde_compute_collision: A must be a power of two in [1,64]");
+    if (B <= 0) return 0;
+    const unsigned nb = blocks_for((int64_t)B * A);
+    TDE_DISPATCH_A(A, tde::collide_kernel<kA, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
+                          B, const_cast<float *>(x), const_cast<float *>(y), const_cast<float *>(psi), (float *)nullptr,
+                          (const float *)nullptr, len, wid, present, (const float *)nullptr, 0.0f, out));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_compute_collision", e);
+}
+
+int tde_kin_collide_step(int32_t B, int32_t A, float *x, float *y, float *psi, float *v, const float *lr,
+                         const float *len, const float *wid, const uint8_t *present, const float *action, float dt,
+                         uint8_t *collided, void *stream)
+{
+    if (!pow2_le64(A)) return bad("tde_kin_collide_step: A must be a power of two in [1,64]");
+    if (B <= 0) return 0;
+    const unsigned nb = blocks_for((int64_t)B * A);
+    TDE_DISPATCH_A(A, tde::collide_kernel<kA, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
+                          B, x, y, psi, v, lr, len, wid, present, action, dt, collided));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_kin_collide_step", e);
+}
+
+int tde_compute_offroad(int32_t B, int32_t A, const float *x, const float *y, const float *psi, const float *len,
+                        const float *wid, const uint8_t *present, const tde_world *world, const int32_t *map_of_env,
+                        float threshold, uint8_t *out, void *stream)
+{
+    if (!world) return bad("tde_compute_offroad: world is NULL");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(tde::offroad_kernel, dim3(blocks_for((int64_t)B * A)), dim3(tde::kBlock), 0, (hipStream_t)stream,
+                       B, A, x, y, psi, len, wid, present, *world, map_of_env, threshold, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_compute_offroad", e);
+}
+
+int tde_waypoint_reward(const tde_config *cfg, int32_t n, const float *pre_x, const float *pre_y, const float *pre_psi,
+                        const float *pre_v, const float *x, const float *y, const float *psi, const float *v,
+                        const uint8_t *offroad, const uint8_t *collided, const uint8_t *tl_violation,
+                        const double *wp_xy, const int32_t *wp_n, int32_t NW, const int32_t *scn, int32_t *steps,
+                        int32_t *target_idx, int32_t *reached, float *reward, uint8_t *terminated, uint8_t *truncated,
+                        double *info, int32_t *info_reached, void *stream)
+{
+    if (!cfg) return bad("tde_waypoint_reward: cfg is NULL");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(tde::reward_kernel, dim3(blocks_for(n)), dim3(tde::kBlock), 0, (hipStream_t)stream, *cfg, n,
+                       pre_x, pre_y, pre_psi, pre_v, x, y, psi, v, offroad, collided, tl_violation, wp_xy, wp_n, NW, scn,
+                       steps, target_idx, reached, reward, terminated, truncated, info, info_reached);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_waypoint_reward", e);
+}
+
+static int check_env_args(const char *fn, const tde_config *cfg, const tde_world *w, const tde_state *st)
+{
+    if (!cfg || !w || !st) { snprintf(g_err, sizeof(g_err), "%s: NULL argument", fn); return (int)hipErrorInvalidValue; }
+    if (!pow2_le64(st->A)) { snprintf(g_err, sizeof(g_err), "%s: A must be a power of two in [1,64]", fn); return (int)hipErrorInvalidValue; }
+    if (w->A != st->A) { snprintf(g_err, sizeof(g_err), "%s: world.A (%d) != state.A (%d)", fn, w->A, st->A); return (int)hipErrorInvalidValue; }
+    return 0;
+}
+
+int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state *st, const uint8_t *mask,
+                  void *stream)
+{
+    int rc = check_env_args("tde_env_reset", cfg, world, st);
+    if (rc) return rc;
+    if (st->B <= 0) return 0;
+    const unsigned nb = blocks_for((int64_t)st->B * st->A);
+    TDE_DISPATCH_A(st->A, tde::env_reset_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, mask));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_env_reset", e);
+}
+
+int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream)
+{
+    int rc = check_env_args("tde_env_step", cfg, world, st);
+    if (rc) return rc;
+    if (!st->action) return bad("tde_env_step: state.action is NULL");
+    if (st->B <= 0) return 0;
+    const unsigned nb = blocks_for((int64_t)st->B * st->A);
+    TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
+                              *cfg, *world, *st, st->action, (float *)nullptr, (uint8_t *)nullptr));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_env_step", e);
+}
+
+int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro,
+                    void *stream)
+{
+    int rc = check_env_args("tde_env_rollout", cfg, world, st);
+    if (rc) return rc;
+    if (!ro || !ro->actions) return bad("tde_env_rollout: rollout/actions is NULL");
+    if (st->B <= 0 || ro->K <= 0) return 0;
+    const unsigned nb = blocks_for((int64_t)st->B * st->A);
+    const int64_t B = st->B;
+    for (int k = 0; k < ro->K; ++k) {
+        const float *act = ro->actions + (int64_t)k * B * 2;
+        float *rk = ro->reward ? ro->reward + (int64_t)k * B : nullptr;
+        uint8_t *dk = ro->done ? ro->done + (int64_t)k * B : nullptr;
+        TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st,
+                                                                                                   act, rk, dk));
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+"""Python mirror of the operator-level interface the reference env calls on its simulator
+(`SimulatorInterface` methods used at ref gym_env.py:117,127,142-144) plus the fused env-level entry points, over
+libtde_hip.so.  Inputs are torch tensors on a HIP device (PyTorch is only the allocator / stream owner); every call
+is asynchronous on torch's current stream.  Argument errors raise ValueError (the reference does no validation, ref
+gym_env.py:115-120; we check dtype/shape/device/contiguity because a bad pointer is fatal on a GPU).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi, _lib
+
+
+def _chk(t, dtype, n, name, device=None, optional=False):
+    if t is None:
+        if optional:
+            return None
+        raise ValueError(f"{name} is required")
+    if not torch.is_tensor(t):
+        raise ValueError(f"{name} must be a torch tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on a HIP device (there is no CPU path)")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if n is not None and t.numel() != n:
+        raise ValueError(f"{name} must have {n} elements, got {t.numel()}")
+    return t.data_ptr()
+
+
+def kinematics_step(x, y, psi, v, lr, action, present=None, dt=0.1):
+    """KinematicBicycle.step for every agent, in place (ref gym_env.py:117; model :245-247). action [...,2]."""
+    L = _lib.load()
+    n, dev = x.numel(), x.device
+    args = [_chk(t, torch.float32, n, nm, dev) for t, nm in ((x, "x"), (y, "y"), (psi, "psi"), (v, "v"), (lr, "lr"))]
+    pp = _chk(present, torch.uint8, n, "present", dev, optional=True)
+    pa = _chk(action, torch.float32, 2 * n, "action", dev)
+    _lib.check(L.tde_kinematics_step(n, *args, pp, pa, dt, _lib.current_stream(dev)), "tde_kinematics_step")
+
+
+def compute_collision(B, A, x, y, psi, length, width, present, out=None):
+    """compute_collision() > 0 per agent (ref gym_env.py:143) -> uint8 [B*A]"""
+    L = _lib.load()
+    n, dev = B * A, x.device
+    ptrs = [_chk(t, torch.float32, n, nm, dev) for t, nm in ((x, "x"), (y, "y"), (psi, "psi"), (length, "length"),
+                                                            (width, "width"))]
+    pp = _chk(present, torch.uint8, n, "present", dev)
+    if out is None:
+        out = torch.empty(n, dtype=torch.uint8, device=dev)
+    po = _chk(out, torch.uint8, n, "out", dev)
+    _lib.check(L.tde_compute_collision(B, A, *ptrs, pp, po, _lib.current_stream(dev)), "tde_compute_collision")
+    return out
+
+
+def compute_offroad(B, A, x, y, psi, length, width, present, dworld, map_of_env, threshold=0.5, out=None):
+    """compute_offroad() > 0 per agent (ref gym_env.py:142) -> uint8 [B*A]"""
+    L = _lib.load()
+    n, dev = B * A, x.device
+    ptrs = [_chk(t, torch.float32, n, nm, dev) for t, nm in ((x, "x"), (y, "y"), (psi, "psi"), (length, "length"),
+                                                            (width, "width"))]
+    pp = _chk(present, torch.uint8, n, "present", dev)
+    pm = _chk(map_of_env, torch.int32, B, "map_of_env", dev)
+    if out is None:
+        out = torch.empty(n, dtype=torch.uint8, device=dev)
+    po = _chk(out, torch.uint8, n, "out", dev)
+    _lib.check(L.tde_compute_offroad(B, A, *ptrs, pp, C.byref(dworld.struct), pm, threshold, po,
+                                     _lib.current_stream(dev)), "tde_compute_offroad")
+    return out
+
+
+def kin_collide_step(B, A, x, y, psi, v, lr, length, width, present, action, dt=0.1, out=None):
+    """fused kinematics + collision for all agents (BASELINE configs[1]); action [B*A,2]"""
+    L = _lib.load()
+    n, dev = B * A, x.device
+    ptrs = [_chk(t, torch.float32, n, nm, dev) for t, nm in ((x, "x"), (y, "y"), (psi, "psi"), (v, "v"), (lr, "lr"),
+                                                            (length, "length"), (width, "width"))]
+    pp = _chk(present, torch.uint8, n, "present", dev)
+    pa = _chk(action, torch.float32, 2 * n, "action", dev)
+    if out is None:
+        out = torch.empty(n, dtype=torch.uint8, device=dev)
+    po = _chk(out, torch.uint8, n, "out", dev)
+    _lib.check(L.tde_kin_collide_step(B, A, *ptrs, pp, pa, dt, po, _lib.current_stream(dev)), "tde_kin_collide_step")
+    return out
+
+
+def waypoint_reward(cfg, pre, post, offroad, collided, tl, wp_xy, wp_n, scn, steps, target_idx, reached,
+                    with_info=True):
+    """Reference-owned reward/termination logic (ref gym_env.py:391-437) for n envs.
+    pre/post: tuples of 4 float32 tensors [n] (x,y,psi,v).  steps/target_idx/reached int32 [n], updated in place."""
+    L = _lib.load()
+    n, dev = pre[0].numel(), pre[0].device
+    p_pre = [_chk(t, torch.float32, n, f"pre[{i}]", dev) for i, t in enumerate(pre)]
+    p_post = [_chk(t, torch.float32, n, f"post[{i}]", dev) for i, t in enumerate(post)]
+    po = _chk(offroad, torch.uint8, n, "offroad", dev)
+    pc = _chk(collided, torch.uint8, n, "collided", dev)
+    pt = _chk(tl, torch.uint8, n, "tl", dev, optional=True)
+    S, NW = wp_xy.shape[0], wp_xy.shape[1]
+    pw = _chk(wp_xy, torch.float64, S * NW * 2, "wp_xy", dev)
+    pn = _chk(wp_n, torch.int32, S, "wp_n", dev)
+    ps = _chk(scn, torch.int32, n, "scn", dev)
+    pst, pti, prc = (_chk(t, torch.int32, n, nm, dev) for t, nm in ((steps, "steps"), (target_idx, "target_idx"),
+                                                                    (reached, "reached")))
+    out = dict(reward=torch.empty(n, dtype=torch.float32, device=dev),
+               terminated=torch.empty(n, dtype=torch.uint8, device=dev),
+               truncated=torch.empty(n, dtype=torch.uint8, device=dev),
+               info=torch.empty((n, 4), dtype=torch.float64, device=dev) if with_info else None,
+               info_reached=torch.empty(n, dtype=torch.int32, device=dev) if with_info else None)
+    _lib.check(L.tde_waypoint_reward(C.byref(cfg), n, *p_pre, *p_post, po, pc, pt, pw, pn, NW, ps, pst, pti, prc,
+                                     out["reward"].data_ptr(), out["terminated"].data_ptr(),
+                                     out["truncated"].data_ptr(),
+                                     None if out["info"] is None else out["info"].data_ptr(),
+                                     None if out["info_reached"] is None else out["info_reached"].data_ptr(),
+                                     _lib.current_stream(dev)), "tde_waypoint_reward")
+    return out
+
+
+def env_reset(cfg, dworld, state, mask=None):
+    L = _lib.load()
+    pm = _chk(mask, torch.uint8, state.B, "mask", optional=True)
+    _lib.check(L.tde_env_reset(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), pm,
+                               _lib.current_stream(state.device)), "tde_env_reset")
+
+
+def env_step(cfg, dworld, state):
+    L = _lib.load()
+    _lib.check(L.tde_env_step(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct),
+                              _lib.current_stream(state.device)), "tde_env_step")
+
+
+def env_rollout(cfg, dworld, state, actions, reward=None, done=None):
+    """actions float32 [K,B,2] on device -> (reward [K,B] f32, done [K,B] u8)"""
+    L = _lib.load()
+    K, B = actions.shape[0], actions.shape[1]
+    dev = actions.device
+    if B != state.B:
+        raise ValueError(f"actions are for {B} envs, state has {state.B}")
+    pa = _chk(actions, torch.float32, K * B * 2, "actions", dev)
+    if reward is None:
+        reward = torch.empty((K, B), dtype=torch.float32, device=dev)
+    if done is None:
+        done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    ro = _abi.TdeRollout(pa, _chk(reward, torch.float32, K * B, "reward", dev), _chk(done, torch.uint8, K * B, "done", dev),
+                         K, 0)
+    _lib.check(L.tde_env_rollout(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(ro),
+                                 _lib.current_stream(dev)), "tde_env_rollout")
+    return reward, done
