@@ -86,7 +86,8 @@ typedef struct tde_map {
  * library they are handed to (device for libtde_hip, host for libtde_oracle). */
 typedef struct tde_world {
     const tde_map *maps;        /* [n_maps] */
-    const float *tri;           /* [n_tri_total][6]  ax,ay,bx,by,cx,cy */
+    const float *tri;           /* [n_tri_total][6]  ax,ay,bx,by,cx,cy (what the oracle's brute force reads) */
+    const float *tri_packed;    /* [n_tri_total][12] ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 (kernels) */
     const int32_t *cell_start;  /* [n_cells_total + 1] CSR offsets into cell_tris (global) */
     const int32_t *cell_tris;   /* candidate triangle ids (global triangle index) */
     const uint8_t *cell_class;  /* [n_cells_total] TDE_CELL_* */

@@ -46,11 +46,16 @@ TDE_DEV void sincos_f32(float xin, float &s, float &c)
 
 TDE_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-// torch.remainder(a, b): result takes the sign of b
-TDE_DEV float pymodf(float a, float b)
+// torch.remainder(a, b) for b > 0: result in [0, b).  fmodf is exact, so the two fast paths (|a| < b: a itself;
+// b <= |a| < 2b: a -+ b, exact by Sterbenz) return the very same bits as the generic call.
+TDE_DEV float pymodf_pos(float a, float b)
 {
-    float r = fmodf(a, b);
-    if (r != 0.0f && ((r < 0.0f) != (b < 0.0f))) r += b;
+    float aa = fabsf(a);
+    float r;
+    if (aa < b) r = a;
+    else if (aa < 2.0f * b) r = a - copysignf(b, a);
+    else r = fmodf(a, b);
+    if (r < 0.0f) r += b;
     return r;
 }
 
@@ -65,7 +70,7 @@ TDE_DEV void bicycle(float &x, float &y, float &psi, float &v, float lr, float a
     float sb, cb;
     sincos_f32(beta, sb, cb);
     float p1 = psi + ((v1 / lr) * sb) * dt;
-    p1 = pymodf(kPi + p1, kTwoPi) - kPi;
+    p1 = pymodf_pos(kPi + p1, kTwoPi) - kPi;
     x = x1; y = y1; psi = p1; v = v1;
 }
 
@@ -117,6 +122,33 @@ TDE_DEV float point_tri_d2(float px, float py, const float *__restrict__ t)
     return d;
 }
 
+// same distances from the packed record (ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,-,-,-): the reciprocals were
+// computed on the host in fp32 exactly like `1.0f / len2`, so no bit changes and no division is left.
+TDE_DEV float seg_d2_inv(float px, float py, float ax, float ay, float bx, float by, float inv)
+{
+    float abx = bx - ax, aby = by - ay;
+    float apx = px - ax, apy = py - ay;
+    float t = (apx * abx + apy * aby) * inv;
+    t = clampf(t, 0.0f, 1.0f);
+    float qx = apx - t * abx, qy = apy - t * aby;
+    return qx * qx + qy * qy;
+}
+
+TDE_DEV float point_tri_d2_packed(float px, float py, const float4 *__restrict__ T)
+{
+    const float4 t0 = T[0], t1 = T[1];
+    const float ax = t0.x, ay = t0.y, bx = t0.z, by = t0.w, cx = t1.x, cy = t1.y;
+    float e0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+    float e1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
+    float e2 = (ax - cx) * (py - cy) - (ay - cy) * (px - cx);
+    if ((e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) || (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f)) return 0.0f;
+    const float inv_ca = T[2].x;
+    float d = seg_d2_inv(px, py, ax, ay, bx, by, t1.z);
+    d = fminf(d, seg_d2_inv(px, py, bx, by, cx, cy, t1.w));
+    d = fminf(d, seg_d2_inv(px, py, cx, cy, ax, ay, inv_ca));
+    return d;
+}
+
 // true if the point is farther than sqrt(thr2) from every triangle of the map; uses the grid index, which is
 // conservative by GRID_MARGIN so the answer equals the oracle's brute force (world.py: build_grid_index).
 TDE_DEV bool point_offroad(const tde_world &w, const tde_map &m, float px, float py, float thr2)
@@ -129,7 +161,8 @@ TDE_DEV bool point_offroad(const tde_world &w, const tde_map &m, float px, float
     if (cls != TDE_CELL_MIXED) return cls == TDE_CELL_EMPTY;
     int k0 = w.cell_start[cell], k1 = w.cell_start[cell + 1];
     for (int k = k0; k < k1; ++k) {
-        if (point_tri_d2(px, py, w.tri + 6 * (int64_t)w.cell_tris[k]) <= thr2) return false;
+        const float4 *T = reinterpret_cast<const float4 *>(w.tri_packed) + 3 * (int64_t)w.cell_tris[k];
+        if (point_tri_d2_packed(px, py, T) <= thr2) return false;
     }
     return true;
 }
@@ -171,9 +204,10 @@ struct RewardOut {
     double psi_smooth, speed_smooth, psi_r, dist_r;
 };
 
-TDE_DEV RewardOut reward_core(const tde_config &cfg, const double *__restrict__ wp, int n_wp, float lx, float ly,
-                              float lpsi, float lv, float x, float y, float psi, float v, bool off, bool col, bool tl,
-                              int k, int &target_idx, int &reached)
+// (wtx, wty) = waypoint[target_idx], only read when target_idx < n_wp (current_target is not None, :394).
+TDE_DEV RewardOut reward_core(const tde_config &cfg, int n_wp, double wtx, double wty, float lx, float ly, float lpsi,
+                              float lv, float x, float y, float psi, float v, bool off, bool col, bool tl, int k,
+                              int &target_idx, int &reached)
 {
     RewardOut o;
     double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
@@ -184,7 +218,7 @@ TDE_DEV RewardOut reward_core(const tde_config &cfg, const double *__restrict__ 
     bool reach = false;
     int ti = target_idx;
     if (ti < n_wp) {
-        double tx = (double)x - wp[2 * ti], ty = (double)y - wp[2 * ti + 1];
+        double tx = (double)x - wtx, ty = (double)y - wty;
         reach = sqrt(tx * tx + ty * ty) < cfg.reach_radius;
     }
     double reach_r = 0.0;

@@ -30,9 +30,10 @@ struct EnvRegs {   // replicated on every lane of the env
     int scn, steps, target_idx, reached, episode;
 };
 
+template <int BLOCK>
 struct Tiles {     // LDS, one slot per lane of the workgroup
-    float x[kBlock], y[kBlock], c[kBlock], s[kBlock], len[kBlock], wid[kBlock];
-    uint8_t present[kBlock];
+    float x[BLOCK], y[BLOCK], c[BLOCK], s[BLOCK], len[BLOCK], wid[BLOCK];
+    uint8_t present[BLOCK];
 };
 
 TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
@@ -70,10 +71,8 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
     er.reached = 0;
     er.episode = (int)(ep + 1u);
     int64_t sa = (int64_t)scn * A + a;
-    ag.x = w.spawn_state[4 * sa + 0];
-    ag.y = w.spawn_state[4 * sa + 1];
-    ag.psi = w.spawn_state[4 * sa + 2];
-    ag.v = w.spawn_state[4 * sa + 3];
+    const float4 ss = reinterpret_cast<const float4 *>(w.spawn_state)[sa];
+    ag.x = ss.x; ag.y = ss.y; ag.psi = ss.z; ag.v = ss.w;
     ag.len = w.spawn_attr[3 * sa + 0];
     ag.wid = w.spawn_attr[3 * sa + 1];
     ag.lr = w.spawn_attr[3 * sa + 2];
@@ -107,43 +106,44 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
 }
 
 // heuristic NPC controller (R14 slot), mirrors tde_npc_action of the oracle; reads the PRE-step tile.
-template <int A>
-TDE_DEV void npc_action(const tde_config &cfg, const tde_world &w, const Tiles &t, int base, int i, const Agent &ag,
-                        float cp, float sp, float &acc, float &beta)
+// (tgx,tgy) is the current route waypoint, has_target = route >= 0 && route_wp < route_n[route].
+template <int A, int BLOCK>
+TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, int i, const Agent &ag, float cp,
+                        float sp, bool has_target, float tgx, float tgy, float &acc, float &beta)
 {
-    float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
-    int rn = ag.route >= 0 ? w.route_n[ag.route] : 0;
-    if (ag.route < 0 || ag.route_wp >= rn) {
+    const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
+    if (!has_target) {
         acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
         beta = 0.0f;
         return;
     }
-    const float *tg = w.route_xy + ((int64_t)ag.route * w.RW + ag.route_wp) * 2;
-    float dx = tg[0] - ag.x, dy = tg[1] - ag.y;
+    float dx = tgx - ag.x, dy = tgy - ag.y;
     float fwd = dx * cp + dy * sp;
     float lat = dy * cp - dx * sp;
     float dist = sqrtf(dx * dx + dy * dy);
     float sin_err = lat / fmaxf(dist, 1e-3f);
     if (fwd < 0.0f) beta = copysignf(smax, lat);
     else beta = clampf(cfg.npc_k_steer * sin_err, -smax, smax);
+    // A leader whose gap is beyond the distance at which the braking-distance speed exceeds v_des cannot change the
+    // result (vd = min(v_des, sqrt(amax*(gap - s0)))): skip the lane / cone tests for it.  The 1 % + 0.1 m margin
+    // dwarfs fp32 rounding, so the action keeps every bit of the oracle's full sweep.
+    const float g_far = (ag.vdes * ag.vdes / amax) * 1.01f + cfg.npc_gap_s0 + 0.1f;
     float gap = 1e30f;
 #pragma unroll 4
     for (int j = 0; j < A; ++j) {
-        int jj = base + j;
+        const int jj = base + j;
         if (j == i || !t.present[jj]) continue;
         float ex = t.x[jj] - ag.x, ey = t.y[jj] - ag.y;
         float fj = ex * cp + ey * sp;
-        float lj = ey * cp - ex * sp;
-        if (fj > 0.0f) {
+        float g = fj - 0.5f * (ag.len + t.len[jj]);
+        if (fj > 0.0f && g < g_far) {
+            float lj = ey * cp - ex * sp;
             float halfw = cfg.npc_lane_half + 0.5f * t.wid[jj];
             float al = fabsf(lj);
             bool inlane = al < halfw;
             float hd = cp * t.c[jj] + sp * t.s[jj];
             bool cone = (j < i) && (fj < cfg.npc_cone_range) && (al < halfw + cfg.npc_cone_k * fj) && (hd > -0.5f);
-            if (inlane || cone) {
-                float g = fj - 0.5f * (ag.len + t.len[jj]);
-                gap = fminf(gap, g);
-            }
+            if (inlane || cone) gap = fminf(gap, g);
         }
     }
     float vd = fminf(ag.vdes, sqrtf(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
@@ -153,22 +153,52 @@ TDE_DEV void npc_action(const tde_config &cfg, const tde_world &w, const Tiles &
 struct StepOut {
     float reward;
     uint8_t terminated, truncated, collided, offroad;
+    bool respawned;
 };
 
 // One timestep for this lane's agent slot.  WaypointSuiteEnv.step over GymEnv.step, ref gym_env.py:369-389,115-120.
 // `act_acc/act_steer` are the ego action of this lane's env (read by every lane, used by slot 0).
-// Called by all 256 lanes of the workgroup (contains barriers).
-template <int A>
-TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_state &st, Tiles &t, int e, int a,
+// Called by all BLOCK lanes of the workgroup (contains barriers).
+template <int A, int BLOCK>
+TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_state &st, Tiles<BLOCK> &t, int e, int a,
                           bool valid, Agent &ag, EnvRegs &er, float act_acc, float act_steer)
 {
     const uint32_t F = cfg.flags;
     const int tid = threadIdx.x;
     const int base = tid - a;                       // first lane of this env inside the workgroup
     const bool live = valid && ag.present;
-    StepOut out{0.0f, 0, 0, 0, 0};
+    const bool npc = (F & TDE_F_NPC) && a > 0;
+    StepOut out{0.0f, 0, 0, 0, 0, false};
 
-    // pre-step tile (positions, heading unit vectors, sizes) for the NPC controller
+    er.steps += 1;                                  // :116
+    const int k = er.steps;
+
+    // ---- issue every table read whose address is already known, ahead of the first barrier --------------------
+    bool has_target = false;
+    float tgx = 0.0f, tgy = 0.0f;
+    if (npc && live && ag.route >= 0 && ag.route_wp < w.route_n[ag.route]) {
+        const float2 tg = reinterpret_cast<const float2 *>(w.route_xy)[(int64_t)ag.route * w.RW + ag.route_wp];
+        has_target = true; tgx = tg.x; tgy = tg.y;
+    }
+    bool replayed = false;
+    float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if ((F & TDE_F_REPLAY) && a > 0 && live && ag.replay >= 0 && k < w.replay_len[ag.replay]) {   // :275-283
+        rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
+        replayed = true;
+    }
+    tde_map m;
+    if (F & TDE_F_OFFROAD) m = w.maps[w.scn_map[er.scn]];
+    int n_wp = 0;
+    double wtx = 0.0, wty = 0.0;
+    if ((F & TDE_F_REWARD) && a == 0 && valid) {
+        n_wp = w.wp_n[er.scn];
+        if (er.target_idx < n_wp) {
+            const double2 tg = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + er.target_idx];
+            wtx = tg.x; wty = tg.y;
+        }
+    }
+
+    // ---- pre-step tile (positions, heading unit vectors, sizes) for the NPC controller ------------------------
     const float lx = ag.x, ly = ag.y, lpsi = ag.psi, lv = ag.v;   // :371-375 last_x, last_y, last_psi, last_speed
     float sp = 0.0f, cp = 1.0f;
     if (F & TDE_F_NPC) {
@@ -177,26 +207,20 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
         t.len[tid] = ag.len; t.wid[tid] = ag.wid; t.present[tid] = live ? 1 : 0;
         __syncthreads();
     }
-    er.steps += 1;                                  // :116
-    const int k = er.steps;
 
     if (live) {
         float acc = 0.0f, beta = 0.0f;
         if (a == 0) { acc = act_acc; beta = act_steer; }
-        else if (F & TDE_F_NPC) npc_action<A>(cfg, w, t, base, a, ag, cp, sp, acc, beta);
+        else if (F & TDE_F_NPC) npc_action<A, BLOCK>(cfg, t, base, a, ag, cp, sp, has_target, tgx, tgy, acc, beta);
         bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);          // :117
-        if ((F & TDE_F_REPLAY) && a > 0 && ag.replay >= 0 && k < w.replay_len[ag.replay]) {   // :275-283
-            const float *r = w.replay_states + ((int64_t)ag.replay * w.RT + k) * 4;
-            ag.x = r[0]; ag.y = r[1]; ag.psi = r[2]; ag.v = r[3];
-        }
-        if ((F & TDE_F_NPC) && a > 0 && ag.route >= 0 && ag.route_wp < w.route_n[ag.route]) {
-            const float *tg = w.route_xy + ((int64_t)ag.route * w.RW + ag.route_wp) * 2;
-            float dx = tg[0] - ag.x, dy = tg[1] - ag.y;
+        if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
+        if (has_target) {
+            float dx = tgx - ag.x, dy = tgy - ag.y;
             if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) ag.route_wp += 1;
         }
     }
 
-    // post-step tile for the all-pairs collision sweep
+    // ---- post-step tile for the all-pairs collision sweep ----------------------------------------------------
     float s1, c1;
     sincos_f32(ag.psi, s1, c1);
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
@@ -206,29 +230,32 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
     __syncthreads();
     bool hit = false;
     if (live) {
+        // Overlapping convex boxes have centres closer than the sum of their circumradii; hl+hw >= circumradius, so
+        // a pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact or in fp32 arithmetic.
+        const float ri = hl + hw;
 #pragma unroll 4
         for (int j = 0; j < A; ++j) {
-            int jj = base + j;
+            const int jj = base + j;
             if (j == a || !t.present[jj]) continue;
-            hit = hit || obb_overlap(ag.x, ag.y, c1, s1, hl, hw, t.x[jj], t.y[jj], t.c[jj], t.s[jj], t.len[jj],
-                                     t.wid[jj]);
+            const float xj = t.x[jj], yj = t.y[jj], hlj = t.len[jj], hwj = t.wid[jj];
+            const float dx = xj - ag.x, dy = yj - ag.y;
+            const float rr = ri + (hlj + hwj);
+            if (dx * dx + dy * dy > (rr * rr) * 1.001f) continue;
+            hit = hit || obb_overlap(ag.x, ag.y, c1, s1, hl, hw, xj, yj, t.c[jj], t.s[jj], hlj, hwj);
         }
     }
     bool off = false;
-    if ((F & TDE_F_OFFROAD) && live) {
-        const tde_map m = w.maps[w.scn_map[er.scn]];
+    if ((F & TDE_F_OFFROAD) && live)
         off = box_offroad(w, m, ag.x, ag.y, c1, s1, hl, hw, cfg.offroad_threshold * cfg.offroad_threshold);
-    }
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
-    // reward / termination: the ego lane computes, then the env's other lanes pick the result up by shuffle
-    int done = 0;
+    // ---- reward / termination on the ego lane; the env's other lanes learn "done" from the wave ballot ----------
     if (F & TDE_F_REWARD) {
+        int done = 0;
         if (a == 0 && valid) {
-            const double *wp = w.wp_xy + (int64_t)er.scn * w.NW * 2;
-            RewardOut r = reward_core(cfg, wp, w.wp_n[er.scn], lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
-                                      false, k, er.target_idx, er.reached);
+            RewardOut r = reward_core(cfg, n_wp, wtx, wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit, false,
+                                      k, er.target_idx, er.reached);
             out.reward = r.reward;
             out.terminated = r.terminated;
             out.truncated = r.truncated;
@@ -240,13 +267,15 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
             done = (r.terminated | r.truncated) ? 1 : 0;
         }
         if (F & TDE_F_AUTORESET) {
-            // wave ballot: skip the reset path when no env of this wavefront finished
-            unsigned long long any = __ballot(done);
+            // wave ballot of the ego lanes' termination flags: the reset path is skipped by wavefronts in which no
+            // env finished; otherwise each lane looks up the bit of its env's ego lane
+            const unsigned long long any = __ballot(done);
             if (any) {
                 const int lane = tid & 63;
-                int env_done = (int)((any >> (lane - a)) & 1ull);   // bit of this env's ego lane
-                if (env_done && valid) reset_lane<A>(cfg, w, e, a, ag, er);
-                if (env_done) out.collided |= 0x80;   // marks "agent was re-spawned": static attrs must be stored
+                if (((any >> (lane - a)) & 1ull) && valid) {
+                    reset_lane<A>(cfg, w, e, a, ag, er);
+                    out.respawned = true;
+                }
             }
         }
     }
@@ -256,12 +285,13 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
 // ------------------------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------------------------
+// one launch = one timestep of every env
 template <int A>
 __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
                                                           const float *__restrict__ action, float *reward_k,
                                                           uint8_t *done_k)
 {
-    __shared__ Tiles t;
+    __shared__ Tiles<kBlock> t;
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int e = (int)(g / A), a = (int)(g % A);
     const bool valid = e < st.B;
@@ -271,15 +301,14 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     load_agent(st, gs, ag);
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
-    const float aa = action[2 * es], as = action[2 * es + 1];
-    StepOut o = step_lane<A>(cfg, w, st, t, es, a, valid, ag, er, aa, as);
+    const float2 act = reinterpret_cast<const float2 *>(action)[es];
+    StepOut o = step_lane<A, kBlock>(cfg, w, st, t, es, a, valid, ag, er, act.x, act.y);
     if (!valid) return;
-    const bool respawned = (o.collided & 0x80) != 0;
     store_agent_dynamic(st, g, ag);
-    if (respawned) store_agent_static(st, g, ag);
+    if (o.respawned) store_agent_static(st, g, ag);
     // flags of a re-spawned agent are cleared, as tde_reset_env does
-    st.collided[g] = respawned ? 0 : (o.collided & 1);
-    st.offroad[g] = respawned ? 0 : o.offroad;
+    st.collided[g] = o.respawned ? 0 : o.collided;
+    st.offroad[g] = o.respawned ? 0 : o.offroad;
     if (a == 0) {
         st.steps[e] = er.steps;
         st.target_idx[e] = er.target_idx;
@@ -287,10 +316,59 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
         st.reward[e] = o.reward;
         st.terminated[e] = o.terminated;
         st.truncated[e] = o.truncated;
-        if (respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
+        if (o.respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
         if (reward_k) reward_k[e] = o.reward;
-        if (done_k)
-            done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | ((o.collided & 1) << 3));
+        if (done_k) done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3));
+    }
+}
+
+// one launch = K timesteps of every env.  A wavefront is a workgroup (64 lanes = 64/A envs): state lives in
+// registers across the K steps, the only per-step global traffic is the ego action (prefetched one step ahead), the
+// per-step reward/done outputs and the read-only tables; wavefronts never wait for each other, so a wave that takes
+// the rare reset / mesh-boundary path does not stall the batch.
+constexpr int kWave = 64;
+template <int A>
+__global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
+{
+    __shared__ Tiles<kWave> t;
+    const int64_t g = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const int e = (int)(g / A), a = (int)(g % A);
+    const int B = st.B;
+    const bool valid = e < B;
+    const int64_t gs = valid ? g : 0;
+    const int es = valid ? e : 0;
+    Agent ag;
+    load_agent(st, gs, ag);
+    if (!valid) ag.present = false;
+    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
+    const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
+    float2 act = acts[es];
+    StepOut o{0.0f, 0, 0, 0, 0, false};
+    for (int k = 0; k < ro.K; ++k) {
+        const int kn = (k + 1 < ro.K) ? k + 1 : k;
+        const float2 act_next = acts[(int64_t)kn * B + es];      // in flight during this step
+        o = step_lane<A, kWave>(cfg, w, st, t, es, a, valid, ag, er, act.x, act.y);
+        if (valid && a == 0) {
+            if (ro.reward) ro.reward[(int64_t)k * B + e] = o.reward;
+            if (ro.done)
+                ro.done[(int64_t)k * B + e] =
+                    (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3));
+        }
+        act = act_next;
+    }
+    if (!valid) return;
+    store_agent_dynamic(st, g, ag);
+    store_agent_static(st, g, ag);
+    st.collided[g] = o.respawned ? 0 : o.collided;
+    st.offroad[g] = o.respawned ? 0 : o.offroad;
+    if (a == 0) {
+        st.scn[e] = er.scn; st.episode[e] = er.episode;
+        st.steps[e] = er.steps;
+        st.target_idx[e] = er.target_idx;
+        st.reached[e] = er.reached;
+        st.reward[e] = o.reward;
+        st.terminated[e] = o.terminated;
+        st.truncated[e] = o.truncated;
     }
 }
 
@@ -338,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
                                                          const float *__restrict__ action, float dt,
                                                          uint8_t *__restrict__ out)
 {
-    __shared__ Tiles t;
+    __shared__ Tiles<kBlock> t;
     const int tid = threadIdx.x;
     const int64_t g = (int64_t)blockIdx.x * kBlock + tid;
     const int a = (int)(g % A);
@@ -405,8 +483,11 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
     steps[i] = k;
     int ti = target_idx[i], rc = reached[i];
     const int s = scn[i];
-    RewardOut r = reward_core(cfg, wp_xy + (int64_t)s * NW * 2, wp_n[s], pre_x[i], pre_y[i], pre_psi[i], pre_v[i], x[i],
-                              y[i], psi[i], v[i], offroad[i] != 0, collided[i] != 0, tl ? tl[i] != 0 : false, k, ti, rc);
+    const int nw = wp_n[s];
+    double wtx = 0.0, wty = 0.0;
+    if (ti < nw) { wtx = wp_xy[((int64_t)s * NW + ti) * 2]; wty = wp_xy[((int64_t)s * NW + ti) * 2 + 1]; }
+    RewardOut r = reward_core(cfg, nw, wtx, wty, pre_x[i], pre_y[i], pre_psi[i], pre_v[i], x[i], y[i], psi[i], v[i],
+                              offroad[i] != 0, collided[i] != 0, tl ? tl[i] != 0 : false, k, ti, rc);
     target_idx[i] = ti;
     reached[i] = rc;
     reward[i] = r.reward;
@@ -563,15 +644,8 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (rc) return rc;
     if (!ro || !ro->actions) return bad("tde_env_rollout: rollout/actions is NULL");
     if (st->B <= 0 || ro->K <= 0) return 0;
-    const unsigned nb = blocks_for((int64_t)st->B * st->A);
-    const int64_t B = st->B;
-    for (int k = 0; k < ro->K; ++k) {
-        const float *act = ro->actions + (int64_t)k * B * 2;
-        float *rk = ro->reward ? ro->reward + (int64_t)k * B : nullptr;
-        uint8_t *dk = ro->done ? ro->done + (int64_t)k * B : nullptr;
-        TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st,
-                                                                                                   act, rk, dk));
-    }
+    const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
+    TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
 }

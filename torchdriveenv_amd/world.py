@@ -80,69 +80,106 @@ def rect_tri_dist(x0, y0, x1, y1, tri):
     return best
 
 
-def build_grid_index(tri, threshold=0.5, cell=2.0, margin=GRID_MARGIN, full_depth=3):
+def _pairs_point_tri_dist(p, tri):
+    """p [P,L,2], tri [P,3,2] -> distance [P,L] of every lattice point to its pair's triangle (0 inside)"""
+    a, b, c = tri[:, None, 0], tri[:, None, 1], tri[:, None, 2]
+
+    def cross(u, v):
+        return u[..., 0] * v[..., 1] - u[..., 1] * v[..., 0]
+
+    def seg(p, a, b):
+        ab, ap = b - a, p - a
+        l2 = (ab * ab).sum(-1)
+        t = np.clip((ap * ab).sum(-1) / np.where(l2 > 0, l2, 1.0), 0.0, 1.0)
+        q = ap - t[..., None] * ab
+        return (q * q).sum(-1)
+
+    e0, e1, e2 = cross(b - a, p - a), cross(c - b, p - b), cross(a - c, p - c)
+    inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+    d2 = np.minimum(np.minimum(seg(p, a, b), seg(p, b, c)), seg(p, c, a))
+    return np.where(inside, 0.0, np.sqrt(d2))
+
+
+def build_grid_index(tri, threshold=0.5, cell=1.0, margin=GRID_MARGIN, lattice=4):
     """Uniform-grid index over a triangle soup `tri` [n,3,2] for the offroad test.
 
-    For every cell: the list of triangles that can be within `threshold` of some point of the cell
-    (conservative by `margin`), and a class:
+    For every cell: the list of triangles that can be within `threshold` of some point of the cell, and a class:
       EMPTY  no such triangle  -> every corner falling in the cell is offroad,
-      FULL   every point of the cell is within threshold-margin of one triangle -> never offroad,
+      FULL   every point of the cell is within `threshold` of the mesh -> never offroad,
       MIXED  test the candidates.
-    The HIP kernel's mask equals the brute-force mask of the oracle because both classifications are
-    conservative by `margin` >> fp32 evaluation error at |coords| <~ 1e3 m.
+    Both classifications are conservative: distances are sampled on a (lattice+1)^2 lattice spanning the cell grown
+    by `margin` (which absorbs the fp32 cell lookup), and the distance field is 1-Lipschitz, so between lattice points
+    it moves by at most h*sqrt(2)/2; on top of that `margin` (>> fp32 evaluation error at |coords| <~ 1e3 m) is kept
+    on both decisions.  Hence the HIP kernel's mask equals the oracle's brute-force mask.
     """
     tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
     R = threshold + margin
-    lo = tri.reshape(-1, 2).min(0) - (R + cell)
-    hi = tri.reshape(-1, 2).max(0) + (R + cell)
+    lo = tri.reshape(-1, 2).min(0) - (R + 2 * cell)
+    hi = tri.reshape(-1, 2).max(0) + (R + 2 * cell)
     # the origin must be exactly representable in fp32 (the kernel subtracts it in fp32)
     ox, oy = float(np.float32(math.floor(lo[0]))), float(np.float32(math.floor(lo[1])))
     nx = int(math.ceil((hi[0] - ox) / cell))
     ny = int(math.ceil((hi[1] - oy) / cell))
-    cand = [[] for _ in range(nx * ny)]
+    h = (cell + 2 * margin) / lattice
+    slack = h * math.sqrt(2.0) / 2.0
+    # (triangle, cell) pairs from dilated triangle bounding boxes
+    pt, pc = [], []
     for k, t in enumerate(tri):
-        bx0, by0 = t.min(0) - R
-        bx1, by1 = t.max(0) + R
-        ix0 = max(0, int(math.floor((bx0 - ox) / cell)))
-        ix1 = min(nx - 1, int(math.floor((bx1 - ox) / cell)))
-        iy0 = max(0, int(math.floor((by0 - oy) / cell)))
-        iy1 = min(ny - 1, int(math.floor((by1 - oy) / cell)))
-        for iy in range(iy0, iy1 + 1):
-            for ix in range(ix0, ix1 + 1):
-                x0, y0 = ox + ix * cell, oy + iy * cell
-                if rect_tri_dist(x0, y0, x0 + cell, y0 + cell, t) <= R:
-                    cand[iy * nx + ix].append(k)
-
-    thr_in = threshold - margin
-
-    def covered(x0, y0, x1, y1, ks, depth):
-        rc = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], dtype=np.float64)
-        for k in ks:
-            if (point_tri_dist(rc, tri[k]) <= thr_in).all():
-                return True
-        if depth == 0:
-            return False
-        xm, ym = 0.5 * (x0 + x1), 0.5 * (y0 + y1)
-        return (covered(x0, y0, xm, ym, ks, depth - 1) and covered(xm, y0, x1, ym, ks, depth - 1) and
-                covered(x0, ym, xm, y1, ks, depth - 1) and covered(xm, ym, x1, y1, ks, depth - 1))
-
-    cls = np.zeros(nx * ny, dtype=np.uint8)
+        bx0, by0 = t.min(0) - (R + slack)
+        bx1, by1 = t.max(0) + (R + slack)
+        ix0 = max(0, int(math.floor((bx0 - ox) / cell)) - 1)
+        ix1 = min(nx - 1, int(math.floor((bx1 - ox) / cell)) + 1)
+        iy0 = max(0, int(math.floor((by0 - oy) / cell)) - 1)
+        iy1 = min(ny - 1, int(math.floor((by1 - oy) / cell)) + 1)
+        iy, ix = np.mgrid[iy0:iy1 + 1, ix0:ix1 + 1]
+        c = (iy * nx + ix).ravel()
+        pc.append(c)
+        pt.append(np.full(c.shape, k, dtype=np.int64))
+    pt, pc = np.concatenate(pt), np.concatenate(pc)
+    g = np.arange(lattice + 1, dtype=np.float64) * h - margin
+    lat = np.stack(np.meshgrid(g, g, indexing="xy"), -1).reshape(-1, 2)          # [L,2] offsets inside a cell
+    L = lat.shape[0]
+    dmin = np.full((nx * ny, L), np.inf)
+    keep = np.zeros(pt.shape, dtype=bool)
+    CH = 200_000
+    for s0 in range(0, len(pt), CH):
+        t_, c_ = pt[s0:s0 + CH], pc[s0:s0 + CH]
+        org = np.stack([ox + (c_ % nx) * cell, oy + (c_ // nx) * cell], -1)      # [P,2]
+        d = _pairs_point_tri_dist(org[:, None, :] + lat[None], tri[t_])          # [P,L]
+        keep[s0:s0 + CH] = d.min(1) <= R + slack
+        np.minimum.at(dmin, c_, d)
+    full = (dmin <= (threshold - margin) - slack).all(1)
+    pt, pc = pt[keep], pc[keep]
+    order = np.lexsort((pt, pc))
+    pt, pc = pt[order], pc[order]
+    has = np.zeros(nx * ny, dtype=bool)
+    has[pc] = True
+    cls = np.where(full, _abi.CELL_FULL, np.where(has, _abi.CELL_MIXED, _abi.CELL_EMPTY)).astype(np.uint8)
+    mixed_pair = cls[pc] == _abi.CELL_MIXED                                       # FULL cells need no list
+    pt, pc = pt[mixed_pair], pc[mixed_pair]
+    counts = np.bincount(pc, minlength=nx * ny)
     start = np.zeros(nx * ny + 1, dtype=np.int32)
-    flat = []
-    for c in range(nx * ny):
-        ks = cand[c]
-        if ks:
-            ix, iy = c % nx, c // nx
-            x0, y0 = ox + ix * cell, oy + iy * cell
-            # the fp32 cell lookup may be off by one ulp at a cell border: grow the rect by the margin
-            if covered(x0 - margin, y0 - margin, x0 + cell + margin, y0 + cell + margin, ks, full_depth):
-                cls[c] = _abi.CELL_FULL
-            else:
-                cls[c] = _abi.CELL_MIXED
-                flat.extend(ks)
-        start[c + 1] = len(flat)
+    start[1:] = np.cumsum(counts)
     return dict(ox=ox, oy=oy, cell=float(cell), nx=nx, ny=ny, cell_class=cls, cell_start=start,
-                cell_tris=np.asarray(flat, dtype=np.int32))
+                cell_tris=pt.astype(np.int32))
+
+
+def pack_triangles(tri32):
+    """Device-side triangle records [n,12] fp32: ax,ay,bx,by | cx,cy,inv|ab|^2,inv|bc|^2 | inv|ca|^2,0,0,0.
+    The reciprocals are computed in fp32 exactly as the oracle's `1.0f / len2` so the kernel's distances keep every
+    bit while doing no division."""
+    t = np.asarray(tri32, dtype=np.float32).reshape(-1, 3, 2)
+    out = np.zeros((len(t), 12), dtype=np.float32)
+    out[:, 0:6] = t.reshape(-1, 6)
+    one = np.float32(1.0)
+    for e, (i, j) in enumerate(((0, 1), (1, 2), (2, 0))):
+        abx = t[:, j, 0] - t[:, i, 0]
+        aby = t[:, j, 1] - t[:, i, 1]
+        len2 = abx * abx + aby * aby
+        with np.errstate(divide="ignore"):
+            inv = np.where(len2 > 0, one / np.where(len2 > 0, len2, one), np.float32(0.0)).astype(np.float32)
+        out[:, 6 + e] = inv
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -241,7 +278,7 @@ class DeviceWorld:
         self.struct = _abi.fill_world_struct(tensors, ints)
 
 
-def assemble_world(meshes, scenarios, A, threshold=0.5, cell=2.0):
+def assemble_world(meshes, scenarios, A, threshold=0.5, cell=1.0):
     """meshes: list of [n,3,2] triangle arrays; scenarios: list of dicts with keys
          map (int), waypoints [(x,y)...], start_heading (float),
          agents: list (slots 1..) of dict(state=(x,y,psi,v), attr=(L,W,lr), vdes, route=[(x,y)..] or None,
@@ -313,7 +350,8 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=2.0):
     for i, r in enumerate(replays):
         replay_states[i, :len(r)] = r
         replay_len[i] = len(r)
-    arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_start=np.concatenate(cs_all),
+    tri_cat = np.concatenate(tri_all, 0)
+    arrays = dict(maps=maps, tri=tri_cat, tri_packed=pack_triangles(tri_cat), cell_start=np.concatenate(cs_all),
                   cell_tris=np.concatenate(ct_all) if ct_all else np.zeros(0, np.int32),
                   cell_class=np.concatenate(cc_all), scn_map=np.asarray([s["map"] for s in scenarios], np.int32),
                   wp_xy=wp_xy, wp_n=wp_n,
