@@ -41,6 +41,7 @@ extern "C" {
 #define TDE_F_ALL (TDE_F_NPC | TDE_F_REPLAY | TDE_F_OFFROAD | TDE_F_REWARD | TDE_F_AUTORESET)
 
 /* cell classes of the offroad grid index (HIP side only; the oracle is brute force over triangles) */
+#define TDE_CELL_MAX_TRIS 63u
 #define TDE_CELL_EMPTY 0u  /* every point of the cell is farther than threshold from every triangle  */
 #define TDE_CELL_MIXED 1u  /* test the cell's candidate triangles                                    */
 #define TDE_CELL_FULL  2u  /* every point of the cell is within threshold of some triangle            */
@@ -87,10 +88,10 @@ typedef struct tde_map {
 typedef struct tde_world {
     const tde_map *maps;        /* [n_maps] */
     const float *tri;           /* [n_tri_total][6]  ax,ay,bx,by,cx,cy (what the oracle's brute force reads) */
-    const float *tri_packed;    /* [n_tri_total][12] ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 (kernels) */
-    const int32_t *cell_start;  /* [n_cells_total + 1] CSR offsets into cell_tris (global) */
-    const int32_t *cell_tris;   /* candidate triangle ids (global triangle index) */
-    const uint8_t *cell_class;  /* [n_cells_total] TDE_CELL_* */
+    const uint32_t *cell_word;  /* [n_cells_total] grid index (kernels): bits 0-1 TDE_CELL_*, bits 2-7 number of
+                                   candidate triangles, bits 8-31 first record of the cell in cell_tri */
+    const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
+                                   ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 */
     /* scenarios = WaypointSuite entries */
     const int32_t *scn_map;     /* [S] map id                                                        */
     const double *wp_xy;        /* [S][NW][2] ego waypoints, float64 like the YAML lists (gym_env.py:314,394) */

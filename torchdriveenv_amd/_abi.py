@@ -60,7 +60,7 @@ MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "
                       ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("_pad0", "i4")])
 assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 40
 
-WORLD_PTRS = ["maps", "tri", "tri_packed", "cell_start", "cell_tris", "cell_class", "scn_map", "wp_xy", "wp_n", "start_heading",
+WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "scn_map", "wp_xy", "wp_n", "start_heading",
               "spawn_state", "spawn_attr", "spawn_vdes", "spawn_route", "spawn_route_wp", "spawn_replay",
               "spawn_present", "route_xy", "route_n", "replay_states", "replay_len"]
 WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT"]
@@ -133,7 +133,7 @@ def default_config(**over):
 
 
 WORLD_DTYPES = {
-    "maps": MAP_DTYPE, "tri": np.float32, "tri_packed": np.float32, "cell_start": np.int32, "cell_tris": np.int32, "cell_class": np.uint8,
+    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32,
     "scn_map": np.int32, "wp_xy": np.float64, "wp_n": np.int32, "start_heading": np.float32,
     "spawn_state": np.float32, "spawn_attr": np.float32, "spawn_vdes": np.float32, "spawn_route": np.int32,
     "spawn_route_wp": np.int32, "spawn_replay": np.int32, "spawn_present": np.uint8, "route_xy": np.float32,

@@ -149,33 +149,68 @@ TDE_DEV float point_tri_d2_packed(float px, float py, const float4 *__restrict__
     return d;
 }
 
-// true if the point is farther than sqrt(thr2) from every triangle of the map; uses the grid index, which is
-// conservative by GRID_MARGIN so the answer equals the oracle's brute force (world.py: build_grid_index).
-TDE_DEV bool point_offroad(const tde_world &w, const tde_map &m, float px, float py, float thr2)
+// ---- offroad through the grid index ---------------------------------------------------------------------------------
+// cell word: bits 0-1 class (EMPTY / MIXED / FULL), bits 2-7 number of candidate triangles, bits 8-31 first record in
+// w.cell_tri.  The classification is conservative by GRID_MARGIN (world.py: build_grid_index), so the mask equals the
+// oracle's brute force over every triangle.
+TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, float py)
 {
     float fx = (px - m.ox) * m.inv_cell;
     float fy = (py - m.oy) * m.inv_cell;
-    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)m.nx && fy < (float)m.ny)) return true;
-    int cell = m.cell_base + (int)fy * m.nx + (int)fx;
-    uint32_t cls = w.cell_class[cell];
-    if (cls != TDE_CELL_MIXED) return cls == TDE_CELL_EMPTY;
-    int k0 = w.cell_start[cell], k1 = w.cell_start[cell + 1];
-    for (int k = k0; k < k1; ++k) {
-        const float4 *T = reinterpret_cast<const float4 *>(w.tri_packed) + 3 * (int64_t)w.cell_tris[k];
-        if (point_tri_d2_packed(px, py, T) <= thr2) return false;
-    }
-    return true;
+    bool in = fx >= 0.0f && fy >= 0.0f && fx < (float)m.nx && fy < (float)m.ny;
+    int cell = in ? m.cell_base + (int)fy * m.nx + (int)fx : m.cell_base;
+    uint32_t word = w.cell_word[cell];
+    return in ? word : (uint32_t)TDE_CELL_EMPTY;
 }
 
-// compute_offroad() > 0 for one box: any of the corners FL, FR, RR, RL off the drivable surface.
-TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, float x, float y, float c, float s, float hl, float hw,
-                         float thr2)
+#define TDE_SEL4(i, a0, a1, a2, a3) ((i) == 0 ? (a0) : (i) == 1 ? (a1) : (i) == 2 ? (a2) : (a3))
+
+// compute_offroad() > 0 for one box: any of the corners FL, FR, RR, RL farther than sqrt(thr2) from the mesh.
+// All four cell words are fetched at once; corners in MIXED cells are then resolved by a per-lane state machine that
+// performs ONE triangle test per loop trip, so a wavefront iterates max-over-lanes(sum of tests) times instead of
+// sum-over-corners(max-over-lanes).  Must be called by all lanes of the wavefront (`live` masks the idle ones).
+TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float x, float y, float c, float s, float hl,
+                         float hw, float thr2)
 {
-    float lx = hl * c, ly = hl * s, wx = hw * s, wy = hw * c;
-    bool off = point_offroad(w, m, (x + lx) - wx, (y + ly) + wy, thr2);
-    off = off || point_offroad(w, m, (x + lx) + wx, (y + ly) - wy, thr2);
-    off = off || point_offroad(w, m, (x - lx) + wx, (y - ly) - wy, thr2);
-    off = off || point_offroad(w, m, (x - lx) - wx, (y - ly) + wy, thr2);
+    const float lx = hl * c, ly = hl * s, wx = hw * s, wy = hw * c;
+    const float px0 = (x + lx) - wx, py0 = (y + ly) + wy;
+    const float px1 = (x + lx) + wx, py1 = (y + ly) - wy;
+    const float px2 = (x - lx) + wx, py2 = (y - ly) - wy;
+    const float px3 = (x - lx) - wx, py3 = (y - ly) + wy;
+    uint32_t w0 = TDE_CELL_FULL, w1 = TDE_CELL_FULL, w2 = TDE_CELL_FULL, w3 = TDE_CELL_FULL;
+    if (live) {
+        w0 = cell_lookup(w, m, px0, py0);
+        w1 = cell_lookup(w, m, px1, py1);
+        w2 = cell_lookup(w, m, px2, py2);
+        w3 = cell_lookup(w, m, px3, py3);
+    }
+    bool off = ((w0 & 3u) == TDE_CELL_EMPTY) || ((w1 & 3u) == TDE_CELL_EMPTY) || ((w2 & 3u) == TDE_CELL_EMPTY) ||
+               ((w3 & 3u) == TDE_CELL_EMPTY);
+    uint32_t pending = off ? 0u
+                           : (((w0 & 3u) == TDE_CELL_MIXED) ? 1u : 0u) | (((w1 & 3u) == TDE_CELL_MIXED) ? 2u : 0u) |
+                                 (((w2 & 3u) == TDE_CELL_MIXED) ? 4u : 0u) | (((w3 & 3u) == TDE_CELL_MIXED) ? 8u : 0u);
+    bool work = false;
+    uint32_t cur = 0, end = 0;
+    float qx = 0.0f, qy = 0.0f;
+    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri);
+    for (;;) {
+        if (!work && pending) {
+            const int ci = __ffs((int)pending) - 1;
+            pending &= pending - 1u;
+            const uint32_t wd = TDE_SEL4(ci, w0, w1, w2, w3);
+            cur = wd >> 8;
+            end = cur + ((wd >> 2) & 63u);
+            qx = TDE_SEL4(ci, px0, px1, px2, px3);
+            qy = TDE_SEL4(ci, py0, py1, py2, py3);
+            work = true;
+        }
+        if (!__ballot(work)) break;
+        if (work) {
+            const float d2 = point_tri_d2_packed(qx, qy, recs + 3 * (size_t)cur);
+            if (d2 <= thr2) work = false;                     // this corner is on the road
+            else if (++cur == end) { off = true; work = false; pending = 0u; }
+        }
+    }
     return off;
 }
 
@@ -198,6 +233,25 @@ TDE_DEV double u01(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 
 // R6/R7/R8/R11/R12 — the reference-owned reward/termination logic, ref gym_env.py:391-437 (see the oracle's
 // tde_reward_core for the line-by-line citations).  float64 math on fp32 state, as the reference's Python does.
+// sqrt(s) > r and sqrt(s) >= r for s >= 0, r >= 0 in float64, deciding on s against r*r whenever s is farther than
+// 1e-12 (relative) from the boundary, i.e. farther than any rounding of the correctly rounded square root could
+// matter; the exact sqrt is only evaluated inside that sliver.  Same truth value as the reference's
+// `math.dist(..) > cutoff` / `math.dist(..) < 3` (gym_env.py:394,402) at a fraction of the instructions.
+TDE_DEV bool sqrt_gt(double s, double r)
+{
+    const double r2 = r * r;
+    if (s > r2 * (1.0 + 1e-12)) return true;
+    if (s < r2 * (1.0 - 1e-12)) return false;
+    return sqrt(s) > r;
+}
+TDE_DEV bool sqrt_ge(double s, double r)
+{
+    const double r2 = r * r;
+    if (s > r2 * (1.0 + 1e-12)) return true;
+    if (s < r2 * (1.0 - 1e-12)) return false;
+    return sqrt(s) >= r;
+}
+
 struct RewardOut {
     float reward;
     uint8_t terminated, truncated;
@@ -211,15 +265,14 @@ TDE_DEV RewardOut reward_core(const tde_config &cfg, int n_wp, double wtx, doubl
 {
     RewardOut o;
     double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
-    double d = sqrt(ddx * ddx + ddy * ddy);
-    o.dist_r = (d > cfg.distance_cutoff) ? cfg.distance_bonus : 0.0;
+    o.dist_r = sqrt_gt(ddx * ddx + ddy * ddy, cfg.distance_cutoff) ? cfg.distance_bonus : 0.0;
     float dpsi = psi - lpsi;
     o.psi_r = (1.0 - cos((double)dpsi)) * (-cfg.heading_penalty);
     bool reach = false;
     int ti = target_idx;
     if (ti < n_wp) {
         double tx = (double)x - wtx, ty = (double)y - wty;
-        reach = sqrt(tx * tx + ty * ty) < cfg.reach_radius;
+        reach = !sqrt_ge(tx * tx + ty * ty, cfg.reach_radius);
     }
     double reach_r = 0.0;
     if (reach) { reach_r = cfg.waypoint_bonus; reached += 1; }

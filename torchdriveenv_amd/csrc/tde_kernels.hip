@@ -30,11 +30,23 @@ struct EnvRegs {   // replicated on every lane of the env
     int scn, steps, target_idx, reached, episode;
 };
 
+// LDS tile, one slot per lane of the workgroup, two 16-B records per agent so that a sweep reads them with
+// ds_read_b128 (all lanes of an env read the same address: broadcast, no bank conflict):
+//     a = (x, y, length, width)          b = (cos psi, sin psi, hl + hw, -)
+// The tile always holds the CURRENT state of every slot: it is written once per step, after the integration, and
+// serves that step's collision sweep and the next step's NPC controller (whose "pre-step" state it is).
+// An absent slot is parked at x = y = kFar, which fails every cheap sweep test by itself (no present flag to read).
 template <int BLOCK>
-struct Tiles {     // LDS, one slot per lane of the workgroup
-    float x[BLOCK], y[BLOCK], c[BLOCK], s[BLOCK], len[BLOCK], wid[BLOCK];
-    uint8_t present[BLOCK];
+struct Tiles {
+    float4 a[BLOCK];
+    float4 b[BLOCK];
 };
+constexpr float kFar = 1e18f;
+
+template <int A> struct MaskOf { using type = uint32_t; };
+template <> struct MaskOf<64> { using type = unsigned long long; };
+TDE_DEV int lowest_bit(uint32_t m) { return __ffs((int)m) - 1; }
+TDE_DEV int lowest_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
 
 TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
 {
@@ -54,6 +66,50 @@ TDE_DEV void store_agent_static(const tde_state &st, int64_t g, const Agent &a)
 {
     st.len[g] = a.len; st.wid[g] = a.wid; st.lr[g] = a.lr; st.vdes[g] = a.vdes;
     st.route[g] = a.route; st.replay[g] = a.replay; st.present[g] = a.present ? 1 : 0;
+}
+
+// Table entries that only change on rare events (route waypoint switch, ego waypoint advance, reset) are kept in
+// registers across the steps of a rollout instead of being re-fetched through a dependent-load chain every step.
+struct Ctx {
+    tde_map m;                 // map of the env's scenario
+    float tgx, tgy;            // NPC: current route waypoint
+    int route_n, replay_len;   // NPC: length of its route / replay row (0 if none)
+    float g_far;               // NPC: gap beyond which a leader cannot cap the speed (see npc_action)
+    double wtx, wty;           // ego: current target waypoint
+    int n_wp;                  // ego: number of waypoints of the scenario
+};
+
+TDE_DEV void load_route_target(const tde_world &w, const Agent &ag, Ctx &cx)
+{
+    if (ag.route >= 0 && ag.route_wp < cx.route_n) {
+        const float2 tg = reinterpret_cast<const float2 *>(w.route_xy)[(int64_t)ag.route * w.RW + ag.route_wp];
+        cx.tgx = tg.x; cx.tgy = tg.y;
+    }
+}
+
+TDE_DEV void load_ego_target(const tde_world &w, const EnvRegs &er, Ctx &cx)
+{
+    if (er.target_idx < cx.n_wp) {
+        const double2 tg = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + er.target_idx];
+        cx.wtx = tg.x; cx.wty = tg.y;
+    }
+}
+
+TDE_DEV void load_ctx(const tde_config &cfg, const tde_world &w, int a, const Agent &ag, const EnvRegs &er, Ctx &cx)
+{
+    const uint32_t F = cfg.flags;
+    cx.tgx = cx.tgy = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0;
+    // A leader whose gap is beyond the distance at which the braking-distance speed exceeds v_des cannot change the
+    // controller's result (vd = min(v_des, sqrt(amax*(gap - s0)))).  The 1 % + 0.1 m margin dwarfs fp32 rounding.
+    cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
+    if (F & TDE_F_OFFROAD) cx.m = w.maps[w.scn_map[er.scn]];
+    if (a > 0) {
+        if ((F & TDE_F_NPC) && ag.route >= 0) { cx.route_n = w.route_n[ag.route]; load_route_target(w, ag, cx); }
+        if ((F & TDE_F_REPLAY) && ag.replay >= 0) cx.replay_len = w.replay_len[ag.replay];
+    } else if (F & TDE_F_REWARD) {
+        cx.n_wp = w.wp_n[er.scn];
+        load_ego_target(w, er, cx);
+    }
 }
 
 // WaypointSuiteEnv.reset + set_start_pos + build_simulator's initial tensors for one env (ref gym_env.py:319-367,
@@ -105,48 +161,62 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
     }
 }
 
-// heuristic NPC controller (R14 slot), mirrors tde_npc_action of the oracle; reads the PRE-step tile.
-// (tgx,tgy) is the current route waypoint, has_target = route >= 0 && route_wp < route_n[route].
+// heuristic NPC controller (R14 slot), mirrors tde_npc_action of the oracle; reads the tile (= pre-step state).
+// Two phases: a branch-free sweep over the A slots with the cheap tests that almost every slot fails (ahead of me?
+// close enough to cap my speed? inside the widest corridor?) builds a candidate bit mask; the exact lane / yield-cone
+// tests then run only for the set bits, every lane walking its own list (the wavefront iterates
+// max-over-lanes(popcount) times, usually 0-2).  Skipped slots cannot change the result, so the action keeps every
+// bit of the oracle's full sweep.
 template <int A, int BLOCK>
 TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, int i, const Agent &ag, float cp,
-                        float sp, bool has_target, float tgx, float tgy, float &acc, float &beta)
+                        float sp, bool has_target, float tgx, float tgy, float g_far, float &acc, float &beta)
 {
+    using mask_t = typename MaskOf<A>::type;
     const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
+    mask_t cand = 0;
+    if (has_target) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float4 pj = t.a[base + j];
+            const float ex = pj.x - ag.x, ey = pj.y - ag.y;
+            const float fj = ex * cp + ey * sp;
+            const float lj = ey * cp - ex * sp;
+            const float g = fj - 0.5f * (ag.len + pj.z);
+            // widest corridor = the yield cone (it contains the lane corridor for fj > 0)
+            const bool wide = fabsf(lj) < (cfg.npc_lane_half + 0.5f * pj.w) + cfg.npc_cone_k * fj;
+            cand |= ((fj > 0.0f) & (g < g_far) & wide) ? (mask_t)1 << j : (mask_t)0;
+        }
+        cand &= ~((mask_t)1 << i);
+    }
+    float gap = 1e30f;
+    while (__ballot(cand != 0)) {
+        if (cand) {
+            const int j = lowest_bit(cand);
+            cand &= cand - 1;
+            const float4 pj = t.a[base + j], qj = t.b[base + j];
+            const float ex = pj.x - ag.x, ey = pj.y - ag.y;
+            const float fj = ex * cp + ey * sp;
+            const float lj = ey * cp - ex * sp;
+            const float halfw = cfg.npc_lane_half + 0.5f * pj.w;
+            const float al = fabsf(lj);
+            const bool inlane = al < halfw;
+            const float hd = cp * qj.x + sp * qj.y;
+            const bool cone = (j < i) && (fj < cfg.npc_cone_range) && (al < halfw + cfg.npc_cone_k * fj) && (hd > -0.5f);
+            if (inlane || cone) gap = fminf(gap, fj - 0.5f * (ag.len + pj.z));
+        }
+    }
     if (!has_target) {
         acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
         beta = 0.0f;
         return;
     }
-    float dx = tgx - ag.x, dy = tgy - ag.y;
-    float fwd = dx * cp + dy * sp;
-    float lat = dy * cp - dx * sp;
-    float dist = sqrtf(dx * dx + dy * dy);
-    float sin_err = lat / fmaxf(dist, 1e-3f);
-    if (fwd < 0.0f) beta = copysignf(smax, lat);
-    else beta = clampf(cfg.npc_k_steer * sin_err, -smax, smax);
-    // A leader whose gap is beyond the distance at which the braking-distance speed exceeds v_des cannot change the
-    // result (vd = min(v_des, sqrt(amax*(gap - s0)))): skip the lane / cone tests for it.  The 1 % + 0.1 m margin
-    // dwarfs fp32 rounding, so the action keeps every bit of the oracle's full sweep.
-    const float g_far = (ag.vdes * ag.vdes / amax) * 1.01f + cfg.npc_gap_s0 + 0.1f;
-    float gap = 1e30f;
-#pragma unroll 4
-    for (int j = 0; j < A; ++j) {
-        const int jj = base + j;
-        if (j == i || !t.present[jj]) continue;
-        float ex = t.x[jj] - ag.x, ey = t.y[jj] - ag.y;
-        float fj = ex * cp + ey * sp;
-        float g = fj - 0.5f * (ag.len + t.len[jj]);
-        if (fj > 0.0f && g < g_far) {
-            float lj = ey * cp - ex * sp;
-            float halfw = cfg.npc_lane_half + 0.5f * t.wid[jj];
-            float al = fabsf(lj);
-            bool inlane = al < halfw;
-            float hd = cp * t.c[jj] + sp * t.s[jj];
-            bool cone = (j < i) && (fj < cfg.npc_cone_range) && (al < halfw + cfg.npc_cone_k * fj) && (hd > -0.5f);
-            if (inlane || cone) gap = fminf(gap, g);
-        }
-    }
-    float vd = fminf(ag.vdes, sqrtf(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
+    const float dx = tgx - ag.x, dy = tgy - ag.y;
+    const float fwd = dx * cp + dy * sp;
+    const float lat = dy * cp - dx * sp;
+    const float dist = sqrtf(dx * dx + dy * dy);
+    const float sin_err = lat / fmaxf(dist, 1e-3f);
+    beta = (fwd < 0.0f) ? copysignf(smax, lat) : clampf(cfg.npc_k_steer * sin_err, -smax, smax);
+    const float vd = fminf(ag.vdes, sqrtf(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
     acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
 }
 
@@ -156,97 +226,95 @@ struct StepOut {
     bool respawned;
 };
 
+TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s)
+{
+    ta = live ? make_float4(ag.x, ag.y, ag.len, ag.wid) : make_float4(kFar, kFar, 0.0f, 0.0f);
+    tb = make_float4(c, s, 0.5f * ag.len + 0.5f * ag.wid, 0.0f);
+}
+
 // One timestep for this lane's agent slot.  WaypointSuiteEnv.step over GymEnv.step, ref gym_env.py:369-389,115-120.
-// `act_acc/act_steer` are the ego action of this lane's env (read by every lane, used by slot 0).
-// Called by all BLOCK lanes of the workgroup (contains barriers).
+// On entry the tile holds the current state of every slot and (c0, s0) = (cos psi, sin psi) of this slot; both are
+// kept up to date on exit.  `act_acc/act_steer` are the ego action of this lane's env (used by slot 0).
+// Called by all BLOCK lanes of the workgroup, converged (contains barriers and wave ballots).
 template <int A, int BLOCK>
 TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_state &st, Tiles<BLOCK> &t, int e, int a,
-                          bool valid, Agent &ag, EnvRegs &er, float act_acc, float act_steer)
+                          bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0, float &s0, float act_acc,
+                          float act_steer)
 {
+    using mask_t = typename MaskOf<A>::type;
     const uint32_t F = cfg.flags;
     const int tid = threadIdx.x;
     const int base = tid - a;                       // first lane of this env inside the workgroup
-    const bool live = valid && ag.present;
-    const bool npc = (F & TDE_F_NPC) && a > 0;
+    bool live = valid && ag.present;
+    const bool npc = (F & TDE_F_NPC) && a > 0 && live;
     StepOut out{0.0f, 0, 0, 0, 0, false};
 
     er.steps += 1;                                  // :116
     const int k = er.steps;
 
-    // ---- issue every table read whose address is already known, ahead of the first barrier --------------------
-    bool has_target = false;
-    float tgx = 0.0f, tgy = 0.0f;
-    if (npc && live && ag.route >= 0 && ag.route_wp < w.route_n[ag.route]) {
-        const float2 tg = reinterpret_cast<const float2 *>(w.route_xy)[(int64_t)ag.route * w.RW + ag.route_wp];
-        has_target = true; tgx = tg.x; tgy = tg.y;
-    }
-    bool replayed = false;
+    // replayed agents take their recorded state at time k (:275-283); issue the read ahead of the sweeps
+    const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
     float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if ((F & TDE_F_REPLAY) && a > 0 && live && ag.replay >= 0 && k < w.replay_len[ag.replay]) {   // :275-283
-        rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-        replayed = true;
-    }
-    tde_map m;
-    if (F & TDE_F_OFFROAD) m = w.maps[w.scn_map[er.scn]];
-    int n_wp = 0;
-    double wtx = 0.0, wty = 0.0;
-    if ((F & TDE_F_REWARD) && a == 0 && valid) {
-        n_wp = w.wp_n[er.scn];
-        if (er.target_idx < n_wp) {
-            const double2 tg = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + er.target_idx];
-            wtx = tg.x; wty = tg.y;
-        }
-    }
+    if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
 
-    // ---- pre-step tile (positions, heading unit vectors, sizes) for the NPC controller ------------------------
+    // ---- actions: ego from outside, NPC slots from the controller (reads the tile = pre-step state) ---------------
     const float lx = ag.x, ly = ag.y, lpsi = ag.psi, lv = ag.v;   // :371-375 last_x, last_y, last_psi, last_speed
-    float sp = 0.0f, cp = 1.0f;
+    const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+    float acc = 0.0f, beta = 0.0f;
+    if (a == 0) { acc = act_acc; beta = act_steer; }
     if (F & TDE_F_NPC) {
-        sincos_f32(ag.psi, sp, cp);
-        t.x[tid] = ag.x; t.y[tid] = ag.y; t.c[tid] = cp; t.s[tid] = sp;
-        t.len[tid] = ag.len; t.wid[tid] = ag.wid; t.present[tid] = live ? 1 : 0;
-        __syncthreads();
+        float na, nb;
+        npc_action<A, BLOCK>(cfg, t, base, a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, na, nb);
+        if (npc) { acc = na; beta = nb; }
     }
 
     if (live) {
-        float acc = 0.0f, beta = 0.0f;
-        if (a == 0) { acc = act_acc; beta = act_steer; }
-        else if (F & TDE_F_NPC) npc_action<A, BLOCK>(cfg, t, base, a, ag, cp, sp, has_target, tgx, tgy, acc, beta);
         bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);          // :117
         if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
-        if (has_target) {
-            float dx = tgx - ag.x, dy = tgy - ag.y;
-            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) ag.route_wp += 1;
-        }
+    }
+    bool switched = false;
+    if (has_target) {
+        const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
+        if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { ag.route_wp += 1; switched = true; }
     }
 
-    // ---- post-step tile for the all-pairs collision sweep ----------------------------------------------------
-    float s1, c1;
-    sincos_f32(ag.psi, s1, c1);
+    // ---- post-step tile: collision sweep now, NPC controller next step -----------------------------------------
+    sincos_f32(ag.psi, s0, c0);
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
-    if (F & TDE_F_NPC) __syncthreads();             // every lane is done reading the pre-step tile
-    t.x[tid] = ag.x; t.y[tid] = ag.y; t.c[tid] = c1; t.s[tid] = s1; t.len[tid] = hl; t.wid[tid] = hw;
-    t.present[tid] = live ? 1 : 0;
+    const float ri = hl + hw;
+    __syncthreads();                                // every lane is done reading the pre-step tile
+    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0);
     __syncthreads();
-    bool hit = false;
+    // Overlapping convex boxes have centres closer than the sum of their circumradii; hl+hw >= circumradius, so a
+    // pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact or in fp32 arithmetic.  Phase 1 marks the
+    // pairs inside that radius (branch-free), phase 2 runs the 4-axis SAT test on the marked ones only.
+    mask_t cand = 0;
     if (live) {
-        // Overlapping convex boxes have centres closer than the sum of their circumradii; hl+hw >= circumradius, so
-        // a pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact or in fp32 arithmetic.
-        const float ri = hl + hw;
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < A; ++j) {
-            const int jj = base + j;
-            if (j == a || !t.present[jj]) continue;
-            const float xj = t.x[jj], yj = t.y[jj], hlj = t.len[jj], hwj = t.wid[jj];
-            const float dx = xj - ag.x, dy = yj - ag.y;
-            const float rr = ri + (hlj + hwj);
-            if (dx * dx + dy * dy > (rr * rr) * 1.001f) continue;
-            hit = hit || obb_overlap(ag.x, ag.y, c1, s1, hl, hw, xj, yj, t.c[jj], t.s[jj], hlj, hwj);
+            const float4 pj = t.a[base + j];
+            const float rj = t.b[base + j].z;
+            const float dx = pj.x - ag.x, dy = pj.y - ag.y;
+            const float rr = ri + rj;
+            cand |= (dx * dx + dy * dy <= (rr * rr) * 1.001f) ? (mask_t)1 << j : (mask_t)0;
+        }
+        cand &= ~((mask_t)1 << a);
+    }
+    bool hit = false;
+    while (__ballot(cand != 0)) {
+        if (cand) {
+            const int j = lowest_bit(cand);
+            cand &= cand - 1;
+            const float4 pj = t.a[base + j], qj = t.b[base + j];
+            hit = hit || obb_overlap(ag.x, ag.y, c0, s0, hl, hw, pj.x, pj.y, qj.x, qj.y, 0.5f * pj.z, 0.5f * pj.w);
         }
     }
+    // the next route waypoint is fetched while the offroad test runs
+    if (switched) load_route_target(w, ag, cx);
+
     bool off = false;
-    if ((F & TDE_F_OFFROAD) && live)
-        off = box_offroad(w, m, ag.x, ag.y, c1, s1, hl, hw, cfg.offroad_threshold * cfg.offroad_threshold);
+    if (F & TDE_F_OFFROAD)
+        off = box_offroad(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, cfg.offroad_threshold * cfg.offroad_threshold);
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
@@ -254,8 +322,9 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
     if (F & TDE_F_REWARD) {
         int done = 0;
         if (a == 0 && valid) {
-            RewardOut r = reward_core(cfg, n_wp, wtx, wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit, false,
-                                      k, er.target_idx, er.reached);
+            const int ti0 = er.target_idx;
+            RewardOut r = reward_core(cfg, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
+                                      false, k, er.target_idx, er.reached);
             out.reward = r.reward;
             out.terminated = r.terminated;
             out.truncated = r.truncated;
@@ -265,6 +334,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
             }
             if (st.info_reached) st.info_reached[e] = er.reached;
             done = (r.terminated | r.truncated) ? 1 : 0;
+            if (er.target_idx != ti0 && !done) load_ego_target(w, er, cx);
         }
         if (F & TDE_F_AUTORESET) {
             // wave ballot of the ego lanes' termination flags: the reset path is skipped by wavefronts in which no
@@ -274,11 +344,16 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
                 const int lane = tid & 63;
                 if (((any >> (lane - a)) & 1ull) && valid) {
                     reset_lane<A>(cfg, w, e, a, ag, er);
+                    load_ctx(cfg, w, a, ag, er, cx);
                     out.respawned = true;
-                }
+                    live = ag.present;
+                    sincos_f32(ag.psi, s0, c0);
+                    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0);   // only this lane reads its slot until
+                }                                                            // the next step's first barrier...
             }
         }
     }
+    __syncthreads();                                // ...so the tile is consistent for the next step's controller
     return out;
 }
 
@@ -301,8 +376,14 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     load_agent(st, gs, ag);
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
+    Ctx cx;
+    load_ctx(cfg, w, a, ag, er, cx);
     const float2 act = reinterpret_cast<const float2 *>(action)[es];
-    StepOut o = step_lane<A, kBlock>(cfg, w, st, t, es, a, valid, ag, er, act.x, act.y);
+    float c0, s0;
+    sincos_f32(ag.psi, s0, c0);
+    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0);
+    __syncthreads();
+    StepOut o = step_lane<A, kBlock>(cfg, w, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
     if (!valid) return;
     store_agent_dynamic(st, g, ag);
     if (o.respawned) store_agent_static(st, g, ag);
@@ -322,10 +403,10 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     }
 }
 
-// one launch = K timesteps of every env.  A wavefront is a workgroup (64 lanes = 64/A envs): state lives in
-// registers across the K steps, the only per-step global traffic is the ego action (prefetched one step ahead), the
-// per-step reward/done outputs and the read-only tables; wavefronts never wait for each other, so a wave that takes
-// the rare reset / mesh-boundary path does not stall the batch.
+// one launch = K timesteps of every env.  A wavefront is a workgroup (64 lanes = 64/A envs): state and the cached
+// table entries (Ctx) live in registers across the K steps, the only per-step global traffic is the ego action
+// (prefetched one step ahead), the per-step reward/done outputs and the grid-index reads; wavefronts never wait for
+// each other, so a wave that takes the rare reset / mesh-boundary path does not stall the batch.
 constexpr int kWave = 64;
 template <int A>
 __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
@@ -341,13 +422,19 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     load_agent(st, gs, ag);
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
+    Ctx cx;
+    load_ctx(cfg, w, a, ag, er, cx);
     const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
     float2 act = acts[es];
+    float c0, s0;
+    sincos_f32(ag.psi, s0, c0);
+    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0);
+    __syncthreads();
     StepOut o{0.0f, 0, 0, 0, 0, false};
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
         const float2 act_next = acts[(int64_t)kn * B + es];      // in flight during this step
-        o = step_lane<A, kWave>(cfg, w, st, t, es, a, valid, ag, er, act.x, act.y);
+        o = step_lane<A, kWave>(cfg, w, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
         if (valid && a == 0) {
             if (ro.reward) ro.reward[(int64_t)k * B + e] = o.reward;
             if (ro.done)
@@ -433,17 +520,31 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
     float s1, c1;
     sincos_f32(P, s1, c1);
     const float hl = 0.5f * len[gs], hw = 0.5f * wid[gs];
-    t.x[tid] = X; t.y[tid] = Y; t.c[tid] = c1; t.s[tid] = s1; t.len[tid] = hl; t.wid[tid] = hw;
-    t.present[tid] = live ? 1 : 0;
+    const float ri = hl + hw;
+    using mask_t = typename MaskOf<A>::type;
+    t.a[tid] = live ? make_float4(X, Y, len[gs], wid[gs]) : make_float4(kFar, kFar, 0.0f, 0.0f);
+    t.b[tid] = make_float4(c1, s1, ri, 0.0f);
     __syncthreads();
-    bool hit = false;
     const int base = tid - a;
+    mask_t cand = 0;
     if (live) {
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < A; ++j) {
-            int jj = base + j;
-            if (j == a || !t.present[jj]) continue;
-            hit = hit || obb_overlap(X, Y, c1, s1, hl, hw, t.x[jj], t.y[jj], t.c[jj], t.s[jj], t.len[jj], t.wid[jj]);
+            const float4 pj = t.a[base + j];
+            const float rj = t.b[base + j].z;
+            const float dx = pj.x - X, dy = pj.y - Y;
+            const float rr = ri + rj;
+            cand |= (dx * dx + dy * dy <= (rr * rr) * 1.001f) ? (mask_t)1 << j : (mask_t)0;
+        }
+        cand &= ~((mask_t)1 << a);
+    }
+    bool hit = false;
+    while (__ballot(cand != 0)) {
+        if (cand) {
+            const int j = lowest_bit(cand);
+            cand &= cand - 1;
+            const float4 pj = t.a[base + j], qj = t.b[base + j];
+            hit = hit || obb_overlap(X, Y, c1, s1, hl, hw, pj.x, pj.y, qj.x, qj.y, 0.5f * pj.z, 0.5f * pj.w);
         }
     }
     if (valid) out[g] = hit ? 1 : 0;
@@ -457,15 +558,14 @@ __global__ __launch_bounds__(kBlock) void offroad_kernel(int B, int A, const flo
                                                          uint8_t *__restrict__ out)
 {
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= (int64_t)B * A) return;
-    uint8_t off = 0;
-    if (present[g]) {
-        float s1, c1;
-        sincos_f32(psi[g], s1, c1);
-        const tde_map m = w.maps[map_of_env[g / A]];
-        off = box_offroad(w, m, x[g], y[g], c1, s1, 0.5f * len[g], 0.5f * wid[g], thr * thr) ? 1 : 0;
-    }
-    out[g] = off;
+    const bool valid = g < (int64_t)B * A;
+    const int64_t gs = valid ? g : 0;
+    const bool live = valid && present[gs] != 0;
+    float s1, c1;
+    sincos_f32(psi[gs], s1, c1);
+    const tde_map m = w.maps[map_of_env[gs / A]];
+    const bool off = box_offroad(w, m, live, x[gs], y[gs], c1, s1, 0.5f * len[gs], 0.5f * wid[gs], thr * thr);
+    if (valid) out[g] = off ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void reward_kernel(

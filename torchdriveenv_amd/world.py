@@ -23,63 +23,6 @@ GRID_MARGIN = 0.05
 # ------------------------------------------------------------------------------------------------
 # geometry helpers (float64, host, build time only)
 # ------------------------------------------------------------------------------------------------
-def _seg_d2(p, a, b):
-    """squared distance of points p[...,2] to segment a-b"""
-    ab = b - a
-    ap = p - a
-    l2 = float(ab @ ab)
-    t = np.clip((ap @ ab) / l2, 0.0, 1.0) if l2 > 0 else np.zeros(p.shape[:-1])
-    q = ap - t[..., None] * ab
-    return (q * q).sum(-1)
-
-
-def point_tri_dist(p, tri):
-    """distance of points p[...,2] to triangle tri[3,2] (0 inside)"""
-    a, b, c = tri
-
-    def cross(u, v):
-        return u[..., 0] * v[..., 1] - u[..., 1] * v[..., 0]
-
-    e0 = cross(b - a, p - a)
-    e1 = cross(c - b, p - b)
-    e2 = cross(a - c, p - c)
-    inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
-    d2 = np.minimum(np.minimum(_seg_d2(p, a, b), _seg_d2(p, b, c)), _seg_d2(p, c, a))
-    return np.where(inside, 0.0, np.sqrt(d2))
-
-
-def _seg_seg_dist(p1, q1, p2, q2):
-    """min distance between segments p1q1 and p2q2 (2-D), scalar float64"""
-
-    def orient(a, b, c):
-        return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
-
-    o1, o2 = orient(p1, q1, p2), orient(p1, q1, q2)
-    o3, o4 = orient(p2, q2, p1), orient(p2, q2, q1)
-    if (o1 * o2 < 0) and (o3 * o4 < 0):
-        return 0.0
-    d = min(_seg_d2(p1[None], p2, q2)[0], _seg_d2(q1[None], p2, q2)[0], _seg_d2(p2[None], p1, q1)[0],
-            _seg_d2(q2[None], p1, q1)[0])
-    return math.sqrt(d)
-
-
-def rect_tri_dist(x0, y0, x1, y1, tri):
-    """distance between the axis-aligned rectangle [x0,x1]x[y0,y1] and a triangle (0 if they touch)"""
-    rc = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]], dtype=np.float64)
-    # a rect corner inside the triangle or a triangle vertex inside the rect -> 0
-    if (point_tri_dist(rc, tri) == 0.0).any():
-        return 0.0
-    if ((tri[:, 0] >= x0) & (tri[:, 0] <= x1) & (tri[:, 1] >= y0) & (tri[:, 1] <= y1)).any():
-        return 0.0
-    best = math.inf
-    for i in range(4):
-        for j in range(3):
-            best = min(best, _seg_seg_dist(rc[i], rc[(i + 1) % 4], tri[j], tri[(j + 1) % 3]))
-            if best == 0.0:
-                return 0.0
-    return best
-
-
 def _pairs_point_tri_dist(p, tri):
     """p [P,L,2], tri [P,3,2] -> distance [P,L] of every lattice point to its pair's triangle (0 inside)"""
     a, b, c = tri[:, None, 0], tri[:, None, 1], tri[:, None, 2]
@@ -287,8 +230,8 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=1.0):
     """
     assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
     maps = np.zeros(len(meshes), dtype=_abi.MAP_DTYPE)
-    tri_all, cs_all, ct_all, cc_all = [], [np.zeros(1, np.int32)], [], []
-    tri_base = cell_base = ct_base = 0
+    tri_all, word_all, rec_all = [], [], []
+    tri_base = cell_base = rec_base = 0
     for m, tri in enumerate(meshes):
         tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
         # the kernels see fp32 vertices: index the fp32-rounded mesh
@@ -296,13 +239,18 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=1.0):
         g = build_grid_index(tri32.astype(np.float64), threshold, cell)
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
                    tri_base, len(tri), 0)
+        packed = pack_triangles(tri32)
+        counts = np.diff(g["cell_start"]).astype(np.int64)
+        assert counts.max(initial=0) <= 63, "more than 63 candidate triangles in one grid cell: use a smaller cell"
+        start = g["cell_start"][:-1].astype(np.int64) + rec_base
+        assert start.max(initial=0) < (1 << 24), "grid index too large for the 24-bit record offset"
+        word_all.append((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
+                         (start.astype(np.uint32) << 8)).astype(np.uint32))
+        rec_all.append(packed[g["cell_tris"]])          # per-cell copies: one dependent load less in the kernel
         tri_all.append(tri32.reshape(-1, 6))
-        cs_all.append(g["cell_start"][1:] + ct_base)
-        ct_all.append(g["cell_tris"] + tri_base)
-        cc_all.append(g["cell_class"])
         tri_base += len(tri)
         cell_base += g["nx"] * g["ny"]
-        ct_base += len(g["cell_tris"])
+        rec_base += len(g["cell_tris"])
     S = len(scenarios)
     NW = max(2, max(len(s["waypoints"]) for s in scenarios))
     wp_xy = np.zeros((S, NW, 2), np.float64)
@@ -350,10 +298,9 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=1.0):
     for i, r in enumerate(replays):
         replay_states[i, :len(r)] = r
         replay_len[i] = len(r)
-    tri_cat = np.concatenate(tri_all, 0)
-    arrays = dict(maps=maps, tri=tri_cat, tri_packed=pack_triangles(tri_cat), cell_start=np.concatenate(cs_all),
-                  cell_tris=np.concatenate(ct_all) if ct_all else np.zeros(0, np.int32),
-                  cell_class=np.concatenate(cc_all), scn_map=np.asarray([s["map"] for s in scenarios], np.int32),
+    rec_cat = np.concatenate(rec_all, 0) if rec_base else np.zeros((1, 12), np.float32)
+    arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_word=np.concatenate(word_all), cell_tri=rec_cat,
+                  scn_map=np.asarray([s["map"] for s in scenarios], np.int32),
                   wp_xy=wp_xy, wp_n=wp_n,
                   start_heading=np.asarray([s["start_heading"] for s in scenarios], np.float32),
                   spawn_state=spawn_state, spawn_attr=spawn_attr, spawn_vdes=spawn_vdes, spawn_route=spawn_route,
