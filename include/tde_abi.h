@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 1
+#define TDE_ABI_VERSION 2
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -83,6 +83,28 @@ typedef struct tde_map {
     int32_t _pad0;
 } tde_map;
 
+/* One (scenario, slot) spawn record: everything a slot gets at reset, 64 B so that the kernels read it with four
+ * 16-B loads.  Slot 0 (ego) only uses len/wid/lr: its pose is sampled (gym_env.py:351-367). */
+typedef struct tde_spawn {
+    float x, y, psi, v;         /* initial state (scenario agent_states, gym_env.py:222-224) */
+    float len, wid, lr, vdes;   /* attrs (gym_env.py:225-226) + NPC desired speed */
+    int32_t route;              /* NPC route id or -1 */
+    int32_t route_wp;           /* first route waypoint the NPC heads for */
+    int32_t route_n;            /* number of waypoints of that route (0 if none) */
+    int32_t replay;             /* replay row id or -1 (car_sequence_suite, gym_env.py:275-283) */
+    int32_t replay_len;         /* T of that replay row (0 if none) */
+    int32_t present;            /* slot used by this scenario */
+    int32_t _pad0, _pad1;
+} tde_spawn;
+
+/* One WaypointSuite entry (gym_env.py:63-68). */
+typedef struct tde_scenario {
+    int32_t map;                /* map id */
+    int32_t wp_n;               /* number of ego waypoints */
+    float start_heading;        /* stand-in for find_lanelet_directions at the start point (gym_env.py:359) */
+    int32_t _pad0;
+} tde_scenario;
+
 /* Static world tables, replicated per GPU.  All pointers live in the address space of the
  * library they are handed to (device for libtde_hip, host for libtde_oracle). */
 typedef struct tde_world {
@@ -92,22 +114,11 @@ typedef struct tde_world {
                                    candidate triangles, bits 8-31 first record of the cell in cell_tri */
     const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
                                    ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 */
-    /* scenarios = WaypointSuite entries */
-    const int32_t *scn_map;     /* [S] map id                                                        */
+    const tde_scenario *scn;    /* [S] */
     const double *wp_xy;        /* [S][NW][2] ego waypoints, float64 like the YAML lists (gym_env.py:314,394) */
-    const int32_t *wp_n;        /* [S] number of waypoints                                           */
-    const float *start_heading; /* [S] stand-in for find_lanelet_directions at the start point (gym_env.py:359) */
-    const float *spawn_state;   /* [S][A][4] initial (x,y,psi,v); slot 0 is overwritten by the sampled ego start */
-    const float *spawn_attr;    /* [S][A][3] (length,width,rear_axis_offset) */
-    const float *spawn_vdes;    /* [S][A] NPC desired speed */
-    const int32_t *spawn_route; /* [S][A] NPC route id or -1 */
-    const int32_t *spawn_route_wp; /* [S][A] first route waypoint index the NPC heads for */
-    const int32_t *spawn_replay;/* [S][A] replay row id or -1 (car_sequence_suite, gym_env.py:275-283) */
-    const uint8_t *spawn_present;/* [S][A] */
+    const tde_spawn *spawn;     /* [S][A] */
     const float *route_xy;      /* [R][RW][2] NPC route polylines */
-    const int32_t *route_n;     /* [R] */
     const float *replay_states; /* [P][RT][4] */
-    const int32_t *replay_len;  /* [P] T of each replay row */
     int32_t n_maps, n_scn, NW, A;
     int32_t n_routes, RW, n_replay, RT;
 } tde_world;
@@ -118,9 +129,7 @@ typedef struct tde_state {
     float *x, *y, *psi, *v;     /* kinematic state (R4) */
     float *len, *wid, *lr;      /* attrs */
     float *vdes;                /* NPC desired speed */
-    int32_t *route;             /* NPC route id or -1 */
-    int32_t *route_wp;          /* NPC current route waypoint index */
-    int32_t *replay;            /* replay row id or -1 */
+    int32_t *route_wp;          /* NPC current route waypoint index (route / replay ids come from the spawn record) */
     uint8_t *present;           /* present mask (gym_env.py:262-263: all ones in the reference) */
     uint8_t *collided;          /* out: compute_collision() > 0 per agent (R9) */
     uint8_t *offroad;           /* out: compute_offroad() > 0 per agent (R10) */

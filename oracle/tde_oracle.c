@@ -308,7 +308,7 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
         tde_oracle_philox(cfg->seed, (uint32_t)e, ep, 2u + b, 0x7DEu, rn);
         for (int k = 0; k < 4; ++k) acc += tde_u01(rn[k]);
     }
-    double psi0 = (double)w->start_heading[scn] + (acc - 6.0) * 0.1;
+    double psi0 = (double)w->scn[scn].start_heading + (acc - 6.0) * 0.1;
 
     st->scn[e] = scn;
     st->steps[e] = 0;          /* :339 */
@@ -318,19 +318,17 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
 
     for (int32_t a = 0; a < A; ++a) {
         int64_t g = (int64_t)e * A + a;
-        int64_t sa = (int64_t)scn * A + a;
-        st->x[g] = w->spawn_state[4 * sa + 0];
-        st->y[g] = w->spawn_state[4 * sa + 1];
-        st->psi[g] = w->spawn_state[4 * sa + 2];
-        st->v[g] = w->spawn_state[4 * sa + 3];
-        st->len[g] = w->spawn_attr[3 * sa + 0];
-        st->wid[g] = w->spawn_attr[3 * sa + 1];
-        st->lr[g] = w->spawn_attr[3 * sa + 2];
-        st->vdes[g] = w->spawn_vdes[sa];
-        st->route[g] = w->spawn_route[sa];
-        st->route_wp[g] = w->spawn_route_wp[sa];
-        st->replay[g] = w->spawn_replay[sa];
-        st->present[g] = w->spawn_present[sa];
+        const tde_spawn *sp = &w->spawn[(int64_t)scn * A + a];
+        st->x[g] = sp->x;
+        st->y[g] = sp->y;
+        st->psi[g] = sp->psi;
+        st->v[g] = sp->v;
+        st->len[g] = sp->len;
+        st->wid[g] = sp->wid;
+        st->lr[g] = sp->lr;
+        st->vdes[g] = sp->vdes;
+        st->route_wp[g] = sp->route_wp;
+        st->present[g] = (uint8_t)(sp->present != 0);
         st->collided[g] = 0;
         st->offroad[g] = 0;
     }
@@ -341,8 +339,6 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
     st->psi[g0] = (float)psi0;
     st->v[g0] = (float)speed;
     st->present[g0] = 1;
-    st->route[g0] = -1;
-    st->replay[g0] = -1;
     st->vdes[g0] = 0.0f;
     if (cfg->flags & TDE_F_EGO_ONLY_ATTRS) {
         /* :194-196 */
@@ -366,11 +362,11 @@ TDE_EXPORT int tde_oracle_env_reset(const tde_config *cfg, const tde_world *w, t
 /* ------------------------------------------------------------------------------------------------ */
 static void tde_npc_action(const tde_config *cfg, const tde_world *w, int32_t A, int32_t i, const float *x,
                            const float *y, const float *c, const float *s, const float *v, const float *len,
-                           const float *wid, const uint8_t *present, float vdes, int32_t route, int32_t wpi,
-                           float *acc_out, float *beta_out)
+                           const float *wid, const uint8_t *present, float vdes, int32_t route, int32_t route_n,
+                           int32_t wpi, float *acc_out, float *beta_out)
 {
     float amax = cfg->npc_max_accel, smax = cfg->npc_max_steer;
-    if (route < 0 || wpi >= w->route_n[route]) {
+    if (route < 0 || wpi >= route_n) {
         /* no route (left): brake to a stop, wheels straight */
         *acc_out = tde_clampf(cfg->npc_k_speed * (0.0f - v[i]), -amax, amax);
         *beta_out = 0.0f;
@@ -511,18 +507,19 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
     /* :117 simulator.step(action): ego takes the external action; NPC slots take the controller's action
      * (or coast with zero action, as NPCWrapper does before teleporting), then replayed agents are
      * overwritten with their recorded state at time k. */
+    const tde_spawn *spawn = w->spawn + (int64_t)st->scn[e] * A;   /* route / replay ids of the env's slots */
     for (int32_t a = 0; a < A; ++a) {
         if (!present[a]) continue;
         float acc = 0.0f, beta = 0.0f;
         if (a == 0) { acc = a_acc; beta = a_steer; }
         else if (F & TDE_F_NPC)
-            tde_npc_action(cfg, w, A, a, px, py, pc, ps, pv, L, W, present, st->vdes[g0 + a], st->route[g0 + a],
-                           st->route_wp[g0 + a], &acc, &beta);
+            tde_npc_action(cfg, w, A, a, px, py, pc, ps, pv, L, W, present, st->vdes[g0 + a], spawn[a].route,
+                           spawn[a].route_n, st->route_wp[g0 + a], &acc, &beta);
         float nx = px[a], ny = py[a], np_ = pp[a], nv = pv[a];
         tde_oracle_bicycle(&nx, &ny, &np_, &nv, LR[a], acc, beta, cfg->dt);
         if ((F & TDE_F_REPLAY) && a > 0) {
-            int32_t row = st->replay[g0 + a];
-            if (row >= 0 && k < w->replay_len[row]) {
+            int32_t row = spawn[a].replay;
+            if (row >= 0 && k < spawn[a].replay_len) {
                 const float *r = w->replay_states + ((int64_t)row * w->RT + k) * 4;
                 nx = r[0]; ny = r[1]; np_ = r[2]; nv = r[3];
             }
@@ -530,8 +527,8 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
         X[a] = nx; Y[a] = ny; P[a] = np_; V[a] = nv;
         /* NPC route waypoint switch, judged on the post-step position */
         if ((F & TDE_F_NPC) && a > 0) {
-            int32_t route = st->route[g0 + a], wpi = st->route_wp[g0 + a];
-            if (route >= 0 && wpi < w->route_n[route]) {
+            int32_t route = spawn[a].route, wpi = st->route_wp[g0 + a];
+            if (route >= 0 && wpi < spawn[a].route_n) {
                 const float *t = w->route_xy + ((int64_t)route * w->RW + wpi) * 2;
                 float dx = t[0] - nx, dy = t[1] - ny;
                 if (dx * dx + dy * dy < cfg->npc_reach * cfg->npc_reach) st->route_wp[g0 + a] = wpi + 1;
@@ -555,7 +552,7 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
     }
     if (F & TDE_F_OFFROAD) {
         float thr2 = cfg->offroad_threshold * cfg->offroad_threshold;
-        int32_t map_id = w->scn_map[st->scn[e]];
+        int32_t map_id = w->scn[st->scn[e]].map;
         for (int32_t a = 0; a < A; ++a)
             st->offroad[g0 + a] = present[a] ? (uint8_t)tde_agent_offroad(w, map_id, X[a], Y[a], c[a], s[a],
                                                                           0.5f * L[a], 0.5f * W[a], thr2)
@@ -568,7 +565,7 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
         const int32_t scn = st->scn[e];
         const float pre[4] = {px[0], py[0], pp[0], pv[0]};
         const float post[4] = {X[0], Y[0], P[0], V[0]};
-        tde_reward_core(cfg, w->wp_xy + (int64_t)scn * w->NW * 2, w->wp_n[scn], pre, post, st->offroad[g0],
+        tde_reward_core(cfg, w->wp_xy + (int64_t)scn * w->NW * 2, w->scn[scn].wp_n, pre, post, st->offroad[g0],
                         st->collided[g0], 0, k, &st->target_idx[e], &st->reached[e], &out.reward, &out.terminated,
                         &out.truncated, st->info ? st->info + 4 * (int64_t)e : NULL,
                         st->info_reached ? &st->info_reached[e] : NULL);

@@ -97,7 +97,7 @@ def test_offroad_mask_bit_exact(small_world):
     rng = np.random.default_rng(5)
     B, A = 600, 16
     n = B * A
-    scn_map = w.arrays["scn_map"]
+    scn_map = w.map_of_scn()
     map_of_env = rng.integers(0, w.ints["n_maps"], B).astype(np.int32)
     # poses along the roads with lateral offsets that straddle the road edge (3.5 m) +- threshold
     s = rng.uniform(-130, 130, n)

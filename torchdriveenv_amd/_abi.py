@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 1
+TDE_ABI_VERSION = 2
 TDE_MAX_AGENTS = 64
 
 F_NPC = 1 << 0
@@ -60,9 +60,13 @@ MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "
                       ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("_pad0", "i4")])
 assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 40
 
-WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "scn_map", "wp_xy", "wp_n", "start_heading",
-              "spawn_state", "spawn_attr", "spawn_vdes", "spawn_route", "spawn_route_wp", "spawn_replay",
-              "spawn_present", "route_xy", "route_n", "replay_states", "replay_len"]
+SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("len", "f4"), ("wid", "f4"),
+                        ("lr", "f4"), ("vdes", "f4"), ("route", "i4"), ("route_wp", "i4"), ("route_n", "i4"),
+                        ("replay", "i4"), ("replay_len", "i4"), ("present", "i4"), ("_pad0", "i4"), ("_pad1", "i4")])
+SCN_DTYPE = np.dtype([("map", "i4"), ("wp_n", "i4"), ("start_heading", "f4"), ("_pad0", "i4")])
+assert SPAWN_DTYPE.itemsize == 64 and SCN_DTYPE.itemsize == 16
+
+WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "scn", "wp_xy", "spawn", "route_xy", "replay_states"]
 WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT"]
 
 
@@ -71,7 +75,7 @@ class TdeWorld(C.Structure):
 
 
 STATE_AGENT_F32 = ["x", "y", "psi", "v", "len", "wid", "lr", "vdes"]
-STATE_AGENT_I32 = ["route", "route_wp", "replay"]
+STATE_AGENT_I32 = ["route_wp"]
 STATE_AGENT_U8 = ["present", "collided", "offroad"]
 STATE_ENV_I32 = ["scn", "steps", "target_idx", "reached", "episode"]
 STATE_PTRS = (STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8 + STATE_ENV_I32 +
@@ -133,11 +137,8 @@ def default_config(**over):
 
 
 WORLD_DTYPES = {
-    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32,
-    "scn_map": np.int32, "wp_xy": np.float64, "wp_n": np.int32, "start_heading": np.float32,
-    "spawn_state": np.float32, "spawn_attr": np.float32, "spawn_vdes": np.float32, "spawn_route": np.int32,
-    "spawn_route_wp": np.int32, "spawn_replay": np.int32, "spawn_present": np.uint8, "route_xy": np.float32,
-    "route_n": np.int32, "replay_states": np.float32, "replay_len": np.int32,
+    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "scn": SCN_DTYPE,
+    "wp_xy": np.float64, "spawn": SPAWN_DTYPE, "route_xy": np.float32, "replay_states": np.float32,
 }
 
 STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n in STATE_AGENT_I32},

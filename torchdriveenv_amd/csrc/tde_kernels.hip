@@ -52,7 +52,8 @@ TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
 {
     a.x = st.x[g]; a.y = st.y[g]; a.psi = st.psi[g]; a.v = st.v[g];
     a.len = st.len[g]; a.wid = st.wid[g]; a.lr = st.lr[g]; a.vdes = st.vdes[g];
-    a.route = st.route[g]; a.route_wp = st.route_wp[g]; a.replay = st.replay[g];
+    a.route_wp = st.route_wp[g];
+    a.route = -1; a.replay = -1;        // filled from the spawn record by load_ctx
     a.present = st.present[g] != 0;
 }
 
@@ -65,7 +66,7 @@ TDE_DEV void store_agent_dynamic(const tde_state &st, int64_t g, const Agent &a)
 TDE_DEV void store_agent_static(const tde_state &st, int64_t g, const Agent &a)
 {
     st.len[g] = a.len; st.wid[g] = a.wid; st.lr[g] = a.lr; st.vdes[g] = a.vdes;
-    st.route[g] = a.route; st.replay[g] = a.replay; st.present[g] = a.present ? 1 : 0;
+    st.present[g] = a.present ? 1 : 0;
 }
 
 // Table entries that only change on rare events (route waypoint switch, ego waypoint advance, reset) are kept in
@@ -95,19 +96,27 @@ TDE_DEV void load_ego_target(const tde_world &w, const EnvRegs &er, Ctx &cx)
     }
 }
 
-TDE_DEV void load_ctx(const tde_config &cfg, const tde_world &w, int a, const Agent &ag, const EnvRegs &er, Ctx &cx)
+// sp4 = the slot's spawn record as four 16-B words (tde_spawn), or nullptr to fetch it here
+template <int A>
+TDE_DEV void load_ctx(const tde_config &cfg, const tde_world &w, int a, Agent &ag, const EnvRegs &er, Ctx &cx)
 {
     const uint32_t F = cfg.flags;
     cx.tgx = cx.tgy = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0;
     // A leader whose gap is beyond the distance at which the braking-distance speed exceeds v_des cannot change the
     // controller's result (vd = min(v_des, sqrt(amax*(gap - s0)))).  The 1 % + 0.1 m margin dwarfs fp32 rounding.
     cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
-    if (F & TDE_F_OFFROAD) cx.m = w.maps[w.scn_map[er.scn]];
+    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[er.scn];          // map, wp_n, start_heading, pad
+    if (F & TDE_F_OFFROAD) cx.m = w.maps[sc.x];
+    ag.route = -1; ag.replay = -1;
     if (a > 0) {
-        if ((F & TDE_F_NPC) && ag.route >= 0) { cx.route_n = w.route_n[ag.route]; load_route_target(w, ag, cx); }
-        if ((F & TDE_F_REPLAY) && ag.replay >= 0) cx.replay_len = w.replay_len[ag.replay];
+        if (F & (TDE_F_NPC | TDE_F_REPLAY)) {
+            const int4 *rec = reinterpret_cast<const int4 *>(w.spawn + ((int64_t)er.scn * A + a));
+            const int4 r2 = rec[2];                                              // route, route_wp, route_n, replay
+            if (F & TDE_F_NPC) { ag.route = r2.x; cx.route_n = r2.z; load_route_target(w, ag, cx); }
+            if (F & TDE_F_REPLAY) { ag.replay = r2.w; cx.replay_len = rec[3].x; }
+        }
     } else if (F & TDE_F_REWARD) {
-        cx.n_wp = w.wp_n[er.scn];
+        cx.n_wp = sc.y;
         load_ego_target(w, er, cx);
     }
 }
@@ -126,17 +135,13 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
     er.target_idx = 1;
     er.reached = 0;
     er.episode = (int)(ep + 1u);
-    int64_t sa = (int64_t)scn * A + a;
-    const float4 ss = reinterpret_cast<const float4 *>(w.spawn_state)[sa];
+    const float4 *rec = reinterpret_cast<const float4 *>(w.spawn + ((int64_t)scn * A + a));
+    const float4 ss = rec[0], sa = rec[1];
+    const int4 si = reinterpret_cast<const int4 *>(rec)[2], sj = reinterpret_cast<const int4 *>(rec)[3];
     ag.x = ss.x; ag.y = ss.y; ag.psi = ss.z; ag.v = ss.w;
-    ag.len = w.spawn_attr[3 * sa + 0];
-    ag.wid = w.spawn_attr[3 * sa + 1];
-    ag.lr = w.spawn_attr[3 * sa + 2];
-    ag.vdes = w.spawn_vdes[sa];
-    ag.route = w.spawn_route[sa];
-    ag.route_wp = w.spawn_route_wp[sa];
-    ag.replay = w.spawn_replay[sa];
-    ag.present = w.spawn_present[sa] != 0;
+    ag.len = sa.x; ag.wid = sa.y; ag.lr = sa.z; ag.vdes = sa.w;
+    ag.route = si.x; ag.route_wp = si.y; ag.replay = si.w;
+    ag.present = sj.y != 0;
     if (a == 0) {
         uint32_t r1[4], rn[4];
         philox(cfg.seed, (uint32_t)e, ep, 1u, 0x7DEu, r1);
@@ -150,7 +155,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
             philox(cfg.seed, (uint32_t)e, ep, 2u + b, 0x7DEu, rn);
             for (int k = 0; k < 4; ++k) acc += u01(rn[k]);
         }
-        double psi0 = (double)w.start_heading[scn] + (acc - 6.0) * 0.1;
+        double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (acc - 6.0) * 0.1;
         ag.x = (float)sx; ag.y = (float)sy; ag.psi = (float)psi0; ag.v = (float)speed;
         ag.present = true; ag.route = -1; ag.replay = -1; ag.vdes = 0.0f;
         if (cfg.flags & TDE_F_EGO_ONLY_ATTRS) {
@@ -344,7 +349,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
                 const int lane = tid & 63;
                 if (((any >> (lane - a)) & 1ull) && valid) {
                     reset_lane<A>(cfg, w, e, a, ag, er);
-                    load_ctx(cfg, w, a, ag, er, cx);
+                    load_ctx<A>(cfg, w, a, ag, er, cx);
                     out.respawned = true;
                     live = ag.present;
                     sincos_f32(ag.psi, s0, c0);
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
     Ctx cx;
-    load_ctx(cfg, w, a, ag, er, cx);
+    load_ctx<A>(cfg, w, a, ag, er, cx);
     const float2 act = reinterpret_cast<const float2 *>(action)[es];
     float c0, s0;
     sincos_f32(ag.psi, s0, c0);
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
     Ctx cx;
-    load_ctx(cfg, w, a, ag, er, cx);
+    load_ctx<A>(cfg, w, a, ag, er, cx);
     const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
     float2 act = acts[es];
     float c0, s0;

@@ -29,8 +29,6 @@ class EnvState:
         if not with_info:
             self.arrays["info"] = None
             self.arrays["info_reached"] = None
-        self.arrays["route"][...] = -1
-        self.arrays["replay"][...] = -1
         self.struct = _abi.fill_state_struct(self.arrays, B, A)
 
     def __getitem__(self, k):

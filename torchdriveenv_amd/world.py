@@ -203,15 +203,15 @@ class World:
 
         tens = {}
         for k, a in self.arrays.items():
-            if a.dtype == _abi.MAP_DTYPE:
-                t = torch.from_numpy(a.view(np.uint8).copy())
+            if a.dtype.names is not None:      # record arrays travel as raw bytes
+                t = torch.from_numpy(a.reshape(-1).view(np.uint8).copy())
             else:
                 t = torch.from_numpy(a.copy())
             tens[k] = t.to(device)
         return DeviceWorld(tens, self.ints)
 
     def map_of_scn(self):
-        return self.arrays["scn_map"]
+        return np.ascontiguousarray(self.arrays["scn"]["map"])
 
 
 class DeviceWorld:
@@ -254,57 +254,44 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=1.0):
     S = len(scenarios)
     NW = max(2, max(len(s["waypoints"]) for s in scenarios))
     wp_xy = np.zeros((S, NW, 2), np.float64)
-    wp_n = np.zeros(S, np.int32)
-    spawn_state = np.zeros((S, A, 4), np.float32)
-    spawn_attr = np.ones((S, A, 3), np.float32)
-    spawn_vdes = np.zeros((S, A), np.float32)
-    spawn_route = -np.ones((S, A), np.int32)
-    spawn_route_wp = np.zeros((S, A), np.int32)
-    spawn_replay = -np.ones((S, A), np.int32)
-    spawn_present = np.zeros((S, A), np.uint8)
+    scn = np.zeros(S, _abi.SCN_DTYPE)
+    spawn = np.zeros((S, A), _abi.SPAWN_DTYPE)
+    spawn["len"], spawn["wid"], spawn["lr"] = 1.0, 1.0, 1.0
+    spawn["route"], spawn["replay"] = -1, -1
     routes, replays = [], []
     for si, s in enumerate(scenarios):
         w = np.asarray(s["waypoints"], np.float64)
         assert len(w) >= 2, "a scenario needs at least two waypoints (gym_env.py:353-354)"
         wp_xy[si, :len(w)] = w
-        wp_n[si] = len(w)
-        spawn_present[si, 0] = 1
-        spawn_attr[si, 0] = s.get("ego_attr", (5.0, 2.0, 1.9))
-        spawn_state[si, 0] = (w[0, 0], w[0, 1], s["start_heading"], 0.0)
+        scn[si] = (s["map"], len(w), s["start_heading"], 0)
+        ego = spawn[si, 0]
+        ego["present"] = 1
+        ego["len"], ego["wid"], ego["lr"] = s.get("ego_attr", (5.0, 2.0, 1.9))
+        ego["x"], ego["y"], ego["psi"] = w[0, 0], w[0, 1], s["start_heading"]
         ags = s.get("agents", [])
         assert len(ags) <= A - 1, f"scenario {si} has {len(ags)} NPCs but only {A - 1} NPC slots"
         for k, ag in enumerate(ags):
-            a = k + 1
-            spawn_present[si, a] = 1
-            spawn_state[si, a] = ag["state"]
-            spawn_attr[si, a] = ag["attr"]
-            spawn_vdes[si, a] = ag.get("vdes", ag["state"][3])
+            r = spawn[si, k + 1]
+            r["present"] = 1
+            r["x"], r["y"], r["psi"], r["v"] = ag["state"]
+            r["len"], r["wid"], r["lr"] = ag["attr"]
+            r["vdes"] = ag.get("vdes", ag["state"][3])
             if ag.get("route") is not None and len(ag["route"]) > 0:
-                spawn_route[si, a] = len(routes)
+                r["route"], r["route_n"], r["route_wp"] = len(routes), len(ag["route"]), ag.get("route_wp", 0)
                 routes.append(np.asarray(ag["route"], np.float32))
-                spawn_route_wp[si, a] = ag.get("route_wp", 0)
             if ag.get("replay") is not None and len(ag["replay"]) > 0:
-                spawn_replay[si, a] = len(replays)
+                r["replay"], r["replay_len"] = len(replays), len(ag["replay"])
                 replays.append(np.asarray(ag["replay"], np.float32))
     RW = max([len(r) for r in routes], default=1)
     route_xy = np.zeros((max(1, len(routes)), RW, 2), np.float32)
-    route_n = np.zeros(max(1, len(routes)), np.int32)
     for i, r in enumerate(routes):
         route_xy[i, :len(r)] = r
-        route_n[i] = len(r)
     RT = max([len(r) for r in replays], default=1)
     replay_states = np.zeros((max(1, len(replays)), RT, 4), np.float32)
-    replay_len = np.zeros(max(1, len(replays)), np.int32)
     for i, r in enumerate(replays):
         replay_states[i, :len(r)] = r
-        replay_len[i] = len(r)
     rec_cat = np.concatenate(rec_all, 0) if rec_base else np.zeros((1, 12), np.float32)
     arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_word=np.concatenate(word_all), cell_tri=rec_cat,
-                  scn_map=np.asarray([s["map"] for s in scenarios], np.int32),
-                  wp_xy=wp_xy, wp_n=wp_n,
-                  start_heading=np.asarray([s["start_heading"] for s in scenarios], np.float32),
-                  spawn_state=spawn_state, spawn_attr=spawn_attr, spawn_vdes=spawn_vdes, spawn_route=spawn_route,
-                  spawn_route_wp=spawn_route_wp, spawn_replay=spawn_replay, spawn_present=spawn_present,
-                  route_xy=route_xy, route_n=route_n, replay_states=replay_states, replay_len=replay_len)
+                  scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states)
     ints = dict(n_maps=len(meshes), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT)
     return World(arrays, ints)
