@@ -158,12 +158,24 @@ typedef struct tde_rollout {
     int32_t _pad0;
 } tde_rollout;
 
-/* ego-centred birdview raster (R13; BASELINE config 5) */
+/* ego-centred, ego-aligned birdview raster (R13; BASELINE config 5).  Observation space (3,64,64) uint8, channels
+ * first (gym_env.py:95).  Pixel (row r, col c) is sampled at its centre; the ego sits at the image centre with its
+ * heading pointing up: forward = (H/2 - (r+.5))*res, left = (W/2 - (c+.5))*res, res = fov / W.
+ * Layers, painted in this order: background, drivable surface (= within offroad_threshold of the mesh, the same
+ * predicate the offroad infraction uses), remaining ego waypoints (discs), NPC boxes, ego box.
+ * With n_stack > 1 the output holds the last n_stack frames, oldest first (SB3 VecFrameStack(channels_order="first"),
+ * examples/rl_training.py:160): older frames are shifted down and the new frame is written last. */
+#define TDE_RGB_BACKGROUND 255, 255, 255
+#define TDE_RGB_ROAD       128, 128, 128
+#define TDE_RGB_WAYPOINT    44, 160,  44
+#define TDE_RGB_NPC         31, 119, 180
+#define TDE_RGB_EGO        214,  39,  40
+#define TDE_WAYPOINT_RADIUS 1.0f
 typedef struct tde_render {
-    uint8_t *out;               /* [B][3][H][W] uint8, channels first (obs space gym_env.py:95) */
-    int32_t H, W;               /* 64, 64 */
-    float fov;                  /* metres covered by the view edge */
-    int32_t _pad0;
+    uint8_t *out;               /* [B][3*max(n_stack,1)][H][W] uint8 */
+    int32_t H, W;               /* 64, 64 (W a multiple of 16) */
+    float fov;                  /* metres covered by the image width (35 in torchdrivesim's default RendererConfig) */
+    int32_t n_stack;            /* 0/1: single frame; n: frame stack of n */
 } tde_render;
 
 #ifdef __cplusplus

@@ -89,6 +89,12 @@ TDE_API int tde_env_step(const tde_config *cfg, const tde_world *world, const td
 TDE_API int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_state *state,
                             const tde_rollout *rollout, void *stream);
 
+/* GymEnv.get_obs / render: simulator.render_egocentric() for the ego of every env -> uint8 [B][3*n_stack][H][W]
+ * (channels first, obs space gym_env.py:95; frame stack as VecFrameStack(n_stack=3, channels_order="first"),
+ * examples/rl_training.py:160).  Replaces: gym_env.py:122-124, 152-155.  Layer/palette definition: tde_abi.h. */
+TDE_API int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *state,
+                           const tde_render *render, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

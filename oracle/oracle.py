@@ -178,3 +178,19 @@ def waypoint_reward(cfg, pre, post, offroad, collided, tl, wp_xy, wp_n, scn, ste
                                  _p(reached), _p(out["reward"]), _p(out["terminated"]), _p(out["truncated"]),
                                  _p(out["info"]), _p(out["info_reached"]))
     return out
+
+
+def render_ego(cfg, world, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
+    """ego-centred birdview [B, 3*n_stack, H, W] uint8 of the current state (frame-stack semantics if n_stack > 1)"""
+    L = lib()
+    if not getattr(L, "_rd_bound", False):
+        L.tde_oracle_render_ego.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld),
+                                            C.POINTER(_abi.TdeState), C.POINTER(_abi.TdeRender)]
+        L.tde_oracle_render_ego.restype = C.c_int
+        L._rd_bound = True
+    ns = max(1, n_stack)
+    if out is None:
+        out = np.zeros((state.B, 3 * ns, H, W), np.uint8)
+    rd = _abi.TdeRender(_p(out), H, W, fov, n_stack)
+    L.tde_oracle_render_ego(C.byref(cfg), C.byref(world.host_struct()), C.byref(state.struct), C.byref(rd))
+    return out

@@ -608,6 +608,62 @@ TDE_EXPORT int tde_oracle_env_rollout(const tde_config *cfg, const tde_world *w,
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* R13: get_obs -> simulator.render_egocentric() (gym_env.py:122-124), restated as a point-sampled     */
+/* raster (layer definitions in include/tde_abi.h).  PARITY UNPINNED: torchdrivesim's renderer is not   */
+/* in the reference repository; palette, sampling and draw order are defined here.                     */
+/* ------------------------------------------------------------------------------------------------ */
+static void tde_render_env(const tde_config *cfg, const tde_world *w, const tde_state *st, const tde_render *rd,
+                           int32_t e)
+{
+    static const uint8_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
+                         NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
+    const int32_t A = st->A, H = rd->H, W = rd->W;
+    const int32_t ns = rd->n_stack > 1 ? rd->n_stack : 1;
+    const int64_t g0 = (int64_t)e * A;
+    const int64_t plane = (int64_t)H * W;
+    uint8_t *out = rd->out + (int64_t)e * 3 * ns * plane;
+    if (ns > 1) memmove(out, out + 3 * plane, (size_t)(3 * (ns - 1) * plane));
+    uint8_t *img = out + 3 * (ns - 1) * plane;
+    const int32_t scn = st->scn[e];
+    const tde_map *m = &w->maps[w->scn[scn].map];
+    const float *tri = w->tri + 6 * (int64_t)m->tri_base;
+    const float thr2 = cfg->offroad_threshold * cfg->offroad_threshold;
+    float ca[TDE_MAX_AGENTS], sa[TDE_MAX_AGENTS];
+    for (int32_t a = 0; a < A; ++a) tde_oracle_sincosf(st->psi[g0 + a], &sa[a], &ca[a]);
+    const float ex = st->x[g0], ey = st->y[g0], ce = ca[0], se = sa[0];
+    const float res = rd->fov / (float)W;
+    const double *wp = w->wp_xy + (int64_t)scn * w->NW * 2;
+    const int32_t n_wp = w->scn[scn].wp_n, ti = st->target_idx[e];
+    for (int32_t r = 0; r < H; ++r)
+        for (int32_t c = 0; c < W; ++c) {
+            float f = (0.5f * (float)H - ((float)r + 0.5f)) * res;
+            float l = (0.5f * (float)W - ((float)c + 0.5f)) * res;
+            float wx = (ex + f * ce) - l * se;
+            float wy = (ey + f * se) + l * ce;
+            const uint8_t *col = BG;
+            if (!(tde_oracle_point_mesh_d2(wx, wy, tri, m->n_tri) > thr2)) col = ROAD;
+            for (int32_t k = ti; k < n_wp; ++k) {
+                float dx = wx - (float)wp[2 * k], dy = wy - (float)wp[2 * k + 1];
+                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) col = WP;
+            }
+            for (int32_t a = A - 1; a >= 0; --a) {
+                if (!st->present[g0 + a]) continue;
+                float dx = wx - st->x[g0 + a], dy = wy - st->y[g0 + a];
+                float p = dx * ca[a] + dy * sa[a], q = dy * ca[a] - dx * sa[a];
+                if (fabsf(p) <= 0.5f * st->len[g0 + a] && fabsf(q) <= 0.5f * st->wid[g0 + a]) col = a ? NPC : EGO;
+            }
+            for (int ch = 0; ch < 3; ++ch) img[ch * plane + (int64_t)r * W + c] = col[ch];
+        }
+}
+
+TDE_EXPORT int tde_oracle_render_ego(const tde_config *cfg, const tde_world *w, const tde_state *st, const tde_render *rd)
+{
+#pragma omp parallel for schedule(static)
+    for (int32_t e = 0; e < st->B; ++e) tde_render_env(cfg, w, st, rd, e);
+    return 0;
+}
+
 TDE_EXPORT int tde_oracle_num_threads(void)
 {
 #ifdef _OPENMP

@@ -292,3 +292,31 @@ def test_full_size_8192x16_subset_and_determinism():
     done = runs[0][1]
     assert (done & 2).sum() > 0 and (done & 1).sum() > 0
     assert np.isfinite(runs[0][0]).all()
+
+
+@pytest.mark.parametrize("A,n_stack", [(16, 1), (16, 3), (32, 1)])
+def test_render_ego_bit_exact(A, n_stack):
+    """R13 / BASELINE configs[4]: 64x64x3 ego birdview; every pixel equal to the oracle's brute-force raster"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=6, A=A, seed=3, n_maps=2)
+    cfg = _abi.default_config(seed=8)
+    B = 24
+    hs, ds, dw = _pair(world, B, A, cfg)
+    rng = np.random.default_rng(4)
+    hout = dout = None
+    for t in range(12):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+        if t % 3 == 2:
+            hout = oracle.render_ego(cfg, world, hs, n_stack=n_stack, out=hout)
+            dout = ops.render_ego(cfg, dw, ds, n_stack=n_stack, out=dout)
+            got = dout.cpu().numpy()
+            assert got.shape == (B, 3 * n_stack, 64, 64) and got.dtype == np.uint8
+            assert np.array_equal(got, hout), f"{(got != hout).sum()} pixels differ at t={t}"
+    last = hout[:, -3:]
+    assert (last[:, 0, 32, 32] == 214).all()              # the ego covers the image centre
+    assert len(np.unique(last.reshape(B, 3, -1).transpose(0, 2, 1).reshape(-1, 3), axis=0)) >= 4

@@ -91,7 +91,7 @@ class TdeRollout(C.Structure):
 
 
 class TdeRender(C.Structure):
-    _fields_ = [("out", _p), ("H", C.c_int32), ("W", C.c_int32), ("fov", C.c_float), ("_pad0", C.c_int32)]
+    _fields_ = [("out", _p), ("H", C.c_int32), ("W", C.c_int32), ("fov", C.c_float), ("n_stack", C.c_int32)]
 
 
 def ptr_of(a):

@@ -605,6 +605,136 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
     if (info_reached) info_reached[i] = rc;
 }
 
+// ---- R13: ego-centred birdview raster (get_obs -> render_egocentric, ref gym_env.py:122-124; layers: tde_abi.h) ----
+// One workgroup per env view.  The env's agents and remaining ego waypoints are culled against the view circle into
+// LDS lists first (a typical view holds 2-5 of the 16-32 agents), then every lane shades 16 consecutive pixels of a
+// row and writes them as one 16-B store per colour plane (channels-first uint8: fully coalesced 12 KiB per view).
+constexpr int kRenderMaxWp = 64;
+__global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_world w, tde_state st, tde_render rd)
+{
+    __shared__ float4 s_box[TDE_MAX_AGENTS];     // x, y, cos, sin
+    __shared__ float2 s_ext[TDE_MAX_AGENTS];     // hl, hw
+    __shared__ float2 s_wp[kRenderMaxWp];
+    __shared__ int s_nbox, s_nwp;
+    __shared__ float s_ego[6];                   // x, y, cos, sin, hl, hw
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int A = st.A, H = rd.H, W = rd.W;
+    const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
+    const int64_t plane = (int64_t)H * W;
+    uint8_t *out = rd.out + (int64_t)e * 3 * ns * plane;
+    const int64_t g0 = (int64_t)e * A;
+    const int scn = st.scn[e];
+    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[scn];
+    const tde_map m = w.maps[sc.x];
+    const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
+    const float res = rd.fov / (float)W;
+    // view circle: half diagonal of the image plus slack; lists are supersets, so culling cannot change a pixel
+    const float rview = 0.75f * res * (float)(H > W ? H : W) + 1.0f;
+    if (tid == 0) { s_nbox = 0; s_nwp = 0; }
+    const float ex = st.x[g0], ey = st.y[g0];
+    __syncthreads();
+    if (tid < A) {
+        const int64_t g = g0 + tid;
+        float sa, ca;
+        sincos_f32(st.psi[g], sa, ca);
+        const float x = st.x[g], y = st.y[g], hl = 0.5f * st.len[g], hw = 0.5f * st.wid[g];
+        if (tid == 0) {
+            s_ego[0] = x; s_ego[1] = y; s_ego[2] = ca; s_ego[3] = sa; s_ego[4] = hl; s_ego[5] = hw;
+        } else if (st.present[g]) {
+            const float dx = x - ex, dy = y - ey, rr = rview + (hl + hw);
+            if (dx * dx + dy * dy <= rr * rr) {
+                const int k = atomicAdd(&s_nbox, 1);
+                s_box[k] = make_float4(x, y, ca, sa);
+                s_ext[k] = make_float2(hl, hw);
+            }
+        }
+    }
+    {
+        const int ti = st.target_idx[e], n_wp = sc.y;
+        for (int k = ti + tid; k < n_wp; k += kBlock) {
+            const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
+            const float tx = (float)t.x, ty = (float)t.y;
+            const float dx = tx - ex, dy = ty - ey, rr = rview + TDE_WAYPOINT_RADIUS;
+            if (dx * dx + dy * dy <= rr * rr) {
+                const int q = atomicAdd(&s_nwp, 1);
+                if (q < kRenderMaxWp) s_wp[q] = make_float2(tx, ty);
+            }
+        }
+    }
+    // frame stack: shift the older frames down by one frame (read everything, barrier, write)
+    if (ns > 1) {
+        const int nvec = (int)(3 * (ns - 1) * plane / 16);
+        const uint4 *src = reinterpret_cast<const uint4 *>(out + 3 * plane);
+        uint4 *dst = reinterpret_cast<uint4 *>(out);
+        for (int i0 = 0; i0 < nvec; i0 += kBlock * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) v[u] = src[i]; }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) dst[i] = v[u]; }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const int nbox = s_nbox, nwp = s_nwp < kRenderMaxWp ? s_nwp : kRenderMaxWp;
+    const float ce = s_ego[2], se = s_ego[3], ehl = s_ego[4], ehw = s_ego[5];
+    uint8_t *img = out + 3 * (ns - 1) * plane;
+    const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
+                   NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
+    const int nchunk = (int)(plane / 16);
+    for (int ch = tid; ch < nchunk; ch += kBlock) {
+        const int r = (ch * 16) / W, c0 = (ch * 16) % W;
+        const float f = (0.5f * (float)H - ((float)r + 0.5f)) * res;
+        uint32_t pr[4] = {0, 0, 0, 0}, pg[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const float l = (0.5f * (float)W - ((float)(c0 + i) + 0.5f)) * res;
+            const float wx = (ex + f * ce) - l * se;
+            const float wy = (ey + f * se) + l * ce;
+            int layer = 0;                                        // 0 bg, 1 road, 2 waypoint, 3 npc, 4 ego
+            {
+                const uint32_t wd = cell_lookup(w, m, wx, wy);
+                const uint32_t cls = wd & 3u;
+                bool road = cls == TDE_CELL_FULL;
+                if (cls == TDE_CELL_MIXED) {
+                    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 8);
+                    const int n = (int)((wd >> 2) & 63u);
+                    for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
+                }
+                if (road) layer = 1;
+            }
+            for (int k = 0; k < nwp; ++k) {
+                const float2 t = s_wp[k];
+                const float dx = wx - t.x, dy = wy - t.y;
+                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
+            }
+            for (int k = 0; k < nbox; ++k) {
+                const float4 b = s_box[k];
+                const float2 x2 = s_ext[k];
+                const float dx = wx - b.x, dy = wy - b.y;
+                const float p = dx * b.z + dy * b.w, q = dy * b.z - dx * b.w;
+                if (fabsf(p) <= x2.x && fabsf(q) <= x2.y) layer = 3;
+            }
+            {
+                const float dx = wx - ex, dy = wy - ey;
+                const float p = dx * ce + dy * se, q = dy * ce - dx * se;
+                if (fabsf(p) <= ehl && fabsf(q) <= ehw) layer = 4;
+            }
+            const uint32_t R = TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
+            const uint32_t G = TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
+            const uint32_t Bc = TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
+            pr[i >> 2] |= R << (8 * (i & 3));
+            pg[i >> 2] |= G << (8 * (i & 3));
+            pb[i >> 2] |= Bc << (8 * (i & 3));
+        }
+        const int64_t o = (int64_t)r * W + c0;
+        *reinterpret_cast<uint4 *>(img + o) = make_uint4(pr[0], pr[1], pr[2], pr[3]);
+        *reinterpret_cast<uint4 *>(img + plane + o) = make_uint4(pg[0], pg[1], pg[2], pg[3]);
+        *reinterpret_cast<uint4 *>(img + 2 * plane + o) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+    }
+}
+
 }  // namespace tde
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -753,6 +883,19 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
+}
+
+int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_render *rd,
+                   void *stream)
+{
+    int rc = check_env_args("tde_render_ego", cfg, world, st);
+    if (rc) return rc;
+    if (!rd || !rd->out) return bad("tde_render_ego: render/out is NULL");
+    if (rd->H <= 0 || rd->W <= 0 || (rd->W % 16) != 0) return bad("tde_render_ego: W must be a positive multiple of 16");
+    if (st->B <= 0) return 0;
+    tde::render_ego_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_render_ego", e);
 }
 
 }  // extern "C"

@@ -148,3 +148,17 @@ def env_rollout(cfg, dworld, state, actions, reward=None, done=None):
     _lib.check(L.tde_env_rollout(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(ro),
                                  _lib.current_stream(dev)), "tde_env_rollout")
     return reward, done
+
+
+def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
+    """render_egocentric() of every env's ego -> uint8 [B, 3*n_stack, H, W] on device (ref gym_env.py:122-124).
+    With n_stack > 1 `out` must be the buffer of the previous call: older frames are shifted, the new one appended."""
+    L = _lib.load()
+    ns = max(1, n_stack)
+    dev = state.device
+    if out is None:
+        out = torch.zeros((state.B, 3 * ns, H, W), dtype=torch.uint8, device=dev)
+    rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack)
+    _lib.check(L.tde_render_ego(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(rd),
+                                _lib.current_stream(dev)), "tde_render_ego")
+    return out
