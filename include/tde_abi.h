@@ -41,7 +41,7 @@ extern "C" {
 #define TDE_F_ALL (TDE_F_NPC | TDE_F_REPLAY | TDE_F_OFFROAD | TDE_F_REWARD | TDE_F_AUTORESET)
 
 /* cell classes of the offroad grid index (HIP side only; the oracle is brute force over triangles) */
-#define TDE_CELL_MAX_TRIS 63u
+#define TDE_CELL_MAX_TRIS 255u
 #define TDE_CELL_EMPTY 0u  /* every point of the cell is farther than threshold from every triangle  */
 #define TDE_CELL_MIXED 1u  /* test the cell's candidate triangles                                    */
 #define TDE_CELL_FULL  2u  /* every point of the cell is within threshold of some triangle            */
@@ -69,6 +69,9 @@ typedef struct tde_config {
     int32_t terminated_at_infraction; /* 1  gym_env.py:44 */
     uint32_t flags;             /* TDE_F_* */
     float npc_cone_range;       /* yield cone length [m] */
+    uint32_t env_base;          /* global index of this shard's env 0: the reset RNG is keyed by env_base + e, so
+                                   a batch sharded over GPUs replays exactly the episodes of the unsharded batch */
+    int32_t _pad0;
 } tde_config;
 
 /* One drivable-surface map: triangle soup + uniform grid index. */
@@ -110,8 +113,8 @@ typedef struct tde_scenario {
 typedef struct tde_world {
     const tde_map *maps;        /* [n_maps] */
     const float *tri;           /* [n_tri_total][6]  ax,ay,bx,by,cx,cy (what the oracle's brute force reads) */
-    const uint32_t *cell_word;  /* [n_cells_total] grid index (kernels): bits 0-1 TDE_CELL_*, bits 2-7 number of
-                                   candidate triangles, bits 8-31 first record of the cell in cell_tri */
+    const uint32_t *cell_word;  /* [n_cells_total] grid index (kernels): bits 0-1 TDE_CELL_*, bits 2-9 number of
+                                   candidate triangles, bits 10-31 first record of the cell in cell_tri */
     const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
                                    ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 */
     const tde_scenario *scn;    /* [S] */

@@ -264,6 +264,18 @@ def main():
         pos = pos + d / L * 0.4
     cases.append(run_case(gym_env, "threeway_follow_all_waypoints", dict(shipped, max_environment_steps=400), wp0, traj))
 
+    # 9. BASELINE configs[0] input data: the Three-Way validation scenario (validation case 0), as data
+    three = dict(source="torchdriveenv/data/validation_cases.yml case 0 (Three-Way, README.md:23)",
+                 location=val["locations"][0], waypoints=wp0,
+                 car_sequences={str(k): v for k, v in (val["car_sequence_suite"][0] or {}).items()},
+                 scenario=dict(agent_states=val["scenarios"][0]["agent_states"],
+                               agent_attributes=val["scenarios"][0]["agent_attributes"]),
+                 # the only shipped replay car (case 1: 300 identical states, validation_cases.yml:86-1289)
+                 parked_replay_example=dict(state=val["car_sequence_suite"][1][1][0],
+                                            length=len(val["car_sequence_suite"][1][1])))
+    with open(os.path.join(os.path.dirname(OUT), "threeway_scenario.json"), "w") as f:
+        json.dump(three, f)
+
     meta = dict(generator="oracle/gen_golden.py",
                 reference="inverted-ai/torchdriveenv torchdriveenv/gym_env.py (WaypointSuiteEnv + SingleAgentWrapper, "
                           "run unmodified over a scripted simulator; third-party imports stubbed)",

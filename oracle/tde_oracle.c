@@ -291,9 +291,10 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
 {
     const int32_t A = st->A;
     uint32_t ep = (uint32_t)st->episode[e];
+    const uint32_t ge = cfg->env_base + (uint32_t)e;   /* global env index keys the stream */
     uint32_t r0[4], r1[4], rn[4];
-    tde_oracle_philox(cfg->seed, (uint32_t)e, ep, 0u, 0x7DEu, r0);
-    tde_oracle_philox(cfg->seed, (uint32_t)e, ep, 1u, 0x7DEu, r1);
+    tde_oracle_philox(cfg->seed, ge, ep, 0u, 0x7DEu, r0);
+    tde_oracle_philox(cfg->seed, ge, ep, 1u, 0x7DEu, r1);
     /* np.random.randint(len(waypoint_suite))  :320 */
     int32_t scn = (int32_t)(((uint64_t)r0[0] * (uint64_t)w->n_scn) >> 32);
     const double *wp = w->wp_xy + (int64_t)scn * w->NW * 2;
@@ -305,7 +306,7 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
     /* start_orientation = lanelet direction + normal(0, 0.1)  :359-361; normal = Irwin-Hall(12) - 6 */
     double acc = 0.0;
     for (uint32_t b = 0; b < 3; ++b) {
-        tde_oracle_philox(cfg->seed, (uint32_t)e, ep, 2u + b, 0x7DEu, rn);
+        tde_oracle_philox(cfg->seed, ge, ep, 2u + b, 0x7DEu, rn);
         for (int k = 0; k < 4; ++k) acc += tde_u01(rn[k]);
     }
     double psi0 = (double)w->scn[scn].start_heading + (acc - 6.0) * 0.1;

@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/tde_hip.h
+declares (no compute calls without a GPU); the product never touches the oracle; failures are loud."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tde_hip.h")).read()
+    return re.findall(r"TDE_API\s+[\w\s\*]+?\b(tde_\w+)\s*\(", src)
+
+
+def test_library_exports_every_declared_symbol():
+    from torchdriveenv_amd import _lib, build
+
+    build.build()
+    syms = declared_symbols()
+    assert len(syms) >= 11 and "tde_env_step" in syms and "tde_render_ego" in syms
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/tde_hip.h but not exported"
+    assert sorted(syms) == sorted(_lib.SYMBOLS), "python loader and header disagree on the C-ABI"
+    assert L.tde_abi_version() == _lib._abi.TDE_ABI_VERSION
+    assert _lib.load() is not None     # full loader: argtypes + ABI version check
+
+
+def test_abi_struct_sizes_match_header():
+    """compile a tiny C program against include/tde_abi.h and compare sizeof/offsetof with the ctypes mirror"""
+    import subprocess
+    import tempfile
+
+    from torchdriveenv_amd import _abi
+
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "tde_abi.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tde_config), sizeof(tde_map), sizeof(tde_world),
+         sizeof(tde_state), sizeof(tde_rollout), sizeof(tde_render), sizeof(tde_spawn), sizeof(tde_scenario),
+         offsetof(tde_config, flags), offsetof(tde_world, n_maps), offsetof(tde_state, B));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        got = [int(t) for t in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    C = ctypes
+    want = [C.sizeof(_abi.TdeConfig), C.sizeof(_abi.TdeMap), C.sizeof(_abi.TdeWorld), C.sizeof(_abi.TdeState),
+            C.sizeof(_abi.TdeRollout), C.sizeof(_abi.TdeRender), _abi.SPAWN_DTYPE.itemsize, _abi.SCN_DTYPE.itemsize,
+            _abi.TdeConfig.flags.offset, _abi.TdeWorld.n_maps.offset, _abi.TdeState.B.offset]
+    assert got == want
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "torchdriveenv_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f"{f} imports the oracle"
+                assert "libtde_oracle" not in txt and "tde_oracle_" not in txt, f"{f} references the oracle"
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from torchdriveenv_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libtde_hip.so")
+    with pytest.raises(_lib.TdeError, match="no fallback"):
+        _lib.load()
+
+
+def test_ops_reject_cpu_tensors_and_bad_shapes():
+    import torch
+
+    from torchdriveenv_amd import ops
+
+    x = torch.zeros(8)
+    with pytest.raises(ValueError, match="HIP device"):
+        ops.kinematics_step(x, x, x, x, x, torch.zeros(8, 2))
+    with pytest.raises(ValueError, match="float32"):
+        ops.kinematics_step(x.double(), x, x, x, x, torch.zeros(8, 2))
+
+
+def test_env_requires_gpu():
+    import torch
+
+    from torchdriveenv_amd.config import EnvConfig
+    from torchdriveenv_amd.env import BatchedWaypointEnv
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        BatchedWaypointEnv(EnvConfig(), None, num_envs=1)

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: world_size-2 gloo job.  Each rank steps ITS shard (the oracle stands in for the GPU kernels —
+same C-ABI structs, same sharding code), results are host-gathered on rank 0 and must equal the unsharded batch bit
+for bit: no data-path collective, RNG keyed by the global env index (tde_config.env_base)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world_size, port, total, K, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from oracle import oracle
+    from torchdriveenv_amd import _abi
+    from torchdriveenv_amd.sharding import host_gather, shard_config, shard_range
+    from torchdriveenv_amd.state import EnvState
+    from torchdriveenv_amd.synth import synthetic_world
+
+    oracle.set_num_threads(1)
+    world = synthetic_world(n_scn=4, A=8, seed=0, n_maps=2)          # replicated static tables
+    cfg, n = shard_config(_abi.default_config(seed=9, distance_cutoff=0.25), rank, world_size, total)
+    lo, hi = shard_range(rank, world_size, total)
+    st = EnvState(n, 8)
+    oracle.env_reset(cfg, world, st)
+    rng = np.random.default_rng(0)
+    actions = np.stack([rng.uniform(-1, 1, (K, total)), rng.uniform(-0.3, 0.3, (K, total))], -1).astype(np.float32)
+    dist.barrier()
+    reward, done = oracle.env_rollout(cfg, world, st, np.ascontiguousarray(actions[:, lo:hi]))
+    dist.barrier()
+    parts = host_gather(dict(lo=lo, reward=reward, done=done, x=st["x"].copy(), episode=st["episode"].copy()))
+    if rank == 0:
+        q.put(parts)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_rollout_equals_unsharded():
+    total, K = 24, 60
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    parts = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import oracle
+    from torchdriveenv_amd import _abi
+    from torchdriveenv_amd.state import EnvState
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=4, A=8, seed=0, n_maps=2)
+    cfg = _abi.default_config(seed=9, distance_cutoff=0.25)
+    st = EnvState(total, 8)
+    oracle.env_reset(cfg, world, st)
+    rng = np.random.default_rng(0)
+    actions = np.stack([rng.uniform(-1, 1, (K, total)), rng.uniform(-0.3, 0.3, (K, total))], -1).astype(np.float32)
+    reward, done = oracle.env_rollout(cfg, world, st, actions)
+    assert [p["lo"] for p in parts] == [0, 12]
+    assert np.array_equal(np.concatenate([p["reward"] for p in parts], 1).view(np.uint32), reward.view(np.uint32))
+    assert np.array_equal(np.concatenate([p["done"] for p in parts], 1), done)
+    assert np.array_equal(np.concatenate([p["x"] for p in parts]).view(np.uint32), st["x"].view(np.uint32))
+    assert np.array_equal(np.concatenate([p["episode"] for p in parts]), st["episode"])
+    assert st["episode"].max() > 1

@@ -1,0 +1,127 @@
+"""The host-side mirror of the reference surface on a real GPU: B=1 Three-Way scenario through the reference-shaped API
+(BASELINE configs[0]) checked against the oracle stepping the same world, and the batched / VecEnv-shaped API."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from torchdriveenv_amd import _abi  # noqa: E402
+from torchdriveenv_amd.config import EnvConfig, Scenario, WaypointSuite  # noqa: E402
+from torchdriveenv_amd.env import BatchedWaypointEnv, SingleAgentWrapper, WaypointSuiteEnv, make  # noqa: E402
+from torchdriveenv_amd.state import EnvState  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def threeway_suite():
+    t = json.load(open(os.path.join(ROOT, "tests", "golden", "threeway_scenario.json")))
+    wp, sc, parked = t["waypoints"], t["scenario"], t["parked_replay_example"]
+    extra = [[wp[2][0] + 4.0, wp[2][1] + 3.0, 0.0, 0.0], [wp[4][0] - 3.0, wp[4][1] + 4.0, 0.0, 0.0]]
+    # all four NPCs replayed: the two scenario agents drive straight at their scenario speed, two parked cars
+    seqs = {}
+    for slot, s in enumerate(sc["agent_states"], start=1):
+        x, y, psi, v = s
+        seqs[slot] = [[x + np.cos(psi) * v * 0.1 * k, y + np.sin(psi) * v * 0.1 * k, psi, v] for k in range(120)]
+    seqs[3] = [extra[0]] * parked["length"]
+    seqs[4] = [extra[1]] * parked["length"]
+    return WaypointSuite(locations=[t["location"]], waypoint_suite=[wp], car_sequence_suite=[seqs],
+                         scenarios=[Scenario(agent_states=sc["agent_states"] + extra,
+                                             agent_attributes=sc["agent_attributes"] + [[5.0, 2.0, 2.0]] * 2)])
+
+
+def test_config1_threeway_b1_reference_api_vs_oracle():
+    cfg = EnvConfig(seed=3, distance_cutoff=0.25)
+    env = make(cfg, threeway_suite(), agents_per_env=8)
+    assert isinstance(env, SingleAgentWrapper) and isinstance(env.env, WaypointSuiteEnv)
+    obs, info = env.reset()
+    assert obs.shape == (3, 64, 64) and obs.dtype == np.uint8 and info == {}
+    inner = env.env._env
+    # the oracle steps the same world from the same reset
+    hs = EnvState(1, 8)
+    ocfg = inner.tde_cfg
+    oracle.env_reset(ocfg, inner.world, hs)
+    assert np.array_equal(hs["x"].view(np.uint32), inner.state["x"].cpu().numpy().view(np.uint32))
+    total, n_term = 0.0, 0
+    for t in range(200):
+        action = np.array([0.6, 0.0 if t < 25 else -0.02], dtype=np.float32)
+        obs, reward, terminated, truncated, info = env.step(action)
+        hs["action"][...] = action
+        oracle.env_step(ocfg, inner.world, hs)
+        # reference shapes / types (gym_env.py:453-472)
+        assert obs.shape == (3, 64, 64) and obs.dtype == np.uint8
+        assert isinstance(reward, float) and isinstance(terminated, bool) and isinstance(truncated, bool)
+        for k in ("offroad", "collision", "traffic_light_violation"):
+            assert torch.is_tensor(info[k]) and info[k].dim() == 0 and info[k].device.type == "cpu"
+        for k in ("is_success", "reached_waypoint_num", "psi_smoothness", "psi_reward", "dist_reward",
+                  "speed_smoothness"):
+            assert k in info
+        assert np.float32(reward) == hs["reward"][0]
+        assert terminated == bool(hs["terminated"][0]) and truncated == bool(hs["truncated"][0])
+        assert float(info["collision"]) == float(hs["collided"][0]) and float(info["offroad"]) == float(hs["offroad"][0])
+        assert info["reached_waypoint_num"] == hs["info_reached"][0]
+        assert np.array_equal(inner.state["x"].cpu().numpy().view(np.uint32), hs["x"].view(np.uint32))
+        assert np.array_equal(obs, oracle.render_ego(ocfg, inner.world, hs)[0])
+        total += reward
+        if terminated or truncated:
+            n_term += 1
+            break
+    assert env.env.environment_steps == int(hs["steps"][0]) and n_term == 1
+    assert env.env.reached_waypoint_num >= 1          # it drove through at least the first waypoint
+    img = env.render()
+    assert img.shape == (64, 64, 3) and img.dtype == np.uint8
+
+
+def test_batched_env_device_api_and_vecenv_adapter(small_world):
+    cfg = EnvConfig(seed=11, distance_cutoff=0.25, frame_stack=3)
+    B = 64
+    env = BatchedWaypointEnv(cfg, small_world, num_envs=B, device="cuda:0", frame_stack=3)
+    obs = env.reset()
+    assert obs.shape == (B, 9, 64, 64) and obs.dtype == torch.uint8 and obs.is_cuda
+    g = torch.Generator().manual_seed(0)
+    ndone = 0
+    for t in range(30):
+        a = torch.stack([torch.rand(B, generator=g) * 2 - 1, torch.rand(B, generator=g) * 0.6 - 0.3], -1)
+        obs, rew, term, trunc, info = env.step(a)
+        assert rew.shape == (B,) and term.dtype == torch.bool and obs.is_cuda
+        assert set(info) >= {"offroad", "collision", "traffic_light_violation", "is_success", "reached_waypoint_num",
+                             "psi_smoothness", "speed_smoothness", "psi_reward", "dist_reward"}
+        ndone += int((term | trunc).sum())
+    # newest frame is last in the stack; the previous call's newest frame moved one slot down
+    prev_last = obs[:, 6:9].clone()
+    obs2, *_ = env.step(torch.zeros(B, 2))
+    keep = ~(env.state["steps"] == 0)          # envs that did not just reset
+    assert torch.equal(obs2[keep][:, 3:6], prev_last[keep])
+    # SB3-shaped numpy path with terminal_observation
+    env2 = BatchedWaypointEnv(cfg, small_world, num_envs=B, device="cuda:0", frame_stack=1)
+    o = env2.vec_reset()
+    assert o.shape == (B, 3, 64, 64) and o.dtype == np.uint8
+    seen_terminal = False
+    rng = np.random.default_rng(1)
+    for t in range(60):
+        o, r, d, infos = env2.vec_step(np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1))
+        assert o.shape == (B, 3, 64, 64) and r.shape == (B,) and d.dtype == bool and len(infos) == B
+        for i in np.nonzero(d)[0]:
+            assert infos[i]["terminal_observation"].shape == (3, 64, 64)
+            assert int(env2.state["steps"][i]) == 0        # re-spawned
+            seen_terminal = True
+    assert seen_terminal
+    sd = env2.state_dict()
+    env2.vec_step(np.zeros((B, 2), np.float32))
+    env2.load_state_dict(sd)
+    assert torch.equal(env2.state["x"], sd["x"])
+
+
+def test_rollout_api_and_state_obs(small_world):
+    cfg = EnvConfig(seed=2)
+    env = BatchedWaypointEnv(cfg, small_world, num_envs=128, device="cuda:0", obs_mode="state", with_info=False)
+    o = env.reset()
+    assert o.shape == (128, 8) and o.dtype == torch.float32
+    acts = torch.zeros(50, 128, 2, device="cuda:0")
+    acts[..., 0] = 0.3
+    r, d = env.rollout(acts)
+    assert r.shape == (50, 128) and d.shape == (50, 128) and torch.isfinite(r).all()

@@ -1,0 +1,77 @@
+import math
+import os
+
+import numpy as np
+import yaml
+
+from torchdriveenv_amd import _abi
+from torchdriveenv_amd.config import EnvConfig, Scenario, WaypointSuite, to_tde_config
+from torchdriveenv_amd.loaders import construct_env_config, load_env_config, load_waypoint_suite_data
+from torchdriveenv_amd.sharding import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_env_config_defaults_match_reference():
+    c = EnvConfig()          # ref gym_env.py:34-54
+    assert (c.ego_only, c.max_environment_steps, c.frame_stack) == (False, 200, 3)
+    assert (c.waypoint_bonus, c.heading_penalty, c.distance_bonus, c.distance_cutoff) == (100., 25., 1., 0.5)
+    assert c.use_background_traffic and c.terminated_at_infraction and c.seed is None
+    assert c.render_mode == "rgb_array" and c.video_res == 1024 and c.video_fov == 500 and c.device is None
+    assert c.simulator.renderer.left_handed_coordinates and c.simulator.renderer.highlight_ego_vehicle
+    assert c.simulator.collision_metric == "nograd" and c.simulator.offroad_threshold == 0.5
+    t = to_tde_config(c, seed=5, flags=_abi.F_ALL)
+    assert (t.waypoint_bonus, t.heading_penalty, t.distance_cutoff, t.max_steps, t.seed) == (100., 25., 0.5, 200, 5)
+    assert abs(t.dt - 0.1) < 1e-8 and t.reach_radius == 3.0
+
+
+def test_yaml_loaders(tmp_path):
+    (tmp_path / "env.yml").write_text(yaml.safe_dump(dict(ego_only=True, distance_cutoff=0.25, frame_stack=3,
+                                                          simulator=dict(offroad_threshold=0.4))))
+    c = load_env_config(str(tmp_path / "env.yml"))
+    assert c.ego_only and c.distance_cutoff == 0.25 and c.simulator.offroad_threshold == 0.4
+    assert construct_env_config(dict(waypoint_bonus=10.0)).waypoint_bonus == 10.0
+    suite = dict(locations=["Town01", "Town02"], waypoint_suite=[[[0, 0], [10, 0], [20, 0]], [[0, 0], [0, 15]]],
+                 car_sequence_suite=[{1: [[5, 3, 0, 0]] * 4}, None],
+                 scenarios=[dict(agent_states=[[5, 3, 0, 0]], agent_attributes=[[5, 2, 2]], recurrent_states=[[0.0]]), None])
+    (tmp_path / "suite.yml").write_text(yaml.safe_dump(suite))
+    d = load_waypoint_suite_data(str(tmp_path / "suite.yml"))
+    assert isinstance(d, WaypointSuite) and isinstance(d.scenarios[0], Scenario) and d.scenarios[1] is None
+    assert list(d.car_sequence_suite[0].keys()) == [1] and d.locations == ["Town01", "Town02"]
+
+
+def test_world_from_threeway_fixture():
+    """BASELINE configs[0] inputs: validation case 0 (data extracted by oracle/gen_golden.py)"""
+    import json
+
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+
+    t = json.load(open(os.path.join(ROOT, "tests", "golden", "threeway_scenario.json")))
+    parked = t["parked_replay_example"]
+    sc = t["scenario"]
+    # ego + the 2 scenario agents + 2 parked replay cars next to the route = "ego + 4 replay NPCs"
+    wp = t["waypoints"]
+    extra = [[wp[2][0] + 4.0, wp[2][1] + 3.0, 0.0, 0.0], [wp[4][0] - 3.0, wp[4][1] + 4.0, 0.0, 0.0]]
+    seqs = {3: [extra[0]] * parked["length"], 4: [extra[1]] * parked["length"]}
+    data = WaypointSuite(locations=[t["location"]], waypoint_suite=[wp], car_sequence_suite=[seqs],
+                         scenarios=[Scenario(agent_states=sc["agent_states"] + extra,
+                                             agent_attributes=sc["agent_attributes"] + [[5.0, 2.0, 2.0]] * 2)])
+    w = world_from_waypoint_suite(data, agents_per_env=8)
+    assert w.A == 8 and w.n_scn == 1 and w.arrays["scn"]["wp_n"][0] == len(wp)
+    sp = w.arrays["spawn"][0]
+    assert sp["present"].tolist() == [1, 1, 1, 1, 1, 0, 0, 0]
+    assert sp["replay"][3] >= 0 and sp["replay_len"][3] == 300 and sp["route"][1] >= 0 and sp["replay"][1] == -1
+    assert math.isclose(w.arrays["scn"]["start_heading"][0],
+                        math.atan2(wp[1][1] - wp[0][1], wp[1][0] - wp[0][0]), rel_tol=1e-6)
+    # every waypoint lies on the synthetic drivable corridor
+    from oracle import oracle
+    m = w.arrays["maps"][0]
+    tri = w.arrays["tri"][m["tri_base"]:m["tri_base"] + m["n_tri"]]
+    assert all(oracle.point_mesh_d2(np.float32(x), np.float32(y), tri) == 0.0 for x, y in wp)
+
+
+def test_shard_ranges_partition_the_batch():
+    for total, ws in ((65536, 8), (10, 3), (7, 8)):
+        r = [shard_range(k, ws, total) for k in range(ws)]
+        assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert shard_range(3, 8, 65536) == (3 * 8192, 4 * 8192)

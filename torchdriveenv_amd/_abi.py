@@ -45,6 +45,8 @@ class TdeConfig(C.Structure):
         ("terminated_at_infraction", C.c_int32),
         ("flags", C.c_uint32),
         ("npc_cone_range", C.c_float),
+        ("env_base", C.c_uint32),
+        ("_pad0", C.c_int32),
     ]
 
 
@@ -129,6 +131,7 @@ def default_config(**over):
     cfg.max_steps = 200
     cfg.terminated_at_infraction = 1
     cfg.flags = F_ALL
+    cfg.env_base = 0
     for k, v in over.items():
         if not hasattr(cfg, k):
             raise AttributeError(f"tde_config has no field {k!r}")

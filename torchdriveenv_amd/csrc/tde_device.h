@@ -150,7 +150,7 @@ TDE_DEV float point_tri_d2_packed(float px, float py, const float4 *__restrict__
 }
 
 // ---- offroad through the grid index ---------------------------------------------------------------------------------
-// cell word: bits 0-1 class (EMPTY / MIXED / FULL), bits 2-7 number of candidate triangles, bits 8-31 first record in
+// cell word: bits 0-1 class (EMPTY / MIXED / FULL), bits 2-9 number of candidate triangles, bits 10-31 first record in
 // w.cell_tri.  The classification is conservative by GRID_MARGIN (world.py: build_grid_index), so the mask equals the
 // oracle's brute force over every triangle.
 TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, float py)
@@ -198,8 +198,8 @@ TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float 
             const int ci = __ffs((int)pending) - 1;
             pending &= pending - 1u;
             const uint32_t wd = TDE_SEL4(ci, w0, w1, w2, w3);
-            cur = wd >> 8;
-            end = cur + ((wd >> 2) & 63u);
+            cur = wd >> 10;
+            end = cur + ((wd >> 2) & 255u);
             qx = TDE_SEL4(ci, px0, px1, px2, px3);
             qy = TDE_SEL4(ci, py0, py1, py2, py3);
             work = true;

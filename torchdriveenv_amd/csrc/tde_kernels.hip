@@ -127,8 +127,9 @@ template <int A>
 TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a, Agent &ag, EnvRegs &er)
 {
     uint32_t ep = (uint32_t)er.episode;
+    const uint32_t ge = cfg.env_base + (uint32_t)e;     // global env index keys the stream
     uint32_t r0[4];
-    philox(cfg.seed, (uint32_t)e, ep, 0u, 0x7DEu, r0);
+    philox(cfg.seed, ge, ep, 0u, 0x7DEu, r0);
     int scn = (int)(((uint64_t)r0[0] * (uint64_t)w.n_scn) >> 32);
     er.scn = scn;
     er.steps = 0;
@@ -144,7 +145,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
     ag.present = sj.y != 0;
     if (a == 0) {
         uint32_t r1[4], rn[4];
-        philox(cfg.seed, (uint32_t)e, ep, 1u, 0x7DEu, r1);
+        philox(cfg.seed, ge, ep, 1u, 0x7DEu, r1);
         const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
         double f = u01(r0[1]);
         double sx = wp[0] + f * (wp[2] - wp[0]);
@@ -152,7 +153,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
         double speed = u01(r0[2]) * 10.0;
         double acc = 0.0;
         for (uint32_t b = 0; b < 3; ++b) {
-            philox(cfg.seed, (uint32_t)e, ep, 2u + b, 0x7DEu, rn);
+            philox(cfg.seed, ge, ep, 2u + b, 0x7DEu, rn);
             for (int k = 0; k < 4; ++k) acc += u01(rn[k]);
         }
         double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (acc - 6.0) * 0.1;
@@ -698,8 +699,8 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
                 const uint32_t cls = wd & 3u;
                 bool road = cls == TDE_CELL_FULL;
                 if (cls == TDE_CELL_MIXED) {
-                    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 8);
-                    const int n = (int)((wd >> 2) & 63u);
+                    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
+                    const int n = (int)((wd >> 2) & 255u);
                     for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
                 }
                 if (road) layer = 1;

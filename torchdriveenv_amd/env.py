@@ -1,0 +1,384 @@
+"""Host-side mirror of the reference's env surface over the HIP step path.
+
+  * `BatchedWaypointEnv`  — B envs per GPU in one fused kernel per step; device-resident torch outputs (fast path) and
+    an SB3-`VecEnv`-shaped numpy API (`step_async/step_wait`, auto-reset with `terminal_observation`), so
+    `SubprocVecEnv` (ref examples/rl_training.py:159) is unnecessary.
+  * `WaypointSuiteEnv` + `SingleAgentWrapper` — the B=1, one-exposed-agent interface the reference registers as
+    'torchdriveenv-v0' (ref __init__.py:10, gym_env.py:303-487): same signatures, shapes, dtypes and info keys.
+
+What stays in Python is only argument marshalling; every number comes from libtde_hip.so.  There is no CPU fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _abi, ops
+from .config import EnvConfig, WaypointSuite, to_tde_config
+from .state import EnvState
+from .world import World, assemble_world, corridor_mesh
+
+try:  # optional: neither gymnasium nor SB3 ships in this image
+    import gymnasium as gym
+    _GymEnvBase, _GymWrapperBase = gym.Env, gym.Wrapper
+except Exception:  # pragma: no cover
+    gym = None
+    _GymEnvBase = object
+
+    class _GymWrapperBase:
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):
+            if name == "env":
+                raise AttributeError(name)
+            return getattr(self.env, name)
+
+
+class Box:
+    """stand-in for gym.spaces.Box when gymnasium is absent (same attributes)"""
+
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.low = np.asarray(low, dtype=dtype) if shape is None else np.full(shape, low, dtype=dtype)
+        self.high = np.asarray(high, dtype=dtype) if shape is None else np.full(shape, high, dtype=dtype)
+        self.shape = self.low.shape
+        self.dtype = np.dtype(dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and np.all(x >= self.low) and np.all(x <= self.high)
+
+
+def _box(low, high, shape=None, dtype=np.float32):
+    if gym is not None:
+        return gym.spaces.Box(low=low, high=high, shape=shape, dtype=dtype) if shape is not None else \
+            gym.spaces.Box(low=np.asarray(low, dtype=dtype), high=np.asarray(high, dtype=dtype), dtype=dtype)
+    return Box(low, high, shape, dtype)
+
+
+# action space of the reference: acceleration in [-1, 1], steering in [-0.3, 0.3], raw units (ref gym_env.py:83-94)
+ACTION_LOW, ACTION_HIGH = (-1.0, -0.3), (1.0, 0.3)
+
+
+def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=12.0, threshold=0.5):
+    """WaypointSuite -> World.  Agent ordering follows the reference: slot 0 ego, then the scenario's agents
+    (ref gym_env.py:219-228); `car_sequence_suite[i][k]` replays slot k (ref gym_env.py:275-283).
+    The CARLA town meshes the reference takes from torchdrivesim's package data are not available, so each scenario
+    gets a synthetic drivable corridor around its waypoints, scenario agents and replay paths; non-replayed scenario
+    agents get a straight route along their initial heading for the heuristic NPC controller."""
+    meshes, scenarios = [], []
+    n = len(data.waypoint_suite)
+    for i in range(n):
+        wps = [tuple(p) for p in data.waypoint_suite[i]]
+        scen = data.scenarios[i] if data.scenarios is not None else None
+        seqs = (data.car_sequence_suite[i] if data.car_sequence_suite is not None else None) or {}
+        seqs = {int(k): v for k, v in seqs.items()}
+        polylines = [wps]
+        agents = []
+        if scen is not None and scen.agent_states:
+            for k, (s, a) in enumerate(zip(scen.agent_states, scen.agent_attributes)):
+                slot = k + 1
+                x, y, psi, v = [float(t) for t in s[:4]]
+                replay = seqs.get(slot)
+                route = None
+                if replay is None:
+                    ahead = max(30.0, 25.0 * max(v, 1.0))
+                    route = [(x + math.cos(psi) * d, y + math.sin(psi) * d) for d in np.arange(8.0, ahead, 8.0)]
+                    polylines.append([(x, y)] + route)
+                else:
+                    polylines.append([(r[0], r[1]) for r in replay[::10]] + [(replay[-1][0], replay[-1][1])])
+                agents.append(dict(state=(x, y, psi, v), attr=tuple(float(t) for t in a[:3]), vdes=v, route=route,
+                                   replay=[tuple(float(t) for t in r[:4]) for r in replay] if replay else None))
+        for slot, replay in seqs.items():          # replay cars that are not scenario agents
+            if slot - 1 >= len(agents) and replay:
+                r0 = replay[0]
+                agents.append(dict(state=tuple(float(t) for t in r0[:4]), attr=(5.0, 2.0, 1.9), vdes=0.0, route=None,
+                                   replay=[tuple(float(t) for t in r[:4]) for r in replay]))
+                polylines.append([(r[0], r[1]) for r in replay[::10]] + [(replay[-1][0], replay[-1][1])])
+        heading = math.atan2(wps[1][1] - wps[0][1], wps[1][0] - wps[0][0])
+        meshes.append(corridor_mesh(polylines, width=road_width))
+        scenarios.append(dict(map=i, waypoints=wps, start_heading=heading, agents=agents[:agents_per_env - 1]))
+    return assemble_world(meshes, scenarios, agents_per_env, threshold=threshold)
+
+
+class BatchedWaypointEnv:
+    """`num_envs` independent WaypointSuite envs stepped by one fused HIP kernel per timestep.
+
+    step(actions [B,2]) -> (obs, reward f32[B], terminated bool[B], truncated bool[B], info dict of [B] tensors), all
+    device-resident torch tensors.  obs is the ego-centred birdview uint8 [B, 3*frame_stack, 64, 64] (obs_mode
+    "birdview", the reference's observation, ref gym_env.py:95,122-124) or a compact float32 [B, 8] kinematic vector
+    (obs_mode "state").  Finished envs are re-spawned inside the same kernel (auto_reset=True)."""
+
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 10}   # ref gym_env.py:73-76
+
+    def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
+                 frame_stack=1, auto_reset=True, with_info=True):
+        if cfg.render_mode is not None and cfg.render_mode not in ("rgb_array", "video"):
+            raise NotImplementedError                              # ref gym_env.py:79-80
+        if obs_mode not in ("birdview", "state"):
+            raise ValueError("obs_mode must be 'birdview' or 'state'")
+        self.config = cfg
+        dev = device or cfg.device or ("cuda" if torch.cuda.is_available() else None)
+        if dev is None or not torch.cuda.is_available():
+            raise RuntimeError("torchdriveenv_amd needs a HIP device: there is no CPU path")
+        self.torch_device = torch.device(dev if str(dev) != "cuda" else "cuda:0")
+        self.world = data if isinstance(data, World) else world_from_waypoint_suite(
+            data, agents_per_env, threshold=cfg.simulator.offroad_threshold)
+        self.A = self.world.A
+        self.num_envs = int(num_envs)
+        seed = cfg.seed if cfg.seed is not None else int(np.random.randint(0, 2**31 - 1))  # ref helpers.py:39-41
+        self.seed_value = seed
+        flags = _abi.F_NPC | _abi.F_REPLAY | _abi.F_OFFROAD | _abi.F_REWARD
+        if auto_reset:
+            flags |= _abi.F_AUTORESET
+        if cfg.ego_only:
+            flags |= _abi.F_EGO_ONLY_ATTRS
+        self.tde_cfg = to_tde_config(cfg, seed, flags)
+        self.dworld = self.world.to_device(self.torch_device)
+        self.state = EnvState(self.num_envs, self.A, device=self.torch_device, with_info=with_info)
+        self.obs_mode, self.frame_stack = obs_mode, max(1, int(frame_stack))
+        r = cfg.simulator.renderer
+        self._res, self._fov = int(r.res), float(r.fov)
+        self._obs = None
+        self.action_space = _box(ACTION_LOW, ACTION_HIGH)
+        self.observation_space = (_box(0, 255, (3 * self.frame_stack, self._res, self._res), np.uint8)
+                                  if obs_mode == "birdview" else _box(-np.inf, np.inf, (8,), np.float32))
+        self.reward_range = (-float("inf"), float("inf"))           # ref gym_env.py:97
+        self._pending = None
+
+    # ---- device-resident API ------------------------------------------------------------------------------
+    def reset(self, seed=None, options=None, mask=None):
+        """re-spawn all envs (or those in `mask`, uint8/bool [B]).  `seed` is ignored like in the reference
+        (ref gym_env.py:107-109); seeding is EnvConfig.seed."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.torch_device).to(torch.uint8).contiguous()
+        ops.env_reset(self.tde_cfg, self.dworld, self.state, m)
+        if self.obs_mode == "birdview" and self.frame_stack > 1:
+            if self._obs is None or m is None:
+                self._obs = None
+            else:
+                self._obs[m.bool()] = 0                              # VecFrameStack clears the stack on reset
+        return self.get_obs()
+
+    def step(self, actions):
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).reshape(self.num_envs, 2)
+        self.state["action"].copy_(a)
+        ops.env_step(self.tde_cfg, self.dworld, self.state)
+        st = self.state
+        return (self.get_obs(), st["reward"], st["terminated"].bool(), st["truncated"].bool(), self.get_info())
+
+    def rollout(self, actions):
+        """K open-loop steps from a resident [K,B,2] action tensor -> (reward [K,B], done bits [K,B])"""
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).contiguous()
+        return ops.env_rollout(self.tde_cfg, self.dworld, self.state, a)
+
+    def get_obs(self):
+        if self.obs_mode == "state":
+            return self._state_obs()
+        self._obs = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov,
+                                   self.frame_stack, self._obs)
+        return self._obs
+
+    def _state_obs(self):
+        st, B, A = self.state, self.num_envs, self.A
+        ego = slice(0, B * A, A)
+        x, y, psi, v = st["x"][ego], st["y"][ego], st["psi"][ego], st["v"][ego]
+        wp = self.dworld.tensors["wp_xy"].view(-1, self.world.ints["NW"], 2)
+        scn = st["scn"].long()
+        n_wp = torch.from_numpy(np.ascontiguousarray(self.world.arrays["scn"]["wp_n"])).to(self.torch_device)[scn]
+        ti = torch.minimum(st["target_idx"].long(), n_wp.long() - 1)
+        tgt = wp[scn, ti].to(torch.float32)
+        dx, dy = tgt[:, 0] - x, tgt[:, 1] - y
+        c, s = torch.cos(psi), torch.sin(psi)
+        return torch.stack([x, y, psi, v, dx * c + dy * s, dy * c - dx * s,
+                            (st["target_idx"] < n_wp).float(), st["steps"].float()], -1)
+
+    def get_info(self):
+        """info schema of the reference (ref gym_env.py:419-437), one entry per env"""
+        st, A = self.state, self.A
+        ego = slice(0, self.num_envs * A, A)
+        info = dict(offroad=st["offroad"][ego].float(), collision=st["collided"][ego].float(),
+                    traffic_light_violation=torch.zeros(self.num_envs, device=self.torch_device),
+                    is_success=st["truncated"].bool())
+        if st["info"] is not None:
+            inf = st["info"]
+            info.update(reached_waypoint_num=st["info_reached"], psi_smoothness=inf[:, 0], speed_smoothness=inf[:, 1],
+                        psi_reward=inf[:, 2], dist_reward=inf[:, 3])
+        return info
+
+    def render(self):
+        """(B, H, W, 3) uint8 of the current ego views (ref gym_env.py:152-155)"""
+        img = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1)
+        return img.permute(0, 2, 3, 1).cpu().numpy()
+
+    def close(self):
+        pass
+
+    def state_dict(self):
+        """snapshot of every mutable buffer (checkpoint / parity replays)"""
+        return {k: v.clone() for k, v in self.state.arrays.items() if v is not None}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            self.state.arrays[k].copy_(v)
+
+    # ---- SB3 VecEnv-shaped numpy API (compatibility path: one D2H copy per step) -------------------------
+    def step_async(self, actions):
+        self._pending = np.asarray(actions, dtype=np.float32)
+
+    def step_wait(self):
+        if self._pending is None:
+            raise RuntimeError("step_wait() without step_async()")
+        acts, self._pending = self._pending, None
+        auto = bool(self.tde_cfg.flags & _abi.F_AUTORESET)
+        # terminal_observation needs the pre-reset frame: run the step without in-kernel reset, then reset the
+        # finished envs with the masked reset kernel
+        self.tde_cfg.flags &= ~_abi.F_AUTORESET
+        try:
+            obs, rew, term, trunc, info = self.step(acts)
+        finally:
+            if auto:
+                self.tde_cfg.flags |= _abi.F_AUTORESET
+        done = (term | trunc)
+        obs_np = obs.cpu().numpy().copy()
+        rew_np, done_np = rew.cpu().numpy().copy(), done.cpu().numpy().copy()
+        trunc_np, term_np = trunc.cpu().numpy(), term.cpu().numpy()
+        info_np = {k: v.cpu().numpy() for k, v in info.items()}
+        infos = []
+        for i in range(self.num_envs):
+            d = {k: (v[i].item() if hasattr(v[i], "item") else v[i]) for k, v in info_np.items()}
+            d["TimeLimit.truncated"] = bool(trunc_np[i] and not term_np[i])
+            infos.append(d)
+        if auto and done_np.any():
+            new_obs = self.reset(mask=done).cpu().numpy()
+            for i in np.nonzero(done_np)[0]:
+                infos[i]["terminal_observation"] = obs_np[i]
+                obs_np[i] = new_obs[i]
+        return obs_np, rew_np, done_np, infos
+
+    def vec_step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def vec_reset(self):
+        return self.reset().cpu().numpy()
+
+    def get_attr(self, name, indices=None):
+        n = self.num_envs if indices is None else len(indices)
+        return [getattr(self, name)] * n
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self, name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return [getattr(self, method_name)(*args, **kwargs)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * (self.num_envs if indices is None else len(indices))
+
+    def seed(self, seed=None):                                      # ref gym_env.py:149-150 (no-op there too)
+        return [None] * self.num_envs
+
+
+class WaypointSuiteEnv(_GymEnvBase):
+    """B = 1 env with the reference's (B, A_exposed) = (1, 1) tensor interface (ref gym_env.py:303-437): `step` takes
+    a (1,1,2) float32 tensor and returns obs (1,1,3,64,64) uint8 ndarray, reward float, terminated bool, truncated
+    bool, info with (1,1) tensors — what `SingleAgentWrapper` then squeezes."""
+
+    metadata = {"render_modes": ["video", "rgb_array"], "render_fps": 10}
+
+    def __init__(self, cfg: EnvConfig, data, agents_per_env=8):
+        self.config = cfg
+        self._env = BatchedWaypointEnv(cfg, data, num_envs=1, agents_per_env=agents_per_env, obs_mode="birdview",
+                                       frame_stack=1, auto_reset=False)
+        self.torch_device = self._env.torch_device
+        self.render_mode = cfg.render_mode
+        self.max_environment_steps = cfg.max_environment_steps
+        self.action_space = _box(ACTION_LOW, ACTION_HIGH)
+        self.observation_space = _box(0, 255, (3, 64, 64), np.uint8)
+        self.reward_range = (-float("inf"), float("inf"))
+        self.collision_threshold = 0.0
+        self.offroad_threshold = 0.0
+
+    @property
+    def environment_steps(self):
+        return int(self._env.state["steps"][0])
+
+    @property
+    def current_target_idx(self):
+        return int(self._env.state["target_idx"][0])
+
+    @property
+    def reached_waypoint_num(self):
+        return int(self._env.state["reached"][0])
+
+    def reset(self, seed=None, options=None):                       # ref gym_env.py:319-349
+        obs = self._env.reset()
+        return obs.cpu().numpy().reshape(1, 1, 3, 64, 64).astype(np.uint8), {}
+
+    def step(self, action):                                         # ref gym_env.py:369-389
+        obs, rew, term, trunc, info = self._env.step(torch.as_tensor(action).reshape(1, 2))
+        info = {k: (v.reshape(1, 1) if k in ("offroad", "collision", "traffic_light_violation") else
+                    (bool(v[0]) if v.dtype == torch.bool else v[0].item())) for k, v in info.items()}
+        return (obs.cpu().numpy().reshape(1, 1, 3, 64, 64).astype(np.uint8), float(rew[0]), bool(term[0]),
+                bool(trunc[0]), info)
+
+    def render(self):                                               # ref gym_env.py:152-157
+        if self.render_mode == "rgb_array":
+            return self._env.render()[0]
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+    def seed(self, seed=None):
+        pass
+
+
+class SingleAgentWrapper(_GymWrapperBase):
+    """Removes batch and agent dimensions (ref gym_env.py:440-487): numpy (2,) action in, obs (3,64,64) uint8,
+    reward float, terminated bool, truncated bool, info with 0-d CPU tensors out."""
+
+    def __init__(self, env):
+        super().__init__(env)
+
+    def reset(self, **kwargs):
+        obs, info = self.env.reset(**kwargs)
+        return self.transform_out(obs), info
+
+    def step(self, action):
+        action = torch.Tensor(action).unsqueeze(0).unsqueeze(0).to(self.env.torch_device)   # ref :454
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        return (self.transform_out(obs), self.transform_out(reward), self.transform_out(terminated), truncated,
+                self.transform_out(info))
+
+    def transform_out(self, x):                                     # ref gym_env.py:463-472
+        if torch.is_tensor(x):
+            return x.squeeze(0).squeeze(0).cpu()
+        if isinstance(x, dict):
+            return {k: self.transform_out(v) for k, v in x.items()}
+        if isinstance(x, np.ndarray):
+            return self.transform_out(torch.tensor(x)).cpu().numpy()
+        return x
+
+    def render(self, *args, **kwargs):
+        return self.env.render(*args, **kwargs)
+
+    def close(self):
+        self.env.close()
+
+
+def make(cfg: EnvConfig, data, agents_per_env=8):
+    """what gym.make('torchdriveenv-v0', args={'cfg': cfg, 'data': data}) returns in the reference (ref __init__.py:10)"""
+    return SingleAgentWrapper(WaypointSuiteEnv(cfg=cfg, data=data, agents_per_env=agents_per_env))
+
+
+if gym is not None:  # pragma: no cover
+    try:
+        gym.register('torchdriveenv-v0', entry_point=lambda args: make(args['cfg'], args['data']))
+    except Exception:
+        pass

@@ -145,7 +145,7 @@ def strip_mesh(polyline, width, seg_len=5.0):
             q = a + d * ((i + 1) / k)
             tris.append([p - n, q - n, q + n])
             tris.append([p - n, q + n, p + n])
-    return np.asarray(tris, dtype=np.float64)
+    return np.asarray(tris, dtype=np.float64).reshape(-1, 3, 2)
 
 
 def disc_mesh(center, radius, n=12):
@@ -160,7 +160,13 @@ def corridor_mesh(polylines, width=12.0, seg_len=6.0, joint_radius=None):
     their CARLA town meshes are not in the reference repository)."""
     parts = []
     for pl in polylines:
-        pl = np.asarray(pl, dtype=np.float64)
+        pl = np.asarray(pl, dtype=np.float64).reshape(-1, 2)
+        keep = [0] + [i for i in range(1, len(pl)) if np.hypot(*(pl[i] - pl[i - 1])) > 1.0]   # drop repeated points
+        dedup = [keep[0]]
+        for i in keep[1:]:
+            if np.hypot(*(pl[i] - pl[dedup[-1]])) > 1.0:
+                dedup.append(i)
+        pl = pl[dedup]
         if len(pl) >= 2:
             parts.append(strip_mesh(pl, width, seg_len))
         r = joint_radius if joint_radius is not None else 0.5 * width
@@ -241,11 +247,11 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=1.0):
                    tri_base, len(tri), 0)
         packed = pack_triangles(tri32)
         counts = np.diff(g["cell_start"]).astype(np.int64)
-        assert counts.max(initial=0) <= 63, "more than 63 candidate triangles in one grid cell: use a smaller cell"
+        assert counts.max(initial=0) <= 255, "more than 255 candidate triangles in one grid cell: use a smaller cell"
         start = g["cell_start"][:-1].astype(np.int64) + rec_base
-        assert start.max(initial=0) < (1 << 24), "grid index too large for the 24-bit record offset"
+        assert start.max(initial=0) < (1 << 22), "grid index too large for the 22-bit record offset"
         word_all.append((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
-                         (start.astype(np.uint32) << 8)).astype(np.uint32))
+                         (start.astype(np.uint32) << 10)).astype(np.uint32))
         rec_all.append(packed[g["cell_tris"]])          # per-cell copies: one dependent load less in the kernel
         tri_all.append(tri32.reshape(-1, 6))
         tri_base += len(tri)
