@@ -41,7 +41,7 @@ def cpu_baseline(world, cfg, budget_s=12.0):
 
     cores = os.cpu_count() or 1
     oracle.set_num_threads(cores)
-    B = 512
+    B = 2048 if cores >= 64 else 512
     hs = EnvState(B, A_AGENTS)
     oracle.env_reset(cfg, world, hs)
     rng = np.random.default_rng(0)
@@ -158,14 +158,20 @@ def main():
     if rank == 0:
         n = world_size
         env_steps = B * n * args.steps
-        launches = args.steps                              # one fused step kernel per step
+        # dominant kernel: rollout mode = tde::env_rollout_kernel<16>, ONE launch per CH timesteps;
+        # step mode = tde::env_step_kernel<16>, one launch per timestep
+        steps_per_launch = CH if args.mode == "rollout" else 1
+        launches = -(-args.steps // steps_per_launch)
         kern_us = dev_ms * 1e3 / launches                  # HIP-event time of the region / launches
-        achieved = BYTES_PER_ENV_STEP * B / (kern_us * 1e-6) / 1e9
+        alg_bytes = BYTES_PER_ENV_STEP * B * (args.steps / launches)
+        achieved = alg_bytes / (kern_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.mode == "rollout":
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("steps_per_launch") == steps_per_launch and tj.get("envs") == B:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -179,8 +185,10 @@ def main():
                        "sharding": f"{n} independent shard(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": f"tde::env_step_kernel<{A}>", "kernel_avg_us": kern_us,
-                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * B},
+                         "kernel": f"tde::env_rollout_kernel<{A}>" if args.mode == "rollout"
+                         else f"tde::env_step_kernel<{A}>",
+                         "kernel_avg_us": kern_us, "launches": launches, "steps_per_launch": steps_per_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes, "us_per_step": dev_ms * 1e3 / args.steps},
             "check": chk,
         }
         if n == 1 and not args.no_cpu_baseline:
