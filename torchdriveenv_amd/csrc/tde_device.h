@@ -252,6 +252,31 @@ TDE_DEV bool sqrt_ge(double s, double r)
     return sqrt(s) >= r;
 }
 
+// Kernel arguments that only the rare paths (reset, waypoint switches) or the few ego lanes read.  They are parked in
+// LDS at kernel start: by-value argument structs of this path need ~110 SGPRs, more than the 102-SGPR file, and what
+// does not fit is spilled to VGPR lanes and re-read with v_readlane on every use inside the step loop.
+struct Cold {
+    double waypoint_bonus, heading_penalty, distance_bonus, distance_cutoff, reach_radius;
+    uint64_t seed;
+    const tde_spawn *spawn;
+    const tde_scenario *scn;
+    const double *wp_xy;
+    const tde_map *maps;
+    const float *route_xy;
+    uint32_t env_base;
+    int n_scn, NW, RW, max_steps, terminated_at_infraction;
+};
+
+TDE_DEV void fill_cold(Cold &c, const tde_config &cfg, const tde_world &w)
+{
+    c.waypoint_bonus = cfg.waypoint_bonus; c.heading_penalty = cfg.heading_penalty;
+    c.distance_bonus = cfg.distance_bonus; c.distance_cutoff = cfg.distance_cutoff;
+    c.reach_radius = cfg.reach_radius; c.seed = cfg.seed;
+    c.spawn = w.spawn; c.scn = w.scn; c.wp_xy = w.wp_xy; c.maps = w.maps; c.route_xy = w.route_xy;
+    c.env_base = cfg.env_base; c.n_scn = w.n_scn; c.NW = w.NW; c.RW = w.RW;
+    c.max_steps = cfg.max_steps; c.terminated_at_infraction = cfg.terminated_at_infraction;
+}
+
 struct RewardOut {
     float reward;
     uint8_t terminated, truncated;
@@ -259,7 +284,8 @@ struct RewardOut {
 };
 
 // (wtx, wty) = waypoint[target_idx], only read when target_idx < n_wp (current_target is not None, :394).
-TDE_DEV RewardOut reward_core(const tde_config &cfg, int n_wp, double wtx, double wty, float lx, float ly, float lpsi,
+template <typename CFG>
+TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, float lx, float ly, float lpsi,
                               float lv, float x, float y, float psi, float v, bool off, bool col, bool tl, int k,
                               int &target_idx, int &reached)
 {

@@ -80,7 +80,7 @@ struct Ctx {
     int n_wp;                  // ego: number of waypoints of the scenario
 };
 
-TDE_DEV void load_route_target(const tde_world &w, const Agent &ag, Ctx &cx)
+TDE_DEV void load_route_target(const Cold &w, const Agent &ag, Ctx &cx)
 {
     if (ag.route >= 0 && ag.route_wp < cx.route_n) {
         const float2 tg = reinterpret_cast<const float2 *>(w.route_xy)[(int64_t)ag.route * w.RW + ag.route_wp];
@@ -88,7 +88,7 @@ TDE_DEV void load_route_target(const tde_world &w, const Agent &ag, Ctx &cx)
     }
 }
 
-TDE_DEV void load_ego_target(const tde_world &w, const EnvRegs &er, Ctx &cx)
+TDE_DEV void load_ego_target(const Cold &w, const EnvRegs &er, Ctx &cx)
 {
     if (er.target_idx < cx.n_wp) {
         const double2 tg = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + er.target_idx];
@@ -98,7 +98,7 @@ TDE_DEV void load_ego_target(const tde_world &w, const EnvRegs &er, Ctx &cx)
 
 // sp4 = the slot's spawn record as four 16-B words (tde_spawn), or nullptr to fetch it here
 template <int A>
-TDE_DEV void load_ctx(const tde_config &cfg, const tde_world &w, int a, Agent &ag, const EnvRegs &er, Ctx &cx)
+TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, const EnvRegs &er, Ctx &cx)
 {
     const uint32_t F = cfg.flags;
     cx.tgx = cx.tgy = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0;
@@ -124,12 +124,13 @@ TDE_DEV void load_ctx(const tde_config &cfg, const tde_world &w, int a, Agent &a
 // WaypointSuiteEnv.reset + set_start_pos + build_simulator's initial tensors for one env (ref gym_env.py:319-367,
 // 192-198, 241-247); every lane of the env runs it for its own slot.  Mirrors tde_reset_env of the oracle.
 template <int A>
-TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a, Agent &ag, EnvRegs &er)
+TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er)
 {
     uint32_t ep = (uint32_t)er.episode;
-    const uint32_t ge = cfg.env_base + (uint32_t)e;     // global env index keys the stream
+    const uint32_t ge = w.env_base + (uint32_t)e;       // global env index keys the stream
+    const uint64_t seed = w.seed;
     uint32_t r0[4];
-    philox(cfg.seed, ge, ep, 0u, 0x7DEu, r0);
+    philox(seed, ge, ep, 0u, 0x7DEu, r0);
     int scn = (int)(((uint64_t)r0[0] * (uint64_t)w.n_scn) >> 32);
     er.scn = scn;
     er.steps = 0;
@@ -145,7 +146,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
     ag.present = sj.y != 0;
     if (a == 0) {
         uint32_t r1[4], rn[4];
-        philox(cfg.seed, ge, ep, 1u, 0x7DEu, r1);
+        philox(seed, ge, ep, 1u, 0x7DEu, r1);
         const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
         double f = u01(r0[1]);
         double sx = wp[0] + f * (wp[2] - wp[0]);
@@ -153,7 +154,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const tde_world &w, int e, int a,
         double speed = u01(r0[2]) * 10.0;
         double acc = 0.0;
         for (uint32_t b = 0; b < 3; ++b) {
-            philox(cfg.seed, ge, ep, 2u + b, 0x7DEu, rn);
+            philox(seed, ge, ep, 2u + b, 0x7DEu, rn);
             for (int k = 0; k < 4; ++k) acc += u01(rn[k]);
         }
         double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (acc - 6.0) * 0.1;
@@ -243,9 +244,9 @@ TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag,
 // kept up to date on exit.  `act_acc/act_steer` are the ego action of this lane's env (used by slot 0).
 // Called by all BLOCK lanes of the workgroup, converged (contains barriers and wave ballots).
 template <int A, int BLOCK>
-TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_state &st, Tiles<BLOCK> &t, int e, int a,
-                          bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0, float &s0, float act_acc,
-                          float act_steer)
+TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold &cold, const tde_state &st,
+                          Tiles<BLOCK> &t, int e, int a, bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0,
+                          float &s0, float act_acc, float act_steer)
 {
     using mask_t = typename MaskOf<A>::type;
     const uint32_t F = cfg.flags;
@@ -316,7 +317,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
         }
     }
     // the next route waypoint is fetched while the offroad test runs
-    if (switched) load_route_target(w, ag, cx);
+    if (switched) load_route_target(cold, ag, cx);
 
     bool off = false;
     if (F & TDE_F_OFFROAD)
@@ -329,7 +330,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
         int done = 0;
         if (a == 0 && valid) {
             const int ti0 = er.target_idx;
-            RewardOut r = reward_core(cfg, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
+            RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
                                       false, k, er.target_idx, er.reached);
             out.reward = r.reward;
             out.terminated = r.terminated;
@@ -340,7 +341,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
             }
             if (st.info_reached) st.info_reached[e] = er.reached;
             done = (r.terminated | r.truncated) ? 1 : 0;
-            if (er.target_idx != ti0 && !done) load_ego_target(w, er, cx);
+            if (er.target_idx != ti0 && !done) load_ego_target(cold, er, cx);
         }
         if (F & TDE_F_AUTORESET) {
             // wave ballot of the ego lanes' termination flags: the reset path is skipped by wavefronts in which no
@@ -349,8 +350,8 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const tde_s
             if (any) {
                 const int lane = tid & 63;
                 if (((any >> (lane - a)) & 1ull) && valid) {
-                    reset_lane<A>(cfg, w, e, a, ag, er);
-                    load_ctx<A>(cfg, w, a, ag, er, cx);
+                    reset_lane<A>(cfg, cold, e, a, ag, er);
+                    load_ctx<A>(cfg, cold, a, ag, er, cx);
                     out.respawned = true;
                     live = ag.present;
                     sincos_f32(ag.psi, s0, c0);
@@ -373,6 +374,9 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
                                                           uint8_t *done_k)
 {
     __shared__ Tiles<kBlock> t;
+    __shared__ Cold cold;
+    if (threadIdx.x == 0) fill_cold(cold, cfg, w);
+    __syncthreads();
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int e = (int)(g / A), a = (int)(g % A);
     const bool valid = e < st.B;
@@ -383,13 +387,13 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
     Ctx cx;
-    load_ctx<A>(cfg, w, a, ag, er, cx);
+    load_ctx<A>(cfg, cold, a, ag, er, cx);
     const float2 act = reinterpret_cast<const float2 *>(action)[es];
     float c0, s0;
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0);
     __syncthreads();
-    StepOut o = step_lane<A, kBlock>(cfg, w, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
+    StepOut o = step_lane<A, kBlock>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
     if (!valid) return;
     store_agent_dynamic(st, g, ag);
     if (o.respawned) store_agent_static(st, g, ag);
@@ -418,6 +422,9 @@ template <int A>
 __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
 {
     __shared__ Tiles<kWave> t;
+    __shared__ Cold cold;
+    if (threadIdx.x == 0) fill_cold(cold, cfg, w);
+    __syncthreads();
     const int64_t g = (int64_t)blockIdx.x * kWave + threadIdx.x;
     const int e = (int)(g / A), a = (int)(g % A);
     const int B = st.B;
@@ -429,7 +436,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
     Ctx cx;
-    load_ctx<A>(cfg, w, a, ag, er, cx);
+    load_ctx<A>(cfg, cold, a, ag, er, cx);
     const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
     float2 act = acts[es];
     float c0, s0;
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
         const float2 act_next = acts[(int64_t)kn * B + es];      // in flight during this step
-        o = step_lane<A, kWave>(cfg, w, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
+        o = step_lane<A, kWave>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
         if (valid && a == 0) {
             if (ro.reward) ro.reward[(int64_t)k * B + e] = o.reward;
             if (ro.done)
@@ -475,7 +482,9 @@ __global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_w
     if (mask && !mask[e]) return;
     Agent ag;
     EnvRegs er{0, 0, 0, 0, st.episode[e]};
-    reset_lane<A>(cfg, w, e, a, ag, er);
+    Cold cold;
+    fill_cold(cold, cfg, w);
+    reset_lane<A>(cfg, cold, e, a, ag, er);
     store_agent_dynamic(st, g, ag);
     store_agent_static(st, g, ag);
     st.collided[g] = 0;
