@@ -155,12 +155,14 @@ TDE_DEV float point_tri_d2_packed(float px, float py, const float4 *__restrict__
 // oracle's brute force over every triangle.
 TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, float py)
 {
-    float fx = (px - m.ox) * m.inv_cell;
-    float fy = (py - m.oy) * m.inv_cell;
-    bool in = fx >= 0.0f && fy >= 0.0f && fx < (float)m.nx && fy < (float)m.ny;
-    int cell = in ? m.cell_base + (int)fy * m.nx + (int)fx : m.cell_base;
-    uint32_t word = w.cell_word[cell];
-    return in ? word : (uint32_t)TDE_CELL_EMPTY;
+    // The grid is padded by >= 2 EMPTY cells on every side, so clamping the cell index to the grid (v_med3) replaces
+    // the four bounds tests: anything outside lands in an EMPTY border cell (the float->int conversion saturates for
+    // +-inf and returns 0 for NaN, both of which clamp to the border as well).
+    const float fx = (px - m.ox) * m.inv_cell;
+    const float fy = (py - m.oy) * m.inv_cell;
+    const int ix = min(max((int)fx, 0), m.nx - 1);
+    const int iy = min(max((int)fy, 0), m.ny - 1);
+    return w.cell_word[m.cell_base + iy * m.nx + ix];
 }
 
 #define TDE_SEL4(i, a0, a1, a2, a3) ((i) == 0 ? (a0) : (i) == 1 ? (a1) : (i) == 2 ? (a2) : (a3))

@@ -32,7 +32,7 @@ struct EnvRegs {   // replicated on every lane of the env
 
 // LDS tile, one slot per lane of the workgroup, two 16-B records per agent so that a sweep reads them with
 // ds_read_b128 (all lanes of an env read the same address: broadcast, no bank conflict):
-//     a = (x, y, length, width)          b = (cos psi, sin psi, hl + hw, -)
+//     a = (x, y, hl, lane_half + hw)     b = (cos psi, sin psi, hl + hw, hw)        (hl, hw = half length / width)
 // The tile always holds the CURRENT state of every slot: it is written once per step, after the integration, and
 // serves that step's collision sweep and the next step's NPC controller (whose "pre-step" state it is).
 // An absent slot is parked at x = y = kFar, which fails every cheap sweep test by itself (no present flag to read).
@@ -181,17 +181,20 @@ TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, 
     using mask_t = typename MaskOf<A>::type;
     const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
     mask_t cand = 0;
+    const float hl_i = 0.5f * ag.len;
     if (has_target) {
+        // conservative forms of the exact tests below (5 cm / 1 cm of slack >> fp32 rounding): a slot that fails
+        // here fails there; min3 > 0 folds the three conditions into one sign test
+        const float lim_i = (g_far + hl_i) + 0.05f;
 #pragma unroll
         for (int j = 0; j < A; ++j) {
             const float4 pj = t.a[base + j];
             const float ex = pj.x - ag.x, ey = pj.y - ag.y;
             const float fj = ex * cp + ey * sp;
             const float lj = ey * cp - ex * sp;
-            const float g = fj - 0.5f * (ag.len + pj.z);
-            // widest corridor = the yield cone (it contains the lane corridor for fj > 0)
-            const bool wide = fabsf(lj) < (cfg.npc_lane_half + 0.5f * pj.w) + cfg.npc_cone_k * fj;
-            cand |= ((fj > 0.0f) & (g < g_far) & wide) ? (mask_t)1 << j : (mask_t)0;
+            const float near = (lim_i + pj.z) - fj;                                  // g < g_far
+            const float wide = ((pj.w + 0.01f) + cfg.npc_cone_k * fj) - fabsf(lj);      // inside the widest corridor
+            cand |= (fminf(fminf(fj, near), wide) > 0.0f) ? (mask_t)1 << j : (mask_t)0;
         }
         cand &= ~((mask_t)1 << i);
     }
@@ -204,12 +207,14 @@ TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, 
             const float ex = pj.x - ag.x, ey = pj.y - ag.y;
             const float fj = ex * cp + ey * sp;
             const float lj = ey * cp - ex * sp;
-            const float halfw = cfg.npc_lane_half + 0.5f * pj.w;
+            const float halfw = pj.w;                      // = npc_lane_half + 0.5f * wid_j, formed by slot j
             const float al = fabsf(lj);
             const bool inlane = al < halfw;
             const float hd = cp * qj.x + sp * qj.y;
             const bool cone = (j < i) && (fj < cfg.npc_cone_range) && (al < halfw + cfg.npc_cone_k * fj) && (hd > -0.5f);
-            if (inlane || cone) gap = fminf(gap, fj - 0.5f * (ag.len + pj.z));
+            // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit (scaling by 2 commutes with rounding)
+            const float g = fj - (hl_i + pj.z);
+            if (fj > 0.0f && (inlane || cone)) gap = fminf(gap, g);
         }
     }
     if (!has_target) {
@@ -233,10 +238,11 @@ struct StepOut {
     bool respawned;
 };
 
-TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s)
+TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s, float lane_half)
 {
-    ta = live ? make_float4(ag.x, ag.y, ag.len, ag.wid) : make_float4(kFar, kFar, 0.0f, 0.0f);
-    tb = make_float4(c, s, 0.5f * ag.len + 0.5f * ag.wid, 0.0f);
+    const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
+    ta = live ? make_float4(ag.x, ag.y, hl, lane_half + hw) : make_float4(kFar, kFar, 0.0f, 0.0f);
+    tb = make_float4(c, s, hl + hw, hw);
 }
 
 // One timestep for this lane's agent slot.  WaypointSuiteEnv.step over GymEnv.step, ref gym_env.py:369-389,115-120.
@@ -290,7 +296,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
     const float ri = hl + hw;
     __syncthreads();                                // every lane is done reading the pre-step tile
-    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0);
+    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
     // Overlapping convex boxes have centres closer than the sum of their circumradii; hl+hw >= circumradius, so a
     // pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact or in fp32 arithmetic.  Phase 1 marks the
@@ -313,7 +319,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
             const int j = lowest_bit(cand);
             cand &= cand - 1;
             const float4 pj = t.a[base + j], qj = t.b[base + j];
-            hit = hit || obb_overlap(ag.x, ag.y, c0, s0, hl, hw, pj.x, pj.y, qj.x, qj.y, 0.5f * pj.z, 0.5f * pj.w);
+            hit = hit || obb_overlap(ag.x, ag.y, c0, s0, hl, hw, pj.x, pj.y, qj.x, qj.y, pj.z, qj.w);
         }
     }
     // the next route waypoint is fetched while the offroad test runs
@@ -355,7 +361,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
                     out.respawned = true;
                     live = ag.present;
                     sincos_f32(ag.psi, s0, c0);
-                    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0);   // only this lane reads its slot until
+                    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);   // only this lane reads its slot until
                 }                                                            // the next step's first barrier...
             }
         }
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     const float2 act = reinterpret_cast<const float2 *>(action)[es];
     float c0, s0;
     sincos_f32(ag.psi, s0, c0);
-    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0);
+    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
     StepOut o = step_lane<A, kBlock>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
     if (!valid) return;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     float2 act = acts[es];
     float c0, s0;
     sincos_f32(ag.psi, s0, c0);
-    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0);
+    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
     StepOut o{0.0f, 0, 0, 0, 0, false};
     for (int k = 0; k < ro.K; ++k) {
@@ -537,8 +543,8 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
     const float hl = 0.5f * len[gs], hw = 0.5f * wid[gs];
     const float ri = hl + hw;
     using mask_t = typename MaskOf<A>::type;
-    t.a[tid] = live ? make_float4(X, Y, len[gs], wid[gs]) : make_float4(kFar, kFar, 0.0f, 0.0f);
-    t.b[tid] = make_float4(c1, s1, ri, 0.0f);
+    t.a[tid] = live ? make_float4(X, Y, hl, 0.0f) : make_float4(kFar, kFar, 0.0f, 0.0f);
+    t.b[tid] = make_float4(c1, s1, ri, hw);
     __syncthreads();
     const int base = tid - a;
     mask_t cand = 0;
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
             const int j = lowest_bit(cand);
             cand &= cand - 1;
             const float4 pj = t.a[base + j], qj = t.b[base + j];
-            hit = hit || obb_overlap(X, Y, c1, s1, hl, hw, pj.x, pj.y, qj.x, qj.y, 0.5f * pj.z, 0.5f * pj.w);
+            hit = hit || obb_overlap(X, Y, c1, s1, hl, hw, pj.x, pj.y, qj.x, qj.y, pj.z, qj.w);
         }
     }
     if (valid) out[g] = hit ? 1 : 0;
