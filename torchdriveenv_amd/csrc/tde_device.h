@@ -168,24 +168,36 @@ TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, flo
 #define TDE_SEL4(i, a0, a1, a2, a3) ((i) == 0 ? (a0) : (i) == 1 ? (a1) : (i) == 2 ? (a2) : (a3))
 
 // compute_offroad() > 0 for one box: any of the corners FL, FR, RR, RL farther than sqrt(thr2) from the mesh.
-// All four cell words are fetched at once; corners in MIXED cells are then resolved by a per-lane state machine that
-// performs ONE triangle test per loop trip, so a wavefront iterates max-over-lanes(sum of tests) times instead of
-// sum-over-corners(max-over-lanes).  Must be called by all lanes of the wavefront (`live` masks the idle ones).
-TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float x, float y, float c, float s, float hl,
-                         float hw, float thr2)
+// Split in two so that the four dependent cell-word loads are in flight while other work (the collision sweep) runs:
+//   offroad_issue   computes the corners and fetches their cell words,
+//   offroad_resolve classifies them; corners in MIXED cells are resolved by a per-lane state machine that performs
+//                   ONE triangle test per loop trip, so a wavefront iterates max-over-lanes(sum of tests) times
+//                   instead of sum-over-corners(max-over-lanes).  Must be called by all lanes of the wavefront.
+struct Corners {
+    float px0, py0, px1, py1, px2, py2, px3, py3;
+    uint32_t w0, w1, w2, w3;
+};
+
+TDE_DEV void offroad_issue(const tde_world &w, const tde_map &m, bool live, float x, float y, float c, float s, float hl,
+                           float hw, Corners &k)
 {
     const float lx = hl * c, ly = hl * s, wx = hw * s, wy = hw * c;
-    const float px0 = (x + lx) - wx, py0 = (y + ly) + wy;
-    const float px1 = (x + lx) + wx, py1 = (y + ly) - wy;
-    const float px2 = (x - lx) + wx, py2 = (y - ly) - wy;
-    const float px3 = (x - lx) - wx, py3 = (y - ly) + wy;
-    uint32_t w0 = TDE_CELL_FULL, w1 = TDE_CELL_FULL, w2 = TDE_CELL_FULL, w3 = TDE_CELL_FULL;
+    k.px0 = (x + lx) - wx; k.py0 = (y + ly) + wy;
+    k.px1 = (x + lx) + wx; k.py1 = (y + ly) - wy;
+    k.px2 = (x - lx) + wx; k.py2 = (y - ly) - wy;
+    k.px3 = (x - lx) - wx; k.py3 = (y - ly) + wy;
+    k.w0 = k.w1 = k.w2 = k.w3 = TDE_CELL_FULL;
     if (live) {
-        w0 = cell_lookup(w, m, px0, py0);
-        w1 = cell_lookup(w, m, px1, py1);
-        w2 = cell_lookup(w, m, px2, py2);
-        w3 = cell_lookup(w, m, px3, py3);
+        k.w0 = cell_lookup(w, m, k.px0, k.py0);
+        k.w1 = cell_lookup(w, m, k.px1, k.py1);
+        k.w2 = cell_lookup(w, m, k.px2, k.py2);
+        k.w3 = cell_lookup(w, m, k.px3, k.py3);
     }
+}
+
+TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
+{
+    const uint32_t w0 = k.w0, w1 = k.w1, w2 = k.w2, w3 = k.w3;
     bool off = ((w0 & 3u) == TDE_CELL_EMPTY) || ((w1 & 3u) == TDE_CELL_EMPTY) || ((w2 & 3u) == TDE_CELL_EMPTY) ||
                ((w3 & 3u) == TDE_CELL_EMPTY);
     uint32_t pending = off ? 0u
@@ -202,8 +214,8 @@ TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float 
             const uint32_t wd = TDE_SEL4(ci, w0, w1, w2, w3);
             cur = wd >> 10;
             end = cur + ((wd >> 2) & 255u);
-            qx = TDE_SEL4(ci, px0, px1, px2, px3);
-            qy = TDE_SEL4(ci, py0, py1, py2, py3);
+            qx = TDE_SEL4(ci, k.px0, k.px1, k.px2, k.px3);
+            qy = TDE_SEL4(ci, k.py0, k.py1, k.py2, k.py3);
             work = true;
         }
         if (!__ballot(work)) break;
@@ -214,6 +226,14 @@ TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float 
         }
     }
     return off;
+}
+
+TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float x, float y, float c, float s, float hl,
+                         float hw, float thr2)
+{
+    Corners k;
+    offroad_issue(w, m, live, x, y, c, s, hl, hw, k);
+    return offroad_resolve(w, k, thr2);
 }
 
 // Philox4x32-10, key = seed, counter = (c0,c1,c2,c3) — the reset RNG (R16).

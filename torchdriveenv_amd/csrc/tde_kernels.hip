@@ -295,6 +295,9 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     sincos_f32(ag.psi, s0, c0);
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
     const float ri = hl + hw;
+    Corners corners;                                // cell words of the four corners: loads stay in flight during
+    if (F & TDE_F_OFFROAD)                          // the collision sweep
+        offroad_issue(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
     __syncthreads();                                // every lane is done reading the pre-step tile
     write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
@@ -326,8 +329,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     if (switched) load_route_target(cold, ag, cx);
 
     bool off = false;
-    if (F & TDE_F_OFFROAD)
-        off = box_offroad(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, cfg.offroad_threshold * cfg.offroad_threshold);
+    if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, cfg.offroad_threshold * cfg.offroad_threshold);
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 

@@ -43,7 +43,7 @@ def _pairs_point_tri_dist(p, tri):
     return np.where(inside, 0.0, np.sqrt(d2))
 
 
-def build_grid_index(tri, threshold=0.5, cell=1.0, margin=GRID_MARGIN, lattice=4):
+def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4):
     """Uniform-grid index over a triangle soup `tri` [n,3,2] for the offroad test.
 
     For every cell: the list of triangles that can be within `threshold` of some point of the cell, and a class:
@@ -227,7 +227,7 @@ class DeviceWorld:
         self.struct = _abi.fill_world_struct(tensors, ints)
 
 
-def assemble_world(meshes, scenarios, A, threshold=0.5, cell=1.0):
+def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5):
     """meshes: list of [n,3,2] triangle arrays; scenarios: list of dicts with keys
          map (int), waypoints [(x,y)...], start_heading (float),
          agents: list (slots 1..) of dict(state=(x,y,psi,v), attr=(L,W,lr), vdes, route=[(x,y)..] or None,
