@@ -42,6 +42,7 @@ extern "C" {
 
 /* cell classes of the offroad grid index (HIP side only; the oracle is brute force over triangles) */
 #define TDE_CELL_MAX_TRIS 255u
+#define TDE_CLEARANCE_UNIT 0.125f
 #define TDE_CELL_EMPTY 0u  /* every point of the cell is farther than threshold from every triangle  */
 #define TDE_CELL_MIXED 1u  /* test the cell's candidate triangles                                    */
 #define TDE_CELL_FULL  2u  /* every point of the cell is within threshold of some triangle            */
@@ -113,8 +114,10 @@ typedef struct tde_scenario {
 typedef struct tde_world {
     const tde_map *maps;        /* [n_maps] */
     const float *tri;           /* [n_tri_total][6]  ax,ay,bx,by,cx,cy (what the oracle's brute force reads) */
-    const uint32_t *cell_word;  /* [n_cells_total] grid index (kernels): bits 0-1 TDE_CELL_*, bits 2-9 number of
-                                   candidate triangles, bits 10-31 first record of the cell in cell_tri */
+    const uint32_t *cell_word;  /* [n_cells_total] grid index (kernels): bits 0-1 TDE_CELL_*; MIXED cells: bits 2-9
+                                   number of candidate triangles, bits 10-31 first record in cell_tri; FULL / EMPTY
+                                   cells: bits 2-9 clearance in units of TDE_CLEARANCE_UNIT (every point that close to the cell
+                                   lies in a cell of the same class) */
     const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
                                    ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 */
     const tde_scenario *scn;    /* [S] */

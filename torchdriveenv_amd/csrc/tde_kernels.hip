@@ -624,21 +624,33 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
 }
 
 // ---- R13: ego-centred birdview raster (get_obs -> render_egocentric, ref gym_env.py:122-124; layers: tde_abi.h) ----
-// One workgroup per env view.  The env's agents and remaining ego waypoints are culled against the view circle into
-// LDS lists first (a typical view holds 2-5 of the 16-32 agents), then every lane shades 16 consecutive pixels of a
-// row and writes them as one 16-B store per colour plane (channels-first uint8: fully coalesced 12 KiB per view).
+// One workgroup per env view, image staged in LDS (12 KiB for 3x64x64).
+//   pass 0  agents / remaining waypoints culled against the view circle into LDS lists with conservative pixel-space
+//           bounding boxes (a typical view holds 2-5 of the 16-32 agents); older frames of a frame stack shifted;
+//   pass 1  one lane per 4x4 pixel block: ONE grid lookup at the block centre — the cell word's clearance says whether
+//           every pixel of the block falls in cells of that same class (all road / all background); blocks that also
+//           miss every object box are filled with four 32-bit LDS stores per colour plane, the others are queued;
+//   pass 2  the queued blocks' pixels are shaded exactly like the oracle (per-pixel grid lookup + candidate triangle
+//           tests, waypoint discs, agent boxes), 16 pixels of a block spread over 16 lanes so no lane idles;
+//   pass 3  the LDS image is streamed out with 16-B stores: 12 KiB per view, fully coalesced.
+// Every shortcut is conservative (supersets / clearance margins), so each pixel equals the per-pixel specification.
 constexpr int kRenderMaxWp = 64;
+constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS image)
+
+struct RenderBox { float x, y, c, s, hl, hw; int rmin, rmax, cmin, cmax; };
+
 __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_world w, tde_state st, tde_render rd)
 {
-    __shared__ float4 s_box[TDE_MAX_AGENTS];     // x, y, cos, sin
-    __shared__ float2 s_ext[TDE_MAX_AGENTS];     // hl, hw
-    __shared__ float2 s_wp[kRenderMaxWp];
-    __shared__ int s_nbox, s_nwp;
-    __shared__ float s_ego[6];                   // x, y, cos, sin, hl, hw
+    __shared__ uint32_t s_img[3 * kRenderMaxPix / 4];
+    __shared__ RenderBox s_box[TDE_MAX_AGENTS];          // slot 0.. = NPC boxes in view, ego kept separately
+    __shared__ float4 s_wp[kRenderMaxWp];                // x, y, then pixel bbox packed as 2 x (min | max << 16)
+    __shared__ RenderBox s_ego;
+    __shared__ uint16_t s_work[kBlock];
+    __shared__ int s_nbox, s_nwp, s_nwork;
     const int e = blockIdx.x, tid = threadIdx.x;
     const int A = st.A, H = rd.H, W = rd.W;
     const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
-    const int64_t plane = (int64_t)H * W;
+    const int plane = H * W;
     uint8_t *out = rd.out + (int64_t)e * 3 * ns * plane;
     const int64_t g0 = (int64_t)e * A;
     const int scn = st.scn[e];
@@ -646,25 +658,36 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     const tde_map m = w.maps[sc.x];
     const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
     const float res = rd.fov / (float)W;
+    const float inv_res = 1.0f / res;
+    const float halfH = 0.5f * (float)H, halfW = 0.5f * (float)W;
     // view circle: half diagonal of the image plus slack; lists are supersets, so culling cannot change a pixel
     const float rview = 0.75f * res * (float)(H > W ? H : W) + 1.0f;
-    if (tid == 0) { s_nbox = 0; s_nwp = 0; }
+    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; }
     const float ex = st.x[g0], ey = st.y[g0];
+    float se, ce;
+    sincos_f32(st.psi[g0], se, ce);
     __syncthreads();
+
+    // conservative pixel bounding box (rows/cols, inclusive) of a disc of radius rad around world point (x, y)
+    auto pixel_bbox = [&](float x, float y, float rad, int &rmin, int &rmax, int &cmin, int &cmax) {
+        const float dx = x - ex, dy = y - ey;
+        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
+        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.5f;
+        rmin = (int)floorf(rc - pr); rmax = (int)ceilf(rc + pr);
+        cmin = (int)floorf(cc - pr); cmax = (int)ceilf(cc + pr);
+    };
     if (tid < A) {
         const int64_t g = g0 + tid;
         float sa, ca;
         sincos_f32(st.psi[g], sa, ca);
-        const float x = st.x[g], y = st.y[g], hl = 0.5f * st.len[g], hw = 0.5f * st.wid[g];
+        RenderBox b;
+        b.x = st.x[g]; b.y = st.y[g]; b.c = ca; b.s = sa; b.hl = 0.5f * st.len[g]; b.hw = 0.5f * st.wid[g];
+        pixel_bbox(b.x, b.y, b.hl + b.hw, b.rmin, b.rmax, b.cmin, b.cmax);
         if (tid == 0) {
-            s_ego[0] = x; s_ego[1] = y; s_ego[2] = ca; s_ego[3] = sa; s_ego[4] = hl; s_ego[5] = hw;
+            s_ego = b;
         } else if (st.present[g]) {
-            const float dx = x - ex, dy = y - ey, rr = rview + (hl + hw);
-            if (dx * dx + dy * dy <= rr * rr) {
-                const int k = atomicAdd(&s_nbox, 1);
-                s_box[k] = make_float4(x, y, ca, sa);
-                s_ext[k] = make_float2(hl, hw);
-            }
+            const float dx = b.x - ex, dy = b.y - ey, rr = rview + (b.hl + b.hw);
+            if (dx * dx + dy * dy <= rr * rr) s_box[atomicAdd(&s_nbox, 1)] = b;
         }
     }
     {
@@ -675,13 +698,19 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
             const float dx = tx - ex, dy = ty - ey, rr = rview + TDE_WAYPOINT_RADIUS;
             if (dx * dx + dy * dy <= rr * rr) {
                 const int q = atomicAdd(&s_nwp, 1);
-                if (q < kRenderMaxWp) s_wp[q] = make_float2(tx, ty);
+                if (q < kRenderMaxWp) {
+                    int rmin, rmax, cmin, cmax;
+                    pixel_bbox(tx, ty, TDE_WAYPOINT_RADIUS, rmin, rmax, cmin, cmax);
+                    rmin = max(rmin, -1); cmin = max(cmin, -1); rmax = min(max(rmax, -1), 4095); cmax = min(max(cmax, -1), 4095);
+                    s_wp[q] = make_float4(tx, ty, __int_as_float((rmin + 1) | ((rmax + 1) << 16)),
+                                          __int_as_float((cmin + 1) | ((cmax + 1) << 16)));
+                }
             }
         }
     }
     // frame stack: shift the older frames down by one frame (read everything, barrier, write)
     if (ns > 1) {
-        const int nvec = (int)(3 * (ns - 1) * plane / 16);
+        const int nvec = 3 * (ns - 1) * plane / 16;
         const uint4 *src = reinterpret_cast<const uint4 *>(out + 3 * plane);
         uint4 *dst = reinterpret_cast<uint4 *>(out);
         for (int i0 = 0; i0 < nvec; i0 += kBlock * 4) {
@@ -696,61 +725,97 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     }
     __syncthreads();
     const int nbox = s_nbox, nwp = s_nwp < kRenderMaxWp ? s_nwp : kRenderMaxWp;
-    const float ce = s_ego[2], se = s_ego[3], ehl = s_ego[4], ehw = s_ego[5];
-    uint8_t *img = out + 3 * (ns - 1) * plane;
     const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
                    NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
-    const int nchunk = (int)(plane / 16);
-    for (int ch = tid; ch < nchunk; ch += kBlock) {
-        const int r = (ch * 16) / W, c0 = (ch * 16) % W;
-        const float f = (0.5f * (float)H - ((float)r + 0.5f)) * res;
-        uint32_t pr[4] = {0, 0, 0, 0}, pg[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const float l = (0.5f * (float)W - ((float)(c0 + i) + 0.5f)) * res;
-            const float wx = (ex + f * ce) - l * se;
-            const float wy = (ey + f * se) + l * ce;
-            int layer = 0;                                        // 0 bg, 1 road, 2 waypoint, 3 npc, 4 ego
-            {
-                const uint32_t wd = cell_lookup(w, m, wx, wy);
-                const uint32_t cls = wd & 3u;
-                bool road = cls == TDE_CELL_FULL;
-                if (cls == TDE_CELL_MIXED) {
-                    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
-                    const int n = (int)((wd >> 2) & 255u);
-                    for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
-                }
-                if (road) layer = 1;
-            }
-            for (int k = 0; k < nwp; ++k) {
-                const float2 t = s_wp[k];
-                const float dx = wx - t.x, dy = wy - t.y;
-                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
-            }
-            for (int k = 0; k < nbox; ++k) {
-                const float4 b = s_box[k];
-                const float2 x2 = s_ext[k];
-                const float dx = wx - b.x, dy = wy - b.y;
-                const float p = dx * b.z + dy * b.w, q = dy * b.z - dx * b.w;
-                if (fabsf(p) <= x2.x && fabsf(q) <= x2.y) layer = 3;
-            }
-            {
-                const float dx = wx - ex, dy = wy - ey;
-                const float p = dx * ce + dy * se, q = dy * ce - dx * se;
-                if (fabsf(p) <= ehl && fabsf(q) <= ehw) layer = 4;
-            }
-            const uint32_t R = TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
-            const uint32_t G = TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
-            const uint32_t Bc = TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
-            pr[i >> 2] |= R << (8 * (i & 3));
-            pg[i >> 2] |= G << (8 * (i & 3));
-            pb[i >> 2] |= Bc << (8 * (i & 3));
+    const int Wq = W / 4;                                 // dwords per image row
+    const int bw = W / 4, nblk = (H / 4) * bw;
+
+    // ---- pass 1: classify 4x4 blocks -------------------------------------------------------------------------
+    const float rblock = 1.5f * 1.41421356f * res * 1.01f + 0.02f;   // pixel centres of a block lie this close to its centre
+    for (int bi = tid; bi < nblk; bi += kBlock) {
+        const int r0 = (bi / bw) * 4, c0 = (bi % bw) * 4;
+        const float f = (halfH - ((float)r0 + 2.0f)) * res, l = (halfW - ((float)c0 + 2.0f)) * res;
+        const float wx = (ex + f * ce) - l * se, wy = (ey + f * se) + l * ce;
+        const uint32_t wd = cell_lookup(w, m, wx, wy);
+        const uint32_t cls = wd & 3u;
+        const bool uniform = (cls != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((wd >> 2) & 255u) >= rblock);
+        bool touched = (r0 <= s_ego.rmax) && (r0 + 3 >= s_ego.rmin) && (c0 <= s_ego.cmax) && (c0 + 3 >= s_ego.cmin);
+        for (int k = 0; k < nbox; ++k)
+            touched = touched || ((r0 <= s_box[k].rmax) && (r0 + 3 >= s_box[k].rmin) && (c0 <= s_box[k].cmax) &&
+                                  (c0 + 3 >= s_box[k].cmin));
+        for (int k = 0; k < nwp; ++k) {
+            const int rr = __float_as_int(s_wp[k].z), cc = __float_as_int(s_wp[k].w);
+            touched = touched || ((r0 + 1 <= (rr >> 16)) && (r0 + 4 >= (rr & 0xffff)) && (c0 + 1 <= (cc >> 16)) &&
+                                  (c0 + 4 >= (cc & 0xffff)));
         }
-        const int64_t o = (int64_t)r * W + c0;
-        *reinterpret_cast<uint4 *>(img + o) = make_uint4(pr[0], pr[1], pr[2], pr[3]);
-        *reinterpret_cast<uint4 *>(img + plane + o) = make_uint4(pg[0], pg[1], pg[2], pg[3]);
-        *reinterpret_cast<uint4 *>(img + 2 * plane + o) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+        if (uniform && !touched) {
+            const bool road = cls == TDE_CELL_FULL;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const uint32_t v = (road ? ROAD[ch] : BG[ch]) * 0x01010101u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_img[ch * (plane / 4) + (r0 + i) * Wq + (c0 >> 2)] = v;
+            }
+        } else {
+            // bit 15: the road layer of the whole block is known; bit 14: it is road
+            s_work[atomicAdd(&s_nwork, 1)] = (uint16_t)(bi | (uniform ? 0x8000 : 0) | ((cls == TDE_CELL_FULL) ? 0x4000 : 0));
+        }
     }
+    __syncthreads();
+
+    // ---- pass 2: exact per-pixel shading of the queued blocks, 16 lanes per block -------------------------------
+    const int npix = s_nwork * 16;
+    uint8_t *img8 = reinterpret_cast<uint8_t *>(s_img);
+    for (int wi = tid; wi < npix; wi += kBlock) {
+        const uint32_t item = s_work[wi >> 4];
+        const int bi = item & 0x3fff, pi = wi & 15;
+        const int r = (bi / bw) * 4 + (pi >> 2), c = (bi % bw) * 4 + (pi & 3);
+        const float f = (halfH - ((float)r + 0.5f)) * res;
+        const float l = (halfW - ((float)c + 0.5f)) * res;
+        const float wx = (ex + f * ce) - l * se;
+        const float wy = (ey + f * se) + l * ce;
+        int layer = 0;                                        // 0 bg, 1 road, 2 waypoint, 3 npc, 4 ego
+        if (item & 0x8000) {
+            layer = (item & 0x4000) ? 1 : 0;
+        } else {
+            const uint32_t wd = cell_lookup(w, m, wx, wy);
+            const uint32_t cls = wd & 3u;
+            bool road = cls == TDE_CELL_FULL;
+            if (cls == TDE_CELL_MIXED) {
+                const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
+                const int n = (int)((wd >> 2) & 255u);
+                for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
+            }
+            layer = road ? 1 : 0;
+        }
+        for (int k = 0; k < nwp; ++k) {
+            const float4 t = s_wp[k];
+            const float dx = wx - t.x, dy = wy - t.y;
+            if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
+        }
+        for (int k = 0; k < nbox; ++k) {
+            const RenderBox &b = s_box[k];
+            if (r < b.rmin || r > b.rmax || c < b.cmin || c > b.cmax) continue;
+            const float dx = wx - b.x, dy = wy - b.y;
+            const float p = dx * b.c + dy * b.s, q = dy * b.c - dx * b.s;
+            if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) layer = 3;
+        }
+        {
+            const float dx = wx - ex, dy = wy - ey;
+            const float p = dx * ce + dy * se, q = dy * ce - dx * se;
+            if (fabsf(p) <= s_ego.hl && fabsf(q) <= s_ego.hw) layer = 4;
+        }
+        const int o = r * W + c;
+        img8[o] = (uint8_t)TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
+        img8[plane + o] = (uint8_t)TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
+        img8[2 * plane + o] = (uint8_t)TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
+    }
+    __syncthreads();
+
+    // ---- pass 3: stream the image out --------------------------------------------------------------------------
+    uint4 *dst = reinterpret_cast<uint4 *>(out + 3 * (ns - 1) * plane);
+    const uint4 *src = reinterpret_cast<const uint4 *>(s_img);
+    for (int i = tid; i < 3 * plane / 16; i += kBlock) dst[i] = src[i];
 }
 
 }  // namespace tde
@@ -909,7 +974,9 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     int rc = check_env_args("tde_render_ego", cfg, world, st);
     if (rc) return rc;
     if (!rd || !rd->out) return bad("tde_render_ego: render/out is NULL");
-    if (rd->H <= 0 || rd->W <= 0 || (rd->W % 16) != 0) return bad("tde_render_ego: W must be a positive multiple of 16");
+    if (rd->H <= 0 || rd->W <= 0 || (rd->W % 4) != 0 || (rd->H % 4) != 0 || (rd->H * rd->W) % 16 != 0 ||
+        rd->H * rd->W > tde::kRenderMaxPix)
+        return bad("tde_render_ego: H and W must be positive multiples of 4 with H*W <= 4096");
     if (st->B <= 0) return 0;
     tde::render_ego_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
     hipError_t e = hipGetLastError();

@@ -107,6 +107,27 @@ def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4
                 cell_tris=pt.astype(np.int32))
 
 
+CLEARANCE_UNIT = 0.125   # metres per count of the clearance field
+
+
+def cell_clearance(g, cell):
+    """per cell, floor(rho / CLEARANCE_UNIT) clipped to 255, where rho is the distance between the cell's rectangle and
+    the nearest cell rectangle of another class (FULL or EMPTY cells; 0 for MIXED): every point within rho of any
+    point of the cell lies in a cell of the same class.  Exact rectangle-to-rectangle distance = centre distance to
+    the other-class set dilated by one cell (Chebyshev), from a Euclidean distance transform."""
+    from scipy.ndimage import binary_dilation, distance_transform_edt
+
+    cls = g["cell_class"].reshape(g["ny"], g["nx"])
+    out = np.zeros(cls.shape, np.float64)
+    for c in (_abi.CELL_FULL, _abi.CELL_EMPTY):
+        m = cls == c
+        if m.any():
+            other = binary_dilation(~m, structure=np.ones((3, 3), bool))
+            d = distance_transform_edt(~other) * cell - 1e-3
+            out = np.where(m, d, out)
+    return np.clip(np.floor(np.maximum(out, 0.0) / CLEARANCE_UNIT), 0, 255).astype(np.int64).reshape(-1)
+
+
 def pack_triangles(tri32):
     """Device-side triangle records [n,12] fp32: ax,ay,bx,by | cx,cy,inv|ab|^2,inv|bc|^2 | inv|ca|^2,0,0,0.
     The reciprocals are computed in fp32 exactly as the oracle's `1.0f / len2` so the kernel's distances keep every
@@ -247,6 +268,10 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5):
                    tri_base, len(tri), 0)
         packed = pack_triangles(tri32)
         counts = np.diff(g["cell_start"]).astype(np.int64)
+        # FULL / EMPTY cells carry no candidate list: their count field holds a clearance instead (quarter metres,
+        # rounded down): every point within that distance of ANY point of the cell lies in a cell of the same class.
+        # The rasteriser uses it to classify a whole 4x4 pixel block with one lookup.
+        counts = np.where(g["cell_class"] == _abi.CELL_MIXED, counts, cell_clearance(g, cell))
         assert counts.max(initial=0) <= 255, "more than 255 candidate triangles in one grid cell: use a smaller cell"
         start = g["cell_start"][:-1].astype(np.int64) + rec_base
         assert start.max(initial=0) < (1 << 22), "grid index too large for the 22-bit record offset"
