@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 2
+#define TDE_ABI_VERSION 3
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -38,6 +38,7 @@ extern "C" {
 #define TDE_F_REWARD     (1u << 3)  /* WaypointSuite reward/advance/terminate/truncate (gym_env.py:369-437) */
 #define TDE_F_AUTORESET  (1u << 4)  /* envs that finished this step are re-spawned in place (VecEnv semantics) */
 #define TDE_F_EGO_ONLY_ATTRS (1u << 5) /* cfg.ego_only: random ego attrs at reset (gym_env.py:192-198) */
+#define TDE_F_TRAFFIC_LIGHTS (1u << 6) /* red-light stop-line violation, third term of is_terminated (gym_env.py:415) */
 #define TDE_F_ALL (TDE_F_NPC | TDE_F_REPLAY | TDE_F_OFFROAD | TDE_F_REWARD | TDE_F_AUTORESET)
 
 /* cell classes of the offroad grid index (HIP side only; the oracle is brute force over triangles) */
@@ -84,8 +85,26 @@ typedef struct tde_map {
     int32_t cell_base;          /* first cell of this map in cell_class / cell_start */
     int32_t tri_base;           /* first triangle of this map in tri */
     int32_t n_tri;
-    int32_t _pad0;
+    int32_t stop_base, n_stop;  /* stop lines of this map in tde_world.stoplines */
+    int32_t phase_base, n_phase;/* traffic-light cycle of this map in tde_world.phases */
+    int32_t cycle_steps;        /* length of the cycle in env steps (0: no lights) */
+    int32_t _pad0, _pad1;
 } tde_map;
+
+/* A stop line: an oriented box across an inbound lane, governed by traffic light `light` of its map
+ * (reference: map_cfg.stoplines with agent_type 'traffic_light', gym_env.py:183). */
+typedef struct tde_stopline {
+    float x, y, c, s;           /* centre, cos/sin of its heading */
+    float hl, hw;               /* half extents */
+    int32_t light;              /* light index (bit in tde_light_phase.red_mask) */
+    int32_t _pad0;
+} tde_stopline;
+
+/* One phase of a map's light cycle: it lasts until step `end_step` of the cycle; lights in red_mask are red. */
+typedef struct tde_light_phase {
+    int32_t end_step;
+    uint32_t red_mask;
+} tde_light_phase;
 
 /* One (scenario, slot) spawn record: everything a slot gets at reset, 64 B so that the kernels read it with four
  * 16-B loads.  Slot 0 (ego) only uses len/wid/lr: its pose is sampled (gym_env.py:351-367). */
@@ -125,6 +144,8 @@ typedef struct tde_world {
     const tde_spawn *spawn;     /* [S][A] */
     const float *route_xy;      /* [R][RW][2] NPC route polylines */
     const float *replay_states; /* [P][RT][4] */
+    const tde_stopline *stoplines;   /* [n_stop_total] */
+    const tde_light_phase *phases;   /* [n_phase_total] */
     int32_t n_maps, n_scn, NW, A;
     int32_t n_routes, RW, n_replay, RT;
 } tde_world;
@@ -149,6 +170,7 @@ typedef struct tde_state {
     float *reward;              /* out [B] (R6) */
     uint8_t *terminated;        /* out [B] (R8) */
     uint8_t *truncated;         /* out [B] (R11) */
+    uint8_t *tl_violation;      /* out [B]: compute_traffic_lights_violations() > 0 for the ego (gym_env.py:144,415,429) */
     double *info;               /* out [B][4] psi_smoothness, speed_smoothness, psi_reward, dist_reward (R12; Python floats
                                    in the reference, hence float64); may be NULL */
     int32_t *info_reached;      /* out [B] reached_waypoint_num as reported by get_info (gym_env.py:425,431); may be NULL */
@@ -159,7 +181,8 @@ typedef struct tde_state {
 typedef struct tde_rollout {
     const float *actions;       /* [K][B][2] */
     float *reward;              /* [K][B] */
-    uint8_t *done;              /* [K][B] bit0 terminated, bit1 truncated, bit2 ego offroad, bit3 ego collided */
+    uint8_t *done;              /* [K][B] bit0 terminated, bit1 truncated, bit2 ego offroad, bit3 ego collided,
+                                   bit4 ego red-light violation */
     int32_t K;
     int32_t _pad0;
 } tde_rollout;

@@ -477,9 +477,27 @@ TDE_EXPORT int tde_oracle_waypoint_reward(const tde_config *cfg, int32_t n, cons
 /* ------------------------------------------------------------------------------------------------ */
 /* One env, one timestep: WaypointSuiteEnv.step (gym_env.py:369-389) over GymEnv.step (:115-120).     */
 /* ------------------------------------------------------------------------------------------------ */
+/* compute_traffic_lights_violations() > 0 for one box (gym_env.py:144,415,429): the box overlaps a stop line whose
+ * light is red at env step k.  PARITY UNPINNED (torchdrivesim internals); the light cycle restarts with the episode. */
+static int tde_tl_violation(const tde_world *w, const tde_map *m, int32_t k, float x, float y, float c, float s, float hl,
+                            float hw)
+{
+    if (m->cycle_steps <= 0 || m->n_stop <= 0) return 0;
+    int32_t t = k % m->cycle_steps;
+    uint32_t red = 0;
+    for (int32_t p = 0; p < m->n_phase; ++p)
+        if (t < w->phases[m->phase_base + p].end_step) { red = w->phases[m->phase_base + p].red_mask; break; }
+    for (int32_t i = 0; i < m->n_stop; ++i) {
+        const tde_stopline *sl = &w->stoplines[m->stop_base + i];
+        if (((red >> sl->light) & 1u) && tde_oracle_obb_overlap(x, y, c, s, hl, hw, sl->x, sl->y, sl->c, sl->s, sl->hl, sl->hw))
+            return 1;
+    }
+    return 0;
+}
+
 typedef struct {
     float reward;
-    uint8_t terminated, truncated;
+    uint8_t terminated, truncated, tl;
 } tde_env_out;
 
 static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_state *st, int32_t e, float a_acc,
@@ -491,7 +509,7 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
     float *X = st->x + g0, *Y = st->y + g0, *P = st->psi + g0, *V = st->v + g0;
     const float *L = st->len + g0, *W = st->wid + g0, *LR = st->lr + g0;
     const uint8_t *present = st->present + g0;
-    tde_env_out out = {0.0f, 0, 0};
+    tde_env_out out = {0.0f, 0, 0, 0};
 
     /* :371-375 snapshot of the pre-step state (all agents: the NPC controller reads it too) */
     float px[TDE_MAX_AGENTS], py[TDE_MAX_AGENTS], pp[TDE_MAX_AGENTS], pv[TDE_MAX_AGENTS];
@@ -562,12 +580,16 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
         for (int32_t a = 0; a < A; ++a) st->offroad[g0 + a] = 0;
     }
 
+    if (F & TDE_F_TRAFFIC_LIGHTS)
+        out.tl = (uint8_t)tde_tl_violation(w, &w->maps[w->scn[st->scn[e]].map], k, X[0], Y[0], c[0], s[0], 0.5f * L[0],
+                                           0.5f * W[0]);
+    if (st->tl_violation) st->tl_violation[e] = out.tl;
     if (F & TDE_F_REWARD) {
         const int32_t scn = st->scn[e];
         const float pre[4] = {px[0], py[0], pp[0], pv[0]};
         const float post[4] = {X[0], Y[0], P[0], V[0]};
         tde_reward_core(cfg, w->wp_xy + (int64_t)scn * w->NW * 2, w->scn[scn].wp_n, pre, post, st->offroad[g0],
-                        st->collided[g0], 0, k, &st->target_idx[e], &st->reached[e], &out.reward, &out.terminated,
+                        st->collided[g0], out.tl, k, &st->target_idx[e], &st->reached[e], &out.reward, &out.terminated,
                         &out.truncated, st->info ? st->info + 4 * (int64_t)e : NULL,
                         st->info_reached ? &st->info_reached[e] : NULL);
     }
@@ -599,7 +621,7 @@ TDE_EXPORT int tde_oracle_env_rollout(const tde_config *cfg, const tde_world *w,
             tde_env_out o = tde_step_env(cfg, w, st, e, act[0], act[1]);
             ro->reward[(int64_t)k * B + e] = o.reward;
             ro->done[(int64_t)k * B + e] = (uint8_t)(o.terminated | (o.truncated << 1) | (st->offroad[g0] << 2) |
-                                                     (st->collided[g0] << 3));
+                                                     (st->collided[g0] << 3) | (o.tl << 4));
             st->reward[e] = o.reward;
             st->terminated[e] = o.terminated;
             st->truncated[e] = o.truncated;

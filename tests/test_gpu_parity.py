@@ -180,14 +180,15 @@ def test_env_reset_bit_exact(small_world):
     assert np.all((L0 >= 4.8) & (L0 < 5.5))
 
 
-@pytest.mark.parametrize("flags", [_abi.F_ALL, _abi.F_ALL & ~_abi.F_AUTORESET, _abi.F_REWARD | _abi.F_OFFROAD, 0])
+@pytest.mark.parametrize("flags", [_abi.F_ALL, _abi.F_ALL | _abi.F_TRAFFIC_LIGHTS, _abi.F_ALL & ~_abi.F_AUTORESET,
+                                   _abi.F_REWARD | _abi.F_OFFROAD | _abi.F_TRAFFIC_LIGHTS, 0])
 def test_env_step_bit_exact_over_an_episode(small_world, flags):
     """full fused step, 250 consecutive steps (> one 200-step episode, so truncation + auto-reset are crossed)"""
     cfg = _abi.default_config(seed=21, flags=flags, distance_cutoff=0.25)
     B, A = 333, 16   # ragged: last workgroup partially filled
     hs, ds, dw = _pair(small_world, B, A, cfg)
     rng = np.random.default_rng(3)
-    n_term = n_trunc = n_col = n_off = 0
+    n_term = n_trunc = n_col = n_off = n_tl = 0
     for t in range(250):
         act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
         if t % 50 < 10:
@@ -199,8 +200,12 @@ def test_env_step_bit_exact_over_an_episode(small_world, flags):
         if t % 10 == 0 or t > 195:
             assert_state_equal(hs.host(), ds.host(), f"step {t} flags {flags}")
         n_term += int(hs["terminated"].sum()); n_trunc += int(hs["truncated"].sum())
-        n_col += int(hs["collided"].sum()); n_off += int(hs["offroad"].sum())
+        n_col += int(hs["collided"].sum()); n_off += int(hs["offroad"].sum()); n_tl += int(hs["tl_violation"].sum())
     assert_state_equal(hs.host(), ds.host(), "end")
+    if flags & _abi.F_TRAFFIC_LIGHTS:
+        assert n_tl > 0
+    else:
+        assert n_tl == 0
     if flags & _abi.F_REWARD:
         assert n_trunc > 0
     if flags == _abi.F_ALL:
@@ -320,3 +325,37 @@ def test_render_ego_bit_exact(A, n_stack):
     last = hout[:, -3:]
     assert (last[:, 0, 32, 32] == 214).all()              # the ego covers the image centre
     assert len(np.unique(last.reshape(B, 3, -1).transpose(0, 2, 1).reshape(-1, 3), axis=0)) >= 4
+
+
+def test_traffic_light_violation_known_answers(small_world):
+    """R8 third term: ego box on a stop line -> violation only while that light is red"""
+    w = small_world
+    dw = w.to_device(DEV)
+    m = w.arrays["maps"][0]
+    sl = w.arrays["stoplines"][m["stop_base"]]            # arm 0 stop line, light 0
+    phases = w.arrays["phases"][m["phase_base"]:m["phase_base"] + m["n_phase"]]
+    cfg = _abi.default_config(seed=1, flags=_abi.F_REWARD | _abi.F_TRAFFIC_LIGHTS, terminated_at_infraction=1,
+                              max_steps=10_000)
+    hs, ds = EnvState(1, 16), EnvState(1, 16, device=DEV)
+    for stt, reset in ((hs, lambda: oracle.env_reset(cfg, w, hs)), (ds, lambda: ops.env_reset(cfg, dw, ds))):
+        reset()
+    scn0 = int(np.nonzero(w.arrays["scn"]["map"] == 0)[0][0])
+    for stt in (hs, ds):
+        stt["scn"][...] = scn0
+        stt["present"][...] = 0
+        stt["present"][0] = 1
+        stt["x"][0], stt["y"][0] = float(sl["x"]), float(sl["y"])
+        stt["psi"][0], stt["v"][0] = float(np.arctan2(sl["s"], sl["c"])), 0.0
+    seen = []
+    for k in range(1, int(m["cycle_steps"]) + 5):
+        hs["action"][...] = 0
+        ds["action"][...] = 0
+        oracle.env_step(cfg, w, hs)
+        ops.env_step(cfg, dw, ds)
+        t = k % int(m["cycle_steps"])
+        red = int(phases["red_mask"][np.argmax(t < phases["end_step"])])
+        want = (red >> int(sl["light"])) & 1
+        assert int(hs["tl_violation"][0]) == want == int(ds["tl_violation"].cpu()[0]), k
+        assert int(hs["terminated"][0]) == want == int(ds["terminated"].cpu()[0])
+        seen.append(want)
+    assert 0 < sum(seen) < len(seen)

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 2
+TDE_ABI_VERSION = 3
 TDE_MAX_AGENTS = 64
 
 F_NPC = 1 << 0
@@ -16,6 +16,7 @@ F_OFFROAD = 1 << 2
 F_REWARD = 1 << 3
 F_AUTORESET = 1 << 4
 F_EGO_ONLY_ATTRS = 1 << 5
+F_TRAFFIC_LIGHTS = 1 << 6
 F_ALL = F_NPC | F_REPLAY | F_OFFROAD | F_REWARD | F_AUTORESET
 
 CELL_EMPTY, CELL_MIXED, CELL_FULL = 0, 1, 2
@@ -54,13 +55,18 @@ class TdeMap(C.Structure):
     _fields_ = [
         ("ox", C.c_float), ("oy", C.c_float), ("cell", C.c_float), ("inv_cell", C.c_float),
         ("nx", C.c_int32), ("ny", C.c_int32), ("cell_base", C.c_int32), ("tri_base", C.c_int32),
-        ("n_tri", C.c_int32), ("_pad0", C.c_int32),
+        ("n_tri", C.c_int32), ("stop_base", C.c_int32), ("n_stop", C.c_int32), ("phase_base", C.c_int32),
+        ("n_phase", C.c_int32), ("cycle_steps", C.c_int32), ("_pad0", C.c_int32), ("_pad1", C.c_int32),
     ]
 
 
 MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "f4"), ("nx", "i4"), ("ny", "i4"),
-                      ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("_pad0", "i4")])
-assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 40
+                      ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("stop_base", "i4"), ("n_stop", "i4"),
+                      ("phase_base", "i4"), ("n_phase", "i4"), ("cycle_steps", "i4"), ("_pad0", "i4"), ("_pad1", "i4")])
+STOPLINE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("c", "f4"), ("s", "f4"), ("hl", "f4"), ("hw", "f4"),
+                           ("light", "i4"), ("_pad0", "i4")])
+PHASE_DTYPE = np.dtype([("end_step", "i4"), ("red_mask", "u4")])
+assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 64 and STOPLINE_DTYPE.itemsize == 32 and PHASE_DTYPE.itemsize == 8
 
 SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("len", "f4"), ("wid", "f4"),
                         ("lr", "f4"), ("vdes", "f4"), ("route", "i4"), ("route_wp", "i4"), ("route_n", "i4"),
@@ -68,7 +74,8 @@ SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("
 SCN_DTYPE = np.dtype([("map", "i4"), ("wp_n", "i4"), ("start_heading", "f4"), ("_pad0", "i4")])
 assert SPAWN_DTYPE.itemsize == 64 and SCN_DTYPE.itemsize == 16
 
-WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "scn", "wp_xy", "spawn", "route_xy", "replay_states"]
+WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
+              "stoplines", "phases"]
 WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT"]
 
 
@@ -81,7 +88,7 @@ STATE_AGENT_I32 = ["route_wp"]
 STATE_AGENT_U8 = ["present", "collided", "offroad"]
 STATE_ENV_I32 = ["scn", "steps", "target_idx", "reached", "episode"]
 STATE_PTRS = (STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8 + STATE_ENV_I32 +
-              ["action", "reward", "terminated", "truncated", "info", "info_reached"])
+              ["action", "reward", "terminated", "truncated", "tl_violation", "info", "info_reached"])
 
 
 class TdeState(C.Structure):
@@ -142,18 +149,21 @@ def default_config(**over):
 WORLD_DTYPES = {
     "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "scn": SCN_DTYPE,
     "wp_xy": np.float64, "spawn": SPAWN_DTYPE, "route_xy": np.float32, "replay_states": np.float32,
+    "stoplines": STOPLINE_DTYPE, "phases": PHASE_DTYPE,
 }
 
 STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n in STATE_AGENT_I32},
                 **{n: np.uint8 for n in STATE_AGENT_U8}, **{n: np.int32 for n in STATE_ENV_I32},
                 "action": np.float32, "reward": np.float32, "terminated": np.uint8, "truncated": np.uint8,
+                "tl_violation": np.uint8,
                 "info": np.float64, "info_reached": np.int32}
 
 
 def state_shapes(B, A):
     sh = {n: (B * A,) for n in STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8}
     sh.update({n: (B,) for n in STATE_ENV_I32})
-    sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "info": (B, 4),
+    sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "tl_violation": (B,),
+               "info": (B, 4),
                "info_reached": (B,)})
     return sh
 

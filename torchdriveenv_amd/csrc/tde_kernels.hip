@@ -234,9 +234,30 @@ TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, 
 
 struct StepOut {
     float reward;
-    uint8_t terminated, truncated, collided, offroad;
+    uint8_t terminated, truncated, collided, offroad, tl;
     bool respawned;
 };
+
+// compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
+// is red at env step k.  Mirrors tde_tl_violation of the oracle.
+TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, int k, float x, float y, float c, float s, float hl,
+                          float hw)
+{
+    if (m.cycle_steps <= 0 || m.n_stop <= 0) return false;
+    const int t = k % m.cycle_steps;
+    uint32_t red = 0;
+    for (int p = 0; p < m.n_phase; ++p) {
+        const tde_light_phase ph = w.phases[m.phase_base + p];
+        if (t < ph.end_step) { red = ph.red_mask; break; }
+    }
+    bool v = false;
+    for (int i = 0; i < m.n_stop; ++i) {
+        const float4 a = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[0];
+        const float4 b = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[1];   // hl, hw, light, pad
+        if ((red >> __float_as_int(b.z)) & 1u) v = v || obb_overlap(x, y, c, s, hl, hw, a.x, a.y, a.z, a.w, b.x, b.y);
+    }
+    return v;
+}
 
 TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s, float lane_half)
 {
@@ -260,7 +281,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     const int base = tid - a;                       // first lane of this env inside the workgroup
     bool live = valid && ag.present;
     const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-    StepOut out{0.0f, 0, 0, 0, 0, false};
+    StepOut out{0.0f, 0, 0, 0, 0, 0, false};
 
     er.steps += 1;                                  // :116
     const int k = er.steps;
@@ -333,13 +354,21 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
+    bool tl = false;
+    if ((F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid) {
+        // the map descriptor is only cached when the offroad test is on
+        const tde_map mm = (F & TDE_F_OFFROAD) ? cx.m : cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
+        tl = tl_violation(w, mm, k, ag.x, ag.y, c0, s0, hl, hw);
+    }
+    out.tl = tl ? 1 : 0;
+
     // ---- reward / termination on the ego lane; the env's other lanes learn "done" from the wave ballot ----------
     if (F & TDE_F_REWARD) {
         int done = 0;
         if (a == 0 && valid) {
             const int ti0 = er.target_idx;
             RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
-                                      false, k, er.target_idx, er.reached);
+                                      tl, k, er.target_idx, er.reached);
             out.reward = r.reward;
             out.terminated = r.terminated;
             out.truncated = r.truncated;
@@ -415,9 +444,11 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
         st.reward[e] = o.reward;
         st.terminated[e] = o.terminated;
         st.truncated[e] = o.truncated;
+        if (st.tl_violation) st.tl_violation[e] = o.tl;
         if (o.respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
         if (reward_k) reward_k[e] = o.reward;
-        if (done_k) done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3));
+        if (done_k)
+            done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
     }
 }
 
@@ -451,7 +482,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
-    StepOut o{0.0f, 0, 0, 0, 0, false};
+    StepOut o{0.0f, 0, 0, 0, 0, 0, false};
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
         const float2 act_next = acts[(int64_t)kn * B + es];      // in flight during this step
@@ -460,7 +491,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
             if (ro.reward) ro.reward[(int64_t)k * B + e] = o.reward;
             if (ro.done)
                 ro.done[(int64_t)k * B + e] =
-                    (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3));
+                    (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
         }
         act = act_next;
     }
@@ -477,6 +508,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
         st.reward[e] = o.reward;
         st.terminated[e] = o.terminated;
         st.truncated[e] = o.truncated;
+        if (st.tl_violation) st.tl_violation[e] = o.tl;
     }
 }
 

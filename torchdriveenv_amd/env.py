@@ -136,6 +136,8 @@ class BatchedWaypointEnv:
             flags |= _abi.F_AUTORESET
         if cfg.ego_only:
             flags |= _abi.F_EGO_ONLY_ATTRS
+        if self.world.has_lights:
+            flags |= _abi.F_TRAFFIC_LIGHTS
         self.tde_cfg = to_tde_config(cfg, seed, flags)
         self.dworld = self.world.to_device(self.torch_device)
         self.state = EnvState(self.num_envs, self.A, device=self.torch_device, with_info=with_info)
@@ -202,7 +204,7 @@ class BatchedWaypointEnv:
         st, A = self.state, self.A
         ego = slice(0, self.num_envs * A, A)
         info = dict(offroad=st["offroad"][ego].float(), collision=st["collided"][ego].float(),
-                    traffic_light_violation=torch.zeros(self.num_envs, device=self.torch_device),
+                    traffic_light_violation=st["tl_violation"].float(),
                     is_success=st["truncated"].bool())
         if st["info"] is not None:
             inf = st["info"]

@@ -49,6 +49,18 @@ class Junction:
         parts.append(disc_mesh((0.0, 0.0), 0.5 * ROAD_W + 5.5, 12))  # widened junction box
         return np.concatenate(parts, 0)
 
+    def lights(self, s_stop=11.0):
+        """one light per arm with a stop line across its inbound lane; the first two arms (the main road) share a
+        green, the side arm(s) get the other one, with all-red clearance phases (10 Hz steps)"""
+        stop = []
+        for arm, d in enumerate(self.d):
+            t = -d                                         # inbound travel direction
+            pos = d * s_stop + _right(t) * (0.5 * LANE)
+            stop.append((float(pos[0]), float(pos[1]), math.atan2(t[1], t[0]), 1.0, LANE, arm))
+        main, side = [0, 1], list(range(2, len(self.d)))
+        phases = [(80, side), (15, main + side), (50, main), (15, main + side)]
+        return dict(stoplines=stop, phases=phases)
+
     def lane(self, arm, outbound, s0, s1, step=2.0):
         """lane-centre polyline on an arm between distances s0 -> s1 from the junction centre"""
         d = self.d[arm]
@@ -73,7 +85,7 @@ def _attrs(rng):
     return (L, W, lr)
 
 
-def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.5, threshold=0.5):
+def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.5, threshold=0.5, lights=True):
     """World with `n_scn` scenarios of A-1 NPCs each on `n_maps` junction maps.  Deterministic in `seed`."""
     rng = np.random.default_rng(seed)
     juncs = []
@@ -147,4 +159,5 @@ def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.5, thre
             agents.append(dict(state=(float(pos[0]), float(pos[1]), psi, speed), attr=_attrs(rng), vdes=max(speed, 3.0),
                                route=route, replay=None))
         scenarios.append(dict(map=m, waypoints=wps, start_heading=heading, agents=agents, ego_attr=_attrs(rng)))
-    return assemble_world(meshes, scenarios, A, threshold=threshold, cell=cell)
+    return assemble_world(meshes, scenarios, A, threshold=threshold, cell=cell,
+                          lights=[j.lights() for j in juncs] if lights else None)

@@ -205,6 +205,7 @@ class World:
     def __init__(self, arrays, ints):
         self.arrays = {k: np.ascontiguousarray(arrays[k], dtype=_abi.WORLD_DTYPES[k]) for k in _abi.WORLD_PTRS}
         self.ints = {k: int(ints[k]) for k in _abi.WORLD_INTS}
+        self.has_lights = bool(np.asarray(arrays["maps"])["cycle_steps"].max() > 0)
         # zero-length tables still need a valid pointer
         for k, a in self.arrays.items():
             if a.size == 0:
@@ -248,7 +249,7 @@ class DeviceWorld:
         self.struct = _abi.fill_world_struct(tensors, ints)
 
 
-def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5):
+def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
     """meshes: list of [n,3,2] triangle arrays; scenarios: list of dicts with keys
          map (int), waypoints [(x,y)...], start_heading (float),
          agents: list (slots 1..) of dict(state=(x,y,psi,v), attr=(L,W,lr), vdes, route=[(x,y)..] or None,
@@ -256,6 +257,9 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5):
          ego_attr (L,W,lr)
     """
     assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
+    # lights: per map None or dict(stoplines=[(x, y, psi, length, width, light)...], phases=[(n_steps, red_lights)...])
+    lights = lights or [None] * len(meshes)
+    stop_all, phase_all = [], []
     maps = np.zeros(len(meshes), dtype=_abi.MAP_DTYPE)
     tri_all, word_all, rec_all = [], [], []
     tri_base = cell_base = rec_base = 0
@@ -264,8 +268,18 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5):
         # the kernels see fp32 vertices: index the fp32-rounded mesh
         tri32 = tri.astype(np.float32)
         g = build_grid_index(tri32.astype(np.float64), threshold, cell)
+        lt = lights[m]
+        n_stop = n_phase = cycle = 0
+        if lt:
+            n_stop, n_phase = len(lt["stoplines"]), len(lt["phases"])
+            assert n_phase >= 1 and max(sl[5] for sl in lt["stoplines"]) < 32
+            for (x, y, psi, length, width, light) in lt["stoplines"]:
+                stop_all.append((x, y, math.cos(psi), math.sin(psi), 0.5 * length, 0.5 * width, light, 0))
+            for (n_steps, red) in lt["phases"]:
+                cycle += int(n_steps)
+                phase_all.append((cycle, sum(1 << int(i) for i in red)))
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
-                   tri_base, len(tri), 0)
+                   tri_base, len(tri), len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle, 0, 0)
         packed = pack_triangles(tri32)
         counts = np.diff(g["cell_start"]).astype(np.int64)
         # FULL / EMPTY cells carry no candidate list: their count field holds a clearance instead (quarter metres,
@@ -323,6 +337,9 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5):
         replay_states[i, :len(r)] = r
     rec_cat = np.concatenate(rec_all, 0) if rec_base else np.zeros((1, 12), np.float32)
     arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_word=np.concatenate(word_all), cell_tri=rec_cat,
-                  scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states)
+                  scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states,
+                  stoplines=np.asarray(stop_all, dtype=_abi.STOPLINE_DTYPE) if stop_all
+                  else np.zeros(1, _abi.STOPLINE_DTYPE),
+                  phases=np.asarray(phase_all, dtype=_abi.PHASE_DTYPE) if phase_all else np.zeros(1, _abi.PHASE_DTYPE))
     ints = dict(n_maps=len(meshes), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT)
     return World(arrays, ints)
