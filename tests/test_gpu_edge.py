@@ -1,0 +1,138 @@
+"""Edge cases through the C-ABI on a GPU: degenerate sizes, absent agents, argument errors, NaN propagation,
+graph capture (the entry points allocate nothing and only touch the stream they are given)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from torchdriveenv_amd import _abi, _lib, ops  # noqa: E402
+from torchdriveenv_amd.state import EnvState  # noqa: E402
+from torchdriveenv_amd.synth import synthetic_world  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_single_env_single_agent_and_empty_batch():
+    world = synthetic_world(n_scn=2, A=1, seed=0, n_maps=1)
+    cfg = _abi.default_config(seed=4)
+    dw = world.to_device(DEV)
+    hs, ds = EnvState(1, 1), EnvState(1, 1, device=DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    for t in range(40):
+        hs["action"][...] = [0.8, 0.01]
+        ds["action"].copy_(dev(hs["action"]))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+    h, d = hs.host(), ds.host()
+    for k in h:
+        if k != "action":
+            assert np.array_equal(h[k].view(np.uint8), d[k].view(np.uint8)), k
+    # B = 0: every entry point is a no-op that reports success
+    L = _lib.load()
+    st0 = _abi.TdeState()
+    st0.B, st0.A = 0, 1
+    assert L.tde_env_step(C.byref(cfg), C.byref(dw.struct), C.byref(st0), None) == 0
+    assert L.tde_env_reset(C.byref(cfg), C.byref(dw.struct), C.byref(st0), None, None) == 0
+    assert L.tde_compute_collision(0, 4, None, None, None, None, None, None, None, None) == 0
+
+
+def test_all_npcs_absent_matches_oracle(small_world):
+    cfg = _abi.default_config(seed=6)
+    dw = small_world.to_device(DEV)
+    B, A = 37, 16
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    oracle.env_reset(cfg, small_world, hs)
+    ops.env_reset(cfg, dw, ds)
+    mask = np.zeros(B * A, np.uint8)
+    mask[::A] = 1                                       # only the egos stay
+    hs["present"][...] = mask
+    ds["present"].copy_(dev(mask))
+    cfg2 = _abi.default_config(seed=6, flags=_abi.F_ALL & ~_abi.F_AUTORESET)
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg2, small_world, hs)
+        ops.env_step(cfg2, dw, ds)
+    h, d = hs.host(), ds.host()
+    for k in h:
+        if k != "action":
+            assert np.array_equal(h[k].view(np.uint8), d[k].view(np.uint8)), k
+    assert h["collided"].sum() == 0
+
+
+def test_argument_errors_are_reported_not_fatal(small_world):
+    L = _lib.load()
+    cfg = _abi.default_config()
+    dw = small_world.to_device(DEV)
+    st = EnvState(4, 16, device=DEV)
+    bad = _abi.TdeState.from_buffer_copy(st.struct)
+    bad.A = 12                                           # not a power of two
+    rc = L.tde_env_step(C.byref(cfg), C.byref(dw.struct), C.byref(bad), None)
+    assert rc != 0 and b"power of two" in L.tde_last_error()
+    bad.A = 8                                            # does not match the world tables
+    rc = L.tde_env_step(C.byref(cfg), C.byref(dw.struct), C.byref(bad), None)
+    assert rc != 0 and b"world.A" in L.tde_last_error()
+    assert L.tde_env_step(None, C.byref(dw.struct), C.byref(st.struct), None) != 0
+    with pytest.raises(_lib.TdeError):
+        _lib.check(rc, "tde_env_step")
+    with pytest.raises(ValueError):
+        ops.env_rollout(cfg, dw, st, torch.zeros(3, 5, 2, device=DEV))      # wrong env count
+    with pytest.raises(ValueError, match="contiguous"):
+        ops.kinematics_step(*(torch.zeros(8, 2, device=DEV)[:, 0] for _ in range(5)), torch.zeros(8, 2, device=DEV))
+
+
+def test_nan_action_propagates_to_that_env_only(small_world):
+    cfg = _abi.default_config(seed=2, flags=_abi.F_ALL & ~_abi.F_AUTORESET)
+    dw = small_world.to_device(DEV)
+    B, A = 8, 16
+    ds = EnvState(B, A, device=DEV)
+    ops.env_reset(cfg, dw, ds)
+    act = torch.zeros(B, 2, device=DEV)
+    act[3, 0] = float("nan")
+    ds["action"].copy_(act)
+    ops.env_step(cfg, dw, ds)
+    x = ds["x"].cpu().numpy().reshape(B, A)
+    assert np.isnan(x[3, 0]) and np.isfinite(np.delete(x, 3, 0)).all() and np.isfinite(x[3, 1:]).all()
+
+
+def test_step_and_render_are_graph_capturable(small_world):
+    """hipGraph capture of a closed-loop timestep (step + render): nothing allocates or syncs inside the calls"""
+    cfg = _abi.default_config(seed=9)
+    dw = small_world.to_device(DEV)
+    B, A = 256, 16
+    ds, ref = EnvState(B, A, device=DEV), EnvState(B, A, device=DEV)
+    ops.env_reset(cfg, dw, ds)
+    ops.env_reset(cfg, dw, ref)
+    img = torch.zeros(B, 3, 64, 64, dtype=torch.uint8, device=DEV)
+    img_ref = torch.zeros_like(img)
+    ds["action"][:, 0] = 0.5
+    ref["action"][:, 0] = 0.5
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.env_step(cfg, dw, ds)                        # warm-up on the side stream
+        ops.render_ego(cfg, dw, ds, out=img)
+    torch.cuda.current_stream().wait_stream(s)
+    ops.env_step(cfg, dw, ref)
+    ops.render_ego(cfg, dw, ref, out=img_ref)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.env_step(cfg, dw, ds)
+        ops.render_ego(cfg, dw, ds, out=img)
+    for _ in range(20):
+        g.replay()
+        ops.env_step(cfg, dw, ref)
+        ops.render_ego(cfg, dw, ref, out=img_ref)
+    torch.cuda.synchronize()
+    assert torch.equal(ds["x"], ref["x"]) and torch.equal(ds["steps"], ref["steps"]) and torch.equal(img, img_ref)

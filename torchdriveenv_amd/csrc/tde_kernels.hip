@@ -978,8 +978,8 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
 {
     int rc = check_env_args("tde_env_step", cfg, world, st);
     if (rc) return rc;
-    if (!st->action) return bad("tde_env_step: state.action is NULL");
     if (st->B <= 0) return 0;
+    if (!st->action) return bad("tde_env_step: state.action is NULL");
     const unsigned nb = blocks_for((int64_t)st->B * st->A);
     TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
                               *cfg, *world, *st, st->action, (float *)nullptr, (uint8_t *)nullptr));
@@ -992,8 +992,9 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
 {
     int rc = check_env_args("tde_env_rollout", cfg, world, st);
     if (rc) return rc;
-    if (!ro || !ro->actions) return bad("tde_env_rollout: rollout/actions is NULL");
+    if (!ro) return bad("tde_env_rollout: rollout is NULL");
     if (st->B <= 0 || ro->K <= 0) return 0;
+    if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
     TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
     hipError_t e = hipGetLastError();
