@@ -5,7 +5,7 @@ import os
 from . import _abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtde_hip.so")
+LIB_PATH = os.environ.get("TDE_HIP_LIB") or os.path.join(_PKG, "libtde_hip.so")   # override: A/B builds only
 
 # every symbol include/tde_hip.h declares
 SYMBOLS = ["tde_abi_version", "tde_last_error", "tde_kinematics_step", "tde_compute_collision",
