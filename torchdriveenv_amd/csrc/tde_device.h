@@ -236,8 +236,9 @@ TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float 
     return offroad_resolve(w, k, thr2);
 }
 
-// Philox4x32-10, key = seed, counter = (c0,c1,c2,c3) — the reset RNG (R16).
-TDE_DEV void philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4])
+// Philox4x32-10, key = seed, counter = (c0,c1,c2,c3) — the reset RNG (R16).  Returned by value (uint4) so the four
+// words live in registers: an output array would be placed in scratch memory.
+TDE_DEV uint4 philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
 {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -248,7 +249,7 @@ TDE_DEV void philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    return make_uint4(c0, c1, c2, c3);
 }
 
 TDE_DEV double u01(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }

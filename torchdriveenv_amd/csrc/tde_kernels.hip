@@ -106,7 +106,7 @@ TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, co
     // controller's result (vd = min(v_des, sqrt(amax*(gap - s0)))).  The 1 % + 0.1 m margin dwarfs fp32 rounding.
     cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
     const int4 sc = reinterpret_cast<const int4 *>(w.scn)[er.scn];          // map, wp_n, start_heading, pad
-    if (F & TDE_F_OFFROAD) cx.m = w.maps[sc.x];
+    if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) cx.m = w.maps[sc.x];
     ag.route = -1; ag.replay = -1;
     if (a > 0) {
         if (F & (TDE_F_NPC | TDE_F_REPLAY)) {
@@ -129,9 +129,8 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
     uint32_t ep = (uint32_t)er.episode;
     const uint32_t ge = w.env_base + (uint32_t)e;       // global env index keys the stream
     const uint64_t seed = w.seed;
-    uint32_t r0[4];
-    philox(seed, ge, ep, 0u, 0x7DEu, r0);
-    int scn = (int)(((uint64_t)r0[0] * (uint64_t)w.n_scn) >> 32);
+    const uint4 r0 = philox(seed, ge, ep, 0u, 0x7DEu);
+    int scn = (int)(((uint64_t)r0.x * (uint64_t)w.n_scn) >> 32);
     er.scn = scn;
     er.steps = 0;
     er.target_idx = 1;
@@ -145,25 +144,25 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
     ag.route = si.x; ag.route_wp = si.y; ag.replay = si.w;
     ag.present = sj.y != 0;
     if (a == 0) {
-        uint32_t r1[4], rn[4];
-        philox(seed, ge, ep, 1u, 0x7DEu, r1);
+        const uint4 r1 = philox(seed, ge, ep, 1u, 0x7DEu);
         const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
-        double f = u01(r0[1]);
+        double f = u01(r0.y);
         double sx = wp[0] + f * (wp[2] - wp[0]);
         double sy = wp[1] + f * (wp[3] - wp[1]);
-        double speed = u01(r0[2]) * 10.0;
+        double speed = u01(r0.z) * 10.0;
         double acc = 0.0;
+#pragma unroll
         for (uint32_t b = 0; b < 3; ++b) {
-            philox(seed, ge, ep, 2u + b, 0x7DEu, rn);
-            for (int k = 0; k < 4; ++k) acc += u01(rn[k]);
+            const uint4 rn = philox(seed, ge, ep, 2u + b, 0x7DEu);
+            acc += u01(rn.x); acc += u01(rn.y); acc += u01(rn.z); acc += u01(rn.w);
         }
         double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (acc - 6.0) * 0.1;
         ag.x = (float)sx; ag.y = (float)sy; ag.psi = (float)psi0; ag.v = (float)speed;
         ag.present = true; ag.route = -1; ag.replay = -1; ag.vdes = 0.0f;
         if (cfg.flags & TDE_F_EGO_ONLY_ATTRS) {
-            ag.len = (float)(u01(r0[3]) * (5.5 - 4.8) + 4.8);
-            ag.wid = (float)(u01(r1[0]) * (2.2 - 1.8) + 1.8);
-            ag.lr = (float)(u01(r1[1]) * (0.97 - 0.82) + 0.82);
+            ag.len = (float)(u01(r0.w) * (5.5 - 4.8) + 4.8);
+            ag.wid = (float)(u01(r1.x) * (2.2 - 1.8) + 1.8);
+            ag.lr = (float)(u01(r1.y) * (0.97 - 0.82) + 0.82);
         }
     }
 }
@@ -356,9 +355,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 
     bool tl = false;
     if ((F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid) {
-        // the map descriptor is only cached when the offroad test is on
-        const tde_map mm = (F & TDE_F_OFFROAD) ? cx.m : cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
-        tl = tl_violation(w, mm, k, ag.x, ag.y, c0, s0, hl, hw);
+        tl = tl_violation(w, cx.m, k, ag.x, ag.y, c0, s0, hl, hw);
     }
     out.tl = tl ? 1 : 0;
 
@@ -701,25 +698,28 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     __syncthreads();
 
     // conservative pixel bounding box (rows/cols, inclusive) of a disc of radius rad around world point (x, y)
-    auto pixel_bbox = [&](float x, float y, float rad, int &rmin, int &rmax, int &cmin, int &cmax) {
+    auto pixel_bbox = [=](float x, float y, float rad) -> int4 {          // (rmin, rmax, cmin, cmax)
         const float dx = x - ex, dy = y - ey;
         const float f = dx * ce + dy * se, l = dy * ce - dx * se;
         const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.5f;
-        rmin = (int)floorf(rc - pr); rmax = (int)ceilf(rc + pr);
-        cmin = (int)floorf(cc - pr); cmax = (int)ceilf(cc + pr);
+        return make_int4((int)floorf(rc - pr), (int)ceilf(rc + pr), (int)floorf(cc - pr), (int)ceilf(cc + pr));
     };
     if (tid < A) {
         const int64_t g = g0 + tid;
         float sa, ca;
         sincos_f32(st.psi[g], sa, ca);
-        RenderBox b;
-        b.x = st.x[g]; b.y = st.y[g]; b.c = ca; b.s = sa; b.hl = 0.5f * st.len[g]; b.hw = 0.5f * st.wid[g];
-        pixel_bbox(b.x, b.y, b.hl + b.hw, b.rmin, b.rmax, b.cmin, b.cmax);
+        const float bx = st.x[g], by = st.y[g], bhl = 0.5f * st.len[g], bhw = 0.5f * st.wid[g];
+        const int4 bb = pixel_bbox(bx, by, bhl + bhw);
+        RenderBox *dstb = nullptr;
         if (tid == 0) {
-            s_ego = b;
+            dstb = &s_ego;
         } else if (st.present[g]) {
-            const float dx = b.x - ex, dy = b.y - ey, rr = rview + (b.hl + b.hw);
-            if (dx * dx + dy * dy <= rr * rr) s_box[atomicAdd(&s_nbox, 1)] = b;
+            const float dx = bx - ex, dy = by - ey, rr = rview + (bhl + bhw);
+            if (dx * dx + dy * dy <= rr * rr) dstb = &s_box[atomicAdd(&s_nbox, 1)];
+        }
+        if (dstb) {
+            dstb->x = bx; dstb->y = by; dstb->c = ca; dstb->s = sa; dstb->hl = bhl; dstb->hw = bhw;
+            dstb->rmin = bb.x; dstb->rmax = bb.y; dstb->cmin = bb.z; dstb->cmax = bb.w;
         }
     }
     {
@@ -731,8 +731,8 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
             if (dx * dx + dy * dy <= rr * rr) {
                 const int q = atomicAdd(&s_nwp, 1);
                 if (q < kRenderMaxWp) {
-                    int rmin, rmax, cmin, cmax;
-                    pixel_bbox(tx, ty, TDE_WAYPOINT_RADIUS, rmin, rmax, cmin, cmax);
+                    const int4 bb = pixel_bbox(tx, ty, TDE_WAYPOINT_RADIUS);
+                    int rmin = bb.x, rmax = bb.y, cmin = bb.z, cmax = bb.w;
                     rmin = max(rmin, -1); cmin = max(cmin, -1); rmax = min(max(rmax, -1), 4095); cmax = min(max(cmax, -1), 4095);
                     s_wp[q] = make_float4(tx, ty, __int_as_float((rmin + 1) | ((rmax + 1) << 16)),
                                           __int_as_float((cmin + 1) | ((cmax + 1) << 16)));
