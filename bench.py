@@ -121,8 +121,7 @@ def main():
                 ops.env_rollout(cfg, dw, st, actions[:k], reward[:k], done[:k])
             else:
                 for i in range(k):
-                    st["action"].copy_(actions[i])
-                    ops.env_step(cfg, dw, st)
+                    ops.env_step(cfg, dw, st, action=actions[i])
             left -= k
 
     run(args.warmup)

@@ -168,8 +168,7 @@ class BatchedWaypointEnv:
 
     def step(self, actions):
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).reshape(self.num_envs, 2)
-        self.state["action"].copy_(a)
-        ops.env_step(self.tde_cfg, self.dworld, self.state)
+        ops.env_step(self.tde_cfg, self.dworld, self.state, action=a.contiguous())
         st = self.state
         return (self.get_obs(), st["reward"], st["terminated"].bool(), st["truncated"].bool(), self.get_info())
 

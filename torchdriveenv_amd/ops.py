@@ -125,9 +125,15 @@ def env_reset(cfg, dworld, state, mask=None):
                                _lib.current_stream(state.device)), "tde_env_reset")
 
 
-def env_step(cfg, dworld, state):
+def env_step(cfg, dworld, state, action=None):
+    """one timestep of every env.  `action` (float32 [B,2] on the device) is read in place if given, else
+    state["action"] is used."""
     L = _lib.load()
-    _lib.check(L.tde_env_step(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct),
+    st = state.struct
+    if action is not None:
+        st = _abi.TdeState.from_buffer_copy(state.struct)
+        st.action = _chk(action, torch.float32, 2 * state.B, "action", torch.device(state.device))
+    _lib.check(L.tde_env_step(C.byref(cfg), C.byref(dworld.struct), C.byref(st),
                               _lib.current_stream(state.device)), "tde_env_step")
 
 
