@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs", type=int, default=B_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the N>1 timing reduce (nccl = RCCL; gloo for tests that put "
+                         "several ranks on one GPU)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
                     help="rollout: K steps per C-ABI call (default); step: one C-ABI call per step from Python")
     args = ap.parse_args()
@@ -92,9 +95,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     _lib.load()
@@ -141,7 +148,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if dist is not None:
-        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
 

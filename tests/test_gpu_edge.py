@@ -136,3 +136,30 @@ def test_step_and_render_are_graph_capturable(small_world):
         ops.render_ego(cfg, dw, ref, out=img_ref)
     torch.cuda.synchronize()
     assert torch.equal(ds["x"], ref["x"]) and torch.equal(ds["steps"], ref["steps"]) and torch.equal(img, img_ref)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """the N > 1 launch path of bench.py (torch.distributed.run, barrier, MAX reduce, host gather), with two ranks
+    sharing this box's single GPU over gloo; the JSON contract is checked on the one line rank 0 prints"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "500",
+           "--warmup", "250", "--backend", "gloo", "--envs", "2048"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 500 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert j["metric"] == "env-steps/sec" and j["value"] > 0 and len(j["check"]) == 2
+    assert abs(j["value"] - 2 * 2048 * 500 / (j["ms_per_step"] * 1e-3 * 500)) / j["value"] < 1e-6
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(j["roofline"])
