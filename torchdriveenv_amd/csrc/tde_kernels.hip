@@ -658,9 +658,12 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
 //           bounding boxes (a typical view holds 2-5 of the 16-32 agents); older frames of a frame stack shifted;
 //   pass 1  one lane per 4x4 pixel block: ONE grid lookup at the block centre — the cell word's clearance says whether
 //           every pixel of the block falls in cells of that same class (all road / all background); blocks that also
-//           miss every object box are filled with four 32-bit LDS stores per colour plane, the others are queued;
-//   pass 2  the queued blocks' pixels are shaded exactly like the oracle (per-pixel grid lookup + candidate triangle
-//           tests, waypoint discs, agent boxes), 16 pixels of a block spread over 16 lanes so no lane idles;
+//           miss every object box are filled with four 32-bit LDS stores per colour plane.  Blocks on a road edge are
+//           refined into 2x2 sub-blocks (same test at each sub-block centre, 16-bit stores); the pixels that are
+//           left are queued;
+//   pass 2a the queued pixels, spread evenly over the lanes, are shaded exactly like the oracle (waypoint discs, agent
+//           boxes, grid class) — except that pixels in MIXED grid cells not covered by an object are re-queued ...
+//   pass 2b ... and resolved here with the candidate-triangle tests, so the expensive divergent part runs densely;
 //   pass 3  the LDS image is streamed out with 16-B stores: 12 KiB per view, fully coalesced.
 // Every shortcut is conservative (supersets / clearance margins), so each pixel equals the per-pixel specification.
 constexpr int kRenderMaxWp = 64;
@@ -674,8 +677,8 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     __shared__ RenderBox s_box[TDE_MAX_AGENTS];          // slot 0.. = NPC boxes in view, ego kept separately
     __shared__ float4 s_wp[kRenderMaxWp];                // x, y, then pixel bbox packed as 2 x (min | max << 16)
     __shared__ RenderBox s_ego;
-    __shared__ uint16_t s_work[kBlock];
-    __shared__ int s_nbox, s_nwp, s_nwork;
+    __shared__ uint16_t s_work[kRenderMaxPix];           // pixels that need exact shading (r * W + c), then reused in
+    __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed;      // place for the pixels deferred to the triangle pass
     const int e = blockIdx.x, tid = threadIdx.x;
     const int A = st.A, H = rd.H, W = rd.W;
     const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
@@ -691,25 +694,36 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     const float halfH = 0.5f * (float)H, halfW = 0.5f * (float)W;
     // view circle: half diagonal of the image plus slack; lists are supersets, so culling cannot change a pixel
     const float rview = 0.75f * res * (float)(H > W ? H : W) + 1.0f;
-    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; }
+    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }
     const float ex = st.x[g0], ey = st.y[g0];
     float se, ce;
     sincos_f32(st.psi[g0], se, ce);
     __syncthreads();
 
     // conservative pixel bounding box (rows/cols, inclusive) of a disc of radius rad around world point (x, y)
+    // conservative pixel bounding boxes (rows/cols, inclusive; one pixel of slack for rounding): of a disc ...
     auto pixel_bbox = [=](float x, float y, float rad) -> int4 {          // (rmin, rmax, cmin, cmax)
         const float dx = x - ex, dy = y - ey;
         const float f = dx * ce + dy * se, l = dy * ce - dx * se;
-        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.5f;
+        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.0f;
         return make_int4((int)floorf(rc - pr), (int)ceilf(rc + pr), (int)floorf(cc - pr), (int)ceilf(cc + pr));
+    };
+    // ... and of an oriented box (its extent along the image axes is |cos|*hl + |sin|*hw and vice versa)
+    auto box_bbox = [=](float x, float y, float cb, float sb, float hl, float hw) -> int4 {
+        const float dx = x - ex, dy = y - ey;
+        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
+        const float cr = cb * ce + sb * se, sr = sb * ce - cb * se;      // box heading relative to the ego's
+        const float ef = fabsf(cr) * hl + fabsf(sr) * hw, el = fabsf(sr) * hl + fabsf(cr) * hw;
+        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f;
+        const float pr = ef * inv_res + 1.0f, pc = el * inv_res + 1.0f;
+        return make_int4((int)floorf(rc - pr), (int)ceilf(rc + pr), (int)floorf(cc - pc), (int)ceilf(cc + pc));
     };
     if (tid < A) {
         const int64_t g = g0 + tid;
         float sa, ca;
         sincos_f32(st.psi[g], sa, ca);
         const float bx = st.x[g], by = st.y[g], bhl = 0.5f * st.len[g], bhw = 0.5f * st.wid[g];
-        const int4 bb = pixel_bbox(bx, by, bhl + bhw);
+        const int4 bb = box_bbox(bx, by, ca, sa, bhl, bhw);
         RenderBox *dstb = nullptr;
         if (tid == 0) {
             dstb = &s_ego;
@@ -762,8 +776,10 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     const int Wq = W / 4;                                 // dwords per image row
     const int bw = W / 4, nblk = (H / 4) * bw;
 
-    // ---- pass 1: classify 4x4 blocks -------------------------------------------------------------------------
-    const float rblock = 1.5f * 1.41421356f * res * 1.01f + 0.02f;   // pixel centres of a block lie this close to its centre
+    // ---- pass 1: classify 4x4 blocks, refine road-edge blocks to 2x2 ---------------------------------------------
+    const float rblock = 1.5f * 1.41421356f * res * 1.01f + 0.02f;   // pixel centres of a 4x4 block lie this close to its centre
+    const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // ... of a 2x2 block
+    uint16_t *img16 = reinterpret_cast<uint16_t *>(s_img);
     for (int bi = tid; bi < nblk; bi += kBlock) {
         const int r0 = (bi / bw) * 4, c0 = (bi % bw) * 4;
         const float f = (halfH - ((float)r0 + 2.0f)) * res, l = (halfW - ((float)c0 + 2.0f)) * res;
@@ -780,7 +796,10 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
             touched = touched || ((r0 + 1 <= (rr >> 16)) && (r0 + 4 >= (rr & 0xffff)) && (c0 + 1 <= (cc >> 16)) &&
                                   (c0 + 4 >= (cc & 0xffff)));
         }
-        if (uniform && !touched) {
+        uint32_t need = 0;                                     // bit (dr*4 + dc): pixel needs exact shading
+        if (touched) {
+            need = 0xFFFFu;
+        } else if (uniform) {
             const bool road = cls == TDE_CELL_FULL;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
@@ -789,58 +808,101 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
                 for (int i = 0; i < 4; ++i) s_img[ch * (plane / 4) + (r0 + i) * Wq + (c0 >> 2)] = v;
             }
         } else {
-            // bit 15: the road layer of the whole block is known; bit 14: it is road
-            s_work[atomicAdd(&s_nwork, 1)] = (uint16_t)(bi | (uniform ? 0x8000 : 0) | ((cls == TDE_CELL_FULL) ? 0x4000 : 0));
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
+                const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = (halfW - ((float)(c0 + dc) + 1.0f)) * res;
+                const uint32_t ws = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
+                const uint32_t cs = ws & 3u;
+                if ((cs != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((ws >> 2) & 255u) >= rsub)) {
+                    const bool road = cs == TDE_CELL_FULL;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const uint16_t v = (uint16_t)((road ? ROAD[ch] : BG[ch]) * 0x0101u);
+                        img16[(ch * plane + (r0 + dr) * W + c0 + dc) >> 1] = v;
+                        img16[(ch * plane + (r0 + dr + 1) * W + c0 + dc) >> 1] = v;
+                    }
+                } else {
+                    need |= 0x33u << (dr * 4 + dc);
+                }
+            }
+        }
+        if (need) {
+            const int n = __popc(need);
+            int at = atomicAdd(&s_nwork, n);
+            while (need) {
+                const int b = __ffs((int)need) - 1;
+                need &= need - 1u;
+                s_work[at++] = (uint16_t)((r0 + (b >> 2)) * W + c0 + (b & 3));
+            }
         }
     }
     __syncthreads();
 
-    // ---- pass 2: exact per-pixel shading of the queued blocks, 16 lanes per block -------------------------------
-    const int npix = s_nwork * 16;
+    // ---- pass 2a: exact shading of the queued pixels; pixels in MIXED grid cells are deferred --------------------
     uint8_t *img8 = reinterpret_cast<uint8_t *>(s_img);
-    for (int wi = tid; wi < npix; wi += kBlock) {
-        const uint32_t item = s_work[wi >> 4];
-        const int bi = item & 0x3fff, pi = wi & 15;
-        const int r = (bi / bw) * 4 + (pi >> 2), c = (bi % bw) * 4 + (pi & 3);
+    const int npix = s_nwork;
+    for (int base = 0; base < npix; base += kBlock) {
+        const int wi = base + tid;
+        bool defer = false;
+        int pix = 0;
+        if (wi < npix) {
+            pix = s_work[wi];
+            const int r = pix / W, c = pix % W;
+            const float f = (halfH - ((float)r + 0.5f)) * res;
+            const float l = (halfW - ((float)c + 0.5f)) * res;
+            const float wx = (ex + f * ce) - l * se;
+            const float wy = (ey + f * se) + l * ce;
+            int layer = -1;                                   // 0 bg, 1 road, 2 waypoint, 3 npc, 4 ego
+            for (int k = 0; k < nwp; ++k) {
+                const float4 t = s_wp[k];
+                const float dx = wx - t.x, dy = wy - t.y;
+                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
+            }
+            for (int k = 0; k < nbox; ++k) {
+                const RenderBox &b = s_box[k];
+                if (r < b.rmin || r > b.rmax || c < b.cmin || c > b.cmax) continue;
+                const float dx = wx - b.x, dy = wy - b.y;
+                const float p = dx * b.c + dy * b.s, q = dy * b.c - dx * b.s;
+                if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) layer = 3;
+            }
+            {
+                const float dx = wx - ex, dy = wy - ey;
+                const float p = dx * ce + dy * se, q = dy * ce - dx * se;
+                if (fabsf(p) <= s_ego.hl && fabsf(q) <= s_ego.hw) layer = 4;
+            }
+            if (layer < 0) {
+                const uint32_t cls = cell_lookup(w, m, wx, wy) & 3u;
+                if (cls == TDE_CELL_MIXED) defer = true;
+                else layer = (cls == TDE_CELL_FULL) ? 1 : 0;
+            }
+            if (!defer) {
+                img8[pix] = (uint8_t)TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
+                img8[plane + pix] = (uint8_t)TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
+                img8[2 * plane + pix] = (uint8_t)TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
+            }
+        }
+        __syncthreads();                                      // every lane has read its entry of this chunk:
+        if (defer) s_work[atomicAdd(&s_nmixed, 1)] = (uint16_t)pix;   // the compacted list may overwrite it
+        __syncthreads();
+    }
+    // ---- pass 2b: deferred pixels: candidate-triangle tests ---------------------------------------------------
+    const int nmixed = s_nmixed;
+    for (int wi = tid; wi < nmixed; wi += kBlock) {
+        const int pix = s_work[wi];
+        const int r = pix / W, c = pix % W;
         const float f = (halfH - ((float)r + 0.5f)) * res;
         const float l = (halfW - ((float)c + 0.5f)) * res;
         const float wx = (ex + f * ce) - l * se;
         const float wy = (ey + f * se) + l * ce;
-        int layer = 0;                                        // 0 bg, 1 road, 2 waypoint, 3 npc, 4 ego
-        if (item & 0x8000) {
-            layer = (item & 0x4000) ? 1 : 0;
-        } else {
-            const uint32_t wd = cell_lookup(w, m, wx, wy);
-            const uint32_t cls = wd & 3u;
-            bool road = cls == TDE_CELL_FULL;
-            if (cls == TDE_CELL_MIXED) {
-                const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
-                const int n = (int)((wd >> 2) & 255u);
-                for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
-            }
-            layer = road ? 1 : 0;
-        }
-        for (int k = 0; k < nwp; ++k) {
-            const float4 t = s_wp[k];
-            const float dx = wx - t.x, dy = wy - t.y;
-            if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
-        }
-        for (int k = 0; k < nbox; ++k) {
-            const RenderBox &b = s_box[k];
-            if (r < b.rmin || r > b.rmax || c < b.cmin || c > b.cmax) continue;
-            const float dx = wx - b.x, dy = wy - b.y;
-            const float p = dx * b.c + dy * b.s, q = dy * b.c - dx * b.s;
-            if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) layer = 3;
-        }
-        {
-            const float dx = wx - ex, dy = wy - ey;
-            const float p = dx * ce + dy * se, q = dy * ce - dx * se;
-            if (fabsf(p) <= s_ego.hl && fabsf(q) <= s_ego.hw) layer = 4;
-        }
-        const int o = r * W + c;
-        img8[o] = (uint8_t)TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
-        img8[plane + o] = (uint8_t)TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
-        img8[2 * plane + o] = (uint8_t)TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
+        const uint32_t wd = cell_lookup(w, m, wx, wy);
+        const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
+        const int n = (int)((wd >> 2) & 255u);
+        bool road = false;
+        for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
+        img8[pix] = (uint8_t)(road ? ROAD[0] : BG[0]);
+        img8[plane + pix] = (uint8_t)(road ? ROAD[1] : BG[1]);
+        img8[2 * plane + pix] = (uint8_t)(road ? ROAD[2] : BG[2]);
     }
     __syncthreads();
 
