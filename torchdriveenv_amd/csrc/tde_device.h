@@ -93,37 +93,9 @@ TDE_DEV bool obb_overlap(float xi, float yi, float ci, float si, float hli, floa
     return ok;
 }
 
-// R10 building blocks: squared distance point -> segment / triangle (0 inside).
-TDE_DEV float seg_d2(float px, float py, float ax, float ay, float bx, float by)
-{
-    float abx = bx - ax, aby = by - ay;
-    float apx = px - ax, apy = py - ay;
-    float len2 = abx * abx + aby * aby;
-    float t = 0.0f;
-    if (len2 > 0.0f) {
-        float inv = 1.0f / len2;
-        t = (apx * abx + apy * aby) * inv;
-        t = clampf(t, 0.0f, 1.0f);
-    }
-    float qx = apx - t * abx, qy = apy - t * aby;
-    return qx * qx + qy * qy;
-}
-
-TDE_DEV float point_tri_d2(float px, float py, const float *__restrict__ t)
-{
-    float ax = t[0], ay = t[1], bx = t[2], by = t[3], cx = t[4], cy = t[5];
-    float e0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-    float e1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
-    float e2 = (ax - cx) * (py - cy) - (ay - cy) * (px - cx);
-    if ((e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) || (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f)) return 0.0f;
-    float d = seg_d2(px, py, ax, ay, bx, by);
-    d = fminf(d, seg_d2(px, py, bx, by, cx, cy));
-    d = fminf(d, seg_d2(px, py, cx, cy, ax, ay));
-    return d;
-}
-
-// same distances from the packed record (ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,-,-,-): the reciprocals were
-// computed on the host in fp32 exactly like `1.0f / len2`, so no bit changes and no division is left.
+// R10 building blocks: squared distance point -> segment / triangle (0 inside), from the packed triangle record
+// (ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,-,-,-): the reciprocals were computed on the host in fp32 exactly like the
+// oracle's `1.0f / len2`, so the distances keep every bit while the kernel performs no division.
 TDE_DEV float seg_d2_inv(float px, float py, float ax, float ay, float bx, float by, float inv)
 {
     float abx = bx - ax, aby = by - ay;
