@@ -2,7 +2,7 @@
 """bench.py — headline benchmark of the batched env step path (BASELINE.json metric: env-steps/sec and agent-steps/sec
 at 8192 envs x 16 agents on 1/2/4/8 MI355X).
 
-    python bench.py --gpus 1 --steps 4000 --warmup 400
+    python bench.py --gpus 1 --steps 40000 --warmup 2000
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -66,8 +66,8 @@ def cpu_baseline(world, cfg, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=40000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--envs", type=int, default=B_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
