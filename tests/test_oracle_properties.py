@@ -1,0 +1,90 @@
+"""Size-independent properties of the oracle (hypothesis): invariances the domain offers, used as a second pin on the
+delegated arithmetic and as the template for the full-size GPU checks."""
+import math
+
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from oracle import oracle
+from torchdriveenv_amd import _abi
+from torchdriveenv_amd.state import EnvState
+
+F = st.floats
+pose = st.tuples(F(-50, 50), F(-50, 50), F(-math.pi, math.pi))
+
+
+def box(p, L=4.6, W=2.0):
+    return (p[0], p[1], math.cos(p[2]), math.sin(p[2]), L / 2, W / 2)
+
+
+@settings(max_examples=300, deadline=None)
+@given(pose, pose, F(-100, 100), F(-100, 100), F(-math.pi, math.pi))
+def test_sat_is_symmetric_and_rigid_motion_invariant_away_from_the_boundary(a, b, tx, ty, rot):
+    r = oracle.obb_overlap(box(a), box(b))
+    assert r == oracle.obb_overlap(box(b), box(a))
+    # a clearly-overlapping or clearly-separated pair keeps its verdict under a rigid motion
+    d = math.hypot(a[0] - b[0], a[1] - b[1])
+    if d < 1.9 or d > 5.1:       # inside both incircles' reach / beyond both circumcircles
+        def move(p):
+            c, s = math.cos(rot), math.sin(rot)
+            return (c * p[0] - s * p[1] + tx, s * p[0] + c * p[1] + ty, p[2] + rot)
+        assert oracle.obb_overlap(box(move(a)), box(move(b))) == r == (1 if d < 1.9 else 0)
+
+
+@settings(max_examples=200, deadline=None)
+@given(F(-200, 200), F(-200, 200), F(-math.pi, math.pi), F(-5, 25), F(1.4, 2.7), F(-1, 1), F(-0.3, 0.3))
+def test_bicycle_step_properties(x, y, psi, v, lr, a, beta):
+    nx, ny, npsi, nv = oracle.bicycle(x, y, psi, v, lr, a, beta)
+    assert abs(nv - (v + a * 0.1)) < 1e-5
+    assert abs(math.hypot(nx - np.float32(x), ny - np.float32(y)) - abs(nv) * 0.1) < 1e-3   # arc length = |v'| dt
+    assert -math.pi - 1e-6 <= npsi < math.pi + 1e-6
+    want = (math.pi + (psi + nv / lr * math.sin(beta) * 0.1)) % (2 * math.pi) - math.pi
+    err = abs(npsi - want)
+    assert min(err, 2 * math.pi - err) < 1e-4
+
+
+@settings(max_examples=100, deadline=None)
+@given(F(-30, 30), F(-30, 30))
+def test_point_triangle_distance_is_translation_consistent(px, py):
+    tri = np.array([[0, 0, 10, 0, 0, 10]], np.float32)
+    d0 = oracle.point_mesh_d2(px, py, tri)
+    sh = np.array([[100, 50, 110, 50, 100, 60]], np.float32)
+    d1 = oracle.point_mesh_d2(px + 100, py + 50, sh)
+    assert abs(math.sqrt(d0) - math.sqrt(d1)) < 1e-3
+    inside = px >= 0 and py >= 0 and px + py <= 10
+    assert (d0 == 0.0) == inside or abs(px) < 1e-4 or abs(py) < 1e-4 or abs(px + py - 10) < 1e-4
+
+
+def test_rollout_equals_repeated_steps_and_reward_bounds(small_world):
+    cfg = _abi.default_config(seed=5, distance_cutoff=0.25)
+    B, A, K = 48, 16, 230
+    a, b = EnvState(B, A), EnvState(B, A)
+    oracle.env_reset(cfg, small_world, a)
+    oracle.env_reset(cfg, small_world, b)
+    rng = np.random.default_rng(0)
+    actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+    r, d = oracle.env_rollout(cfg, small_world, a, actions)
+    for k in range(K):
+        b["action"][...] = actions[k]
+        oracle.env_step(cfg, small_world, b)
+        assert np.array_equal(b["reward"].view(np.uint32), r[k].view(np.uint32))
+        assert np.array_equal(b["terminated"] | (b["truncated"] << 1), d[k] & 3)
+    ha, hb = a.host(), b.host()
+    for k in ha:
+        if k != "action":
+            assert np.array_equal(ha[k].view(np.uint8), hb[k].view(np.uint8)), k
+    # reward = waypoint_bonus*[reach] + distance_bonus*[moved] - heading_penalty*(1 - cos dpsi)
+    assert r.max() <= 101.0 + 1e-6 and r.min() >= -50.0 - 1e-6
+    assert ((r > 50) == (r > 99 - 50)).all()
+    # episodes never exceed max_steps, and every truncation happens exactly at max_steps
+    assert a["steps"].max() <= cfg.max_steps
+    # determinism: same seed, same result; different seed, different episodes
+    c = EnvState(B, A)
+    oracle.env_reset(cfg, small_world, c)
+    r2, _ = oracle.env_rollout(cfg, small_world, c, actions)
+    assert np.array_equal(r.view(np.uint32), r2.view(np.uint32))
+    cfg3 = _abi.default_config(seed=6, distance_cutoff=0.25)
+    e, f0 = EnvState(B, A), EnvState(B, A)
+    oracle.env_reset(cfg3, small_world, e)
+    oracle.env_reset(cfg, small_world, f0)
+    assert not np.array_equal(e["x"], f0["x"])

@@ -12,6 +12,17 @@ import torch
 from . import _abi, _lib
 
 
+def _call(dev, fn, *args):
+    """invoke a C-ABI entry point with `dev` as the current HIP device (a stream is only valid on its own device);
+    the guard costs nothing in the usual single-device-per-process layout"""
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if torch.cuda.current_device() != idx:
+        with torch.cuda.device(idx):
+            return fn(*args)
+    return fn(*args)
+
+
 def _chk(t, dtype, n, name, device=None, optional=False):
     if t is None:
         if optional:
@@ -39,7 +50,7 @@ def kinematics_step(x, y, psi, v, lr, action, present=None, dt=0.1):
     args = [_chk(t, torch.float32, n, nm, dev) for t, nm in ((x, "x"), (y, "y"), (psi, "psi"), (v, "v"), (lr, "lr"))]
     pp = _chk(present, torch.uint8, n, "present", dev, optional=True)
     pa = _chk(action, torch.float32, 2 * n, "action", dev)
-    _lib.check(L.tde_kinematics_step(n, *args, pp, pa, dt, _lib.current_stream(dev)), "tde_kinematics_step")
+    _lib.check(_call(dev, L.tde_kinematics_step, n, *args, pp, pa, dt, _lib.current_stream(dev)), "tde_kinematics_step")
 
 
 def compute_collision(B, A, x, y, psi, length, width, present, out=None):
@@ -52,7 +63,7 @@ def compute_collision(B, A, x, y, psi, length, width, present, out=None):
     if out is None:
         out = torch.empty(n, dtype=torch.uint8, device=dev)
     po = _chk(out, torch.uint8, n, "out", dev)
-    _lib.check(L.tde_compute_collision(B, A, *ptrs, pp, po, _lib.current_stream(dev)), "tde_compute_collision")
+    _lib.check(_call(dev, L.tde_compute_collision, B, A, *ptrs, pp, po, _lib.current_stream(dev)), "tde_compute_collision")
     return out
 
 
@@ -67,7 +78,7 @@ def compute_offroad(B, A, x, y, psi, length, width, present, dworld, map_of_env,
     if out is None:
         out = torch.empty(n, dtype=torch.uint8, device=dev)
     po = _chk(out, torch.uint8, n, "out", dev)
-    _lib.check(L.tde_compute_offroad(B, A, *ptrs, pp, C.byref(dworld.struct), pm, threshold, po,
+    _lib.check(_call(dev, L.tde_compute_offroad, B, A, *ptrs, pp, C.byref(dworld.struct), pm, threshold, po,
                                      _lib.current_stream(dev)), "tde_compute_offroad")
     return out
 
@@ -83,7 +94,7 @@ def kin_collide_step(B, A, x, y, psi, v, lr, length, width, present, action, dt=
     if out is None:
         out = torch.empty(n, dtype=torch.uint8, device=dev)
     po = _chk(out, torch.uint8, n, "out", dev)
-    _lib.check(L.tde_kin_collide_step(B, A, *ptrs, pp, pa, dt, po, _lib.current_stream(dev)), "tde_kin_collide_step")
+    _lib.check(_call(dev, L.tde_kin_collide_step, B, A, *ptrs, pp, pa, dt, po, _lib.current_stream(dev)), "tde_kin_collide_step")
     return out
 
 
@@ -109,7 +120,7 @@ def waypoint_reward(cfg, pre, post, offroad, collided, tl, wp_xy, wp_n, scn, ste
                truncated=torch.empty(n, dtype=torch.uint8, device=dev),
                info=torch.empty((n, 4), dtype=torch.float64, device=dev) if with_info else None,
                info_reached=torch.empty(n, dtype=torch.int32, device=dev) if with_info else None)
-    _lib.check(L.tde_waypoint_reward(C.byref(cfg), n, *p_pre, *p_post, po, pc, pt, pw, pn, NW, ps, pst, pti, prc,
+    _lib.check(_call(dev, L.tde_waypoint_reward, C.byref(cfg), n, *p_pre, *p_post, po, pc, pt, pw, pn, NW, ps, pst, pti, prc,
                                      out["reward"].data_ptr(), out["terminated"].data_ptr(),
                                      out["truncated"].data_ptr(),
                                      None if out["info"] is None else out["info"].data_ptr(),
@@ -121,7 +132,7 @@ def waypoint_reward(cfg, pre, post, offroad, collided, tl, wp_xy, wp_n, scn, ste
 def env_reset(cfg, dworld, state, mask=None):
     L = _lib.load()
     pm = _chk(mask, torch.uint8, state.B, "mask", optional=True)
-    _lib.check(L.tde_env_reset(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), pm,
+    _lib.check(_call(state.device, L.tde_env_reset, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), pm,
                                _lib.current_stream(state.device)), "tde_env_reset")
 
 
@@ -133,7 +144,7 @@ def env_step(cfg, dworld, state, action=None):
     if action is not None:
         st = _abi.TdeState.from_buffer_copy(state.struct)
         st.action = _chk(action, torch.float32, 2 * state.B, "action", torch.device(state.device))
-    _lib.check(L.tde_env_step(C.byref(cfg), C.byref(dworld.struct), C.byref(st),
+    _lib.check(_call(state.device, L.tde_env_step, C.byref(cfg), C.byref(dworld.struct), C.byref(st),
                               _lib.current_stream(state.device)), "tde_env_step")
 
 
@@ -151,7 +162,7 @@ def env_rollout(cfg, dworld, state, actions, reward=None, done=None):
         done = torch.empty((K, B), dtype=torch.uint8, device=dev)
     ro = _abi.TdeRollout(pa, _chk(reward, torch.float32, K * B, "reward", dev), _chk(done, torch.uint8, K * B, "done", dev),
                          K, 0)
-    _lib.check(L.tde_env_rollout(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(ro),
+    _lib.check(_call(dev, L.tde_env_rollout, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(ro),
                                  _lib.current_stream(dev)), "tde_env_rollout")
     return reward, done
 
@@ -165,6 +176,6 @@ def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
     if out is None:
         out = torch.zeros((state.B, 3 * ns, H, W), dtype=torch.uint8, device=dev)
     rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack)
-    _lib.check(L.tde_render_ego(C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(rd),
+    _lib.check(_call(dev, L.tde_render_ego, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(rd),
                                 _lib.current_stream(dev)), "tde_render_ego")
     return out
