@@ -81,7 +81,8 @@ typedef struct tde_map {
     float ox, oy;               /* grid origin (lower-left corner of cell (0,0)) */
     float cell;                 /* cell edge [m] */
     float inv_cell;             /* 1/cell */
-    int32_t nx, ny;             /* grid size */
+    int32_t nx, ny;             /* grid size in cells, multiples of 8: cell words are stored in 8x8-cell tiles,
+                                   word of cell (ix,iy) at ((iy>>3)*(nx>>3) + (ix>>3))*64 + (iy&7)*8 + (ix&7) */
     int32_t cell_base;          /* first cell of this map in cell_class / cell_start */
     int32_t tri_base;           /* first triangle of this map in tri */
     int32_t n_tri;

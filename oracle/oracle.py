@@ -16,12 +16,26 @@ _LIB_PATH = os.path.join(_HERE, "libtde_oracle.so")
 
 
 def build(force=False):
+    """(re)build libtde_oracle.so when it is older than its sources.  Safe against concurrent callers (pytest-xdist,
+    the 2-rank gloo test): the build runs under a file lock and the library is replaced atomically."""
+    import fcntl
+
     src = os.path.join(_HERE, "tde_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "tde_abi.h")
-    stale = (not os.path.exists(_LIB_PATH) or
-             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
-    if force or stale:
-        subprocess.run(["make", "-C", _HERE, "-B", "libtde_oracle.so"], check=True, capture_output=True)
+
+    def stale():
+        return (not os.path.exists(_LIB_PATH) or
+                os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+
+    if force or stale():
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                tmp = _LIB_PATH + f".tmp{os.getpid()}"
+                subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                                "-fvisibility=hidden", "-Wall", "-Wextra", "-fopenmp", "-shared", "-o", tmp, src, "-lm"],
+                               check=True, capture_output=True)        # same flags as oracle/Makefile
+                os.replace(tmp, _LIB_PATH)
     return _LIB_PATH
 
 

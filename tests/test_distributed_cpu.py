@@ -49,6 +49,8 @@ def _worker(rank, world_size, port, total, K, q):
 @pytest.mark.timeout(300)
 def test_two_rank_sharded_rollout_equals_unsharded():
     total, K = 24, 60
+    from oracle import oracle as _o
+    _o.build()                                   # before the ranks start (they only load it)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -359,3 +359,29 @@ def test_traffic_light_violation_known_answers(small_world):
         assert int(hs["terminated"][0]) == want == int(ds["terminated"].cpu()[0])
         seen.append(want)
     assert 0 < sum(seen) < len(seen)
+
+
+def test_render_crowded_view_takes_the_all_pixels_path():
+    """more agent boxes in view than the LDS list holds (64 slots packed around the ego): the fallback that shades every
+    pixel from the global tables must still equal the oracle"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=4, A=64, seed=5, n_maps=2)
+    cfg = _abi.default_config(seed=3)
+    B, A = 6, 64
+    hs, ds, dw = _pair(world, B, A, cfg)
+    rng = np.random.default_rng(0)
+    h = hs.host()
+    ex, ey = h["x"].reshape(B, A)[:, :1], h["y"].reshape(B, A)[:, :1]
+    x = (ex + rng.uniform(-14, 14, (B, A))).astype(np.float32)
+    y = (ey + rng.uniform(-14, 14, (B, A))).astype(np.float32)
+    x[:, 0], y[:, 0] = ex[:, 0], ey[:, 0]
+    psi = rng.uniform(-np.pi, np.pi, (B, A)).astype(np.float32)
+    psi[:, 0] = h["psi"].reshape(B, A)[:, 0]
+    present = np.ones((B, A), np.uint8)
+    for stt in (hs, ds):
+        stt.load(dict(x=x.reshape(-1), y=y.reshape(-1), psi=psi.reshape(-1), present=present.reshape(-1)))
+    want = oracle.render_ego(cfg, world, hs)
+    got = ops.render_ego(cfg, dw, ds).cpu().numpy()
+    assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ"
+    assert (want[:, 0] == 31).sum() > 2000                 # plenty of NPC-coloured pixels

@@ -95,7 +95,9 @@ def grid_offroad_numpy(world, map_id, px, py, thr):
         if not (fx >= 0 and fy >= 0 and fx < m["nx"] and fy < m["ny"]):
             out[i] = True
             continue
-        wd = int(words[m["cell_base"] + int(fy) * m["nx"] + int(fx)])
+        ix, iy = int(fx), int(fy)
+        tile = (iy >> 3) * (m["nx"] >> 3) + (ix >> 3)
+        wd = int(words[m["cell_base"] + (tile << 6) + ((iy & 7) << 3) + (ix & 7)])
         cls = wd & 3
         if cls != _abi.CELL_MIXED:
             out[i] = cls == _abi.CELL_EMPTY

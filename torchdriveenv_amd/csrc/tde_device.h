@@ -134,7 +134,9 @@ TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, flo
     const float fy = (py - m.oy) * m.inv_cell;
     const int ix = min(max((int)fx, 0), m.nx - 1);
     const int iy = min(max((int)fy, 0), m.ny - 1);
-    return w.cell_word[m.cell_base + iy * m.nx + ix];
+    // cell words are stored in 8x8-cell tiles (256 B) so that neighbouring points share cache lines
+    const int tile = (iy >> 3) * (m.nx >> 3) + (ix >> 3);
+    return w.cell_word[m.cell_base + (tile << 6) + ((iy & 7) << 3) + (ix & 7)];
 }
 
 #define TDE_SEL4(i, a0, a1, a2, a3) ((i) == 0 ? (a0) : (i) == 1 ? (a1) : (i) == 2 ? (a2) : (a3))

@@ -668,16 +668,18 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
 // Every shortcut is conservative (supersets / clearance margins), so each pixel equals the per-pixel specification.
 constexpr int kRenderMaxWp = 64;
 constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS image)
+constexpr int kRenderWork = 2048;                 // exact-pixel queue (a view that needs more takes the all-pixels path)
+constexpr int kRenderMaxBox = 40;                 // agent boxes kept per view (more: all-pixels path)
 
 struct RenderBox { float x, y, c, s, hl, hw; int rmin, rmax, cmin, cmax; };
 
 __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_world w, tde_state st, tde_render rd)
 {
     __shared__ uint32_t s_img[3 * kRenderMaxPix / 4];
-    __shared__ RenderBox s_box[TDE_MAX_AGENTS];          // slot 0.. = NPC boxes in view, ego kept separately
+    __shared__ RenderBox s_box[kRenderMaxBox];           // NPC boxes in view, ego kept separately
     __shared__ float4 s_wp[kRenderMaxWp];                // x, y, then pixel bbox packed as 2 x (min | max << 16)
     __shared__ RenderBox s_ego;
-    __shared__ uint16_t s_work[kRenderMaxPix];           // pixels that need exact shading (r * W + c), then reused in
+    __shared__ uint16_t s_work[kRenderWork];             // pixels that need exact shading (r * W + c), then reused in
     __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed;      // place for the pixels deferred to the triangle pass
     const int e = blockIdx.x, tid = threadIdx.x;
     const int A = st.A, H = rd.H, W = rd.W;
@@ -729,7 +731,10 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
             dstb = &s_ego;
         } else if (st.present[g]) {
             const float dx = bx - ex, dy = by - ey, rr = rview + (bhl + bhw);
-            if (dx * dx + dy * dy <= rr * rr) dstb = &s_box[atomicAdd(&s_nbox, 1)];
+            if (dx * dx + dy * dy <= rr * rr) {
+                const int k = atomicAdd(&s_nbox, 1);
+                if (k < kRenderMaxBox) dstb = &s_box[k];        // beyond: the view takes the all-pixels path
+            }
         }
         if (dstb) {
             dstb->x = bx; dstb->y = by; dstb->c = ca; dstb->s = sa; dstb->hl = bhl; dstb->hw = bhw;
@@ -770,7 +775,8 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
         }
     }
     __syncthreads();
-    const int nbox = s_nbox, nwp = s_nwp < kRenderMaxWp ? s_nwp : kRenderMaxWp;
+    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp;
+    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp;
     const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
                    NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
     const int Wq = W / 4;                                 // dwords per image row
@@ -830,6 +836,7 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
         if (need) {
             const int n = __popc(need);
             int at = atomicAdd(&s_nwork, n);
+            if (at + n > kRenderWork) need = 0;                 // queue full: the view takes the all-pixels path
             while (need) {
                 const int b = __ffs((int)need) - 1;
                 need &= need - 1u;
@@ -839,9 +846,51 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     }
     __syncthreads();
 
-    // ---- pass 2a: exact shading of the queued pixels; pixels in MIXED grid cells are deferred --------------------
     uint8_t *img8 = reinterpret_cast<uint8_t *>(s_img);
-    const int npix = s_nwork;
+    const bool all_pixels = crowded || s_nwork > kRenderWork;
+    if (all_pixels) {
+        // rare fallback (more boxes / waypoints / edge pixels in view than the LDS lists hold): every pixel is shaded
+        // from the global tables, literally as the specification reads
+        const int ti = st.target_idx[e], n_wp = sc.y;
+        for (int pix = tid; pix < plane; pix += kBlock) {
+            const int r = pix / W, c = pix % W;
+            const float f = (halfH - ((float)r + 0.5f)) * res;
+            const float l = (halfW - ((float)c + 0.5f)) * res;
+            const float wx = (ex + f * ce) - l * se;
+            const float wy = (ey + f * se) + l * ce;
+            int layer = 0;
+            {
+                const uint32_t wd = cell_lookup(w, m, wx, wy);
+                const uint32_t cls = wd & 3u;
+                bool road = cls == TDE_CELL_FULL;
+                if (cls == TDE_CELL_MIXED) {
+                    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
+                    const int n = (int)((wd >> 2) & 255u);
+                    for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
+                }
+                layer = road ? 1 : 0;
+            }
+            for (int k = ti; k < n_wp; ++k) {
+                const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
+                const float dx = wx - (float)t.x, dy = wy - (float)t.y;
+                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
+            }
+            for (int a = A - 1; a >= 0; --a) {
+                const int64_t g = g0 + a;
+                if (!st.present[g]) continue;
+                float sa, ca;
+                sincos_f32(st.psi[g], sa, ca);
+                const float dx = wx - st.x[g], dy = wy - st.y[g];
+                const float p = dx * ca + dy * sa, q = dy * ca - dx * sa;
+                if (fabsf(p) <= 0.5f * st.len[g] && fabsf(q) <= 0.5f * st.wid[g]) layer = a ? 3 : 4;
+            }
+            img8[pix] = (uint8_t)TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
+            img8[plane + pix] = (uint8_t)TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
+            img8[2 * plane + pix] = (uint8_t)TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
+        }
+    }
+    // ---- pass 2a: exact shading of the queued pixels; pixels in MIXED grid cells are deferred --------------------
+    const int npix = all_pixels ? 0 : s_nwork;
     for (int base = 0; base < npix; base += kBlock) {
         const int wi = base + tid;
         bool defer = false;

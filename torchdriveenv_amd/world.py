@@ -18,6 +18,15 @@ from . import _abi
 
 # margin that makes the grid classification robust to fp32 evaluation and to the fp32 cell lookup
 GRID_MARGIN = 0.05
+# cell words are stored in tiles of GRID_TILE x GRID_TILE cells (256 B): lookups of neighbouring points (the four
+# corners of a box, the pixels of an image row) then share cache lines instead of touching one line per grid row
+GRID_TILE = 8
+
+
+def tile_cells(a, nx, ny):
+    """row-major [ny*nx] cell array -> tiled order: ((iy//T)*(nx//T) + ix//T)*T*T + (iy%T)*T + ix%T"""
+    T = GRID_TILE
+    return np.ascontiguousarray(a.reshape(ny // T, T, nx // T, T).transpose(0, 2, 1, 3)).reshape(-1)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -61,8 +70,9 @@ def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4
     hi = tri.reshape(-1, 2).max(0) + (R + 2 * cell)
     # the origin must be exactly representable in fp32 (the kernel subtracts it in fp32)
     ox, oy = float(np.float32(math.floor(lo[0]))), float(np.float32(math.floor(lo[1])))
-    nx = int(math.ceil((hi[0] - ox) / cell))
-    ny = int(math.ceil((hi[1] - oy) / cell))
+    # grid sizes are multiples of GRID_TILE: the cell words are stored tile by tile (tile_cells)
+    nx = GRID_TILE * int(math.ceil((hi[0] - ox) / cell / GRID_TILE))
+    ny = GRID_TILE * int(math.ceil((hi[1] - oy) / cell / GRID_TILE))
     h = (cell + 2 * margin) / lattice
     slack = h * math.sqrt(2.0) / 2.0
     # (triangle, cell) pairs from dilated triangle bounding boxes
@@ -289,8 +299,8 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         assert counts.max(initial=0) <= 255, "more than 255 candidate triangles in one grid cell: use a smaller cell"
         start = g["cell_start"][:-1].astype(np.int64) + rec_base
         assert start.max(initial=0) < (1 << 22), "grid index too large for the 22-bit record offset"
-        word_all.append((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
-                         (start.astype(np.uint32) << 10)).astype(np.uint32))
+        word_all.append(tile_cells((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
+                                    (start.astype(np.uint32) << 10)).astype(np.uint32), g["nx"], g["ny"]))
         rec_all.append(packed[g["cell_tris"]])          # per-cell copies: one dependent load less in the kernel
         tri_all.append(tri32.reshape(-1, 6))
         tri_base += len(tri)
