@@ -2,6 +2,7 @@ import math
 import os
 
 import numpy as np
+import pytest
 import yaml
 
 from torchdriveenv_amd import _abi
@@ -75,3 +76,37 @@ def test_shard_ranges_partition_the_batch():
         r = [shard_range(k, ws, total) for k in range(ws)]
         assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r, r[1:]))
     assert shard_range(3, 8, 65536) == (3 * 8192, 4 * 8192)
+
+
+REF_DATA = "/root/reference/torchdriveenv/data"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DATA, "validation_cases.yml")),
+                    reason="reference data files are only present in the build container")
+def test_reference_suites_load_and_step_with_the_oracle():
+    """the reference's own validation / training suites go through the loaders and the world builder unchanged"""
+    from oracle import oracle
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+    from torchdriveenv_amd.state import EnvState
+
+    val = load_waypoint_suite_data(os.path.join(REF_DATA, "validation_cases.yml"))
+    assert val.locations == ["Town07", "Town07", "Town03", "Town03", "Town01"] and len(val.waypoint_suite) == 5
+    assert list(val.car_sequence_suite[1].keys()) == [1] and len(val.car_sequence_suite[1][1]) == 300
+    assert len(val.scenarios[0].agent_states) == 2
+    w = world_from_waypoint_suite(val, agents_per_env=8)
+    assert w.n_scn == 5 and w.arrays["spawn"][1, 1]["replay_len"] == 300
+    cfg = _abi.default_config(seed=1, distance_cutoff=0.25)
+    st = EnvState(10, 8)
+    oracle.env_reset(cfg, w, st)
+    assert set(st["scn"]) <= set(range(5))
+    for _ in range(60):
+        st["action"][...] = [0.5, 0.0]
+        oracle.env_step(cfg, w, st)
+    assert np.isfinite(st["x"]).all() and st["episode"].min() >= 1
+    # the parked replay car of case 1 stays where the file puts it
+    e = int(np.nonzero(st["scn"] == 1)[0][0]) if (st["scn"] == 1).any() else None
+    if e is not None:
+        assert abs(st["x"][e * 8 + 1] - (-55.70970916748047)) < 1e-4 and st["v"][e * 8 + 1] == 0.0
+    train = load_waypoint_suite_data(os.path.join(REF_DATA, "training_cases.yml"))
+    assert len(train.waypoint_suite) == 100 and all(5 <= len(wp) <= 20 for wp in train.waypoint_suite)
+    assert all(s is None for s in train.scenarios)
