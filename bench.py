@@ -98,9 +98,13 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                    device_id=torch.device(f"cuda:{local_rank}"))
-        else:
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                        device_id=torch.device(f"cuda:{local_rank}"))
+            except Exception as exc:      # e.g. several ranks on one GPU: the data path needs no collective, so the
+                print(f"[bench] RCCL init failed ({type(exc).__name__}); timing reduce over gloo", file=sys.stderr)
+                args.backend = "gloo"     # barrier / MAX reduce may as well run over gloo
+        if args.backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
@@ -157,10 +161,14 @@ def main():
                episodes=int(st["episode"].max()))
     assert np.isfinite(chk["reward_sum"])
     if dist is not None:
-        gathered = [None] * world_size if rank == 0 else None
-        dist.gather_object(chk, gathered, dst=0)          # the "host gather" of per-shard results
-        chk = gathered if rank == 0 else chk
-
+        # the "host gather" of per-shard results: three numbers per rank through all_gather (no pickling, so it works
+        # the same over RCCL and gloo), assembled on the host
+        mine = torch.tensor([chk["reward_sum"], chk["done_frac"], float(chk["episodes"])], dtype=torch.float64,
+                            device=dev if args.backend == "nccl" else "cpu")
+        parts = [torch.empty_like(mine) for _ in range(world_size)]
+        dist.all_gather(parts, mine)
+        chk = [dict(rank=i, reward_sum=float(p[0]), done_frac=float(p[1]), episodes=int(p[2]))
+               for i, p in enumerate(parts)]
     if rank == 0:
         n = world_size
         env_steps = B * n * args.steps
@@ -188,7 +196,8 @@ def main():
             "config": {"workload": f"configs[2]: {B} envs x {A} agents per GPU, full step (kinematics + NPC + replay + "
                                    "OBB collision + offroad mesh + waypoint reward + auto-reset)",
                        "envs_per_gpu": B, "agents_per_env": A, "mode": args.mode, "steps_per_call": CH,
-                       "sharding": f"{n} independent shard(s), no data-path collective"},
+                       "sharding": f"{n} independent shard(s), no data-path collective",
+                       "timing_backend": (args.backend if n > 1 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": f"tde::env_rollout_kernel<{A}>" if args.mode == "rollout"
