@@ -357,6 +357,16 @@ TDE_EXPORT int tde_oracle_env_reset(const tde_config *cfg, const tde_world *w, t
     return 0;
 }
 
+/* lights of map m that are red at env step k (the cycle restarts with the episode) */
+static uint32_t tde_red_mask(const tde_world *w, const tde_map *m, int32_t k)
+{
+    if (m->cycle_steps <= 0) return 0u;
+    int32_t t = k % m->cycle_steps;
+    for (int32_t p = 0; p < m->n_phase; ++p)
+        if (t < w->phases[m->phase_base + p].end_step) return w->phases[m->phase_base + p].red_mask;
+    return 0u;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Heuristic NPC controller (R14 slot): pure-pursuit steering on the NPC's route + gap-keeping speed. */
 /* Reads the PRE-step state of every agent of the env.                                               */
@@ -364,7 +374,7 @@ TDE_EXPORT int tde_oracle_env_reset(const tde_config *cfg, const tde_world *w, t
 static void tde_npc_action(const tde_config *cfg, const tde_world *w, int32_t A, int32_t i, const float *x,
                            const float *y, const float *c, const float *s, const float *v, const float *len,
                            const float *wid, const uint8_t *present, float vdes, int32_t route, int32_t route_n,
-                           int32_t wpi, float *acc_out, float *beta_out)
+                           int32_t wpi, const tde_map *m, uint32_t red, float *acc_out, float *beta_out)
 {
     float amax = cfg->npc_max_accel, smax = cfg->npc_max_steer;
     if (route < 0 || wpi >= route_n) {
@@ -401,6 +411,21 @@ static void tde_npc_action(const tde_config *cfg, const tde_world *w, int32_t A,
                 float g = fj - 0.5f * (len[i] + len[j]);
                 gap = fminf(gap, g);
             }
+        }
+    }
+    /* a red stop line ahead in the own lane (same travel direction) counts as a standing leader; the IAI NPCs of the
+     * reference are fed the light state too (gym_env.py:290-291).  Only evaluated while the front bumper has not yet
+     * crossed the line centre, so a car caught on the line by the phase change drives on. */
+    if (m && red) {
+        for (int32_t k = 0; k < m->n_stop; ++k) {
+            const tde_stopline *sl = &w->stoplines[m->stop_base + k];
+            if (!((red >> sl->light) & 1u)) continue;
+            float ex = sl->x - x[i], ey = sl->y - y[i];
+            float fj = ex * cp + ey * sp;
+            float lj = ey * cp - ex * sp;
+            float hd = cp * sl->c + sp * sl->s;
+            float g = fj - 0.5f * len[i];
+            if (g > 0.0f && fabsf(lj) < sl->hw && hd > 0.5f) gap = fminf(gap, g + cfg->npc_gap_s0 - 1.0f);
         }
     }
     /* speed from which a brake at amax/2 stops inside the gap */
@@ -483,10 +508,7 @@ static int tde_tl_violation(const tde_world *w, const tde_map *m, int32_t k, flo
                             float hw)
 {
     if (m->cycle_steps <= 0 || m->n_stop <= 0) return 0;
-    int32_t t = k % m->cycle_steps;
-    uint32_t red = 0;
-    for (int32_t p = 0; p < m->n_phase; ++p)
-        if (t < w->phases[m->phase_base + p].end_step) { red = w->phases[m->phase_base + p].red_mask; break; }
+    const uint32_t red = tde_red_mask(w, m, k);
     for (int32_t i = 0; i < m->n_stop; ++i) {
         const tde_stopline *sl = &w->stoplines[m->stop_base + i];
         if (((red >> sl->light) & 1u) && tde_oracle_obb_overlap(x, y, c, s, hl, hw, sl->x, sl->y, sl->c, sl->s, sl->hl, sl->hw))
@@ -527,13 +549,15 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
      * (or coast with zero action, as NPCWrapper does before teleporting), then replayed agents are
      * overwritten with their recorded state at time k. */
     const tde_spawn *spawn = w->spawn + (int64_t)st->scn[e] * A;   /* route / replay ids of the env's slots */
+    const tde_map *lights_map = (F & TDE_F_TRAFFIC_LIGHTS) ? &w->maps[w->scn[st->scn[e]].map] : NULL;
+    const uint32_t red_now = lights_map ? tde_red_mask(w, lights_map, st->steps[e]) : 0u;   /* lights at decision time */
     for (int32_t a = 0; a < A; ++a) {
         if (!present[a]) continue;
         float acc = 0.0f, beta = 0.0f;
         if (a == 0) { acc = a_acc; beta = a_steer; }
         else if (F & TDE_F_NPC)
             tde_npc_action(cfg, w, A, a, px, py, pc, ps, pv, L, W, present, st->vdes[g0 + a], spawn[a].route,
-                           spawn[a].route_n, st->route_wp[g0 + a], &acc, &beta);
+                           spawn[a].route_n, st->route_wp[g0 + a], lights_map, red_now, &acc, &beta);
         float nx = px[a], ny = py[a], np_ = pp[a], nv = pv[a];
         tde_oracle_bicycle(&nx, &ny, &np_, &nv, LR[a], acc, beta, cfg->dt);
         if ((F & TDE_F_REPLAY) && a > 0) {

@@ -175,7 +175,8 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
 // bit of the oracle's full sweep.
 template <int A, int BLOCK>
 TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, int i, const Agent &ag, float cp,
-                        float sp, bool has_target, float tgx, float tgy, float g_far, float &acc, float &beta)
+                        float sp, bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc,
+                        float &beta)
 {
     using mask_t = typename MaskOf<A>::type;
     const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
@@ -227,6 +228,7 @@ TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, 
     const float dist = sqrtf(dx * dx + dy * dy);
     const float sin_err = lat / fmaxf(dist, 1e-3f);
     beta = (fwd < 0.0f) ? copysignf(smax, lat) : clampf(cfg.npc_k_steer * sin_err, -smax, smax);
+    gap = fminf(gap, red_gap);
     const float vd = fminf(ag.vdes, sqrtf(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
     acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
 }
@@ -237,25 +239,53 @@ struct StepOut {
     bool respawned;
 };
 
-// compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
-// is red at env step k.  Mirrors tde_tl_violation of the oracle.
-TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, int k, float x, float y, float c, float s, float hl,
-                          float hw)
+// lights of map m that are red at env step k (the cycle restarts with the episode)
+TDE_DEV uint32_t red_mask(const tde_world &w, const tde_map &m, int k)
 {
-    if (m.cycle_steps <= 0 || m.n_stop <= 0) return false;
+    if (m.cycle_steps <= 0) return 0u;
     const int t = k % m.cycle_steps;
     uint32_t red = 0;
     for (int p = 0; p < m.n_phase; ++p) {
         const tde_light_phase ph = w.phases[m.phase_base + p];
         if (t < ph.end_step) { red = ph.red_mask; break; }
     }
+    return red;
+}
+
+// compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
+// is red.  Mirrors tde_tl_violation of the oracle.
+TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, uint32_t red, float x, float y, float c, float s,
+                          float hl, float hw)
+{
     bool v = false;
-    for (int i = 0; i < m.n_stop; ++i) {
-        const float4 a = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[0];
-        const float4 b = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[1];   // hl, hw, light, pad
-        if ((red >> __float_as_int(b.z)) & 1u) v = v || obb_overlap(x, y, c, s, hl, hw, a.x, a.y, a.z, a.w, b.x, b.y);
+    if (red) {
+        for (int i = 0; i < m.n_stop; ++i) {
+            const float4 a = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[0];
+            const float4 b = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[1];   // hl, hw, light, pad
+            if ((red >> __float_as_int(b.z)) & 1u) v = v || obb_overlap(x, y, c, s, hl, hw, a.x, a.y, a.z, a.w, b.x, b.y);
+        }
     }
     return v;
+}
+
+// gap to a red stop line ahead in the own lane (same travel direction), treated as a standing leader by the NPC
+// controller.  Mirrors the stop-line loop of the oracle's tde_npc_action.
+TDE_DEV float red_line_gap(const tde_config &cfg, const tde_world &w, const tde_map &m, uint32_t red, const Agent &ag,
+                           float cp, float sp)
+{
+    float gap = 1e30f;
+    for (int k = 0; k < m.n_stop; ++k) {
+        const float4 a = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + k))[0];
+        const float4 b = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + k))[1];
+        if (!((red >> __float_as_int(b.z)) & 1u)) continue;
+        const float ex = a.x - ag.x, ey = a.y - ag.y;
+        const float fj = ex * cp + ey * sp;
+        const float lj = ey * cp - ex * sp;
+        const float hd = cp * a.z + sp * a.w;
+        const float g = fj - 0.5f * ag.len;
+        if (g > 0.0f && fabsf(lj) < b.y && hd > 0.5f) gap = fminf(gap, g + cfg.npc_gap_s0 - 1.0f);
+    }
+    return gap;
 }
 
 TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s, float lane_half)
@@ -295,9 +325,11 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
     float acc = 0.0f, beta = 0.0f;
     if (a == 0) { acc = act_acc; beta = act_steer; }
+    const uint32_t red = (F & TDE_F_TRAFFIC_LIGHTS) ? red_mask(w, cx.m, k) : 0u;
     if (F & TDE_F_NPC) {
         float na, nb;
-        npc_action<A, BLOCK>(cfg, t, base, a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, na, nb);
+        const float red_gap = (red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
+        npc_action<A, BLOCK>(cfg, t, base, a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
         if (npc) { acc = na; beta = nb; }
     }
 
@@ -355,7 +387,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 
     bool tl = false;
     if ((F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid) {
-        tl = tl_violation(w, cx.m, k, ag.x, ag.y, c0, s0, hl, hw);
+        tl = tl_violation(w, cx.m, red, ag.x, ag.y, c0, s0, hl, hw);
     }
     out.tl = tl ? 1 : 0;
 
