@@ -299,7 +299,9 @@ TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag,
 // On entry the tile holds the current state of every slot and (c0, s0) = (cos psi, sin psi) of this slot; both are
 // kept up to date on exit.  `act_acc/act_steer` are the ego action of this lane's env (used by slot 0).
 // Called by all BLOCK lanes of the workgroup, converged (contains barriers and wave ballots).
-template <int A, int BLOCK>
+// LIGHTS: compiled with the traffic-light code (stop-line violation of the ego, NPCs stopping at red lines); the
+// kernels without it serve configs that have no lights at zero cost.
+template <int A, int BLOCK, bool LIGHTS>
 TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold &cold, const tde_state &st,
                           Tiles<BLOCK> &t, int e, int a, bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0,
                           float &s0, float act_acc, float act_steer)
@@ -325,10 +327,10 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
     float acc = 0.0f, beta = 0.0f;
     if (a == 0) { acc = act_acc; beta = act_steer; }
-    const uint32_t red = (F & TDE_F_TRAFFIC_LIGHTS) ? red_mask(w, cx.m, k) : 0u;
+    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
     if (F & TDE_F_NPC) {
         float na, nb;
-        const float red_gap = (red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
+        const float red_gap = (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
         npc_action<A, BLOCK>(cfg, t, base, a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
         if (npc) { acc = na; beta = nb; }
     }
@@ -386,7 +388,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     out.offroad = off ? 1 : 0;
 
     bool tl = false;
-    if ((F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid) {
+    if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid) {
         tl = tl_violation(w, cx.m, red, ag.x, ag.y, c0, s0, hl, hw);
     }
     out.tl = tl ? 1 : 0;
@@ -434,7 +436,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 // kernels
 // ------------------------------------------------------------------------------------------------------------------
 // one launch = one timestep of every env
-template <int A>
+template <int A, bool LIGHTS>
 __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
                                                           const float *__restrict__ action, float *reward_k,
                                                           uint8_t *done_k)
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
-    StepOut o = step_lane<A, kBlock>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
+    StepOut o = step_lane<A, kBlock, LIGHTS>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
     if (!valid) return;
     store_agent_dynamic(st, g, ag);
     if (o.respawned) store_agent_static(st, g, ag);
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
 // (prefetched one step ahead), the per-step reward/done outputs and the grid-index reads; wavefronts never wait for
 // each other, so a wave that takes the rare reset / mesh-boundary path does not stall the batch.
 constexpr int kWave = 64;
-template <int A>
+template <int A, bool LIGHTS>
 __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
 {
     __shared__ Tiles<kWave> t;
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
         const float2 act_next = acts[(int64_t)kn * B + es];      // in flight during this step
-        o = step_lane<A, kWave>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
+        o = step_lane<A, kWave, LIGHTS>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
         if (valid && a == 0) {
             if (ro.reward) ro.reward[(int64_t)k * B + e] = o.reward;
             if (ro.done)
@@ -1124,8 +1126,13 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     if (st->B <= 0) return 0;
     if (!st->action) return bad("tde_env_step: state.action is NULL");
     const unsigned nb = blocks_for((int64_t)st->B * st->A);
-    TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
-                              *cfg, *world, *st, st->action, (float *)nullptr, (uint8_t *)nullptr));
+    if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) {
+        TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
+                                  *cfg, *world, *st, st->action, (float *)nullptr, (uint8_t *)nullptr));
+    } else {
+        TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
+                                  *cfg, *world, *st, st->action, (float *)nullptr, (uint8_t *)nullptr));
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_step", e);
 }
@@ -1139,7 +1146,11 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (st->B <= 0 || ro->K <= 0) return 0;
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-    TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+    if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) {
+        TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, true><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+    } else {
+        TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, false><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
 }
