@@ -200,8 +200,8 @@ def main():
                        "timing_backend": (args.backend if n > 1 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": f"tde::env_rollout_kernel<{A}>" if args.mode == "rollout"
-                         else f"tde::env_step_kernel<{A}>",
+                         "kernel": f"tde::env_rollout_kernel<{A}, false>" if args.mode == "rollout"
+                         else f"tde::env_step_kernel<{A}, false>",
                          "kernel_avg_us": kern_us, "launches": launches, "steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_step": dev_ms * 1e3 / args.steps},
             "check": chk,
