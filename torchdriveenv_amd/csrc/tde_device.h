@@ -44,6 +44,22 @@ TDE_DEV void sincos_f32(float xin, float &s, float &c)
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// sin of a small angle, same bits as sincos_f32: for |x| < 0.75 the reduction index rint(x*2/pi) is 0, the three
+// Cody-Waite subtractions are exact no-ops and the quadrant is 0, so only the sine polynomial is left.
+TDE_DEV float sin_small_f32(float x)
+{
+    if (fabsf(x) < 0.75f) {
+        float z = x * x;
+        float ps = -1.9515295891e-4f;
+        ps = ps * z + 8.3321608736e-3f;
+        ps = ps * z - 1.6666654611e-1f;
+        return x + (x * z) * ps;
+    }
+    float s, c;
+    sincos_f32(x, s, c);
+    return s;
+}
+
 TDE_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
 // torch.remainder(a, b) for b > 0: result in [0, b).  fmodf is exact, so the two fast paths (|a| < b: a itself;
@@ -67,8 +83,7 @@ TDE_DEV void bicycle(float &x, float &y, float &psi, float &v, float lr, float a
     sincos_f32(psi + beta, sn, cs);
     float x1 = x + (v1 * cs) * dt;
     float y1 = y + (v1 * sn) * dt;
-    float sb, cb;
-    sincos_f32(beta, sb, cb);
+    float sb = sin_small_f32(beta);                  // steering is bounded by 0.3 rad in the action space
     float p1 = psi + ((v1 / lr) * sb) * dt;
     p1 = pymodf_pos(kPi + p1, kTwoPi) - kPi;
     x = x1; y = y1; psi = p1; v = v1;
@@ -284,7 +299,7 @@ struct RewardOut {
 template <typename CFG>
 TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, float lx, float ly, float lpsi,
                               float lv, float x, float y, float psi, float v, bool off, bool col, bool tl, int k,
-                              int &target_idx, int &reached)
+                              int &target_idx, int &reached, bool want_info = true)
 {
     RewardOut o;
     double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
@@ -302,8 +317,11 @@ TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, 
     o.reward = (float)((reach_r + o.dist_r) + o.psi_r);
     o.terminated = (uint8_t)(cfg.terminated_at_infraction && (off || col || tl));
     o.truncated = (uint8_t)(k >= cfg.max_steps);
-    o.psi_smooth = (double)fabsf((lpsi - psi) / 0.1f);
-    o.speed_smooth = (double)fabsf((lv - v) / 0.1f);
+    o.psi_smooth = o.speed_smooth = 0.0;
+    if (want_info) {
+        o.psi_smooth = (double)fabsf((lpsi - psi) / 0.1f);
+        o.speed_smooth = (double)fabsf((lv - v) / 0.1f);
+    }
     if (reach) target_idx = ti + 1;
     return o;
 }

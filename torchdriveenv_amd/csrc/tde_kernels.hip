@@ -399,7 +399,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
         if (a == 0 && valid) {
             const int ti0 = er.target_idx;
             RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
-                                      tl, k, er.target_idx, er.reached);
+                                      tl, k, er.target_idx, er.reached, st.info != nullptr);
             out.reward = r.reward;
             out.terminated = r.terminated;
             out.truncated = r.truncated;
