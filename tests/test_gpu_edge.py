@@ -163,3 +163,19 @@ def test_bench_two_ranks_on_one_gpu():
     assert j["metric"] == "env-steps/sec" and j["value"] > 0 and len(j["check"]) == 2
     assert abs(j["value"] - 2 * 2048 * 500 / (j["ms_per_step"] * 1e-3 * 500)) / j["value"] < 1e-6
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(j["roofline"])
+
+
+def test_render_other_sizes_and_bad_sizes(small_world):
+    cfg = _abi.default_config(seed=1)
+    dw = small_world.to_device(DEV)
+    hs, ds = EnvState(5, 16), EnvState(5, 16, device=DEV)
+    oracle.env_reset(cfg, small_world, hs)
+    ops.env_reset(cfg, dw, ds)
+    for (H, W, fov) in ((32, 32, 35.0), (64, 32, 20.0), (48, 64, 50.0)):
+        want = oracle.render_ego(cfg, small_world, hs, H=H, W=W, fov=fov)
+        got = ops.render_ego(cfg, dw, ds, H=H, W=W, fov=fov).cpu().numpy()
+        assert np.array_equal(got, want), (H, W, int((got != want).sum()))
+    with pytest.raises(_lib.TdeError, match="multiples of 4"):
+        ops.render_ego(cfg, dw, ds, H=30, W=30)
+    with pytest.raises(_lib.TdeError, match="4096"):
+        ops.render_ego(cfg, dw, ds, H=128, W=64)
