@@ -110,3 +110,33 @@ def test_reference_suites_load_and_step_with_the_oracle():
     train = load_waypoint_suite_data(os.path.join(REF_DATA, "training_cases.yml"))
     assert len(train.waypoint_suite) == 100 and all(5 <= len(wp) <= 20 for wp in train.waypoint_suite)
     assert all(s is None for s in train.scenarios)
+
+
+def test_load_labeled_data_schema(tmp_path):
+    """scenario-builder export schema (ref env_utils.py:31-105): parked car -> 200 identical states, recorded
+    trajectory -> one row per state with speed 0, single-state agents get an integer speed in [5, 10]"""
+    import json
+
+    from torchdriveenv_amd.loaders import load_labeled_data
+
+    st = lambda x, y, o: {"center": {"x": x, "y": y}, "orientation": o}   # noqa: E731
+    attrs = {"length": 4.5, "width": 2.0, "rear_axis_offset": 1.5}
+    doc = {"individual_suggestions": {"0": {"states": [st(1, 2, 0), st(3, 4, 0)]}},
+           "predetermined_agents": {
+               "1": {"states": {"0": st(5, 6, 0.5)}, "static_attributes": dict(attrs, max_speed=0)},
+               "2": {"states": {"0": st(7, 8, 0.1), "1": st(8, 8, 0.1)}, "static_attributes": attrs},
+               "3": {"states": {"0": st(9, 9, 0.2)}, "static_attributes": attrs}}}
+    (tmp_path / "case_Town03_x.json").write_text(json.dumps(doc))
+    (tmp_path / "notes.txt").write_text("ignored")
+    (tmp_path / "case_Town01_y.json").write_text(json.dumps({"individual_suggestions": doc["individual_suggestions"]}))
+    s = load_labeled_data(str(tmp_path))
+    i = s.locations.index("Town03")
+    assert sorted(s.locations) == ["Town01", "Town03"] and s.waypoint_suite[i] == [[1, 2], [3, 4]]
+    seq = s.car_sequence_suite[i]
+    assert len(seq[1]) == 200 and seq[1][0] == [5, 6, 0.5, 0] and len(seq[2]) == 2 and 3 not in seq
+    rows = s.scenarios[i].agent_states
+    assert rows[1] == [7, 8, 0.1, 0] and 5 <= rows[0][3] <= 10 and 5 <= rows[2][3] <= 10
+    assert s.scenarios[i].agent_attributes[0] == [4.5, 2.0, 1.5] and len(s.scenarios[i].recurrent_states[0]) == 132
+    j = s.locations.index("Town01")
+    assert s.scenarios[j] is None and s.car_sequence_suite[j] is None
+    assert s.traffic_light_state_suite == [None, None] and s.stop_sign_suite == [None, None]

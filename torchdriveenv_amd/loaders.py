@@ -47,44 +47,47 @@ def load_waypoint_suite_data(yaml_path):                   # ref env_utils.py:20
     return data
 
 
-def load_labeled_data(data_dir):                           # ref env_utils.py:31-105 (scenario-builder JSON export)
+def _xy(state):
+    return state["center"]["x"], state["center"]["y"]
+
+
+def _labeled_case(doc):
+    """one scenario-builder export -> (waypoints, Scenario | None, car_sequences | None)   ref env_utils.py:52-100"""
+    waypoints = [list(_xy(st)) for st in doc["individual_suggestions"]["0"]["states"]]
+    agents = doc.get("predetermined_agents")
+    if agents is None:
+        return waypoints, None, None
+    rows, sizes, sequences = [], [], {}
+    for key, ag in agents.items():
+        first = ag["states"]["0"]
+        x0, y0 = _xy(first)
+        # a single recorded state means "drive on": the reference draws an integer speed in [5, 10]   (:68-71)
+        speed = random.randint(5, 10) if len(ag["states"]) == 1 else 0
+        rows.append([x0, y0, first["orientation"], speed])
+        sa = ag["static_attributes"]
+        sizes.append([sa["length"], sa["width"], sa["rear_axis_offset"]])
+        if sa.get("max_speed", None) == 0:                       # parked: 200 copies of the first state   (:86-91)
+            sequences[int(key)] = [[x0, y0, first["orientation"], 0] for _ in range(200)]
+        elif len(ag["states"]) > 1:                              # recorded trajectory, speed column 0      (:93-98)
+            sequences[int(key)] = [[*_xy(ag["states"][t]), ag["states"][t]["orientation"], 0] for t in ag["states"]]
+    scenario = Scenario(agent_states=rows, agent_attributes=sizes,
+                        recurrent_states=[[0] * 132 for _ in rows]) if rows else None
+    return waypoints, scenario, sequences
+
+
+def load_labeled_data(data_dir):
+    """directory of scenario-builder JSON exports -> WaypointSuite (same result as ref env_utils.py:31-105)"""
     suite = WaypointSuite(locations=[], waypoint_suite=[], scenarios=[], car_sequence_suite=[])
-    suite.traffic_light_state_suite = []
-    suite.stop_sign_suite = []
-    for json_file in os.listdir(data_dir):
-        if json_file[-5:] != ".json":
+    suite.traffic_light_state_suite, suite.stop_sign_suite = [], []
+    for name in os.listdir(data_dir):
+        if not name.endswith(".json"):
             continue
-        suite.locations.append(json_file.split('_')[1])
-        with open(os.path.join(data_dir, json_file)) as f:
-            data = json.load(f)
-        suite.waypoint_suite.append([[s['center']['x'], s['center']['y']]
-                                     for s in data['individual_suggestions']['0']['states']])
-        scenario, car_sequences = None, None
-        agents = data.get("predetermined_agents")
-        if agents is not None:
-            states, attrs, recur = [], [], []
-            for aid in agents:
-                ag = agents[aid]
-                speed = random.randint(5, 10) if len(ag['states']) == 1 else 0      # :68-71
-                s0 = ag['states']['0']
-                states.append([s0['center']['x'], s0['center']['y'], s0['orientation'], speed])
-                sa = ag['static_attributes']
-                attrs.append([sa['length'], sa['width'], sa['rear_axis_offset']])
-                recur.append([0] * 132)
-            if states:
-                scenario = Scenario(agent_states=states, agent_attributes=attrs, recurrent_states=recur)
-            car_sequences = {}
-            for aid in agents:
-                ag = agents[aid]
-                s0 = ag['states']['0']
-                if ag["static_attributes"].get("max_speed", None) == 0:            # parked car, :86-91
-                    car_sequences[int(aid)] = [[s0['center']['x'], s0['center']['y'], s0['orientation'], 0]
-                                               for _ in range(200)]
-                elif len(ag['states']) > 1:                                          # :93-98
-                    car_sequences[int(aid)] = [[ag['states'][i]['center']['x'], ag['states'][i]['center']['y'],
-                                                ag['states'][i]['orientation'], 0] for i in ag['states']]
+        with open(os.path.join(data_dir, name)) as f:
+            waypoints, scenario, sequences = _labeled_case(json.load(f))
+        suite.locations.append(name.split("_")[1])
+        suite.waypoint_suite.append(waypoints)
         suite.scenarios.append(scenario)
-        suite.car_sequence_suite.append(car_sequences)
+        suite.car_sequence_suite.append(sequences)
         suite.traffic_light_state_suite.append(None)
         suite.stop_sign_suite.append(None)
     return suite
