@@ -2,10 +2,11 @@
 // exposes them (include/tde_hip.h).  No torch types anywhere: plain device pointers, sizes and a hipStream_t.
 //
 // Mapping (DESIGN.md "Kernels"): one lane per agent slot, env-major, so an env of A (power of two <= 64) slots is a
-// contiguous lane group inside ONE wavefront; 256-thread workgroups hold 256/A envs.  Per-env agent tiles are staged
-// in LDS for the all-pairs sweeps (NPC gap search on the pre-step tile, OBB collision on the post-step tile); env
-// termination is gathered with a wave ballot.  HBM traffic per step is the SoA state read + write; the drivable-mesh
-// grid index and the scenario tables are read-only and stay in L2 / Infinity Cache.
+// contiguous lane group inside ONE wavefront.  The persistent rollout kernel runs one wavefront per workgroup (64/A
+// envs) for K timesteps with the agent state in registers; the one-step kernel uses 256-thread workgroups.  Per-env
+// agent tiles are staged in LDS for the all-pairs sweeps (one tile per step serves the collision sweep of that step
+// and the NPC controller of the next); env termination is gathered with a wave ballot; the drivable-mesh grid index
+// and the scenario tables are read-only and stay in L2 / Infinity Cache.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
