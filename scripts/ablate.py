@@ -8,7 +8,7 @@ from torchdriveenv_amd.synth import synthetic_world
 
 B, A, K = 8192, 16, 250
 dev = torch.device("cuda:0")
-world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=float(os.environ.get("TDE_CELL", "0.5")))
+world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=float(os.environ.get("TDE_CELL", "0.25")))
 dw = world.to_device(dev)
 g = torch.Generator().manual_seed(0)
 actions = torch.stack([torch.rand(K, B, generator=g) * 2 - 1, torch.rand(K, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)

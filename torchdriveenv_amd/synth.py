@@ -85,7 +85,7 @@ def _attrs(rng):
     return (L, W, lr)
 
 
-def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.5, threshold=0.5, lights=True):
+def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.25, threshold=0.5, lights=True):
     """World with `n_scn` scenarios of A-1 NPCs each on `n_maps` junction maps.  Deterministic in `seed`."""
     rng = np.random.default_rng(seed)
     juncs = []
