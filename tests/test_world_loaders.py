@@ -140,3 +140,128 @@ def test_load_labeled_data_schema(tmp_path):
     j = s.locations.index("Town01")
     assert s.scenarios[j] is None and s.car_sequence_suite[j] is None
     assert s.traffic_light_state_suite == [None, None] and s.stop_sign_suite == [None, None]
+
+
+def _bg_doc(town, density, agents):
+    return {"location": f"carla:{town}", "agent_density": density, "random_seed": 1,
+            "agent_states": [{"center": {"x": x, "y": y}, "orientation": o, "speed": v} for x, y, o, v in agents],
+            "agent_attributes": [{"length": 4.5 + 0.1 * k, "width": 2.0, "rear_axis_offset": 1.7, "agent_type": None,
+                                  "waypoint": None} for k in range(len(agents))],
+            "recurrent_states": [{"packed": [0.0] * 4} for _ in agents]}
+
+
+def test_background_traffic_files(tmp_path):
+    """background-traffic schema and file choice of ref gym_env.py:200-220: town taken from the file name, files with
+    agents + density >= 100 are never drawn, recurrent states are dropped"""
+    import json
+    import random
+
+    from torchdriveenv_amd.loaders import load_background_traffic, pick_background_traffic
+
+    ag = [(0.0, 0.0, 0.1, 5.0), (150.0, 0.0, 3.1, 7.0)]
+    (tmp_path / "carla_Town03_10_1.json").write_text(json.dumps(_bg_doc("Town03", 10, ag)))
+    (tmp_path / "carla_Town03_99_2.json").write_text(json.dumps(_bg_doc("Town03", 99, ag)))    # 2 + 99 >= 100
+    (tmp_path / "carla_Town04_10_3.json").write_text(json.dumps(_bg_doc("Town04", 10, ag[:1])))
+    bt = load_background_traffic(str(tmp_path / "carla_Town03_10_1.json"))
+    assert bt["agent_states"][1] == [150.0, 0.0, 3.1, 7.0] and bt["agent_attributes"][1] == [4.6, 2.0, 1.7]
+    assert "recurrent_states" not in bt
+    for s in range(8):
+        got = pick_background_traffic("carla_Town03", str(tmp_path), rng=random.Random(s))
+        assert got["agent_density"] == 10 and len(got["agent_states"]) == 2
+    assert len(pick_background_traffic("Town04", str(tmp_path))["agent_states"]) == 1      # the suites' bare town name
+    assert pick_background_traffic("carla_Town07", str(tmp_path)) is None
+    assert pick_background_traffic("carla_Town03", str(tmp_path / "missing")) is None
+
+
+def test_world_with_background_traffic(tmp_path):
+    """ref gym_env.py:223-231: the ego takes the first background agent's attributes; only background agents farther
+    than 100 m from the ego start are kept; they come after the scenario's own agents; ego_only drops them all"""
+    import json
+
+    from torchdriveenv_amd.config import Scenario, WaypointSuite
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+
+    ag = [(5.0, 0.0, 0.0, 5.0),          # 5 m from the ego start: dropped (near field)
+          (0.0, 99.0, 0.0, 5.0),         # 99 m: dropped
+          (0.0, 180.0, 1.0, 6.0),        # 180 m: kept, second nearest
+          (120.0, 0.0, 3.1, 7.0),        # 120 m: kept, nearest
+          (0.0, 400.0, 0.0, 5.0)]        # beyond background_radius: dropped
+    (tmp_path / "carla_Town03_10_1.json").write_text(json.dumps(_bg_doc("Town03", 10, ag)))
+    data = WaypointSuite(locations=["carla_Town03"], waypoint_suite=[[[0.0, 0.0], [15.0, 0.0], [30.0, 0.0]]],
+                         scenarios=[Scenario(agent_states=[[20.0, 0.0, 0.0, 3.0]], agent_attributes=[[4.0, 1.9, 1.5]],
+                                             recurrent_states=[[0] * 132])],
+                         car_sequence_suite=[None])
+    w = world_from_waypoint_suite(data, agents_per_env=8, background=str(tmp_path))
+    sp = w.arrays["spawn"].reshape(-1, 8)[0]
+    assert list(sp["present"][:5]) == [1, 1, 1, 1, 0]
+    assert np.allclose([sp["len"][0], sp["wid"][0], sp["lr"][0]], [4.5, 2.0, 1.7])          # attributes of bg agent 0
+    assert np.allclose([sp["x"][1], sp["len"][1]], [20.0, 4.0])                              # scenario agent first
+    assert np.allclose([sp["x"][2], sp["y"][2], sp["len"][2]], [120.0, 0.0, 4.8])            # nearest kept bg agent
+    assert np.allclose([sp["x"][3], sp["y"][3], sp["v"][3]], [0.0, 180.0, 6.0])
+    # fewer free slots than kept agents: the nearest ones win
+    w4 = world_from_waypoint_suite(data, agents_per_env=4, background=str(tmp_path))
+    sp4 = w4.arrays["spawn"].reshape(-1, 4)[0]
+    assert list(sp4["present"]) == [1, 1, 1, 1] and np.allclose(sp4["x"][2:], [120.0, 0.0])
+    # no file for the town -> unchanged world; ego_only -> the ego alone
+    w0 = world_from_waypoint_suite(data, agents_per_env=8, background=lambda loc: None)
+    assert list(w0.arrays["spawn"].reshape(-1, 8)[0]["present"][:3]) == [1, 1, 0]
+    we = world_from_waypoint_suite(data, agents_per_env=8, background=str(tmp_path), ego_only=True)
+    assert list(we.arrays["spawn"].reshape(-1, 8)[0]["present"][:2]) == [1, 0]
+    # the background agents stand on drivable surface and step with the oracle without going offroad at once
+    from oracle import oracle
+    from torchdriveenv_amd import _abi
+    from torchdriveenv_amd.state import EnvState
+
+    cfg = _abi.default_config(seed=3)
+    st = EnvState(1, 8)
+    oracle.env_reset(cfg, w, st)
+    st["action"][:] = 0.0
+    oracle.env_step(cfg, w, st)
+    assert st["present"][:4].tolist() == [1, 1, 1, 1] and st["offroad"][:4].tolist() == [0, 0, 0, 0]
+
+
+def test_world_save_load_round_trip(tmp_path):
+    from torchdriveenv_amd.synth import synthetic_world
+    from torchdriveenv_amd.world import World
+
+    w = synthetic_world(n_scn=6, A=8, seed=1, n_maps=2)
+    p = str(tmp_path / "world.npz")
+    w.save(p)
+    w2 = World.load(p)
+    assert w.ints == w2.ints and w.has_lights == w2.has_lights
+    for k, a in w.arrays.items():
+        assert a.dtype == w2.arrays[k].dtype and a.tobytes() == w2.arrays[k].tobytes(), k
+
+
+REF_BG = "/root/reference/torchdriveenv/resources/background_traffic"
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_BG) and os.path.exists(os.path.join(REF_DATA, "validation_cases.yml"))),
+                    reason="reference data not present (GPU box)")
+def test_reference_background_traffic_files_populate_the_world():
+    """the reference's own 75 background-traffic files parse, and validation case 2 (Town03) gets its free slots
+    filled with agents that are > 100 m from the ego start"""
+    import random
+
+    from torchdriveenv_amd.config import WaypointSuite
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+    from torchdriveenv_amd.loaders import load_background_traffic, load_waypoint_suite_data, pick_background_traffic
+
+    files = sorted(os.listdir(REF_BG))
+    assert len(files) == 75
+    for n in files[::9]:
+        bt = load_background_traffic(os.path.join(REF_BG, n))
+        assert len(bt["agent_states"]) == len(bt["agent_attributes"]) > 0 and len(bt["agent_states"][0]) == 4
+    val = load_waypoint_suite_data(os.path.join(REF_DATA, "validation_cases.yml"))
+    one = WaypointSuite(locations=val.locations[2:3], waypoint_suite=val.waypoint_suite[2:3],
+                        scenarios=val.scenarios[2:3], car_sequence_suite=val.car_sequence_suite[2:3])
+    bt = pick_background_traffic(one.locations[0], REF_BG, random.Random(0))
+    w = world_from_waypoint_suite(one, agents_per_env=8, background=lambda loc: bt, background_radius=160.0)
+    sp = w.arrays["spawn"].reshape(-1, 8)[0]
+    n_own = len(one.scenarios[0].agent_states) if one.scenarios[0] is not None else 0
+    ego = np.array(one.waypoint_suite[0][0])
+    kept = [k for k in range(1 + n_own, 8) if sp["present"][k]]
+    assert kept, "no background agent between 100 m and 160 m for this file"
+    for k in kept:
+        assert 100.0 < math.dist(ego, (sp["x"][k], sp["y"][k])) <= 160.0
+    assert np.allclose([sp["len"][0], sp["wid"][0], sp["lr"][0]], bt["agent_attributes"][0])

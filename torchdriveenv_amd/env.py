@@ -63,18 +63,33 @@ def _box(low, high, shape=None, dtype=np.float32):
 ACTION_LOW, ACTION_HIGH = (-1.0, -0.3), (1.0, 0.3)
 
 
-def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=12.0, threshold=0.5):
+def _straight_route(x, y, psi, v):
+    ahead = max(30.0, 25.0 * max(v, 1.0))
+    return [(x + math.cos(psi) * d, y + math.sin(psi) * d) for d in np.arange(8.0, ahead, 8.0)]
+
+
+def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=12.0, threshold=0.5,
+                              background=None, background_radius=250.0, ego_only=False):
     """WaypointSuite -> World.  Agent ordering follows the reference: slot 0 ego, then the scenario's agents
     (ref gym_env.py:219-228); `car_sequence_suite[i][k]` replays slot k (ref gym_env.py:275-283).
     The CARLA town meshes the reference takes from torchdrivesim's package data are not available, so each scenario
     gets a synthetic drivable corridor around its waypoints, scenario agents and replay paths; non-replayed scenario
-    agents get a straight route along their initial heading for the heuristic NPC controller."""
+    agents get a straight route along their initial heading for the heuristic NPC controller.
+
+    `background`: directory of background-traffic JSON files (ref gym_env.py:200-235), or a callable
+    location -> dict from `loaders.load_background_traffic`.  As in the reference the ego takes the attributes of the
+    file's first agent (:223) and the file's agents farther than 100 m from the ego start are kept (:227-231); the
+    near field, which the reference fills through a remote INITIALIZE call (:232-235), stays empty.  Of the kept
+    agents the nearest ones (within `background_radius`, so the synthetic corridor mesh stays local) fill the free
+    slots after the scenario's own agents.  `ego_only`: the ego alone, no scenario / replay / background agents
+    (ref gym_env.py:192-198)."""
+    from . import loaders
     meshes, scenarios = [], []
     n = len(data.waypoint_suite)
     for i in range(n):
         wps = [tuple(p) for p in data.waypoint_suite[i]]
-        scen = data.scenarios[i] if data.scenarios is not None else None
-        seqs = (data.car_sequence_suite[i] if data.car_sequence_suite is not None else None) or {}
+        scen = data.scenarios[i] if data.scenarios is not None and not ego_only else None
+        seqs = (data.car_sequence_suite[i] if data.car_sequence_suite is not None and not ego_only else None) or {}
         seqs = {int(k): v for k, v in seqs.items()}
         polylines = [wps]
         agents = []
@@ -85,8 +100,7 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
                 replay = seqs.get(slot)
                 route = None
                 if replay is None:
-                    ahead = max(30.0, 25.0 * max(v, 1.0))
-                    route = [(x + math.cos(psi) * d, y + math.sin(psi) * d) for d in np.arange(8.0, ahead, 8.0)]
+                    route = _straight_route(x, y, psi, v)
                     polylines.append([(x, y)] + route)
                 else:
                     polylines.append([(r[0], r[1]) for r in replay[::10]] + [(replay[-1][0], replay[-1][1])])
@@ -98,9 +112,26 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
                 agents.append(dict(state=tuple(float(t) for t in r0[:4]), attr=(5.0, 2.0, 1.9), vdes=0.0, route=None,
                                    replay=[tuple(float(t) for t in r[:4]) for r in replay]))
                 polylines.append([(r[0], r[1]) for r in replay[::10]] + [(replay[-1][0], replay[-1][1])])
+        ego_attr = None
+        if background is not None and not ego_only:
+            loc = data.locations[i] if data.locations else ""
+            bt = background(loc) if callable(background) else loaders.pick_background_traffic(loc, background)
+            if bt is not None and bt["agent_states"]:
+                ego_attr = tuple(float(t) for t in bt["agent_attributes"][0][:3])
+                far = [(math.dist(wps[0], s[:2]), k) for k, s in enumerate(bt["agent_states"])]
+                far = sorted((d, k) for d, k in far if 100.0 < d <= background_radius)
+                for _, k in far[:max(0, agents_per_env - 1 - len(agents))]:
+                    x, y, psi, v = [float(t) for t in bt["agent_states"][k][:4]]
+                    route = _straight_route(x, y, psi, v)
+                    polylines.append([(x, y)] + route)
+                    agents.append(dict(state=(x, y, psi, v), attr=tuple(float(t) for t in bt["agent_attributes"][k][:3]),
+                                       vdes=v, route=route, replay=None))
         heading = math.atan2(wps[1][1] - wps[0][1], wps[1][0] - wps[0][0])
         meshes.append(corridor_mesh(polylines, width=road_width))
-        scenarios.append(dict(map=i, waypoints=wps, start_heading=heading, agents=agents[:agents_per_env - 1]))
+        scn = dict(map=i, waypoints=wps, start_heading=heading, agents=agents[:agents_per_env - 1])
+        if ego_attr is not None:
+            scn["ego_attr"] = ego_attr
+        scenarios.append(scn)
     return assemble_world(meshes, scenarios, agents_per_env, threshold=threshold)
 
 
@@ -115,7 +146,7 @@ class BatchedWaypointEnv:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 10}   # ref gym_env.py:73-76
 
     def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
-                 frame_stack=1, auto_reset=True, with_info=True):
+                 frame_stack=1, auto_reset=True, with_info=True, background=None):
         if cfg.render_mode is not None and cfg.render_mode not in ("rgb_array", "video"):
             raise NotImplementedError                              # ref gym_env.py:79-80
         if obs_mode not in ("birdview", "state"):
@@ -125,8 +156,12 @@ class BatchedWaypointEnv:
         if dev is None or not torch.cuda.is_available():
             raise RuntimeError("torchdriveenv_amd needs a HIP device: there is no CPU path")
         self.torch_device = torch.device(dev if str(dev) != "cuda" else "cuda:0")
+        if background is None and cfg.use_background_traffic:        # ref gym_env.py:200-203: the packaged directory
+            from .loaders import pick_background_traffic
+            background = pick_background_traffic                     # (searched under TORCHDRIVEENV_DATA; None if absent)
         self.world = data if isinstance(data, World) else world_from_waypoint_suite(
-            data, agents_per_env, threshold=cfg.simulator.offroad_threshold)
+            data, agents_per_env, threshold=cfg.simulator.offroad_threshold,
+            background=background if cfg.use_background_traffic else None, ego_only=cfg.ego_only)
         self.A = self.world.A
         self.num_envs = int(num_envs)
         seed = cfg.seed if cfg.seed is not None else int(np.random.randint(0, 2**31 - 1))  # ref helpers.py:39-41

@@ -93,6 +93,45 @@ def load_labeled_data(data_dir):
     return suite
 
 
+def load_background_traffic(json_path):
+    """one `resources/background_traffic/*.json` file of the reference (the schema read at ref gym_env.py:207-216) ->
+    dict(location, agent_density, random_seed, agent_states [[x, y, psi, v]], agent_attributes [[length, width,
+    rear_axis_offset]]).  The recurrent states feed the remote model only (ref gym_env.py:216,286-287) and are dropped."""
+    with open(json_path) as f:
+        doc = json.load(f)
+    states = [[*_xy(st), st["orientation"], st["speed"]] for st in doc["agent_states"]]
+    attrs = [[at["length"], at["width"], at["rear_axis_offset"]] for at in doc["agent_attributes"]]
+    return dict(location=doc["location"], agent_density=doc["agent_density"], random_seed=doc.get("random_seed"),
+                agent_states=states, agent_attributes=attrs)
+
+
+def _background_dirs():
+    return [os.path.join(root, "background_traffic") for root in _data_path()] + \
+           [os.path.join(os.path.dirname(root), "resources", "background_traffic") for root in _data_path()]
+
+
+def pick_background_traffic(location, background_dir=None, rng=random):
+    """the file choice of ref gym_env.py:202-220: a random file of the directory whose name carries the town of
+    `location` (map name "carla_Town03", or the suite's bare "Town03", == name.split("_")[1]), redrawn until
+    agents + density < 100.
+    Returns the loaded dict, or None when the directory holds no file for that town."""
+    dirs = [background_dir] if background_dir else _background_dirs()
+    town = location[6:] if location.startswith("carla_") else location
+    for d in dirs:
+        if not d or not os.path.isdir(d):
+            continue
+        names = sorted(n for n in os.listdir(d) if n.endswith(".json") and len(n.split("_")) > 1
+                       and n.split("_")[1] == town)
+        docs = []
+        for n in names:
+            bt = load_background_traffic(os.path.join(d, n))
+            if len(bt["agent_states"]) + bt["agent_density"] < 100:
+                docs.append(bt)
+        if docs:
+            return rng.choice(docs)
+    return None
+
+
 def _data_path():
     roots = []
     if os.environ.get("TORCHDRIVEENV_DATA"):

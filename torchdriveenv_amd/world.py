@@ -32,23 +32,34 @@ def tile_cells(a, nx, ny):
 # ------------------------------------------------------------------------------------------------
 # geometry helpers (float64, host, build time only)
 # ------------------------------------------------------------------------------------------------
-def _pairs_point_tri_dist(p, tri):
-    """p [P,L,2], tri [P,3,2] -> distance [P,L] of every lattice point to its pair's triangle (0 inside)"""
-    a, b, c = tri[:, None, 0], tri[:, None, 1], tri[:, None, 2]
-
-    def cross(u, v):
-        return u[..., 0] * v[..., 1] - u[..., 1] * v[..., 0]
-
-    def seg(p, a, b):
-        ab, ap = b - a, p - a
-        l2 = (ab * ab).sum(-1)
-        t = np.clip((ap * ab).sum(-1) / np.where(l2 > 0, l2, 1.0), 0.0, 1.0)
-        q = ap - t[..., None] * ab
-        return (q * q).sum(-1)
-
-    e0, e1, e2 = cross(b - a, p - a), cross(c - b, p - b), cross(a - c, p - c)
-    inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
-    d2 = np.minimum(np.minimum(seg(p, a, b), seg(p, b, c)), seg(p, c, a))
+def _pairs_point_tri_dist(p, tri, want_depth=False):
+    """p [P,L,2], tri [P,3,2] -> distance [P,L] of every lattice point to its pair's triangle (0 inside); with
+    `want_depth` also the distance of inside points to the triangle's boundary (0 outside).
+    Component-wise (x and y as separate arrays): reductions over a length-2 axis are what numpy is slowest at."""
+    px, py = p[..., 0], p[..., 1]
+    vx = [tri[:, k, 0][:, None] for k in range(3)]
+    vy = [tri[:, k, 1][:, None] for k in range(3)]
+    d2 = None
+    pos = neg = None
+    depth2 = None
+    for k in range(3):
+        ax, ay, bx, by = vx[k], vy[k], vx[(k + 1) % 3], vy[(k + 1) % 3]
+        abx, aby = bx - ax, by - ay
+        apx, apy = px - ax, py - ay
+        e = abx * apy - aby * apx
+        pos = (e >= 0) if pos is None else pos & (e >= 0)
+        neg = (e <= 0) if neg is None else neg & (e <= 0)
+        l2 = abx * abx + aby * aby
+        t = np.clip((apx * abx + apy * aby) / np.where(l2 > 0, l2, 1.0), 0.0, 1.0)
+        qx, qy = apx - t * abx, apy - t * aby
+        s = qx * qx + qy * qy
+        d2 = s if d2 is None else np.minimum(d2, s)
+        if want_depth:
+            h2 = e * e / np.where(l2 > 0, l2, 1.0)
+            depth2 = h2 if depth2 is None else np.minimum(depth2, h2)
+    inside = pos | neg
+    if want_depth:
+        return np.where(inside, 0.0, np.sqrt(d2)), np.where(inside, np.sqrt(depth2), 0.0)
     return np.where(inside, 0.0, np.sqrt(d2))
 
 
@@ -92,16 +103,30 @@ def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4
     g = np.arange(lattice + 1, dtype=np.float64) * h - margin
     lat = np.stack(np.meshgrid(g, g, indexing="xy"), -1).reshape(-1, 2)          # [L,2] offsets inside a cell
     L = lat.shape[0]
-    dmin = np.full((nx * ny, L), np.inf)
+    ucell, row = np.unique(pc, return_inverse=True)                             # lattice minima only for touched cells
+    dmin = np.full((len(ucell), L), np.inf)
     keep = np.zeros(pt.shape, dtype=bool)
-    CH = 200_000
+    covered = np.zeros(nx * ny, dtype=bool)
+    # the lattice is only evaluated for pairs the cell centre cannot decide: with r = half diagonal of the grown cell,
+    # a centre farther than R + slack + r keeps every lattice point beyond R + slack (the pair matters to neither
+    # decision); a centre at depth >= r inside the triangle puts the whole grown cell inside it (cell is FULL)
+    r = (0.5 * cell + margin) * math.sqrt(2.0) + 1e-9
+    ctr = np.array([[0.5 * cell, 0.5 * cell]])
+    CH = 400_000
     for s0 in range(0, len(pt), CH):
         t_, c_ = pt[s0:s0 + CH], pc[s0:s0 + CH]
         org = np.stack([ox + (c_ % nx) * cell, oy + (c_ // nx) * cell], -1)      # [P,2]
-        d = _pairs_point_tri_dist(org[:, None, :] + lat[None], tri[t_])          # [P,L]
-        keep[s0:s0 + CH] = d.min(1) <= R + slack
-        np.minimum.at(dmin, c_, d)
-    full = (dmin <= (threshold - margin) - slack).all(1)
+        dc, depth = _pairs_point_tri_dist(org[:, None, :] + ctr[None], tri[t_], want_depth=True)
+        dc, depth = dc[:, 0], depth[:, 0]
+        deep = depth >= r
+        covered[c_[deep]] = True
+        band = np.nonzero(~deep & (dc <= R + slack + r))[0]
+        if len(band):
+            d = _pairs_point_tri_dist(org[band][:, None, :] + lat[None], tri[t_[band]])   # [P',L]
+            keep[s0 + band] = d.min(1) <= R + slack
+            np.minimum.at(dmin, row[s0 + band], d)
+    full = covered
+    full[ucell] |= (dmin <= (threshold - margin) - slack).all(1)
     pt, pc = pt[keep], pc[keep]
     order = np.lexsort((pt, pc))
     pt, pc = pt[order], pc[order]
@@ -250,6 +275,27 @@ class World:
 
     def map_of_scn(self):
         return np.ascontiguousarray(self.arrays["scn"]["map"])
+
+    def save(self, path):
+        """cache the assembled tables (grid indexes of town-sized meshes take seconds per scenario to build)"""
+        blobs = {f"a_{k}": a.reshape(-1).view(np.uint8) if a.dtype.names is not None else a
+                 for k, a in self.arrays.items()}
+        ints = np.array([self.ints[k] for k in _abi.WORLD_INTS], dtype=np.int64)
+        with open(path, "wb") as f:
+            np.savez(f, abi=np.int64(_abi.TDE_ABI_VERSION), ints=ints, **blobs)
+
+    @classmethod
+    def load(cls, path):
+        with np.load(path) as z:
+            if int(z["abi"]) != _abi.TDE_ABI_VERSION:
+                raise ValueError(f"{path}: built for ABI {int(z['abi'])}, this library is ABI {_abi.TDE_ABI_VERSION}")
+            ints = dict(zip(_abi.WORLD_INTS, (int(v) for v in z["ints"])))
+            arrays = {}
+            for k in _abi.WORLD_PTRS:
+                dt = np.dtype(_abi.WORLD_DTYPES[k])
+                a = z[f"a_{k}"]
+                arrays[k] = a.view(dt) if dt.names is not None else a
+        return cls(arrays, ints)
 
 
 class DeviceWorld:
