@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/tde_hip.h"
 #include "tde_device.h"
@@ -45,6 +47,24 @@ struct Tiles {
 constexpr float kFar = 1e18f;
 
 template <int A> struct MaskOf { using type = uint32_t; };
+
+// All-pairs sweeps read the A tile rows of the lane's env.  Issued one by one next to their use, every ds_read_b128
+// exposes its full LDS latency to the lone wavefront (stamps: ~120 cycles per swept slot for ~45 cycles of work);
+// the rows are therefore fetched in blocks of kSweepBlock before any of them is used.
+constexpr int kSweepBlock = 8;
+template <int A, typename F> TDE_DEV void sweep_rows(const float4 *rows, F &&f)
+{
+    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
+#pragma unroll
+    for (int c = 0; c < A; c += C) {
+        float4 r[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) r[j] = rows[c + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < C; ++j) f(c + j, r[j]);
+    }
+}
 template <> struct MaskOf<64> { using type = unsigned long long; };
 TDE_DEV int lowest_bit(uint32_t m) { return __ffs((int)m) - 1; }
 TDE_DEV int lowest_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
@@ -174,8 +194,9 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
 // tests then run only for the set bits, every lane walking its own list (the wavefront iterates
 // max-over-lanes(popcount) times, usually 0-2).  Skipped slots cannot change the result, so the action keeps every
 // bit of the oracle's full sweep.
-template <int A, int BLOCK>
-TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, int i, const Agent &ag, float cp,
+// ra / rb: the a / b tile rows of the lane's env (slot 0 first).
+template <int A>
+TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp,
                         float sp, bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc,
                         float &beta)
 {
@@ -186,17 +207,18 @@ TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, 
     if (has_target) {
         // conservative forms of the exact tests below (5 cm / 1 cm of slack >> fp32 rounding): a slot that fails
         // here fails there; min3 > 0 folds the three conditions into one sign test
+        // The prefilter only has to be a superset, so it is free to round differently from the exact tests: the
+        // forward / lateral offsets are evaluated as bilinear forms with fused multiply-adds (|error| < 1e-3 m for
+        // |coordinates| < 1e4 m, inside the 1 cm the three conditions are relaxed by).
         const float lim_i = (g_far + hl_i) + 0.05f;
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float4 pj = t.a[base + j];
-            const float ex = pj.x - ag.x, ey = pj.y - ag.y;
-            const float fj = ex * cp + ey * sp;
-            const float lj = ey * cp - ex * sp;
-            const float near = (lim_i + pj.z) - fj;                                  // g < g_far
-            const float wide = ((pj.w + 0.01f) + cfg.npc_cone_k * fj) - fabsf(lj);      // inside the widest corridor
-            cand |= (fminf(fminf(fj, near), wide) > 0.0f) ? (mask_t)1 << j : (mask_t)0;
-        }
+        const float nPi = -(ag.x * cp + ag.y * sp), nQi = -(ag.y * cp - ag.x * sp);
+        sweep_rows<A>(ra, [&](int j, const float4 &pj) {      // pj = (x, y, reach, lane half width) of slot j
+            const float fj = __builtin_fmaf(pj.x, cp, __builtin_fmaf(pj.y, sp, nPi));
+            const float lj = __builtin_fmaf(pj.y, cp, __builtin_fmaf(-pj.x, sp, nQi));
+            const float near = (lim_i + pj.z) - fj;                                  // g < g_far (reach >= hl_j)
+            const float wide = __builtin_fmaf(cfg.npc_cone_k, fj, pj.w) - fabsf(lj);    // inside the widest corridor
+            cand |= (fminf(fminf(fj, near), wide) > -0.01f) ? (mask_t)1 << j : (mask_t)0;
+        });
         cand &= ~((mask_t)1 << i);
     }
     float gap = 1e30f;
@@ -204,17 +226,18 @@ TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, 
         if (cand) {
             const int j = lowest_bit(cand);
             cand &= cand - 1;
-            const float4 pj = t.a[base + j], qj = t.b[base + j];
+            const float4 pj = ra[j], qj = rb[j];
             const float ex = pj.x - ag.x, ey = pj.y - ag.y;
             const float fj = ex * cp + ey * sp;
             const float lj = ey * cp - ex * sp;
             const float halfw = pj.w;                      // = npc_lane_half + 0.5f * wid_j, formed by slot j
+            const float hl_j = qj.z;
             const float al = fabsf(lj);
             const bool inlane = al < halfw;
             const float hd = cp * qj.x + sp * qj.y;
             const bool cone = (j < i) && (fj < cfg.npc_cone_range) && (al < halfw + cfg.npc_cone_k * fj) && (hd > -0.5f);
             // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit (scaling by 2 commutes with rounding)
-            const float g = fj - (hl_i + pj.z);
+            const float g = fj - (hl_i + hl_j);
             if (fj > 0.0f && (inlane || cone)) gap = fminf(gap, g);
         }
     }
@@ -232,6 +255,37 @@ TDE_DEV void npc_action(const tde_config &cfg, const Tiles<BLOCK> &t, int base, 
     gap = fminf(gap, red_gap);
     const float vd = fminf(ag.vdes, sqrtf(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
     acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
+}
+
+// R9 for one slot against the A slots of its env (rows ra / rb).  Overlapping convex boxes have centres closer than the
+// sum of their circumradii; hl+hw >= circumradius, so a pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact
+// or in fp32 arithmetic (the 1.001 is folded into the radii, kReach).  Phase 1 marks the pairs inside that radius
+// (branch-free, free to fuse its multiply-adds), phase 2 runs the 4-axis SAT test on the marked ones only.
+// Called by all lanes of the wavefront, converged.
+template <int A>
+TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
+                          float hl, float hw, float ri)
+{
+    using mask_t = typename MaskOf<A>::type;
+    mask_t cand = 0;
+    if (live) {
+        sweep_rows<A>(ra, [&](int j, const float4 &pj) {
+            const float dx = pj.x - x, dy = pj.y - y;
+            const float rr = ri + pj.z;
+            cand |= (__builtin_fmaf(dx, dx, dy * dy) <= rr * rr) ? (mask_t)1 << j : (mask_t)0;
+        });
+        cand &= ~((mask_t)1 << a);
+    }
+    bool hit = false;
+    while (__ballot(cand != 0)) {
+        if (cand) {
+            const int j = lowest_bit(cand);
+            cand &= cand - 1;
+            const float4 pj = ra[j], qj = rb[j];
+            hit = hit || obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
+        }
+    }
+    return hit;
 }
 
 struct StepOut {
@@ -289,11 +343,16 @@ TDE_DEV float red_line_gap(const tde_config &cfg, const tde_world &w, const tde_
     return gap;
 }
 
+// hl + hw bounds the circumradius; kReach^2 >= 1.001 keeps the circle test a superset of the SAT test in fp32
+constexpr float kReach = 1.0005f;
+
 TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s, float lane_half)
 {
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
-    ta = live ? make_float4(ag.x, ag.y, hl, lane_half + hw) : make_float4(kFar, kFar, 0.0f, 0.0f);
-    tb = make_float4(c, s, hl + hw, hw);
+    // a: what the branch-free sweeps read (position, reach = padded hl + hw, lane half width); b: the rest of what the
+    // exact tests need (heading, half extents)
+    ta = live ? make_float4(ag.x, ag.y, (hl + hw) * kReach, lane_half + hw) : make_float4(kFar, kFar, 0.0f, 0.0f);
+    tb = make_float4(c, s, hl, hw);
 }
 
 // One timestep for this lane's agent slot.  WaypointSuiteEnv.step over GymEnv.step, ref gym_env.py:369-389,115-120.
@@ -332,7 +391,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     if (F & TDE_F_NPC) {
         float na, nb;
         const float red_gap = (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
-        npc_action<A, BLOCK>(cfg, t, base, a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+        npc_action<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
         if (npc) { acc = na; beta = nb; }
     }
 
@@ -349,37 +408,14 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     // ---- post-step tile: collision sweep now, NPC controller next step -----------------------------------------
     sincos_f32(ag.psi, s0, c0);
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
-    const float ri = hl + hw;
+    const float ri = (hl + hw) * kReach;
     Corners corners;                                // cell words of the four corners: loads stay in flight during
     if (F & TDE_F_OFFROAD)                          // the collision sweep
         offroad_issue(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
     __syncthreads();                                // every lane is done reading the pre-step tile
     write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
-    // Overlapping convex boxes have centres closer than the sum of their circumradii; hl+hw >= circumradius, so a
-    // pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact or in fp32 arithmetic.  Phase 1 marks the
-    // pairs inside that radius (branch-free), phase 2 runs the 4-axis SAT test on the marked ones only.
-    mask_t cand = 0;
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float4 pj = t.a[base + j];
-            const float rj = t.b[base + j].z;
-            const float dx = pj.x - ag.x, dy = pj.y - ag.y;
-            const float rr = ri + rj;
-            cand |= (dx * dx + dy * dy <= (rr * rr) * 1.001f) ? (mask_t)1 << j : (mask_t)0;
-        }
-        cand &= ~((mask_t)1 << a);
-    }
-    bool hit = false;
-    while (__ballot(cand != 0)) {
-        if (cand) {
-            const int j = lowest_bit(cand);
-            cand &= cand - 1;
-            const float4 pj = t.a[base + j], qj = t.b[base + j];
-            hit = hit || obb_overlap(ag.x, ag.y, c0, s0, hl, hw, pj.x, pj.y, qj.x, qj.y, pj.z, qj.w);
-        }
-    }
+    const bool hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
     // the next route waypoint is fetched while the offroad test runs
     if (switched) load_route_target(cold, ag, cx);
 
@@ -544,6 +580,208 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two-role persistent rollout.  A lone wavefront cannot issue faster than its dependent-instruction latency allows
+// (~10 cycles per dependent fp32 VALU op against ~2 cycles of issue, scripts/ubench/valu_latency.hip), and the headline
+// batch only fills two wavefronts per SIMD, so the single-role kernel above leaves half of the issue slots empty.
+// Here every group of 64 agent slots is served by TWO wavefronts of one workgroup that split the step by role:
+//   drive : NPC controller + bicycle integration + replay + route switching (R4, R5, R14) -> the next tile
+//   judge : collision, offroad, stop-line violation, reward / termination, outputs, waypoint advance (R6-R12)
+// The judge works on step i while the driver already computes step i+1 from the same tile, speculating that no env of
+// its wavefront finished; when one did (about 7 % of wave-steps) the driver re-spawns those lanes and recomputes.
+// Tiles are double-buffered by step parity; per step two LDS-only barriers:
+//   A: judge has published done(i-1) and is finished with both tile buffers
+//   B: driver has committed the rows of step i (and any re-spawned rows of step i-1)
+// Same arithmetic in the same order per agent as step_lane, so results stay bit-identical to the oracle.
+// ------------------------------------------------------------------------------------------------------------------
+struct DuoShared {
+    float4 a[2][kWave], b[2][kWave];
+    float4 c[2][kWave];                  // (psi, v, live, -): what the judge's ego lane and liveness test need
+    unsigned long long done;             // ballot of the ego lanes whose env finished at the last judged step
+};
+
+// LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
+TDE_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+TDE_DEV void write_rows(DuoShared &sh, int buf, int lane, bool live, const Agent &ag, float c, float s, float lane_half)
+{
+    write_tile_slot(sh.a[buf][lane], sh.b[buf][lane], live, ag, c, s, lane_half);
+    sh.c[buf][lane] = make_float4(ag.psi, ag.v, live ? 1.0f : 0.0f, 0.0f);
+}
+
+template <int A, bool LIGHTS>
+__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_rollout_duo_kernel(tde_config cfg, tde_world w, tde_state st,
+                                                                    tde_rollout ro)
+{
+    __shared__ DuoShared sh;
+    __shared__ Cold cold;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = drive, 1 = judge
+    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull; }
+    const uint32_t F = cfg.flags;
+    const int64_t g = (int64_t)blockIdx.x * kWave + lane;
+    const int e = (int)(g / A), a = (int)(g % A);
+    const int B = st.B;
+    const bool valid = e < B;
+    const int64_t gs = valid ? g : 0;
+    const int es = valid ? e : 0;
+    const int base = lane - a;
+    Agent ag;
+    load_agent(st, gs, ag);
+    if (!valid) ag.present = false;
+    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
+    __syncthreads();                                         // cold is filled
+    Ctx cx;
+    load_ctx<A>(cfg, cold, a, ag, er, cx);
+
+    if (role == 0) {
+        // ================================ drive ================================
+        float c0, s0;
+        sincos_f32(ag.psi, s0, c0);
+        write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
+        lds_barrier();                                       // rows of the launch state are in buffer 1
+        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
+        float2 act = acts[es];
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1, q = p ^ 1;
+            const int kn = (i + 1 < ro.K) ? i + 1 : i;
+            const float2 act_next = acts[(int64_t)kn * B + es];
+            float nx, ny, npsi, nv, nc, ns;
+            int nwp, k;
+            bool switched, live;
+            for (int pass = 0;; ++pass) {
+                // one step from the rows in buffer q, nothing committed yet (step_lane up to the tile write)
+                k = er.steps + 1;                                                            // :116
+                live = valid && ag.present;
+                const bool npc = (F & TDE_F_NPC) && a > 0 && live;
+                const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
+                float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
+                const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                float acc = 0.0f, beta = 0.0f;
+                if (a == 0) { acc = act.x; beta = act.y; }
+                if (F & TDE_F_NPC) {
+                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
+                    const float red_gap =
+                        (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
+                    float na, nb;
+                    npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
+                                  cx.g_far, red_gap, na, nb);
+                    if (npc) { acc = na; beta = nb; }
+                }
+                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
+                if (live) {
+                    bicycle(nx, ny, npsi, nv, ag.lr, acc, beta, cfg.dt);                      // :117
+                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
+                }
+                switched = false;
+                nwp = ag.route_wp;
+                if (has_target) {
+                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;
+                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
+                }
+                sincos_f32(npsi, ns, nc);
+                if (pass) break;
+                lds_barrier();                               // A: done(i-1) is published
+                const unsigned long long dn = sh.done;
+                if (!dn) break;
+                // an env of this wavefront finished at step i-1: re-spawn its lanes (as step_lane does in place),
+                // put their rows into buffer q and recompute the step
+                if (((dn >> base) & 1ull) && valid) {
+                    reset_lane<A>(cfg, cold, e, a, ag, er);
+                    load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    sincos_f32(ag.psi, s0, c0);
+                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);
+                }
+            }
+            ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
+            c0 = nc; s0 = ns;
+            er.steps = k;
+            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            if (switched) load_route_target(cold, ag, cx);
+            act = act_next;
+        }
+        lds_barrier();                                       // A of the step after the last: done(K-1)
+        const unsigned long long dn = sh.done;
+        if (((dn >> base) & 1ull) && valid) reset_lane<A>(cfg, cold, e, a, ag, er);
+        if (!valid) return;
+        store_agent_dynamic(st, g, ag);
+        store_agent_static(st, g, ag);
+    } else {
+        // ================================ judge ================================
+        StepOut o{0.0f, 0, 0, 0, 0, 0, false};
+        const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
+        lds_barrier();
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1, q = p ^ 1;
+            lds_barrier();                                   // A
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            er.steps += 1;
+            const int k = er.steps;
+            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
+            const bool live = rc.z != 0.0f;
+            const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
+            Corners corners;
+            if (F & TDE_F_OFFROAD) offroad_issue(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+            const bool hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, live, x, y, c0, s0, hl, hw, ra.z);
+            bool off = false;
+            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2);
+            bool tl = false;
+            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
+                tl = tl_violation(w, cx.m, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
+            o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false};
+            unsigned long long any = 0ull;
+            if (F & TDE_F_REWARD) {
+                int done = 0;
+                if (a == 0 && valid) {
+                    const float4 pa = sh.a[q][lane], pc = sh.c[q][lane];      // state before the step (:371-375)
+                    const int ti0 = er.target_idx;
+                    RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, pa.x, pa.y, pc.x, pc.y, x, y, rc.x, rc.y,
+                                              off, hit, tl, k, er.target_idx, er.reached, st.info != nullptr);
+                    o.reward = r.reward;
+                    o.terminated = r.terminated;
+                    o.truncated = r.truncated;
+                    if (st.info) {
+                        double *inf = st.info + 4 * (int64_t)e;
+                        inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
+                    }
+                    if (st.info_reached) st.info_reached[e] = er.reached;
+                    done = (r.terminated | r.truncated) ? 1 : 0;
+                    if (er.target_idx != ti0 && !done) load_ego_target(cold, er, cx);
+                }
+                if (F & TDE_F_AUTORESET) any = __ballot(done);
+            }
+            if (lane == 0) sh.done = any;
+            if (valid && a == 0) {
+                if (ro.reward) ro.reward[(int64_t)i * B + e] = o.reward;
+                if (ro.done)
+                    ro.done[(int64_t)i * B + e] =
+                        (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
+            }
+            if (any && ((any >> base) & 1ull) && valid) {
+                reset_lane<A>(cfg, cold, e, a, ag, er);
+                load_ctx<A>(cfg, cold, a, ag, er, cx);
+                o.respawned = true;
+            }
+        }
+        lds_barrier();                                       // lets the driver read done(K-1)
+        if (!valid) return;
+        st.collided[g] = o.respawned ? 0 : o.collided;
+        st.offroad[g] = o.respawned ? 0 : o.offroad;
+        if (a == 0) {
+            st.scn[e] = er.scn; st.episode[e] = er.episode;
+            st.steps[e] = er.steps;
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = o.reward;
+            st.terminated[e] = o.terminated;
+            st.truncated[e] = o.truncated;
+            if (st.tl_violation) st.tl_violation[e] = o.tl;
+        }
+    }
+}
+
 template <int A>
 __global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_world w, tde_state st,
                                                            const uint8_t *__restrict__ mask)
@@ -607,33 +845,12 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
     float s1, c1;
     sincos_f32(P, s1, c1);
     const float hl = 0.5f * len[gs], hw = 0.5f * wid[gs];
-    const float ri = hl + hw;
-    using mask_t = typename MaskOf<A>::type;
-    t.a[tid] = live ? make_float4(X, Y, hl, 0.0f) : make_float4(kFar, kFar, 0.0f, 0.0f);
-    t.b[tid] = make_float4(c1, s1, ri, hw);
+    const float ri = (hl + hw) * kReach;
+    t.a[tid] = live ? make_float4(X, Y, ri, 0.0f) : make_float4(kFar, kFar, 0.0f, 0.0f);
+    t.b[tid] = make_float4(c1, s1, hl, hw);
     __syncthreads();
     const int base = tid - a;
-    mask_t cand = 0;
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float4 pj = t.a[base + j];
-            const float rj = t.b[base + j].z;
-            const float dx = pj.x - X, dy = pj.y - Y;
-            const float rr = ri + rj;
-            cand |= (dx * dx + dy * dy <= (rr * rr) * 1.001f) ? (mask_t)1 << j : (mask_t)0;
-        }
-        cand &= ~((mask_t)1 << a);
-    }
-    bool hit = false;
-    while (__ballot(cand != 0)) {
-        if (cand) {
-            const int j = lowest_bit(cand);
-            cand &= cand - 1;
-            const float4 pj = t.a[base + j], qj = t.b[base + j];
-            hit = hit || obb_overlap(X, Y, c1, s1, hl, hw, pj.x, pj.y, qj.x, qj.y, pj.z, qj.w);
-        }
-    }
+    const bool hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, X, Y, c1, s1, hl, hw, ri);
     if (valid) out[g] = hit ? 1 : 0;
 }
 
@@ -1147,10 +1364,20 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (st->B <= 0 || ro->K <= 0) return 0;
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-    if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) {
-        TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, true><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+    static const bool solo = [] { const char *v = getenv("TDE_ROLLOUT"); return v && !strcmp(v, "solo"); }();
+    const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    if (solo) {
+        if (lights) {
+            TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, true><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+        } else {
+            TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, false><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+        }
     } else {
-        TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, false><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+        if (lights) {
+            TDE_DISPATCH_A(st->A, tde::env_rollout_duo_kernel<kA, true><<<nb, 2 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+        } else {
+            TDE_DISPATCH_A(st->A, tde::env_rollout_duo_kernel<kA, false><<<nb, 2 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
+        }
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
