@@ -28,7 +28,7 @@ ops.env_reset(cfg, dw, st)
 for _ in range(4):
     ops.env_rollout(cfg, dw, st, actions, reward, done)
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 12)()
+out = (C.c_ulonglong * 24)()
 lib.tde_debug_stamps(out, 1)
 reps = 4
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,10 +39,18 @@ e1.record()
 torch.cuda.synchronize()
 lib.tde_debug_stamps(out, 0)
 waves = B * A // 64
-names = ["npc prefilter", "npc exact", "npc rest", "bicycle+sincos+offroad issue", "tile write+collision prefilter",
-         "collision exact", "offroad resolve", "reward", "reset+barrier", "outputs/loop"]
-tot = sum(out[:10])
+drive = ["prologue + controller prefilter", "controller exact loop", "controller rest", "bicycle", "route + sincos",
+         "wait A (done of prev step)", "re-spawn fixup + commit rows", "wait B", "route target + loop"]
+if os.environ.get("TDE_STAMPS_V1"):
+    drive = ["controller (spec)", "bicycle+sincos (spec)", "wait A (done of prev step)",
+             "re-spawn fixup + commit rows", "wait B"]
+judge = ["wait A", "wait B (rows of this step)", "read rows + collision", "offroad resolve", "tl + reward", "publish + reset"]
 us = e0.elapsed_time(e1) * 1e3 / (reps * K)
-print(f"{B} envs: {us:.2f} us/step (stamped build); memtime ticks per wave-step = {tot / (waves * reps * K):.0f}")
-for n, v in zip(names, out[:10]):
-    print(f"  {n:34s} {v / (waves * reps * K):8.1f} ticks  {100.0 * v / tot:5.1f} %  ~{us * v / tot:5.2f} us")
+n = waves * reps * K
+print(f"{B} envs: {us:.2f} us/step (stamped build)")
+for title, names, off in (("drive wavefront", drive, 0), ("judge wavefront", judge, 12)):
+    tot = sum(out[off:off + 12])
+    print(f" {title}: {tot / n:.0f} memtime ticks per wave-step")
+    for i, nm in enumerate(names):
+        v = out[off + i]
+        print(f"   {nm:34s} {v / n:8.1f} ticks  {100.0 * v / tot:5.1f} %")

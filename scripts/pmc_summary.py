@@ -6,7 +6,7 @@ for a in sys.argv[1:]:
     if a.startswith("--div="): div = float(a[6:])
     else: args.append(a)
 for path in args:
-    for f in glob.glob(path + "/*/*counter_collection.csv"):
+    for f in (glob.glob(path + "/*/*counter_collection.csv") + glob.glob(path + "/*counter_collection.csv")):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -7,7 +7,7 @@ fetch_dir, write_dir, kernel, steps_per_launch, envs, out = sys.argv[1:7]
 
 def mean_counter(d, name):
     vals = []
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for f in (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"] and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"]))

@@ -51,7 +51,7 @@ template <int A> struct MaskOf { using type = uint32_t; };
 // All-pairs sweeps read the A tile rows of the lane's env.  Issued one by one next to their use, every ds_read_b128
 // exposes its full LDS latency to the lone wavefront (stamps: ~120 cycles per swept slot for ~45 cycles of work);
 // the rows are therefore fetched in blocks of kSweepBlock before any of them is used.
-constexpr int kSweepBlock = 8;
+constexpr int kSweepBlock = 4;
 template <int A, typename F> TDE_DEV void sweep_rows(const float4 *rows, F &&f)
 {
     constexpr int C = A < kSweepBlock ? A : kSweepBlock;
@@ -636,6 +636,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 
     if (role == 0) {
         // ================================ drive ================================
+        __builtin_amdgcn_s_setprio(3);           // the driver is the serial chain of the simulation; the judge fills in
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
         write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
