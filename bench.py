@@ -57,8 +57,20 @@ def cpu_baseline(world, cfg, budget_s=12.0):
     t0 = time.perf_counter()
     oracle.env_rollout(cfg, world, hs, a)
     dt = time.perf_counter() - t0
+    # the reference's own operating point: ONE env stepped call by call on one thread
+    oracle.set_num_threads(1)
+    h1 = EnvState(1, A_AGENTS)
+    oracle.env_reset(cfg, world, h1)
+    h1["action"][:] = 0.0
+    n1, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 1.5:
+        for _ in range(50):
+            oracle.env_step(cfg, world, h1)
+        n1 += 50
+    b1 = n1 / (time.perf_counter() - t0)
+    oracle.set_num_threads(cores)
     return {"value": B * K / dt, "unit": "env-steps/s", "agent_steps_per_s": B * A_AGENTS * K / dt,
-            "cores": oracle.num_threads(), "kind": "port",
+            "cores": oracle.num_threads(), "kind": "port", "b1_single_thread_env_steps_per_s": b1,
             "sample": f"{B} envs x {A_AGENTS} agents x {K} steps of the same workload, oracle/tde_oracle.c "
                       f"(brute-force mesh distance, OpenMP over envs), {dt:.1f} s"}
 

@@ -95,6 +95,12 @@ TDE_API int tde_env_rollout(const tde_config *cfg, const tde_world *world, const
 TDE_API int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *state,
                            const tde_render *render, void *stream);
 
+/* Compact kinematic observation of every env's ego, float32 [B][8] (no reference counterpart; the reference only has
+ * the birdview of gym_env.py:122-124): x, y, psi, v, offset of the current target waypoint in the ego frame (forward,
+ * left; 0 when the route is finished, gym_env.py:378-383), 1 while a target exists, environment_steps.  One launch
+ * instead of a dozen framework ops per step in closed-loop use. */
+TDE_API int tde_state_obs(const tde_world *world, const tde_state *state, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,43 @@
+"""SURVEY §8(d) metric (ii) / (iii): end-to-end wall time of one step through the Python boundary,
+(ii) with device-resident outputs (BatchedWaypointEnv.step), (iii) with numpy outputs (the SB3-shaped vec_step path,
+one D2H copy of obs/reward/done/info per step).  obs_mode "state" (8 floats per env) and "birdview" (3x64x64 u8)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from torchdriveenv_amd.config import EnvConfig
+from torchdriveenv_amd.env import BatchedWaypointEnv
+from torchdriveenv_amd.synth import synthetic_world
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+world = synthetic_world(n_scn=64, A=16, seed=0, n_maps=4)
+out = {"envs": B, "agents": 16, "steps": N}
+for mode in ("state", "birdview"):
+    env = BatchedWaypointEnv(EnvConfig(seed=3), world, num_envs=B, obs_mode=mode, with_info=True)
+    env.reset()
+    act = torch.zeros(B, 2, device=env.torch_device)
+    for _ in range(20):
+        env.step(act)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        env.step(act)
+    torch.cuda.synchronize()
+    dt_dev = (time.perf_counter() - t0) / N
+    act_np = np.zeros((B, 2), np.float32)
+    n2 = max(10, N // 10)
+    for _ in range(3):
+        env.vec_step(act_np)
+    t0 = time.perf_counter()
+    for _ in range(n2):
+        env.vec_step(act_np)
+    dt_np = (time.perf_counter() - t0) / n2
+    out[mode] = {"device_outputs_us_per_step": dt_dev * 1e6, "device_outputs_env_steps_per_s": B / dt_dev,
+                 "numpy_outputs_us_per_step": dt_np * 1e6, "numpy_outputs_env_steps_per_s": B / dt_np}
+print(json.dumps(out))

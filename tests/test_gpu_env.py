@@ -125,3 +125,36 @@ def test_rollout_api_and_state_obs(small_world):
     acts[..., 0] = 0.3
     r, d = env.rollout(acts)
     assert r.shape == (50, 128) and d.shape == (50, 128) and torch.isfinite(r).all()
+
+
+def test_state_obs_operator_matches_numpy(small_world):
+    """tde_state_obs: x, y, psi, v, target offset in the ego frame, target flag, steps — against plain numpy"""
+    cfg = EnvConfig(seed=4)
+    env = BatchedWaypointEnv(cfg, small_world, num_envs=96, device="cuda:0", obs_mode="state", with_info=True)
+    env.reset()
+    acts = torch.zeros(96, 2, device="cuda:0")
+    acts[:, 0] = 0.5
+    for _ in range(30):
+        o, r, term, trunc, info = env.step(acts)
+    st = {k: v.cpu().numpy() for k, v in env.state.arrays.items() if v is not None}
+    A = env.A
+    x, y, psi, v = (st[k][::A] for k in ("x", "y", "psi", "v"))
+    w = small_world
+    n_wp = w.arrays["scn"]["wp_n"][st["scn"]]
+    wp = w.arrays["wp_xy"].reshape(-1, w.ints["NW"], 2)
+    has = st["target_idx"] < n_wp
+    ti = np.minimum(st["target_idx"], n_wp - 1)
+    tgt = wp[st["scn"], ti].astype(np.float32)
+    dx, dy = tgt[:, 0] - x, tgt[:, 1] - y
+    c, s = np.cos(psi), np.sin(psi)
+    exp = np.stack([x, y, psi, v, np.where(has, dx * c + dy * s, 0), np.where(has, dy * c - dx * s, 0),
+                    has.astype(np.float32), st["steps"].astype(np.float32)], -1)
+    got = o.cpu().numpy()
+    assert got.shape == (96, 8)
+    np.testing.assert_array_equal(got[:, [0, 1, 2, 3, 6, 7]], exp[:, [0, 1, 2, 3, 6, 7]])
+    np.testing.assert_allclose(got[:, 4:6], exp[:, 4:6], rtol=0, atol=2e-4)
+    # flags come back as bool views of the uint8 state, info entries are formed on access
+    assert term.dtype == torch.bool and trunc.dtype == torch.bool
+    assert set(info.keys()) >= {"offroad", "collision", "traffic_light_violation", "is_success", "psi_smoothness"}
+    assert info["offroad"].shape == (96,) and info["offroad"].dtype == torch.float32
+    assert "psi_reward" in info and info.get("nope") is None

@@ -924,6 +924,30 @@ constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS image)
 constexpr int kRenderWork = 2048;                 // exact-pixel queue (a view that needs more takes the all-pixels path)
 constexpr int kRenderMaxBox = 40;                 // agent boxes kept per view (more: all-pixels path)
 
+// compact observation of the ego (obs_mode "state" of the host mirror): one lane per env
+__global__ __launch_bounds__(kBlock) void state_obs_kernel(tde_world w, tde_state st, float *__restrict__ out)
+{
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= st.B) return;
+    const int64_t g = (int64_t)e * st.A;
+    const float x = st.x[g], y = st.y[g], psi = st.psi[g], v = st.v[g];
+    const int scn = st.scn[e], ti = st.target_idx[e];
+    const int n_wp = reinterpret_cast<const int4 *>(w.scn)[scn].y;
+    const bool has = ti < n_wp;
+    float fwd = 0.0f, lat = 0.0f;
+    if (has) {
+        const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + ti];
+        float s, c;
+        sincos_f32(psi, s, c);
+        const float dx = (float)t.x - x, dy = (float)t.y - y;
+        fwd = dx * c + dy * s;
+        lat = dy * c - dx * s;
+    }
+    float4 *o = reinterpret_cast<float4 *>(out) + 2 * (int64_t)e;
+    o[0] = make_float4(x, y, psi, v);
+    o[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)st.steps[e]);
+}
+
 struct RenderBox { float x, y, c, s, hl, hw; int rmin, rmax, cmin, cmax; };
 
 __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_world w, tde_state st, tde_render rd)
@@ -1397,6 +1421,17 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     tde::render_ego_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
+}
+
+int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void *stream)
+{
+    if (!world || !st || !out) return bad("tde_state_obs: world/state/out is NULL");
+    if (st->B <= 0) return 0;
+    if (!st->x || !st->y || !st->psi || !st->v || !st->scn || !st->target_idx || !st->steps || !world->scn || !world->wp_xy)
+        return bad("tde_state_obs: a required state / world pointer is NULL");
+    tde::state_obs_kernel<<<blocks_for(st->B), tde::kBlock, 0, (hipStream_t)stream>>>(*world, *st, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_state_obs", e);
 }
 
 }  // extern "C"

@@ -135,6 +135,60 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
     return assemble_world(meshes, scenarios, agents_per_env, threshold=threshold)
 
 
+class _LazyInfo(dict):
+    """dict of per-env info tensors (ref gym_env.py:419-437) whose values are built when first read"""
+
+    KEYS = ("offroad", "collision", "traffic_light_violation", "is_success")
+    EXTRA = ("reached_waypoint_num", "psi_smoothness", "speed_smoothness", "psi_reward", "dist_reward")
+
+    def __init__(self, st, B, A):
+        super().__init__()
+        self._st, self._ego = st, slice(0, B * A, A)
+        self._keys = self.KEYS + (self.EXTRA if st["info"] is not None else ())
+
+    def _make(self, k):
+        st = self._st
+        if k == "offroad":
+            return st["offroad"][self._ego].float()
+        if k == "collision":
+            return st["collided"][self._ego].float()
+        if k == "traffic_light_violation":
+            return st["tl_violation"].float()
+        if k == "is_success":
+            return st["truncated"].view(torch.bool)
+        if k == "reached_waypoint_num":
+            return st["info_reached"]
+        return st["info"][:, ("psi_smoothness", "speed_smoothness", "psi_reward", "dist_reward").index(k)]
+
+    def __missing__(self, k):
+        if k not in self._keys:
+            raise KeyError(k)
+        v = self._make(k)
+        dict.__setitem__(self, k, v)
+        return v
+
+    def __contains__(self, k):
+        return k in self._keys
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def keys(self):
+        return list(self._keys)
+
+    def items(self):
+        return [(k, self[k]) for k in self._keys]
+
+    def values(self):
+        return [self[k] for k in self._keys]
+
+    def get(self, k, default=None):
+        return self[k] if k in self._keys else default
+
+
 class BatchedWaypointEnv:
     """`num_envs` independent WaypointSuite envs stepped by one fused HIP kernel per timestep.
 
@@ -202,10 +256,14 @@ class BatchedWaypointEnv:
         return self.get_obs()
 
     def step(self, actions):
-        a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).reshape(self.num_envs, 2)
-        ops.env_step(self.tde_cfg, self.dworld, self.state, action=a.contiguous())
+        a = actions if torch.is_tensor(actions) and actions.device == self.torch_device else \
+            torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device)
+        a = a.to(torch.float32).reshape(self.num_envs, 2).contiguous()
+        ops.env_step(self.tde_cfg, self.dworld, self.state, action=a)
         st = self.state
-        return (self.get_obs(), st["reward"], st["terminated"].bool(), st["truncated"].bool(), self.get_info())
+        # uint8 0/1 flags seen as bool without a copy; info entries are only computed when they are read
+        return (self.get_obs(), st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool),
+                self.get_info())
 
     def rollout(self, actions):
         """K open-loop steps from a resident [K,B,2] action tensor -> (reward [K,B], done bits [K,B])"""
@@ -214,37 +272,16 @@ class BatchedWaypointEnv:
 
     def get_obs(self):
         if self.obs_mode == "state":
-            return self._state_obs()
+            # x, y, psi, v, target offset (forward, left) in the ego frame, target-exists flag, environment_steps
+            return ops.state_obs(self.dworld, self.state)
         self._obs = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov,
                                    self.frame_stack, self._obs)
         return self._obs
 
-    def _state_obs(self):
-        st, B, A = self.state, self.num_envs, self.A
-        ego = slice(0, B * A, A)
-        x, y, psi, v = st["x"][ego], st["y"][ego], st["psi"][ego], st["v"][ego]
-        wp = self.dworld.tensors["wp_xy"].view(-1, self.world.ints["NW"], 2)
-        scn = st["scn"].long()
-        n_wp = torch.from_numpy(np.ascontiguousarray(self.world.arrays["scn"]["wp_n"])).to(self.torch_device)[scn]
-        ti = torch.minimum(st["target_idx"].long(), n_wp.long() - 1)
-        tgt = wp[scn, ti].to(torch.float32)
-        dx, dy = tgt[:, 0] - x, tgt[:, 1] - y
-        c, s = torch.cos(psi), torch.sin(psi)
-        return torch.stack([x, y, psi, v, dx * c + dy * s, dy * c - dx * s,
-                            (st["target_idx"] < n_wp).float(), st["steps"].float()], -1)
-
     def get_info(self):
-        """info schema of the reference (ref gym_env.py:419-437), one entry per env"""
-        st, A = self.state, self.A
-        ego = slice(0, self.num_envs * A, A)
-        info = dict(offroad=st["offroad"][ego].float(), collision=st["collided"][ego].float(),
-                    traffic_light_violation=st["tl_violation"].float(),
-                    is_success=st["truncated"].bool())
-        if st["info"] is not None:
-            inf = st["info"]
-            info.update(reached_waypoint_num=st["info_reached"], psi_smoothness=inf[:, 0], speed_smoothness=inf[:, 1],
-                        psi_reward=inf[:, 2], dist_reward=inf[:, 3])
-        return info
+        """info schema of the reference (ref gym_env.py:419-437), one entry per env; a mapping whose tensors are formed
+        on first access (a training loop that never reads `psi_smoothness` does not pay for it)"""
+        return _LazyInfo(self.state, self.num_envs, self.A)
 
     def render(self):
         """(B, H, W, 3) uint8 of the current ego views (ref gym_env.py:152-155)"""
@@ -280,20 +317,20 @@ class BatchedWaypointEnv:
             if auto:
                 self.tde_cfg.flags |= _abi.F_AUTORESET
         done = (term | trunc)
-        obs_np = obs.cpu().numpy().copy()
-        rew_np, done_np = rew.cpu().numpy().copy(), done.cpu().numpy().copy()
+        obs_np = obs.cpu().numpy()                                   # a fresh host copy each step (D2H)
+        rew_np, done_np = rew.cpu().numpy(), done.cpu().numpy()
         trunc_np, term_np = trunc.cpu().numpy(), term.cpu().numpy()
-        info_np = {k: v.cpu().numpy() for k, v in info.items()}
-        infos = []
-        for i in range(self.num_envs):
-            d = {k: (v[i].item() if hasattr(v[i], "item") else v[i]) for k, v in info_np.items()}
-            d["TimeLimit.truncated"] = bool(trunc_np[i] and not term_np[i])
-            infos.append(d)
+        keys = info.keys()
+        cols = [info[k].cpu().numpy().tolist() for k in keys] + [(trunc_np & ~term_np).tolist()]
+        keys = keys + ["TimeLimit.truncated"]
+        infos = [dict(zip(keys, row)) for row in zip(*cols)]
         if auto and done_np.any():
-            new_obs = self.reset(mask=done).cpu().numpy()
-            for i in np.nonzero(done_np)[0]:
-                infos[i]["terminal_observation"] = obs_np[i]
-                obs_np[i] = new_obs[i]
+            idx = np.nonzero(done_np)[0]
+            # only the re-spawned envs' first observations cross the bus
+            new_obs = self.reset(mask=done)[torch.as_tensor(idx, device=self.torch_device)].cpu().numpy()
+            for n, i in enumerate(idx):
+                infos[i]["terminal_observation"] = obs_np[i].copy()
+                obs_np[i] = new_obs[n]
         return obs_np, rew_np, done_np, infos
 
     def vec_step(self, actions):

@@ -167,6 +167,19 @@ def env_rollout(cfg, dworld, state, actions, reward=None, done=None):
     return reward, done
 
 
+def state_obs(dworld, state, out=None):
+    """compact kinematic observation of every ego -> float32 [B, 8] on device: x, y, psi, v, target waypoint offset in
+    the ego frame (forward, left), target-exists flag, environment_steps"""
+    L = _lib.load()
+    dev = state.device
+    if out is None:
+        out = torch.empty((state.B, 8), dtype=torch.float32, device=dev)
+    po = _chk(out, torch.float32, state.B * 8, "out", torch.device(dev))
+    _lib.check(_call(dev, L.tde_state_obs, C.byref(dworld.struct), C.byref(state.struct), po, _lib.current_stream(dev)),
+               "tde_state_obs")
+    return out
+
+
 def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
     """render_egocentric() of every env's ego -> uint8 [B, 3*n_stack, H, W] on device (ref gym_env.py:122-124).
     With n_stack > 1 `out` must be the buffer of the previous call: older frames are shifted, the new one appended."""
