@@ -195,7 +195,10 @@ class BatchedWaypointEnv:
     step(actions [B,2]) -> (obs, reward f32[B], terminated bool[B], truncated bool[B], info dict of [B] tensors), all
     device-resident torch tensors.  obs is the ego-centred birdview uint8 [B, 3*frame_stack, 64, 64] (obs_mode
     "birdview", the reference's observation, ref gym_env.py:95,122-124) or a compact float32 [B, 8] kinematic vector
-    (obs_mode "state").  Finished envs are re-spawned inside the same kernel (auto_reset=True)."""
+    (obs_mode "state").  Finished envs are re-spawned inside the same kernel (auto_reset=True).
+    reward / terminated / truncated are the env's own buffers, overwritten by the next step (clone what must be
+    kept).  (Replaying step + observation from a captured HIP graph was measured and is slower than the two direct
+    launches: 27.9 vs 18.5 us per step at 8192 envs.)"""
 
     metadata = {"render_modes": ["rgb_array"], "render_fps": 10}   # ref gym_env.py:73-76
 
