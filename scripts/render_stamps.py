@@ -1,0 +1,26 @@
+"""s_memtime stamps per pass of the rasteriser (debug build with tde_debug_stamps)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torchdriveenv_amd import _abi, _lib, ops
+from torchdriveenv_amd.state import EnvState
+from torchdriveenv_amd.synth import synthetic_world
+A = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+B, K = 8192, 50
+dev = torch.device("cuda:0"); lib = _lib.load()
+world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4); dw = world.to_device(dev)
+cfg = _abi.default_config(seed=1, distance_cutoff=0.25)
+st = EnvState(B, A, device=dev, with_info=False); ops.env_reset(cfg, dw, st)
+g = torch.Generator().manual_seed(0)
+actions = torch.stack([torch.rand(K, B, generator=g) * 2 - 1, torch.rand(K, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)
+ops.env_rollout(cfg, dw, st, actions)
+img = ops.render_ego(cfg, dw, st)
+torch.cuda.synchronize()
+out = (C.c_ulonglong * 24)(); lib.tde_debug_stamps(out, 1)
+for _ in range(5): img = ops.render_ego(cfg, dw, st, out=img)
+torch.cuda.synchronize(); lib.tde_debug_stamps(out, 0)
+n = out[10]
+names = ["cull + shift", "blocks", "queued pixels", "waypoints", "boxes", "ego", "stream out"]
+print("views", n, "queued px/view", out[11] / n, "boxes/view", out[12] / n, "waypoints/view", out[13] / n)
+for i, nm in enumerate(names): print(f"  {nm:16s} {out[i] / n:9.0f} ticks")
+print("  total", sum(out[:7]) / n)

@@ -14,7 +14,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fvisibility=hidden",
          # packed fp32 (v_pk_*_f32) issues slower than two scalar ops on gfx950 for this mix and costs v_mov shuffles:
          # same-box A/B 7.2 -> 6.7 us/step without the SLP vectoriser
-         "-fno-slp-vectorize"]
+         "-fno-slp-vectorize",
+         # the loop vectoriser does the same to short column loops (the rasteriser went from 38 to 129 VGPRs with it)
+         "-fno-vectorize"]
 
 
 def build(force=False, verbose=False):

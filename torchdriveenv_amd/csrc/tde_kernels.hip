@@ -1238,7 +1238,330 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
     for (int i = tid; i < 3 * plane / 16; i += kBlock) dst[i] = src[i];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Layer-plane rasteriser (default of tde_render_ego).  Same picture as render_ego_kernel, pixel for pixel, organised
+// by object instead of by pixel:
+//   the LDS image is ONE byte per pixel holding the layer (0 background, 1 road, 2 waypoint, 3 NPC, 4 ego);
+//   pass 1  base layer per 4x4 block from the grid class + clearance of its centre cell (2x2 refinement at road
+//           edges); only the pixels of sub-blocks that straddle a road edge are queued,
+//   pass 2  queued pixels: their own cell word, candidate-triangle tests in MIXED cells,
+//   pass 3  objects paint over the base in layer order - waypoint discs, NPC boxes, the ego - each thread taking one
+//           row of one object's conservative pixel bounding box: sum-of-bbox-rows tests instead of
+//           (queued pixels) x (objects),
+//   pass 4  16 layer bytes -> 3 x 16 colour bytes with one v_perm_b32 per dword and channel, 16-B coalesced stores.
+// The per-pixel expressions (pixel centre -> world point, disc / box tests) are the specification's, so every pixel
+// equals the all-pixels path below and the oracle.
+// ------------------------------------------------------------------------------------------------------------------
+struct PixelSpan { int rmin, rmax, cmin, cmax; };
+
+__global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, tde_world w, tde_state st, tde_render rd)
+{
+    __shared__ uint32_t s_layer[kRenderMaxPix / 4];
+    __shared__ RenderBox s_box[kRenderMaxBox];           // NPC boxes in view, ego kept separately
+    __shared__ float2 s_wp[kRenderMaxWp];
+    __shared__ PixelSpan s_wpbb[kRenderMaxWp];
+    __shared__ RenderBox s_ego;
+    __shared__ uint16_t s_work[kRenderWork];             // pixels whose base layer needs the exact test (r * W + c)
+    __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int A = st.A, H = rd.H, W = rd.W;
+    const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
+    const int plane = H * W;
+    uint8_t *out = rd.out + (int64_t)e * 3 * ns * plane;
+    const int64_t g0 = (int64_t)e * A;
+    const int scn = st.scn[e];
+    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[scn];
+    const tde_map m = w.maps[sc.x];
+    const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
+    const float res = rd.fov / (float)W;
+    const float inv_res = 1.0f / res;
+    const float halfH = 0.5f * (float)H, halfW = 0.5f * (float)W;
+    const float rview = 0.75f * res * (float)(H > W ? H : W) + 1.0f;   // view circle: lists are supersets
+    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }
+    const float ex = st.x[g0], ey = st.y[g0];
+    float se, ce;
+    sincos_f32(st.psi[g0], se, ce);
+    __syncthreads();
+
+    // conservative pixel bounding boxes (inclusive, one pixel of slack for rounding), clipped to the image
+    auto clip = [=](float rlo, float rhi, float clo, float chi) -> PixelSpan {
+        PixelSpan b;
+        b.rmin = max((int)floorf(rlo), 0); b.rmax = min((int)ceilf(rhi), H - 1);
+        b.cmin = max((int)floorf(clo), 0); b.cmax = min((int)ceilf(chi), W - 1);
+        return b;
+    };
+    auto disc_span = [=](float x, float y, float rad) -> PixelSpan {
+        const float dx = x - ex, dy = y - ey;
+        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
+        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.0f;
+        return clip(rc - pr, rc + pr, cc - pr, cc + pr);
+    };
+    auto box_span = [=](float x, float y, float cb, float sb, float hl, float hw) -> PixelSpan {
+        const float dx = x - ex, dy = y - ey;
+        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
+        const float cr = cb * ce + sb * se, sr = sb * ce - cb * se;      // box heading relative to the ego's
+        const float ef = fabsf(cr) * hl + fabsf(sr) * hw, el = fabsf(sr) * hl + fabsf(cr) * hw;
+        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f;
+        const float pr = ef * inv_res + 1.0f, pc = el * inv_res + 1.0f;
+        return clip(rc - pr, rc + pr, cc - pc, cc + pc);
+    };
+    // ---- pass 0: cull agents and waypoints to the view --------------------------------------------------------
+    if (tid < A) {
+        const int64_t g = g0 + tid;
+        float sa, ca;
+        sincos_f32(st.psi[g], sa, ca);
+        const float bx = st.x[g], by = st.y[g], bhl = 0.5f * st.len[g], bhw = 0.5f * st.wid[g];
+        RenderBox *dstb = nullptr;
+        if (tid == 0) {
+            dstb = &s_ego;
+        } else if (st.present[g]) {
+            const float dx = bx - ex, dy = by - ey, rr = rview + (bhl + bhw);
+            if (dx * dx + dy * dy <= rr * rr) {
+                const int k = atomicAdd(&s_nbox, 1);
+                if (k < kRenderMaxBox) dstb = &s_box[k];        // beyond: the view takes the all-pixels path
+            }
+        }
+        if (dstb) {
+            const PixelSpan bb = box_span(bx, by, ca, sa, bhl, bhw);
+            dstb->x = bx; dstb->y = by; dstb->c = ca; dstb->s = sa; dstb->hl = bhl; dstb->hw = bhw;
+            dstb->rmin = bb.rmin; dstb->rmax = bb.rmax; dstb->cmin = bb.cmin; dstb->cmax = bb.cmax;
+        }
+    }
+    {
+        const int ti = st.target_idx[e], n_wp = sc.y;
+        for (int k = ti + tid; k < n_wp; k += kBlock) {
+            const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
+            const float tx = (float)t.x, ty = (float)t.y;
+            const float dx = tx - ex, dy = ty - ey, rr = rview + TDE_WAYPOINT_RADIUS;
+            if (dx * dx + dy * dy <= rr * rr) {
+                const int q = atomicAdd(&s_nwp, 1);
+                if (q < kRenderMaxWp) { s_wp[q] = make_float2(tx, ty); s_wpbb[q] = disc_span(tx, ty, TDE_WAYPOINT_RADIUS); }
+            }
+        }
+    }
+    // frame stack: shift the older frames down by one frame (read everything, barrier, write)
+    if (ns > 1) {
+        const int nvec = 3 * (ns - 1) * plane / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(out + 3 * plane);
+        uint4 *dst = reinterpret_cast<uint4 *>(out);
+        for (int i0 = 0; i0 < nvec; i0 += kBlock * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) v[u] = src[i]; }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) dst[i] = v[u]; }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp;
+    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp;
+    uint8_t *lay8 = reinterpret_cast<uint8_t *>(s_layer);
+    uint16_t *lay16 = reinterpret_cast<uint16_t *>(s_layer);
+    const int Wq = W / 4;                                 // dwords per image row
+    auto pixel_world = [=](int r, int c, float &wx, float &wy) {
+        const float f = (halfH - ((float)r + 0.5f)) * res;
+        const float l = (halfW - ((float)c + 0.5f)) * res;
+        wx = (ex + f * ce) - l * se;
+        wy = (ey + f * se) + l * ce;
+    };
+    auto base_layer = [&](float wx, float wy) -> int {   // 1 on the drivable surface (within the threshold), else 0
+        const uint32_t wd = cell_lookup(w, m, wx, wy);
+        const uint32_t cls = wd & 3u;
+        bool road = cls == TDE_CELL_FULL;
+        if (cls == TDE_CELL_MIXED) {
+            const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
+            const int n = (int)((wd >> 2) & 255u);
+            for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
+        }
+        return road ? 1 : 0;
+    };
+
+    if (!crowded) {
+        // ---- pass 1: base layer of 4x4 blocks, 2x2 refinement at road edges ----------------------------------
+        const int bw = W / 4, nblk = (H / 4) * bw;
+        const float rblock = 1.5f * 1.41421356f * res * 1.01f + 0.02f;   // pixel centres of a 4x4 block lie this close to its centre
+        const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // ... of a 2x2 block
+        for (int bi = tid; bi < nblk; bi += kBlock) {
+            const int r0 = (bi / bw) * 4, c0 = (bi % bw) * 4;
+            const float f = (halfH - ((float)r0 + 2.0f)) * res, l = (halfW - ((float)c0 + 2.0f)) * res;
+            const uint32_t wd = cell_lookup(w, m, (ex + f * ce) - l * se, (ey + f * se) + l * ce);
+            const uint32_t cls = wd & 3u;
+            uint32_t need = 0;                                     // bit (dr*4 + dc): pixel needs the exact test
+            if ((cls != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((wd >> 2) & 255u) >= rblock)) {
+                const uint32_t v = (cls == TDE_CELL_FULL) ? 0x01010101u : 0u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_layer[(r0 + i) * Wq + (c0 >> 2)] = v;
+            } else {
+#pragma unroll
+                for (int sb = 0; sb < 4; ++sb) {
+                    const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
+                    const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = (halfW - ((float)(c0 + dc) + 1.0f)) * res;
+                    const uint32_t ws = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
+                    const uint32_t cs = ws & 3u;
+                    if ((cs != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((ws >> 2) & 255u) >= rsub)) {
+                        const uint16_t v = (cs == TDE_CELL_FULL) ? (uint16_t)0x0101u : (uint16_t)0u;
+                        lay16[((r0 + dr) * W + c0 + dc) >> 1] = v;
+                        lay16[((r0 + dr + 1) * W + c0 + dc) >> 1] = v;
+                    } else {
+                        need |= 0x33u << (dr * 4 + dc);
+                    }
+                }
+            }
+            if (need) {
+                const int n = __popc(need);
+                int at = atomicAdd(&s_nwork, n);
+                if (at + n > kRenderWork) need = 0;             // queue full: the view takes the all-pixels path
+                while (need) {
+                    const int b = __ffs((int)need) - 1;
+                    need &= need - 1u;
+                    s_work[at++] = (uint16_t)((r0 + (b >> 2)) * W + c0 + (b & 3));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool all_pixels = crowded || s_nwork > kRenderWork;
+    if (all_pixels) {
+        // rare fallback (more boxes / waypoints / edge pixels in view than the LDS lists hold): every pixel is shaded
+        // from the global tables, literally as the specification reads
+        const int ti = st.target_idx[e], n_wp = sc.y;
+        for (int pix = tid; pix < plane; pix += kBlock) {
+            float wx, wy;
+            pixel_world(pix / W, pix % W, wx, wy);
+            int layer = base_layer(wx, wy);
+            for (int k = ti; k < n_wp; ++k) {
+                const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
+                const float dx = wx - (float)t.x, dy = wy - (float)t.y;
+                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
+            }
+            for (int a = A - 1; a >= 0; --a) {
+                const int64_t g = g0 + a;
+                if (!st.present[g]) continue;
+                float sa, ca;
+                sincos_f32(st.psi[g], sa, ca);
+                const float dx = wx - st.x[g], dy = wy - st.y[g];
+                const float p = dx * ca + dy * sa, q = dy * ca - dx * sa;
+                if (fabsf(p) <= 0.5f * st.len[g] && fabsf(q) <= 0.5f * st.wid[g]) layer = a ? 3 : 4;
+            }
+            lay8[pix] = (uint8_t)layer;
+        }
+    } else {
+        // ---- pass 2a: queued road-edge pixels: their own cell word; pixels in MIXED cells are compacted ... ---------
+        const int npix = s_nwork;
+        for (int base = 0; base < npix; base += kBlock) {
+            const int wi = base + tid;
+            bool defer = false;
+            int pix = 0;
+            if (wi < npix) {
+                pix = s_work[wi];
+                float wx, wy;
+                pixel_world(pix / W, pix % W, wx, wy);
+                const uint32_t cls = cell_lookup(w, m, wx, wy) & 3u;
+                if (cls == TDE_CELL_MIXED) defer = true;
+                else lay8[pix] = (cls == TDE_CELL_FULL) ? 1 : 0;
+            }
+            __syncthreads();                                  // every lane has read its entry of this chunk:
+            if (defer) s_work[atomicAdd(&s_nmixed, 1)] = (uint16_t)pix;   // the compacted list may overwrite it
+            __syncthreads();
+        }
+        // ---- pass 2b: ... and get their candidate-triangle tests here, densely -------------------------------------
+        const int nmixed = s_nmixed;
+        for (int wi = tid; wi < nmixed; wi += kBlock) {
+            const int pix = s_work[wi];
+            float wx, wy;
+            pixel_world(pix / W, pix % W, wx, wy);
+            lay8[pix] = (uint8_t)base_layer(wx, wy);
+        }
+        __syncthreads();
+        // ---- pass 3: objects over the base, in layer order; one thread per row of an object's pixel span -----------
+        if (nwp > 0) {
+            int total = 0;
+            #pragma unroll 1
+            for (int j = 0; j < nwp; ++j) total += max(s_wpbb[j].rmax - s_wpbb[j].rmin + 1, 0);
+            for (int i = tid; i < total; i += kBlock) {
+                int k = 0, start = 0, acc = 0;
+                #pragma unroll 1
+                for (int j = 0; j < nwp; ++j) {
+                    acc += max(s_wpbb[j].rmax - s_wpbb[j].rmin + 1, 0);
+                    if (i >= acc) { k = j + 1; start = acc; }
+                }
+                const PixelSpan b = s_wpbb[k];
+                const float2 t = s_wp[k];
+                const int r = b.rmin + (i - start);
+                #pragma unroll 1
+                for (int c = b.cmin; c <= b.cmax; ++c) {
+                    float wx, wy;
+                    pixel_world(r, c, wx, wy);
+                    const float dx = wx - t.x, dy = wy - t.y;
+                    if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) lay8[r * W + c] = 2;
+                }
+            }
+            __syncthreads();
+        }
+        if (nbox > 0) {
+            int total = 0;
+            #pragma unroll 1
+            for (int j = 0; j < nbox; ++j) total += max(s_box[j].rmax - s_box[j].rmin + 1, 0);
+            for (int i = tid; i < total; i += kBlock) {
+                int k = 0, start = 0, acc = 0;
+                #pragma unroll 1
+                for (int j = 0; j < nbox; ++j) {
+                    acc += max(s_box[j].rmax - s_box[j].rmin + 1, 0);
+                    if (i >= acc) { k = j + 1; start = acc; }
+                }
+                const RenderBox b = s_box[k];
+                const int r = b.rmin + (i - start);
+                #pragma unroll 1
+                for (int c = b.cmin; c <= b.cmax; ++c) {
+                    float wx, wy;
+                    pixel_world(r, c, wx, wy);
+                    const float dx = wx - b.x, dy = wy - b.y;
+                    const float p = dx * b.c + dy * b.s, q = dy * b.c - dx * b.s;
+                    if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) lay8[r * W + c] = 3;
+                }
+            }
+            __syncthreads();
+        }
+        {
+            const RenderBox b = s_ego;
+            const int rows = max(b.rmax - b.rmin + 1, 0);
+            for (int i = tid; i < rows; i += kBlock) {
+                const int r = b.rmin + i;
+                #pragma unroll 1
+                for (int c = b.cmin; c <= b.cmax; ++c) {
+                    float wx, wy;
+                    pixel_world(r, c, wx, wy);
+                    const float dx = wx - ex, dy = wy - ey;
+                    const float p = dx * ce + dy * se, q = dy * ce - dx * se;
+                    if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) lay8[r * W + c] = 4;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 4: layers -> colours, streamed out ---------------------------------------------------------------
+    const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
+                   NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
+    uint8_t *frame = out + 3 * (ns - 1) * plane;
+    const uint4 *src = reinterpret_cast<const uint4 *>(s_layer);
+    for (int i = tid; i < plane / 16; i += kBlock) {
+        const uint4 v = src[i];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const uint32_t lo = BG[ch] | (ROAD[ch] << 8) | (WP[ch] << 16) | (NPC[ch] << 24), hi = EGO[ch];
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(hi, lo, v.x); o.y = __builtin_amdgcn_perm(hi, lo, v.y);
+            o.z = __builtin_amdgcn_perm(hi, lo, v.z); o.w = __builtin_amdgcn_perm(hi, lo, v.w);
+            reinterpret_cast<uint4 *>(frame + ch * plane)[i] = o;
+        }
+    }
+}
+
 }  // namespace tde
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // C-ABI
@@ -1418,7 +1741,9 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
         rd->H * rd->W > tde::kRenderMaxPix)
         return bad("tde_render_ego: H and W must be positive multiples of 4 with H*W <= 4096");
     if (st->B <= 0) return 0;
-    tde::render_ego_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
+    static const bool by_pixel = [] { const char *v = getenv("TDE_RENDER"); return v && !strcmp(v, "pixel"); }();
+    if (by_pixel) tde::render_ego_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
+    else tde::render_layers_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
 }
