@@ -20,7 +20,7 @@ out = (C.c_ulonglong * 24)(); lib.tde_debug_stamps(out, 1)
 for _ in range(5): img = ops.render_ego(cfg, dw, st, out=img)
 torch.cuda.synchronize(); lib.tde_debug_stamps(out, 0)
 n = out[10]
-names = ["cull + shift", "blocks", "queued pixels", "waypoints", "boxes", "ego", "stream out"]
-print("views", n, "queued px/view", out[11] / n, "boxes/view", out[12] / n, "waypoints/view", out[13] / n)
-for i, nm in enumerate(names): print(f"  {nm:16s} {out[i] / n:9.0f} ticks")
-print("  total", sum(out[:7]) / n)
+names = ["cull + shift", "blocks", "queued pixels (cell word)", "mixed pixels (triangles)", "objects", "stream out"]
+print("views sampled", n, "queued px/view", out[11] / n, "mixed px/view", out[12] / n)
+for i, nm in enumerate(names): print(f"  {nm:28s} {out[i] / n:9.0f} ticks")
+print("  total", sum(out[:6]) / n)

@@ -1242,11 +1242,12 @@ __global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_
 // Layer-plane rasteriser (default of tde_render_ego).  Same picture as render_ego_kernel, pixel for pixel, organised
 // by object instead of by pixel:
 //   the LDS image is ONE byte per pixel holding the layer (0 background, 1 road, 2 waypoint, 3 NPC, 4 ego);
-//   pass 1  base layer per 4x4 block from the grid class + clearance of its centre cell (2x2 refinement at road
-//           edges); only the pixels of sub-blocks that straddle a road edge are queued,
-//   pass 2  queued pixels: their own cell word, candidate-triangle tests in MIXED cells,
-//   pass 3  objects paint over the base in layer order - waypoint discs, NPC boxes, the ego - each thread taking one
-//           row of one object's conservative pixel bounding box: sum-of-bbox-rows tests instead of
+//   pass 1  base layer per 2x2 block from the grid class + clearance of its centre cell (four independent lookups per
+//           thread); only the pixels of blocks that straddle a road edge are queued,
+//   pass 2  queued pixels: their own cell word; those in MIXED cells are compacted (with the word) and get their
+//           candidate-triangle tests densely,
+//   pass 3  objects paint over the base in layer order - waypoint discs, NPC boxes, the ego - the workgroup covering
+//           each object's conservative pixel span as a 16 x 16 tile: sum-of-spans tests instead of
 //           (queued pixels) x (objects),
 //   pass 4  16 layer bytes -> 3 x 16 colour bytes with one v_perm_b32 per dword and channel, 16-B coalesced stores.
 // The per-pixel expressions (pixel centre -> world point, disc / box tests) are the specification's, so every pixel
@@ -1262,6 +1263,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     __shared__ PixelSpan s_wpbb[kRenderMaxWp];
     __shared__ RenderBox s_ego;
     __shared__ uint16_t s_work[kRenderWork];             // pixels whose base layer needs the exact test (r * W + c)
+    __shared__ uint32_t s_mixed[kRenderWork];            // cell words of the queued pixels that lie in MIXED cells
     __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed;
     const int e = blockIdx.x, tid = threadIdx.x;
     const int A = st.A, H = rd.H, W = rd.W;
@@ -1379,34 +1381,29 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     };
 
     if (!crowded) {
-        // ---- pass 1: base layer of 4x4 blocks, 2x2 refinement at road edges ----------------------------------
+        // ---- pass 1: base layer of 2x2 blocks (four per thread: the four cell words are in flight together) -------
         const int bw = W / 4, nblk = (H / 4) * bw;
-        const float rblock = 1.5f * 1.41421356f * res * 1.01f + 0.02f;   // pixel centres of a 4x4 block lie this close to its centre
-        const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // ... of a 2x2 block
+        const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // pixel centres of a 2x2 block lie this close to its centre
         for (int bi = tid; bi < nblk; bi += kBlock) {
             const int r0 = (bi / bw) * 4, c0 = (bi % bw) * 4;
-            const float f = (halfH - ((float)r0 + 2.0f)) * res, l = (halfW - ((float)c0 + 2.0f)) * res;
-            const uint32_t wd = cell_lookup(w, m, (ex + f * ce) - l * se, (ey + f * se) + l * ce);
-            const uint32_t cls = wd & 3u;
+            uint32_t ws[4];
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
+                const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = (halfW - ((float)(c0 + dc) + 1.0f)) * res;
+                ws[sb] = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
+            }
             uint32_t need = 0;                                     // bit (dr*4 + dc): pixel needs the exact test
-            if ((cls != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((wd >> 2) & 255u) >= rblock)) {
-                const uint32_t v = (cls == TDE_CELL_FULL) ? 0x01010101u : 0u;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s_layer[(r0 + i) * Wq + (c0 >> 2)] = v;
-            } else {
-#pragma unroll
-                for (int sb = 0; sb < 4; ++sb) {
-                    const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
-                    const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = (halfW - ((float)(c0 + dc) + 1.0f)) * res;
-                    const uint32_t ws = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
-                    const uint32_t cs = ws & 3u;
-                    if ((cs != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((ws >> 2) & 255u) >= rsub)) {
-                        const uint16_t v = (cs == TDE_CELL_FULL) ? (uint16_t)0x0101u : (uint16_t)0u;
-                        lay16[((r0 + dr) * W + c0 + dc) >> 1] = v;
-                        lay16[((r0 + dr + 1) * W + c0 + dc) >> 1] = v;
-                    } else {
-                        need |= 0x33u << (dr * 4 + dc);
-                    }
+            for (int sb = 0; sb < 4; ++sb) {
+                const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
+                const uint32_t cs = ws[sb] & 3u;
+                if ((cs != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((ws[sb] >> 2) & 255u) >= rsub)) {
+                    const uint16_t v = (cs == TDE_CELL_FULL) ? (uint16_t)0x0101u : (uint16_t)0u;
+                    lay16[((r0 + dr) * W + c0 + dc) >> 1] = v;
+                    lay16[((r0 + dr + 1) * W + c0 + dc) >> 1] = v;
+                } else {
+                    need |= 0x33u << (dr * 4 + dc);
                 }
             }
             if (need) {
@@ -1454,90 +1451,78 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             const int wi = base + tid;
             bool defer = false;
             int pix = 0;
+            uint32_t wd = 0;
             if (wi < npix) {
                 pix = s_work[wi];
                 float wx, wy;
                 pixel_world(pix / W, pix % W, wx, wy);
-                const uint32_t cls = cell_lookup(w, m, wx, wy) & 3u;
+                wd = cell_lookup(w, m, wx, wy);
+                const uint32_t cls = wd & 3u;
                 if (cls == TDE_CELL_MIXED) defer = true;
                 else lay8[pix] = (cls == TDE_CELL_FULL) ? 1 : 0;
             }
             __syncthreads();                                  // every lane has read its entry of this chunk:
-            if (defer) s_work[atomicAdd(&s_nmixed, 1)] = (uint16_t)pix;   // the compacted list may overwrite it
+            if (defer) {                                      // the compacted list may overwrite it
+                const int at = atomicAdd(&s_nmixed, 1);
+                s_work[at] = (uint16_t)pix;
+                s_mixed[at] = wd;                             // its cell word travels along: no second lookup
+            }
             __syncthreads();
         }
         // ---- pass 2b: ... and get their candidate-triangle tests here, densely -------------------------------------
         const int nmixed = s_nmixed;
         for (int wi = tid; wi < nmixed; wi += kBlock) {
             const int pix = s_work[wi];
+            const uint32_t wd = s_mixed[wi];
             float wx, wy;
             pixel_world(pix / W, pix % W, wx, wy);
-            lay8[pix] = (uint8_t)base_layer(wx, wy);
+            const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
+            const int n = (int)((wd >> 2) & 255u);
+            bool road = false;
+            for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
+            lay8[pix] = road ? 1 : 0;
         }
         __syncthreads();
-        // ---- pass 3: objects over the base, in layer order; one thread per row of an object's pixel span -----------
-        if (nwp > 0) {
-            int total = 0;
-            #pragma unroll 1
-            for (int j = 0; j < nwp; ++j) total += max(s_wpbb[j].rmax - s_wpbb[j].rmin + 1, 0);
-            for (int i = tid; i < total; i += kBlock) {
-                int k = 0, start = 0, acc = 0;
-                #pragma unroll 1
-                for (int j = 0; j < nwp; ++j) {
-                    acc += max(s_wpbb[j].rmax - s_wpbb[j].rmin + 1, 0);
-                    if (i >= acc) { k = j + 1; start = acc; }
-                }
-                const PixelSpan b = s_wpbb[k];
-                const float2 t = s_wp[k];
-                const int r = b.rmin + (i - start);
-                #pragma unroll 1
-                for (int c = b.cmin; c <= b.cmax; ++c) {
+        // ---- pass 3: objects over the base, in layer order (waypoint discs, NPC boxes, the ego): the workgroup covers
+        // an object's conservative pixel span as a 16 x 16 tile of threads (one pixel per thread at 64 x 64) ------------
+        const int tr = tid >> 4, tc = tid & 15;
+        for (int k = 0; k < nwp; ++k) {
+            const PixelSpan b = s_wpbb[k];
+            const float2 t = s_wp[k];
+            for (int r = b.rmin + tr; r <= b.rmax; r += 16)
+                for (int c = b.cmin + tc; c <= b.cmax; c += 16) {
                     float wx, wy;
                     pixel_world(r, c, wx, wy);
                     const float dx = wx - t.x, dy = wy - t.y;
                     if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) lay8[r * W + c] = 2;
                 }
-            }
-            __syncthreads();
         }
-        if (nbox > 0) {
-            int total = 0;
-            #pragma unroll 1
-            for (int j = 0; j < nbox; ++j) total += max(s_box[j].rmax - s_box[j].rmin + 1, 0);
-            for (int i = tid; i < total; i += kBlock) {
-                int k = 0, start = 0, acc = 0;
-                #pragma unroll 1
-                for (int j = 0; j < nbox; ++j) {
-                    acc += max(s_box[j].rmax - s_box[j].rmin + 1, 0);
-                    if (i >= acc) { k = j + 1; start = acc; }
-                }
-                const RenderBox b = s_box[k];
-                const int r = b.rmin + (i - start);
-                #pragma unroll 1
-                for (int c = b.cmin; c <= b.cmax; ++c) {
+        if (nwp > 0) __syncthreads();
+        for (int k = 0; k < nbox; ++k) {
+            const RenderBox &b = s_box[k];
+            const float bx = b.x, by = b.y, bc = b.c, bs = b.s, bhl = b.hl, bhw = b.hw;
+            const int rmax = b.rmax, cmin = b.cmin, cmax = b.cmax;
+            for (int r = b.rmin + tr; r <= rmax; r += 16)
+                for (int c = cmin + tc; c <= cmax; c += 16) {
                     float wx, wy;
                     pixel_world(r, c, wx, wy);
-                    const float dx = wx - b.x, dy = wy - b.y;
-                    const float p = dx * b.c + dy * b.s, q = dy * b.c - dx * b.s;
-                    if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) lay8[r * W + c] = 3;
+                    const float dx = wx - bx, dy = wy - by;
+                    const float p = dx * bc + dy * bs, q = dy * bc - dx * bs;
+                    if (fabsf(p) <= bhl && fabsf(q) <= bhw) lay8[r * W + c] = 3;
                 }
-            }
-            __syncthreads();
         }
+        if (nbox > 0) __syncthreads();
         {
-            const RenderBox b = s_ego;
-            const int rows = max(b.rmax - b.rmin + 1, 0);
-            for (int i = tid; i < rows; i += kBlock) {
-                const int r = b.rmin + i;
-                #pragma unroll 1
-                for (int c = b.cmin; c <= b.cmax; ++c) {
+            const float ehl = s_ego.hl, ehw = s_ego.hw;
+            const int rmax = s_ego.rmax, cmin = s_ego.cmin, cmax = s_ego.cmax;
+            for (int r = s_ego.rmin + tr; r <= rmax; r += 16)
+                for (int c = cmin + tc; c <= cmax; c += 16) {
                     float wx, wy;
                     pixel_world(r, c, wx, wy);
                     const float dx = wx - ex, dy = wy - ey;
                     const float p = dx * ce + dy * se, q = dy * ce - dx * se;
-                    if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) lay8[r * W + c] = 4;
+                    if (fabsf(p) <= ehl && fabsf(q) <= ehw) lay8[r * W + c] = 4;
                 }
-            }
         }
     }
     __syncthreads();
