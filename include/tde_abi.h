@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 3
+#define TDE_ABI_VERSION 4
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -206,7 +206,17 @@ typedef struct tde_render {
     int32_t H, W;               /* 64, 64 (multiples of 4, H*W <= 4096: the image is staged in 12 KiB of LDS) */
     float fov;                  /* metres covered by the image width (35 in torchdrivesim's default RendererConfig) */
     int32_t n_stack;            /* 0/1: single frame; n: frame stack of n */
+    /* Frame stack without moving pixels (optional; NULL: the older frames of `out` are shifted in place by a launch of
+     * their own).  `layers` is a caller-owned ring of the stack's frames as one LAYER byte per pixel,
+     * uint8 [B][n_stack][H*W], initialised to TDE_LAYER_BLANK and kept between calls; `phase` counts the calls made on
+     * this stack (0, 1, 2, ...).  Each call stores the new frame's layer plane in slot phase % n_stack and writes all
+     * n_stack frames of `out` (oldest first) by expanding the ring through the palette: 4 KiB read + 4 KiB written per
+     * older frame and view instead of 12 + 12, no ordering hazard, one launch.  A caller that clears a view's stack
+     * (VecFrameStack on reset) fills its ring slots with TDE_LAYER_BLANK. */
+    uint8_t *layers;
+    int32_t phase, _pad;
 } tde_render;
+#define TDE_LAYER_BLANK 5       /* palette entry (0, 0, 0): a frame that has not been rendered yet */
 
 #ifdef __cplusplus
 }

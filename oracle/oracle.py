@@ -205,6 +205,6 @@ def render_ego(cfg, world, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
     ns = max(1, n_stack)
     if out is None:
         out = np.zeros((state.B, 3 * ns, H, W), np.uint8)
-    rd = _abi.TdeRender(_p(out), H, W, fov, n_stack)
+    rd = _abi.TdeRender(_p(out), H, W, fov, n_stack, None, 0, 0)     # the oracle shifts the stack in place
     L.tde_oracle_render_ego(C.byref(cfg), C.byref(world.host_struct()), C.byref(state.struct), C.byref(rd))
     return out

@@ -18,19 +18,26 @@ g = torch.Generator().manual_seed(0)
 actions = torch.stack([torch.rand(K, B, generator=g) * 2 - 1, torch.rand(K, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)
 ops.env_rollout(cfg, dw, st, actions)
 out = {}
-for ns in (1, 3):
+for ns, ring in ((1, False), (3, False), (3, True)):
     img = None
+    stack = ops.FrameStack(B, ns, device=dev) if ring else None
+
+    def render(img):
+        return stack.render(cfg, dw, st) if ring else ops.render_ego(cfg, dw, st, n_stack=ns, out=img)
+
     for _ in range(3):
-        img = ops.render_ego(cfg, dw, st, n_stack=ns, out=img)
+        img = render(img)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     n = 20
     for _ in range(n):
-        img = ops.render_ego(cfg, dw, st, n_stack=ns, out=img)
+        img = render(img)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
-    wbytes = B * 12288
-    out[f"render_n_stack{ns}"] = dict(us=us, write_GBps=wbytes / us / 1e3, frac_of_8TBps=wbytes / us / 1e3 / 8000)
+    wbytes = B * 12288 * ns               # every frame of the stack is (re)written: that is what the policy reads
+    out[f"render_n_stack{ns}" + ("_layer_ring" if ring else "")] = dict(
+        us=us, write_GBps=wbytes / us / 1e3, frac_of_8TBps=wbytes / us / 1e3 / 8000)
+    del img, stack
 # step + render per timestep (closed loop shape): one step launch + one render launch
 st["action"].copy_(actions[0])
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

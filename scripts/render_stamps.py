@@ -20,7 +20,8 @@ out = (C.c_ulonglong * 24)(); lib.tde_debug_stamps(out, 1)
 for _ in range(5): img = ops.render_ego(cfg, dw, st, out=img)
 torch.cuda.synchronize(); lib.tde_debug_stamps(out, 0)
 n = out[10]
-names = ["cull + shift", "blocks", "queued pixels (cell word)", "mixed pixels (triangles)", "objects", "stream out"]
+names = ["cull + shift", "blocks", "queued pixels (cell word)", "mixed pixels (triangles)", "objects", "stream out",
+         "prologue (scn -> map, ego pose)"]
 print("views sampled", n, "queued px/view", out[11] / n, "mixed px/view", out[12] / n)
 for i, nm in enumerate(names): print(f"  {nm:28s} {out[i] / n:9.0f} ticks")
-print("  total", sum(out[:6]) / n)
+print("  total", sum(out[:7]) / n)

@@ -297,9 +297,10 @@ def test_full_size_8192x16_subset_and_determinism():
     assert np.isfinite(runs[0][0]).all()
 
 
-@pytest.mark.parametrize("A,n_stack", [(16, 1), (16, 3), (32, 1)])
-def test_render_ego_bit_exact(A, n_stack):
-    """R13 / BASELINE configs[4]: 64x64x3 ego birdview; every pixel equal to the oracle's brute-force raster"""
+@pytest.mark.parametrize("A,n_stack,ring", [(16, 1, False), (16, 3, False), (16, 3, True), (32, 1, False)])
+def test_render_ego_bit_exact(A, n_stack, ring):
+    """R13 / BASELINE configs[4]: 64x64x3 ego birdview; every pixel equal to the oracle's brute-force raster.
+    ring: the frame stack is kept as a ring of layer planes (ops.FrameStack) instead of being shifted in place"""
     from torchdriveenv_amd.synth import synthetic_world
 
     world = synthetic_world(n_scn=6, A=A, seed=3, n_maps=2)
@@ -308,6 +309,7 @@ def test_render_ego_bit_exact(A, n_stack):
     hs, ds, dw = _pair(world, B, A, cfg)
     rng = np.random.default_rng(4)
     hout = dout = None
+    stack = ops.FrameStack(B, n_stack, device=DEV) if ring else None
     for t in range(12):
         act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
         hs["action"][...] = act
@@ -316,7 +318,7 @@ def test_render_ego_bit_exact(A, n_stack):
         ops.env_step(cfg, dw, ds)
         if t % 3 == 2:
             hout = oracle.render_ego(cfg, world, hs, n_stack=n_stack, out=hout)
-            dout = ops.render_ego(cfg, dw, ds, n_stack=n_stack, out=dout)
+            dout = stack.render(cfg, dw, ds) if ring else ops.render_ego(cfg, dw, ds, n_stack=n_stack, out=dout)
             got = dout.cpu().numpy()
             assert got.shape == (B, 3 * n_stack, 64, 64) and got.dtype == np.uint8
             assert np.array_equal(got, hout), f"{(got != hout).sum()} pixels differ at t={t}"

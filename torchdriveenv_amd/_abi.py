@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 3
+TDE_ABI_VERSION = 4
 TDE_MAX_AGENTS = 64
 
 F_NPC = 1 << 0
@@ -100,7 +100,11 @@ class TdeRollout(C.Structure):
 
 
 class TdeRender(C.Structure):
-    _fields_ = [("out", _p), ("H", C.c_int32), ("W", C.c_int32), ("fov", C.c_float), ("n_stack", C.c_int32)]
+    _fields_ = [("out", _p), ("H", C.c_int32), ("W", C.c_int32), ("fov", C.c_float), ("n_stack", C.c_int32),
+                ("layers", _p), ("phase", C.c_int32), ("_pad", C.c_int32)]
+
+
+LAYER_BLANK = 5
 
 
 def ptr_of(a):

@@ -906,21 +906,12 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
 }
 
 // ---- R13: ego-centred birdview raster (get_obs -> render_egocentric, ref gym_env.py:122-124; layers: tde_abi.h) ----
-// One workgroup per env view, image staged in LDS (12 KiB for 3x64x64).
-//   pass 0  agents / remaining waypoints culled against the view circle into LDS lists with conservative pixel-space
-//           bounding boxes (a typical view holds 2-5 of the 16-32 agents); older frames of a frame stack shifted;
-//   pass 1  one lane per 4x4 pixel block: ONE grid lookup at the block centre — the cell word's clearance says whether
-//           every pixel of the block falls in cells of that same class (all road / all background); blocks that also
-//           miss every object box are filled with four 32-bit LDS stores per colour plane.  Blocks on a road edge are
-//           refined into 2x2 sub-blocks (same test at each sub-block centre, 16-bit stores); the pixels that are
-//           left are queued;
-//   pass 2a the queued pixels, spread evenly over the lanes, are shaded exactly like the oracle (waypoint discs, agent
-//           boxes, grid class) — except that pixels in MIXED grid cells not covered by an object are re-queued ...
-//   pass 2b ... and resolved here with the candidate-triangle tests, so the expensive divergent part runs densely;
-//   pass 3  the LDS image is streamed out with 16-B stores: 12 KiB per view, fully coalesced.
-// Every shortcut is conservative (supersets / clearance margins), so each pixel equals the per-pixel specification.
+// One workgroup per env view (render_layers_kernel below).  pass 0: agents / remaining waypoints are culled against
+// the view circle into LDS lists with conservative pixel-space spans (a typical 35 m view holds 1-3 of the 16-32
+// agents).  Every shortcut is conservative (supersets / clearance margins), so each pixel equals the per-pixel
+// specification.
 constexpr int kRenderMaxWp = 64;
-constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS image)
+constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS layer plane, one byte per pixel)
 constexpr int kRenderWork = 2048;                 // exact-pixel queue (a view that needs more takes the all-pixels path)
 constexpr int kRenderMaxBox = 40;                 // agent boxes kept per view (more: all-pixels path)
 
@@ -950,297 +941,31 @@ __global__ __launch_bounds__(kBlock) void state_obs_kernel(tde_world w, tde_stat
 
 struct RenderBox { float x, y, c, s, hl, hw; int rmin, rmax, cmin, cmax; };
 
-__global__ __launch_bounds__(kBlock) void render_ego_kernel(tde_config cfg, tde_world w, tde_state st, tde_render rd)
+// Frame stack (VecFrameStack(n_stack, channels_order="first"), ref examples/rl_training.py:160): the older frames of
+// every view move down by one frame, in place, before the new frame is rasterised.  A launch of its own: as a pure
+// streaming copy it runs at cache / HBM bandwidth, whereas inside the rasteriser's workgroups the same bytes cost two
+// exposed round trips per view (212 -> ~110 us per 8192 views at n_stack 3).  One workgroup per view and chunk: read
+// the chunk, barrier, write it (dst trails src by one frame, so later chunks read above everything written so far).
+__global__ __launch_bounds__(kBlock) void frame_shift_kernel(uint8_t *__restrict__ stack, int plane, int ns)
 {
-    __shared__ uint32_t s_img[3 * kRenderMaxPix / 4];
-    __shared__ RenderBox s_box[kRenderMaxBox];           // NPC boxes in view, ego kept separately
-    __shared__ float4 s_wp[kRenderMaxWp];                // x, y, then pixel bbox packed as 2 x (min | max << 16)
-    __shared__ RenderBox s_ego;
-    __shared__ uint16_t s_work[kRenderWork];             // pixels that need exact shading (r * W + c), then reused in
-    __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed;      // place for the pixels deferred to the triangle pass
-    const int e = blockIdx.x, tid = threadIdx.x;
-    const int A = st.A, H = rd.H, W = rd.W;
-    const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
-    const int plane = H * W;
-    uint8_t *out = rd.out + (int64_t)e * 3 * ns * plane;
-    const int64_t g0 = (int64_t)e * A;
-    const int scn = st.scn[e];
-    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[scn];
-    const tde_map m = w.maps[sc.x];
-    const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
-    const float res = rd.fov / (float)W;
-    const float inv_res = 1.0f / res;
-    const float halfH = 0.5f * (float)H, halfW = 0.5f * (float)W;
-    // view circle: half diagonal of the image plus slack; lists are supersets, so culling cannot change a pixel
-    const float rview = 0.75f * res * (float)(H > W ? H : W) + 1.0f;
-    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }
-    const float ex = st.x[g0], ey = st.y[g0];
-    float se, ce;
-    sincos_f32(st.psi[g0], se, ce);
-    __syncthreads();
-
-    // conservative pixel bounding box (rows/cols, inclusive) of a disc of radius rad around world point (x, y)
-    // conservative pixel bounding boxes (rows/cols, inclusive; one pixel of slack for rounding): of a disc ...
-    auto pixel_bbox = [=](float x, float y, float rad) -> int4 {          // (rmin, rmax, cmin, cmax)
-        const float dx = x - ex, dy = y - ey;
-        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
-        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.0f;
-        return make_int4((int)floorf(rc - pr), (int)ceilf(rc + pr), (int)floorf(cc - pr), (int)ceilf(cc + pr));
-    };
-    // ... and of an oriented box (its extent along the image axes is |cos|*hl + |sin|*hw and vice versa)
-    auto box_bbox = [=](float x, float y, float cb, float sb, float hl, float hw) -> int4 {
-        const float dx = x - ex, dy = y - ey;
-        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
-        const float cr = cb * ce + sb * se, sr = sb * ce - cb * se;      // box heading relative to the ego's
-        const float ef = fabsf(cr) * hl + fabsf(sr) * hw, el = fabsf(sr) * hl + fabsf(cr) * hw;
-        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f;
-        const float pr = ef * inv_res + 1.0f, pc = el * inv_res + 1.0f;
-        return make_int4((int)floorf(rc - pr), (int)ceilf(rc + pr), (int)floorf(cc - pc), (int)ceilf(cc + pc));
-    };
-    if (tid < A) {
-        const int64_t g = g0 + tid;
-        float sa, ca;
-        sincos_f32(st.psi[g], sa, ca);
-        const float bx = st.x[g], by = st.y[g], bhl = 0.5f * st.len[g], bhw = 0.5f * st.wid[g];
-        const int4 bb = box_bbox(bx, by, ca, sa, bhl, bhw);
-        RenderBox *dstb = nullptr;
-        if (tid == 0) {
-            dstb = &s_ego;
-        } else if (st.present[g]) {
-            const float dx = bx - ex, dy = by - ey, rr = rview + (bhl + bhw);
-            if (dx * dx + dy * dy <= rr * rr) {
-                const int k = atomicAdd(&s_nbox, 1);
-                if (k < kRenderMaxBox) dstb = &s_box[k];        // beyond: the view takes the all-pixels path
-            }
-        }
-        if (dstb) {
-            dstb->x = bx; dstb->y = by; dstb->c = ca; dstb->s = sa; dstb->hl = bhl; dstb->hw = bhw;
-            dstb->rmin = bb.x; dstb->rmax = bb.y; dstb->cmin = bb.z; dstb->cmax = bb.w;
-        }
-    }
-    {
-        const int ti = st.target_idx[e], n_wp = sc.y;
-        for (int k = ti + tid; k < n_wp; k += kBlock) {
-            const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
-            const float tx = (float)t.x, ty = (float)t.y;
-            const float dx = tx - ex, dy = ty - ey, rr = rview + TDE_WAYPOINT_RADIUS;
-            if (dx * dx + dy * dy <= rr * rr) {
-                const int q = atomicAdd(&s_nwp, 1);
-                if (q < kRenderMaxWp) {
-                    const int4 bb = pixel_bbox(tx, ty, TDE_WAYPOINT_RADIUS);
-                    int rmin = bb.x, rmax = bb.y, cmin = bb.z, cmax = bb.w;
-                    rmin = max(rmin, -1); cmin = max(cmin, -1); rmax = min(max(rmax, -1), 4095); cmax = min(max(cmax, -1), 4095);
-                    s_wp[q] = make_float4(tx, ty, __int_as_float((rmin + 1) | ((rmax + 1) << 16)),
-                                          __int_as_float((cmin + 1) | ((cmax + 1) << 16)));
-                }
-            }
-        }
-    }
-    // frame stack: shift the older frames down by one frame (read everything, barrier, write)
-    if (ns > 1) {
-        const int nvec = 3 * (ns - 1) * plane / 16;
-        const uint4 *src = reinterpret_cast<const uint4 *>(out + 3 * plane);
-        uint4 *dst = reinterpret_cast<uint4 *>(out);
-        for (int i0 = 0; i0 < nvec; i0 += kBlock * 4) {
-            uint4 v[4];
+    uint8_t *out = stack + (int64_t)blockIdx.x * 3 * ns * plane;
+    const int tid = threadIdx.x;
+    const int nvec = 3 * (ns - 1) * plane / 16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(out + 3 * plane);
+    uint4 *dst = reinterpret_cast<uint4 *>(out);
+    for (int i0 = 0; i0 < nvec; i0 += kBlock * 8) {
+        uint4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) v[u] = src[i]; }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) dst[i] = v[u]; }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp;
-    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp;
-    const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
-                   NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
-    const int Wq = W / 4;                                 // dwords per image row
-    const int bw = W / 4, nblk = (H / 4) * bw;
-
-    // ---- pass 1: classify 4x4 blocks, refine road-edge blocks to 2x2 ---------------------------------------------
-    const float rblock = 1.5f * 1.41421356f * res * 1.01f + 0.02f;   // pixel centres of a 4x4 block lie this close to its centre
-    const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // ... of a 2x2 block
-    uint16_t *img16 = reinterpret_cast<uint16_t *>(s_img);
-    for (int bi = tid; bi < nblk; bi += kBlock) {
-        const int r0 = (bi / bw) * 4, c0 = (bi % bw) * 4;
-        const float f = (halfH - ((float)r0 + 2.0f)) * res, l = (halfW - ((float)c0 + 2.0f)) * res;
-        const float wx = (ex + f * ce) - l * se, wy = (ey + f * se) + l * ce;
-        const uint32_t wd = cell_lookup(w, m, wx, wy);
-        const uint32_t cls = wd & 3u;
-        const bool uniform = (cls != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((wd >> 2) & 255u) >= rblock);
-        bool touched = (r0 <= s_ego.rmax) && (r0 + 3 >= s_ego.rmin) && (c0 <= s_ego.cmax) && (c0 + 3 >= s_ego.cmin);
-        for (int k = 0; k < nbox; ++k)
-            touched = touched || ((r0 <= s_box[k].rmax) && (r0 + 3 >= s_box[k].rmin) && (c0 <= s_box[k].cmax) &&
-                                  (c0 + 3 >= s_box[k].cmin));
-        for (int k = 0; k < nwp; ++k) {
-            const int rr = __float_as_int(s_wp[k].z), cc = __float_as_int(s_wp[k].w);
-            touched = touched || ((r0 + 1 <= (rr >> 16)) && (r0 + 4 >= (rr & 0xffff)) && (c0 + 1 <= (cc >> 16)) &&
-                                  (c0 + 4 >= (cc & 0xffff)));
-        }
-        uint32_t need = 0;                                     // bit (dr*4 + dc): pixel needs exact shading
-        if (touched) {
-            need = 0xFFFFu;
-        } else if (uniform) {
-            const bool road = cls == TDE_CELL_FULL;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const uint32_t v = (road ? ROAD[ch] : BG[ch]) * 0x01010101u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s_img[ch * (plane / 4) + (r0 + i) * Wq + (c0 >> 2)] = v;
-            }
-        } else {
-#pragma unroll
-            for (int sb = 0; sb < 4; ++sb) {
-                const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
-                const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = (halfW - ((float)(c0 + dc) + 1.0f)) * res;
-                const uint32_t ws = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
-                const uint32_t cs = ws & 3u;
-                if ((cs != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((ws >> 2) & 255u) >= rsub)) {
-                    const bool road = cs == TDE_CELL_FULL;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const uint16_t v = (uint16_t)((road ? ROAD[ch] : BG[ch]) * 0x0101u);
-                        img16[(ch * plane + (r0 + dr) * W + c0 + dc) >> 1] = v;
-                        img16[(ch * plane + (r0 + dr + 1) * W + c0 + dc) >> 1] = v;
-                    }
-                } else {
-                    need |= 0x33u << (dr * 4 + dc);
-                }
-            }
-        }
-        if (need) {
-            const int n = __popc(need);
-            int at = atomicAdd(&s_nwork, n);
-            if (at + n > kRenderWork) need = 0;                 // queue full: the view takes the all-pixels path
-            while (need) {
-                const int b = __ffs((int)need) - 1;
-                need &= need - 1u;
-                s_work[at++] = (uint16_t)((r0 + (b >> 2)) * W + c0 + (b & 3));
-            }
-        }
-    }
-    __syncthreads();
-
-    uint8_t *img8 = reinterpret_cast<uint8_t *>(s_img);
-    const bool all_pixels = crowded || s_nwork > kRenderWork;
-    if (all_pixels) {
-        // rare fallback (more boxes / waypoints / edge pixels in view than the LDS lists hold): every pixel is shaded
-        // from the global tables, literally as the specification reads
-        const int ti = st.target_idx[e], n_wp = sc.y;
-        for (int pix = tid; pix < plane; pix += kBlock) {
-            const int r = pix / W, c = pix % W;
-            const float f = (halfH - ((float)r + 0.5f)) * res;
-            const float l = (halfW - ((float)c + 0.5f)) * res;
-            const float wx = (ex + f * ce) - l * se;
-            const float wy = (ey + f * se) + l * ce;
-            int layer = 0;
-            {
-                const uint32_t wd = cell_lookup(w, m, wx, wy);
-                const uint32_t cls = wd & 3u;
-                bool road = cls == TDE_CELL_FULL;
-                if (cls == TDE_CELL_MIXED) {
-                    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
-                    const int n = (int)((wd >> 2) & 255u);
-                    for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
-                }
-                layer = road ? 1 : 0;
-            }
-            for (int k = ti; k < n_wp; ++k) {
-                const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
-                const float dx = wx - (float)t.x, dy = wy - (float)t.y;
-                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
-            }
-            for (int a = A - 1; a >= 0; --a) {
-                const int64_t g = g0 + a;
-                if (!st.present[g]) continue;
-                float sa, ca;
-                sincos_f32(st.psi[g], sa, ca);
-                const float dx = wx - st.x[g], dy = wy - st.y[g];
-                const float p = dx * ca + dy * sa, q = dy * ca - dx * sa;
-                if (fabsf(p) <= 0.5f * st.len[g] && fabsf(q) <= 0.5f * st.wid[g]) layer = a ? 3 : 4;
-            }
-            img8[pix] = (uint8_t)TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
-            img8[plane + pix] = (uint8_t)TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
-            img8[2 * plane + pix] = (uint8_t)TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
-        }
-    }
-    // ---- pass 2a: exact shading of the queued pixels; pixels in MIXED grid cells are deferred --------------------
-    const int npix = all_pixels ? 0 : s_nwork;
-    for (int base = 0; base < npix; base += kBlock) {
-        const int wi = base + tid;
-        bool defer = false;
-        int pix = 0;
-        if (wi < npix) {
-            pix = s_work[wi];
-            const int r = pix / W, c = pix % W;
-            const float f = (halfH - ((float)r + 0.5f)) * res;
-            const float l = (halfW - ((float)c + 0.5f)) * res;
-            const float wx = (ex + f * ce) - l * se;
-            const float wy = (ey + f * se) + l * ce;
-            int layer = -1;                                   // 0 bg, 1 road, 2 waypoint, 3 npc, 4 ego
-            for (int k = 0; k < nwp; ++k) {
-                const float4 t = s_wp[k];
-                const float dx = wx - t.x, dy = wy - t.y;
-                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
-            }
-            for (int k = 0; k < nbox; ++k) {
-                const RenderBox &b = s_box[k];
-                if (r < b.rmin || r > b.rmax || c < b.cmin || c > b.cmax) continue;
-                const float dx = wx - b.x, dy = wy - b.y;
-                const float p = dx * b.c + dy * b.s, q = dy * b.c - dx * b.s;
-                if (fabsf(p) <= b.hl && fabsf(q) <= b.hw) layer = 3;
-            }
-            {
-                const float dx = wx - ex, dy = wy - ey;
-                const float p = dx * ce + dy * se, q = dy * ce - dx * se;
-                if (fabsf(p) <= s_ego.hl && fabsf(q) <= s_ego.hw) layer = 4;
-            }
-            if (layer < 0) {
-                const uint32_t cls = cell_lookup(w, m, wx, wy) & 3u;
-                if (cls == TDE_CELL_MIXED) defer = true;
-                else layer = (cls == TDE_CELL_FULL) ? 1 : 0;
-            }
-            if (!defer) {
-                img8[pix] = (uint8_t)TDE_SEL4(layer, BG[0], ROAD[0], WP[0], layer == 3 ? NPC[0] : EGO[0]);
-                img8[plane + pix] = (uint8_t)TDE_SEL4(layer, BG[1], ROAD[1], WP[1], layer == 3 ? NPC[1] : EGO[1]);
-                img8[2 * plane + pix] = (uint8_t)TDE_SEL4(layer, BG[2], ROAD[2], WP[2], layer == 3 ? NPC[2] : EGO[2]);
-            }
-        }
-        __syncthreads();                                      // every lane has read its entry of this chunk:
-        if (defer) s_work[atomicAdd(&s_nmixed, 1)] = (uint16_t)pix;   // the compacted list may overwrite it
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) v[u] = src[i]; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) dst[i] = v[u]; }
     }
-    // ---- pass 2b: deferred pixels: candidate-triangle tests ---------------------------------------------------
-    const int nmixed = s_nmixed;
-    for (int wi = tid; wi < nmixed; wi += kBlock) {
-        const int pix = s_work[wi];
-        const int r = pix / W, c = pix % W;
-        const float f = (halfH - ((float)r + 0.5f)) * res;
-        const float l = (halfW - ((float)c + 0.5f)) * res;
-        const float wx = (ex + f * ce) - l * se;
-        const float wy = (ey + f * se) + l * ce;
-        const uint32_t wd = cell_lookup(w, m, wx, wy);
-        const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
-        const int n = (int)((wd >> 2) & 255u);
-        bool road = false;
-        for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
-        img8[pix] = (uint8_t)(road ? ROAD[0] : BG[0]);
-        img8[plane + pix] = (uint8_t)(road ? ROAD[1] : BG[1]);
-        img8[2 * plane + pix] = (uint8_t)(road ? ROAD[2] : BG[2]);
-    }
-    __syncthreads();
-
-    // ---- pass 3: stream the image out --------------------------------------------------------------------------
-    uint4 *dst = reinterpret_cast<uint4 *>(out + 3 * (ns - 1) * plane);
-    const uint4 *src = reinterpret_cast<const uint4 *>(s_img);
-    for (int i = tid; i < 3 * plane / 16; i += kBlock) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Layer-plane rasteriser (default of tde_render_ego).  Same picture as render_ego_kernel, pixel for pixel, organised
-// by object instead of by pixel:
+// Layer-plane rasteriser (tde_render_ego), organised by object instead of by pixel:
 //   the LDS image is ONE byte per pixel holding the layer (0 background, 1 road, 2 waypoint, 3 NPC, 4 ego);
 //   pass 1  base layer per 2x2 block from the grid class + clearance of its centre cell (four independent lookups per
 //           thread); only the pixels of blocks that straddle a road edge are queued,
@@ -1265,10 +990,11 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     __shared__ uint16_t s_work[kRenderWork];             // pixels whose base layer needs the exact test (r * W + c)
     __shared__ uint32_t s_mixed[kRenderWork];            // cell words of the queued pixels that lie in MIXED cells
     __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed;
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int A = st.A, H = rd.H, W = rd.W;
     const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
     const int plane = H * W;
+    const int e = blockIdx.x;      // (frame stack: see pass 4; without a layer ring frame_shift_kernel ran before this launch)
     uint8_t *out = rd.out + (int64_t)e * 3 * ns * plane;
     const int64_t g0 = (int64_t)e * A;
     const int scn = st.scn[e];
@@ -1339,21 +1065,6 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
                 const int q = atomicAdd(&s_nwp, 1);
                 if (q < kRenderMaxWp) { s_wp[q] = make_float2(tx, ty); s_wpbb[q] = disc_span(tx, ty, TDE_WAYPOINT_RADIUS); }
             }
-        }
-    }
-    // frame stack: shift the older frames down by one frame (read everything, barrier, write)
-    if (ns > 1) {
-        const int nvec = 3 * (ns - 1) * plane / 16;
-        const uint4 *src = reinterpret_cast<const uint4 *>(out + 3 * plane);
-        uint4 *dst = reinterpret_cast<uint4 *>(out);
-        for (int i0 = 0; i0 < nvec; i0 += kBlock * 4) {
-            uint4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) v[u] = src[i]; }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) dst[i] = v[u]; }
-            __syncthreads();
         }
     }
     __syncthreads();
@@ -1528,12 +1239,10 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     __syncthreads();
 
     // ---- pass 4: layers -> colours, streamed out ---------------------------------------------------------------
+    // v_perm_b32 is a byte look-up in an 8-entry table: entries 0-4 the palette, 5 = TDE_LAYER_BLANK (0, 0, 0).
     const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
                    NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
-    uint8_t *frame = out + 3 * (ns - 1) * plane;
-    const uint4 *src = reinterpret_cast<const uint4 *>(s_layer);
-    for (int i = tid; i < plane / 16; i += kBlock) {
-        const uint4 v = src[i];
+    auto expand = [&](const uint4 &v, uint8_t *frame, int i) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const uint32_t lo = BG[ch] | (ROAD[ch] << 8) | (WP[ch] << 16) | (NPC[ch] << 24), hi = EGO[ch];
@@ -1542,6 +1251,26 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             o.z = __builtin_amdgcn_perm(hi, lo, v.z); o.w = __builtin_amdgcn_perm(hi, lo, v.w);
             reinterpret_cast<uint4 *>(frame + ch * plane)[i] = o;
         }
+    };
+    const uint4 *src = reinterpret_cast<const uint4 *>(s_layer);
+    const int nv = plane / 16;
+    if (ns > 1 && rd.layers) {
+        // frame stack from the ring of layer planes: slot of the new frame = phase % ns; output frame j (oldest first)
+        // is ring slot (phase + 1 + j) % ns.  Nothing is shifted: every frame of `out` is written from its layer plane.
+        uint8_t *ring = rd.layers + (int64_t)e * ns * plane;
+        const int slot_new = rd.phase % ns;
+        for (int i = tid; i < nv; i += kBlock) {
+            const uint4 v = src[i];
+            reinterpret_cast<uint4 *>(ring + (int64_t)slot_new * plane)[i] = v;
+            expand(v, out + 3 * (ns - 1) * plane, i);
+        }
+        for (int j = 0; j < ns - 1; ++j) {
+            const int slot = (rd.phase + 1 + j) % ns;
+            const uint4 *old = reinterpret_cast<const uint4 *>(ring + (int64_t)slot * plane);
+            for (int i = tid; i < nv; i += kBlock) expand(old[i], out + 3 * j * plane, i);
+        }
+    } else {
+        for (int i = tid; i < nv; i += kBlock) expand(src[i], out + 3 * (ns - 1) * plane, i);
     }
 }
 
@@ -1726,9 +1455,9 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
         rd->H * rd->W > tde::kRenderMaxPix)
         return bad("tde_render_ego: H and W must be positive multiples of 4 with H*W <= 4096");
     if (st->B <= 0) return 0;
-    static const bool by_pixel = [] { const char *v = getenv("TDE_RENDER"); return v && !strcmp(v, "pixel"); }();
-    if (by_pixel) tde::render_ego_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
-    else tde::render_layers_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
+    if (rd->n_stack > 1 && !rd->layers)
+        tde::frame_shift_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(rd->out, rd->H * rd->W, rd->n_stack);
+    tde::render_layers_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
 }

@@ -236,7 +236,7 @@ class BatchedWaypointEnv:
         self.obs_mode, self.frame_stack = obs_mode, max(1, int(frame_stack))
         r = cfg.simulator.renderer
         self._res, self._fov = int(r.res), float(r.fov)
-        self._obs = None
+        self._obs = self._stack = None
         self.action_space = _box(ACTION_LOW, ACTION_HIGH)
         self.observation_space = (_box(0, 255, (3 * self.frame_stack, self._res, self._res), np.uint8)
                                   if obs_mode == "birdview" else _box(-np.inf, np.inf, (8,), np.float32))
@@ -251,11 +251,8 @@ class BatchedWaypointEnv:
         if mask is not None:
             m = torch.as_tensor(mask, device=self.torch_device).to(torch.uint8).contiguous()
         ops.env_reset(self.tde_cfg, self.dworld, self.state, m)
-        if self.obs_mode == "birdview" and self.frame_stack > 1:
-            if self._obs is None or m is None:
-                self._obs = None
-            else:
-                self._obs[m.bool()] = 0                              # VecFrameStack clears the stack on reset
+        if self.obs_mode == "birdview" and self._stack is not None:
+            self._stack.clear(None if m is None else m.bool())       # VecFrameStack clears the stack on reset
         return self.get_obs()
 
     def step(self, actions):
@@ -277,8 +274,12 @@ class BatchedWaypointEnv:
         if self.obs_mode == "state":
             # x, y, psi, v, target offset (forward, left) in the ego frame, target-exists flag, environment_steps
             return ops.state_obs(self.dworld, self.state)
-        self._obs = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov,
-                                   self.frame_stack, self._obs)
+        if self.frame_stack > 1:
+            if self._stack is None:
+                self._stack = ops.FrameStack(self.num_envs, self.frame_stack, self._res, self._res, self.torch_device)
+            self._obs = self._stack.render(self.tde_cfg, self.dworld, self.state, self._fov)
+            return self._obs
+        self._obs = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, self._obs)
         return self._obs
 
     def get_info(self):

@@ -180,15 +180,42 @@ def state_obs(dworld, state, out=None):
     return out
 
 
-def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
+def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None, layers=None, phase=0):
     """render_egocentric() of every env's ego -> uint8 [B, 3*n_stack, H, W] on device (ref gym_env.py:122-124).
-    With n_stack > 1 `out` must be the buffer of the previous call: older frames are shifted, the new one appended."""
+    Frame stack (n_stack > 1): `out` is the stack of the previous call.  With `layers` (uint8 [B, n_stack, H*W], see
+    FrameStack) nothing is shifted: the ring of layer planes is expanded into all frames of `out`; without it the older
+    frames are shifted in place by a launch of their own."""
     L = _lib.load()
     ns = max(1, n_stack)
     dev = state.device
     if out is None:
         out = torch.zeros((state.B, 3 * ns, H, W), dtype=torch.uint8, device=dev)
-    rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack)
+    pl = _chk(layers, torch.uint8, state.B * ns * H * W, "layers", optional=True) if ns > 1 else None
+    rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack, pl, int(phase), 0)
     _lib.check(_call(dev, L.tde_render_ego, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(rd),
-                                _lib.current_stream(dev)), "tde_render_ego")
+                     _lib.current_stream(dev)), "tde_render_ego")
     return out
+
+
+class FrameStack:
+    """Device-side VecFrameStack(n_stack, channels_order="first") (ref examples/rl_training.py:160) kept as a ring of
+    one-byte-per-pixel layer planes: every call writes all n_stack frames of `obs` (oldest first) from the ring, so no
+    pixels are moved between calls."""
+
+    def __init__(self, B, n_stack, H=64, W=64, device="cuda"):
+        self.n_stack, self.H, self.W = int(n_stack), H, W
+        self.obs = torch.zeros((B, 3 * self.n_stack, H, W), dtype=torch.uint8, device=device)
+        self.layers = torch.full((B, self.n_stack, H * W), _abi.LAYER_BLANK, dtype=torch.uint8, device=device)
+        self.phase = 0
+
+    def render(self, cfg, dworld, state, fov=35.0):
+        render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, self.phase)
+        self.phase += 1
+        return self.obs
+
+    def clear(self, mask=None):
+        """blank the stack of the masked views (all views without a mask), as VecFrameStack does on reset"""
+        if mask is None:
+            self.layers.fill_(_abi.LAYER_BLANK)
+        else:
+            self.layers[mask] = _abi.LAYER_BLANK
