@@ -1067,9 +1067,8 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             }
         }
     }
-    __syncthreads();
-    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp;
-    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp;
+    // no barrier here: pass 1 does not read the lists, so the wavefronts without culling work start it at once and the
+    // few culling lanes' dependent loads hide behind it (the lists are complete at the barrier that ends pass 1)
     uint8_t *lay8 = reinterpret_cast<uint8_t *>(s_layer);
     uint16_t *lay16 = reinterpret_cast<uint16_t *>(s_layer);
     const int Wq = W / 4;                                 // dwords per image row
@@ -1091,7 +1090,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         return road ? 1 : 0;
     };
 
-    if (!crowded) {
+    {
         // ---- pass 1: base layer of 2x2 blocks (four per thread: the four cell words are in flight together) -------
         const int bw = W / 4, nblk = (H / 4) * bw;
         const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // pixel centres of a 2x2 block lie this close to its centre
@@ -1130,6 +1129,8 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         }
     }
     __syncthreads();
+    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp;
+    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp;
     const bool all_pixels = crowded || s_nwork > kRenderWork;
     if (all_pixels) {
         // rare fallback (more boxes / waypoints / edge pixels in view than the LDS lists hold): every pixel is shaded
