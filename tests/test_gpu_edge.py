@@ -179,3 +179,37 @@ def test_render_other_sizes_and_bad_sizes(small_world):
         ops.render_ego(cfg, dw, ds, H=30, W=30)
     with pytest.raises(_lib.TdeError, match="4096"):
         ops.render_ego(cfg, dw, ds, H=128, W=64)
+
+
+@pytest.mark.parametrize("H,W,n_stack", [(32, 32, 2), (48, 64, 4), (64, 64, 5)])
+def test_frame_stack_other_sizes_ring_and_in_place(small_world, H, W, n_stack):
+    """frame stack of other depths / image sizes, both ways (ring of layer planes, shifted in place) against the
+    oracle's memmove; a cleared view starts again from blank (all-zero) frames like VecFrameStack after a reset"""
+    cfg = _abi.default_config(seed=2)
+    dw = small_world.to_device(DEV)
+    B = 6
+    hs, ds = EnvState(B, 16), EnvState(B, 16, device=DEV)
+    oracle.env_reset(cfg, small_world, hs)
+    ops.env_reset(cfg, dw, ds)
+    stack = ops.FrameStack(B, n_stack, H, W, device=DEV)
+    want = inplace = None
+    rng = np.random.default_rng(0)
+    for t in range(n_stack + 3):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(torch.from_numpy(act).to(DEV))
+        oracle.env_step(cfg, small_world, hs)
+        ops.env_step(cfg, dw, ds)
+        want = oracle.render_ego(cfg, small_world, hs, H=H, W=W, n_stack=n_stack, out=want)
+        inplace = ops.render_ego(cfg, dw, ds, H=H, W=W, n_stack=n_stack, out=inplace)
+        ring = stack.render(cfg, dw, ds)
+        assert np.array_equal(inplace.cpu().numpy(), want), ("in place", t)
+        assert np.array_equal(ring.cpu().numpy(), want), ("ring", t)
+        if t == n_stack + 1:                               # one frame after the clear: only the newest is drawn
+            assert (want[1, :-3] == 0).all() and want[1, -3:].any() and want[0, :3].any()
+        if t == n_stack:                                   # clear views 1 and 4 on both sides
+            m = torch.zeros(B, dtype=torch.bool, device=DEV)
+            m[[1, 4]] = True
+            stack.clear(m)
+            want[[1, 4]] = 0
+            inplace[m] = 0
