@@ -585,8 +585,9 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
 // (~10 cycles per dependent fp32 VALU op against ~2 cycles of issue, scripts/ubench/valu_latency.hip), and the headline
 // batch only fills two wavefronts per SIMD, so the single-role kernel above leaves half of the issue slots empty.
 // Here every group of 64 agent slots is served by TWO wavefronts of one workgroup that split the step by role:
-//   drive : NPC controller + bicycle integration + replay + route switching (R4, R5, R14) -> the next tile
-//   judge : collision, offroad, stop-line violation, reward / termination, outputs, waypoint advance (R6-R12)
+//   drive : NPC controller + bicycle integration + replay + route switching (R4, R5, R14) -> the next tile; the ego
+//           lane's reward arithmetic and waypoint advance (R2, R6, R7, R12), which only need the pose before and after
+//   judge : collision, offroad, stop-line violation, terminated / truncated, the done byte (R8-R11)
 // The judge works on step i while the driver already computes step i+1 from the same tile, speculating that no env of
 // its wavefront finished; when one did (about 7 % of wave-steps) the driver re-spawns those lanes and recomputes.
 // Tiles are double-buffered by step parity; per step two LDS-only barriers:
@@ -643,12 +644,13 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         lds_barrier();                                       // rows of the launch state are in buffer 1
         const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
         float2 act = acts[es];
+        RewardOut rw{};
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1, q = p ^ 1;
             const int kn = (i + 1 < ro.K) ? i + 1 : i;
             const float2 act_next = acts[(int64_t)kn * B + es];
             float nx, ny, npsi, nv, nc, ns;
-            int nwp, k;
+            int nwp, k, n_target = er.target_idx, n_reached = er.reached;
             bool switched, live;
             for (int pass = 0;; ++pass) {
                 // one step from the rows in buffer q, nothing committed yet (step_lane up to the tile write)
@@ -682,6 +684,14 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                     if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
                 }
                 sincos_f32(npsi, ns, nc);
+                // The ego lane's reward arithmetic and waypoint bookkeeping (:391-411, :378-383) live here: they need the
+                // pose before and after the step, which this wavefront holds, and not the infraction flags (only
+                // `terminated` does, which the judge settles); this wavefront would otherwise idle at barrier A.
+                if ((F & TDE_F_REWARD) && a == 0 && valid) {
+                    n_target = er.target_idx; n_reached = er.reached;
+                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, ag.x, ag.y, ag.psi, ag.v, nx, ny, npsi, nv, false,
+                                     false, false, k, n_target, n_reached, st.info != nullptr);
+                }
                 if (pass) break;
                 lds_barrier();                               // A: done(i-1) is published
                 const unsigned long long dn = sh.done;
@@ -701,6 +711,19 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);
             lds_barrier();                                   // B: rows of step i are in buffer p
             if (switched) load_route_target(cold, ag, cx);
+            if (a == 0 && valid) {
+                if (F & TDE_F_REWARD) {
+                    const bool advanced = n_target != er.target_idx;
+                    er.target_idx = n_target; er.reached = n_reached;
+                    if (st.info) {
+                        double *inf = st.info + 4 * (int64_t)e;
+                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
+                    }
+                    if (st.info_reached) st.info_reached[e] = er.reached;
+                    if (advanced) load_ego_target(cold, er, cx);   // (a finished env reloads it when it re-spawns)
+                }
+                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;
+            }
             act = act_next;
         }
         lds_barrier();                                       // A of the step after the last: done(K-1)
@@ -709,13 +732,18 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (!valid) return;
         store_agent_dynamic(st, g, ag);
         store_agent_static(st, g, ag);
+        if (a == 0) {
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = rw.reward;
+        }
     } else {
         // ================================ judge ================================
         StepOut o{0.0f, 0, 0, 0, 0, 0, false};
         const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
         lds_barrier();
         for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1, q = p ^ 1;
+            const int p = i & 1;
             lds_barrier();                                   // A
             lds_barrier();                                   // B: rows of step i are in buffer p
             er.steps += 1;
@@ -733,33 +761,19 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 tl = tl_violation(w, cx.m, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
             o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false};
             unsigned long long any = 0ull;
-            if (F & TDE_F_REWARD) {
+            if (F & TDE_F_REWARD) {                          // R8 / R11: the flags settle here (reward: the driver)
                 int done = 0;
                 if (a == 0 && valid) {
-                    const float4 pa = sh.a[q][lane], pc = sh.c[q][lane];      // state before the step (:371-375)
-                    const int ti0 = er.target_idx;
-                    RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, pa.x, pa.y, pc.x, pc.y, x, y, rc.x, rc.y,
-                                              off, hit, tl, k, er.target_idx, er.reached, st.info != nullptr);
-                    o.reward = r.reward;
-                    o.terminated = r.terminated;
-                    o.truncated = r.truncated;
-                    if (st.info) {
-                        double *inf = st.info + 4 * (int64_t)e;
-                        inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
-                    }
-                    if (st.info_reached) st.info_reached[e] = er.reached;
-                    done = (r.terminated | r.truncated) ? 1 : 0;
-                    if (er.target_idx != ti0 && !done) load_ego_target(cold, er, cx);
+                    o.terminated = (uint8_t)(cold.terminated_at_infraction && (off || hit || tl));
+                    o.truncated = (uint8_t)(k >= cold.max_steps);
+                    done = (o.terminated | o.truncated) ? 1 : 0;
                 }
                 if (F & TDE_F_AUTORESET) any = __ballot(done);
             }
             if (lane == 0) sh.done = any;
-            if (valid && a == 0) {
-                if (ro.reward) ro.reward[(int64_t)i * B + e] = o.reward;
-                if (ro.done)
-                    ro.done[(int64_t)i * B + e] =
-                        (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
-            }
+            if (valid && a == 0 && ro.done)
+                ro.done[(int64_t)i * B + e] =
+                    (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
             if (any && ((any >> base) & 1ull) && valid) {
                 reset_lane<A>(cfg, cold, e, a, ag, er);
                 load_ctx<A>(cfg, cold, a, ag, er, cx);
@@ -773,9 +787,6 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (a == 0) {
             st.scn[e] = er.scn; st.episode[e] = er.episode;
             st.steps[e] = er.steps;
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            st.reward[e] = o.reward;
             st.terminated[e] = o.terminated;
             st.truncated[e] = o.truncated;
             if (st.tl_violation) st.tl_violation[e] = o.tl;
