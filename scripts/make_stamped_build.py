@@ -1,0 +1,120 @@
+"""Builds ab/libS.so: the library with s_memtime stamps / counters patched into ONE kernel, plus the debug entry point
+`tde_debug_stamps` that scripts/phase_stamps.py, render_stamps.py and trip_counts.py read.  The instrumentation is
+applied to a copy of csrc/tde_kernels.hip by text substitution (asserted), so the shipped kernels stay clean.
+
+    python scripts/make_stamped_build.py duo|render|trips      # then  TDE_HIP_LIB=$PWD/ab/libS.so python scripts/...
+
+duo    : driver / judge phases of env_rollout_duo_kernel        -> scripts/phase_stamps.py
+render : passes of render_layers_kernel                         -> scripts/render_stamps.py
+trips  : exact-loop trip counts of the controller / collision   -> scripts/trip_counts.py
+The stamps cost 10-40 % themselves: read the shares, not the totals.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "torchdriveenv_amd", "csrc", "tde_kernels.hip")
+sys.path.insert(0, ROOT)
+from torchdriveenv_amd.build import FLAGS  # noqa: E402
+
+PRELUDE = '''struct Stamps {
+    unsigned long long last, acc[12];
+    __device__ void start() { for (int i = 0; i < 12; ++i) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    __device__ void mark(int k) { unsigned long long n = __builtin_amdgcn_s_memtime(); acc[k] += n - last; last = n; }
+};
+__device__ unsigned long long g_stamps[24];
+'''
+EPILOGUE = '''
+extern "C" __attribute__((visibility("default"))) int tde_debug_stamps(unsigned long long *out, int clear)
+{
+    unsigned long long z[24] = {0};
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tde::g_stamps), sizeof(z));
+    if (e == hipSuccess && clear) e = hipMemcpyToSymbol(HIP_SYMBOL(tde::g_stamps), z, sizeof(z));
+    return (int)e;
+}
+'''
+ANCHOR = "template <int A> struct MaskOf { using type = uint32_t; };"
+
+
+def sub(text, old, new, count=1):
+    assert old in text, f"anchor not found (the kernel source moved on):\n{old[:120]}"
+    return text.replace(old, new, count)
+
+
+def kernel_span(s, name):
+    a = s.index(f"void {name}(")
+    b = s.index("\n}\n", a) + 3
+    return a, b
+
+
+def patch_duo(s):
+    a, b = kernel_span(s, "env_rollout_duo_kernel")
+    k = s[a:b]
+    k = sub(k, "        RewardOut rw{};\n        for (int i = 0; i < ro.K; ++i) {",
+            "        RewardOut rw{};\n        Stamps stp; stp.start();\n        for (int i = 0; i < ro.K; ++i) {")
+    k = sub(k, "                sincos_f32(npsi, ns, nc);\n", "                sincos_f32(npsi, ns, nc);\n                stp.mark(0);\n")
+    k = sub(k, "                if (pass) break;\n                lds_barrier();                               // A: done(i-1) is published\n",
+            "                stp.mark(1);\n                if (pass) break;\n                lds_barrier();                               // A: done(i-1) is published\n                stp.mark(2);\n")
+    k = sub(k, "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n",
+            "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            stp.mark(3);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            stp.mark(4);\n")
+    k = sub(k, "            act = act_next;\n        }\n", "            act = act_next;\n        }\n        if (lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[i], stp.acc[i]);\n")
+    k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            lds_barrier();                                   // A\n            lds_barrier();                                   // B: rows of step i are in buffer p\n",
+            "        lds_barrier();\n        Stamps stp; stp.start();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            lds_barrier();                                   // A\n            stp.mark(0);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            stp.mark(1);\n")
+    k = sub(k, "            bool off = false;\n            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2);\n",
+            "            stp.mark(2);\n            bool off = false;\n            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2);\n            stp.mark(3);\n")
+    k = sub(k, "            if (lane == 0) sh.done = any;\n", "            stp.mark(4);\n            if (lane == 0) sh.done = any;\n")
+    k = sub(k, "                o.respawned = true;\n            }\n        }\n",
+            "                o.respawned = true;\n            }\n            stp.mark(5);\n        }\n        if (lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[12 + i], stp.acc[i]);\n")
+    return s[:a] + k + s[b:]
+
+
+def patch_render(s):
+    a, b = kernel_span(s, "render_layers_kernel")
+    k = s[a:b]
+
+    def mark(n):
+        return ("    { unsigned long long tn = __builtin_amdgcn_s_memtime(); if (tid == 0) g_loc[%d] += tn - tlast; "
+                "tlast = tn; }\n" % n)
+    k = sub(k, "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }\n",
+            "    unsigned long long tlast = __builtin_amdgcn_s_memtime();\n    unsigned long long g_loc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};\n"
+            "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }\n")
+    k = sub(k, "    __syncthreads();\n    const bool crowded =", mark(1) + "    __syncthreads();\n    const bool crowded =")
+    k = sub(k, "        // ---- pass 2b:", mark(2) + "        // ---- pass 2b:")
+    k = sub(k, "        // ---- pass 3: objects over the base", mark(3) + "        // ---- pass 3: objects over the base")
+    k = sub(k, "    __syncthreads();\n\n    // ---- pass 4:", mark(4) + "    __syncthreads();\n\n    // ---- pass 4:")
+    k = k[:k.rindex("}")] + mark(5) + ("    if (tid == 0 && (blockIdx.x & 15) == 0) { for (int i = 0; i < 7; ++i) atomicAdd(&g_stamps[i], g_loc[i]); "
+                                       "atomicAdd(&g_stamps[10], 1ull); atomicAdd(&g_stamps[11], (unsigned long long)s_nwork); "
+                                       "atomicAdd(&g_stamps[12], (unsigned long long)s_nmixed); }\n}\n")
+    return s[:a] + k + s[b:]
+
+
+def patch_trips(s):
+    s = sub(s, "    float gap = 1e30f;\n    while (__ballot(cand != 0)) {\n",
+            "    float gap = 1e30f;\n    if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[1], 1ull);\n"
+            "    atomicAdd(&g_stamps[3], (unsigned long long)__popcll((unsigned long long)cand));\n"
+            "    while (__ballot(cand != 0)) {\n        if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[0], 1ull);\n")
+    s = sub(s, "    bool hit = false;\n    while (__ballot(cand != 0)) {\n",
+            "    bool hit = false;\n    if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[5], 1ull);\n"
+            "    atomicAdd(&g_stamps[6], (unsigned long long)__popcll((unsigned long long)cand));\n"
+            "    while (__ballot(cand != 0)) {\n        if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[4], 1ull);\n")
+    return s
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "duo"
+    s = open(SRC).read()
+    s = sub(s, ANCHOR, PRELUDE + ANCHOR)
+    s = {"duo": patch_duo, "render": patch_render, "trips": patch_trips}[mode](s) + EPILOGUE
+    os.makedirs(os.path.join(ROOT, "ab"), exist_ok=True)
+    tmp = os.path.join(ROOT, "ab", f"tde_kernels_{mode}_stamped.hip")
+    open(tmp, "w").write(s)
+    out = os.path.join(ROOT, "ab", "libS.so")
+    cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "torchdriveenv_amd", "csrc"),
+                                              "-I" + os.path.join(ROOT, "include"), "-o", out, tmp]
+    subprocess.run(cmd, check=True)
+    print(out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,5 @@
-"""Per-phase wavefront time of the persistent rollout kernel from s_memtime stamps (debug build of the library with
-`tde_debug_stamps`).  usage: TDE_HIP_LIB=ab/libS.so python scripts/phase_stamps.py [envs]"""
+"""Per-phase wavefront time of the two-role rollout kernel from s_memtime stamps.
+usage: python scripts/make_stamped_build.py duo && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/phase_stamps.py [envs]"""
 import ctypes as C
 import os
 import sys
@@ -39,12 +39,10 @@ e1.record()
 torch.cuda.synchronize()
 lib.tde_debug_stamps(out, 0)
 waves = B * A // 64
-drive = ["prologue + controller prefilter", "controller exact loop", "controller rest", "bicycle", "route + sincos",
-         "wait A (done of prev step)", "re-spawn fixup + commit rows", "wait B", "route target + loop"]
-if os.environ.get("TDE_STAMPS_V1"):
-    drive = ["controller (spec)", "bicycle+sincos (spec)", "wait A (done of prev step)",
-             "re-spawn fixup + commit rows", "wait B"]
-judge = ["wait A", "wait B (rows of this step)", "read rows + collision", "offroad resolve", "tl + reward", "publish + reset"]
+drive = ["controller + bicycle + sincos (spec)", "reward arithmetic (ego lane)", "wait A (done of prev step)",
+         "re-spawn fixup + commit rows", "wait B"]
+judge = ["wait A", "wait B (rows of this step)", "read rows + collision", "offroad resolve", "stop lines + flags",
+         "publish + reset"]
 us = e0.elapsed_time(e1) * 1e3 / (reps * K)
 n = waves * reps * K
 print(f"{B} envs: {us:.2f} us/step (stamped build)")

@@ -1,4 +1,5 @@
-"""s_memtime stamps per pass of the rasteriser (debug build with tde_debug_stamps)."""
+"""s_memtime stamps per pass of the rasteriser.
+usage: python scripts/make_stamped_build.py render && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/render_stamps.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,8 +21,7 @@ out = (C.c_ulonglong * 24)(); lib.tde_debug_stamps(out, 1)
 for _ in range(5): img = ops.render_ego(cfg, dw, st, out=img)
 torch.cuda.synchronize(); lib.tde_debug_stamps(out, 0)
 n = out[10]
-names = ["cull + shift", "blocks", "queued pixels (cell word)", "mixed pixels (triangles)", "objects", "stream out",
-         "prologue (scn -> map, ego pose)"]
+names = ["(unused)", "cull + blocks", "queued pixels (cell word)", "mixed pixels (triangles)", "objects", "stream out"]
 print("views sampled", n, "queued px/view", out[11] / n, "mixed px/view", out[12] / n)
 for i, nm in enumerate(names): print(f"  {nm:28s} {out[i] / n:9.0f} ticks")
-print("  total", sum(out[:7]) / n)
+print("  total", sum(out[:6]) / n)

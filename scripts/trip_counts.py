@@ -16,5 +16,6 @@ ops.env_rollout(cfg, dw, st, actions, reward, done); torch.cuda.synchronize()
 out = (C.c_ulonglong * 24)(); lib.tde_debug_stamps(out, 1)
 ops.env_rollout(cfg, dw, st, actions, reward, done); torch.cuda.synchronize()
 lib.tde_debug_stamps(out, 0)
-print("npc: sweeps", out[1], "exact trips per sweep", out[0] / out[1], "lanes with cand per sweep", out[2] / out[1], "cand per lane-sweep", out[3] / (64 * out[1]))
+# usage: python scripts/make_stamped_build.py trips && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/trip_counts.py
+print("npc: sweeps", out[1], "exact trips per sweep", out[0] / out[1], "cand per lane-sweep", out[3] / (64 * out[1]))
 print("coll: sweeps", out[5], "exact trips per sweep", out[4] / out[5], "cand per lane-sweep", out[6] / (64 * out[5]))
