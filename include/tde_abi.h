@@ -175,6 +175,10 @@ typedef struct tde_state {
     double *info;               /* out [B][4] psi_smoothness, speed_smoothness, psi_reward, dist_reward (R12; Python floats
                                    in the reference, hence float64); may be NULL */
     int32_t *info_reached;      /* out [B] reached_waypoint_num as reported by get_info (gym_env.py:425,431); may be NULL */
+    uint8_t *done_bits;         /* out [B], tde_env_step only, may be NULL: the ego's flags of THIS step before any in-place
+                                   re-spawn clears them (what get_info reports at a terminal step, gym_env.py:426-429):
+                                   bit0 terminated, bit1 truncated, bit2 offroad, bit3 collided, bit4 red-light violation
+                                   (the layout of tde_rollout.done) */
     int32_t B, A;
 } tde_state;
 

@@ -628,6 +628,9 @@ TDE_EXPORT int tde_oracle_env_step(const tde_config *cfg, const tde_world *w, td
         st->reward[e] = o.reward;
         st->terminated[e] = o.terminated;
         st->truncated[e] = o.truncated;
+        if (st->done_bits)                                  /* the ego's flags before a re-spawn clears them */
+            st->done_bits[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (st->offroad[(int64_t)e * st->A] << 2) |
+                                         (st->collided[(int64_t)e * st->A] << 3) | (o.tl << 4));
         if ((cfg->flags & TDE_F_AUTORESET) && (o.terminated || o.truncated)) tde_reset_env(cfg, w, st, e);
     }
     return 0;

@@ -158,3 +158,23 @@ def test_state_obs_operator_matches_numpy(small_world):
     assert set(info.keys()) >= {"offroad", "collision", "traffic_light_violation", "is_success", "psi_smoothness"}
     assert info["offroad"].shape == (96,) and info["offroad"].dtype == torch.float32
     assert "psi_reward" in info and info.get("nope") is None
+
+
+def test_terminal_info_survives_in_place_respawn(small_world):
+    """get_info at a terminal step reports the infraction that ended the episode (ref gym_env.py:426-429) even though
+    the env was re-spawned inside the same kernel (tde_state.done_bits)"""
+    cfg = EnvConfig(seed=5)
+    B = 256
+    env = BatchedWaypointEnv(cfg, small_world, num_envs=B, device="cuda:0", obs_mode="state", with_info=True)
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    seen = 0
+    for t in range(120):
+        a = torch.stack([torch.rand(B, generator=g) * 2 - 1, torch.rand(B, generator=g) * 0.6 - 0.3], -1)
+        obs, rew, term, trunc, info = env.step(a)
+        if term.any():
+            infr = (info["offroad"] > 0) | (info["collision"] > 0) | (info["traffic_light_violation"] > 0)
+            assert torch.equal(infr, term), t                       # terminated <=> an infraction is reported
+            assert (env.state["steps"][term] == 0).all()            # ... although those envs already re-spawned
+            seen += int(term.sum())
+    assert seen > 10

@@ -1420,10 +1420,10 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     const unsigned nb = blocks_for((int64_t)st->B * st->A);
     if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) {
         TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
-                                  *cfg, *world, *st, st->action, (float *)nullptr, (uint8_t *)nullptr));
+                                  *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits));
     } else {
         TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
-                                  *cfg, *world, *st, st->action, (float *)nullptr, (uint8_t *)nullptr));
+                                  *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits));
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_step", e);

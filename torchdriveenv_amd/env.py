@@ -148,10 +148,11 @@ class _LazyInfo(dict):
 
     def _make(self, k):
         st = self._st
+        bits = st["done_bits"]                # the ego's flags of this step, kept when the env re-spawned in place
         if k == "offroad":
-            return st["offroad"][self._ego].float()
+            return ((bits >> 2) & 1).float() if bits is not None else st["offroad"][self._ego].float()
         if k == "collision":
-            return st["collided"][self._ego].float()
+            return ((bits >> 3) & 1).float() if bits is not None else st["collided"][self._ego].float()
         if k == "traffic_light_violation":
             return st["tl_violation"].float()
         if k == "is_success":

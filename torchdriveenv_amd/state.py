@@ -29,6 +29,7 @@ class EnvState:
         if not with_info:
             self.arrays["info"] = None
             self.arrays["info_reached"] = None
+            self.arrays["done_bits"] = None
         self.struct = _abi.fill_state_struct(self.arrays, B, A)
 
     def __getitem__(self, k):
