@@ -179,6 +179,10 @@ typedef struct tde_state {
                                    re-spawn clears them (what get_info reports at a terminal step, gym_env.py:426-429):
                                    bit0 terminated, bit1 truncated, bit2 offroad, bit3 collided, bit4 red-light violation
                                    (the layout of tde_rollout.done) */
+    float *obs;                 /* out [B][8], tde_env_step only, may be NULL: the compact ego observation of tde_state_obs
+                                   (x, y, psi, v, target offset forward / left, target flag, steps) of the state AFTER
+                                   the step and any re-spawn - the same values as a tde_state_obs call would give, without
+                                   the second launch */
     int32_t B, A;
 } tde_state;
 

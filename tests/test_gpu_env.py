@@ -178,3 +178,23 @@ def test_terminal_info_survives_in_place_respawn(small_world):
             assert (env.state["steps"][term] == 0).all()            # ... although those envs already re-spawned
             seen += int(term.sum())
     assert seen > 10
+
+
+@pytest.mark.parametrize("flags", [_abi.F_ALL, _abi.F_ALL & ~_abi.F_AUTORESET, _abi.F_NPC | _abi.F_OFFROAD])
+def test_step_writes_the_same_observation_as_state_obs(small_world, flags):
+    """tde_state.obs: the compact observation written by tde_env_step itself equals a tde_state_obs call on the state
+    after the step, bit for bit - through re-spawns, finished episodes without re-spawn, and with the reward path off"""
+    from torchdriveenv_amd import ops
+    from torchdriveenv_amd.state import EnvState
+
+    cfg = _abi.default_config(seed=9, flags=flags, max_steps=40)
+    dw = small_world.to_device("cuda:0")
+    B = 192
+    st = EnvState(B, small_world.A, device="cuda:0", with_obs=True)
+    ops.env_reset(cfg, dw, st)
+    g = torch.Generator().manual_seed(2)
+    for t in range(90):
+        a = torch.stack([torch.rand(B, generator=g) * 2 - 1, torch.rand(B, generator=g) * 0.6 - 0.3], -1).cuda()
+        ops.env_step(cfg, dw, st, action=a)
+        want = ops.state_obs(dw, st)
+        assert torch.equal(st["obs"], want), (t, int((st["obs"] != want).any(1).sum()))

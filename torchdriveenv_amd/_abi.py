@@ -88,7 +88,7 @@ STATE_AGENT_I32 = ["route_wp"]
 STATE_AGENT_U8 = ["present", "collided", "offroad"]
 STATE_ENV_I32 = ["scn", "steps", "target_idx", "reached", "episode"]
 STATE_PTRS = (STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8 + STATE_ENV_I32 +
-              ["action", "reward", "terminated", "truncated", "tl_violation", "info", "info_reached", "done_bits"])
+              ["action", "reward", "terminated", "truncated", "tl_violation", "info", "info_reached", "done_bits", "obs"])
 
 
 class TdeState(C.Structure):
@@ -160,7 +160,7 @@ STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n
                 **{n: np.uint8 for n in STATE_AGENT_U8}, **{n: np.int32 for n in STATE_ENV_I32},
                 "action": np.float32, "reward": np.float32, "terminated": np.uint8, "truncated": np.uint8,
                 "tl_violation": np.uint8,
-                "info": np.float64, "info_reached": np.int32, "done_bits": np.uint8}
+                "info": np.float64, "info_reached": np.int32, "done_bits": np.uint8, "obs": np.float32}
 
 
 def state_shapes(B, A):
@@ -168,7 +168,7 @@ def state_shapes(B, A):
     sh.update({n: (B,) for n in STATE_ENV_I32})
     sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "tl_violation": (B,),
                "info": (B, 4),
-               "info_reached": (B,), "done_bits": (B,)})
+               "info_reached": (B,), "done_bits": (B,), "obs": (B, 8)})
     return sh
 
 

@@ -517,6 +517,29 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
         if (reward_k) reward_k[e] = o.reward;
         if (done_k)
             done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
+        if (st.obs) {
+            // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it.  The cached
+            // ego target is current unless the reward path is off or the episode just ended without a re-spawn.
+            const bool ended = (o.terminated | o.truncated) && !o.respawned;
+            bool has;
+            double tx, ty;
+            if ((cfg.flags & TDE_F_REWARD) && !ended) {
+                has = er.target_idx < cx.n_wp; tx = cx.wtx; ty = cx.wty;
+            } else {
+                has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
+                const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
+                tx = t2.x; ty = t2.y;
+            }
+            float fwd = 0.0f, lat = 0.0f;
+            if (has) {
+                const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
+                fwd = dx * c0 + dy * s0;
+                lat = dy * c0 - dx * s0;
+            }
+            float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
+            ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
+            ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
+        }
     }
 }
 

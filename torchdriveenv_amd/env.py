@@ -233,7 +233,9 @@ class BatchedWaypointEnv:
             flags |= _abi.F_TRAFFIC_LIGHTS
         self.tde_cfg = to_tde_config(cfg, seed, flags)
         self.dworld = self.world.to_device(self.torch_device)
-        self.state = EnvState(self.num_envs, self.A, device=self.torch_device, with_info=with_info)
+        # obs_mode "state": tde_env_step writes the compact observation itself (no second launch per step)
+        self.state = EnvState(self.num_envs, self.A, device=self.torch_device, with_info=with_info,
+                              with_obs=(obs_mode == "state"))
         self.obs_mode, self.frame_stack = obs_mode, max(1, int(frame_stack))
         r = cfg.simulator.renderer
         self._res, self._fov = int(r.res), float(r.fov)
@@ -263,7 +265,8 @@ class BatchedWaypointEnv:
         ops.env_step(self.tde_cfg, self.dworld, self.state, action=a)
         st = self.state
         # uint8 0/1 flags seen as bool without a copy; info entries are only computed when they are read
-        return (self.get_obs(), st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool),
+        obs = st["obs"] if self.obs_mode == "state" else self.get_obs()
+        return (obs, st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool),
                 self.get_info())
 
     def rollout(self, actions):
@@ -274,7 +277,7 @@ class BatchedWaypointEnv:
     def get_obs(self):
         if self.obs_mode == "state":
             # x, y, psi, v, target offset (forward, left) in the ego frame, target-exists flag, environment_steps
-            return ops.state_obs(self.dworld, self.state)
+            return ops.state_obs(self.dworld, self.state, self.state["obs"])
         if self.frame_stack > 1:
             if self._stack is None:
                 self._stack = ops.FrameStack(self.num_envs, self.frame_stack, self._res, self._res, self.torch_device)

@@ -12,7 +12,7 @@ from . import _abi
 class EnvState:
     """`arrays[name]` are numpy arrays (host; used with the CPU oracle in tests) or torch tensors (device)."""
 
-    def __init__(self, B, A, device=None, with_info=True):
+    def __init__(self, B, A, device=None, with_info=True, with_obs=False):
         assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
         self.B, self.A, self.device = int(B), int(A), device
         shapes = _abi.state_shapes(B, A)
@@ -30,6 +30,8 @@ class EnvState:
             self.arrays["info"] = None
             self.arrays["info_reached"] = None
             self.arrays["done_bits"] = None
+        if not with_obs:
+            self.arrays["obs"] = None
         self.struct = _abi.fill_state_struct(self.arrays, B, A)
 
     def __getitem__(self, k):
