@@ -184,8 +184,8 @@ def main():
     if rank == 0:
         n = world_size
         env_steps = B * n * args.steps
-        # dominant kernel: rollout mode = tde::env_rollout_duo_kernel<16> (drive + judge wavefront per 64 agent slots;
-        # TDE_ROLLOUT=solo selects the one-wavefront env_rollout_kernel), ONE launch per CH timesteps;
+        # dominant kernel: rollout mode = tde::env_rollout_trio_kernel<16> (drive + two judge wavefronts per 64 agent
+        # slots; TDE_ROLLOUT=duo|solo select the two- / one-wavefront forms), ONE launch per CH timesteps;
         # step mode = tde::env_step_kernel<16>, one launch per timestep
         steps_per_launch = CH if args.mode == "rollout" else 1
         launches = -(-args.steps // steps_per_launch)
@@ -213,8 +213,10 @@ def main():
                        "timing_backend": (args.backend if n > 1 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": (f"tde::env_rollout_kernel<{A}, false>" if os.environ.get("TDE_ROLLOUT") == "solo"
-                                    else f"tde::env_rollout_duo_kernel<{A}, false>") if args.mode == "rollout"
+                         "kernel": {"solo": f"tde::env_rollout_kernel<{A}, false>",
+                                    "duo": f"tde::env_rollout_duo_kernel<{A}, false>"}.get(
+                             os.environ.get("TDE_ROLLOUT", ""), f"tde::env_rollout_trio_kernel<{A}, false>")
+                         if args.mode == "rollout"
                          else f"tde::env_step_kernel<{A}, false>",
                          "kernel_avg_us": kern_us, "launches": launches, "steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_step": dev_ms * 1e3 / args.steps},

@@ -5,6 +5,9 @@ python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 python bench.py --mode step --steps 4000 --warmup 500 --no-cpu-baseline > $O/bench_stepmode.json 2>> $O/bench.err
 TDE_ROLLOUT=solo python bench.py --no-cpu-baseline > $O/bench_solo.json 2>> $O/bench.err
+TDE_ROLLOUT=duo python bench.py --no-cpu-baseline > $O/bench_duo.json 2>> $O/bench.err
+python scripts/rollout_matrix.py > $O/rollout_matrix_default.txt 2>/dev/null
+TDE_ROLLOUT=duo python scripts/rollout_matrix.py > $O/rollout_matrix_duo.txt 2>/dev/null
 python scripts/ablate.py > $O/ablation.txt 2>/dev/null
 python scripts/scale_envs.py > $O/scale_envs.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 bench.py --steps 10000 --warmup 1000 --no-cpu-baseline > $O/stats.log 2>&1

@@ -624,6 +624,7 @@ struct DuoShared {
     float4 a[2][kWave], b[2][kWave];
     float4 c[2][kWave];                  // (psi, v, live, -): what the judge's ego lane and liveness test need
     unsigned long long done;             // ballot of the ego lanes whose env finished at the last judged step
+    unsigned long long hit_mask, off_mask, tl_mask;   // three-role kernel: per-slot ballots of the judges, previous step
 };
 
 // LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
@@ -652,16 +653,20 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
     const int64_t gs = valid ? g : 0;
     const int es = valid ? e : 0;
     const int base = lane - a;
-    Agent ag;
-    load_agent(st, gs, ag);
-    if (!valid) ag.present = false;
-    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
     __syncthreads();                                         // cold is filled
-    Ctx cx;
+    // every role loads its own copy of the per-lane state inside its branch: with nothing live across the role switch
+    // the register allocator treats the roles separately (the shared prologue cost tens of scratch spills)
+#define TDE_ROLE_PROLOGUE                                                                                 \
+    Agent ag;                                                                                             \
+    load_agent(st, gs, ag);                                                                               \
+    if (!valid) ag.present = false;                                                                       \
+    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};              \
+    Ctx cx;                                                                                               \
     load_ctx<A>(cfg, cold, a, ag, er, cx);
 
     if (role == 0) {
         // ================================ drive ================================
+        TDE_ROLE_PROLOGUE
         __builtin_amdgcn_s_setprio(3);           // the driver is the serial chain of the simulation; the judge fills in
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
@@ -764,6 +769,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         }
     } else {
         // ================================ judge ================================
+        TDE_ROLE_PROLOGUE
         StepOut o{0.0f, 0, 0, 0, 0, 0, false};
         const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
         lds_barrier();
@@ -818,6 +824,245 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         }
     }
 }
+
+#undef TDE_ROLE_PROLOGUE
+
+// ------------------------------------------------------------------------------------------------------------------
+// Three roles per group: the same loop with the judge split in two wavefronts, six wavefronts per SIMD (80 VGPRs each):
+//   drive   : as above, without the reward arithmetic
+//   judge C : collision of all slots; the ego lane's reward arithmetic, waypoint advance, outputs
+//   judge O : offroad of all slots, stop-line violation of the ego
+// The judges publish per-slot ballots (hit / off / tl); at barrier A every wavefront that needs done(i-1) forms it
+// from those masks by itself (R8: terminated = infraction of the ego; R11: truncated = step count), so the judges never
+// wait for each other.  What depends on the other judge's mask (the done byte, terminated, C's own re-spawn
+// bookkeeping) is settled by C after the next barrier A.
+// ------------------------------------------------------------------------------------------------------------------
+template <int A, bool LIGHTS>
+__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_rollout_trio_kernel(tde_config cfg, tde_world w, tde_state st,
+                                                                    tde_rollout ro)
+{
+    __shared__ DuoShared sh;
+    __shared__ Cold cold;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = drive, 1 = judge
+    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull; sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull; }
+    const uint32_t F = cfg.flags;
+    const int64_t g = (int64_t)blockIdx.x * kWave + lane;
+    const int e = (int)(g / A), a = (int)(g % A);
+    const int B = st.B;
+    const bool valid = e < B;
+    const int64_t gs = valid ? g : 0;
+    const int es = valid ? e : 0;
+    const int base = lane - a;
+    __syncthreads();                                         // cold is filled
+    // every role loads its own copy of the per-lane state inside its branch: nothing is live across the role switch
+#define TDE_ROLE_PROLOGUE                                                                                 \
+    Agent ag;                                                                                             \
+    load_agent(st, gs, ag);                                                                               \
+    if (!valid) ag.present = false;                                                                       \
+    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};              \
+    Ctx cx;                                                                                               \
+    load_ctx<A>(cfg, cold, a, ag, er, cx);
+
+    // done(i-1) of every ego lane from the judges' masks of that step (k = its environment_steps): R8 / R11
+    auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
+        const unsigned long long ego = __ballot(a == 0 && valid);
+        const unsigned long long infr = sh.off_mask | sh.hit_mask | sh.tl_mask;
+        term_m = ((F & TDE_F_REWARD) && cold.terminated_at_infraction) ? (infr & ego) : 0ull;
+        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= cold.max_steps) : 0ull;
+        return ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? (term_m | trunc_m) : 0ull;
+    };
+    if (role == 0) {
+        // ================================ drive ================================
+        TDE_ROLE_PROLOGUE
+        __builtin_amdgcn_s_setprio(3);           // the driver is the serial chain of the simulation; the judge fills in
+        float c0, s0;
+        sincos_f32(ag.psi, s0, c0);
+        write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
+        lds_barrier();                                       // rows of the launch state are in buffer 1
+        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
+        float2 act = acts[es];
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1, q = p ^ 1;
+            const int kn = (i + 1 < ro.K) ? i + 1 : i;
+            const float2 act_next = acts[(int64_t)kn * B + es];
+            float nx, ny, npsi, nv, nc, ns;
+            int nwp, k;
+            bool switched, live;
+            for (int pass = 0;; ++pass) {
+                // one step from the rows in buffer q, nothing committed yet (step_lane up to the tile write)
+                k = er.steps + 1;                                                            // :116
+                live = valid && ag.present;
+                const bool npc = (F & TDE_F_NPC) && a > 0 && live;
+                const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
+                float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
+                const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                float acc = 0.0f, beta = 0.0f;
+                if (a == 0) { acc = act.x; beta = act.y; }
+                if (F & TDE_F_NPC) {
+                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
+                    const float red_gap =
+                        (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
+                    float na, nb;
+                    npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
+                                  cx.g_far, red_gap, na, nb);
+                    if (npc) { acc = na; beta = nb; }
+                }
+                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
+                if (live) {
+                    bicycle(nx, ny, npsi, nv, ag.lr, acc, beta, cfg.dt);                      // :117
+                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
+                }
+                switched = false;
+                nwp = ag.route_wp;
+                if (has_target) {
+                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;
+                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
+                }
+                sincos_f32(npsi, ns, nc);
+                if (pass) break;
+                lds_barrier();                               // A: the judges' masks of step i-1 are published
+                unsigned long long term_m, trunc_m;
+                const unsigned long long dn = i > 0 ? done_of(er.steps, term_m, trunc_m) : 0ull;
+                if (!dn) break;
+                // an env of this wavefront finished at step i-1: re-spawn its lanes (as step_lane does in place),
+                // put their rows into buffer q and recompute the step
+                if (((dn >> base) & 1ull) && valid) {
+                    reset_lane<A>(cfg, cold, e, a, ag, er);
+                    load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    sincos_f32(ag.psi, s0, c0);
+                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);
+                }
+            }
+            ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
+            c0 = nc; s0 = ns;
+            er.steps = k;
+            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            if (switched) load_route_target(cold, ag, cx);
+            act = act_next;
+        }
+        lds_barrier();                                       // A of the step after the last: masks of step K-1
+        {
+            unsigned long long term_m, trunc_m;
+            const unsigned long long dn = done_of(er.steps, term_m, trunc_m);
+            if (lane == 0) sh.done = dn;
+            lds_barrier();                                   // the judges read it for their final flag stores
+            if (((dn >> base) & 1ull) && valid) reset_lane<A>(cfg, cold, e, a, ag, er);
+        }
+        if (!valid) return;
+        store_agent_dynamic(st, g, ag);
+        store_agent_static(st, g, ag);
+    } else if (role == 1) {
+        // ===================== judge C: collision, reward, outputs, waypoint advance =====================
+        TDE_ROLE_PROLOGUE
+        bool hit = false;
+        RewardOut rw{};
+        uint8_t last_term = 0, last_trunc = 0;
+        // what needs the other judge's masks (terminated, the done byte, this wavefront's own re-spawn bookkeeping) is
+        // settled after the next barrier A
+        auto settle = [&](int i) {           // i = the step whose masks are complete now
+            unsigned long long term_m, trunc_m;
+            const unsigned long long dn = done_of(er.steps, term_m, trunc_m);
+            if (a == 0 && valid) {
+                last_term = (uint8_t)((term_m >> lane) & 1ull); last_trunc = (uint8_t)((trunc_m >> lane) & 1ull);
+                if (ro.done)
+                    ro.done[(int64_t)i * B + e] = (uint8_t)(
+                        last_term | (last_trunc << 1) | (((sh.off_mask >> lane) & 1ull) << 2) |
+                        (((sh.hit_mask >> lane) & 1ull) << 3) | (((sh.tl_mask >> lane) & 1ull) << 4));
+            }
+            return dn;
+        };
+        lds_barrier();
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1, q = p ^ 1;
+            lds_barrier();                                   // A: masks of step i-1 are complete
+            if (i > 0) {
+                const unsigned long long dn = settle(i - 1);
+                if (dn && ((dn >> base) & 1ull) && valid) {
+                    reset_lane<A>(cfg, cold, e, a, ag, er);
+                    load_ctx<A>(cfg, cold, a, ag, er, cx);
+                }
+            }
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            er.steps += 1;
+            const int k = er.steps;
+            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
+            hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) sh.hit_mask = m;
+            if (a == 0 && valid) {
+                if (F & TDE_F_REWARD) {
+                    const float4 pa = sh.a[q][lane], pc = sh.c[q][lane];      // state before the step (:371-375)
+                    const int ti0 = er.target_idx;
+                    // the infraction flags arrive later: this call settles everything but `terminated`
+                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, pa.x, pa.y, pc.x, pc.y, ra.x, ra.y, rc.x, rc.y, false,
+                                     false, false, k, er.target_idx, er.reached, st.info != nullptr);
+                    if (st.info) {
+                        double *inf = st.info + 4 * (int64_t)e;
+                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
+                    }
+                    if (st.info_reached) st.info_reached[e] = er.reached;
+                    if (er.target_idx != ti0) load_ego_target(cold, er, cx);
+                }
+                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;
+            }
+        }
+        lds_barrier();                                       // A'
+        settle(ro.K - 1);
+        lds_barrier();                                       // done(K-1) is in sh.done
+        const bool respawned = ((sh.done >> base) & 1ull) != 0;
+        if (respawned && valid) reset_lane<A>(cfg, cold, e, a, ag, er);
+        if (!valid) return;
+        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);
+        if (a == 0) {
+            st.scn[e] = er.scn; st.episode[e] = er.episode;
+            st.steps[e] = er.steps;
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = rw.reward;
+            st.terminated[e] = last_term;
+            st.truncated[e] = last_trunc;
+        }
+    } else {
+        // ===================== judge O: offroad, stop lines =====================
+        TDE_ROLE_PROLOGUE
+        const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
+        bool off = false, tl = false;
+        lds_barrier();
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1;
+            lds_barrier();                                   // A: masks of step i-1 are complete
+            if (i > 0) {
+                unsigned long long term_m, trunc_m;
+                const unsigned long long dn = done_of(er.steps, term_m, trunc_m);
+                if (dn && ((dn >> base) & 1ull) && valid) {
+                    reset_lane<A>(cfg, cold, e, a, ag, er);
+                    load_ctx<A>(cfg, cold, a, ag, er, cx);
+                }
+            }
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            er.steps += 1;
+            const int k = er.steps;
+            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
+            const bool live = rc.z != 0.0f;
+            off = false;
+            if (F & TDE_F_OFFROAD) off = box_offroad(w, cx.m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
+            tl = false;
+            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
+                tl = tl_violation(w, cx.m, red_mask(w, cx.m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+            const unsigned long long om = __ballot(off), tm = __ballot(tl);
+            if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
+        }
+        lds_barrier();                                       // A'
+        lds_barrier();                                       // done(K-1) is in sh.done
+        if (!valid) return;
+        st.offroad[g] = ((sh.done >> base) & 1ull) ? 0 : (off ? 1 : 0);
+        if (a == 0 && st.tl_violation) st.tl_violation[e] = tl ? 1 : 0;
+    }
+}
+#undef TDE_ROLE_PROLOGUE
 
 template <int A>
 __global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_world w, tde_state st,
@@ -1466,7 +1711,26 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (st->B <= 0 || ro->K <= 0) return 0;
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-    static const bool solo = [] { const char *v = getenv("TDE_ROLLOUT"); return v && !strcmp(v, "solo"); }();
+    // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (TDE_ROLLOUT=solo|duo|trio forces
+    // one).  Measured same-box (scripts/rollout_matrix.py): three roles win at 16 agents per env without traffic lights
+    // (the headline configuration, -5 %); two roles everywhere else (the 80-VGPR cap of six wavefronts per SIMD costs
+    // more than the third wavefront gains at other group shapes, and with the stop-line code).
+    static const int forced = [] {
+        const char *v = getenv("TDE_ROLLOUT");
+        return !v ? 0 : !strcmp(v, "solo") ? 1 : !strcmp(v, "duo") ? 2 : !strcmp(v, "trio") ? 3 : 0;
+    }();
+    const bool lights0 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    const int team = forced ? forced : (st->A == 16 && !lights0) ? 3 : 2;
+    const bool solo = team == 1;
+    if (team == 3 && st->A == 16) {
+        if (lights0) {
+            tde::env_rollout_trio_kernel<16, true><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
+        } else {
+            tde::env_rollout_trio_kernel<16, false><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
+        }
+        hipError_t e3 = hipGetLastError();
+        return e3 == hipSuccess ? 0 : fail("tde_env_rollout", e3);
+    }
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     if (solo) {
         if (lights) {
