@@ -213,3 +213,20 @@ def test_frame_stack_other_sizes_ring_and_in_place(small_world, H, W, n_stack):
             stack.clear(m)
             want[[1, 4]] = 0
             inplace[m] = 0
+
+
+@pytest.mark.parametrize("mode", ["solo", "duo", "trio"])
+def test_every_rollout_kernel_matches_the_oracle(mode):
+    """tde_env_rollout picks a one-, two- or three-wavefront kernel by group shape; TDE_ROLLOUT forces one (read once
+    per process, hence the subprocess).  Each of them must reproduce the oracle bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TDE_ROLLOUT=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "rollout_matches or full_size"], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
