@@ -307,31 +307,71 @@ TDE_DEV uint32_t red_mask(const tde_world &w, const tde_map &m, int k)
     return red;
 }
 
+// The red mask only changes at phase boundaries: the persistent kernels keep it with the window of env steps [lo, hi)
+// it holds for (red is a function of the map and the env step; a re-spawn may change the map: invalidate()).
+struct RedCache {
+    uint32_t red;
+    int lo, hi;
+    TDE_DEV void invalidate() { lo = hi = 0; }
+};
+
+TDE_DEV uint32_t red_mask_cached(const tde_world &w, const tde_map &m, int k, RedCache &rc)
+{
+    if (k >= rc.lo && k < rc.hi) return rc.red;
+    rc.red = 0u; rc.lo = k; rc.hi = k + 1;
+    if (m.cycle_steps <= 0) { rc.lo = 0; rc.hi = 0x7fffffff; return 0u; }
+    const int t = k % m.cycle_steps;
+    int begin = 0;
+    for (int p = 0; p < m.n_phase; ++p) {
+        const tde_light_phase ph = w.phases[m.phase_base + p];
+        if (t < ph.end_step) { rc.red = ph.red_mask; rc.lo = k - (t - begin); rc.hi = k + (ph.end_step - t); break; }
+        begin = ph.end_step;
+    }
+    return rc.red;
+}
+
 // compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
 // is red.  Mirrors tde_tl_violation of the oracle.
-TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, uint32_t red, float x, float y, float c, float s,
-                          float hl, float hw)
+// `line(i, a, b)` fetches stop line i of the map: (x, y, cos, sin) and (hl, hw, light, -)
+template <typename L>
+TDE_DEV bool tl_violation_of(L &&line, int n_stop, uint32_t red, float x, float y, float c, float s, float hl, float hw)
 {
     bool v = false;
     if (red) {
-        for (int i = 0; i < m.n_stop; ++i) {
-            const float4 a = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[0];
-            const float4 b = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i))[1];   // hl, hw, light, pad
+        for (int i = 0; i < n_stop; ++i) {
+            float4 a, b;
+            line(i, a, b);
             if ((red >> __float_as_int(b.z)) & 1u) v = v || obb_overlap(x, y, c, s, hl, hw, a.x, a.y, a.z, a.w, b.x, b.y);
         }
     }
     return v;
 }
 
+struct GlobalLines {
+    const tde_stopline *base;
+    TDE_DEV void operator()(int i, float4 &a, float4 &b) const
+    {
+        a = reinterpret_cast<const float4 *>(base + i)[0];
+        b = reinterpret_cast<const float4 *>(base + i)[1];
+    }
+};
+
+TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, uint32_t red, float x, float y, float c, float s,
+                          float hl, float hw)
+{
+    return tl_violation_of(GlobalLines{w.stoplines + m.stop_base}, m.n_stop, red, x, y, c, s, hl, hw);
+}
+
 // gap to a red stop line ahead in the own lane (same travel direction), treated as a standing leader by the NPC
 // controller.  Mirrors the stop-line loop of the oracle's tde_npc_action.
-TDE_DEV float red_line_gap(const tde_config &cfg, const tde_world &w, const tde_map &m, uint32_t red, const Agent &ag,
-                           float cp, float sp)
+template <typename L>
+TDE_DEV float red_line_gap_of(const tde_config &cfg, L &&line, int n_stop, uint32_t red, const Agent &ag, float cp,
+                              float sp)
 {
     float gap = 1e30f;
-    for (int k = 0; k < m.n_stop; ++k) {
-        const float4 a = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + k))[0];
-        const float4 b = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + k))[1];
+    for (int k = 0; k < n_stop; ++k) {
+        float4 a, b;
+        line(k, a, b);
         if (!((red >> __float_as_int(b.z)) & 1u)) continue;
         const float ex = a.x - ag.x, ey = a.y - ag.y;
         const float fj = ex * cp + ey * sp;
@@ -341,6 +381,12 @@ TDE_DEV float red_line_gap(const tde_config &cfg, const tde_world &w, const tde_
         if (g > 0.0f && fabsf(lj) < b.y && hd > 0.5f) gap = fminf(gap, g + cfg.npc_gap_s0 - 1.0f);
     }
     return gap;
+}
+
+TDE_DEV float red_line_gap(const tde_config &cfg, const tde_world &w, const tde_map &m, uint32_t red, const Agent &ag,
+                           float cp, float sp)
+{
+    return red_line_gap_of(cfg, GlobalLines{w.stoplines + m.stop_base}, m.n_stop, red, ag, cp, sp);
 }
 
 // hl + hw bounds the circumradius; kReach^2 >= 1.001 keeps the circle test a superset of the SAT test in fp32
@@ -625,6 +671,35 @@ struct DuoShared {
     float4 c[2][kWave];                  // (psi, v, live, -): what the judge's ego lane and liveness test need
     unsigned long long done;             // ballot of the ego lanes whose env finished at the last judged step
     unsigned long long hit_mask, off_mask, tl_mask;   // three-role kernel: per-slot ballots of the judges, previous step
+    // the first kStopCache stop lines of every env's map (A >= 8, i.e. at most 8 envs per group): the per-step stop-line
+    // loops read LDS instead of walking the global table with one exposed L2 round trip per line
+    float4 stop[8][8][2];
+};
+constexpr int kStopCache = 8;
+
+// lanes a < min(n_stop, kStopCache) of an env fetch one line each (the driver calls it at start and after re-spawns)
+template <int A>
+TDE_DEV void fill_stop_cache(DuoShared &sh, const tde_world &w, const tde_map &m, int lane, int a)
+{
+    if constexpr (A >= 8) {
+        if (a < kStopCache && a < m.n_stop) {
+            const float4 *src = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + a));
+            sh.stop[lane / A][a][0] = src[0];
+            sh.stop[lane / A][a][1] = src[1];
+        }
+    }
+}
+
+template <int A>
+struct CachedLines {
+    const DuoShared &sh;
+    const tde_stopline *base;
+    int envw;
+    TDE_DEV void operator()(int i, float4 &a, float4 &b) const
+    {
+        if (A >= 8 && i < kStopCache) { a = sh.stop[envw][i][0]; b = sh.stop[envw][i][1]; }
+        else { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
+    }
 };
 
 // LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
@@ -667,10 +742,12 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
     if (role == 0) {
         // ================================ drive ================================
         TDE_ROLE_PROLOGUE
+        RedCache redc; redc.invalidate();
         __builtin_amdgcn_s_setprio(3);           // the driver is the serial chain of the simulation; the judge fills in
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
         write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
         lds_barrier();                                       // rows of the launch state are in buffer 1
         const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
         float2 act = acts[es];
@@ -694,9 +771,9 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 float acc = 0.0f, beta = 0.0f;
                 if (a == 0) { acc = act.x; beta = act.y; }
                 if (F & TDE_F_NPC) {
-                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
+                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
                     const float red_gap =
-                        (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
+                        (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
                     float na, nb;
                     npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
                                   cx.g_far, red_gap, na, nb);
@@ -731,8 +808,10 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 if (((dn >> base) & 1ull) && valid) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    redc.invalidate();
                     sincos_f32(ag.psi, s0, c0);
                     write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);
+                    if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
                 }
             }
             ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
@@ -770,6 +849,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
     } else {
         // ================================ judge ================================
         TDE_ROLE_PROLOGUE
+        RedCache redc; redc.invalidate();
         StepOut o{0.0f, 0, 0, 0, 0, 0, false};
         const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
         lds_barrier();
@@ -789,7 +869,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2);
             bool tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-                tl = tl_violation(w, cx.m, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
+                tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
             o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false};
             unsigned long long any = 0ull;
             if (F & TDE_F_REWARD) {                          // R8 / R11: the flags settle here (reward: the driver)
@@ -808,6 +888,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (any && ((any >> base) & 1ull) && valid) {
                 reset_lane<A>(cfg, cold, e, a, ag, er);
                 load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    redc.invalidate();
                 o.respawned = true;
             }
         }
@@ -875,10 +956,12 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     if (role == 0) {
         // ================================ drive ================================
         TDE_ROLE_PROLOGUE
+        RedCache redc; redc.invalidate();
         __builtin_amdgcn_s_setprio(3);           // the driver is the serial chain of the simulation; the judge fills in
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
         write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
         lds_barrier();                                       // rows of the launch state are in buffer 1
         const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
         float2 act = acts[es];
@@ -901,9 +984,9 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 float acc = 0.0f, beta = 0.0f;
                 if (a == 0) { acc = act.x; beta = act.y; }
                 if (F & TDE_F_NPC) {
-                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
+                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
                     const float red_gap =
-                        (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
+                        (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
                     float na, nb;
                     npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
                                   cx.g_far, red_gap, na, nb);
@@ -931,8 +1014,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 if (((dn >> base) & 1ull) && valid) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    redc.invalidate();
                     sincos_f32(ag.psi, s0, c0);
                     write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);
+                    if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
                 }
             }
             ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
@@ -957,6 +1042,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs, waypoint advance =====================
         TDE_ROLE_PROLOGUE
+        RedCache redc; redc.invalidate();
         bool hit = false;
         RewardOut rw{};
         uint8_t last_term = 0, last_trunc = 0;
@@ -983,6 +1069,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 if (dn && ((dn >> base) & 1ull) && valid) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    redc.invalidate();
                 }
             }
             lds_barrier();                                   // B: rows of step i are in buffer p
@@ -1028,6 +1115,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     } else {
         // ===================== judge O: offroad, stop lines =====================
         TDE_ROLE_PROLOGUE
+        RedCache redc; redc.invalidate();
         const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
         bool off = false, tl = false;
         lds_barrier();
@@ -1040,6 +1128,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 if (dn && ((dn >> base) & 1ull) && valid) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    redc.invalidate();
                 }
             }
             lds_barrier();                                   // B: rows of step i are in buffer p
@@ -1051,7 +1140,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             if (F & TDE_F_OFFROAD) off = box_offroad(w, cx.m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
             tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-                tl = tl_violation(w, cx.m, red_mask(w, cx.m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+                tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
             const unsigned long long om = __ballot(off), tm = __ballot(tl);
             if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
         }
