@@ -211,7 +211,7 @@ typedef struct tde_rollout {
 #define TDE_WAYPOINT_RADIUS 1.0f
 typedef struct tde_render {
     uint8_t *out;               /* [B][3*max(n_stack,1)][H][W] uint8 */
-    int32_t H, W;               /* 64, 64 (multiples of 4, H*W <= 4096: the image is staged in 12 KiB of LDS) */
+    int32_t H, W;               /* 64, 64 (multiples of 4, H*W <= 4096: the view is staged in LDS as one layer byte per pixel) */
     float fov;                  /* metres covered by the image width (35 in torchdrivesim's default RendererConfig) */
     int32_t n_stack;            /* 0/1: single frame; n: frame stack of n */
     /* Frame stack without moving pixels (optional; NULL: the older frames of `out` are shifted in place by a launch of
