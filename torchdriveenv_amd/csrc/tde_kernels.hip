@@ -1814,22 +1814,23 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
     // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (TDE_ROLLOUT=solo|duo|trio forces
-    // one).  Measured same-box (scripts/rollout_matrix.py): three roles win at 16 agents per env without traffic lights
-    // (the headline configuration, -5 %); two roles everywhere else (the 80-VGPR cap of six wavefronts per SIMD costs
-    // more than the third wavefront gains at other group shapes, and with the stop-line code).
+    // one).  Measured same-box (scripts/rollout_matrix.py, profiles/r01_j_rollout_matrix.txt): three roles win at 8, 16
+    // and 32 agents per env, with and without traffic lights (3.90 vs 4.25, 4.11 vs 4.44, 4.63 vs 4.82 us per step); at
+    // 64 agents per env the 64-slot sweeps do not fit the 80-VGPR cap of six wavefronts per SIMD (7.45 vs 5.90).
     static const int forced = [] {
         const char *v = getenv("TDE_ROLLOUT");
         return !v ? 0 : !strcmp(v, "solo") ? 1 : !strcmp(v, "duo") ? 2 : !strcmp(v, "trio") ? 3 : 0;
     }();
     const bool lights0 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-    const int team = forced ? forced : (st->A == 16 && !lights0) ? 3 : 2;
+    const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
+    const int team = forced ? forced : trio_shape ? 3 : 2;
     const bool solo = team == 1;
-    if (team == 3 && st->A == 16) {
-        if (lights0) {
-            tde::env_rollout_trio_kernel<16, true><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
-        } else {
-            tde::env_rollout_trio_kernel<16, false><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
-        }
+    if (team == 3 && trio_shape) {
+#define TDE_LAUNCH_TRIO(AA)                                                                                              \
+    if (lights0) tde::env_rollout_trio_kernel<AA, true><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro); \
+    else tde::env_rollout_trio_kernel<AA, false><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
+        if (st->A == 8) { TDE_LAUNCH_TRIO(8); } else if (st->A == 16) { TDE_LAUNCH_TRIO(16); } else { TDE_LAUNCH_TRIO(32); }
+#undef TDE_LAUNCH_TRIO
         hipError_t e3 = hipGetLastError();
         return e3 == hipSuccess ? 0 : fail("tde_env_rollout", e3);
     }
