@@ -2,11 +2,12 @@
 // exposes them (include/tde_hip.h).  No torch types anywhere: plain device pointers, sizes and a hipStream_t.
 //
 // Mapping (DESIGN.md "Kernels"): one lane per agent slot, env-major, so an env of A (power of two <= 64) slots is a
-// contiguous lane group inside ONE wavefront.  The persistent rollout kernel runs one wavefront per workgroup (64/A
-// envs) for K timesteps with the agent state in registers; the one-step kernel uses 256-thread workgroups.  Per-env
-// agent tiles are staged in LDS for the all-pairs sweeps (one tile per step serves the collision sweep of that step
-// and the NPC controller of the next); env termination is gathered with a wave ballot; the drivable-mesh grid index
-// and the scenario tables are read-only and stay in L2 / Infinity Cache.
+// contiguous lane group inside ONE wavefront.  The persistent rollout kernels run K timesteps per launch with the agent
+// state in registers, every group of 64 slots (64/A envs) served by one, two or three wavefronts that split the step by
+// role (env_rollout_kernel / _duo_ / _trio_, chosen by group shape); the one-step kernel uses 256-thread workgroups.
+// Per-env agent tiles are staged in LDS for the all-pairs sweeps (one tile per step serves the collision sweep of that
+// step and the NPC controller of the next); env termination is gathered with wave ballots; the drivable-mesh grid
+// index and the scenario tables are read-only and stay in L2 / Infinity Cache.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -35,7 +36,8 @@ struct EnvRegs {   // replicated on every lane of the env
 
 // LDS tile, one slot per lane of the workgroup, two 16-B records per agent so that a sweep reads them with
 // ds_read_b128 (all lanes of an env read the same address: broadcast, no bank conflict):
-//     a = (x, y, hl, lane_half + hw)     b = (cos psi, sin psi, hl + hw, hw)        (hl, hw = half length / width)
+//     a = (x, y, reach, lane_half + hw)     b = (cos psi, sin psi, hl, hw)
+//     (hl, hw = half length / width; reach = (hl + hw) * kReach bounds the circumradius)
 // The tile always holds the CURRENT state of every slot: it is written once per step, after the integration, and
 // serves that step's collision sweep and the next step's NPC controller (whose "pre-step" state it is).
 // An absent slot is parked at x = y = kFar, which fails every cheap sweep test by itself (no present flag to read).
