@@ -2,36 +2,69 @@
 """bench.py — headline benchmark of the batched env step path (BASELINE.json metric: env-steps/sec and agent-steps/sec
 at 8192 envs x 16 agents on 1/2/4/8 MI355X).
 
-    python bench.py --gpus 1 --steps 40000 --warmup 2000
+    python bench.py                                   # N=1, configs[2] (8192 envs x 16 agents, full step)
+    python bench.py --gpus N --steps K --warmup W     # N>1: starts one rank per GPU itself (no torchrun needed) ...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # ... or runs as a rank of an existing launcher
+    python bench.py --config 5                        # configs[4]: 8192 envs x 32 agents + 64x64x3 birdview raster
+    python bench.py --config 2                        # configs[1]: 1024 envs x 8 agents, kinematics + collision only
 
-A "step" is ONE timestep of the whole batch held by a GPU: configs[2] = 8192 envs x 16 agents, full step (bicycle
-kinematics, heuristic NPC controller, replay NPCs, all-pairs OBB collision, drivable-mesh offroad, WaypointSuite
-reward / termination / truncation, in-place auto-reset).  State, world tables and the ego-action buffer are resident in
-HBM when the timed region starts; steps are driven through the C-ABI (tde_env_rollout) with no host round trip.
-Multi-GPU: envs are independent -> every rank owns its own 8192-env shard (weak scaling), no data-path collective; the
-only collective is the MAX over ranks of the timed region.
+A "step" is ONE timestep of the whole batch held by a GPU.  State, world tables and the ego-action buffer are resident
+in HBM when the timed region starts; steps are driven through the C-ABI (tde_env_rollout: up to 250 consecutive
+timesteps per call, no host round trip in between).
+
+Timing protocol (what makes a short driver invocation such as `--steps 20 --warmup 5` report the steady state):
+  * un-timed: `--warmup` steps, and in any case at least one full 250-step launch and >= 50 ms of launches;
+  * timed: `repeats` back-to-back copies of the `--steps` block, repeats chosen so that the region lasts >= 0.25 s;
+    the steps*repeats consecutive timesteps are issued in launches of up to 250 steps (the rollout call's operating
+    point); `steps` / `warmup` echo the command line, `ms_per_step` = wall / (steps * repeats);
+  * the region is bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks;
+  * every timed launch is also bracketed by HIP events on the launch stream: `roofline` is computed from those
+    (algorithmic bytes of the launches actually made / their summed duration), with min / median per launch.
+
+Multi-GPU: envs are independent, so the global batch (configs[3] = 65536 envs at N=8) is cut into contiguous shards of
+8192 envs, one rank per GPU (weak scaling), with the reset RNG keyed by the GLOBAL env index (tde_config.env_base via
+sharding.shard_config): the N shards together are exactly the unsharded batch.  No data-path collective; the only
+collectives are the barrier, the MAX of the timed region and the host gather of per-shard check sums.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ENVS, A_AGENTS = 8192, 16
-# SURVEY §8(d) / BASELINE.md §4 algorithmic bytes: per agent-step 46 B (state r/w, attrs r, 2 flag bytes), per NPC
-# agent-step 16 B (controller target + index), per env-step 38 B (action, target, counters, reward, done flags)
-BYTES_PER_ENV_STEP = 46 * A_AGENTS + 16 * (A_AGENTS - 1) + 38   # = 1014
-HBM_PEAK_GBPS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+CH = 250                          # timesteps per tde_env_rollout call (rows of the resident action buffer)
+MIN_WARM_S, MIN_REGION_S = 0.05, 0.25
+
+# SURVEY §8(d) algorithmic bytes: per agent-step 46 B (state r/w 32, attrs 12, 2 flag bytes), per NPC agent-step 16 B
+# (controller target + index), per env-step 38 B (action, target, counters, reward, done flags); config 2 (kinematics +
+# collision only) 53 B per agent-step; config 5 adds 12 288 B of pixels per env-step.
+CONFIGS = {
+    3: dict(name="configs[2]", envs=8192, agents=16,
+            what="full step (kinematics + NPC + replay + OBB collision + offroad mesh + waypoint reward + auto-reset)"),
+    2: dict(name="configs[1]", envs=1024, agents=8, what="bicycle kinematics + OBB collision only"),
+    5: dict(name="configs[4]", envs=8192, agents=32,
+            what="full step + 64x64x3 uint8 ego birdview per env (HIP rasteriser), one step launch + one raster "
+                 "launch per timestep"),
+}
 
 
-def cpu_baseline(world, cfg, budget_s=12.0):
+def bytes_per_env_step(config, A):
+    if config == 2:
+        return 53 * A
+    full = 46 * A + 16 * (A - 1) + 38
+    return full + (12288 if config == 5 else 0)
+
+
+def cpu_baseline(world, cfg, A, budget_s=12.0):
     """The CPU oracle (a scalar C port of the same step, OpenMP over envs) timed on this box's host cores on a bounded
     sample of the same workload."""
     import numpy as np
@@ -42,7 +75,7 @@ def cpu_baseline(world, cfg, budget_s=12.0):
     cores = os.cpu_count() or 1
     oracle.set_num_threads(cores)
     B = 2048 if cores >= 64 else 512
-    hs = EnvState(B, A_AGENTS)
+    hs = EnvState(B, A)
     oracle.env_reset(cfg, world, hs)
     rng = np.random.default_rng(0)
 
@@ -59,7 +92,7 @@ def cpu_baseline(world, cfg, budget_s=12.0):
     dt = time.perf_counter() - t0
     # the reference's own operating point: ONE env stepped call by call on one thread
     oracle.set_num_threads(1)
-    h1 = EnvState(1, A_AGENTS)
+    h1 = EnvState(1, A)
     oracle.env_reset(cfg, world, h1)
     h1["action"][:] = 0.0
     n1, t0 = 0, time.perf_counter()
@@ -69,10 +102,32 @@ def cpu_baseline(world, cfg, budget_s=12.0):
         n1 += 50
     b1 = n1 / (time.perf_counter() - t0)
     oracle.set_num_threads(cores)
-    return {"value": B * K / dt, "unit": "env-steps/s", "agent_steps_per_s": B * A_AGENTS * K / dt,
+    return {"value": B * K / dt, "unit": "env-steps/s", "agent_steps_per_s": B * A * K / dt,
             "cores": oracle.num_threads(), "kind": "port", "b1_single_thread_env_steps_per_s": b1,
-            "sample": f"{B} envs x {A_AGENTS} agents x {K} steps of the same workload, oracle/tde_oracle.c "
+            "sample": f"{B} envs x {A} agents x {K} steps of the same workload, oracle/tde_oracle.c "
                       f"(brute-force mesh distance, OpenMP over envs), {dt:.1f} s"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one fresh child process per rank.  This process has not
+    touched the GPU (no HIP call, no torch import), so the children are ordinary new processes; rank 0's JSON line
+    passes through on stdout."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -80,151 +135,213 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--envs", type=int, default=B_ENVS)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json config, 1-based: 3 = the headline (default), 2 = kinematics + collision only, "
+                         "5 = 32 agents + birdview raster")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for the N>1 timing reduce (nccl = RCCL; gloo for tests that put "
-                         "several ranks on one GPU)")
+                    help="process group of the N>1 barrier / timing reduce (nccl = RCCL, one rank per GPU; gloo for "
+                         "tests that put several ranks on one GPU)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
-                    help="rollout: K steps per C-ABI call (default); step: one C-ABI call per step from Python")
+                    help="rollout: up to 250 steps per C-ABI call (default); step: one C-ABI call per step from Python")
     args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size == 1 and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))               # before anything touches the GPU
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
 
     import numpy as np
     import torch
 
     from torchdriveenv_amd import _abi, _lib, ops
+    from torchdriveenv_amd.sharding import shard_config, shard_range
     from torchdriveenv_amd.state import EnvState
     from torchdriveenv_amd.synth import synthetic_world
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a HIP device: there is no CPU path")
     dist = None
     if world_size > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+        if args.backend == "nccl" and ndev < world_size:
+            raise SystemExit(f"--backend nccl needs one GPU per rank ({world_size} ranks, {ndev} device(s)); several "
+                             "ranks on one GPU only time over --backend gloo")
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                        device_id=torch.device(f"cuda:{local_rank}"))
-            except Exception as exc:      # e.g. several ranks on one GPU: the data path needs no collective, so the
-                print(f"[bench] RCCL init failed ({type(exc).__name__}); timing reduce over gloo", file=sys.stderr)
-                args.backend = "gloo"     # barrier / MAX reduce may as well run over gloo
-        if args.backend == "gloo":
+        if args.backend == "nccl":                     # no silent fallback: an RCCL failure fails the run
+            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        else:
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     _lib.load()
 
-    B, A = args.envs, A_AGENTS
+    C = CONFIGS[args.config]
+    B, A = (args.envs or C["envs"]), C["agents"]
+    n = world_size
     world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)          # same tables on every GPU (replicated)
-    cfg = _abi.default_config(seed=1000 + rank, distance_cutoff=0.25)  # shipped reward constants; per-shard seed
+    flags = 0 if args.config == 2 else _abi.F_ALL
+    base_cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=flags)   # shipped reward constants
+    cfg, nb = shard_config(base_cfg, rank, n, B * n)                  # env_base = rank * B: shard of the global batch
+    assert nb == B and shard_range(rank, n, B * n) == (rank * B, (rank + 1) * B)
     dw = world.to_device(dev)
     st = EnvState(B, A, device=dev, with_info=False)
     ops.env_reset(cfg, dw, st)
+    stepwise = args.mode == "step" or args.config == 5
+    spl = 1 if stepwise else CH                                       # steps per launch of the dominant kernel
 
-    CH = 250                                                           # steps per C-ABI call (action buffer rows)
+    # columns [rank*B, (rank+1)*B) of the global [CH, n*B, 2] action tensor (defined shard by shard from seed = rank)
     g = torch.Generator(device="cpu").manual_seed(rank)
     actions = torch.stack([torch.rand(CH, B, generator=g) * 2 - 1, torch.rand(CH, B, generator=g) * 0.6 - 0.3], -1)
     actions = actions.to(torch.float32).contiguous().to(dev)
     reward = torch.empty((CH, B), dtype=torch.float32, device=dev)
     done = torch.empty((CH, B), dtype=torch.uint8, device=dev)
+    img = ops.render_ego(cfg, dw, st) if args.config == 5 else None
 
-    def run(nsteps):
-        left = nsteps
+    def launch(k, row):
+        """k consecutive timesteps (k <= CH); `row` = first row of the action buffer to use"""
+        if not stepwise:
+            ops.env_rollout(cfg, dw, st, actions[:k], reward[:k], done[:k])
+            return
+        for i in range(k):
+            ops.env_step(cfg, dw, st, action=actions[(row + i) % CH])
+            if img is not None:
+                ops.render_ego(cfg, dw, st, out=img)
+
+    def run(nsteps, events=None):
+        left, row = nsteps, 0
         while left > 0:
             k = min(CH, left)
-            if args.mode == "rollout":
-                ops.env_rollout(cfg, dw, st, actions[:k], reward[:k], done[:k])
-            else:
-                for i in range(k):
-                    ops.env_step(cfg, dw, st, action=actions[i])
+            if events is not None and len(events) < 8192:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()                        # on torch's current stream == the stream the kernels are launched on
+                events.append((ev, k))
+            launch(k, row)
             left -= k
+            row += k
 
-    run(args.warmup)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- un-timed: the CLI's warm-up, at least one full-length launch, at least MIN_WARM_S of launches --------------
+    t0 = time.perf_counter()
+    run(max(args.warmup, CH))
+    torch.cuda.synchronize()
+    warm_steps = max(args.warmup, CH)
+    while time.perf_counter() - t0 < MIN_WARM_S:
+        run(CH)
+        torch.cuda.synchronize()
+        warm_steps += CH
+    t1 = time.perf_counter()
+    run(CH)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t1) / CH                             # s per step, warm
+    repeats = max(1, int(-(-MIN_REGION_S // max(est * args.steps, 1e-9))))
+    if dist is not None:                                              # every rank must time the same number of steps
+        rr = torch.tensor([repeats], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+        repeats = int(rr[0])
+    total = args.steps * repeats
+
+    # ---- timed region ---------------------------------------------------------------------------------------------
+    events = []
+    ev_end = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()                       # on torch's current stream == the stream the kernels are launched on
-    run(args.steps)
-    ev1.record()
+    run(total, events)
+    ev_end.record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    # per-launch durations from the HIP events (launch i lasts from its event to the next one)
+    marks = [e for e, _ in events] + [ev_end]
+    lens = [k for _, k in events]
+    dur_us = [marks[i].elapsed_time(marks[i + 1]) * 1e3 for i in range(len(events))]
+    dev_ms = marks[0].elapsed_time(ev_end)
     if dist is not None:
         tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
 
     # sanity of what was just computed (not timed): finite rewards, episodes progressing
-    chk = dict(reward_sum=float(reward.double().sum()), done_frac=float((done > 0).float().mean()),
+    chk = dict(reward_sum=float((st["reward"] if stepwise else reward).double().sum()),
+               done_frac=float(((st["terminated"] | st["truncated"]) if stepwise else (done > 0)).float().mean()),
                episodes=int(st["episode"].max()))
     assert np.isfinite(chk["reward_sum"])
     if dist is not None:
-        # the "host gather" of per-shard results: three numbers per rank through all_gather (no pickling, so it works
+        # the "host gather" of per-shard results: a few numbers per rank through all_gather (no pickling, so it works
         # the same over RCCL and gloo), assembled on the host
-        mine = torch.tensor([chk["reward_sum"], chk["done_frac"], float(chk["episodes"])], dtype=torch.float64,
-                            device=dev if args.backend == "nccl" else "cpu")
+        mine = torch.tensor([chk["reward_sum"], chk["done_frac"], float(chk["episodes"]), float(cfg.env_base)],
+                            dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         parts = [torch.empty_like(mine) for _ in range(world_size)]
         dist.all_gather(parts, mine)
-        chk = [dict(rank=i, reward_sum=float(p[0]), done_frac=float(p[1]), episodes=int(p[2]))
+        chk = [dict(rank=i, env_base=int(p[3]), reward_sum=float(p[0]), done_frac=float(p[1]), episodes=int(p[2]))
                for i, p in enumerate(parts)]
     if rank == 0:
-        n = world_size
-        env_steps = B * n * args.steps
-        # dominant kernel: rollout mode = tde::env_rollout_trio_kernel<16> (drive + two judge wavefronts per 64 agent
-        # slots; TDE_ROLLOUT=duo|solo select the two- / one-wavefront forms), ONE launch per CH timesteps;
-        # step mode = tde::env_step_kernel<16>, one launch per timestep
-        steps_per_launch = CH if args.mode == "rollout" else 1
-        launches = -(-args.steps // steps_per_launch)
-        kern_us = dev_ms * 1e3 / launches                  # HIP-event time of the region / launches
-        alg_bytes = BYTES_PER_ENV_STEP * B * (args.steps / launches)
-        achieved = alg_bytes / (kern_us * 1e-6) / 1e9
+        bpes = bytes_per_env_step(args.config, A)
+        env_steps = B * n * total
+        # dominant kernel: rollout = tde::env_rollout_trio_kernel<A> (drive + two judge wavefronts per 64 agent slots;
+        # TDE_ROLLOUT=duo|solo force the two- / one-wavefront forms), one launch per <= CH timesteps;
+        # step mode = tde::env_step_kernel<A>; config 5 = step + tde::render_layers_kernel per timestep
+        if args.config == 5:
+            kernel = f"tde::env_step_kernel<{A}> + tde::render_layers_kernel"
+        elif stepwise:
+            kernel = f"tde::env_step_kernel<{A}, false, false>"
+        else:
+            team = {"solo": "", "duo": "_duo", "trio": "_trio"}.get(
+                os.environ.get("TDE_ROLLOUT", ""), "_trio" if A in (8, 16, 32) else "_duo")
+            kernel = f"tde::env_rollout{team}_kernel<{A}, false>"
+        # per-step-equivalent durations of the timed launches (a launch of k steps: its duration / k * spl)
+        per = sorted(d / k * spl for d, k in zip(dur_us, lens)) if not stepwise else sorted(d / k for d, k in zip(dur_us, lens))
+        kern_us = sum(dur_us) / max(1, sum(lens)) * spl               # average duration per launch of `spl` steps
+        alg_launch = float(bpes * B * spl)
+        achieved = alg_launch / (kern_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.mode == "rollout":
+        if os.path.exists(tpath) and args.config == 3 and not stepwise:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("steps_per_launch") == steps_per_launch and tj.get("envs") == B:
+                full = [k for k in lens if k == CH]
+                if tj.get("steps_per_launch") == CH and tj.get("envs") == B and len(full) >= len(lens) - 1 and full:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
             "metric": "env-steps/sec", "value": env_steps / wall, "unit": "env-steps/s",
             "agent_steps_per_sec": env_steps * A / wall,
-            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "repeats": repeats,
+            "ms_per_step": wall * 1e3 / total,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[2]: {B} envs x {A} agents per GPU, full step (kinematics + NPC + replay + "
-                                   "OBB collision + offroad mesh + waypoint reward + auto-reset)",
-                       "envs_per_gpu": B, "agents_per_env": A, "mode": args.mode, "steps_per_call": CH,
-                       "sharding": f"{n} independent shard(s), no data-path collective",
+            "config": {"workload": f"{C['name']}: {B} envs x {A} agents per GPU, {C['what']}",
+                       "envs_per_gpu": B, "agents_per_env": A, "global_envs": B * n, "mode": args.mode,
+                       "steps_per_call": spl, "timed_steps": total, "untimed_warmup_steps": warm_steps + CH,
+                       "sharding": f"{n} contiguous shard(s) of one global batch (env_base = rank * {B}), "
+                                   "no data-path collective",
                        "timing_backend": (args.backend if n > 1 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {"solo": f"tde::env_rollout_kernel<{A}, false>",
-                                    "duo": f"tde::env_rollout_duo_kernel<{A}, false>"}.get(
-                             os.environ.get("TDE_ROLLOUT", ""), f"tde::env_rollout_trio_kernel<{A}, false>")
-                         if args.mode == "rollout"
-                         else f"tde::env_step_kernel<{A}, false>",
-                         "kernel_avg_us": kern_us, "launches": launches, "steps_per_launch": steps_per_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes, "us_per_step": dev_ms * 1e3 / args.steps},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
+                         "kernel_avg_us": kern_us, "kernel_min_us": per[0] if per else None,
+                         "kernel_median_us": per[len(per) // 2] if per else None,
+                         "launches": len(lens), "steps_per_launch": spl,
+                         "launch_lengths": sorted(set(lens)), "algorithmic_bytes_per_launch": alg_launch,
+                         "bytes_per_env_step": bpes, "us_per_step": dev_ms * 1e3 / total,
+                         "timer": "HIP events on the launch stream around every timed launch (rank 0)"},
             "check": chk,
         }
         if n == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(world, cfg)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(world, base_cfg, A)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

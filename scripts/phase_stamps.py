@@ -1,5 +1,6 @@
-"""Per-phase wavefront time of the two-role rollout kernel from s_memtime stamps.
-usage: python scripts/make_stamped_build.py duo && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/phase_stamps.py [envs]"""
+"""Per-phase wavefront time of the two- / three-role rollout kernels from s_memtime stamps.
+usage: python scripts/make_stamped_build.py duo|trio && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/phase_stamps.py [duo|trio] [envs]
+(duo: run under TDE_ROLLOUT=duo)"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +12,9 @@ from torchdriveenv_amd import _abi, _lib, ops
 from torchdriveenv_amd.state import EnvState
 from torchdriveenv_amd.synth import synthetic_world
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+MODE = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].isdigit() else "duo"
+_num = [a for a in sys.argv[1:] if a.isdigit()]
+B = int(_num[0]) if _num else 8192
 A, K = 16, 250
 dev = torch.device("cuda:0")
 lib = _lib.load()
@@ -45,9 +48,18 @@ judge = ["wait A", "wait B (rows of this step)", "read rows + collision", "offro
          "publish + reset"]
 us = e0.elapsed_time(e1) * 1e3 / (reps * K)
 n = waves * reps * K
-print(f"{B} envs: {us:.2f} us/step (stamped build)")
-for title, names, off in (("drive wavefront", drive, 0), ("judge wavefront", judge, 12)):
-    tot = sum(out[off:off + 12])
+print(f"{B} envs: {us:.2f} us/step (stamped build, {MODE})")
+groups = (("drive wavefront", drive, 0, 12), ("judge wavefront", judge, 12, 12))
+if MODE == "trio":
+    groups = (("drive wavefront", ["loop top (action prefetch, replay read)", "controller: prefilter sweep",
+                                   "controller: exact loop", "controller: steering + speed", "bicycle",
+                                   "route switch + sincos", "wait A (masks of prev step)", "done test + commit rows",
+                                   "wait B", "route reload + loop end"], 0, 12),
+              ("judge C wavefront", ["wait A", "settle (done byte, re-spawn)", "wait B", "read rows + collision",
+                                     "reward (ego lane) + outputs"], 12, 6),
+              ("judge O wavefront", ["wait A", "done test + re-spawn", "wait B", "offroad + stop lines"], 18, 6))
+for title, names, off, width in groups:
+    tot = sum(out[off:off + width])
     print(f" {title}: {tot / n:.0f} memtime ticks per wave-step")
     for i, nm in enumerate(names):
         v = out[off + i]

@@ -138,9 +138,11 @@ def test_step_and_render_are_graph_capturable(small_world):
     assert torch.equal(ds["x"], ref["x"]) and torch.equal(ds["steps"], ref["steps"]) and torch.equal(img, img_ref)
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """the N > 1 launch path of bench.py (torch.distributed.run, barrier, MAX reduce, host gather), with two ranks
-    sharing this box's single GPU over gloo; the JSON contract is checked on the one line rank 0 prints"""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_on_one_gpu(launcher):
+    """the N > 1 path of bench.py: started as plain `python bench.py --gpus 2` (bench.py spawns its own ranks, the
+    driver's command shape) and under torch.distributed.run; barrier, MAX reduce, host gather, with two ranks sharing
+    this box's single GPU over gloo; the JSON contract is checked on the one line rank 0 prints"""
     import json
     import os
     import socket
@@ -151,18 +153,82 @@ def test_bench_two_ranks_on_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "500",
-           "--warmup", "250", "--backend", "gloo", "--envs", "2048"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "500", "--warmup", "250", "--backend", "gloo",
+            "--envs", "2048"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 500 and j["scaling"] == "weak" and j["higher_is_better"] is True
     assert j["metric"] == "env-steps/sec" and j["value"] > 0 and len(j["check"]) == 2
-    assert abs(j["value"] - 2 * 2048 * 500 / (j["ms_per_step"] * 1e-3 * 500)) / j["value"] < 1e-6
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(j["roofline"])
+    timed = j["steps"] * j["repeats"]
+    assert j["config"]["timed_steps"] == timed
+    assert abs(j["value"] - 2 * 2048 * timed / (j["ms_per_step"] * 1e-3 * timed)) / j["value"] < 1e-6
+    # the two ranks are shards of ONE global batch: global env index bases 0 and 2048
+    assert [c["env_base"] for c in j["check"]] == [0, 2048] and j["config"]["global_envs"] == 4096
+    rf = j["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_min_us", "kernel_median_us"} <= set(rf)
+    # self-consistent roofline block: bytes per launch = bytes per env-step x envs x steps per launch
+    assert rf["algorithmic_bytes_per_launch"] == rf["bytes_per_env_step"] * 2048 * rf["steps_per_launch"]
+    assert rf["bytes_per_env_step"] == 1014 and rf["steps_per_launch"] == 250 and rf["launch_lengths"] == [250]
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["kernel_avg_us"] / 1e3) / rf["achieved"] < 1e-6
+
+
+def test_bench_nccl_refuses_ranks_sharing_a_gpu():
+    """--backend nccl (the default) must fail, not fall back to gloo, when the ranks cannot each have a GPU"""
+    import os
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a single-GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "1",
+                          "--envs", "256"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode != 0 and "--backend gloo" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_sharded_hip_batch_equals_unsharded(small_world):
+    """tde_config.env_base on the HIP path: two shards (env_base 0 and B/2) stepped by the kernels reproduce the
+    unsharded HIP batch and the oracle bit for bit (contiguous env shards, reset RNG keyed by global env)"""
+    from torchdriveenv_amd.sharding import shard_config
+
+    B, A, K = 192, 16, 230
+    base = _abi.default_config(seed=21, distance_cutoff=0.25)
+    dw = small_world.to_device(DEV)
+    rng = np.random.default_rng(4)
+    actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+    full = EnvState(B, A, device=DEV)
+    ops.env_reset(base, dw, full)
+    fr, fd = ops.env_rollout(base, dw, full, dev(actions))
+    hs = EnvState(B, A)
+    oracle.env_reset(base, small_world, hs)
+    hr, hd = oracle.env_rollout(base, small_world, hs, actions)
+    assert np.array_equal(fr.cpu().numpy().view(np.uint32), hr.view(np.uint32)) and np.array_equal(fd.cpu().numpy(), hd)
+    parts = []
+    for rank in range(2):
+        cfg, n = shard_config(base, rank, 2, B)
+        assert cfg.env_base == rank * (B // 2) and n == B // 2
+        st = EnvState(n, A, device=DEV)
+        ops.env_reset(cfg, dw, st)
+        r, d = ops.env_rollout(cfg, dw, st, dev(actions[:, rank * n:(rank + 1) * n]))
+        parts.append((r.cpu().numpy(), d.cpu().numpy(), st.host()))
+    assert np.array_equal(np.concatenate([p[0] for p in parts], 1).view(np.uint32), hr.view(np.uint32))
+    assert np.array_equal(np.concatenate([p[1] for p in parts], 1), hd)
+    want = full.host()
+    for k in ("x", "y", "psi", "v", "episode", "scn", "steps", "target_idx", "collided", "offroad"):
+        got = np.concatenate([p[2][k] for p in parts])
+        assert np.array_equal(got.view(np.uint8), want[k].view(np.uint8)), k
+    assert want["episode"].max() > 1
 
 
 def test_render_other_sizes_and_bad_sizes(small_world):
