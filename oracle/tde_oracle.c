@@ -24,8 +24,8 @@
  * Floating-point contract (what makes HIP-vs-oracle comparisons bit-exact):
  *   - every fp32 expression below is evaluated exactly as written, left to right, one IEEE-754 rounding per
  *     operation: build with -ffp-contract=off and without -ffast-math (oracle/Makefile does);
- *   - sin/cos of fp32 angles use tde_oracle_sincosf (Cody-Waite reduction + minimax polynomials, plain
- *     mul/add only) rather than libm, so that the HIP kernel can reproduce every bit; its error against
+ *   - sin/cos of fp32 angles use tde_oracle_sincosf (Cody-Waite reduction + minimax polynomials evaluated with
+ *     explicit fmaf, one rounding each) rather than libm, so that the HIP kernel can reproduce every bit; its error against
  *     libm sinf/cosf is <= 2 ulp on [-8, 8] (tests/test_oracle_math.py), far inside the 1e-5 state tolerance
  *     the north star allows against torch.sin/torch.cos;
  *   - the reward is float64 arithmetic on fp32 state, as in the reference (math.dist / math.cos on Python
@@ -57,24 +57,24 @@ static const float TDE_PIO2_A = 1.5703125f;
 static const float TDE_PIO2_B = 4.837512969970703125e-4f;
 static const float TDE_PIO2_C = 7.54978995489188216e-8f;
 
-/* sin(r) and cos(r) for |r| <= pi/4 (+ reduction slop), simultaneously. */
+/* sin and cos of an fp32 angle: Cody-Waite reduction by pi/2, then sin(r) and cos(r) for |r| <= pi/4 (+ reduction
+ * slop) from minimax polynomials.  Every multiply-add is an explicit fmaf (ONE rounding; exact on any IEEE platform,
+ * hardware FMA or libm's software one), which is what lets the HIP kernels reproduce every bit with v_fma_f32. */
 TDE_EXPORT void tde_oracle_sincosf(float xin, float *s_out, float *c_out)
 {
     float kf = rintf(xin * TDE_2_OVER_PI);
-    float r = xin - kf * TDE_PIO2_A;
-    r = r - kf * TDE_PIO2_B;
-    r = r - kf * TDE_PIO2_C;
+    float r = fmaf(-kf, TDE_PIO2_A, xin);
+    r = fmaf(-kf, TDE_PIO2_B, r);
+    r = fmaf(-kf, TDE_PIO2_C, r);
     float z = r * r;
     /* sin: r + r*z*(S1 + z*(S2 + z*S3)) */
-    float ps = -1.9515295891e-4f;
-    ps = ps * z + 8.3321608736e-3f;
-    ps = ps * z - 1.6666654611e-1f;
-    float sn = r + (r * z) * ps;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float sn = fmaf(r * z, ps, r);
     /* cos: 1 - z/2 + z*z*(C1 + z*(C2 + z*C3)) */
-    float pc = 2.443315711809948e-5f;
-    pc = pc * z - 1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    float cs = (1.0f - 0.5f * z) + (z * z) * pc;
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    float cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
     int q = ((int)kf) & 3;
     float s, c;
     if (q == 0)      { s = sn;  c = cs;  }

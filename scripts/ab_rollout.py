@@ -1,0 +1,74 @@
+"""Interleaved same-process A/B of libtde_hip.so builds on the headline rollout (8192 envs x 16 agents, 250 steps per
+launch): every library is dlopen'ed in THIS process and the launches alternate lib by lib, so clocks, box and cache
+state are shared.  Reports median / min / mean us per step over >= 40 launches per library.
+
+    python scripts/ab_rollout.py [--envs 8192] [--agents 16] [--launches 40] [--lights] [--env NAME=VAL:lib] libA.so libB.so ...
+A library argument may be prefixed with rollout kernel choice, e.g. duo:path.so (sets TDE_ROLLOUT for that handle's
+first call; the choice is latched per library at first use)."""
+import argparse
+import ctypes as C
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from torchdriveenv_amd import _abi
+from torchdriveenv_amd.state import EnvState
+from torchdriveenv_amd.synth import synthetic_world
+
+ap = argparse.ArgumentParser()
+ap.add_argument("libs", nargs="+")
+ap.add_argument("--envs", type=int, default=8192)
+ap.add_argument("--agents", type=int, default=16)
+ap.add_argument("--launches", type=int, default=40)
+ap.add_argument("--steps", type=int, default=250)
+ap.add_argument("--lights", action="store_true")
+args = ap.parse_args()
+
+B, A, K = args.envs, args.agents, args.steps
+dev = torch.device("cuda:0")
+world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+dw = world.to_device(dev)
+g = torch.Generator().manual_seed(0)
+actions = torch.stack([torch.rand(K, B, generator=g) * 2 - 1, torch.rand(K, B, generator=g) * 0.6 - 0.3], -1)
+actions = actions.float().contiguous().to(dev)
+reward = torch.empty((K, B), device=dev)
+done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0)
+cfg = _abi.default_config(seed=1, distance_cutoff=0.25, flags=flags)
+ro = _abi.TdeRollout(actions.data_ptr(), reward.data_ptr(), done.data_ptr(), K, 0)
+stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+handles = []
+for spec in args.libs:
+    mode, _, path = spec.rpartition(":")
+    path = os.path.abspath(path)
+    if mode:
+        os.environ["TDE_ROLLOUT"] = mode
+    else:
+        os.environ.pop("TDE_ROLLOUT", None)
+    L = C.CDLL(path)
+    L.tde_env_rollout.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld), C.POINTER(_abi.TdeState),
+                                  C.POINTER(_abi.TdeRollout), C.c_void_p]
+    L.tde_env_reset.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld), C.POINTER(_abi.TdeState),
+                                C.c_void_p, C.c_void_p]
+    st = EnvState(B, A, device=dev, with_info=False)           # every library steps its own copy of the batch
+    assert L.tde_env_reset(C.byref(cfg), C.byref(dw.struct), C.byref(st.struct), None, stream) == 0
+    for _ in range(2):                                          # warm-up; latches the TDE_ROLLOUT choice of this handle
+        assert L.tde_env_rollout(C.byref(cfg), C.byref(dw.struct), C.byref(st.struct), C.byref(ro), stream) == 0
+    torch.cuda.synchronize()
+    handles.append((spec, L, st, []))
+
+for r in range(args.launches):
+    for spec, L, st, ts in handles:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.tde_env_rollout(C.byref(cfg), C.byref(dw.struct), C.byref(st.struct), C.byref(ro), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / K)
+print(f"{B} envs x {A} agents, {K} steps per launch, {args.launches} interleaved launches per library, lights={int(args.lights)}")
+for spec, L, st, ts in handles:
+    print(f"  {spec:40s} median {statistics.median(ts):6.3f}  min {min(ts):6.3f}  mean {statistics.mean(ts):6.3f} us/step")

@@ -25,13 +25,19 @@ PRELUDE = '''struct Stamps {
     __device__ void mark(int k) { unsigned long long n = __builtin_amdgcn_s_memtime(); acc[k] += n - last; last = n; }
 };
 __device__ unsigned long long g_stamps[24];
-// light-weight marker (trio patch): only `last` lives in registers; lane 0 adds the elapsed ticks to g_stamps[k]
+// light-weight marker (trio patch): only `last` lives in registers; lane 0 of the wavefront adds the elapsed ticks to
+// a per-workgroup LDS accumulator (every index is written by one role only), flushed to g_stamps once per launch
+__shared__ unsigned long long s_acc[24];
 __device__ __forceinline__ void tde_mark(unsigned long long *last, int k)
 {
     if (!last) return;
     const unsigned long long n = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[k], n - *last);
+    if ((threadIdx.x & 63) == 0) s_acc[k] += n - *last;
     *last = n;
+}
+__device__ __forceinline__ void tde_flush(int lo, int hi)
+{
+    if ((threadIdx.x & 63) == 0) for (int i = lo; i < hi; ++i) atomicAdd(&g_stamps[i], s_acc[i]);
 }
 '''
 EPILOGUE = '''
@@ -79,36 +85,48 @@ def patch_duo(s):
 
 
 def patch_trio(s):
-    """driver phases of env_rollout_trio_kernel (indices 0-9) and the two judges (12-17, 18-23)"""
+    """driver phases of env_rollout_trio_kernel (indices 0-9) and the two judges (12-16, 18-21)"""
     # npc_action gets an optional stamp cursor
     s = sub(s, "float g_far, float red_gap, float &acc,\n                        float &beta)\n{",
             "float g_far, float red_gap, float &acc,\n                        float &beta, unsigned long long *stl = nullptr)\n{")
-    s = sub(s, "        cand &= ~((mask_t)1 << i);\n    }\n    float gap = 1e30f;\n",
-            "        cand &= ~((mask_t)1 << i);\n    }\n    tde_mark(stl, 1);\n    float gap = 1e30f;\n")
+    s = sub(s, "        cand &= ~bit_of_row<A>(i);\n    }\n    float gap = 1e30f;\n",
+            "        cand &= ~bit_of_row<A>(i);\n    }\n    tde_mark(stl, 1);\n    float gap = 1e30f;\n")
     s = sub(s, "    if (!has_target) {\n        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);",
             "    tde_mark(stl, 2);\n    if (!has_target) {\n        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);")
     a, b = kernel_span(s, "env_rollout_trio_kernel")
     k = s[a:b]
-    k = sub(k, "        float2 act = acts[es];\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const int kn",
-            "        float2 act = acts[es];\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const int kn")
-    k = sub(k, "                if (F & TDE_F_NPC) {\n                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;\n                    const float red_gap =\n                        (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;\n                    float na, nb;\n                    npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,\n                                  cx.g_far, red_gap, na, nb);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;\n                if (live) {\n                    bicycle(nx, ny, npsi, nv, ag.lr, acc, beta, cfg.dt);                      // :117\n                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }\n                }\n                switched = false;\n                nwp = ag.route_wp;\n                if (has_target) {\n                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;\n                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }\n                }\n                sincos_f32(npsi, ns, nc);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n",
-            "                tde_mark(&stl, 0);\n                if (F & TDE_F_NPC) {\n                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;\n                    const float red_gap =\n                        (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;\n                    float na, nb;\n                    npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,\n                                  cx.g_far, red_gap, na, nb, &stl);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                tde_mark(&stl, 3);\n                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;\n                if (live) {\n                    bicycle(nx, ny, npsi, nv, ag.lr, acc, beta, cfg.dt);                      // :117\n                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }\n                }\n                tde_mark(&stl, 4);\n                switched = false;\n                nwp = ag.route_wp;\n                if (has_target) {\n                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;\n                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }\n                }\n                sincos_f32(npsi, ns, nc);\n                tde_mark(&stl, 5);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n                tde_mark(&stl, 6);\n")
-    k = sub(k, "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            if (switched) load_route_target(cold, ag, cx);\n            act = act_next;\n        }\n        lds_barrier();                                       // A of the step after the last: masks of step K-1",
-            "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            tde_mark(&stl, 7);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 8);\n            if (switched) load_route_target(cold, ag, cx);\n            act = act_next;\n            tde_mark(&stl, 9);\n        }\n        lds_barrier();                                       // A of the step after the last: masks of step K-1")
-    # judge C
+    k = sub(k, "    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull;",
+            "    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull;")
+    # ---- driver
+    k = sub(k, "        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];",
+            "        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];")
+    k = sub(k, "                if (F & TDE_F_NPC) {\n                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;",
+            "                tde_mark(&stl, 0);\n                if (F & TDE_F_NPC) {\n                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;")
+    k = sub(k, "                                  cx.g_far, red_gap, na, nb);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                nx = ag.x;",
+            "                                  cx.g_far, red_gap, na, nb, &stl);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                tde_mark(&stl, 3);\n                nx = ag.x;")
+    k = sub(k, "                switched = false;\n                nwp = ag.route_wp;", "                tde_mark(&stl, 4);\n                switched = false;\n                nwp = ag.route_wp;")
+    k = sub(k, "                sincos_f32(npsi, ns, nc);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n",
+            "                sincos_f32(npsi, ns, nc);\n                tde_mark(&stl, 5);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n                tde_mark(&stl, 6);\n")
+    k = sub(k, "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            if (switched) load_route_target(cold, ag, cx);\n        }\n",
+            "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            tde_mark(&stl, 7);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 8);\n            if (switched) load_route_target(cold, ag, cx);\n            tde_mark(&stl, 9);\n        }\n        tde_flush(0, 10);\n")
+    # ---- judge C
     k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
             "        lds_barrier();\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 12);\n")
     k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            hit = collide_rows",
             "            tde_mark(&stl, 13);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 14);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            hit = collide_rows")
     k = sub(k, "            if (lane == 0) sh.hit_mask = m;\n", "            if (lane == 0) sh.hit_mask = m;\n            tde_mark(&stl, 15);\n")
     k = sub(k, "                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;\n            }\n        }\n        lds_barrier();                                       // A'",
-            "                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;\n            }\n            tde_mark(&stl, 16);\n        }\n        lds_barrier();                                       // A'")
-    # judge O
-    k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
-            "        lds_barrier();\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 18);\n")
+            "                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;\n            }\n            tde_mark(&stl, 16);\n        }\n        tde_flush(12, 17);\n        lds_barrier();                                       // A'")
+    # ---- judge O
+    k = sub(k, "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
+            "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 18);\n")
+    k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            float2 act2",
+            "        lds_barrier();\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            float2 act2")
     k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            const bool live = rc.z != 0.0f;\n            off = false;",
             "            tde_mark(&stl, 19);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 20);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            const bool live = rc.z != 0.0f;\n            off = false;")
-    k = sub(k, "            if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n", "            if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n            tde_mark(&stl, 21);\n")
+    k = sub(k, "            if (ego) sh.act[p][lane] = act2;", "            if (ego) sh.act[p][lane] = act2;\n            tde_mark(&stl, 21);")
+    k = sub(k, "        lds_barrier();                                       // A'\n        lds_barrier();                                       // done(K-1) is in sh.done\n        if (!valid) return;\n        st.offroad[g]",
+            "        tde_flush(18, 22);\n        lds_barrier();                                       // A'\n        lds_barrier();                                       // done(K-1) is in sh.done\n        if (!valid) return;\n        st.offroad[g]")
     return s[:a] + k + s[b:]
 
 

@@ -21,39 +21,40 @@ constexpr float kPio2A = 1.5703125f;                // Cody-Waite split of pi/2 
 constexpr float kPio2B = 4.837512969970703125e-4f;
 constexpr float kPio2C = 7.54978995489188216e-8f;
 
-// sin and cos of an fp32 angle: plain mul/add only, so CPU and GPU agree bit for bit (<= 2 ulp vs libm).
+// sin and cos of an fp32 angle.  ONE specification shared with the CPU checker: Cody-Waite reduction
+// by pi/2 and degree-7/8 minimax polynomials, every multiply-add an explicit fused multiply-add (fmaf: one rounding, the
+// same on CPU and GPU), so CPU and GPU agree bit for bit (<= 2 ulp vs libm).  Half the instructions of the unfused form.
 TDE_DEV void sincos_f32(float xin, float &s, float &c)
 {
-    float kf = __builtin_rintf(xin * k2OverPi);
-    float r = xin - kf * kPio2A;
-    r = r - kf * kPio2B;
-    r = r - kf * kPio2C;
-    float z = r * r;
-    float ps = -1.9515295891e-4f;
-    ps = ps * z + 8.3321608736e-3f;
-    ps = ps * z - 1.6666654611e-1f;
-    float sn = r + (r * z) * ps;
-    float pc = 2.443315711809948e-5f;
-    pc = pc * z - 1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    float cs = (1.0f - 0.5f * z) + (z * z) * pc;
-    int q = ((int)kf) & 3;
-    float a = (q & 1) ? cs : sn;   // q: 0 (sn,cs) 1 (cs,-sn) 2 (-sn,-cs) 3 (-cs,sn)
-    float b = (q & 1) ? sn : cs;
-    s = (q & 2) ? -a : a;
-    c = ((q + 1) & 2) ? -b : b;
+    const float kf = __builtin_rintf(xin * k2OverPi);
+    float r = __builtin_fmaf(-kf, kPio2A, xin);
+    r = __builtin_fmaf(-kf, kPio2B, r);
+    r = __builtin_fmaf(-kf, kPio2C, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+    const uint32_t q = (uint32_t)(int)kf;   // q mod 4: 0 (sn,cs) 1 (cs,-sn) 2 (-sn,-cs) 3 (-cs,sn)
+    const bool odd = (q & 1u) != 0u;
+    const float a = odd ? cs : sn;
+    const float b = odd ? sn : cs;
+    // negation = sign-bit flip: integer ops instead of two more compare/select pairs
+    s = __uint_as_float(__float_as_uint(a) ^ ((q & 2u) << 30));
+    c = __uint_as_float(__float_as_uint(b) ^ (((q + 1u) & 2u) << 30));
 }
 
 // sin of a small angle, same bits as sincos_f32: for |x| < 0.75 the reduction index rint(x*2/pi) is 0, the three
-// Cody-Waite subtractions are exact no-ops and the quadrant is 0, so only the sine polynomial is left.
+// Cody-Waite steps are exact no-ops (fma(-0, A, x) = x) and the quadrant is 0, so only the sine polynomial is left.
 TDE_DEV float sin_small_f32(float x)
 {
     if (fabsf(x) < 0.75f) {
-        float z = x * x;
-        float ps = -1.9515295891e-4f;
-        ps = ps * z + 8.3321608736e-3f;
-        ps = ps * z - 1.6666654611e-1f;
-        return x + (x * z) * ps;
+        const float z = x * x;
+        float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+        ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+        return __builtin_fmaf(x * z, ps, x);
     }
     float s, c;
     sincos_f32(x, s, c);

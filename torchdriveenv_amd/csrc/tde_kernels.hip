@@ -20,6 +20,7 @@
 namespace tde {
 
 constexpr int kBlock = 256;
+constexpr int kWave = 64;
 
 // ------------------------------------------------------------------------------------------------------------------
 // per-lane registers
@@ -36,7 +37,7 @@ struct EnvRegs {   // replicated on every lane of the env
 
 // LDS tile, one slot per lane of the workgroup, two 16-B records per agent so that a sweep reads them with
 // ds_read_b128 (all lanes of an env read the same address: broadcast, no bank conflict):
-//     a = (x, y, reach, lane_half + hw)     b = (cos psi, sin psi, hl, hw)
+//     a = (x, y, reach, lane_half + hw + 0.01)     b = (cos psi, sin psi, hl, hw)
 //     (hl, hw = half length / width; reach = (hl + hw) * kReach bounds the circumradius)
 // The tile always holds the CURRENT state of every slot: it is written once per step, after the integration, and
 // serves that step's collision sweep and the next step's NPC controller (whose "pre-step" state it is).
@@ -49,27 +50,84 @@ struct Tiles {
 constexpr float kFar = 1e18f;
 
 template <int A> struct MaskOf { using type = uint32_t; };
-
-// All-pairs sweeps read the A tile rows of the lane's env.  Issued one by one next to their use, every ds_read_b128
-// exposes its full LDS latency to the lone wavefront (stamps: ~120 cycles per swept slot for ~45 cycles of work);
-// the rows are therefore fetched in blocks of kSweepBlock before any of them is used.
-constexpr int kSweepBlock = 4;
-template <int A, typename F> TDE_DEV void sweep_rows(const float4 *rows, F &&f)
-{
-    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
-#pragma unroll
-    for (int c = 0; c < A; c += C) {
-        float4 r[C];
-#pragma unroll
-        for (int j = 0; j < C; ++j) r[j] = rows[c + j];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < C; ++j) f(c + j, r[j]);
-    }
-}
 template <> struct MaskOf<64> { using type = unsigned long long; };
 TDE_DEV int lowest_bit(uint32_t m) { return __ffs((int)m) - 1; }
 TDE_DEV int lowest_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
+
+// All-pairs sweeps read the A tile rows of the lane's env and reduce each row to ONE candidate bit.  What shapes them
+// (scripts/ubench/valu_latency.hip: a lone wavefront issues a dependent VALU instruction every ~10 cycles, independent
+// ones every ~5, and a v_cmp -> v_cndmask pair through VCC costs ~24):
+//   * rows are processed in blocks of kSweepBlock, STAGE by stage across the block (every stage is kSweepBlock or
+//     2 x kSweepBlock independent instructions), the stages pinned in that order (pin() below);
+//   * the block's tile rows are fetched one block ahead, right after the last stage that reads the previous ones;
+//   * the row's verdict is formed as a float whose SIGN bit says "candidate" and shifted into the mask with one
+//     v_alignbit_b32 (mask = mask << 1 | sign): no compare, no select, no VCC.
+// Bit order: row r of the env lands in bit A-1-r (row_of_bit / bit_of_row below).
+constexpr int kSweepBlock = 2;
+// Stage pins.  sched_barrier only constrains the machine scheduler, and instruction selection is free to place pure
+// arithmetic on either side of it; an empty asm that takes the stage's values as read-write operands is a real data
+// dependency: everything that produces them is issued before it, everything that consumes them after it.  The
+// "memory" form keeps the LDS reads of the next block on their side of the pin (it does not wait for them).
+template <int C> TDE_DEV void pin(float (&a)[C])
+{
+#pragma unroll
+    for (int j = 0; j < C; ++j) asm volatile("" : "+v"(a[j]));
+}
+template <int C> TDE_DEV void pin(float (&a)[C], float (&b)[C])
+{
+#pragma unroll
+    for (int j = 0; j < C; ++j) asm volatile("" : "+v"(a[j]), "+v"(b[j]));
+}
+TDE_DEV void pin_memory() { asm volatile("" ::: "memory"); }
+template <int A> TDE_DEV int row_of_bit(int b) { return A - 1 - b; }
+template <int A> TDE_DEV typename MaskOf<A>::type bit_of_row(int r) { return (typename MaskOf<A>::type)1 << (A - 1 - r); }
+TDE_DEV uint32_t push_sign(uint32_t mask, float verdict)
+{
+    return __builtin_amdgcn_alignbit(mask, __float_as_uint(verdict), 31);   // ({mask, verdict} >> 31): mask << 1 | sign
+}
+// `stage(rows, verdicts, prefetch)`: computes the C verdict floats of a block from its C tile rows
+// (C = min(A, kSweepBlock)) and calls `prefetch()` at the point where the rows have been consumed.  Two register sets
+// alternate, so a block's rows are requested a whole block (about 20 instructions) before they are used: with one set
+// the 2 x ds_read_b128 were waited for a handful of instructions after their issue (~60 exposed cycles per block).
+template <int A, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks(const float4 *rows, S &&stage)
+{
+    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
+    constexpr int NB = A / C;
+    uint32_t word = 0, hi = 0;
+#ifndef TDE_SWEEP_AHEAD
+#define TDE_SWEEP_AHEAD 1
+#endif
+    // 1: one register set, the next block fetched in place; 2: two sets, a block's rows requested a whole block ahead
+    // (hides the LDS latency but costs 8 more VGPRs: under the 80-VGPR cap of the three-role kernel the spills it
+    // causes cost more than it saves, same-box A/B 3.76 vs 3.69 us per step)
+    constexpr int AHEAD = TDE_SWEEP_AHEAD;
+    float4 r0[C], r1[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) r0[j] = rows[j];
+    if (NB > 1 && AHEAD == 2) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) r1[j] = rows[C + j];
+    }
+    auto block = [&](int b, float4 (&r)[C]) {
+        float v[C];
+        stage(r, v, [&]() {                        // the rows are consumed: block b + AHEAD lands in the same registers
+            if (b + AHEAD < NB) {
+#pragma unroll
+                for (int j = 0; j < C; ++j) r[j] = rows[(b + AHEAD) * C + j];
+            }
+        });
+#pragma unroll
+        for (int j = 0; j < C; ++j) word = push_sign(word, v[j]);
+        if (A == 64 && (b + 1) * C == 32) { hi = word; word = 0; }
+    };
+#pragma unroll
+    for (int b = 0; b < NB; b += 2) {
+        block(b, r0);
+        if (b + 1 < NB) { if (AHEAD == 2) block(b + 1, r1); else block(b + 1, r0); }
+    }
+    if constexpr (A == 64) return ((unsigned long long)hi << 32) | word;
+    else return word;
+}
 
 TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
 {
@@ -203,44 +261,65 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
                         float &beta)
 {
     using mask_t = typename MaskOf<A>::type;
+    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
     const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
     mask_t cand = 0;
     const float hl_i = 0.5f * ag.len;
     if (has_target) {
-        // conservative forms of the exact tests below (5 cm / 1 cm of slack >> fp32 rounding): a slot that fails
-        // here fails there; min3 > 0 folds the three conditions into one sign test
-        // The prefilter only has to be a superset, so it is free to round differently from the exact tests: the
-        // forward / lateral offsets are evaluated as bilinear forms with fused multiply-adds (|error| < 1e-3 m for
-        // |coordinates| < 1e4 m, inside the 1 cm the three conditions are relaxed by).
-        const float lim_i = (g_far + hl_i) + 0.05f;
-        const float nPi = -(ag.x * cp + ag.y * sp), nQi = -(ag.y * cp - ag.x * sp);
-        sweep_rows<A>(ra, [&](int j, const float4 &pj) {      // pj = (x, y, reach, lane half width) of slot j
-            const float fj = __builtin_fmaf(pj.x, cp, __builtin_fmaf(pj.y, sp, nPi));
-            const float lj = __builtin_fmaf(pj.y, cp, __builtin_fmaf(-pj.x, sp, nQi));
-            const float near = (lim_i + pj.z) - fj;                                  // g < g_far (reach >= hl_j)
-            const float wide = __builtin_fmaf(cfg.npc_cone_k, fj, pj.w) - fabsf(lj);    // inside the widest corridor
-            cand |= (fminf(fminf(fj, near), wide) > -0.01f) ? (mask_t)1 << j : (mask_t)0;
+        // Conservative forms of the exact tests below: a slot that passes there passes here.  The prefilter only has to
+        // be a superset, so it is free to round differently: the forward / lateral offsets are bilinear forms evaluated
+        // with fused multiply-adds (|error| < 1e-3 m for |coordinates| < 1e4 m) and every condition is relaxed by 1 cm,
+        // folded into the constants so that each is a plain sign test:
+        //   ahead            f' = fj + 0.01                                   > 0
+        //   gap < g_far      n  = reach_j - f' + (g_far + hl_i + 0.05 + 0.02) > 0      (reach_j >= hl_j)
+        //   widest corridor  w  = max(cone_k, 0) * f' + (halfw_j + 0.01) - |lj| > 0    (tile row a.w = halfw_j + 0.01)
+        // verdict = max3(-f', -n, -w): negative (sign bit set) <=> all three hold.
+        const float nP = 0.01f - (ag.x * cp + ag.y * sp), nQ = -(ag.y * cp - ag.x * sp);
+        const float L = (g_far + hl_i) + 0.07f;
+        const float kc = fmaxf(cfg.npc_cone_k, 0.0f);
+        cand = sweep_blocks<A>(ra, [&](float4 (&r)[C], float (&v)[C], auto &&prefetch) {
+            float f[C], l[C], n[C], w[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].y, sp, nP); l[j] = __builtin_fmaf(-r[j].x, sp, nQ); }
+            pin(f, l);
+#pragma unroll
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].x, cp, f[j]); l[j] = __builtin_fmaf(r[j].y, cp, l[j]); }
+            pin(f, l);
+#pragma unroll
+            for (int j = 0; j < C; ++j) { n[j] = r[j].z - f[j]; w[j] = __builtin_fmaf(kc, f[j], r[j].w); }
+            pin(n, w);
+            pin_memory();
+            prefetch();                                        // the rows are consumed: fetch the next block's
+            pin_memory();
+#pragma unroll
+            for (int j = 0; j < C; ++j) { n[j] = n[j] + L; w[j] = w[j] - fabsf(l[j]); }
+            pin(n, w);
+#pragma unroll
+            for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
+            pin(v);
         });
-        cand &= ~((mask_t)1 << i);
+        cand &= ~bit_of_row<A>(i);
     }
     float gap = 1e30f;
     while (__ballot(cand != 0)) {
         if (cand) {
-            const int j = lowest_bit(cand);
+            const int j = row_of_bit<A>(lowest_bit(cand));
             cand &= cand - 1;
             const float4 pj = ra[j], qj = rb[j];
             const float ex = pj.x - ag.x, ey = pj.y - ag.y;
             const float fj = ex * cp + ey * sp;
             const float lj = ey * cp - ex * sp;
-            const float halfw = pj.w;                      // = npc_lane_half + 0.5f * wid_j, formed by slot j
+            const float halfw = cfg.npc_lane_half + qj.w;  // = npc_lane_half + 0.5f * wid_j (qj.w = hw_j = 0.5f * wid_j)
             const float hl_j = qj.z;
             const float al = fabsf(lj);
-            const bool inlane = al < halfw;
             const float hd = cp * qj.x + sp * qj.y;
-            const bool cone = (j < i) && (fj < cfg.npc_cone_range) && (al < halfw + cfg.npc_cone_k * fj) && (hd > -0.5f);
+            // branch-free: bitwise and/or of the predicates (no short-circuit control flow around a handful of ops)
+            const bool inlane = al < halfw;
+            const bool cone = (j < i) & (fj < cfg.npc_cone_range) & (al < halfw + cfg.npc_cone_k * fj) & (hd > -0.5f);
             // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit (scaling by 2 commutes with rounding)
             const float g = fj - (hl_i + hl_j);
-            if (fj > 0.0f && (inlane || cone)) gap = fminf(gap, g);
+            const bool take = (fj > 0.0f) & (inlane | cone);
+            gap = take ? fminf(gap, g) : gap;
         }
     }
     if (!has_target) {
@@ -269,22 +348,38 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
                           float hl, float hw, float ri)
 {
     using mask_t = typename MaskOf<A>::type;
+    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
     mask_t cand = 0;
     if (live) {
-        sweep_rows<A>(ra, [&](int j, const float4 &pj) {
-            const float dx = pj.x - x, dy = pj.y - y;
-            const float rr = ri + pj.z;
-            cand |= (__builtin_fmaf(dx, dx, dy * dy) <= rr * rr) ? (mask_t)1 << j : (mask_t)0;
+        // verdict = d^2 - (ri + rj)^2: negative <=> inside the sum of the (padded) circumradii
+        cand = sweep_blocks<A>(ra, [&](float4 (&r)[C], float (&v)[C], auto &&prefetch) {
+            float dx[C], dy[C], rr[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) { dx[j] = r[j].x - x; dy[j] = r[j].y - y; rr[j] = ri + r[j].z; }
+            pin(dx, dy);
+            pin(rr);
+            pin_memory();
+            prefetch();
+            pin_memory();
+#pragma unroll
+            for (int j = 0; j < C; ++j) dy[j] = dy[j] * dy[j];
+            pin(dy);
+#pragma unroll
+            for (int j = 0; j < C; ++j) dx[j] = __builtin_fmaf(dx[j], dx[j], dy[j]);
+            pin(dx);
+#pragma unroll
+            for (int j = 0; j < C; ++j) v[j] = __builtin_fmaf(-rr[j], rr[j], dx[j]);
+            pin(v);
         });
-        cand &= ~((mask_t)1 << a);
+        cand &= ~bit_of_row<A>(a);
     }
     bool hit = false;
     while (__ballot(cand != 0)) {
         if (cand) {
-            const int j = lowest_bit(cand);
+            const int j = row_of_bit<A>(lowest_bit(cand));
             cand &= cand - 1;
             const float4 pj = ra[j], qj = rb[j];
-            hit = hit || obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
+            hit = hit | obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
         }
     }
     return hit;
@@ -397,9 +492,9 @@ constexpr float kReach = 1.0005f;
 TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s, float lane_half)
 {
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
-    // a: what the branch-free sweeps read (position, reach = padded hl + hw, lane half width); b: the rest of what the
-    // exact tests need (heading, half extents)
-    ta = live ? make_float4(ag.x, ag.y, (hl + hw) * kReach, lane_half + hw) : make_float4(kFar, kFar, 0.0f, 0.0f);
+    // a: what the branch-free sweeps read (position, reach = padded hl + hw, lane half width + 1 cm of prefilter slack);
+    // b: the rest of what the exact tests need (heading, half extents)
+    ta = live ? make_float4(ag.x, ag.y, (hl + hw) * kReach, (lane_half + hw) + 0.01f) : make_float4(kFar, kFar, 0.0f, 0.0f);
     tb = make_float4(c, s, hl, hw);
 }
 
@@ -597,7 +692,6 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
 // table entries (Ctx) live in registers across the K steps, the only per-step global traffic is the ego action
 // (prefetched one step ahead), the per-step reward/done outputs and the grid-index reads; wavefronts never wait for
 // each other, so a wave that takes the rare reset / mesh-boundary path does not stall the batch.
-constexpr int kWave = 64;
 template <int A, bool LIGHTS>
 __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
 {
@@ -676,6 +770,9 @@ struct DuoShared {
     // the first kStopCache stop lines of every env's map (A >= 8, i.e. at most 8 envs per group): the per-step stop-line
     // loops read LDS instead of walking the global table with one exposed L2 round trip per line
     float4 stop[8][8][2];
+    // three-role kernel: the ego actions of the next two steps, relayed by judge O (slot = step & 1, indexed by the ego's
+    // lane): the driver's loop then issues no global load of its own, so nothing in it ever waits on vmcnt
+    float2 act[2][kWave];
 };
 constexpr int kStopCache = 8;
 
@@ -966,13 +1063,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         sincos_f32(ag.psi, s0, c0);
         write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
-        lds_barrier();                                       // rows of the launch state are in buffer 1
-        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
-        float2 act = acts[es];
+        lds_barrier();                                       // rows of the launch state are in buffer 1; actions 0, 1 relayed
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1, q = p ^ 1;
-            const int kn = (i + 1 < ro.K) ? i + 1 : i;
-            const float2 act_next = acts[(int64_t)kn * B + es];
+            const float2 act = sh.act[p][base];              // ego action of step i (judge O fetched it two steps ago)
             float nx, ny, npsi, nv, nc, ns;
             int nwp, k;
             bool switched, live;
@@ -1030,7 +1124,6 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);
             lds_barrier();                                   // B: rows of step i are in buffer p
             if (switched) load_route_target(cold, ag, cx);
-            act = act_next;
         }
         lds_barrier();                                       // A of the step after the last: masks of step K-1
         {
@@ -1124,9 +1217,19 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         RedCache redc; redc.invalidate();
         const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
         bool off = false, tl = false;
+        // action relay: this wavefront (lowest priority, off the simulation's serial chain) fetches the ego actions two
+        // steps ahead and parks them in LDS for the driver
+        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
+        const bool ego = a == 0 && valid;
+        if (ego) {
+            sh.act[0][lane] = acts[e];
+            sh.act[1][lane] = acts[(int64_t)(ro.K > 1 ? 1 : 0) * B + e];
+        }
         lds_barrier();
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1;
+            float2 act2 = make_float2(0.0f, 0.0f);
+            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step
             lds_barrier();                                   // A: masks of step i-1 are complete
             if (i > 0) {
                 unsigned long long term_m, trunc_m;
@@ -1149,6 +1252,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
             const unsigned long long om = __ballot(off), tm = __ballot(tl);
             if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
+            if (ego) sh.act[p][lane] = act2;                 // step i+2 -> slot i & 1 (step i's action is consumed: B passed)
         }
         lds_barrier();                                       // A'
         lds_barrier();                                       // done(K-1) is in sh.done
