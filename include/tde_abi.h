@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 4
+#define TDE_ABI_VERSION 5
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -73,7 +73,11 @@ typedef struct tde_config {
     float npc_cone_range;       /* yield cone length [m] */
     uint32_t env_base;          /* global index of this shard's env 0: the reset RNG is keyed by env_base + e, so
                                    a batch sharded over GPUs replays exactly the episodes of the unsharded batch */
-    int32_t _pad0;
+    int32_t offroad_threshold_squared; /* 0: a corner is off the road when its DISTANCE to the mesh exceeds
+                                   offroad_threshold (d^2 > thr^2); 1: when its SQUARED distance does (d^2 > thr), the reading
+                                   under which torchdrivesim's pytorch3d-style point-mesh distance is already squared.
+                                   Upstream is unpinned here (source absent): both readings are built and tested.  The grid
+                                   index of a World is built for the effective distance (thr or sqrt(thr)). */
 } tde_config;
 
 /* One drivable-surface map: triangle soup + uniform grid index. */
@@ -183,6 +187,13 @@ typedef struct tde_state {
                                    (x, y, psi, v, target offset forward / left, target flag, steps) of the state AFTER
                                    the step and any re-spawn - the same values as a tde_state_obs call would give, without
                                    the second launch */
+    double *ep_return;          /* in/out [B], tde_env_step / tde_env_reset only, may be NULL: sum of the rewards of the running
+                                   episode (float64, as Monitor sums Python floats: examples/rl_training.py:123-128); zeroed by a
+                                   reset and by an in-place re-spawn */
+    double *ep_final;           /* out [B], tde_env_step only, may be NULL: written for the envs that finish at THIS step with the
+                                   return of the episode that just ended (its length is environment_steps at that step: the k
+                                   of done_bits' step, also reported as ep_final_len); other entries keep their value */
+    int32_t *ep_final_len;      /* out [B], with ep_final */
     int32_t B, A;
 } tde_state;
 
@@ -200,7 +211,9 @@ typedef struct tde_rollout {
  * first (gym_env.py:95).  Pixel (row r, col c) is sampled at its centre; the ego sits at the image centre with its
  * heading pointing up: forward = (H/2 - (r+.5))*res, left = (W/2 - (c+.5))*res, res = fov / W.
  * Layers, painted in this order: background, drivable surface (= within offroad_threshold of the mesh, the same
- * predicate the offroad infraction uses), remaining ego waypoints (discs), NPC boxes, ego box.
+ * predicate the offroad infraction uses), stop lines of the map coloured by their light's state at the env's current
+ * step (only with TDE_F_TRAFFIC_LIGHTS: the traffic controls the reference hands to the renderer, gym_env.py:187-189,
+ * 259-266), remaining ego waypoints (discs), NPC boxes, ego box.
  * With n_stack > 1 the output holds the last n_stack frames, oldest first (SB3 VecFrameStack(channels_order="first"),
  * examples/rl_training.py:160): older frames are shifted down and the new frame is written last. */
 #define TDE_RGB_BACKGROUND 255, 255, 255
@@ -208,7 +221,21 @@ typedef struct tde_rollout {
 #define TDE_RGB_WAYPOINT    44, 160,  44
 #define TDE_RGB_NPC         31, 119, 180
 #define TDE_RGB_EGO        214,  39,  40
+#define TDE_RGB_STOP_RED   255,   0,   0   /* stop line whose light is red */
+#define TDE_RGB_STOP_GO      0, 255,   0   /* stop line whose light is not red */
 #define TDE_WAYPOINT_RADIUS 1.0f
+/* layer codes of the one-byte-per-pixel planes (tde_render.layers); the palette above in this order */
+#define TDE_LAYER_BACKGROUND 0
+#define TDE_LAYER_ROAD       1
+#define TDE_LAYER_WAYPOINT   2
+#define TDE_LAYER_NPC        3
+#define TDE_LAYER_EGO        4
+#define TDE_LAYER_STOP_RED   6
+#define TDE_LAYER_STOP_GO    7
+/* tde_render.flags */
+#define TDE_RENDER_LEFT_HANDED   (1 << 0)  /* RendererConfig.left_handed_coordinates (True in the reference, gym_env.py:46):
+                                              the lateral image axis is mirrored (world +y is to the RIGHT of +x) */
+#define TDE_RENDER_PLAIN_EGO     (1 << 1)  /* highlight_ego_vehicle = False (gym_env.py:47 sets True): ego painted as an NPC */
 typedef struct tde_render {
     uint8_t *out;               /* [B][3*max(n_stack,1)][H][W] uint8 */
     int32_t H, W;               /* 64, 64 (multiples of 4, H*W <= 4096: the view is staged in LDS as one layer byte per pixel) */
@@ -222,7 +249,16 @@ typedef struct tde_render {
      * older frame and view instead of 12 + 12, no ordering hazard, one launch.  A caller that clears a view's stack
      * (VecFrameStack on reset) fills its ring slots with TDE_LAYER_BLANK. */
     uint8_t *layers;
-    int32_t phase, _pad;
+    int32_t phase;              /* >= 0; callers keep it reduced modulo n_stack */
+    int32_t flags;              /* TDE_RENDER_* */
+    const uint8_t *fresh;       /* optional u8 [B] (NULL: none): views with (fresh[e] & 3) != 0 just (re)started their episode -
+                                   their older ring slots are blanked inside this call, so the first stacked observation of an
+                                   episode holds (blank, ..., blank, frame 0) as VecFrameStack gives after a reset.  Bits 0-1
+                                   are the done bits of tde_state.done_bits: after a step with TDE_F_AUTORESET pass done_bits
+                                   itself (the finished envs were re-spawned in place); a plain 0/1 reset mask works too. */
+    const uint8_t *only;        /* optional u8 [B] (NULL: all): render only these views; the others keep their ring, their
+                                   `out` pixels and do not consume a ring slot (phase is per call, so a masked call must
+                                   use the phase of the LAST full call: it re-renders the newest slot of the masked views) */
 } tde_render;
 #define TDE_LAYER_BLANK 5       /* palette entry (0, 0, 0): a frame that has not been rendered yet */
 

@@ -194,8 +194,9 @@ def waypoint_reward(cfg, pre, post, offroad, collided, tl, wp_xy, wp_n, scn, ste
     return out
 
 
-def render_ego(cfg, world, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
-    """ego-centred birdview [B, 3*n_stack, H, W] uint8 of the current state (frame-stack semantics if n_stack > 1)"""
+def render_ego(cfg, world, state, H=64, W=64, fov=35.0, n_stack=1, out=None, flags=0, fresh=None, only=None):
+    """ego-centred birdview [B, 3*n_stack, H, W] uint8 of the current state (frame-stack semantics if n_stack > 1).
+    flags: _abi.RENDER_*; fresh / only: optional uint8 [B] masks (tde_render.fresh / .only)"""
     L = lib()
     if not getattr(L, "_rd_bound", False):
         L.tde_oracle_render_ego.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld),
@@ -205,6 +206,8 @@ def render_ego(cfg, world, state, H=64, W=64, fov=35.0, n_stack=1, out=None):
     ns = max(1, n_stack)
     if out is None:
         out = np.zeros((state.B, 3 * ns, H, W), np.uint8)
-    rd = _abi.TdeRender(_p(out), H, W, fov, n_stack, None, 0, 0)     # the oracle shifts the stack in place
+    fresh = None if fresh is None else np.ascontiguousarray(fresh, np.uint8)
+    only = None if only is None else np.ascontiguousarray(only, np.uint8)
+    rd = _abi.TdeRender(_p(out), H, W, fov, n_stack, None, 0, int(flags), _p(fresh), _p(only))   # (stack shifted in place)
     L.tde_oracle_render_ego(C.byref(cfg), C.byref(world.host_struct()), C.byref(state.struct), C.byref(rd))
     return out

@@ -241,6 +241,12 @@ static int tde_agent_offroad(const tde_world *w, int32_t map_id, float x, float 
     return 0;
 }
 
+/* the squared threshold both modes compare d^2 with (tde_config.offroad_threshold_squared) */
+static inline float tde_thr2(const tde_config *cfg)
+{
+    return cfg->offroad_threshold_squared ? cfg->offroad_threshold : cfg->offroad_threshold * cfg->offroad_threshold;
+}
+
 /* operator form; map_of_env[e] selects the map of env e */
 TDE_EXPORT void tde_oracle_compute_offroad(int32_t B, int32_t A, const float *x, const float *y, const float *psi,
                                            const float *len, const float *wid, const uint8_t *present,
@@ -316,6 +322,7 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
     st->target_idx[e] = 1;     /* :325 */
     st->reached[e] = 0;        /* :338 */
     st->episode[e] = (int32_t)(ep + 1u);
+    if (st->ep_return) st->ep_return[e] = 0.0;   /* Monitor.reset: the reward list restarts */
 
     for (int32_t a = 0; a < A; ++a) {
         int64_t g = (int64_t)e * A + a;
@@ -594,7 +601,7 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
         st->collided[g0 + i] = hit;
     }
     if (F & TDE_F_OFFROAD) {
-        float thr2 = cfg->offroad_threshold * cfg->offroad_threshold;
+        float thr2 = tde_thr2(cfg);
         int32_t map_id = w->scn[st->scn[e]].map;
         for (int32_t a = 0; a < A; ++a)
             st->offroad[g0 + a] = present[a] ? (uint8_t)tde_agent_offroad(w, map_id, X[a], Y[a], c[a], s[a],
@@ -631,6 +638,13 @@ TDE_EXPORT int tde_oracle_env_step(const tde_config *cfg, const tde_world *w, td
         if (st->done_bits)                                  /* the ego's flags before a re-spawn clears them */
             st->done_bits[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (st->offroad[(int64_t)e * st->A] << 2) |
                                          (st->collided[(int64_t)e * st->A] << 3) | (o.tl << 4));
+        if (st->ep_return) {                                /* Monitor.step: rewards.append(float(reward)); ep_rew = sum(rewards) */
+            st->ep_return[e] = st->ep_return[e] + (double)o.reward;
+            if (o.terminated || o.truncated) {
+                if (st->ep_final) st->ep_final[e] = st->ep_return[e];
+                if (st->ep_final_len) st->ep_final_len[e] = st->steps[e];
+            }
+        }
         if ((cfg->flags & TDE_F_AUTORESET) && (o.terminated || o.truncated)) tde_reset_env(cfg, w, st, e);
     }
     return 0;
@@ -667,18 +681,27 @@ static void tde_render_env(const tde_config *cfg, const tde_world *w, const tde_
                            int32_t e)
 {
     static const uint8_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
-                         NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
+                         NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO}, STOP_RED[3] = {TDE_RGB_STOP_RED},
+                         STOP_GO[3] = {TDE_RGB_STOP_GO};
+    if (rd->only && !rd->only[e]) return;                 /* masked call: this view is left as it is */
     const int32_t A = st->A, H = rd->H, W = rd->W;
     const int32_t ns = rd->n_stack > 1 ? rd->n_stack : 1;
     const int64_t g0 = (int64_t)e * A;
     const int64_t plane = (int64_t)H * W;
     uint8_t *out = rd->out + (int64_t)e * 3 * ns * plane;
-    if (ns > 1) memmove(out, out + 3 * plane, (size_t)(3 * (ns - 1) * plane));
+    /* frame stack: a full call shifts the older frames down; a masked call (rd->only) re-renders the newest frame in
+     * place; a view whose episode just started (rd->fresh) shows blank older frames (VecFrameStack after a reset) */
+    if (ns > 1 && !rd->only) memmove(out, out + 3 * plane, (size_t)(3 * (ns - 1) * plane));
+    if (ns > 1 && rd->fresh && (rd->fresh[e] & 3)) memset(out, 0, (size_t)(3 * (ns - 1) * plane));
     uint8_t *img = out + 3 * (ns - 1) * plane;
     const int32_t scn = st->scn[e];
     const tde_map *m = &w->maps[w->scn[scn].map];
     const float *tri = w->tri + 6 * (int64_t)m->tri_base;
-    const float thr2 = cfg->offroad_threshold * cfg->offroad_threshold;
+    const float thr2 = tde_thr2(cfg);
+    const int lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    const uint32_t red = lights ? tde_red_mask(w, m, st->steps[e]) : 0u;     /* light state at the env's current step */
+    const float lsign = (rd->flags & TDE_RENDER_LEFT_HANDED) ? -1.0f : 1.0f;
+    const uint8_t *ego_col = (rd->flags & TDE_RENDER_PLAIN_EGO) ? NPC : EGO;
     float ca[TDE_MAX_AGENTS], sa[TDE_MAX_AGENTS];
     for (int32_t a = 0; a < A; ++a) tde_oracle_sincosf(st->psi[g0 + a], &sa[a], &ca[a]);
     const float ex = st->x[g0], ey = st->y[g0], ce = ca[0], se = sa[0];
@@ -688,11 +711,18 @@ static void tde_render_env(const tde_config *cfg, const tde_world *w, const tde_
     for (int32_t r = 0; r < H; ++r)
         for (int32_t c = 0; c < W; ++c) {
             float f = (0.5f * (float)H - ((float)r + 0.5f)) * res;
-            float l = (0.5f * (float)W - ((float)c + 0.5f)) * res;
+            float l = ((0.5f * (float)W - ((float)c + 0.5f)) * res) * lsign;
             float wx = (ex + f * ce) - l * se;
             float wy = (ey + f * se) + l * ce;
             const uint8_t *col = BG;
             if (!(tde_oracle_point_mesh_d2(wx, wy, tri, m->n_tri) > thr2)) col = ROAD;
+            if (lights)
+                for (int32_t k = 0; k < m->n_stop; ++k) {
+                    const tde_stopline *sl = &w->stoplines[m->stop_base + k];
+                    float dx = wx - sl->x, dy = wy - sl->y;
+                    float p = dx * sl->c + dy * sl->s, q = dy * sl->c - dx * sl->s;
+                    if (fabsf(p) <= sl->hl && fabsf(q) <= sl->hw) col = ((red >> sl->light) & 1u) ? STOP_RED : STOP_GO;
+                }
             for (int32_t k = ti; k < n_wp; ++k) {
                 float dx = wx - (float)wp[2 * k], dy = wy - (float)wp[2 * k + 1];
                 if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) col = WP;
@@ -701,7 +731,7 @@ static void tde_render_env(const tde_config *cfg, const tde_world *w, const tde_
                 if (!st->present[g0 + a]) continue;
                 float dx = wx - st->x[g0 + a], dy = wy - st->y[g0 + a];
                 float p = dx * ca[a] + dy * sa[a], q = dy * ca[a] - dx * sa[a];
-                if (fabsf(p) <= 0.5f * st->len[g0 + a] && fabsf(q) <= 0.5f * st->wid[g0 + a]) col = a ? NPC : EGO;
+                if (fabsf(p) <= 0.5f * st->len[g0 + a] && fabsf(q) <= 0.5f * st->wid[g0 + a]) col = a ? NPC : ego_col;
             }
             for (int ch = 0; ch < 3; ++ch) img[ch * plane + (int64_t)r * W + c] = col[ch];
         }

@@ -1,0 +1,285 @@
+"""GPU parity / semantics of the round-2 additions, through the C-ABI: stop-line layer and left-handed raster pixel-exact
+against the oracle, masked / fresh frame-stack calls, both readings of the offroad threshold, Monitor-style episode
+statistics, VecFrameStack semantics of the batched env (device path and SB3 path), the SB3 VecEnv adapter."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from torchdriveenv_amd import _abi, ops  # noqa: E402
+from torchdriveenv_amd.config import EnvConfig, RendererConfig, SimulatorConfig  # noqa: E402
+from torchdriveenv_amd.env import BatchedWaypointEnv, LazyInfos, WaypointVecEnv  # noqa: E402
+from torchdriveenv_amd.state import EnvState  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _pair(world, B, A, cfg):
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    oracle.env_reset(cfg, world, hs)
+    ds.load(hs.host())
+    return hs, ds, world.to_device(DEV)
+
+
+def _step_both(cfg, world, dw, hs, ds, rng, n=1):
+    for _ in range(n):
+        act = np.stack([rng.uniform(0, 1, hs.B), rng.uniform(-0.2, 0.2, hs.B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+
+
+@pytest.mark.parametrize("A,flags", [(16, 0), (16, _abi.RENDER_LEFT_HANDED), (32, _abi.RENDER_LEFT_HANDED | _abi.RENDER_PLAIN_EGO)])
+def test_render_with_lights_and_flags_bit_exact(A, flags):
+    """every pixel equals the oracle's with the traffic-control layer on (stop lines coloured by the light state at the
+    env's step), in the right- and left-handed raster, with and without the ego highlight; BASELINE configs[4] shape"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=6, A=A, seed=3, n_maps=2)
+    cfg = _abi.default_config(seed=8, flags=_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS, terminated_at_infraction=0)
+    B = 24
+    hs, ds, dw = _pair(world, B, A, cfg)
+    rng = np.random.default_rng(4)
+    RED, GO = _abi.PALETTE[_abi.LAYER_STOP_RED], _abi.PALETTE[_abi.LAYER_STOP_GO]
+    seen = {RED: 0, GO: 0}
+    maps, stops, scn_map = world.arrays["maps"], world.arrays["stoplines"], world.arrays["scn"]["map"]
+    for t in range(10):
+        _step_both(cfg, world, dw, hs, ds, rng, 4)
+        if t % 2:                                         # park half of the egos in front of a stop line of their map
+            for e in range(0, B, 2):
+                m = maps[scn_map[hs["scn"][e]]]
+                sl = stops[m["stop_base"] + (e // 2) % m["n_stop"]]
+                g = e * A
+                hs["x"][g], hs["y"][g] = sl["x"] - 5.0 * sl["c"], sl["y"] - 5.0 * sl["s"]
+                hs["psi"][g] = np.arctan2(sl["s"], sl["c"]) + 0.3
+            ds.load(hs.host())
+        want = oracle.render_ego(cfg, world, hs, flags=flags)
+        got = ops.render_ego(cfg, dw, ds, flags=flags).cpu().numpy()
+        assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ at t={t}"
+        px = want.transpose(0, 2, 3, 1).reshape(-1, 3)
+        for col in seen:
+            seen[col] += int((px == np.array(col)).all(1).sum())
+    assert seen[RED] > 50 and seen[GO] > 50               # both light states were on screen
+
+
+def test_render_masked_and_fresh_calls_match_oracle(small_world):
+    """tde_render.only / .fresh with the in-place stack and with the layer ring: same pixels as the oracle"""
+    cfg = _abi.default_config(seed=12, flags=_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS)
+    B, A = 20, 16
+    hs, ds, dw = _pair(small_world, B, A, cfg)
+    rng = np.random.default_rng(2)
+    ring = ops.FrameStack(B, 3, device=DEV)
+    hout = dout = None
+    for t in range(9):
+        _step_both(cfg, small_world, dw, hs, ds, rng, 2)
+        fresh = np.zeros(B, np.uint8)
+        if t % 3 == 1:
+            fresh[rng.integers(0, B, 4)] = rng.integers(1, 4, 4)                 # done-bit patterns
+            fresh[rng.integers(0, B, 2)] = 4 | 8                                  # infraction bits only: not fresh
+        hout = oracle.render_ego(cfg, small_world, hs, n_stack=3, out=hout, fresh=fresh)
+        dout = ops.render_ego(cfg, dw, ds, n_stack=3, out=dout, fresh=dev(fresh))
+        r = ring.render(cfg, dw, ds, fresh=dev(fresh))
+        assert np.array_equal(dout.cpu().numpy(), hout) and np.array_equal(r.cpu().numpy(), hout), t
+        if t % 3 == 2:                                    # some envs are re-spawned between two steps: masked call
+            mask = np.zeros(B, np.uint8)
+            mask[rng.integers(0, B, 5)] = 1
+            oracle.env_reset(cfg, small_world, hs, mask)
+            ops.env_reset(cfg, dw, ds, dev(mask))
+            hout = oracle.render_ego(cfg, small_world, hs, n_stack=3, out=hout, fresh=mask, only=mask)
+            dout = ops.render_ego(cfg, dw, ds, n_stack=3, out=dout, fresh=dev(mask), only=dev(mask))
+            r = ring.rerender(cfg, dw, ds, dev(mask))
+            assert np.array_equal(dout.cpu().numpy(), hout) and np.array_equal(r.cpu().numpy(), hout), t
+    assert ring.phase in (0, 1, 2)
+    with pytest.raises(Exception):
+        ops.render_ego(cfg, dw, ds, n_stack=3, out=dout, layers=ring.layers, phase=-1)
+
+
+@pytest.mark.parametrize("squared", [False, True])
+def test_offroad_threshold_both_readings_bit_exact(squared):
+    """grid index (built for the effective distance) vs the oracle's brute force, threshold on the distance and on the
+    squared distance: masks equal, and the two readings differ on agents that straddle the road edge"""
+    from torchdriveenv_amd.synth import synthetic_world
+    from torchdriveenv_amd.world import effective_offroad_distance
+
+    world = synthetic_world(n_scn=8, A=16, seed=0, n_maps=2, threshold=effective_offroad_distance(0.5, squared))
+    cfg = _abi.default_config(seed=3, offroad_threshold=0.5, offroad_threshold_squared=int(squared),
+                              terminated_at_infraction=0)
+    B, A = 96, 16
+    hs, ds, dw = _pair(world, B, A, cfg)
+    rng = np.random.default_rng(7)
+    n_off = 0
+    for t in range(40):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+        assert np.array_equal(ds["offroad"].cpu().numpy(), hs["offroad"]), t
+        n_off += int(hs["offroad"].sum())
+    for k in ("x", "y", "psi", "v", "reward"):
+        assert np.array_equal(ds[k].cpu().numpy().view(np.uint32), hs[k].view(np.uint32)), k
+    assert n_off > 0
+    # operator form against brute force on boxes pushed across the road edge
+    h = hs.host()
+    y = (h["y"] + rng.uniform(-4, 4, B * A)).astype(np.float32)
+    mo = np.ascontiguousarray(world.arrays["scn"]["map"][h["scn"]].astype(np.int32))
+    thr = float(np.sqrt(0.5)) if squared else 0.5
+    want = oracle.compute_offroad(B, A, h["x"], y, h["psi"], h["len"], h["wid"], h["present"], world, mo, threshold=thr)
+    got = ops.compute_offroad(B, A, dev(h["x"]), dev(y), dev(h["psi"]), dev(h["len"]), dev(h["wid"]), dev(h["present"]),
+                              dw, dev(mo), threshold=thr).cpu().numpy()
+    assert np.array_equal(got, want) and 0 < want.sum() < want.size
+
+
+def test_env_step_episode_statistics_bit_exact(small_world):
+    """ep_return / ep_final / ep_final_len of tde_env_step equal the oracle's (float64 sums: same order, same bits), with
+    in-place re-spawn and without"""
+    for flags in (_abi.F_ALL, _abi.F_ALL & ~_abi.F_AUTORESET):
+        cfg = _abi.default_config(seed=14, distance_cutoff=0.25, flags=flags, max_steps=60)
+        B, A = 160, 16
+        hs, ds, dw = _pair(small_world, B, A, cfg)
+        rng = np.random.default_rng(5)
+        for t in range(150):
+            act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            ds["action"].copy_(dev(act))
+            oracle.env_step(cfg, small_world, hs)
+            ops.env_step(cfg, dw, ds)
+            if t % 10 == 9:
+                for k in ("ep_return", "ep_final"):
+                    assert np.array_equal(ds[k].cpu().numpy().view(np.uint64), hs[k].view(np.uint64)), (k, t)
+                assert np.array_equal(ds["ep_final_len"].cpu().numpy(), hs["ep_final_len"]), t
+            if not (flags & _abi.F_AUTORESET) and t % 40 == 39:
+                m = (hs["terminated"] | hs["truncated"]).astype(np.uint8)
+                oracle.env_reset(cfg, small_world, hs, m)
+                ops.env_reset(cfg, dw, ds, dev(m))
+        assert hs["ep_final_len"].max() > 0 and hs["ep_final"].any()
+
+
+def _single_frames(env):
+    """the current single frame of every env, rendered independently of the env's own stack"""
+    return ops.render_ego(env.tde_cfg, env.dworld, env.state, 64, 64, env._fov, 1, flags=env._rflags).clone()
+
+
+def test_device_frame_stack_restarts_blank_on_in_kernel_respawn(small_world):
+    """auto_reset=True: an env that finishes is re-spawned inside the step kernel; its stacked observation of that very
+    step must be (blank, blank, first frame of the new episode), and every other env keeps (t-1, t, t+1)"""
+    cfg = EnvConfig(seed=21, distance_cutoff=0.25, max_environment_steps=25)
+    B = 96
+    env = BatchedWaypointEnv(cfg, small_world, num_envs=B, device=DEV, frame_stack=3)
+    obs = env.reset()
+    assert not obs[:, :6].any() and torch.equal(obs[:, 6:], _single_frames(env))
+    hist = [torch.zeros_like(obs[:, :3]), torch.zeros_like(obs[:, :3]), obs[:, 6:].clone()]
+    g = torch.Generator().manual_seed(3)
+    n_done = 0
+    for t in range(70):
+        a = torch.stack([torch.rand(B, generator=g) * 2 - 1, torch.rand(B, generator=g) * 0.6 - 0.3], -1)
+        obs, rew, term, trunc, info = env.step(a)
+        done = (term | trunc)
+        cur = _single_frames(env)
+        hist = [hist[1], hist[2], cur]
+        for j in range(2):
+            hist[j] = torch.where(done[:, None, None, None], torch.zeros_like(cur), hist[j])
+        want = torch.cat(hist, 1)
+        assert torch.equal(obs, want), (t, int((obs != want).any(3).any(2).any(1).sum()))
+        n_done += int(done.sum())
+    assert n_done > B                                      # many episodes ended and restarted along the way
+    sd = env.state_dict()
+    o1, *_ = env.step(torch.zeros(B, 2))
+    o1 = o1.clone()
+    env.step(torch.ones(B, 2) * 0.1)
+    env.load_state_dict(sd)
+    o2, *_ = env.step(torch.zeros(B, 2))
+    assert torch.equal(o1, o2)                             # the ring and its phase are part of the checkpoint
+
+
+@pytest.mark.parametrize("copy_obs", [True, False])
+def test_vecenv_frame_stack_terminal_observation_and_episode_stats(small_world, copy_obs):
+    """the SB3 path at frame_stack=3 (the reference's VecFrameStack(n_stack=3)): envs that did not finish keep
+    (t-1, t, t+1) - the masked reset must not touch their stack -, finished envs return (blank, blank, first frame) with
+    the pre-reset stack in info['terminal_observation'], and Monitor's info['episode'] = {r, l, t}"""
+    cfg = EnvConfig(seed=31, distance_cutoff=0.25, max_environment_steps=30)
+    B = 64
+    env = BatchedWaypointEnv(cfg, small_world, num_envs=B, device=DEV, frame_stack=3)
+    venv = WaypointVecEnv(env, copy_obs=copy_obs)
+    assert venv.num_envs == B and venv.observation_space.shape == (9, 64, 64) and venv.action_space.shape == (2,)
+    obs = venv.reset()
+    assert obs.shape == (B, 9, 64, 64) and obs.dtype == np.uint8 and not obs[:, :6].any()
+    hist = [np.zeros_like(obs[:, :3]), np.zeros_like(obs[:, :3]), obs[:, 6:].copy()]
+    rng = np.random.default_rng(1)
+    ret, length, n_done = np.zeros(B), np.zeros(B, np.int64), 0
+    for t in range(80):
+        acts = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1)
+        obs, rew, done, infos = venv.step(acts)
+        assert obs.shape == (B, 9, 64, 64) and rew.shape == (B,) and rew.dtype == np.float32 and done.dtype == bool
+        assert isinstance(infos, LazyInfos) and len(infos) == B
+        ret += rew.astype(np.float64)
+        length += 1
+        cur = obs[:, 6:].copy()                            # newest frame: post-reset for the finished envs
+        pre = [hist[1], hist[2]]
+        for i in range(B):
+            info = infos[i]
+            if done[i]:
+                n_done += 1
+                tob = info["terminal_observation"]
+                assert tob.shape == (9, 64, 64)
+                assert np.array_equal(tob[:3], pre[0][i]) and np.array_equal(tob[3:6], pre[1][i])
+                assert not obs[i, :6].any()                # the new episode's stack restarts blank
+                ep = info["episode"]
+                assert ep["l"] == length[i] and ep["r"] == round(ret[i], 6) and ep["t"] >= 0
+                assert info["TimeLimit.truncated"] == (info["is_success"] and not
+                                                        (info["offroad"] or info["collision"] or info["traffic_light_violation"]))
+                ret[i], length[i] = 0.0, 0
+            else:
+                assert "terminal_observation" not in info and "episode" not in info
+                assert np.array_equal(obs[i, :3], pre[0][i]) and np.array_equal(obs[i, 3:6], pre[1][i]), (t, i)
+        hist = [np.where(done[:, None, None, None], 0, pre[0]), np.where(done[:, None, None, None], 0, pre[1]), cur]
+        hist = [h.astype(np.uint8) for h in hist]
+        assert (env.state["steps"].cpu().numpy()[done] == 0).all()
+    assert n_done > B
+    assert venv.env_is_wrapped(object) == [False] * B and venv.get_attr("num_envs", [0, 1]) == [B, B]
+    assert len(venv.get_images()) == B and venv.seed(1) == [None] * B
+    venv.close()
+
+
+def test_vecenv_state_obs_matches_device_api(small_world):
+    """numpy path == device path on the same seeds (obs_mode 'state'), infos columns included"""
+    cfg = EnvConfig(seed=41, distance_cutoff=0.25, max_environment_steps=40)
+    B = 128
+    a = BatchedWaypointEnv(cfg, small_world, num_envs=B, device=DEV, obs_mode="state")
+    b = BatchedWaypointEnv(cfg, small_world, num_envs=B, device=DEV, obs_mode="state")
+    venv = b.as_vec_env()
+    oa, ob = a.reset(), venv.reset()
+    assert np.array_equal(oa.cpu().numpy(), ob)
+    rng = np.random.default_rng(2)
+    for t in range(90):
+        acts = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        oa, ra, ta, tra, ia = a.step(torch.from_numpy(acts))
+        ob, rb, db, ib = venv.step(acts)
+        assert np.array_equal(oa.cpu().numpy(), ob) and np.array_equal(ra.cpu().numpy(), rb)
+        assert np.array_equal((ta | tra).cpu().numpy(), db)
+        assert np.array_equal(ia["offroad"].cpu().numpy(), ib.column("offroad"))
+        assert np.array_equal(ia["reached_waypoint_num"].cpu().numpy(), ib.column("reached_waypoint_num"))
+        assert np.array_equal(ia["psi_reward"].cpu().numpy(), ib.column("psi_reward"))
+
+
+def test_config_rejections_and_world_threshold_on_the_env(small_world):
+    with pytest.raises(NotImplementedError):
+        BatchedWaypointEnv(EnvConfig(render_mode="video"), small_world, num_envs=2, device=DEV)
+    with pytest.raises(NotImplementedError):
+        BatchedWaypointEnv(EnvConfig(simulator=SimulatorConfig(collision_metric="iou")), small_world, num_envs=2, device=DEV)
+    with pytest.raises(ValueError):                        # the prebuilt World's grid index was built for 0.5 m
+        BatchedWaypointEnv(EnvConfig(simulator=SimulatorConfig(offroad_threshold=0.8)), small_world, num_envs=2, device=DEV)
+    # left-handed (the reference's default) vs right-handed observation of the same state: mirror images
+    lh = BatchedWaypointEnv(EnvConfig(seed=5), small_world, num_envs=8, device=DEV)
+    rh = BatchedWaypointEnv(EnvConfig(seed=5, simulator=SimulatorConfig(
+        renderer=RendererConfig(left_handed_coordinates=False), left_handed_coordinates=False)), small_world, num_envs=8,
+        device=DEV)
+    ol, orr = lh.reset(), rh.reset()
+    assert torch.equal(ol, orr.flip(-1)) and not torch.equal(ol, orr)

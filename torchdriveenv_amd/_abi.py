@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 4
+TDE_ABI_VERSION = 5
 TDE_MAX_AGENTS = 64
 
 F_NPC = 1 << 0
@@ -47,7 +47,7 @@ class TdeConfig(C.Structure):
         ("flags", C.c_uint32),
         ("npc_cone_range", C.c_float),
         ("env_base", C.c_uint32),
-        ("_pad0", C.c_int32),
+        ("offroad_threshold_squared", C.c_int32),
     ]
 
 
@@ -88,7 +88,8 @@ STATE_AGENT_I32 = ["route_wp"]
 STATE_AGENT_U8 = ["present", "collided", "offroad"]
 STATE_ENV_I32 = ["scn", "steps", "target_idx", "reached", "episode"]
 STATE_PTRS = (STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8 + STATE_ENV_I32 +
-              ["action", "reward", "terminated", "truncated", "tl_violation", "info", "info_reached", "done_bits", "obs"])
+              ["action", "reward", "terminated", "truncated", "tl_violation", "info", "info_reached", "done_bits", "obs",
+               "ep_return", "ep_final", "ep_final_len"])
 
 
 class TdeState(C.Structure):
@@ -101,10 +102,15 @@ class TdeRollout(C.Structure):
 
 class TdeRender(C.Structure):
     _fields_ = [("out", _p), ("H", C.c_int32), ("W", C.c_int32), ("fov", C.c_float), ("n_stack", C.c_int32),
-                ("layers", _p), ("phase", C.c_int32), ("_pad", C.c_int32)]
+                ("layers", _p), ("phase", C.c_int32), ("flags", C.c_int32), ("fresh", _p), ("only", _p)]
 
 
 LAYER_BLANK = 5
+LAYER_STOP_RED, LAYER_STOP_GO = 6, 7
+RENDER_LEFT_HANDED, RENDER_PLAIN_EGO = 1 << 0, 1 << 1
+# palette of the layer codes 0..7 (tde_abi.h TDE_RGB_*): background, road, waypoint, NPC, ego, blank, stop red, stop go
+PALETTE = ((255, 255, 255), (128, 128, 128), (44, 160, 44), (31, 119, 180), (214, 39, 40), (0, 0, 0), (255, 0, 0),
+           (0, 255, 0))
 
 
 def ptr_of(a):
@@ -143,6 +149,7 @@ def default_config(**over):
     cfg.terminated_at_infraction = 1
     cfg.flags = F_ALL
     cfg.env_base = 0
+    cfg.offroad_threshold_squared = 0
     for k, v in over.items():
         if not hasattr(cfg, k):
             raise AttributeError(f"tde_config has no field {k!r}")
@@ -160,7 +167,8 @@ STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n
                 **{n: np.uint8 for n in STATE_AGENT_U8}, **{n: np.int32 for n in STATE_ENV_I32},
                 "action": np.float32, "reward": np.float32, "terminated": np.uint8, "truncated": np.uint8,
                 "tl_violation": np.uint8,
-                "info": np.float64, "info_reached": np.int32, "done_bits": np.uint8, "obs": np.float32}
+                "info": np.float64, "info_reached": np.int32, "done_bits": np.uint8, "obs": np.float32,
+                "ep_return": np.float64, "ep_final": np.float64, "ep_final_len": np.int32}
 
 
 def state_shapes(B, A):
@@ -168,7 +176,8 @@ def state_shapes(B, A):
     sh.update({n: (B,) for n in STATE_ENV_I32})
     sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "tl_violation": (B,),
                "info": (B, 4),
-               "info_reached": (B,), "done_bits": (B,), "obs": (B, 8)})
+               "info_reached": (B,), "done_bits": (B,), "obs": (B, 8), "ep_return": (B,), "ep_final": (B,),
+               "ep_final_len": (B,)})
     return sh
 
 

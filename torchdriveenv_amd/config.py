@@ -20,6 +20,9 @@ class SimulatorConfig:
     collision_metric: str = "nograd"          # CollisionMetric.nograd, ref gym_env.py:48
     left_handed_coordinates: bool = True      # ref gym_env.py:49
     offroad_threshold: float = 0.5            # TorchDriveConfig default (not overridden by the env)
+    # how the threshold meets the point-to-mesh distance (torchdrivesim internals are not in the reference repository):
+    # False: distance > threshold; True: SQUARED distance > threshold (pytorch3d-style point_mesh distance)
+    offroad_threshold_squared: bool = False
     # heuristic NPC controller (stands where the IAI call was, ref gym_env.py:285-294)
     npc_k_steer: float = 1.2
     npc_k_speed: float = 3.0
@@ -67,10 +70,42 @@ class WaypointSuite:
     scenarios: List[Optional[Scenario]] = None
 
 
+def validate(cfg: EnvConfig):
+    """Reject what this path does not implement instead of silently ignoring it (the reference accepts these through
+    TorchDriveConfig, ref gym_env.py:46-49, 75-80, 295-297)."""
+    sim = cfg.simulator
+    if str(getattr(sim.collision_metric, "name", sim.collision_metric)) != "nograd":
+        raise NotImplementedError(f"collision_metric={sim.collision_metric!r}: only CollisionMetric.nograd (the reference's "
+                                  "setting, gym_env.py:48) is implemented: strict OBB overlap")
+    if cfg.render_mode == "video":
+        raise NotImplementedError("render_mode='video' (BirdviewRecordingWrapper, gym_env.py:295-297) is not part of the "
+                                  "step path; use render_mode='rgb_array' and record the frames render() returns")
+    if cfg.render_mode not in (None, "rgb_array"):
+        raise NotImplementedError                                   # ref gym_env.py:79-80
+    if sim.left_handed_coordinates != sim.renderer.left_handed_coordinates:
+        raise NotImplementedError("simulator.left_handed_coordinates and renderer.left_handed_coordinates differ: the "
+                                  "reference sets both (gym_env.py:46-49); here the flag mirrors the birdview's lateral axis "
+                                  "(the kinematic model is built with its default handedness, gym_env.py:245)")
+    if sim.npc_cone_k < 0:
+        raise ValueError("simulator.npc_cone_k must be >= 0")
+    if sim.offroad_threshold <= 0:
+        raise ValueError("simulator.offroad_threshold must be > 0")
+
+
+def render_flags(cfg: EnvConfig):
+    """tde_render.flags of this config (RendererConfig, ref gym_env.py:46-47)"""
+    from . import _abi
+
+    r = cfg.simulator.renderer
+    return ((_abi.RENDER_LEFT_HANDED if r.left_handed_coordinates else 0) |
+            (0 if r.highlight_ego_vehicle else _abi.RENDER_PLAIN_EGO))
+
+
 def to_tde_config(cfg: EnvConfig, seed: int, flags: int):
     """EnvConfig -> the C-ABI's tde_config"""
     from . import _abi
 
+    validate(cfg)
     sim = cfg.simulator
     return _abi.default_config(
         waypoint_bonus=float(cfg.waypoint_bonus), heading_penalty=float(cfg.heading_penalty),
@@ -79,4 +114,5 @@ def to_tde_config(cfg: EnvConfig, seed: int, flags: int):
         offroad_threshold=float(sim.offroad_threshold), npc_k_steer=sim.npc_k_steer, npc_k_speed=sim.npc_k_speed,
         npc_gap_s0=sim.npc_gap_s0, npc_cone_k=sim.npc_cone_k, npc_cone_range=sim.npc_cone_range,
         npc_lane_half=sim.npc_lane_half, npc_reach=sim.npc_reach, npc_max_accel=sim.npc_max_accel,
-        npc_max_steer=sim.npc_max_steer, flags=flags)
+        npc_max_steer=sim.npc_max_steer, flags=flags,
+        offroad_threshold_squared=int(bool(sim.offroad_threshold_squared)))

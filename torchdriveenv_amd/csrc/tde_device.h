@@ -61,6 +61,12 @@ TDE_DEV float sin_small_f32(float x)
     return s;
 }
 
+// the squared threshold d^2 is compared with (tde_config.offroad_threshold_squared selects the reading of upstream)
+TDE_DEV float thr2_of(const tde_config &cfg)
+{
+    return cfg.offroad_threshold_squared ? cfg.offroad_threshold : cfg.offroad_threshold * cfg.offroad_threshold;
+}
+
 TDE_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
 // torch.remainder(a, b) for b > 0: result in [0, b).  fmodf is exact, so the two fast paths (|a| < b: a itself;

@@ -389,6 +389,7 @@ struct StepOut {
     float reward;
     uint8_t terminated, truncated, collided, offroad, tl;
     bool respawned;
+    int k;                      // environment_steps of this step (before any re-spawn zeroes the counter)
 };
 
 // lights of map m that are red at env step k (the cycle restarts with the episode)
@@ -515,10 +516,11 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     const int base = tid - a;                       // first lane of this env inside the workgroup
     bool live = valid && ag.present;
     const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-    StepOut out{0.0f, 0, 0, 0, 0, 0, false};
+    StepOut out{0.0f, 0, 0, 0, 0, 0, false, 0};
 
     er.steps += 1;                                  // :116
     const int k = er.steps;
+    out.k = k;
 
     // replayed agents take their recorded state at time k (:275-283); issue the read ahead of the sweeps
     const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
@@ -563,7 +565,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     if (switched) load_route_target(cold, ag, cx);
 
     bool off = false;
-    if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, cfg.offroad_threshold * cfg.offroad_threshold);
+    if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2_of(cfg));
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
@@ -662,6 +664,16 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
         if (reward_k) reward_k[e] = o.reward;
         if (done_k)
             done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
+        if (st.ep_return) {
+            // Monitor-style episode statistics (examples/rl_training.py:123-128): float64 sum of the episode's rewards
+            double ret = st.ep_return[e] + (double)o.reward;
+            if (o.terminated | o.truncated) {
+                if (st.ep_final) st.ep_final[e] = ret;
+                if (st.ep_final_len) st.ep_final_len[e] = o.k;
+                if (o.respawned) ret = 0.0;
+            }
+            st.ep_return[e] = ret;
+        }
         if (OBS && st.obs) {
             // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it.  The cached
             // ego target is current unless the reward path is off or the episode just ended without a re-spawn.
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
-    StepOut o{0.0f, 0, 0, 0, 0, 0, false};
+    StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
         const float2 act_next = acts[(int64_t)kn * B + es];      // in flight during this step
@@ -949,8 +961,8 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         // ================================ judge ================================
         TDE_ROLE_PROLOGUE
         RedCache redc; redc.invalidate();
-        StepOut o{0.0f, 0, 0, 0, 0, 0, false};
-        const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
+        StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
+        const float thr2 = thr2_of(cfg);
         lds_barrier();
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1;
@@ -969,7 +981,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             bool tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
                 tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
-            o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false};
+            o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
             unsigned long long any = 0ull;
             if (F & TDE_F_REWARD) {                          // R8 / R11: the flags settle here (reward: the driver)
                 int done = 0;
@@ -1215,7 +1227,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         __builtin_amdgcn_s_setprio(0);
         TDE_ROLE_PROLOGUE
         RedCache redc; redc.invalidate();
-        const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
+        const float thr2 = thr2_of(cfg);
         bool off = false, tl = false;
         // action relay: this wavefront (lowest priority, off the simulation's serial chain) fetches the ego actions two
         // steps ahead and parks them in LDS for the driver
@@ -1282,6 +1294,7 @@ __global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_w
     st.offroad[g] = 0;
     if (a == 0) {
         st.scn[e] = er.scn; st.steps[e] = 0; st.target_idx[e] = 1; st.reached[e] = 0; st.episode[e] = er.episode;
+        if (st.ep_return) st.ep_return[e] = 0.0;
     }
 }
 
@@ -1394,6 +1407,7 @@ constexpr int kRenderMaxWp = 64;
 constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS layer plane, one byte per pixel)
 constexpr int kRenderWork = 2048;                 // exact-pixel queue (a view that needs more takes the all-pixels path)
 constexpr int kRenderMaxBox = 40;                 // agent boxes kept per view (more: all-pixels path)
+constexpr int kRenderMaxStop = 16;                // stop lines kept per view (more: all-pixels path)
 
 // compact observation of the ego (obs_mode "state" of the host mirror): one lane per env
 __global__ __launch_bounds__(kBlock) void state_obs_kernel(tde_world w, tde_state st, float *__restrict__ out)
@@ -1473,25 +1487,31 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     __shared__ float2 s_wp[kRenderMaxWp];
     __shared__ PixelSpan s_wpbb[kRenderMaxWp];
     __shared__ RenderBox s_ego;
+    __shared__ RenderBox s_stop[kRenderMaxStop];         // stop lines in view
+    __shared__ uint8_t s_stopl[kRenderMaxStop];          // their layer (TDE_LAYER_STOP_RED / _GO)
     __shared__ uint16_t s_work[kRenderWork];             // pixels whose base layer needs the exact test (r * W + c)
     __shared__ uint32_t s_mixed[kRenderWork];            // cell words of the queued pixels that lie in MIXED cells
-    __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed;
+    __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed, s_nstop;
     const int tid = threadIdx.x;
     const int A = st.A, H = rd.H, W = rd.W;
     const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
     const int plane = H * W;
     const int e = blockIdx.x;      // (frame stack: see pass 4; without a layer ring frame_shift_kernel ran before this launch)
+    if (rd.only && !rd.only[e]) return;            // masked call: this view keeps its pixels and its ring
     uint8_t *out = rd.out + (int64_t)e * 3 * ns * plane;
     const int64_t g0 = (int64_t)e * A;
     const int scn = st.scn[e];
     const int4 sc = reinterpret_cast<const int4 *>(w.scn)[scn];
     const tde_map m = w.maps[sc.x];
-    const float thr2 = cfg.offroad_threshold * cfg.offroad_threshold;
+    const float thr2 = thr2_of(cfg);
+    const bool lights = (cfg.flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    const float lsign = (rd.flags & TDE_RENDER_LEFT_HANDED) ? -1.0f : 1.0f;   // left-handed world: lateral image axis mirrored
+    const int ego_layer = (rd.flags & TDE_RENDER_PLAIN_EGO) ? TDE_LAYER_NPC : TDE_LAYER_EGO;
     const float res = rd.fov / (float)W;
     const float inv_res = 1.0f / res;
     const float halfH = 0.5f * (float)H, halfW = 0.5f * (float)W;
     const float rview = 0.75f * res * (float)(H > W ? H : W) + 1.0f;   // view circle: lists are supersets
-    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }
+    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; s_nstop = 0; }
     const float ex = st.x[g0], ey = st.y[g0];
     float se, ce;
     sincos_f32(st.psi[g0], se, ce);
@@ -1506,13 +1526,13 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     };
     auto disc_span = [=](float x, float y, float rad) -> PixelSpan {
         const float dx = x - ex, dy = y - ey;
-        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
+        const float f = dx * ce + dy * se, l = (dy * ce - dx * se) * lsign;
         const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.0f;
         return clip(rc - pr, rc + pr, cc - pr, cc + pr);
     };
     auto box_span = [=](float x, float y, float cb, float sb, float hl, float hw) -> PixelSpan {
         const float dx = x - ex, dy = y - ey;
-        const float f = dx * ce + dy * se, l = dy * ce - dx * se;
+        const float f = dx * ce + dy * se, l = (dy * ce - dx * se) * lsign;
         const float cr = cb * ce + sb * se, sr = sb * ce - cb * se;      // box heading relative to the ego's
         const float ef = fabsf(cr) * hl + fabsf(sr) * hw, el = fabsf(sr) * hl + fabsf(cr) * hw;
         const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f;
@@ -1553,6 +1573,25 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             }
         }
     }
+    if (lights && m.n_stop > 0) {
+        // stop lines of the map, coloured by the state of their light at the env's current step (oracle: tde_red_mask)
+        const uint32_t red = red_mask(w, m, st.steps[e]);
+        for (int q = tid; q < m.n_stop; q += kBlock) {
+            const float4 la = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[0];
+            const float4 lb = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[1];   // hl, hw, light, -
+            const float dx = la.x - ex, dy = la.y - ey, rr = rview + (lb.x + lb.y);
+            if (dx * dx + dy * dy <= rr * rr) {
+                const int at = atomicAdd(&s_nstop, 1);
+                if (at < kRenderMaxStop) {
+                    const PixelSpan bb = box_span(la.x, la.y, la.z, la.w, lb.x, lb.y);
+                    RenderBox &d = s_stop[at];
+                    d.x = la.x; d.y = la.y; d.c = la.z; d.s = la.w; d.hl = lb.x; d.hw = lb.y;
+                    d.rmin = bb.rmin; d.rmax = bb.rmax; d.cmin = bb.cmin; d.cmax = bb.cmax;
+                    s_stopl[at] = ((red >> __float_as_int(lb.z)) & 1u) ? TDE_LAYER_STOP_RED : TDE_LAYER_STOP_GO;
+                }
+            }
+        }
+    }
     // no barrier here: pass 1 does not read the lists, so the wavefronts without culling work start it at once and the
     // few culling lanes' dependent loads hide behind it (the lists are complete at the barrier that ends pass 1)
     uint8_t *lay8 = reinterpret_cast<uint8_t *>(s_layer);
@@ -1560,7 +1599,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     const int Wq = W / 4;                                 // dwords per image row
     auto pixel_world = [=](int r, int c, float &wx, float &wy) {
         const float f = (halfH - ((float)r + 0.5f)) * res;
-        const float l = (halfW - ((float)c + 0.5f)) * res;
+        const float l = ((halfW - ((float)c + 0.5f)) * res) * lsign;
         wx = (ex + f * ce) - l * se;
         wy = (ey + f * se) + l * ce;
     };
@@ -1586,7 +1625,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
                 const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
-                const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = (halfW - ((float)(c0 + dc) + 1.0f)) * res;
+                const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = ((halfW - ((float)(c0 + dc) + 1.0f)) * res) * lsign;
                 ws[sb] = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
             }
             uint32_t need = 0;                                     // bit (dr*4 + dc): pixel needs the exact test
@@ -1615,8 +1654,8 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         }
     }
     __syncthreads();
-    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp;
-    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp;
+    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp || s_nstop > kRenderMaxStop;
+    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp, nstop = crowded ? 0 : s_nstop;
     const bool all_pixels = crowded || s_nwork > kRenderWork;
     if (all_pixels) {
         // rare fallback (more boxes / waypoints / edge pixels in view than the LDS lists hold): every pixel is shaded
@@ -1626,6 +1665,17 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             float wx, wy;
             pixel_world(pix / W, pix % W, wx, wy);
             int layer = base_layer(wx, wy);
+            if (lights) {
+                const uint32_t red = red_mask(w, m, st.steps[e]);
+                for (int q = 0; q < m.n_stop; ++q) {
+                    const float4 la = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[0];
+                    const float4 lb = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[1];
+                    const float dx = wx - la.x, dy = wy - la.y;
+                    const float p = dx * la.z + dy * la.w, q2 = dy * la.z - dx * la.w;
+                    if (fabsf(p) <= lb.x && fabsf(q2) <= lb.y)
+                        layer = ((red >> __float_as_int(lb.z)) & 1u) ? TDE_LAYER_STOP_RED : TDE_LAYER_STOP_GO;
+                }
+            }
             for (int k = ti; k < n_wp; ++k) {
                 const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
                 const float dx = wx - (float)t.x, dy = wy - (float)t.y;
@@ -1638,7 +1688,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
                 sincos_f32(st.psi[g], sa, ca);
                 const float dx = wx - st.x[g], dy = wy - st.y[g];
                 const float p = dx * ca + dy * sa, q = dy * ca - dx * sa;
-                if (fabsf(p) <= 0.5f * st.len[g] && fabsf(q) <= 0.5f * st.wid[g]) layer = a ? 3 : 4;
+                if (fabsf(p) <= 0.5f * st.len[g] && fabsf(q) <= 0.5f * st.wid[g]) layer = a ? TDE_LAYER_NPC : ego_layer;
             }
             lay8[pix] = (uint8_t)layer;
         }
@@ -1684,6 +1734,21 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         // ---- pass 3: objects over the base, in layer order (waypoint discs, NPC boxes, the ego): the workgroup covers
         // an object's conservative pixel span as a 16 x 16 tile of threads (one pixel per thread at 64 x 64) ------------
         const int tr = tid >> 4, tc = tid & 15;
+        for (int k = 0; k < nstop; ++k) {                     // stop lines lie on the road, under everything else
+            const RenderBox &b = s_stop[k];
+            const float bx = b.x, by = b.y, bc = b.c, bs = b.s, bhl = b.hl, bhw = b.hw;
+            const int rmax = b.rmax, cmin = b.cmin, cmax = b.cmax;
+            const uint8_t lay = s_stopl[k];
+            for (int r = b.rmin + tr; r <= rmax; r += 16)
+                for (int c = cmin + tc; c <= cmax; c += 16) {
+                    float wx, wy;
+                    pixel_world(r, c, wx, wy);
+                    const float dx = wx - bx, dy = wy - by;
+                    const float p = dx * bc + dy * bs, q = dy * bc - dx * bs;
+                    if (fabsf(p) <= bhl && fabsf(q) <= bhw) lay8[r * W + c] = lay;
+                }
+        }
+        if (nstop > 0) __syncthreads();
         for (int k = 0; k < nwp; ++k) {
             const PixelSpan b = s_wpbb[k];
             const float2 t = s_wp[k];
@@ -1719,7 +1784,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
                     pixel_world(r, c, wx, wy);
                     const float dx = wx - ex, dy = wy - ey;
                     const float p = dx * ce + dy * se, q = dy * ce - dx * se;
-                    if (fabsf(p) <= ehl && fabsf(q) <= ehw) lay8[r * W + c] = 4;
+                    if (fabsf(p) <= ehl && fabsf(q) <= ehw) lay8[r * W + c] = (uint8_t)ego_layer;
                 }
         }
     }
@@ -1728,11 +1793,12 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     // ---- pass 4: layers -> colours, streamed out ---------------------------------------------------------------
     // v_perm_b32 is a byte look-up in an 8-entry table: entries 0-4 the palette, 5 = TDE_LAYER_BLANK (0, 0, 0).
     const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
-                   NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO};
+                   NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO}, SRED[3] = {TDE_RGB_STOP_RED}, SGO[3] = {TDE_RGB_STOP_GO};
     auto expand = [&](const uint4 &v, uint8_t *frame, int i) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const uint32_t lo = BG[ch] | (ROAD[ch] << 8) | (WP[ch] << 16) | (NPC[ch] << 24), hi = EGO[ch];
+            const uint32_t lo = BG[ch] | (ROAD[ch] << 8) | (WP[ch] << 16) | (NPC[ch] << 24);
+            const uint32_t hi = EGO[ch] | (SRED[ch] << 16) | (SGO[ch] << 24);          // entry 5 = TDE_LAYER_BLANK = 0
             uint4 o;
             o.x = __builtin_amdgcn_perm(hi, lo, v.x); o.y = __builtin_amdgcn_perm(hi, lo, v.y);
             o.z = __builtin_amdgcn_perm(hi, lo, v.z); o.w = __builtin_amdgcn_perm(hi, lo, v.w);
@@ -1744,6 +1810,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     };
     const uint4 *src = reinterpret_cast<const uint4 *>(s_layer);
     const int nv = plane / 16;
+    const bool fresh = rd.fresh && (rd.fresh[e] & 3);   // the episode of this view just (re)started: older frames are blank
     if (ns > 1 && rd.layers) {
         // frame stack from the ring of layer planes: slot of the new frame = phase % ns; output frame j (oldest first)
         // is ring slot (phase + 1 + j) % ns.  Nothing is shifted: every frame of `out` is written from its layer plane.
@@ -1754,13 +1821,23 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             reinterpret_cast<uint4 *>(ring + (int64_t)slot_new * plane)[i] = v;
             expand(v, out + 3 * (ns - 1) * plane, i);
         }
+        const uint32_t bl = TDE_LAYER_BLANK * 0x01010101u;
         for (int j = 0; j < ns - 1; ++j) {
             const int slot = (rd.phase + 1 + j) % ns;
-            const uint4 *old = reinterpret_cast<const uint4 *>(ring + (int64_t)slot * plane);
-            for (int i = tid; i < nv; i += kBlock) expand(old[i], out + 3 * j * plane, i);
+            uint4 *old = reinterpret_cast<uint4 *>(ring + (int64_t)slot * plane);
+            for (int i = tid; i < nv; i += kBlock) {
+                uint4 v;
+                if (fresh) { v = make_uint4(bl, bl, bl, bl); old[i] = v; }     // VecFrameStack: the stack restarts blank
+                else v = old[i];
+                expand(v, out + 3 * j * plane, i);
+            }
         }
     } else {
         for (int i = tid; i < nv; i += kBlock) expand(src[i], out + 3 * (ns - 1) * plane, i);
+        if (fresh && ns > 1) {                       // in-place stack (no ring): blank the older frames of this view
+            uint4 *o4 = reinterpret_cast<uint4 *>(out);
+            for (int i = tid; i < 3 * (ns - 1) * nv; i += kBlock) o4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 }
 
@@ -1967,8 +2044,9 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     if (rd->H <= 0 || rd->W <= 0 || (rd->W % 4) != 0 || (rd->H % 4) != 0 || (rd->H * rd->W) % 16 != 0 ||
         rd->H * rd->W > tde::kRenderMaxPix)
         return bad("tde_render_ego: H and W must be positive multiples of 4 with H*W <= 4096");
+    if (rd->phase < 0) return bad("tde_render_ego: phase must be >= 0 (keep it reduced modulo n_stack)");
     if (st->B <= 0) return 0;
-    if (rd->n_stack > 1 && !rd->layers)
+    if (rd->n_stack > 1 && !rd->layers && !rd->only)       // (a masked call re-renders the newest frame in place)
         tde::frame_shift_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(rd->out, rd->H * rd->W, rd->n_stack);
     tde::render_layers_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
     hipError_t e = hipGetLastError();

@@ -14,9 +14,9 @@ import numpy as np
 import torch
 
 from . import _abi, ops
-from .config import EnvConfig, WaypointSuite, to_tde_config
+from .config import EnvConfig, WaypointSuite, render_flags, to_tde_config, validate
 from .state import EnvState
-from .world import World, assemble_world, corridor_mesh
+from .world import World, assemble_world, check_threshold, corridor_mesh, effective_offroad_distance
 
 try:  # optional: neither gymnasium nor SB3 ships in this image
     import gymnasium as gym
@@ -196,17 +196,20 @@ class BatchedWaypointEnv:
     step(actions [B,2]) -> (obs, reward f32[B], terminated bool[B], truncated bool[B], info dict of [B] tensors), all
     device-resident torch tensors.  obs is the ego-centred birdview uint8 [B, 3*frame_stack, 64, 64] (obs_mode
     "birdview", the reference's observation, ref gym_env.py:95,122-124) or a compact float32 [B, 8] kinematic vector
-    (obs_mode "state").  Finished envs are re-spawned inside the same kernel (auto_reset=True).
+    (obs_mode "state").  Finished envs are re-spawned inside the same kernel (auto_reset=True); with a frame stack their
+    older frames restart blank in the same observation (VecFrameStack semantics, ref examples/rl_training.py:160).
     reward / terminated / truncated are the env's own buffers, overwritten by the next step (clone what must be
     kept).  (Replaying step + observation from a captured HIP graph was measured and is slower than the two direct
-    launches: 27.9 vs 18.5 us per step at 8192 envs.)"""
+    launches: 27.9 vs 18.5 us per step at 8192 envs.)
+
+    The SB3 `VecEnv` interface (numpy in / out, `terminal_observation`, `TimeLimit.truncated`, Monitor's
+    `info["episode"]`) is `as_vec_env()` -> WaypointVecEnv."""
 
     metadata = {"render_modes": ["rgb_array"], "render_fps": 10}   # ref gym_env.py:73-76
 
     def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
-                 frame_stack=1, auto_reset=True, with_info=True, background=None):
-        if cfg.render_mode is not None and cfg.render_mode not in ("rgb_array", "video"):
-            raise NotImplementedError                              # ref gym_env.py:79-80
+                 frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0):
+        validate(cfg)                                              # ref gym_env.py:79-80 and the fields this path rejects
         if obs_mode not in ("birdview", "state"):
             raise ValueError("obs_mode must be 'birdview' or 'state'")
         self.config = cfg
@@ -217,9 +220,13 @@ class BatchedWaypointEnv:
         if background is None and cfg.use_background_traffic:        # ref gym_env.py:200-203: the packaged directory
             from .loaders import pick_background_traffic
             background = pick_background_traffic                     # (searched under TORCHDRIVEENV_DATA; None if absent)
+        sim = cfg.simulator
         self.world = data if isinstance(data, World) else world_from_waypoint_suite(
-            data, agents_per_env, threshold=cfg.simulator.offroad_threshold,
+            data, agents_per_env,
+            threshold=effective_offroad_distance(sim.offroad_threshold, sim.offroad_threshold_squared),
             background=background if cfg.use_background_traffic else None, ego_only=cfg.ego_only)
+        check_threshold(self.world, sim.offroad_threshold, sim.offroad_threshold_squared,
+                        "EnvConfig.simulator.offroad_threshold")   # a prebuilt World bakes its threshold into the grid
         self.A = self.world.A
         self.num_envs = int(num_envs)
         seed = cfg.seed if cfg.seed is not None else int(np.random.randint(0, 2**31 - 1))  # ref helpers.py:39-41
@@ -232,6 +239,7 @@ class BatchedWaypointEnv:
         if self.world.has_lights:
             flags |= _abi.F_TRAFFIC_LIGHTS
         self.tde_cfg = to_tde_config(cfg, seed, flags)
+        self.tde_cfg.env_base = int(env_base)                        # shard of a larger batch: sharding.ShardedBatchedEnv
         self.dworld = self.world.to_device(self.torch_device)
         # obs_mode "state": tde_env_step writes the compact observation itself (no second launch per step)
         self.state = EnvState(self.num_envs, self.A, device=self.torch_device, with_info=with_info,
@@ -239,24 +247,38 @@ class BatchedWaypointEnv:
         self.obs_mode, self.frame_stack = obs_mode, max(1, int(frame_stack))
         r = cfg.simulator.renderer
         self._res, self._fov = int(r.res), float(r.fov)
+        self._rflags = render_flags(cfg)
         self._obs = self._stack = None
         self.action_space = _box(ACTION_LOW, ACTION_HIGH)
         self.observation_space = (_box(0, 255, (3 * self.frame_stack, self._res, self._res), np.uint8)
                                   if obs_mode == "birdview" else _box(-np.inf, np.inf, (8,), np.float32))
         self.reward_range = (-float("inf"), float("inf"))           # ref gym_env.py:97
-        self._pending = None
+        self._vec = None
+
+    @property
+    def auto_reset(self):
+        return bool(self.tde_cfg.flags & _abi.F_AUTORESET)
 
     # ---- device-resident API ------------------------------------------------------------------------------
     def reset(self, seed=None, options=None, mask=None):
         """re-spawn all envs (or those in `mask`, uint8/bool [B]).  `seed` is ignored like in the reference
-        (ref gym_env.py:107-109); seeding is EnvConfig.seed."""
+        (ref gym_env.py:107-109); seeding is EnvConfig.seed.  With a mask only the re-spawned envs' observations
+        change: their newest frame is re-rendered in place and their older frames are blanked; the other envs keep
+        their frame stack exactly as the last step left it."""
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.torch_device).to(torch.uint8).contiguous()
         ops.env_reset(self.tde_cfg, self.dworld, self.state, m)
-        if self.obs_mode == "birdview" and self._stack is not None:
-            self._stack.clear(None if m is None else m.bool())       # VecFrameStack clears the stack on reset
-        return self.get_obs()
+        if self.obs_mode == "state" or m is None or self._obs is None:
+            if self._stack is not None:
+                self._stack.clear()                                  # VecFrameStack clears the stack on reset
+            return self.get_obs()
+        if self._stack is not None:
+            self._obs = self._stack.rerender(self.tde_cfg, self.dworld, self.state, m, self._fov)
+        else:
+            ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, self._obs,
+                           flags=self._rflags, only=m)
+        return self._obs
 
     def step(self, actions):
         a = actions if torch.is_tensor(actions) and actions.device == self.torch_device else \
@@ -264,26 +286,38 @@ class BatchedWaypointEnv:
         a = a.to(torch.float32).reshape(self.num_envs, 2).contiguous()
         ops.env_step(self.tde_cfg, self.dworld, self.state, action=a)
         st = self.state
+        if self.obs_mode == "state":
+            obs = st["obs"]
+        else:
+            fresh = None
+            if self.auto_reset and self.frame_stack > 1:
+                # envs that finished were re-spawned inside the kernel: their frame stack restarts blank.  The render
+                # kernel reads bits 0-1 of the mask, which is exactly the done part of done_bits
+                fresh = st["done_bits"] if st["done_bits"] is not None else (st["terminated"] | st["truncated"])
+            obs = self.get_obs(fresh)
         # uint8 0/1 flags seen as bool without a copy; info entries are only computed when they are read
-        obs = st["obs"] if self.obs_mode == "state" else self.get_obs()
         return (obs, st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool),
                 self.get_info())
 
     def rollout(self, actions):
-        """K open-loop steps from a resident [K,B,2] action tensor -> (reward [K,B], done bits [K,B])"""
+        """K open-loop steps from a resident [K,B,2] action tensor -> (reward [K,B], done bits [K,B]).  (The Monitor-style
+        episode statistics of the closed-loop API are not maintained across a rollout: they follow from the returned
+        arrays.)"""
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).contiguous()
         return ops.env_rollout(self.tde_cfg, self.dworld, self.state, a)
 
-    def get_obs(self):
+    def get_obs(self, fresh=None):
         if self.obs_mode == "state":
             # x, y, psi, v, target offset (forward, left) in the ego frame, target-exists flag, environment_steps
             return ops.state_obs(self.dworld, self.state, self.state["obs"])
         if self.frame_stack > 1:
             if self._stack is None:
-                self._stack = ops.FrameStack(self.num_envs, self.frame_stack, self._res, self._res, self.torch_device)
-            self._obs = self._stack.render(self.tde_cfg, self.dworld, self.state, self._fov)
+                self._stack = ops.FrameStack(self.num_envs, self.frame_stack, self._res, self._res, self.torch_device,
+                                             flags=self._rflags)
+            self._obs = self._stack.render(self.tde_cfg, self.dworld, self.state, self._fov, fresh=fresh)
             return self._obs
-        self._obs = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, self._obs)
+        self._obs = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, self._obs,
+                                   flags=self._rflags)
         return self._obs
 
     def get_info(self):
@@ -293,76 +327,236 @@ class BatchedWaypointEnv:
 
     def render(self):
         """(B, H, W, 3) uint8 of the current ego views (ref gym_env.py:152-155)"""
-        img = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1)
+        img = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, flags=self._rflags)
         return img.permute(0, 2, 3, 1).cpu().numpy()
 
     def close(self):
         pass
 
     def state_dict(self):
-        """snapshot of every mutable buffer (checkpoint / parity replays)"""
-        return {k: v.clone() for k, v in self.state.arrays.items() if v is not None}
+        """snapshot of every mutable buffer (checkpoint / parity replays), the frame-stack ring included"""
+        sd = {k: v.clone() for k, v in self.state.arrays.items() if v is not None}
+        if self._stack is not None:
+            sd["_frame_stack"] = self._stack.state_dict()
+        return sd
 
     def load_state_dict(self, sd):
         for k, v in sd.items():
-            self.state.arrays[k].copy_(v)
+            if k == "_frame_stack":
+                if self._stack is None:
+                    self._stack = ops.FrameStack(self.num_envs, self.frame_stack, self._res, self._res, self.torch_device,
+                                                 flags=self._rflags)
+                self._stack.load_state_dict(v)
+                self._obs = self._stack.obs
+            else:
+                self.state.arrays[k].copy_(v)
 
-    # ---- SB3 VecEnv-shaped numpy API (compatibility path: one D2H copy per step) -------------------------
+    # ---- SB3 VecEnv-shaped numpy API --------------------------------------------------------------------
+    def as_vec_env(self, **kw):
+        """the SB3 `VecEnv` over this batch (one shared adapter per env object)"""
+        if self._vec is None:
+            self._vec = WaypointVecEnv(self, **kw)
+        return self._vec
+
+    def step_async(self, actions):
+        self.as_vec_env().step_async(actions)
+
+    def step_wait(self):
+        return self.as_vec_env().step_wait()
+
+    def vec_step(self, actions):
+        return self.as_vec_env().step(actions)
+
+    def vec_reset(self):
+        return self.as_vec_env().reset()
+
+
+try:  # optional: stable_baselines3 does not ship in this image
+    from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnv
+except Exception:  # pragma: no cover
+    _SB3VecEnv = None
+
+
+class LazyInfos:
+    """The `infos` list of a VecEnv step (one mapping per env) without building num_envs dicts per step: entry i is
+    assembled from the per-env arrays when it is read.  Behaves like a list of dicts for the consumers SB3 has
+    (`infos[i]`, iteration, `len`, `.get("episode")`, `.get("terminal_observation")`, `.get("TimeLimit.truncated")`)."""
+
+    INFO_COLS = ("psi_smoothness", "speed_smoothness", "psi_reward", "dist_reward")
+
+    def __init__(self, n, cols, terminal):
+        self._n, self._cols, self._terminal = n, cols, terminal   # cols: name -> [n] array; terminal: env -> extra entries
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        d = {k: v[i].item() for k, v in self._cols.items()}
+        extra = self._terminal.get(i)
+        if extra:
+            d.update(extra)
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+    def column(self, key):
+        """the whole per-env column of `key` as one array (what a vectorised consumer should read)"""
+        return self._cols[key]
+
+
+class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
+    """stable_baselines3 `VecEnv` over a BatchedWaypointEnv, replacing `SubprocVecEnv` + `Monitor` + `VecFrameStack` of the
+    reference's trainer (ref examples/rl_training.py:121-129, 159-160): numpy actions in, (obs, rewards, dones, infos)
+    out, finished envs re-spawned at once with `terminal_observation`, `TimeLimit.truncated` and Monitor's
+    `episode = {"r", "l", "t"}` in their info.  Subclasses SB3's VecEnv when stable_baselines3 is importable; otherwise
+    the same methods on a plain class (tests/test_vecenv_contract.py walks the abstract interface).
+
+    Per step: one fused step launch, one observation launch, ONE packed device-to-host copy of all per-env outputs and
+    one of the observation, one stream synchronisation; `infos` is a LazyInfos.  copy_obs=False hands out views of a
+    ring of three pinned buffers (an observation stays valid for the two following steps) instead of fresh arrays."""
+
+    def __init__(self, env, copy_obs=True, info_keywords=("offroad", "collision", "traffic_light_violation", "is_success",
+                                                           "reached_waypoint_num", "psi_smoothness", "speed_smoothness",
+                                                           "psi_reward", "dist_reward")):
+        import time
+
+        self.env = env
+        if _SB3VecEnv is not None:
+            _SB3VecEnv.__init__(self, env.num_envs, env.observation_space, env.action_space)
+        else:
+            self.num_envs, self.observation_space, self.action_space = env.num_envs, env.observation_space, env.action_space
+            self.reset_infos = [{} for _ in range(env.num_envs)]
+            self._seeds = [None] * env.num_envs
+            self._options = [{} for _ in range(env.num_envs)]
+        self.render_mode = "rgb_array"
+        self.copy_obs = bool(copy_obs)
+        self.info_keywords = tuple(k for k in info_keywords
+                                   if env.state["info"] is not None or k not in LazyInfos.INFO_COLS + ("reached_waypoint_num",))
+        self._t_start = time.time()
+        self._pending = None
+        shape = (env.num_envs,) + tuple(env.observation_space.shape)
+        self._obs_ring = [torch.empty(shape, dtype=torch.uint8 if env.obs_mode == "birdview" else torch.float32,
+                                      pin_memory=True) for _ in range(1 if copy_obs else 3)]
+        self._turn = 0
+
+    # ---- helpers
+    def _obs_to_host(self, obs, rows=None):
+        buf = self._obs_ring[self._turn % len(self._obs_ring)]
+        buf.copy_(obs, non_blocking=True)
+        return buf
+
+    def reset(self):
+        obs = self.env.reset()
+        buf = self._obs_to_host(obs)
+        torch.cuda.current_stream(self.env.torch_device).synchronize()
+        self._turn += 1
+        self.reset_infos = [{} for _ in range(self.num_envs)]
+        out = buf.numpy()
+        return out.copy() if self.copy_obs else out
+
     def step_async(self, actions):
         self._pending = np.asarray(actions, dtype=np.float32)
 
     def step_wait(self):
+        import time
+
         if self._pending is None:
             raise RuntimeError("step_wait() without step_async()")
+        env = self.env
         acts, self._pending = self._pending, None
-        auto = bool(self.tde_cfg.flags & _abi.F_AUTORESET)
-        # terminal_observation needs the pre-reset frame: run the step without in-kernel reset, then reset the
+        auto = env.auto_reset
+        # terminal_observation needs the pre-reset frame: run the step without in-kernel reset, then re-spawn the
         # finished envs with the masked reset kernel
-        self.tde_cfg.flags &= ~_abi.F_AUTORESET
+        env.tde_cfg.flags &= ~_abi.F_AUTORESET
         try:
-            obs, rew, term, trunc, info = self.step(acts)
+            obs, _, _, _, _ = env.step(acts)
         finally:
             if auto:
-                self.tde_cfg.flags |= _abi.F_AUTORESET
-        done = (term | trunc)
-        obs_np = obs.cpu().numpy()                                   # a fresh host copy each step (D2H)
-        rew_np, done_np = rew.cpu().numpy(), done.cpu().numpy()
-        trunc_np, term_np = trunc.cpu().numpy(), term.cpu().numpy()
-        keys = info.keys()
-        cols = [info[k].cpu().numpy().tolist() for k in keys] + [(trunc_np & ~term_np).tolist()]
-        keys = keys + ["TimeLimit.truncated"]
-        infos = [dict(zip(keys, row)) for row in zip(*cols)]
-        if auto and done_np.any():
-            idx = np.nonzero(done_np)[0]
-            # only the re-spawned envs' first observations cross the bus
-            new_obs = self.reset(mask=done)[torch.as_tensor(idx, device=self.torch_device)].cpu().numpy()
+                env.tde_cfg.flags |= _abi.F_AUTORESET
+        buf = self._obs_to_host(obs)
+        out = env.state.fetch_outputs()                              # ONE copy of every per-env output + the stream sync
+        self._turn += 1
+        obs_np = buf.numpy()
+        if self.copy_obs:
+            obs_np = obs_np.copy()
+        term, trunc = out["terminated"].astype(bool), out["truncated"].astype(bool)
+        done = term | trunc
+        rew = out["reward"].copy()
+        bits = out.get("done_bits")
+        cols = {"TimeLimit.truncated": trunc & ~term}
+        for k in self.info_keywords:
+            if k == "offroad":
+                cols[k] = ((bits >> 2) & 1).astype(np.float32) if bits is not None else None
+            elif k == "collision":
+                cols[k] = ((bits >> 3) & 1).astype(np.float32) if bits is not None else None
+            elif k == "traffic_light_violation":
+                cols[k] = out["tl_violation"].astype(np.float32)
+            elif k == "is_success":
+                cols[k] = trunc.copy()
+            elif k == "reached_waypoint_num":
+                cols[k] = out["info_reached"].copy()
+            else:
+                cols[k] = out["info"][:, LazyInfos.INFO_COLS.index(k)].copy()
+        cols = {k: v for k, v in cols.items() if v is not None}
+        terminal = {}
+        if done.any():
+            idx = np.nonzero(done)[0]
+            ep_r = out["ep_final"][idx].copy() if "ep_final" in out else None
+            ep_l = out["ep_final_len"][idx].copy() if "ep_final_len" in out else None
+            t = round(time.time() - self._t_start, 6)
+            term_obs = obs_np[idx].copy()
+            if auto:
+                # only the re-spawned envs are reset and re-rendered; only their first observations cross the bus
+                dmask = torch.from_numpy(done.astype(np.uint8)).to(env.torch_device, non_blocking=True)
+                new = env.reset(mask=dmask)
+                sel = new[torch.from_numpy(idx).to(env.torch_device)]
+                obs_np[idx] = sel.cpu().numpy()
             for n, i in enumerate(idx):
-                infos[i]["terminal_observation"] = obs_np[i].copy()
-                obs_np[i] = new_obs[n]
-        return obs_np, rew_np, done_np, infos
+                ex = {"terminal_observation": term_obs[n]}
+                if ep_r is not None:                                 # Monitor: round(sum(rewards), 6), len(rewards), elapsed
+                    ex["episode"] = {"r": round(float(ep_r[n]), 6), "l": int(ep_l[n]), "t": t}
+                terminal[int(i)] = ex
+        return obs_np, rew, done, LazyInfos(self.num_envs, cols, terminal)
 
-    def vec_step(self, actions):
+    def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
-    def vec_reset(self):
-        return self.reset().cpu().numpy()
+    def close(self):
+        self.env.close()
 
-    def get_attr(self, name, indices=None):
-        n = self.num_envs if indices is None else len(indices)
-        return [getattr(self, name)] * n
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self.env, attr_name)] * len(self._indices(indices))
 
-    def set_attr(self, name, value, indices=None):
-        setattr(self, name, value)
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self.env, attr_name, value)
 
-    def env_method(self, method_name, *args, indices=None, **kwargs):
-        return [getattr(self, method_name)(*args, **kwargs)]
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        return [getattr(self.env, method_name)(*method_args, **method_kwargs)] * len(self._indices(indices))
 
     def env_is_wrapped(self, wrapper_class, indices=None):
-        return [False] * (self.num_envs if indices is None else len(indices))
+        return [False] * len(self._indices(indices))
 
-    def seed(self, seed=None):                                      # ref gym_env.py:149-150 (no-op there too)
+    def seed(self, seed=None):                                      # ref gym_env.py:149-150 (a no-op there too)
         return [None] * self.num_envs
+
+    def get_images(self):
+        return list(self.env.render())
+
+    def render(self, mode=None):
+        return self.env.render()
+
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        return [indices] if isinstance(indices, int) else list(indices)
 
 
 class WaypointSuiteEnv(_GymEnvBase):

@@ -180,18 +180,25 @@ def state_obs(dworld, state, out=None):
     return out
 
 
-def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None, layers=None, phase=0):
+def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None, layers=None, phase=0, flags=0,
+               fresh=None, only=None):
     """render_egocentric() of every env's ego -> uint8 [B, 3*n_stack, H, W] on device (ref gym_env.py:122-124).
     Frame stack (n_stack > 1): `out` is the stack of the previous call.  With `layers` (uint8 [B, n_stack, H*W], see
     FrameStack) nothing is shifted: the ring of layer planes is expanded into all frames of `out`; without it the older
-    frames are shifted in place by a launch of their own."""
+    frames are shifted in place by a launch of their own.
+    flags: _abi.RENDER_LEFT_HANDED | _abi.RENDER_PLAIN_EGO; fresh / only: optional uint8 [B] device masks
+    (tde_render.fresh: views whose episode just started get blank older frames; tde_render.only: render these views
+    only, re-rendering their newest frame in place)."""
     L = _lib.load()
     ns = max(1, n_stack)
     dev = state.device
     if out is None:
         out = torch.zeros((state.B, 3 * ns, H, W), dtype=torch.uint8, device=dev)
     pl = _chk(layers, torch.uint8, state.B * ns * H * W, "layers", optional=True) if ns > 1 else None
-    rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack, pl, int(phase), 0)
+    pf = _chk(fresh, torch.uint8, state.B, "fresh", optional=True)
+    po = _chk(only, torch.uint8, state.B, "only", optional=True)
+    rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack, pl, int(phase),
+                        int(flags), pf, po)
     _lib.check(_call(dev, L.tde_render_ego, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), C.byref(rd),
                      _lib.current_stream(dev)), "tde_render_ego")
     return out
@@ -200,17 +207,28 @@ def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None, la
 class FrameStack:
     """Device-side VecFrameStack(n_stack, channels_order="first") (ref examples/rl_training.py:160) kept as a ring of
     one-byte-per-pixel layer planes: every call writes all n_stack frames of `obs` (oldest first) from the ring, so no
-    pixels are moved between calls."""
+    pixels are moved between calls.  `phase` (the ring slot of the next frame) stays reduced modulo n_stack."""
 
-    def __init__(self, B, n_stack, H=64, W=64, device="cuda"):
-        self.n_stack, self.H, self.W = int(n_stack), H, W
+    def __init__(self, B, n_stack, H=64, W=64, device="cuda", flags=0):
+        self.n_stack, self.H, self.W, self.flags = int(n_stack), H, W, int(flags)
         self.obs = torch.zeros((B, 3 * self.n_stack, H, W), dtype=torch.uint8, device=device)
         self.layers = torch.full((B, self.n_stack, H * W), _abi.LAYER_BLANK, dtype=torch.uint8, device=device)
         self.phase = 0
 
-    def render(self, cfg, dworld, state, fov=35.0):
-        render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, self.phase)
-        self.phase += 1
+    def render(self, cfg, dworld, state, fov=35.0, fresh=None):
+        """append the current frame of every view; `fresh` (uint8 [B]): views whose episode just (re)started - their
+        older frames become blank, as VecFrameStack shows them after a reset"""
+        render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, self.phase, self.flags,
+                   fresh=fresh)
+        self.phase = (self.phase + 1) % self.n_stack
+        return self.obs
+
+    def rerender(self, cfg, dworld, state, mask, fov=35.0):
+        """re-render the NEWEST frame of the masked views in place (they were re-spawned after the last `render`) and
+        blank their older frames; the other views and the ring position are untouched"""
+        last = (self.phase - 1) % self.n_stack
+        render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, last, self.flags,
+                   fresh=mask, only=mask)
         return self.obs
 
     def clear(self, mask=None):
@@ -219,3 +237,11 @@ class FrameStack:
             self.layers.fill_(_abi.LAYER_BLANK)
         else:
             self.layers[mask] = _abi.LAYER_BLANK
+
+    def state_dict(self):
+        return {"layers": self.layers.clone(), "obs": self.obs.clone(), "phase": self.phase}
+
+    def load_state_dict(self, sd):
+        self.layers.copy_(sd["layers"])
+        self.obs.copy_(sd["obs"])
+        self.phase = int(sd["phase"]) % self.n_stack

@@ -9,30 +9,68 @@ import numpy as np
 from . import _abi
 
 
+# per-env OUTPUTS of a step: on a device they share one byte arena, so the SB3-shaped numpy path fetches all of them with
+# ONE device-to-host copy into a pinned buffer (EnvState.fetch_outputs) instead of one synchronising .cpu() per array
+OUTPUT_KEYS = ["reward", "terminated", "truncated", "tl_violation", "done_bits", "info", "info_reached", "ep_final",
+               "ep_final_len"]
+
+
 class EnvState:
     """`arrays[name]` are numpy arrays (host; used with the CPU oracle in tests) or torch tensors (device)."""
 
-    def __init__(self, B, A, device=None, with_info=True, with_obs=False):
+    def __init__(self, B, A, device=None, with_info=True, with_obs=False, with_episode=None):
         assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
         self.B, self.A, self.device = int(B), int(A), device
+        with_episode = with_info if with_episode is None else with_episode
         shapes = _abi.state_shapes(B, A)
+        off_keys = set()
+        if not with_info:
+            off_keys |= {"info", "info_reached", "done_bits"}
+        if not with_obs:
+            off_keys.add("obs")
+        if not with_episode:
+            off_keys |= {"ep_return", "ep_final", "ep_final_len"}
         self.arrays = {}
+        self._arena = self._pinned = None
+        self._slots = {}
         if device is None:
             for n, sh in shapes.items():
-                self.arrays[n] = np.zeros(sh, dtype=_abi.STATE_DTYPES[n])
+                self.arrays[n] = None if n in off_keys else np.zeros(sh, dtype=_abi.STATE_DTYPES[n])
         else:
             import torch
 
+            off = 0
+            for n in OUTPUT_KEYS:
+                if n in off_keys:
+                    continue
+                nbytes = int(np.prod(shapes[n])) * np.dtype(_abi.STATE_DTYPES[n]).itemsize
+                self._slots[n] = (off, nbytes)
+                off += (nbytes + 15) // 16 * 16
+            self._arena = torch.zeros(max(off, 16), dtype=torch.uint8, device=device)
             for n, sh in shapes.items():
+                if n in off_keys:
+                    self.arrays[n] = None
+                    continue
                 dt = getattr(torch, np.dtype(_abi.STATE_DTYPES[n]).name)
-                self.arrays[n] = torch.zeros(sh, dtype=dt, device=device)
-        if not with_info:
-            self.arrays["info"] = None
-            self.arrays["info_reached"] = None
-            self.arrays["done_bits"] = None
-        if not with_obs:
-            self.arrays["obs"] = None
+                if n in self._slots:
+                    o, nb = self._slots[n]
+                    self.arrays[n] = self._arena[o:o + nb].view(dt).view(sh)
+                else:
+                    self.arrays[n] = torch.zeros(sh, dtype=dt, device=device)
         self.struct = _abi.fill_state_struct(self.arrays, B, A)
+
+    def fetch_outputs(self):
+        """dict of numpy views of every per-env output after ONE device-to-host copy (pinned staging buffer, one
+        stream synchronisation).  The views alias the staging buffer: they are overwritten by the next fetch."""
+        import torch
+
+        if self._pinned is None:
+            self._pinned = torch.empty(self._arena.shape, dtype=torch.uint8, pin_memory=True)
+            self._host = self._pinned.numpy()
+        self._pinned.copy_(self._arena, non_blocking=True)
+        torch.cuda.current_stream(self._arena.device).synchronize()
+        shapes = _abi.state_shapes(self.B, self.A)
+        return {n: self._host[o:o + nb].view(_abi.STATE_DTYPES[n]).reshape(shapes[n]) for n, (o, nb) in self._slots.items()}
 
     def __getitem__(self, k):
         return self.arrays[k]

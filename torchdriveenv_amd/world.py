@@ -237,9 +237,13 @@ def corridor_mesh(polylines, width=12.0, seg_len=6.0, joint_radius=None):
 class World:
     """Host copy of every static table the step path reads (numpy, dtypes of _abi.WORLD_DTYPES)."""
 
-    def __init__(self, arrays, ints):
+    def __init__(self, arrays, ints, threshold=None):
         self.arrays = {k: np.ascontiguousarray(arrays[k], dtype=_abi.WORLD_DTYPES[k]) for k in _abi.WORLD_PTRS}
         self.ints = {k: int(ints[k]) for k in _abi.WORLD_INTS}
+        # The offroad distance the grid index was built for: cell classes and candidate lists bake it in
+        # (build_grid_index), so kernels run with another threshold would silently return wrong masks.  Checked by
+        # check_threshold() wherever a threshold meets a World.  None: unknown (tables assembled by hand).
+        self.threshold = None if threshold is None else float(threshold)
         self.has_lights = bool(np.asarray(arrays["maps"])["cycle_steps"].max() > 0)
         # zero-length tables still need a valid pointer
         for k, a in self.arrays.items():
@@ -271,7 +275,7 @@ class World:
             else:
                 t = torch.from_numpy(a.copy())
             tens[k] = t.to(device)
-        return DeviceWorld(tens, self.ints)
+        return DeviceWorld(tens, self.ints, self.threshold)
 
     def map_of_scn(self):
         return np.ascontiguousarray(self.arrays["scn"]["map"])
@@ -282,7 +286,8 @@ class World:
                  for k, a in self.arrays.items()}
         ints = np.array([self.ints[k] for k in _abi.WORLD_INTS], dtype=np.int64)
         with open(path, "wb") as f:
-            np.savez(f, abi=np.int64(_abi.TDE_ABI_VERSION), ints=ints, **blobs)
+            np.savez(f, abi=np.int64(_abi.TDE_ABI_VERSION), ints=ints,
+                     threshold=np.float64(-1.0 if self.threshold is None else self.threshold), **blobs)
 
     @classmethod
     def load(cls, path):
@@ -295,13 +300,30 @@ class World:
                 dt = np.dtype(_abi.WORLD_DTYPES[k])
                 a = z[f"a_{k}"]
                 arrays[k] = a.view(dt) if dt.names is not None else a
-        return cls(arrays, ints)
+            thr = float(z["threshold"]) if "threshold" in z.files else -1.0
+        return cls(arrays, ints, None if thr < 0 else thr)
+
+
+def effective_offroad_distance(threshold, squared=False):
+    """the distance a box corner may be from the mesh: `threshold`, or sqrt(threshold) when the threshold is applied to
+    the SQUARED distance (tde_config.offroad_threshold_squared)"""
+    return float(np.sqrt(threshold)) if squared else float(threshold)
+
+
+def check_threshold(world, threshold, squared=False, what="offroad_threshold"):
+    """raise if `world`'s grid index was built for another offroad distance than (threshold, squared) asks for"""
+    built = getattr(world, "threshold", None)
+    want = effective_offroad_distance(threshold, squared)
+    if built is not None and abs(built - want) > 1e-6 * max(1.0, want):
+        raise ValueError(f"{what} asks for an offroad distance of {want:g} m but the World's grid index was built for "
+                         f"{built:g} m: rebuild the World (assemble_world(..., threshold={want:g}))")
 
 
 class DeviceWorld:
-    def __init__(self, tensors, ints):
+    def __init__(self, tensors, ints, threshold=None):
         self.tensors = tensors  # keeps the device memory alive
         self.ints = dict(ints)
+        self.threshold = threshold
         self.struct = _abi.fill_world_struct(tensors, ints)
 
 
@@ -398,4 +420,4 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
                   else np.zeros(1, _abi.STOPLINE_DTYPE),
                   phases=np.asarray(phase_all, dtype=_abi.PHASE_DTYPE) if phase_all else np.zeros(1, _abi.PHASE_DTYPE))
     ints = dict(n_maps=len(meshes), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT)
-    return World(arrays, ints)
+    return World(arrays, ints, threshold)
