@@ -65,7 +65,7 @@ def test_config1_threeway_b1_reference_api_vs_oracle():
         assert float(info["collision"]) == float(hs["collided"][0]) and float(info["offroad"]) == float(hs["offroad"][0])
         assert info["reached_waypoint_num"] == hs["info_reached"][0]
         assert np.array_equal(inner.state["x"].cpu().numpy().view(np.uint32), hs["x"].view(np.uint32))
-        assert np.array_equal(obs, oracle.render_ego(ocfg, inner.world, hs)[0])
+        assert np.array_equal(obs, oracle.render_ego(ocfg, inner.world, hs, flags=inner._rflags)[0])   # (left-handed raster: the reference default)
         total += reward
         if terminated or truncated:
             n_term += 1
