@@ -145,6 +145,9 @@ def main():
                          "tests that put several ranks on one GPU)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
                     help="rollout: up to 250 steps per C-ABI call (default); step: one C-ABI call per step from Python")
+    ap.add_argument("--binding", default="ext", choices=["ext", "ctypes"],
+                    help="step mode / config 5: launches through the PyTorch-ROCm C++ extension (default) or through "
+                         "the ctypes binding of the same C-ABI")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,11 +209,24 @@ def main():
     reward = torch.empty((CH, B), dtype=torch.float32, device=dev)
     done = torch.empty((CH, B), dtype=torch.uint8, device=dev)
     img = ops.render_ego(cfg, dw, st) if args.config == 5 else None
+    handle = None
+    if stepwise and args.binding == "ext":
+        import ctypes as C
+
+        from torchdriveenv_amd import _ext
+        handle = _ext.load().EnvHandle(C.addressof(cfg), C.addressof(dw.struct), C.addressof(st.struct), local_rank)
+    cfg_flags = int(cfg.flags)
 
     def launch(k, row):
         """k consecutive timesteps (k <= CH); `row` = first row of the action buffer to use"""
         if not stepwise:
             ops.env_rollout(cfg, dw, st, actions[:k], reward[:k], done[:k])
+            return
+        if handle is not None:
+            for i in range(k):
+                handle.step(actions[(row + i) % CH], cfg_flags)
+                if img is not None:
+                    handle.render(img, 64, 64, 35.0, 1, None, 0, 0, None, None)
             return
         for i in range(k):
             ops.env_step(cfg, dw, st, action=actions[(row + i) % CH])
@@ -325,6 +341,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{C['name']}: {B} envs x {A} agents per GPU, {C['what']}",
                        "envs_per_gpu": B, "agents_per_env": A, "global_envs": B * n, "mode": args.mode,
+                       "binding": (args.binding if stepwise else "ctypes"),
                        "steps_per_call": spl, "timed_steps": total, "untimed_warmup_steps": warm_steps + CH,
                        "sharding": f"{n} contiguous shard(s) of one global batch (env_base = rank * {B}), "
                                    "no data-path collective",
@@ -333,8 +350,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
                          "kernel_avg_us": kern_us, "kernel_min_us": per[0] if per else None,
                          "kernel_median_us": per[len(per) // 2] if per else None,
-                         "launches": len(lens), "steps_per_launch": spl,
-                         "launch_lengths": sorted(set(lens)), "algorithmic_bytes_per_launch": alg_launch,
+                         "launches": (sum(lens) if stepwise else len(lens)), "steps_per_launch": spl,
+                         "launch_lengths": ([1] if stepwise else sorted(set(lens))), "algorithmic_bytes_per_launch": alg_launch,
                          "bytes_per_env_step": bpes, "us_per_step": dev_ms * 1e3 / total,
                          "timer": "HIP events on the launch stream around every timed launch (rank 0)"},
             "check": chk,

@@ -98,3 +98,24 @@ def test_env_requires_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU path"):
         BatchedWaypointEnv(EnvConfig(), None, num_envs=1)
+
+
+def test_torch_extension_builds_in_tree_and_binds_the_same_abi():
+    """the PyTorch-ROCm C++ extension (north_star's boundary form) is built next to libtde_hip.so, links to it (NEEDED
+    entry + $ORIGIN run path, no copy of the kernels), reports the same ABI version and exposes the env-level entry
+    points as methods; no GPU is needed to load it"""
+    import subprocess
+
+    from torchdriveenv_amd import _abi, _ext, _lib
+
+    path = _ext.build()
+    assert os.path.dirname(path).startswith(os.path.join(ROOT, "torchdriveenv_amd"))
+    dyn = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    assert "libtde_hip.so" in dyn and "$ORIGIN/.." in dyn
+    m = _ext.load()
+    assert m.abi_version() == _lib.load().tde_abi_version() == _abi.TDE_ABI_VERSION
+    for meth in ("step", "reset", "rollout", "render", "state_obs"):
+        assert hasattr(m.EnvHandle, meth)
+    # device code lives in libtde_hip.so only: the extension object defines no kernels
+    syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    assert "tde_env_step" not in syms and "PyInit_tde_torch_ext" in syms

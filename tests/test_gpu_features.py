@@ -283,3 +283,82 @@ def test_config_rejections_and_world_threshold_on_the_env(small_world):
         device=DEV)
     ol, orr = lh.reset(), rh.reset()
     assert torch.equal(ol, orr.flip(-1)) and not torch.equal(ol, orr)
+
+
+def test_sharded_env_two_processes_equal_the_unsharded_batch(small_world):
+    """ShardedBatchedEnv: two worker processes (sharing this box's GPU), env_base 0 and B/2, host-gathered observations /
+    rewards / dones / state equal the unsharded HIP env bit for bit through re-spawns"""
+    from torchdriveenv_amd.sharding import ShardedBatchedEnv
+
+    cfg = EnvConfig(seed=51, distance_cutoff=0.25, max_environment_steps=35)
+    B = 96
+    one = BatchedWaypointEnv(cfg, small_world, num_envs=B, device=DEV, obs_mode="state").as_vec_env()
+    two = ShardedBatchedEnv(cfg, small_world, B, n_shards=2, devices=[0, 0], obs_mode="state")
+    try:
+        assert two.ranges == [(0, B // 2), (B // 2, B)]
+        oa, ob = one.reset(), two.reset()
+        assert np.array_equal(oa, ob)
+        rng = np.random.default_rng(3)
+        n_done = 0
+        for t in range(80):
+            acts = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            oa, ra, da, ia = one.step(acts)
+            ob, rb, db, ib = two.step(acts)
+            assert np.array_equal(oa, ob) and np.array_equal(ra.view(np.uint32), rb.view(np.uint32)) and np.array_equal(da, db)
+            for i in np.nonzero(da)[0]:
+                assert ia[i]["episode"]["r"] == ib[i]["episode"]["r"] and ia[i]["episode"]["l"] == ib[i]["episode"]["l"]
+                assert np.array_equal(ia[i]["terminal_observation"], ib[i]["terminal_observation"])
+            assert np.array_equal(ia.column("reached_waypoint_num"), ib.column("reached_waypoint_num"))
+            n_done += int(da.sum())
+        assert n_done > B // 2
+        full = {k: v.cpu().numpy() for k, v in one.env.state.arrays.items() if v is not None}
+        got = two.gather_state()
+        for k in ("x", "y", "psi", "v", "scn", "episode", "steps", "ep_return"):
+            assert np.array_equal(got[k].view(np.uint8), full[k].view(np.uint8)), k
+    finally:
+        two.close()
+
+
+def test_extension_equals_ctypes_equals_oracle(small_world):
+    """the PyTorch-ROCm C++ extension and the ctypes binding call the same C-ABI entry points: stepping the same batch
+    through either gives the same bits as the oracle (state, rewards, flags, episode statistics, observations)"""
+    cfg = EnvConfig(seed=61, distance_cutoff=0.25, max_environment_steps=40)
+    B = 96
+    e_ext = BatchedWaypointEnv(cfg, small_world, num_envs=B, device=DEV, obs_mode="state", binding="ext")
+    e_ct = BatchedWaypointEnv(cfg, small_world, num_envs=B, device=DEV, obs_mode="state", binding="ctypes")
+    assert e_ext._h is not None and e_ct._h is None
+    hs = EnvState(B, small_world.A)
+    ocfg = e_ext.tde_cfg
+    oracle.env_reset(ocfg, small_world, hs)
+    o1, o2 = e_ext.reset(), e_ct.reset()
+    assert torch.equal(o1, o2)
+    rng = np.random.default_rng(6)
+    for t in range(100):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        a = dev(act)
+        o1, r1, t1, tr1, i1 = e_ext.step(a)
+        o2, r2, t2, tr2, i2 = e_ct.step(a)
+        hs["action"][...] = act
+        oracle.env_step(ocfg, small_world, hs)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(tr1, tr2)
+        assert np.array_equal(r1.cpu().numpy().view(np.uint32), hs["reward"].view(np.uint32))
+    h = hs.host()
+    for k in ("x", "y", "psi", "v", "episode", "steps", "ep_return", "ep_final", "collided", "offroad", "done_bits"):
+        a1, a2 = e_ext.state[k].cpu().numpy(), e_ct.state[k].cpu().numpy()
+        assert np.array_equal(a1.view(np.uint8), h[k].view(np.uint8)) and np.array_equal(a2.view(np.uint8), h[k].view(np.uint8)), k
+    # rollout and birdview through the extension
+    acts = torch.zeros(30, B, 2, device=DEV)
+    acts[..., 0] = 0.4
+    ra, da = e_ext.rollout(acts)
+    rb, db = e_ct.rollout(acts)
+    assert torch.equal(ra, rb) and torch.equal(da, db)
+    with pytest.raises(RuntimeError):
+        e_ext._h.step(torch.zeros(B, 2), int(e_ext.tde_cfg.flags))            # a CPU tensor is refused, not dereferenced
+    with pytest.raises(RuntimeError):
+        e_ext._h.step(torch.zeros(B, 3, device=DEV), int(e_ext.tde_cfg.flags))
+    b1 = BatchedWaypointEnv(cfg, small_world, num_envs=16, device=DEV, frame_stack=3, binding="ext")
+    b2 = BatchedWaypointEnv(cfg, small_world, num_envs=16, device=DEV, frame_stack=3, binding="ctypes")
+    assert torch.equal(b1.reset(), b2.reset())
+    for t in range(50):
+        a = torch.rand(16, 2, device=DEV) * 0.6 - 0.3
+        assert torch.equal(b1.step(a)[0], b2.step(a)[0])

@@ -12,6 +12,8 @@ OUT = os.path.join(_PKG, "libtde_hip.so")
 # with the oracle (bit-exact masks AND state).  fp32 divide/sqrt stay IEEE-correct (hipcc default).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden",
+         # a SONAME lets the torch extension's NEEDED entry resolve to the copy _lib.load() has already mapped
+         "-Wl,-soname,libtde_hip.so",
          # packed fp32 (v_pk_*_f32) issues slower than two scalar ops on gfx950 for this mix and costs v_mov shuffles:
          # same-box A/B 7.2 -> 6.7 us/step without the SLP vectoriser
          "-fno-slp-vectorize",

@@ -208,8 +208,12 @@ class BatchedWaypointEnv:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 10}   # ref gym_env.py:73-76
 
     def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
-                 frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0):
-        validate(cfg)                                              # ref gym_env.py:79-80 and the fields this path rejects
+                 frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0, binding="ext"):
+        """binding: "ext" = launches go through the PyTorch-ROCm C++ extension (csrc/tde_torch_ext.cpp), "ctypes" = through
+        the ctypes binding of the same C-ABI (ops.py); both call the very same entry points of libtde_hip.so"""
+        validate(cfg)
+        if binding not in ("ext", "ctypes"):
+            raise ValueError("binding must be 'ext' or 'ctypes'")                                              # ref gym_env.py:79-80 and the fields this path rejects
         if obs_mode not in ("birdview", "state"):
             raise ValueError("obs_mode must be 'birdview' or 'state'")
         self.config = cfg
@@ -254,6 +258,13 @@ class BatchedWaypointEnv:
                                   if obs_mode == "birdview" else _box(-np.inf, np.inf, (8,), np.float32))
         self.reward_range = (-float("inf"), float("inf"))           # ref gym_env.py:97
         self._vec = None
+        self._h = None
+        if binding == "ext":
+            import ctypes as C
+
+            from . import _ext
+            self._h = _ext.load().EnvHandle(C.addressof(self.tde_cfg), C.addressof(self.dworld.struct),
+                                            C.addressof(self.state.struct), self.torch_device.index or 0)
 
     @property
     def auto_reset(self):
@@ -268,7 +279,10 @@ class BatchedWaypointEnv:
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.torch_device).to(torch.uint8).contiguous()
-        ops.env_reset(self.tde_cfg, self.dworld, self.state, m)
+        if self._h is not None:
+            self._h.reset(m, int(self.tde_cfg.flags))
+        else:
+            ops.env_reset(self.tde_cfg, self.dworld, self.state, m)
         if self.obs_mode == "state" or m is None or self._obs is None:
             if self._stack is not None:
                 self._stack.clear()                                  # VecFrameStack clears the stack on reset
@@ -276,15 +290,17 @@ class BatchedWaypointEnv:
         if self._stack is not None:
             self._obs = self._stack.rerender(self.tde_cfg, self.dworld, self.state, m, self._fov)
         else:
-            ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, self._obs,
-                           flags=self._rflags, only=m)
+            self._render1(self._obs, only=m)
         return self._obs
 
     def step(self, actions):
         a = actions if torch.is_tensor(actions) and actions.device == self.torch_device else \
             torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device)
         a = a.to(torch.float32).reshape(self.num_envs, 2).contiguous()
-        ops.env_step(self.tde_cfg, self.dworld, self.state, action=a)
+        if self._h is not None:
+            self._h.step(a, int(self.tde_cfg.flags))
+        else:
+            ops.env_step(self.tde_cfg, self.dworld, self.state, action=a)
         st = self.state
         if self.obs_mode == "state":
             obs = st["obs"]
@@ -304,21 +320,38 @@ class BatchedWaypointEnv:
         episode statistics of the closed-loop API are not maintained across a rollout: they follow from the returned
         arrays.)"""
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).contiguous()
+        if self._h is not None:
+            reward = torch.empty(a.shape[:2], dtype=torch.float32, device=self.torch_device)
+            done = torch.empty(a.shape[:2], dtype=torch.uint8, device=self.torch_device)
+            self._h.rollout(a, reward, done, int(self.tde_cfg.flags))
+            return reward, done
         return ops.env_rollout(self.tde_cfg, self.dworld, self.state, a)
 
     def get_obs(self, fresh=None):
         if self.obs_mode == "state":
             # x, y, psi, v, target offset (forward, left) in the ego frame, target-exists flag, environment_steps
+            if self._h is not None:
+                self._h.state_obs(self.state["obs"])
+                return self.state["obs"]
             return ops.state_obs(self.dworld, self.state, self.state["obs"])
         if self.frame_stack > 1:
             if self._stack is None:
                 self._stack = ops.FrameStack(self.num_envs, self.frame_stack, self._res, self._res, self.torch_device,
-                                             flags=self._rflags)
+                                             flags=self._rflags, handle=self._h)
             self._obs = self._stack.render(self.tde_cfg, self.dworld, self.state, self._fov, fresh=fresh)
             return self._obs
-        self._obs = ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, self._obs,
-                                   flags=self._rflags)
+        if self._obs is None:
+            self._obs = torch.zeros((self.num_envs, 3, self._res, self._res), dtype=torch.uint8, device=self.torch_device)
+        self._render1(self._obs)
         return self._obs
+
+    def _render1(self, out, only=None):
+        """single-frame raster of every (or the masked) view into `out`"""
+        if self._h is not None:
+            self._h.render(out, self._res, self._res, self._fov, 1, None, 0, self._rflags, None, only)
+        else:
+            ops.render_ego(self.tde_cfg, self.dworld, self.state, self._res, self._res, self._fov, 1, out,
+                           flags=self._rflags, only=only)
 
     def get_info(self):
         """info schema of the reference (ref gym_env.py:419-437), one entry per env; a mapping whose tensors are formed
@@ -345,7 +378,7 @@ class BatchedWaypointEnv:
             if k == "_frame_stack":
                 if self._stack is None:
                     self._stack = ops.FrameStack(self.num_envs, self.frame_stack, self._res, self._res, self.torch_device,
-                                                 flags=self._rflags)
+                                                 flags=self._rflags, handle=self._h)
                 self._stack.load_state_dict(v)
                 self._obs = self._stack.obs
             else:

@@ -209,8 +209,9 @@ class FrameStack:
     one-byte-per-pixel layer planes: every call writes all n_stack frames of `obs` (oldest first) from the ring, so no
     pixels are moved between calls.  `phase` (the ring slot of the next frame) stays reduced modulo n_stack."""
 
-    def __init__(self, B, n_stack, H=64, W=64, device="cuda", flags=0):
+    def __init__(self, B, n_stack, H=64, W=64, device="cuda", flags=0, handle=None):
         self.n_stack, self.H, self.W, self.flags = int(n_stack), H, W, int(flags)
+        self.handle = handle                      # optional _ext.EnvHandle: launches go through the C++ extension
         self.obs = torch.zeros((B, 3 * self.n_stack, H, W), dtype=torch.uint8, device=device)
         self.layers = torch.full((B, self.n_stack, H * W), _abi.LAYER_BLANK, dtype=torch.uint8, device=device)
         self.phase = 0
@@ -218,8 +219,11 @@ class FrameStack:
     def render(self, cfg, dworld, state, fov=35.0, fresh=None):
         """append the current frame of every view; `fresh` (uint8 [B]): views whose episode just (re)started - their
         older frames become blank, as VecFrameStack shows them after a reset"""
-        render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, self.phase, self.flags,
-                   fresh=fresh)
+        if self.handle is not None:
+            self.handle.render(self.obs, self.H, self.W, fov, self.n_stack, self.layers, self.phase, self.flags, fresh, None)
+        else:
+            render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, self.phase,
+                       self.flags, fresh=fresh)
         self.phase = (self.phase + 1) % self.n_stack
         return self.obs
 
@@ -227,8 +231,11 @@ class FrameStack:
         """re-render the NEWEST frame of the masked views in place (they were re-spawned after the last `render`) and
         blank their older frames; the other views and the ring position are untouched"""
         last = (self.phase - 1) % self.n_stack
-        render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, last, self.flags,
-                   fresh=mask, only=mask)
+        if self.handle is not None:
+            self.handle.render(self.obs, self.H, self.W, fov, self.n_stack, self.layers, last, self.flags, mask, mask)
+        else:
+            render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, last, self.flags,
+                       fresh=mask, only=mask)
         return self.obs
 
     def clear(self, mask=None):

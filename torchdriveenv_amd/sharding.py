@@ -30,3 +30,138 @@ def host_gather(obj, dst=0):
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(obj, out, dst=dst)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ShardedBatchedEnv: the batch cut into contiguous shards, one worker PROCESS per shard / GPU, host gather of the
+# results (reference analogue: SubprocVecEnv with one process per ENV, examples/rl_training.py:159).
+# ------------------------------------------------------------------------------------------------------------------
+def _shard_worker(rank, n_shards, device, cfg, world, total, kw, conn, shm):
+    """one shard: its own process, its own GPU context, its own BatchedWaypointEnv with env_base = first global env"""
+    import numpy as np
+    import torch
+
+    from .env import BatchedWaypointEnv
+
+    try:
+        torch.cuda.set_device(device)
+        lo, hi = shard_range(rank, n_shards, total)
+        env = BatchedWaypointEnv(cfg, world, num_envs=hi - lo, device=f"cuda:{device}", env_base=lo, **kw)
+        venv = env.as_vec_env(copy_obs=False)
+        obs_all = shm["obs"].numpy()
+        rew_all, done_all = shm["reward"].numpy(), shm["done"].numpy()
+        conn.send(("ready", lo, hi))
+        while True:
+            cmd, arg = conn.recv()
+            if cmd == "reset":
+                obs_all[lo:hi] = venv.reset()
+                conn.send(("ok", None))
+            elif cmd == "step":
+                obs, rew, done, infos = venv.step(shm["action"].numpy()[lo:hi])
+                obs_all[lo:hi] = obs                      # the shard's slice of the gathered (shared, host) buffers
+                rew_all[lo:hi] = rew
+                done_all[lo:hi] = done
+                cols = {k: np.asarray(v) for k, v in infos._cols.items()}
+                conn.send(("ok", (cols, {lo + i: ex for i, ex in infos._terminal.items()})))
+            elif cmd == "state":
+                conn.send(("ok", {k: v.cpu().numpy() for k, v in env.state.arrays.items() if v is not None}))
+            elif cmd == "close":
+                conn.send(("ok", None))
+                break
+    except Exception as exc:                              # pragma: no cover
+        import traceback
+
+        conn.send(("error", f"shard {rank}: {exc}\n{traceback.format_exc()}"))
+
+
+class ShardedBatchedEnv:
+    """`total_envs` envs cut into `n_shards` contiguous shards, one process per shard (one per GPU; several shards may
+    share a GPU), no data-path collective: the reset RNG is keyed by the GLOBAL env index (tde_config.env_base), so the
+    sharded batch is bit for bit the unsharded one.  Every step the shards write their slices of the shared host
+    buffers (observations, rewards, dones) - the host gather - and the caller gets VecEnv-shaped numpy results for the
+    whole batch: step(actions [total, 2]) -> (obs, rewards, dones, infos)."""
+
+    def __init__(self, cfg, world, total_envs, n_shards=None, devices=None, **env_kw):
+        import numpy as np
+        import torch
+        import torch.multiprocessing as mp
+
+        from .env import BatchedWaypointEnv  # noqa: F401  (fail early if the package cannot load)
+
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise RuntimeError("ShardedBatchedEnv needs at least one HIP device")
+        self.n_shards = int(n_shards or ndev)
+        self.devices = list(devices) if devices is not None else [r % ndev for r in range(self.n_shards)]
+        self.num_envs = int(total_envs)
+        obs_mode = env_kw.get("obs_mode", "birdview")
+        fs = max(1, int(env_kw.get("frame_stack", 1)))
+        r = cfg.simulator.renderer
+        oshape = (3 * fs, int(r.res), int(r.res)) if obs_mode == "birdview" else (8,)
+        odt = torch.uint8 if obs_mode == "birdview" else torch.float32
+        self._shm = {"obs": torch.zeros((self.num_envs,) + oshape, dtype=odt).share_memory_(),
+                     "reward": torch.zeros(self.num_envs, dtype=torch.float32).share_memory_(),
+                     "done": torch.zeros(self.num_envs, dtype=torch.bool).share_memory_(),
+                     "action": torch.zeros((self.num_envs, 2), dtype=torch.float32).share_memory_()}
+        ctx = mp.get_context("spawn")
+        self._conns, self._procs, self.ranges = [], [], []
+        for rank in range(self.n_shards):
+            parent, child = ctx.Pipe()
+            p = ctx.Process(target=_shard_worker, args=(rank, self.n_shards, self.devices[rank], cfg, world,
+                                                        self.num_envs, env_kw, child, self._shm), daemon=True)
+            p.start()
+            self._conns.append(parent)
+            self._procs.append(p)
+        for c in self._conns:
+            tag, lo, hi = self._recv(c)
+            self.ranges.append((lo, hi))
+        self._np = np
+
+    @staticmethod
+    def _recv(conn):
+        msg = conn.recv()
+        if msg[0] == "error":
+            raise RuntimeError(msg[1])
+        return msg
+
+    def _all(self, cmd, arg=None):
+        for c in self._conns:
+            c.send((cmd, arg))
+        return [self._recv(c)[1] for c in self._conns]
+
+    def reset(self):
+        self._all("reset")
+        return self._shm["obs"].numpy().copy()
+
+    def step(self, actions):
+        from .env import LazyInfos
+
+        np = self._np
+        self._shm["action"].numpy()[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 2)
+        parts = self._all("step")
+        cols = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0]}
+        terminal = {}
+        for p in parts:
+            terminal.update(p[1])
+        return (self._shm["obs"].numpy().copy(), self._shm["reward"].numpy().copy(), self._shm["done"].numpy().copy(),
+                LazyInfos(self.num_envs, cols, terminal))
+
+    def gather_state(self):
+        """every shard's state arrays concatenated in global env order (tests / checkpoints)"""
+        np = self._np
+        parts = self._all("state")
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+    def close(self):
+        try:
+            self._all("close")
+        except Exception:
+            pass
+        for p in self._procs:
+            p.join(timeout=10)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -251,6 +251,11 @@ class World:
                 self.arrays[k] = np.zeros(max(1, 1), dtype=a.dtype)
         self._host_struct = None
 
+    def __getstate__(self):                      # the cached ctypes struct holds raw pointers: never pickled
+        d = dict(self.__dict__)
+        d["_host_struct"] = None
+        return d
+
     @property
     def A(self):
         return self.ints["A"]
