@@ -211,10 +211,11 @@ def main():
     img = ops.render_ego(cfg, dw, st) if args.config == 5 else None
     handle = None
     if stepwise and args.binding == "ext":
-        import ctypes as C
+        import ctypes
 
         from torchdriveenv_amd import _ext
-        handle = _ext.load().EnvHandle(C.addressof(cfg), C.addressof(dw.struct), C.addressof(st.struct), local_rank)
+        handle = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct),
+                                       local_rank)
     cfg_flags = int(cfg.flags)
 
     def launch(k, row):

@@ -18,8 +18,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 world = synthetic_world(n_scn=64, A=16, seed=0, n_maps=4)
 out = {"envs": B, "agents": 16, "steps": N}
-for mode in ("state", "birdview"):
-    env = BatchedWaypointEnv(EnvConfig(seed=3), world, num_envs=B, obs_mode=mode, with_info=True)
+for mode, fs in (("state", 1), ("birdview", 1), ("birdview", 3)):
+    env = BatchedWaypointEnv(EnvConfig(seed=3), world, num_envs=B, obs_mode=mode, with_info=True, frame_stack=fs)
     env.reset()
     act = torch.zeros(B, 2, device=env.torch_device)
     for _ in range(20):
@@ -38,6 +38,25 @@ for mode in ("state", "birdview"):
     for _ in range(n2):
         env.vec_step(act_np)
     dt_np = (time.perf_counter() - t0) / n2
-    out[mode] = {"device_outputs_us_per_step": dt_dev * 1e6, "device_outputs_env_steps_per_s": B / dt_dev,
+    # the same through the ctypes binding (closed-loop host floor)
+    env_c = BatchedWaypointEnv(EnvConfig(seed=3), world, num_envs=B, obs_mode=mode, with_info=True, frame_stack=fs,
+                               binding="ctypes")
+    env_c.reset()
+    for _ in range(20):
+        env_c.step(act)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        env_c.step(act)
+    torch.cuda.synchronize()
+    dt_ct = (time.perf_counter() - t0) / N
+    del env_c
+    # SB3 consumer pattern: every info entry is looked at (Monitor / _update_info_buffer read .get("episode"))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        o, r, d, infos = env.vec_step(act_np)
+        n_ep = sum(1 for i in np.nonzero(d)[0] if infos[i].get("episode") is not None)
+    dt_ep = (time.perf_counter() - t0) / 3
+    out[mode + (f"_stack{fs}" if fs > 1 else "")] = {"device_outputs_us_per_step_ctypes": dt_ct * 1e6, "numpy_plus_done_infos_us_per_step": dt_ep * 1e6, "device_outputs_us_per_step": dt_dev * 1e6, "device_outputs_env_steps_per_s": B / dt_dev,
                  "numpy_outputs_us_per_step": dt_np * 1e6, "numpy_outputs_env_steps_per_s": B / dt_np}
 print(json.dumps(out))

@@ -385,3 +385,29 @@ def test_render_crowded_view_takes_the_all_pixels_path():
     got = ops.render_ego(cfg, dw, ds).cpu().numpy()
     assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ"
     assert (want[:, 0] == 31).sum() > 2000                 # plenty of NPC-coloured pixels
+
+
+def test_reward_cos_bits_agree_between_libm_and_ocml():
+    """R6: the reward's float64 `cos` is libm on the CPU and OCML on the GPU; the claim that the fp32-rounded reward
+    carries the same bits is checked here on 10^6 random heading changes (both signs, tiny to pi, incl. exact zeros)"""
+    rng = np.random.default_rng(123)
+    n = 1_000_000
+    dpsi = np.concatenate([rng.uniform(-np.pi, np.pi, n // 2), rng.normal(0, 0.05, n // 4),
+                           rng.uniform(-1e-3, 1e-3, n // 4 - 8), np.zeros(8)]).astype(np.float32)
+    pre_psi = rng.uniform(-3, 3, n).astype(np.float32)
+    psi = (pre_psi + dpsi).astype(np.float32)
+    z = np.zeros(n, np.float32)
+    moved = rng.uniform(0, 0.6, n).astype(np.float32)         # around the 0.25 m cut-off
+    cfg = _abi.default_config(distance_cutoff=0.25)
+    wp = np.array([[[1e6, 1e6], [2e6, 2e6]]], np.float64)
+    wp_n = np.array([2], np.int32)
+    scn = np.zeros(n, np.int32)
+    u8 = np.zeros(n, np.uint8)
+    h = dict(steps=np.zeros(n, np.int32), ti=np.ones(n, np.int32), rc=np.zeros(n, np.int32))
+    want = oracle.waypoint_reward(cfg, np.stack([z, z, pre_psi, z], 1), np.stack([moved, z, psi, z], 1), u8, u8, None, wp,
+                                  wp_n, scn, h["steps"], h["ti"], h["rc"])
+    got = ops.waypoint_reward(cfg, tuple(dev(a) for a in (z, z, pre_psi, z)), tuple(dev(a) for a in (moved, z, psi, z)),
+                              dev(u8), dev(u8), None, dev(wp), dev(wp_n), dev(scn), dev(np.zeros(n, np.int32)),
+                              dev(np.ones(n, np.int32)), dev(np.zeros(n, np.int32)))
+    assert np.array_equal(got["reward"].cpu().numpy().view(np.uint32), want["reward"].view(np.uint32))
+    assert np.array_equal(got["info"].cpu().numpy().view(np.uint64), want["info"].view(np.uint64))   # psi_reward in float64 too

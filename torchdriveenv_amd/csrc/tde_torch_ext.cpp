@@ -7,8 +7,9 @@
 // reference loop: gym_env.py:453-461).  The ctypes binding stays as the reference-side stub.
 #include <torch/extension.h>
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm keeps the device type "cuda" for HIP devices: the guard / stream accessors are the "masquerading" ones
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <cstring>
 #include <optional>
@@ -53,16 +54,16 @@ class EnvHandle {
         tde_state st = state_;
         st.action = static_cast<const float *>(dev_ptr(action, at::kFloat, 2 * (int64_t)state_.B, "action", dev_));
         cfg_.flags = static_cast<uint32_t>(flags);
-        const c10::hip::HIPGuard guard(dev_);
-        check_rc(tde_env_step(&cfg_, &world_, &st, c10::hip::getCurrentHIPStream(dev_.index()).stream()), "tde_env_step");
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_env_step(&cfg_, &world_, &st, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_env_step");
     }
 
     void reset(const std::optional<at::Tensor> &mask, int64_t flags)
     {
         cfg_.flags = static_cast<uint32_t>(flags);
         const uint8_t *m = mask ? static_cast<const uint8_t *>(dev_ptr(*mask, at::kByte, state_.B, "mask", dev_)) : nullptr;
-        const c10::hip::HIPGuard guard(dev_);
-        check_rc(tde_env_reset(&cfg_, &world_, &state_, m, c10::hip::getCurrentHIPStream(dev_.index()).stream()), "tde_env_reset");
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_env_reset(&cfg_, &world_, &state_, m, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_env_reset");
     }
 
     void rollout(const at::Tensor &actions, const at::Tensor &reward, const at::Tensor &done, int64_t flags)
@@ -76,8 +77,8 @@ class EnvHandle {
         ro.done = static_cast<uint8_t *>(const_cast<void *>(dev_ptr(done, at::kByte, K * state_.B, "done", dev_)));
         ro.K = static_cast<int32_t>(K);
         ro._pad0 = 0;
-        const c10::hip::HIPGuard guard(dev_);
-        check_rc(tde_env_rollout(&cfg_, &world_, &state_, &ro, c10::hip::getCurrentHIPStream(dev_.index()).stream()), "tde_env_rollout");
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_env_rollout(&cfg_, &world_, &state_, &ro, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_env_rollout");
     }
 
     void render(const at::Tensor &out, int64_t H, int64_t W, double fov, int64_t n_stack, const std::optional<at::Tensor> &layers,
@@ -95,15 +96,15 @@ class EnvHandle {
         rd.flags = static_cast<int32_t>(flags);
         rd.fresh = fresh ? static_cast<const uint8_t *>(dev_ptr(*fresh, at::kByte, state_.B, "fresh", dev_)) : nullptr;
         rd.only = only ? static_cast<const uint8_t *>(dev_ptr(*only, at::kByte, state_.B, "only", dev_)) : nullptr;
-        const c10::hip::HIPGuard guard(dev_);
-        check_rc(tde_render_ego(&cfg_, &world_, &state_, &rd, c10::hip::getCurrentHIPStream(dev_.index()).stream()), "tde_render_ego");
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_render_ego(&cfg_, &world_, &state_, &rd, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_render_ego");
     }
 
     void state_obs(const at::Tensor &out)
     {
         float *p = static_cast<float *>(const_cast<void *>(dev_ptr(out, at::kFloat, (int64_t)state_.B * 8, "out", dev_)));
-        const c10::hip::HIPGuard guard(dev_);
-        check_rc(tde_state_obs(&world_, &state_, p, c10::hip::getCurrentHIPStream(dev_.index()).stream()), "tde_state_obs");
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_state_obs(&world_, &state_, p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_state_obs");
     }
 
     int64_t flags() const { return cfg_.flags; }
