@@ -389,7 +389,8 @@ def test_render_crowded_view_takes_the_all_pixels_path():
 
 def test_reward_cos_bits_agree_between_libm_and_ocml():
     """R6: the reward's float64 `cos` is libm on the CPU and OCML on the GPU; the claim that the fp32-rounded reward
-    carries the same bits is checked here on 10^6 random heading changes (both signs, tiny to pi, incl. exact zeros)"""
+    carries the same bits is checked here on 10^6 random heading changes (both signs, tiny to pi, incl. exact zeros).
+    The float64 psi_reward info term may differ in its last bit (|diff| <= one ulp of cos ~ 1: 25 * 2.2e-16)."""
     rng = np.random.default_rng(123)
     n = 1_000_000
     dpsi = np.concatenate([rng.uniform(-np.pi, np.pi, n // 2), rng.normal(0, 0.05, n // 4),
@@ -410,4 +411,12 @@ def test_reward_cos_bits_agree_between_libm_and_ocml():
                               dev(u8), dev(u8), None, dev(wp), dev(wp_n), dev(scn), dev(np.zeros(n, np.int32)),
                               dev(np.ones(n, np.int32)), dev(np.zeros(n, np.int32)))
     assert np.array_equal(got["reward"].cpu().numpy().view(np.uint32), want["reward"].view(np.uint32))
-    assert np.array_equal(got["info"].cpu().numpy().view(np.uint64), want["info"].view(np.uint64))   # psi_reward in float64 too
+    # the float64 info terms: psi_smoothness / speed_smoothness / dist_reward carry no transcendental -> same bits;
+    # psi_reward = (1 - cos(dpsi)) * -25 in float64 sees the two libraries' cos differ by an ulp of 1.0 on a small share
+    # of the samples (both are faithfully rounded, neither is always correctly rounded): bounded here, and invisible
+    # after the fp32 rounding the reward gets (asserted above on all 10^6 samples)
+    gi, wi = got["info"].cpu().numpy(), want["info"]
+    for col in (0, 1, 3):
+        assert np.array_equal(gi[:, col].view(np.uint64), wi[:, col].view(np.uint64)), col
+    d = np.abs(gi[:, 2] - wi[:, 2])
+    assert d.max() <= 25.0 * 2.3e-16 and (d > 0).mean() < 0.2, (d.max(), (d > 0).mean())

@@ -1406,6 +1406,8 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
 constexpr int kRenderMaxWp = 64;
 constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS layer plane, one byte per pixel)
 constexpr int kRenderWork = 2048;                 // exact-pixel queue (a view that needs more takes the all-pixels path)
+constexpr int kRenderMixed = 1024;                // of which in MIXED cells (more: all-pixels path); LDS per view stays
+                                                  // under 20 KiB = 8 workgroups per CU, the wavefront limit
 constexpr int kRenderMaxBox = 40;                 // agent boxes kept per view (more: all-pixels path)
 constexpr int kRenderMaxStop = 16;                // stop lines kept per view (more: all-pixels path)
 
@@ -1480,8 +1482,47 @@ __global__ __launch_bounds__(kBlock) void frame_shift_kernel(uint8_t *__restrict
 // ------------------------------------------------------------------------------------------------------------------
 struct PixelSpan { int rmin, rmax, cmin, cmax; };
 
-__global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, tde_world w, tde_state st, tde_render rd)
+// Kernel arguments of the rasteriser: only what it reads.  Passing tde_config + tde_world + tde_state + tde_render by value
+// (about 120 SGPRs of arguments) left the kernel at 98-106 SGPRs, and 256-thread workgroups are admitted per CU up to
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)) (MI355X_MICROARCH.md, "Residency"): 6 per CU instead of the 8 that the
+// wavefront limit allows.  With the slim block the kernel stays at or below 80 SGPRs.
+struct RenderArgs {
+    const tde_map *maps;
+    const uint32_t *cell_word;
+    const float *cell_tri;
+    const tde_scenario *scn_tab;
+    const double *wp_xy;
+    const tde_stopline *stoplines;
+    const tde_light_phase *phases;
+    const float *x, *y, *psi, *len, *wid;
+    const uint8_t *present;
+    const int32_t *scn, *steps, *target_idx;
+    tde_render rd;
+    float thr2;
+    uint32_t flags;
+    int32_t NW, A;
+};
+
+#ifndef TDE_RENDER_SGPRS
+#define TDE_RENDER_SGPRS 96
+#endif
+#ifndef TDE_RENDER_BLOCK
+#define TDE_RENDER_BLOCK 256
+#endif
+// threads per view: 256 = four wavefronts; 128 = two (twice the views in flight per CU at the same wavefront count)
+constexpr int kRB = TDE_RENDER_BLOCK;
+__global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPRS))) void render_layers_kernel(RenderArgs ra)
 {
+    // views of the argument block under the names the body uses (only the members set here are ever read)
+    tde_world w{};
+    w.maps = ra.maps; w.cell_word = ra.cell_word; w.cell_tri = ra.cell_tri; w.scn = ra.scn_tab; w.wp_xy = ra.wp_xy;
+    w.stoplines = ra.stoplines; w.phases = ra.phases; w.NW = ra.NW;
+    tde_state st{};
+    st.x = const_cast<float *>(ra.x); st.y = const_cast<float *>(ra.y); st.psi = const_cast<float *>(ra.psi);
+    st.len = const_cast<float *>(ra.len); st.wid = const_cast<float *>(ra.wid);
+    st.present = const_cast<uint8_t *>(ra.present); st.scn = const_cast<int32_t *>(ra.scn);
+    st.steps = const_cast<int32_t *>(ra.steps); st.target_idx = const_cast<int32_t *>(ra.target_idx); st.A = ra.A;
+    const tde_render &rd = ra.rd;
     __shared__ uint32_t s_layer[kRenderMaxPix / 4];
     __shared__ RenderBox s_box[kRenderMaxBox];           // NPC boxes in view, ego kept separately
     __shared__ float2 s_wp[kRenderMaxWp];
@@ -1490,7 +1531,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     __shared__ RenderBox s_stop[kRenderMaxStop];         // stop lines in view
     __shared__ uint8_t s_stopl[kRenderMaxStop];          // their layer (TDE_LAYER_STOP_RED / _GO)
     __shared__ uint16_t s_work[kRenderWork];             // pixels whose base layer needs the exact test (r * W + c)
-    __shared__ uint32_t s_mixed[kRenderWork];            // cell words of the queued pixels that lie in MIXED cells
+    __shared__ uint32_t s_mixed[kRenderMixed];           // cell words of the queued pixels that lie in MIXED cells
     __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed, s_nstop;
     const int tid = threadIdx.x;
     const int A = st.A, H = rd.H, W = rd.W;
@@ -1503,8 +1544,8 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     const int scn = st.scn[e];
     const int4 sc = reinterpret_cast<const int4 *>(w.scn)[scn];
     const tde_map m = w.maps[sc.x];
-    const float thr2 = thr2_of(cfg);
-    const bool lights = (cfg.flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    const float thr2 = ra.thr2;
+    const bool lights = (ra.flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     const float lsign = (rd.flags & TDE_RENDER_LEFT_HANDED) ? -1.0f : 1.0f;   // left-handed world: lateral image axis mirrored
     const int ego_layer = (rd.flags & TDE_RENDER_PLAIN_EGO) ? TDE_LAYER_NPC : TDE_LAYER_EGO;
     const float res = rd.fov / (float)W;
@@ -1563,7 +1604,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     }
     {
         const int ti = st.target_idx[e], n_wp = sc.y;
-        for (int k = ti + tid; k < n_wp; k += kBlock) {
+        for (int k = ti + tid; k < n_wp; k += kRB) {
             const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
             const float tx = (float)t.x, ty = (float)t.y;
             const float dx = tx - ex, dy = ty - ey, rr = rview + TDE_WAYPOINT_RADIUS;
@@ -1576,7 +1617,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     if (lights && m.n_stop > 0) {
         // stop lines of the map, coloured by the state of their light at the env's current step (oracle: tde_red_mask)
         const uint32_t red = red_mask(w, m, st.steps[e]);
-        for (int q = tid; q < m.n_stop; q += kBlock) {
+        for (int q = tid; q < m.n_stop; q += kRB) {
             const float4 la = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[0];
             const float4 lb = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[1];   // hl, hw, light, -
             const float dx = la.x - ex, dy = la.y - ey, rr = rview + (lb.x + lb.y);
@@ -1619,7 +1660,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         // ---- pass 1: base layer of 2x2 blocks (four per thread: the four cell words are in flight together) -------
         const int bw = W / 4, nblk = (H / 4) * bw;
         const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // pixel centres of a 2x2 block lie this close to its centre
-        for (int bi = tid; bi < nblk; bi += kBlock) {
+        for (int bi = tid; bi < nblk; bi += kRB) {
             const int r0 = (bi / bw) * 4, c0 = (bi % bw) * 4;
             uint32_t ws[4];
 #pragma unroll
@@ -1628,7 +1669,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
                 const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = ((halfW - ((float)(c0 + dc) + 1.0f)) * res) * lsign;
                 ws[sb] = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
             }
-            uint32_t need = 0;                                     // bit (dr*4 + dc): pixel needs the exact test
+            uint32_t need = 0;                                     // bit sb: the 2x2 sub-block needs the exact test
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
                 const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
@@ -1638,17 +1679,27 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
                     lay16[((r0 + dr) * W + c0 + dc) >> 1] = v;
                     lay16[((r0 + dr + 1) * W + c0 + dc) >> 1] = v;
                 } else {
-                    need |= 0x33u << (dr * 4 + dc);
+                    need |= 1u << sb;
                 }
             }
             if (need) {
-                const int n = __popc(need);
-                int at = atomicAdd(&s_nwork, n);
-                if (at + n > kRenderWork) need = 0;             // queue full: the view takes the all-pixels path
-                while (need) {
-                    const int b = __ffs((int)need) - 1;
-                    need &= need - 1u;
-                    s_work[at++] = (uint16_t)((r0 + (b >> 2)) * W + c0 + (b & 3));
+                // queue the four pixels of every flagged sub-block: one LDS counter bump per thread, then two packed
+                // 32-bit stores (two 16-bit pixel ids each) per sub-block at its rank among the flagged ones - no
+                // per-pixel loop (the wavefront used to iterate max-over-lanes(popcount) = 16 times almost always)
+                const int n = 4 * __popc(need);
+                const int at = atomicAdd(&s_nwork, n);             // multiples of 4: the 32-bit stores stay aligned
+                if (at + n <= kRenderWork) {                       // (else: queue full, the view takes the all-pixels path)
+                    uint32_t *q32 = reinterpret_cast<uint32_t *>(s_work);
+#pragma unroll
+                    for (int sb = 0; sb < 4; ++sb) {
+                        if ((need >> sb) & 1u) {
+                            const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
+                            const int rank = __popc(need & ((1u << sb) - 1u));
+                            const uint32_t p0 = (uint32_t)((r0 + dr) * W + c0 + dc), p1 = p0 + (uint32_t)W;
+                            q32[(at >> 1) + 2 * rank] = p0 | ((p0 + 1u) << 16);
+                            q32[(at >> 1) + 2 * rank + 1] = p1 | ((p1 + 1u) << 16);
+                        }
+                    }
                 }
             }
         }
@@ -1661,7 +1712,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         // rare fallback (more boxes / waypoints / edge pixels in view than the LDS lists hold): every pixel is shaded
         // from the global tables, literally as the specification reads
         const int ti = st.target_idx[e], n_wp = sc.y;
-        for (int pix = tid; pix < plane; pix += kBlock) {
+        for (int pix = tid; pix < plane; pix += kRB) {
             float wx, wy;
             pixel_world(pix / W, pix % W, wx, wy);
             int layer = base_layer(wx, wy);
@@ -1695,7 +1746,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
     } else {
         // ---- pass 2a: queued road-edge pixels: their own cell word; pixels in MIXED cells are compacted ... ---------
         const int npix = s_nwork;
-        for (int base = 0; base < npix; base += kBlock) {
+        for (int base = 0; base < npix; base += kRB) {
             const int wi = base + tid;
             bool defer = false;
             int pix = 0;
@@ -1712,14 +1763,22 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             __syncthreads();                                  // every lane has read its entry of this chunk:
             if (defer) {                                      // the compacted list may overwrite it
                 const int at = atomicAdd(&s_nmixed, 1);
-                s_work[at] = (uint16_t)pix;
-                s_mixed[at] = wd;                             // its cell word travels along: no second lookup
+                if (at < kRenderMixed) {
+                    s_work[at] = (uint16_t)pix;
+                    s_mixed[at] = wd;                         // its cell word travels along: no second lookup
+                } else {                                      // list full (never seen on the synthetic maps): resolve in place
+                    float wx, wy;
+                    pixel_world(pix / W, pix % W, wx, wy);
+                    lay8[pix] = (uint8_t)base_layer(wx, wy);
+                }
             }
             __syncthreads();
         }
-        // ---- pass 2b: ... and get their candidate-triangle tests here, densely -------------------------------------
-        const int nmixed = s_nmixed;
-        for (int wi = tid; wi < nmixed; wi += kBlock) {
+        // ---- pass 2b: ... and get their candidate-triangle tests here, densely.  Two candidate records are fetched per
+        // trip before either is tested: the loop is a chain of dependent L2 round trips (one per candidate), and two in
+        // flight halve it; the second test runs only when the first did not already settle the pixel.
+        const int nmixed = min(s_nmixed, kRenderMixed);
+        for (int wi = tid; wi < nmixed; wi += kRB) {
             const int pix = s_work[wi];
             const uint32_t wd = s_mixed[wi];
             float wx, wy;
@@ -1727,19 +1786,29 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
             const int n = (int)((wd >> 2) & 255u);
             bool road = false;
-            for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
+            for (int k = 0; k < n && !road; k += 2) {
+                const float4 *r0 = recs + 3 * k, *r1 = recs + 3 * (k + 1 < n ? k + 1 : k);
+                const float4 a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+                const float4 ta[3] = {a0, a1, a2};
+                road = point_tri_d2_packed(wx, wy, ta) <= thr2;
+                if (!road && k + 1 < n) {
+                    const float4 tb[3] = {b0, b1, b2};
+                    road = point_tri_d2_packed(wx, wy, tb) <= thr2;
+                }
+            }
             lay8[pix] = road ? 1 : 0;
         }
         __syncthreads();
         // ---- pass 3: objects over the base, in layer order (waypoint discs, NPC boxes, the ego): the workgroup covers
         // an object's conservative pixel span as a 16 x 16 tile of threads (one pixel per thread at 64 x 64) ------------
-        const int tr = tid >> 4, tc = tid & 15;
+        const int tr = tid >> 4, tc = tid & 15;       // a (kRB / 16) x 16 tile of threads walks an object's pixel span
+        constexpr int TR = kRB / 16;
         for (int k = 0; k < nstop; ++k) {                     // stop lines lie on the road, under everything else
             const RenderBox &b = s_stop[k];
             const float bx = b.x, by = b.y, bc = b.c, bs = b.s, bhl = b.hl, bhw = b.hw;
             const int rmax = b.rmax, cmin = b.cmin, cmax = b.cmax;
             const uint8_t lay = s_stopl[k];
-            for (int r = b.rmin + tr; r <= rmax; r += 16)
+            for (int r = b.rmin + tr; r <= rmax; r += TR)
                 for (int c = cmin + tc; c <= cmax; c += 16) {
                     float wx, wy;
                     pixel_world(r, c, wx, wy);
@@ -1752,7 +1821,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         for (int k = 0; k < nwp; ++k) {
             const PixelSpan b = s_wpbb[k];
             const float2 t = s_wp[k];
-            for (int r = b.rmin + tr; r <= b.rmax; r += 16)
+            for (int r = b.rmin + tr; r <= b.rmax; r += TR)
                 for (int c = b.cmin + tc; c <= b.cmax; c += 16) {
                     float wx, wy;
                     pixel_world(r, c, wx, wy);
@@ -1765,7 +1834,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             const RenderBox &b = s_box[k];
             const float bx = b.x, by = b.y, bc = b.c, bs = b.s, bhl = b.hl, bhw = b.hw;
             const int rmax = b.rmax, cmin = b.cmin, cmax = b.cmax;
-            for (int r = b.rmin + tr; r <= rmax; r += 16)
+            for (int r = b.rmin + tr; r <= rmax; r += TR)
                 for (int c = cmin + tc; c <= cmax; c += 16) {
                     float wx, wy;
                     pixel_world(r, c, wx, wy);
@@ -1778,7 +1847,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         {
             const float ehl = s_ego.hl, ehw = s_ego.hw;
             const int rmax = s_ego.rmax, cmin = s_ego.cmin, cmax = s_ego.cmax;
-            for (int r = s_ego.rmin + tr; r <= rmax; r += 16)
+            for (int r = s_ego.rmin + tr; r <= rmax; r += TR)
                 for (int c = cmin + tc; c <= cmax; c += 16) {
                     float wx, wy;
                     pixel_world(r, c, wx, wy);
@@ -1816,7 +1885,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         // is ring slot (phase + 1 + j) % ns.  Nothing is shifted: every frame of `out` is written from its layer plane.
         uint8_t *ring = rd.layers + (int64_t)e * ns * plane;
         const int slot_new = rd.phase % ns;
-        for (int i = tid; i < nv; i += kBlock) {
+        for (int i = tid; i < nv; i += kRB) {
             const uint4 v = src[i];
             reinterpret_cast<uint4 *>(ring + (int64_t)slot_new * plane)[i] = v;
             expand(v, out + 3 * (ns - 1) * plane, i);
@@ -1825,7 +1894,7 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
         for (int j = 0; j < ns - 1; ++j) {
             const int slot = (rd.phase + 1 + j) % ns;
             uint4 *old = reinterpret_cast<uint4 *>(ring + (int64_t)slot * plane);
-            for (int i = tid; i < nv; i += kBlock) {
+            for (int i = tid; i < nv; i += kRB) {
                 uint4 v;
                 if (fresh) { v = make_uint4(bl, bl, bl, bl); old[i] = v; }     // VecFrameStack: the stack restarts blank
                 else v = old[i];
@@ -1833,10 +1902,10 @@ __global__ __launch_bounds__(kBlock) void render_layers_kernel(tde_config cfg, t
             }
         }
     } else {
-        for (int i = tid; i < nv; i += kBlock) expand(src[i], out + 3 * (ns - 1) * plane, i);
+        for (int i = tid; i < nv; i += kRB) expand(src[i], out + 3 * (ns - 1) * plane, i);
         if (fresh && ns > 1) {                       // in-place stack (no ring): blank the older frames of this view
             uint4 *o4 = reinterpret_cast<uint4 *>(out);
-            for (int i = tid; i < 3 * (ns - 1) * nv; i += kBlock) o4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = tid; i < 3 * (ns - 1) * nv; i += kRB) o4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
 }
@@ -2048,7 +2117,15 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     if (st->B <= 0) return 0;
     if (rd->n_stack > 1 && !rd->layers && !rd->only)       // (a masked call re-renders the newest frame in place)
         tde::frame_shift_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(rd->out, rd->H * rd->W, rd->n_stack);
-    tde::render_layers_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *rd);
+    tde::RenderArgs ra;
+    ra.maps = world->maps; ra.cell_word = world->cell_word; ra.cell_tri = world->cell_tri; ra.scn_tab = world->scn;
+    ra.wp_xy = world->wp_xy; ra.stoplines = world->stoplines; ra.phases = world->phases;
+    ra.x = st->x; ra.y = st->y; ra.psi = st->psi; ra.len = st->len; ra.wid = st->wid; ra.present = st->present;
+    ra.scn = st->scn; ra.steps = st->steps; ra.target_idx = st->target_idx;
+    ra.rd = *rd;
+    ra.thr2 = cfg->offroad_threshold_squared ? cfg->offroad_threshold : cfg->offroad_threshold * cfg->offroad_threshold;
+    ra.flags = cfg->flags; ra.NW = world->NW; ra.A = st->A;
+    tde::render_layers_kernel<<<st->B, tde::kRB, 0, (hipStream_t)stream>>>(ra);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
 }
