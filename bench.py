@@ -314,7 +314,8 @@ def main():
         if args.config == 5:
             kernel = f"tde::env_step_kernel<{A}> + tde::render_layers_kernel"
         elif stepwise:
-            kernel = f"tde::env_step_kernel<{A}, false, false>"
+            kernel = (f"tde::env_step_kernel<{A}, false, false>" if os.environ.get("TDE_STEP") == "solo" or st["slot_cache"] is None
+                      else f"tde::env_step_trio_kernel<{A}, false, false>")
         else:
             team = {"solo": "", "duo": "_duo", "trio": "_trio"}.get(
                 os.environ.get("TDE_ROLLOUT", ""), "_trio" if A in (8, 16, 32) else "_duo")

@@ -155,6 +155,26 @@ typedef struct tde_world {
     int32_t n_routes, RW, n_replay, RT;
 } tde_world;
 
+/* Optional lookup caches of the closed-loop step (tde_env_step): what the step needs from the scenario tables for a
+ * slot / an env, kept next to the state so that a one-step launch starts with independent loads instead of the chain
+ * scenario -> spawn record -> route table (three dependent L2 / HBM round trips before the first useful instruction).
+ * Each entry carries the key it was formed for; the kernel uses it only when the key equals the current state and
+ * rebuilds it otherwise, so any writer of the state (reset, rollout, host edits) leaves the caches correct by
+ * construction.  An entry is valid when its TDE_CACHE_VALID bit is set (zero-initialised memory is invalid). */
+typedef struct tde_slot_cache {
+    int32_t scn, route_wp;      /* key: the env's scenario and this slot's route waypoint index */
+    float tgx, tgy;             /* NPC: current route waypoint */
+    int32_t route, route_n;     /* NPC: route id (-1: none) and its length */
+    int32_t replay, replay_len; /* replay row id (-1: none) and its length; bit 30 of replay_len = entry valid */
+} tde_slot_cache;
+
+typedef struct tde_env_cache {
+    int32_t scn, target_idx;    /* key */
+    int32_t n_wp, map;          /* waypoints of the scenario; its map id; bit 30 of n_wp = entry valid */
+    double wtx, wty;            /* current ego target (undefined when target_idx >= n_wp) */
+} tde_env_cache;
+#define TDE_CACHE_VALID (1 << 30)
+
 /* Mutable per-env / per-agent state and per-step outputs.  Caller-allocated, written in place. */
 typedef struct tde_state {
     /* agent arrays [B*A] */
@@ -194,6 +214,9 @@ typedef struct tde_state {
                                    return of the episode that just ended (its length is environment_steps at that step: the k
                                    of done_bits' step, also reported as ep_final_len); other entries keep their value */
     int32_t *ep_final_len;      /* out [B], with ep_final */
+    tde_slot_cache *slot_cache; /* in/out [B*A], tde_env_step only, may be NULL (with env_cache): see above.  With both caches
+                                   present (and 8, 16 or 32 agents per env) tde_env_step runs its three-role kernel */
+    tde_env_cache *env_cache;   /* in/out [B] */
     int32_t B, A;
 } tde_state;
 

@@ -362,3 +362,58 @@ def test_extension_equals_ctypes_equals_oracle(small_world):
     for t in range(50):
         a = torch.rand(16, 2, device=DEV) * 0.6 - 0.3
         assert torch.equal(b1.step(a)[0], b2.step(a)[0])
+
+
+@pytest.mark.parametrize("A", [8, 16, 32])
+@pytest.mark.parametrize("flags", [_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS, _abi.F_ALL & ~_abi.F_AUTORESET, _abi.F_NPC | _abi.F_OFFROAD])
+def test_step_three_role_kernel_and_caches_bit_exact(A, flags):
+    """tde_env_step with the lookup caches (three-role kernel) and without them (one-role kernel) against the oracle, over
+    re-spawns, masked resets, rollouts in between (which leave the caches keyed for an older state) and state
+    overwritten from the host (caches stale or empty): every array equal bit for bit at every checkpoint"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=8, A=A, seed=2, n_maps=2)
+    cfg = _abi.default_config(seed=17, distance_cutoff=0.25, flags=flags, max_steps=45)
+    B = 100                                               # not a multiple of the group size: partly filled last group
+    hs = EnvState(B, A)
+    fast, slow = EnvState(B, A, device=DEV, with_obs=True), EnvState(B, A, device=DEV, with_obs=True, with_cache=False)
+    assert fast["slot_cache"] is not None and slow["slot_cache"] is None
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    for ds in (fast, slow):
+        ops.env_reset(cfg, dw, ds)
+    rng = np.random.default_rng(8)
+
+    def check(tag):
+        h = hs.host()
+        for ds in (fast, slow):
+            d = ds.host()
+            for k, v in h.items():
+                if k != "action":
+                    assert np.array_equal(v.view(np.uint8), d[k].view(np.uint8)), (tag, k, ds is fast)
+        assert torch.equal(fast["obs"], slow["obs"]) and torch.equal(fast["obs"], ops.state_obs(dw, fast)), tag
+
+    for t in range(140):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        oracle.env_step(cfg, world, hs)
+        for ds in (fast, slow):
+            ds["action"].copy_(dev(act))
+            ops.env_step(cfg, dw, ds)
+        if t % 7 == 6:
+            check(t)
+        if t % 40 == 39:                                  # masked reset of the finished (or a few random) envs
+            m = ((hs["terminated"] | hs["truncated"]) | (rng.uniform(size=B) < 0.1)).astype(np.uint8)
+            oracle.env_reset(cfg, world, hs, m)
+            for ds in (fast, slow):
+                ops.env_reset(cfg, dw, ds, dev(m))
+        if t == 60:                                       # a rollout moves the state on without touching the caches
+            acts = np.stack([rng.uniform(-1, 1, (9, B)), rng.uniform(-0.3, 0.3, (9, B))], -1).astype(np.float32)
+            oracle.env_rollout(cfg, world, hs, acts)
+            for ds in (fast, slow):
+                ops.env_rollout(cfg, dw, ds, dev(acts))
+        if t == 100:                                      # state overwritten from the host: cache entries keyed for the old one
+            for ds in (fast, slow):
+                ds.load(hs.host())
+    check("end")
+    assert hs["episode"].max() > 1 and bool((fast["slot_cache"][:, 7] & (1 << 30)).any())

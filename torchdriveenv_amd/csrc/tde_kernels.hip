@@ -1275,6 +1275,284 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
 }
 #undef TDE_ROLE_PROLOGUE
 
+// ------------------------------------------------------------------------------------------------------------------
+// Closed-loop step, three roles (tde_env_step when the lookup caches are present): ONE timestep per launch, the
+// consumer's loop (SB3 calls step once per policy action, ref gym_env.py:453-461).  env_step_kernel above runs the whole
+// step as one serial chain per wavefront behind a prologue of three dependent table look-ups; here
+//   * the per-slot / per-env table entries come from the self-validating caches next to the state (tde_slot_cache /
+//     tde_env_cache): the prologue is ONE round of independent loads (a stale or empty entry falls back to the chain and
+//     is rewritten),
+//   * the step is split over the three wavefronts of the rollout kernel: drive (controller, bicycle, replay, route
+//     switch -> rows), judge C (collision, the ego's reward, outputs, episode statistics, the compact observation) and
+//     judge O (offroad, stop lines); the judges' prologues and the driver's chain overlap, and the judges run in parallel.
+// Same per-agent arithmetic in the same order as step_lane: results equal the oracle's bit for bit.
+// Barriers: B = rows of the step are committed, A = the judges' masks are published (every role forms done from them).
+// ------------------------------------------------------------------------------------------------------------------
+// the driver's table entries (route target, route / replay ids and lengths; the map when `want_map`) from the slot's
+// cache entry, or - when the entry is missing or keyed for another state - through the table chain of load_ctx
+template <int A>
+TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_state &st, int64_t g, int a, bool valid,
+                             Agent &ag, const EnvRegs &er, Ctx &cx, bool want_map, bool &rebuilt)
+{
+    const uint32_t F = cfg.flags;
+    const int4 *sc4 = reinterpret_cast<const int4 *>(st.slot_cache + g);
+    const int4 s0 = sc4[0], s1 = sc4[1];                  // scn, route_wp, tgx, tgy | route, route_n, replay, replay_len
+    const bool hit = !valid || ((s1.w & TDE_CACHE_VALID) && s0.x == er.scn && s0.y == ag.route_wp);
+    rebuilt = !hit;
+    cx.wtx = cx.wty = 0.0; cx.n_wp = 0;                   // (the ego's target is judge C's business)
+    if (__ballot(!hit)) {                                 // some lane of this wavefront needs the table chain
+        if (!hit) load_ctx<A>(cfg, cold, a, ag, er, cx);  // (also fetches the map when offroad / lights are on)
+    }
+    if (hit) {
+        cx.tgx = __int_as_float(s0.z); cx.tgy = __int_as_float(s0.w);
+        ag.route = s1.x; cx.route_n = s1.y; ag.replay = s1.z; cx.replay_len = s1.w & ~TDE_CACHE_VALID;
+        cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
+        if (want_map && (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS))) {
+            const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + (g / A))[0];     // scn, target_idx, n_wp, map
+            const int map = ((e0.z & TDE_CACHE_VALID) && e0.x == er.scn) ? e0.w : reinterpret_cast<const int4 *>(cold.scn)[er.scn].x;
+            cx.m = cold.maps[map];
+        }
+    }
+}
+
+TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, const EnvRegs &er, const Ctx &cx)
+{
+    int4 *sc4 = reinterpret_cast<int4 *>(st.slot_cache + g);
+    sc4[0] = make_int4(er.scn, ag.route_wp, __float_as_int(cx.tgx), __float_as_int(cx.tgy));
+    sc4[1] = make_int4(ag.route, cx.route_n, ag.replay, cx.replay_len | TDE_CACHE_VALID);
+}
+
+template <int A, bool LIGHTS, bool OBS>
+__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_step_trio_kernel(
+    tde_config cfg, tde_world w, tde_state st)
+{
+    __shared__ DuoShared sh;
+    __shared__ Cold cold;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull; }
+    const uint32_t F = cfg.flags;
+    const int64_t g = (int64_t)blockIdx.x * kWave + lane;
+    const int e = (int)(g / A), a = (int)(g % A);
+    const int B = st.B;
+    const bool valid = e < B;
+    const int64_t gs = valid ? g : 0;
+    const int es = valid ? e : 0;
+    const int base = lane - a;
+    __syncthreads();                                         // cold is filled
+    // done of every ego lane from the judges' masks (k = environment_steps of this step): R8 / R11
+    auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
+        const unsigned long long ego = __ballot(a == 0 && valid);
+        const unsigned long long infr = sh.off_mask | sh.hit_mask | sh.tl_mask;
+        term_m = ((F & TDE_F_REWARD) && cold.terminated_at_infraction) ? (infr & ego) : 0ull;
+        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= cold.max_steps) : 0ull;
+        return ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? (term_m | trunc_m) : 0ull;
+    };
+    if (role == 0) {
+        // ================================ drive ================================
+        __builtin_amdgcn_s_setprio(2);
+        Agent ag;
+        load_agent(st, gs, ag);
+        if (!valid) ag.present = false;
+        EnvRegs er{st.scn[es], st.steps[es], 0, 0, st.episode[es]};
+        const float2 act = reinterpret_cast<const float2 *>(st.action)[es];
+        Ctx cx;
+        bool rebuilt;
+        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, ag, er, cx, LIGHTS, rebuilt);
+        float c0, s0;
+        sincos_f32(ag.psi, s0, c0);
+        bool live = valid && ag.present;
+        write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);        // pre-step rows: what the controller reads
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
+        const int k = er.steps + 1;                                          // :116
+        const bool npc = (F & TDE_F_NPC) && a > 0 && live;
+        const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
+        float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
+        const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+        float acc = 0.0f, beta = 0.0f;
+        if (a == 0) { acc = act.x; beta = act.y; }
+        if (F & TDE_F_NPC) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's own rows are in LDS
+            const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
+            const float red_gap = (LIGHTS && red && has_target)
+                                      ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A},
+                                                        cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+            float na, nb;
+            npc_action<A>(cfg, &sh.a[1][base], &sh.b[1][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap,
+                          na, nb);
+            if (npc) { acc = na; beta = nb; }
+        }
+        if (live) {
+            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);     // :117
+            if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
+        }
+        bool switched = false;
+        if (has_target) {
+            const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
+            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { ag.route_wp += 1; switched = true; }
+        }
+        sincos_f32(ag.psi, s0, c0);
+        er.steps = k;
+        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);
+        lds_barrier();                                       // B: rows of this step are in buffer 0
+        if (switched) load_route_target(cold, ag, cx);       // (the cache entry of the next step)
+        lds_barrier();                                       // A: the judges' masks are published
+        unsigned long long term_m, trunc_m;
+        const unsigned long long dn = done_of(k, term_m, trunc_m);
+        bool respawned = false;
+        if (dn && ((dn >> base) & 1ull) && valid) {
+            reset_lane<A>(cfg, cold, e, a, ag, er);
+            load_ctx<A>(cfg, cold, a, ag, er, cx);
+            respawned = true;
+        }
+        if (!valid) return;
+        store_agent_dynamic(st, g, ag);
+        if (respawned) store_agent_static(st, g, ag);
+        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);
+    } else if (role == 1) {
+        // ===================== judge C: collision, reward, outputs =====================
+        __builtin_amdgcn_s_setprio(1);
+        EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
+        // the ego's pose before the step (:371-375), read before the driver commits the new one at the end of the launch
+        float lx = 0.0f, ly = 0.0f, lpsi = 0.0f, lv = 0.0f;
+        Ctx cx;
+        cx.n_wp = 0; cx.wtx = cx.wty = 0.0;
+        bool ecache_ok = false;
+        if (a == 0 && valid) {
+            lx = st.x[g]; ly = st.y[g]; lpsi = st.psi[g]; lv = st.v[g];
+            if (F & TDE_F_REWARD) {
+                const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + e)[0];
+                ecache_ok = (e0.z & TDE_CACHE_VALID) && e0.x == er.scn && e0.y == er.target_idx;
+                if (ecache_ok) {
+                    const double2 tg = reinterpret_cast<const double2 *>(st.env_cache + e)[1];
+                    cx.n_wp = e0.z & ~TDE_CACHE_VALID; cx.wtx = tg.x; cx.wty = tg.y;
+                } else {
+                    cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
+                    load_ego_target(cold, er, cx);
+                }
+            }
+        }
+        double ep_ret = 0.0;
+        if (a == 0 && valid && st.ep_return) ep_ret = st.ep_return[e];
+        lds_barrier();                                       // B
+        er.steps += 1;
+        const int k = er.steps;
+        const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
+        const bool hit = collide_rows<A>(&sh.a[0][base], &sh.b[0][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
+        const unsigned long long hm = __ballot(hit);
+        if (lane == 0) sh.hit_mask = hm;
+        RewardOut rw{};
+        const int ti0 = er.target_idx;
+        if (a == 0 && valid && (F & TDE_F_REWARD)) {
+            rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ra.x, ra.y, rc.x, rc.y, false, false, false, k,
+                             er.target_idx, er.reached, st.info != nullptr);
+            if (er.target_idx != ti0) load_ego_target(cold, er, cx);
+        }
+        lds_barrier();                                       // A: off / tl masks are in
+        unsigned long long term_m, trunc_m;
+        const unsigned long long dn = done_of(k, term_m, trunc_m);
+        const bool respawned = dn && ((dn >> base) & 1ull) && valid;
+        Agent ag;                                            // only filled (and used) when the env re-spawns
+        ag.x = ra.x; ag.y = ra.y; ag.psi = rc.x; ag.v = rc.y;
+        float oc = rb.x, os = rb.y;
+        const int k_done = k;
+        const int reached_out = er.reached;
+        if (respawned) {
+            reset_lane<A>(cfg, cold, e, a, ag, er);
+            if (a == 0 && (F & TDE_F_REWARD)) {
+                cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
+                load_ego_target(cold, er, cx);
+                if (OBS) sincos_f32(ag.psi, os, oc);
+            }
+        }
+        if (!valid) return;
+        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);
+        if (a == 0) {
+            const uint8_t term = (uint8_t)((term_m >> lane) & 1ull), trunc = (uint8_t)((trunc_m >> lane) & 1ull);
+            const uint8_t off0 = (uint8_t)((sh.off_mask >> lane) & 1ull), hit0 = (uint8_t)((sh.hit_mask >> lane) & 1ull),
+                          tl0 = (uint8_t)((sh.tl_mask >> lane) & 1ull);
+            st.steps[e] = er.steps;
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = rw.reward;
+            st.terminated[e] = term;
+            st.truncated[e] = trunc;
+            if (respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
+            if ((F & TDE_F_REWARD) && st.info) {
+                double *inf = st.info + 4 * (int64_t)e;
+                inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
+            }
+            if ((F & TDE_F_REWARD) && st.info_reached) st.info_reached[e] = reached_out;
+            if (st.done_bits) st.done_bits[e] = (uint8_t)(term | (trunc << 1) | (off0 << 2) | (hit0 << 3) | (tl0 << 4));
+            if (st.ep_return) {
+                double ret = ep_ret + (double)rw.reward;
+                if (term | trunc) {
+                    if (st.ep_final) st.ep_final[e] = ret;
+                    if (st.ep_final_len) st.ep_final_len[e] = k_done;
+                    if (respawned) ret = 0.0;
+                }
+                st.ep_return[e] = ret;
+            }
+            if (F & TDE_F_REWARD) {
+                if (respawned || er.target_idx != ti0 || !ecache_ok) {
+                    int4 *ec4 = reinterpret_cast<int4 *>(st.env_cache + e);
+                    ec4[0] = make_int4(er.scn, er.target_idx, cx.n_wp | TDE_CACHE_VALID, reinterpret_cast<const int4 *>(cold.scn)[er.scn].x);
+                    reinterpret_cast<double2 *>(st.env_cache + e)[1] = make_double2(cx.wtx, cx.wty);
+                }
+            }
+            if (OBS && st.obs) {
+                const bool ended = (term | trunc) && !respawned;
+                bool has;
+                double tx, ty;
+                if ((F & TDE_F_REWARD) && !ended) {
+                    has = er.target_idx < cx.n_wp; tx = cx.wtx; ty = cx.wty;
+                } else {
+                    has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
+                    const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
+                    tx = t2.x; ty = t2.y;
+                }
+                float fwd = 0.0f, lat = 0.0f;
+                if (has) {
+                    const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
+                    fwd = dx * oc + dy * os;
+                    lat = dy * oc - dx * os;
+                }
+                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
+                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
+                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
+            }
+        }
+    } else {
+        // ===================== judge O: offroad, stop lines =====================
+        __builtin_amdgcn_s_setprio(0);
+        const int scn = st.scn[es];
+        const int k = st.steps[es] + 1;
+        tde_map m{};
+        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) {
+            const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + es)[0];
+            const int map = ((e0.z & TDE_CACHE_VALID) && e0.x == scn) ? e0.w : reinterpret_cast<const int4 *>(cold.scn)[scn].x;
+            m = cold.maps[map];
+        }
+        const float thr2 = thr2_of(cfg);
+        lds_barrier();                                       // B
+        const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
+        const bool live = rc.z != 0.0f;
+        bool off = false, tl = false;
+        if (F & TDE_F_OFFROAD) off = box_offroad(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
+            tl = tl_violation(w, m, red_mask(w, m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+        const unsigned long long om = __ballot(off), tm = __ballot(tl);
+        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
+        lds_barrier();                                       // A
+        unsigned long long term_m, trunc_m;
+        const unsigned long long dn = done_of(k, term_m, trunc_m);
+        if (!valid) return;
+        st.offroad[g] = (dn && ((dn >> base) & 1ull)) ? 0 : (off ? 1 : 0);
+        if (a == 0 && st.tl_violation) st.tl_violation[e] = tl ? 1 : 0;
+    }
+}
+
 template <int A>
 __global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_world w, tde_state st,
                                                            const uint8_t *__restrict__ mask)
@@ -2041,8 +2319,23 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     if (rc) return rc;
     if (st->B <= 0) return 0;
     if (!st->action) return bad("tde_env_step: state.action is NULL");
-    const unsigned nb = blocks_for((int64_t)st->B * st->A);
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    // With the lookup caches present (and a group shape the three-role kernels are built for) the step runs as three
+    // wavefronts per 64 agent slots; TDE_STEP=solo forces the one-role kernel (A/B runs).
+    static const bool force_solo = [] { const char *v = getenv("TDE_STEP"); return v && !strcmp(v, "solo"); }();
+    if (st->slot_cache && st->env_cache && (st->A == 8 || st->A == 16 || st->A == 32) && !force_solo) {
+        const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
+#define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st)
+#define TDE_LAUNCH_STEP3_A(AA)                                                                       \
+    if (st->obs) { if (lights) TDE_LAUNCH_STEP3(AA, true, true); else TDE_LAUNCH_STEP3(AA, false, true); } \
+    else { if (lights) TDE_LAUNCH_STEP3(AA, true, false); else TDE_LAUNCH_STEP3(AA, false, false); }
+        if (st->A == 8) { TDE_LAUNCH_STEP3_A(8) } else if (st->A == 16) { TDE_LAUNCH_STEP3_A(16) } else { TDE_LAUNCH_STEP3_A(32) }
+#undef TDE_LAUNCH_STEP3_A
+#undef TDE_LAUNCH_STEP3
+        hipError_t e3 = hipGetLastError();
+        return e3 == hipSuccess ? 0 : fail("tde_env_step", e3);
+    }
+    const unsigned nb = blocks_for((int64_t)st->B * st->A);
 #define TDE_LAUNCH_STEP(L, O)                                                                                          \
     TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                 \
                               *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits))

@@ -18,7 +18,7 @@ OUTPUT_KEYS = ["reward", "terminated", "truncated", "tl_violation", "done_bits",
 class EnvState:
     """`arrays[name]` are numpy arrays (host; used with the CPU oracle in tests) or torch tensors (device)."""
 
-    def __init__(self, B, A, device=None, with_info=True, with_obs=False, with_episode=None):
+    def __init__(self, B, A, device=None, with_info=True, with_obs=False, with_episode=None, with_cache=None):
         assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
         self.B, self.A, self.device = int(B), int(A), device
         with_episode = with_info if with_episode is None else with_episode
@@ -30,6 +30,9 @@ class EnvState:
             off_keys.add("obs")
         if not with_episode:
             off_keys |= {"ep_return", "ep_final", "ep_final_len"}
+        # the step's lookup caches (tde_state.slot_cache / env_cache): device-side only (the oracle has no use for them)
+        if not (with_cache if with_cache is not None else device is not None):
+            off_keys |= {"slot_cache", "env_cache"}
         self.arrays = {}
         self._arena = self._pinned = None
         self._slots = {}
