@@ -217,6 +217,7 @@ def main():
         handle = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct),
                                        local_rank)
     cfg_flags = int(cfg.flags)
+    act_rows = [actions[i] for i in range(CH)]      # views made once: slicing a tensor costs microseconds of host time
 
     def launch(k, row):
         """k consecutive timesteps (k <= CH); `row` = first row of the action buffer to use"""
@@ -225,12 +226,12 @@ def main():
             return
         if handle is not None:
             for i in range(k):
-                handle.step(actions[(row + i) % CH], cfg_flags)
+                handle.step(act_rows[(row + i) % CH], cfg_flags)
                 if img is not None:
                     handle.render(img, 64, 64, 35.0, 1, None, 0, 0, None, None)
             return
         for i in range(k):
-            ops.env_step(cfg, dw, st, action=actions[(row + i) % CH])
+            ops.env_step(cfg, dw, st, action=act_rows[(row + i) % CH])
             if img is not None:
                 ops.render_ego(cfg, dw, st, out=img)
 
@@ -314,8 +315,9 @@ def main():
         if args.config == 5:
             kernel = f"tde::env_step_kernel<{A}> + tde::render_layers_kernel"
         elif stepwise:
-            kernel = (f"tde::env_step_kernel<{A}, false, false>" if os.environ.get("TDE_STEP") == "solo" or st["slot_cache"] is None
-                      else f"tde::env_step_trio_kernel<{A}, false, false>")
+            trio = st["slot_cache"] is not None and A in (8, 16, 32) and (
+                os.environ.get("TDE_STEP") == "trio" or (os.environ.get("TDE_STEP") is None and B * A <= 65536))
+            kernel = f"tde::env_step_trio_kernel<{A}, false, false>" if trio else f"tde::env_step_kernel<{A}, false, false>"
         else:
             team = {"solo": "", "duo": "_duo", "trio": "_trio"}.get(
                 os.environ.get("TDE_ROLLOUT", ""), "_trio" if A in (8, 16, 32) else "_duo")

@@ -166,7 +166,17 @@ typedef struct tde_slot_cache {
     float tgx, tgy;             /* NPC: current route waypoint */
     int32_t route, route_n;     /* NPC: route id (-1: none) and its length */
     int32_t replay, replay_len; /* replay row id (-1: none) and its length; bit 30 of replay_len = entry valid */
+    float tgx2, tgy2;           /* NPC: the route waypoint after the current one (a waypoint switch then needs no look-up
+                                   on the step's dependent chain); undefined when route_wp + 1 >= route_n */
+    int32_t _pad0, _pad1;
 } tde_slot_cache;
+
+/* The NPC controller's action for the NEXT step of a slot, computed at the end of a step behind the judges (it only
+ * needs the state after the step), keyed by the (episode, environment_steps) pair of the state it was computed from. */
+typedef struct tde_act_cache {
+    int32_t episode, steps;     /* key; episode < 0: invalid */
+    float acc, beta;
+} tde_act_cache;
 
 typedef struct tde_env_cache {
     int32_t scn, target_idx;    /* key */
@@ -217,6 +227,10 @@ typedef struct tde_state {
     tde_slot_cache *slot_cache; /* in/out [B*A], tde_env_step only, may be NULL (with env_cache): see above.  With both caches
                                    present (and 8, 16 or 32 agents per env) tde_env_step runs its three-role kernel */
     tde_env_cache *env_cache;   /* in/out [B] */
+    tde_act_cache *act_cache;   /* in/out [B*A], may be NULL: with it the three-role step applies the stored NPC actions at once
+                                   and computes the next step's behind the judges.  The key cannot see a state that was edited
+                                   from outside with its counters unchanged: zero / invalidate the cache after such an edit
+                                   (EnvState.load does) */
     int32_t B, A;
 } tde_state;
 

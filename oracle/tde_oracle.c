@@ -666,7 +666,12 @@ TDE_EXPORT int tde_oracle_env_rollout(const tde_config *cfg, const tde_world *w,
             st->reward[e] = o.reward;
             st->terminated[e] = o.terminated;
             st->truncated[e] = o.truncated;
-            if ((cfg->flags & TDE_F_AUTORESET) && (o.terminated || o.truncated)) tde_reset_env(cfg, w, st, e);
+            if ((cfg->flags & TDE_F_AUTORESET) && (o.terminated || o.truncated)) {
+                /* the Monitor-style episode statistics belong to the closed-loop step API: a rollout leaves them alone */
+                const double keep = st->ep_return ? st->ep_return[e] : 0.0;
+                tde_reset_env(cfg, w, st, e);
+                if (st->ep_return) st->ep_return[e] = keep;
+            }
         }
     }
     return 0;

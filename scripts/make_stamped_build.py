@@ -35,9 +35,12 @@ __device__ __forceinline__ void tde_mark(unsigned long long *last, int k)
     if ((threadIdx.x & 63) == 0) s_acc[k] += n - *last;
     *last = n;
 }
+// per-workgroup slots, plain read-modify-write by one lane (global atomics from every wavefront of every launch
+// serialise at ~12 ns each and distort what they measure); tde_debug_stamps sums the slots on the host
+__device__ unsigned long long g_wg[4096][24];
 __device__ __forceinline__ void tde_flush(int lo, int hi)
 {
-    if ((threadIdx.x & 63) == 0) for (int i = lo; i < hi; ++i) atomicAdd(&g_stamps[i], s_acc[i]);
+    if ((threadIdx.x & 63) == 0) for (int i = lo; i < hi; ++i) g_wg[blockIdx.x & 4095][i] += s_acc[i];
 }
 '''
 EPILOGUE = '''
@@ -46,6 +49,12 @@ extern "C" __attribute__((visibility("default"))) int tde_debug_stamps(unsigned 
     unsigned long long z[24] = {0};
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tde::g_stamps), sizeof(z));
     if (e == hipSuccess && clear) e = hipMemcpyToSymbol(HIP_SYMBOL(tde::g_stamps), z, sizeof(z));
+    static unsigned long long wg[4096][24];
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(wg, HIP_SYMBOL(tde::g_wg), sizeof(wg));
+    if (e == hipSuccess) {
+        for (int b = 0; b < 4096; ++b) for (int i = 0; i < 24; ++i) out[i] += wg[b][i];
+        if (clear) { memset(wg, 0, sizeof(wg)); e = hipMemcpyToSymbol(HIP_SYMBOL(tde::g_wg), wg, sizeof(wg)); }
+    }
     return (int)e;
 }
 '''
@@ -130,6 +139,37 @@ def patch_trio(s):
     return s[:a] + k + s[b:]
 
 
+def patch_step3(s):
+    """milestones of env_step_trio_kernel per role (ticks since the wavefront entered its role): drive 0-5, C 8-12, O 16-19"""
+    a, b = kernel_span(s, "env_step_trio_kernel")
+    k = s[a:b]
+    k = sub(k, "    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.hit_mask = 0ull;",
+            "    unsigned long long stl = __builtin_amdgcn_s_memtime();\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.hit_mask = 0ull;")
+    # drive
+    k = sub(k, "        float c0, s0;\n        sincos_f32(ag.psi, s0, c0);\n        bool live = valid && ag.present;",
+            "        tde_mark(&stl, 0);\n        float c0, s0;\n        sincos_f32(ag.psi, s0, c0);\n        bool live = valid && ag.present;")
+    k = sub(k, "        if (live) {\n            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);     // :117",
+            "        tde_mark(&stl, 1);\n        if (live) {\n            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);     // :117")
+    k = sub(k, "        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n",
+            "        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);\n        tde_mark(&stl, 2);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(&stl, 3);\n")
+    k = sub(k, "        lds_barrier();                                       // A: the judges' masks are published\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;",
+            "        lds_barrier();                                       // A: the judges' masks are published\n        tde_mark(&stl, 4);\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;")
+    k = sub(k, "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);\n",
+            "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);\n        tde_mark(&stl, 5);\n        tde_flush(0, 6);\n")
+    # judge C
+    k = sub(k, "        lds_barrier();                                       // B\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]",
+            "        tde_mark(&stl, 8);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 9);\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]")
+    k = sub(k, "        lds_barrier();                                       // A: off / tl masks are in\n",
+            "        tde_mark(&stl, 10);\n        lds_barrier();                                       // A: off / tl masks are in\n        tde_mark(&stl, 11);\n")
+    # judge O
+    k = sub(k, "        const float thr2 = thr2_of(cfg);\n        lds_barrier();                                       // B\n",
+            "        const float thr2 = thr2_of(cfg);\n        tde_mark(&stl, 16);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 17);\n")
+    k = sub(k, "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n        lds_barrier();                                       // A\n",
+            "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n        tde_mark(&stl, 18);\n        lds_barrier();                                       // A\n        tde_mark(&stl, 19);\n        tde_flush(16, 20);\n")
+    k = sub(k, "        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);", "        tde_flush(8, 12);\n        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);")
+    return s[:a] + k + s[b:]
+
+
 def patch_render(s):
     a, b = kernel_span(s, "render_layers_kernel")
     k = s[a:b]
@@ -166,7 +206,7 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "duo"
     s = open(SRC).read()
     s = sub(s, ANCHOR, PRELUDE + ANCHOR)
-    s = {"duo": patch_duo, "trio": patch_trio, "render": patch_render, "trips": patch_trips}[mode](s) + EPILOGUE
+    s = {"duo": patch_duo, "trio": patch_trio, "step3": patch_step3, "render": patch_render, "trips": patch_trips}[mode](s) + EPILOGUE
     os.makedirs(os.path.join(ROOT, "ab"), exist_ok=True)
     tmp = os.path.join(ROOT, "ab", f"tde_kernels_{mode}_stamped.hip")
     open(tmp, "w").write(s)

@@ -1,0 +1,42 @@
+"""Milestones of the three-role one-step kernel (make_stamped_build.py step3): ticks since the wavefront entered the kernel.
+usage: python scripts/make_stamped_build.py step3 && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/step_stamps.py"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from torchdriveenv_amd import _abi, _lib, ops
+from torchdriveenv_amd.state import EnvState
+from torchdriveenv_amd.synth import synthetic_world
+
+B, A, N = 8192, 16, 400
+dev = torch.device("cuda:0")
+lib = _lib.load()
+world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+dw = world.to_device(dev)
+cfg = _abi.default_config(seed=1, distance_cutoff=0.25)
+st = EnvState(B, A, device=dev, with_info=False)
+ops.env_reset(cfg, dw, st)
+act = torch.zeros(B, 2, device=dev)
+for _ in range(50):
+    ops.env_step(cfg, dw, st, action=act)
+torch.cuda.synchronize()
+out = (C.c_ulonglong * 24)()
+lib.tde_debug_stamps(out, 1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(N):
+    ops.env_step(cfg, dw, st, action=act)
+e1.record()
+torch.cuda.synchronize()
+lib.tde_debug_stamps(out, 0)
+n = (B * A // 64) * N
+print(f"{e0.elapsed_time(e1) * 1e3 / N:.2f} us per step (stamped build)")
+names = {0: "D: entry -> state + cache loaded", 1: "D: controller", 2: "D: bicycle, route switch, sincos, rows", 3: "D: wait B",
+         4: "D: route reload + wait A", 5: "D: done test, re-spawn, stores",
+         8: "C: entry -> prologue done", 9: "C: wait B", 10: "C: collision + reward", 11: "C: wait A",
+         16: "O: entry -> prologue done", 17: "O: wait B", 18: "O: offroad + stop lines", 19: "O: wait A"}
+for i, nm in names.items():
+    print(f"  {nm:42s} {out[i] / n:8.0f} ticks")

@@ -376,6 +376,7 @@ def test_step_three_role_kernel_and_caches_bit_exact(A, flags):
     cfg = _abi.default_config(seed=17, distance_cutoff=0.25, flags=flags, max_steps=45)
     B = 100                                               # not a multiple of the group size: partly filled last group
     hs = EnvState(B, A)
+    # (100 envs: far below the size at which tde_env_step switches back to the one-role kernel)
     fast, slow = EnvState(B, A, device=DEV, with_obs=True), EnvState(B, A, device=DEV, with_obs=True, with_cache=False)
     assert fast["slot_cache"] is not None and slow["slot_cache"] is None
     dw = world.to_device(DEV)
@@ -389,7 +390,9 @@ def test_step_three_role_kernel_and_caches_bit_exact(A, flags):
         for ds in (fast, slow):
             d = ds.host()
             for k, v in h.items():
-                if k != "action":
+                if k == "info":       # float64 psi_reward: libm vs OCML cos may differ in the last bit (test_reward_cos_bits_...)
+                    assert np.array_equal(v[:, [0, 1, 3]], d[k][:, [0, 1, 3]]) and np.abs(v[:, 2] - d[k][:, 2]).max() < 1e-14, (tag, ds is fast)
+                elif k != "action":
                     assert np.array_equal(v.view(np.uint8), d[k].view(np.uint8)), (tag, k, ds is fast)
         assert torch.equal(fast["obs"], slow["obs"]) and torch.equal(fast["obs"], ops.state_obs(dw, fast)), tag
 

@@ -89,7 +89,7 @@ STATE_AGENT_U8 = ["present", "collided", "offroad"]
 STATE_ENV_I32 = ["scn", "steps", "target_idx", "reached", "episode"]
 STATE_PTRS = (STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8 + STATE_ENV_I32 +
               ["action", "reward", "terminated", "truncated", "tl_violation", "info", "info_reached", "done_bits", "obs",
-               "ep_return", "ep_final", "ep_final_len", "slot_cache", "env_cache"])
+               "ep_return", "ep_final", "ep_final_len", "slot_cache", "env_cache", "act_cache"])
 
 
 class TdeState(C.Structure):
@@ -169,7 +169,7 @@ STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n
                 "tl_violation": np.uint8,
                 "info": np.float64, "info_reached": np.int32, "done_bits": np.uint8, "obs": np.float32,
                 "ep_return": np.float64, "ep_final": np.float64, "ep_final_len": np.int32,
-                "slot_cache": np.int32, "env_cache": np.int32}          # opaque 32-byte records (tde_slot_cache / tde_env_cache)
+                "slot_cache": np.int32, "env_cache": np.int32, "act_cache": np.int32}          # opaque 32-byte records (tde_slot_cache / tde_env_cache)
 
 
 def state_shapes(B, A):
@@ -178,7 +178,7 @@ def state_shapes(B, A):
     sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "tl_violation": (B,),
                "info": (B, 4),
                "info_reached": (B,), "done_bits": (B,), "obs": (B, 8), "ep_return": (B,), "ep_final": (B,),
-               "ep_final_len": (B,), "slot_cache": (B * A, 8), "env_cache": (B, 8)})
+               "ep_final_len": (B,), "slot_cache": (B * A, 12), "env_cache": (B, 8), "act_cache": (B * A, 4)})
     return sh
 
 

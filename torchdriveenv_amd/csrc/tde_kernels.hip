@@ -155,6 +155,7 @@ TDE_DEV void store_agent_static(const tde_state &st, int64_t g, const Agent &a)
 struct Ctx {
     tde_map m;                 // map of the env's scenario
     float tgx, tgy;            // NPC: current route waypoint
+    float tgx2, tgy2;          // (three-role step only) the one after it, from / for the slot cache
     int route_n, replay_len;   // NPC: length of its route / replay row (0 if none)
     float g_far;               // NPC: gap beyond which a leader cannot cap the speed (see npc_action)
     double wtx, wty;           // ego: current target waypoint
@@ -1288,24 +1289,38 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
 // Same per-agent arithmetic in the same order as step_lane: results equal the oracle's bit for bit.
 // Barriers: B = rows of the step are committed, A = the judges' masks are published (every role forms done from them).
 // ------------------------------------------------------------------------------------------------------------------
-// the driver's table entries (route target, route / replay ids and lengths; the map when `want_map`) from the slot's
-// cache entry, or - when the entry is missing or keyed for another state - through the table chain of load_ctx
+// The driver's table entries (route target and the one after it, route / replay ids and lengths; the map when
+// `want_map`) from the slot's cache entry (s0, s1, s2: its three 16-byte words, fetched by the caller ahead of the
+// workgroup's first barrier), or - when the entry is missing or keyed for another state - through the table chain.
+TDE_DEV void load_next_target(const Cold &w, const Agent &ag, int route_n, float &x2, float &y2)
+{
+    x2 = y2 = 0.0f;
+    if (ag.route >= 0 && ag.route_wp + 1 < route_n) {
+        const float2 tg = reinterpret_cast<const float2 *>(w.route_xy)[(int64_t)ag.route * w.RW + ag.route_wp + 1];
+        x2 = tg.x; y2 = tg.y;
+    }
+}
+
 template <int A>
 TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_state &st, int64_t g, int a, bool valid,
-                             Agent &ag, const EnvRegs &er, Ctx &cx, bool want_map, bool &rebuilt)
+                             const int4 &s0, const int4 &s1, const int4 &s2, Agent &ag, const EnvRegs &er, Ctx &cx,
+                             bool want_map, bool &rebuilt)
 {
     const uint32_t F = cfg.flags;
-    const int4 *sc4 = reinterpret_cast<const int4 *>(st.slot_cache + g);
-    const int4 s0 = sc4[0], s1 = sc4[1];                  // scn, route_wp, tgx, tgy | route, route_n, replay, replay_len
     const bool hit = !valid || ((s1.w & TDE_CACHE_VALID) && s0.x == er.scn && s0.y == ag.route_wp);
     rebuilt = !hit;
     cx.wtx = cx.wty = 0.0; cx.n_wp = 0;                   // (the ego's target is judge C's business)
+    cx.tgx2 = cx.tgy2 = 0.0f;
     if (__ballot(!hit)) {                                 // some lane of this wavefront needs the table chain
-        if (!hit) load_ctx<A>(cfg, cold, a, ag, er, cx);  // (also fetches the map when offroad / lights are on)
+        if (!hit) {
+            load_ctx<A>(cfg, cold, a, ag, er, cx);        // (also fetches the map when offroad / lights are on)
+            load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);
+        }
     }
     if (hit) {
         cx.tgx = __int_as_float(s0.z); cx.tgy = __int_as_float(s0.w);
         ag.route = s1.x; cx.route_n = s1.y; ag.replay = s1.z; cx.replay_len = s1.w & ~TDE_CACHE_VALID;
+        cx.tgx2 = __int_as_float(s2.x); cx.tgy2 = __int_as_float(s2.y);
         cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
         if (want_map && (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS))) {
             const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + (g / A))[0];     // scn, target_idx, n_wp, map
@@ -1320,6 +1335,7 @@ TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, c
     int4 *sc4 = reinterpret_cast<int4 *>(st.slot_cache + g);
     sc4[0] = make_int4(er.scn, ag.route_wp, __float_as_int(cx.tgx), __float_as_int(cx.tgy));
     sc4[1] = make_int4(ag.route, cx.route_n, ag.replay, cx.replay_len | TDE_CACHE_VALID);
+    sc4[2] = make_int4(__float_as_int(cx.tgx2), __float_as_int(cx.tgy2), 0, 0);
 }
 
 template <int A, bool LIGHTS, bool OBS>
@@ -1339,7 +1355,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     const int64_t gs = valid ? g : 0;
     const int es = valid ? e : 0;
     const int base = lane - a;
-    __syncthreads();                                         // cold is filled
+    // Every role first ISSUES the loads of its state (none of them needs the cold block), then meets the others at the
+    // LDS-only barrier that publishes `cold`: the loads stay in flight across it (a __syncthreads would wait for them).
     // done of every ego lane from the judges' masks (k = environment_steps of this step): R8 / R11
     auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
         const unsigned long long ego = __ballot(a == 0 && valid);
@@ -1356,32 +1373,47 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (!valid) ag.present = false;
         EnvRegs er{st.scn[es], st.steps[es], 0, 0, st.episode[es]};
         const float2 act = reinterpret_cast<const float2 *>(st.action)[es];
+        const int4 *sc4 = reinterpret_cast<const int4 *>(st.slot_cache + gs);
+        const int4 sc0 = sc4[0], sc1 = sc4[1], sc2 = sc4[2];
+        int4 ac = make_int4(-1, 0, 0, 0);                                    // episode, steps, acc, beta
+        if (st.act_cache) ac = reinterpret_cast<const int4 *>(st.act_cache)[gs];
+        lds_barrier();                                                       // cold is published
         Ctx cx;
         bool rebuilt;
-        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, ag, er, cx, LIGHTS, rebuilt);
+        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, sc2, ag, er, cx, LIGHTS, rebuilt);
         float c0, s0;
-        sincos_f32(ag.psi, s0, c0);
-        bool live = valid && ag.present;
-        write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);        // pre-step rows: what the controller reads
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
+        const bool live = valid && ag.present;
         const int k = er.steps + 1;                                          // :116
         const bool npc = (F & TDE_F_NPC) && a > 0 && live;
         const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
         float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-        const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+        bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
         float acc = 0.0f, beta = 0.0f;
         if (a == 0) { acc = act.x; beta = act.y; }
-        if (F & TDE_F_NPC) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's own rows are in LDS
-            const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
+        // the controller's action for this step: stored by the previous launch (key = the state's episode / step counters)
+        // or, when some slot of this wavefront has none, computed here from the pre-step rows
+        auto controller = [&](int buf, int kk, float &na, float &nb) {
+            const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, kk) : 0u;
             const float red_gap = (LIGHTS && red && has_target)
                                       ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A},
                                                         cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-            float na, nb;
-            npc_action<A>(cfg, &sh.a[1][base], &sh.b[1][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap,
-                          na, nb);
-            if (npc) { acc = na; beta = nb; }
+            npc_action<A>(cfg, &sh.a[buf][base], &sh.b[buf][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far,
+                          red_gap, na, nb);
+        };
+        if (F & TDE_F_NPC) {
+            const bool stored = !npc || (ac.x == er.episode && ac.y == er.steps);
+            if (__ballot(!stored)) {
+                sincos_f32(ag.psi, s0, c0);
+                write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's own rows are in LDS
+                float na, nb;
+                controller(1, k, na, nb);
+                if (npc) { acc = na; beta = nb; }
+            } else if (npc) {
+                acc = __int_as_float(ac.z); beta = __int_as_float(ac.w);
+            }
         }
         if (live) {
             bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);     // :117
@@ -1390,26 +1422,50 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         bool switched = false;
         if (has_target) {
             const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
-            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { ag.route_wp += 1; switched = true; }
+            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) {
+                ag.route_wp += 1; switched = true;
+                cx.tgx = cx.tgx2; cx.tgy = cx.tgy2;                          // the look-ahead entry: no table read on the chain
+            }
         }
         sincos_f32(ag.psi, s0, c0);
         er.steps = k;
         write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);
         lds_barrier();                                       // B: rows of this step are in buffer 0
-        if (switched) load_route_target(cold, ag, cx);       // (the cache entry of the next step)
+        if (switched) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);   // (only stored: the entry after the new one)
+        // the controller of the NEXT step runs here, beside the judges of this one: it needs the state after this step
+        // only.  Speculative like the rollout kernels' driver: an env that turns out to have finished is re-spawned below
+        // and the wavefront repeats it on the new rows.
+        float na2 = 0.0f, nb2 = 0.0f;
+        has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+        if ((F & TDE_F_NPC) && st.act_cache) controller(0, k + 1, na2, nb2);
         lds_barrier();                                       // A: the judges' masks are published
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
         bool respawned = false;
-        if (dn && ((dn >> base) & 1ull) && valid) {
-            reset_lane<A>(cfg, cold, e, a, ag, er);
-            load_ctx<A>(cfg, cold, a, ag, er, cx);
-            respawned = true;
+        if (dn) {
+            if (((dn >> base) & 1ull) && valid) {
+                reset_lane<A>(cfg, cold, e, a, ag, er);
+                load_ctx<A>(cfg, cold, a, ag, er, cx);
+                load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);
+                respawned = true;
+                sincos_f32(ag.psi, s0, c0);
+                write_rows(sh, 0, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges are done with the rows)
+                if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
+            }
+            if ((F & TDE_F_NPC) && st.act_cache) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const bool npc2 = (F & TDE_F_NPC) && a > 0 && valid && ag.present;
+                has_target = npc2 && ag.route >= 0 && ag.route_wp < cx.route_n;
+                controller(0, er.steps + 1, na2, nb2);
+            }
         }
         if (!valid) return;
         store_agent_dynamic(st, g, ag);
         if (respawned) store_agent_static(st, g, ag);
         if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);
+        if (st.act_cache)
+            reinterpret_cast<int4 *>(st.act_cache)[g] = make_int4((F & TDE_F_NPC) ? er.episode : -1, er.steps,
+                                                                  __float_as_int(na2), __float_as_int(nb2));
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================
         __builtin_amdgcn_s_setprio(1);
@@ -1419,22 +1475,25 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         Ctx cx;
         cx.n_wp = 0; cx.wtx = cx.wty = 0.0;
         bool ecache_ok = false;
+        int4 e0 = make_int4(0, 0, 0, 0);
+        double2 etg = make_double2(0.0, 0.0);
+        double ep_ret = 0.0;
         if (a == 0 && valid) {
             lx = st.x[g]; ly = st.y[g]; lpsi = st.psi[g]; lv = st.v[g];
-            if (F & TDE_F_REWARD) {
-                const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + e)[0];
-                ecache_ok = (e0.z & TDE_CACHE_VALID) && e0.x == er.scn && e0.y == er.target_idx;
-                if (ecache_ok) {
-                    const double2 tg = reinterpret_cast<const double2 *>(st.env_cache + e)[1];
-                    cx.n_wp = e0.z & ~TDE_CACHE_VALID; cx.wtx = tg.x; cx.wty = tg.y;
-                } else {
-                    cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
-                    load_ego_target(cold, er, cx);
-                }
+            e0 = reinterpret_cast<const int4 *>(st.env_cache + e)[0];
+            etg = reinterpret_cast<const double2 *>(st.env_cache + e)[1];
+            if (st.ep_return) ep_ret = st.ep_return[e];
+        }
+        lds_barrier();                                       // cold is published
+        if (a == 0 && valid && (F & TDE_F_REWARD)) {
+            ecache_ok = (e0.z & TDE_CACHE_VALID) && e0.x == er.scn && e0.y == er.target_idx;
+            if (ecache_ok) {
+                cx.n_wp = e0.z & ~TDE_CACHE_VALID; cx.wtx = etg.x; cx.wty = etg.y;
+            } else {
+                cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
+                load_ego_target(cold, er, cx);
             }
         }
-        double ep_ret = 0.0;
-        if (a == 0 && valid && st.ep_return) ep_ret = st.ep_return[e];
         lds_barrier();                                       // B
         er.steps += 1;
         const int k = er.steps;
@@ -1528,9 +1587,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         __builtin_amdgcn_s_setprio(0);
         const int scn = st.scn[es];
         const int k = st.steps[es] + 1;
+        int4 e0 = make_int4(0, 0, 0, 0);
+        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) e0 = reinterpret_cast<const int4 *>(st.env_cache + es)[0];
+        lds_barrier();                                       // cold is published
         tde_map m{};
         if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) {
-            const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + es)[0];
             const int map = ((e0.z & TDE_CACHE_VALID) && e0.x == scn) ? e0.w : reinterpret_cast<const int4 *>(cold.scn)[scn].x;
             m = cold.maps[map];
         }
@@ -2322,8 +2383,17 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     // With the lookup caches present (and a group shape the three-role kernels are built for) the step runs as three
     // wavefronts per 64 agent slots; TDE_STEP=solo forces the one-role kernel (A/B runs).
-    static const bool force_solo = [] { const char *v = getenv("TDE_STEP"); return v && !strcmp(v, "solo"); }();
-    if (st->slot_cache && st->env_cache && (st->A == 8 || st->A == 16 || st->A == 32) && !force_solo) {
+    // Which one wins is a matter of load (same-box, scripts/launch_cost.py, us per launch at 16 agents per env):
+    //   envs      512   1024   2048   4096   8192   16384
+    //   3 roles   8.5    8.7    9.1   10.1   12.3    19.3      (<= 2048: bounded by the ctypes host floor of 7.2)
+    //   1 role   10.2   10.2   10.3   10.5   11.9    16.4
+    // a launch costs ~5 us of fixed latency (dispatch + one wavefront's dependent chain, which the role split and the
+    // caches shorten) plus ~0.85 us per 1024 envs of issue time (which the two extra prologues lengthen): three roles
+    // up to 65 536 agent slots, one role above.  TDE_STEP=solo|trio forces one.
+    static const int force = [] { const char *v = getenv("TDE_STEP"); return !v ? 0 : !strcmp(v, "solo") ? 1 : !strcmp(v, "trio") ? 3 : 0; }();
+    const bool trio_ok = st->slot_cache && st->env_cache && (st->A == 8 || st->A == 16 || st->A == 32);
+    const bool want_trio = force == 3 || (force == 0 && (int64_t)st->B * st->A <= 65536);
+    if (trio_ok && want_trio) {
         const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
 #define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st)
 #define TDE_LAUNCH_STEP3_A(AA)                                                                       \

@@ -32,7 +32,7 @@ class EnvState:
             off_keys |= {"ep_return", "ep_final", "ep_final_len"}
         # the step's lookup caches (tde_state.slot_cache / env_cache): device-side only (the oracle has no use for them)
         if not (with_cache if with_cache is not None else device is not None):
-            off_keys |= {"slot_cache", "env_cache"}
+            off_keys |= {"slot_cache", "env_cache", "act_cache"}
         self.arrays = {}
         self._arena = self._pinned = None
         self._slots = {}
@@ -60,6 +60,8 @@ class EnvState:
                     self.arrays[n] = self._arena[o:o + nb].view(dt).view(sh)
                 else:
                     self.arrays[n] = torch.zeros(sh, dtype=dt, device=device)
+        if self.arrays.get("act_cache") is not None:
+            self.arrays["act_cache"][:, 0] = -1                   # episode key < 0: invalid
         self.struct = _abi.fill_state_struct(self.arrays, B, A)
 
     def fetch_outputs(self):
@@ -87,8 +89,19 @@ class EnvState:
             out[n] = a.copy() if isinstance(a, np.ndarray) else a.detach().cpu().numpy()
         return out
 
+    def invalidate_caches(self):
+        """forget the step's lookup / action caches (call after editing state arrays by hand: the action cache is keyed by
+        the episode / step counters only)"""
+        for n in ("slot_cache", "env_cache", "act_cache"):
+            a = self.arrays.get(n)
+            if a is not None:
+                a.fill(0) if isinstance(a, np.ndarray) else a.zero_()
+                if n == "act_cache":
+                    (a[:, 0].fill(-1) if isinstance(a, np.ndarray) else a[:, 0].fill_(-1))
+
     def load(self, host_arrays):
-        """overwrite from a dict of numpy arrays (e.g. another state's .host())"""
+        """overwrite from a dict of numpy arrays (e.g. another state's .host()); the caches are invalidated"""
+        self.invalidate_caches()
         for n, a in host_arrays.items():
             dst = self.arrays.get(n)
             if dst is None:
