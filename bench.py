@@ -102,7 +102,30 @@ def cpu_baseline(world, cfg, A, budget_s=12.0):
         n1 += 50
     b1 = n1 / (time.perf_counter() - t0)
     oracle.set_num_threads(cores)
-    return {"value": B * K / dt, "unit": "env-steps/s", "agent_steps_per_s": B * A * K / dt,
+    # (a) of SURVEY 8d: the same step as batched B x A tensor ops on the host (oracle/torch_step.py), all cores
+    bt = None
+    if cfg.flags & 1:                                                  # (the full-step workload)
+        try:
+            import torch
+
+            from oracle.torch_step import TorchWorld, torch_env_step
+            torch.set_num_threads(cores)
+            tw = TorchWorld(world)
+            ht = EnvState(B, A)
+            oracle.env_reset(cfg, world, ht)
+            ht["action"][...] = acts(1)[0]
+            torch_env_step(cfg, world, tw, ht, oracle_reset=oracle.env_reset)          # warm-up
+            nt, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 4.0:
+                ht["action"][...] = acts(1)[0]
+                torch_env_step(cfg, world, tw, ht, oracle_reset=oracle.env_reset)
+                nt += 1
+            dtt = time.perf_counter() - t0
+            bt = {"value": B * nt / dtt, "unit": "env-steps/s", "threads": torch.get_num_threads(),
+                  "sample": f"{B} envs x {A} agents x {nt} steps as batched torch ops on the host (oracle/torch_step.py), {dtt:.1f} s"}
+        except Exception as exc:                                       # pragma: no cover
+            bt = {"error": repr(exc)}
+    return {"batched_torch": bt, "value": B * K / dt, "unit": "env-steps/s", "agent_steps_per_s": B * A * K / dt,
             "cores": oracle.num_threads(), "kind": "port", "b1_single_thread_env_steps_per_s": b1,
             "sample": f"{B} envs x {A} agents x {K} steps of the same workload, oracle/tde_oracle.c "
                       f"(brute-force mesh distance, OpenMP over envs), {dt:.1f} s"}
@@ -128,6 +151,20 @@ def spawn_ranks(n):
     for p in procs:
         rc = max(rc, abs(p.wait()))
     return rc
+
+
+class _StdoutToStderr:
+    """gloo announces its connections on stdout; stdout must carry the ONE JSON line only"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
 
 
 def main():
@@ -183,7 +220,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world_size,
                                     device_id=torch.device(f"cuda:{local_rank}"))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+            with _StdoutToStderr():
+                dist.init_process_group("gloo", rank=rank, world_size=world_size)
+                dist.barrier()
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     _lib.load()

@@ -390,7 +390,7 @@ def test_render_crowded_view_takes_the_all_pixels_path():
 def test_reward_cos_bits_agree_between_libm_and_ocml():
     """R6: the reward's float64 `cos` is libm on the CPU and OCML on the GPU; the claim that the fp32-rounded reward
     carries the same bits is checked here on 10^6 random heading changes (both signs, tiny to pi, incl. exact zeros).
-    The float64 psi_reward info term may differ in its last bit (|diff| <= one ulp of cos ~ 1: 25 * 2.2e-16)."""
+    The float64 psi_reward info term may differ in its last bit (measured: 0.6 % of the samples, by one ulp)."""
     rng = np.random.default_rng(123)
     n = 1_000_000
     dpsi = np.concatenate([rng.uniform(-np.pi, np.pi, n // 2), rng.normal(0, 0.05, n // 4),
@@ -419,4 +419,5 @@ def test_reward_cos_bits_agree_between_libm_and_ocml():
     for col in (0, 1, 3):
         assert np.array_equal(gi[:, col].view(np.uint64), wi[:, col].view(np.uint64)), col
     d = np.abs(gi[:, 2] - wi[:, 2])
-    assert d.max() <= 25.0 * 2.3e-16 and (d > 0).mean() < 0.2, (d.max(), (d > 0).mean())
+    ulp = np.spacing(np.maximum(np.abs(gi[:, 2]), np.abs(wi[:, 2])))
+    assert (d <= ulp).all() and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())     # measured: 0.6 % differ, by one ulp

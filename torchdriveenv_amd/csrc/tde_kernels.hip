@@ -2429,9 +2429,11 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
     // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (TDE_ROLLOUT=solo|duo|trio forces
-    // one).  Measured same-box (scripts/rollout_matrix.py, profiles/r01_j_rollout_matrix.txt): three roles win at 8, 16
-    // and 32 agents per env, with and without traffic lights (3.90 vs 4.25, 4.11 vs 4.44, 4.63 vs 4.82 us per step); at
-    // 64 agents per env the 64-slot sweeps do not fit the 80-VGPR cap of six wavefronts per SIMD (7.45 vs 5.90).
+    // one).  Interleaved same-process A/B, 40 launches each, median us per step (scripts/ab_rollout.py duo:... trio:...,
+    // profiles/r02_b_rollout_matrix.txt): three roles win at 8, 16 and 32 agents per env without traffic lights (3.66 vs
+    // 3.92, 3.69 vs 4.02, 4.48 vs 4.96) and at 8 and 16 with them (5.62 vs 6.04, 5.17 vs 5.62); at 32 with lights the two
+    // are within 1 % (6.26 vs 6.19); at 64 agents per env the 64-slot sweeps do not fit the 80-VGPR cap of six
+    // wavefronts per SIMD, so two roles run there.
     static const int forced = [] {
         const char *v = getenv("TDE_ROLLOUT");
         return !v ? 0 : !strcmp(v, "solo") ? 1 : !strcmp(v, "duo") ? 2 : !strcmp(v, "trio") ? 3 : 0;
