@@ -243,6 +243,22 @@ def test_env_rollout_matches_oracle(small_world):
     assert (hd & 1).sum() > 0
 
 
+def test_env_rollout_without_autoreset_runs_past_termination(small_world):
+    """no TDE_F_AUTORESET: finished envs keep being stepped (no re-spawn); the ego target advanced on the terminal step
+    must be the one the following steps use (the one-role persistent kernel kept a stale one)"""
+    cfg = _abi.default_config(seed=6, distance_cutoff=0.25, flags=_abi.F_ALL & ~_abi.F_AUTORESET, max_steps=40)
+    B, A, K = 96, 16, 120
+    hs, ds, dw = _pair(small_world, B, A, cfg)
+    rng = np.random.default_rng(10)
+    actions = np.stack([rng.uniform(0, 1, (K, B)), rng.uniform(-0.1, 0.1, (K, B))], -1).astype(np.float32)
+    hr, hd = oracle.env_rollout(cfg, small_world, hs, actions)
+    dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32))
+    assert np.array_equal(dd.cpu().numpy(), hd)
+    assert_state_equal(hs.host(), ds.host(), "rollout without autoreset")
+    assert (hd[-1] & 2).all() and hs["reached"].max() >= 2          # everyone truncated long ago, waypoints still counted
+
+
 def test_config2_kin_collide_1024x8():
     """BASELINE.json configs[1]: 1024 envs x 8 agents, bicycle kinematics + OBB collision only"""
     rng = np.random.default_rng(2)

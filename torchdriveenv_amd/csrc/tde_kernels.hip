@@ -592,7 +592,8 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
             }
             if (st.info_reached) st.info_reached[e] = er.reached;
             done = (r.terminated | r.truncated) ? 1 : 0;
-            if (er.target_idx != ti0 && !done) load_ego_target(cold, er, cx);
+            // (a finished env reloads it when it re-spawns; without TDE_F_AUTORESET there is no re-spawn to do so)
+            if (er.target_idx != ti0 && (!done || !(F & TDE_F_AUTORESET))) load_ego_target(cold, er, cx);
         }
         if (F & TDE_F_AUTORESET) {
             // wave ballot of the ego lanes' termination flags: the reset path is skipped by wavefronts in which no
