@@ -435,5 +435,5 @@ def test_reward_cos_bits_agree_between_libm_and_ocml():
     for col in (0, 1, 3):
         assert np.array_equal(gi[:, col].view(np.uint64), wi[:, col].view(np.uint64)), col
     d = np.abs(gi[:, 2] - wi[:, 2])
-    ulp = np.spacing(np.maximum(np.abs(gi[:, 2]), np.abs(wi[:, 2])))
-    assert (d <= ulp).all() and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())     # measured: 0.6 % differ, by one ulp
+    # one ulp of cos (1.1e-16) times the penalty 25, or one ulp of the result near its maximum 50 (7.1e-15)
+    assert d.max() <= 8e-15 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())      # measured: 0.6 % differ, max 7.1e-15
