@@ -296,3 +296,45 @@ def test_every_rollout_kernel_matches_the_oracle(mode):
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+def test_configs3_partitioning_at_full_size_on_one_gpu():
+    """BASELINE configs[3] is 65 536 envs x 16 agents sharded 8 192 per GPU over 8 GPUs.  One GPU can hold the whole
+    batch, so the partitioning is checked at FULL size here: the eight shards (env_base = r * 8192, stepped one after the
+    other on this GPU exactly as rank r would step them) reproduce the unsharded 65 536-env batch bit for bit, and a
+    slice of the LAST shard equals the oracle run with the same global env indices."""
+    from torchdriveenv_amd.sharding import shard_config
+
+    world = synthetic_world(n_scn=64, A=16, seed=0, n_maps=4)
+    base = _abi.default_config(seed=1000, distance_cutoff=0.25)            # bench.py's config
+    N, Bs, A, K = 8, 8192, 16, 48
+    B = N * Bs
+    dw = world.to_device(DEV)
+    g = torch.Generator().manual_seed(5)
+    actions = torch.stack([torch.rand(K, B, generator=g) * 2 - 1, torch.rand(K, B, generator=g) * 0.6 - 0.3], -1).float()
+    full = EnvState(B, A, device=DEV, with_info=False)
+    ops.env_reset(base, dw, full)
+    fr, fd = ops.env_rollout(base, dw, full, actions.contiguous().to(DEV))
+    fr, fd = fr.cpu().numpy(), fd.cpu().numpy()
+    fx, fep = full["x"].cpu().numpy(), full["episode"].cpu().numpy()
+    for r in range(N):
+        cfg, n = shard_config(base, r, N, B)
+        assert n == Bs and cfg.env_base == r * Bs
+        st = EnvState(Bs, A, device=DEV, with_info=False)
+        ops.env_reset(cfg, dw, st)
+        a = actions[:, r * Bs:(r + 1) * Bs].contiguous().to(DEV)
+        sr, sd = ops.env_rollout(cfg, dw, st, a)
+        lo, hi = r * Bs, (r + 1) * Bs
+        assert np.array_equal(sr.cpu().numpy().view(np.uint32), fr[:, lo:hi].view(np.uint32)), r
+        assert np.array_equal(sd.cpu().numpy(), fd[:, lo:hi]), r
+        assert np.array_equal(st["x"].cpu().numpy().view(np.uint32), fx[lo * A:hi * A].view(np.uint32)), r
+        assert np.array_equal(st["episode"].cpu().numpy(), fep[lo:hi]), r
+    # the oracle on the first 96 envs of the last shard (global env indices 57344 ...)
+    cfg, _ = shard_config(base, N - 1, N, B)
+    SUB = 96
+    hs = EnvState(SUB, A)
+    oracle.env_reset(cfg, world, hs)
+    lo = (N - 1) * Bs
+    hr, hd = oracle.env_rollout(cfg, world, hs, np.ascontiguousarray(actions[:, lo:lo + SUB].numpy()))
+    assert np.array_equal(hr.view(np.uint32), fr[:, lo:lo + SUB].view(np.uint32)) and np.array_equal(hd, fd[:, lo:lo + SUB])
+    assert (fd & 1).sum() > 0 and fep.max() >= 2
