@@ -177,9 +177,11 @@ def patch_render(s):
     def mark(n):
         return ("    { unsigned long long tn = __builtin_amdgcn_s_memtime(); if (tid == 0) g_loc[%d] += tn - tlast; "
                 "tlast = tn; }\n" % n)
-    k = sub(k, "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }\n",
+    k = sub(k, "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; s_nstop = 0; }\n",
             "    unsigned long long tlast = __builtin_amdgcn_s_memtime();\n    unsigned long long g_loc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};\n"
-            "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; }\n")
+            "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; s_nstop = 0; }\n")
+    # split the first phase: the cull (pass 0) ends where the block pass begins
+    k = sub(k, "        // ---- pass 1: base layer of 2x2 blocks", mark(6) + "        // ---- pass 1: base layer of 2x2 blocks")
     k = sub(k, "    __syncthreads();\n    const bool crowded =", mark(1) + "    __syncthreads();\n    const bool crowded =")
     k = sub(k, "        // ---- pass 2b:", mark(2) + "        // ---- pass 2b:")
     k = sub(k, "        // ---- pass 3: objects over the base", mark(3) + "        // ---- pass 3: objects over the base")

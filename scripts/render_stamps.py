@@ -21,7 +21,7 @@ out = (C.c_ulonglong * 24)(); lib.tde_debug_stamps(out, 1)
 for _ in range(5): img = ops.render_ego(cfg, dw, st, out=img)
 torch.cuda.synchronize(); lib.tde_debug_stamps(out, 0)
 n = out[10]
-names = ["(unused)", "cull + blocks", "queued pixels (cell word)", "mixed pixels (triangles)", "objects", "stream out"]
+names = {6: "entry + cull (pass 0)", 1: "blocks (pass 1)", 2: "queued pixels (cell word)", 3: "mixed pixels (triangles)", 4: "objects", 5: "stream out"}
 print("views sampled", n, "queued px/view", out[11] / n, "mixed px/view", out[12] / n)
-for i, nm in enumerate(names): print(f"  {nm:28s} {out[i] / n:9.0f} ticks")
-print("  total", sum(out[:6]) / n)
+for i, nm in names.items(): print(f"  {nm:28s} {out[i] / n:9.0f} ticks")
+print("  total", sum(out[:7]) / n)

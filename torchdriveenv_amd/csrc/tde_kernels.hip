@@ -780,7 +780,11 @@ struct DuoShared {
     float4 a[2][kWave], b[2][kWave];
     float4 c[2][kWave];                  // (psi, v, live, -): what the judge's ego lane and liveness test need
     unsigned long long done;             // ballot of the ego lanes whose env finished at the last judged step
-    unsigned long long hit_mask, off_mask, tl_mask;   // three-role kernel: per-slot ballots of the judges, previous step
+    // three-role kernels: per-slot ballots of the judges of the previous step, and next to them the two config words the
+    // done test needs, so that done_of() is ONE LDS round trip (two 16-byte reads) instead of three dependent ones
+    alignas(16) unsigned long long hit_mask;
+    unsigned long long off_mask, tl_mask;
+    int32_t max_steps_w, term_at_infraction_w;
     // the first kStopCache stop lines of every env's map (A >= 8, i.e. at most 8 envs per group): the per-step stop-line
     // loops read LDS instead of walking the global table with one exposed L2 round trip per line
     float4 stop[8][8][2];
@@ -1039,7 +1043,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     __shared__ Cold cold;
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = drive, 1 = judge
-    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull; sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull; }
+    if (threadIdx.x == 0) {
+        fill_cold(cold, cfg, w); sh.done = 0ull; sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull;
+        sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
+    }
     const uint32_t F = cfg.flags;
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
@@ -1061,9 +1068,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     // done(i-1) of every ego lane from the judges' masks of that step (k = its environment_steps): R8 / R11
     auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
         const unsigned long long ego = __ballot(a == 0 && valid);
-        const unsigned long long infr = sh.off_mask | sh.hit_mask | sh.tl_mask;
-        term_m = ((F & TDE_F_REWARD) && cold.terminated_at_infraction) ? (infr & ego) : 0ull;
-        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= cold.max_steps) : 0ull;
+        const uint4 m0 = *reinterpret_cast<const uint4 *>(&sh.hit_mask);          // hit, off
+        const uint4 m1 = *reinterpret_cast<const uint4 *>(&sh.tl_mask);           // tl, max_steps, term_at_infraction
+        const unsigned long long infr = (((unsigned long long)(m0.y | m0.w | m1.y)) << 32) | (m0.x | m0.z | m1.x);
+        term_m = ((F & TDE_F_REWARD) && m1.w) ? (infr & ego) : 0ull;
+        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= (int)m1.z) : 0ull;
         return ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? (term_m | trunc_m) : 0ull;
     };
     if (role == 0) {
@@ -1347,7 +1356,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     __shared__ Cold cold;
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull; }
+    if (threadIdx.x == 0) {
+        fill_cold(cold, cfg, w); sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull;
+        sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
+    }
     const uint32_t F = cfg.flags;
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
@@ -1361,9 +1373,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     // done of every ego lane from the judges' masks (k = environment_steps of this step): R8 / R11
     auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
         const unsigned long long ego = __ballot(a == 0 && valid);
-        const unsigned long long infr = sh.off_mask | sh.hit_mask | sh.tl_mask;
-        term_m = ((F & TDE_F_REWARD) && cold.terminated_at_infraction) ? (infr & ego) : 0ull;
-        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= cold.max_steps) : 0ull;
+        const uint4 m0 = *reinterpret_cast<const uint4 *>(&sh.hit_mask);          // hit, off
+        const uint4 m1 = *reinterpret_cast<const uint4 *>(&sh.tl_mask);           // tl, max_steps, term_at_infraction
+        const unsigned long long infr = (((unsigned long long)(m0.y | m0.w | m1.y)) << 32) | (m0.x | m0.z | m1.x);
+        term_m = ((F & TDE_F_REWARD) && m1.w) ? (infr & ego) : 0ull;
+        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= (int)m1.z) : 0ull;
         return ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? (term_m | trunc_m) : 0ull;
     };
     if (role == 0) {
@@ -1884,6 +1898,8 @@ __global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPR
     const int scn = st.scn[e];
     const int4 sc = reinterpret_cast<const int4 *>(w.scn)[scn];
     const tde_map m = w.maps[sc.x];
+    // (a per-view cache of these two records - one round of loads instead of the chain scenario -> map - was measured and
+    // buys nothing: 66.4 vs 65.8 us; other workgroups cover a view's start-up latency, the kernel is bound by issue)
     const float thr2 = ra.thr2;
     const bool lights = (ra.flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     const float lsign = (rd.flags & TDE_RENDER_LEFT_HANDED) ? -1.0f : 1.0f;   // left-handed world: lateral image axis mirrored
@@ -1920,14 +1936,18 @@ __global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPR
         const float pr = ef * inv_res + 1.0f, pc = el * inv_res + 1.0f;
         return clip(rc - pr, rc + pr, cc - pc, cc + pc);
     };
-    // ---- pass 0: cull agents and waypoints to the view --------------------------------------------------------
-    if (tid < A) {
-        const int64_t g = g0 + tid;
+    // ---- pass 0: cull agents, waypoints and stop lines to the view.  Each kind is handled by a DIFFERENT wavefront (its
+    // dependent loads then overlap with the others' instead of queueing up in wavefront 0, which used to hold the whole
+    // workgroup at the barrier behind pass 1), and the wavefronts without culling work start pass 1 at once.
+    constexpr int kCullAgents = kRB >= 128 ? 64 : 0, kCullWp = kRB >= 256 ? 128 : 0, kCullStop = kRB >= 256 ? 192 : 0;
+    if (tid >= kCullAgents && tid < kCullAgents + A) {
+        const int ai = tid - kCullAgents;
+        const int64_t g = g0 + ai;
         float sa, ca;
         sincos_f32(st.psi[g], sa, ca);
         const float bx = st.x[g], by = st.y[g], bhl = 0.5f * st.len[g], bhw = 0.5f * st.wid[g];
         RenderBox *dstb = nullptr;
-        if (tid == 0) {
+        if (ai == 0) {
             dstb = &s_ego;
         } else if (st.present[g]) {
             const float dx = bx - ex, dy = by - ey, rr = rview + (bhl + bhw);
@@ -1944,7 +1964,7 @@ __global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPR
     }
     {
         const int ti = st.target_idx[e], n_wp = sc.y;
-        for (int k = ti + tid; k < n_wp; k += kRB) {
+        for (int k = ti + (tid - kCullWp); k < n_wp && tid >= kCullWp; k += kRB - kCullWp) {
             const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
             const float tx = (float)t.x, ty = (float)t.y;
             const float dx = tx - ex, dy = ty - ey, rr = rview + TDE_WAYPOINT_RADIUS;
@@ -1957,7 +1977,7 @@ __global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPR
     if (lights && m.n_stop > 0) {
         // stop lines of the map, coloured by the state of their light at the env's current step (oracle: tde_red_mask)
         const uint32_t red = red_mask(w, m, st.steps[e]);
-        for (int q = tid; q < m.n_stop; q += kRB) {
+        for (int q = tid - kCullStop; q < m.n_stop && tid >= kCullStop; q += kRB - kCullStop) {
             const float4 la = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[0];
             const float4 lb = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[1];   // hl, hw, light, -
             const float dx = la.x - ex, dy = la.y - ey, rr = rview + (lb.x + lb.y);
@@ -2086,30 +2106,42 @@ __global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPR
     } else {
         // ---- pass 2a: queued road-edge pixels: their own cell word; pixels in MIXED cells are compacted ... ---------
         const int npix = s_nwork;
-        for (int base = 0; base < npix; base += kRB) {
-            const int wi = base + tid;
-            bool defer = false;
-            int pix = 0;
-            uint32_t wd = 0;
-            if (wi < npix) {
-                pix = s_work[wi];
-                float wx, wy;
-                pixel_world(pix / W, pix % W, wx, wy);
-                wd = cell_lookup(w, m, wx, wy);
-                const uint32_t cls = wd & 3u;
-                if (cls == TDE_CELL_MIXED) defer = true;
-                else lay8[pix] = (cls == TDE_CELL_FULL) ? 1 : 0;
-            }
-            __syncthreads();                                  // every lane has read its entry of this chunk:
-            if (defer) {                                      // the compacted list may overwrite it
-                const int at = atomicAdd(&s_nmixed, 1);
-                if (at < kRenderMixed) {
-                    s_work[at] = (uint16_t)pix;
-                    s_mixed[at] = wd;                         // its cell word travels along: no second lookup
-                } else {                                      // list full (never seen on the synthetic maps): resolve in place
+        for (int base = 0; base < npix; base += 2 * kRB) {          // two pixels per thread and trip: both cell words in flight
+            int pix[2] = {0, 0};
+            uint32_t wd[2] = {0, 0};
+            bool have[2], defer[2] = {false, false};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int wi = base + u * kRB + tid;
+                have[u] = wi < npix;
+                if (have[u]) {
+                    pix[u] = s_work[wi];
                     float wx, wy;
-                    pixel_world(pix / W, pix % W, wx, wy);
-                    lay8[pix] = (uint8_t)base_layer(wx, wy);
+                    pixel_world(pix[u] / W, pix[u] % W, wx, wy);
+                    wd[u] = cell_lookup(w, m, wx, wy);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (have[u]) {
+                    const uint32_t cls = wd[u] & 3u;
+                    if (cls == TDE_CELL_MIXED) defer[u] = true;
+                    else lay8[pix[u]] = (cls == TDE_CELL_FULL) ? 1 : 0;
+                }
+            }
+            __syncthreads();                                  // every lane has read its entries of this chunk:
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (defer[u]) {                               // the compacted list may overwrite them
+                    const int at = atomicAdd(&s_nmixed, 1);
+                    if (at < kRenderMixed) {
+                        s_work[at] = (uint16_t)pix[u];
+                        s_mixed[at] = wd[u];                  // its cell word travels along: no second lookup
+                    } else {                                  // list full (never seen on the synthetic maps): resolve in place
+                        float wx, wy;
+                        pixel_world(pix[u] / W, pix[u] % W, wx, wy);
+                        lay8[pix[u]] = (uint8_t)base_layer(wx, wy);
+                    }
                 }
             }
             __syncthreads();
