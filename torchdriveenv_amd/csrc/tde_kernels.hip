@@ -22,6 +22,17 @@ namespace tde {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
+// 16-byte streaming store as ONE global_store_dwordx4 ... nt.  (__builtin_nontemporal_store on the members of HIP's uint4
+// struct gives four dword stores whose lanes interleave at 16-byte stride: four times the store instructions, each
+// writing a quarter of every cache line it touches.)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+TDE_DEV void store_nt16(void *dst, const uint4 &v)
+{
+    u32x4_t t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(dst));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // per-lane registers
 // ------------------------------------------------------------------------------------------------------------------
@@ -1813,8 +1824,7 @@ __global__ __launch_bounds__(kBlock) void frame_shift_kernel(uint8_t *__restrict
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * kBlock + tid;
             if (i < nvec) {
-                __builtin_nontemporal_store(v[u].x, &dst[i].x); __builtin_nontemporal_store(v[u].y, &dst[i].y);
-                __builtin_nontemporal_store(v[u].z, &dst[i].z); __builtin_nontemporal_store(v[u].w, &dst[i].w);
+                store_nt16(&dst[i], v[u]);
             }
         }
     }
@@ -2245,8 +2255,7 @@ __global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPR
             o.z = __builtin_amdgcn_perm(hi, lo, v.z); o.w = __builtin_amdgcn_perm(hi, lo, v.w);
             // streaming stores: the observation is consumed by the policy, not by this kernel (n_stack 3: 150 -> 95 us)
             uint4 *dstp = reinterpret_cast<uint4 *>(frame + ch * plane) + i;
-            __builtin_nontemporal_store(o.x, &dstp->x); __builtin_nontemporal_store(o.y, &dstp->y);
-            __builtin_nontemporal_store(o.z, &dstp->z); __builtin_nontemporal_store(o.w, &dstp->w);
+            store_nt16(dstp, o);
         }
     };
     const uint4 *src = reinterpret_cast<const uint4 *>(s_layer);
