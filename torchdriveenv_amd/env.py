@@ -449,7 +449,7 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
     reference's trainer (ref examples/rl_training.py:121-129, 159-160): numpy actions in, (obs, rewards, dones, infos)
     out, finished envs re-spawned at once with `terminal_observation`, `TimeLimit.truncated` and Monitor's
     `episode = {"r", "l", "t"}` in their info.  Subclasses SB3's VecEnv when stable_baselines3 is importable; otherwise
-    the same methods on a plain class (tests/test_vecenv_contract.py walks the abstract interface).
+    the same methods on a plain class (tests/test_features_cpu.py walks the abstract interface).
 
     Per step: one fused step launch, one observation launch, ONE packed device-to-host copy of all per-env outputs and
     one of the observation, one stream synchronisation; `infos` is a LazyInfos.  copy_obs=False hands out views of a
