@@ -104,8 +104,8 @@ def patch_trio(s):
             "    tde_mark(stl, 2);\n    if (!has_target) {\n        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);")
     a, b = kernel_span(s, "env_rollout_trio_kernel")
     k = s[a:b]
-    k = sub(k, "    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull;",
-            "    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull;")
+    k = sub(k, "    if (threadIdx.x == 0) {\n        fill_cold(cold, cfg, w); sh.done = 0ull;",
+            "    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) {\n        fill_cold(cold, cfg, w); sh.done = 0ull;")
     # ---- driver
     k = sub(k, "        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];",
             "        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];")

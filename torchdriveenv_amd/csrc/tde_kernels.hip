@@ -140,6 +140,42 @@ template <int A, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks(const
     else return word;
 }
 
+// The same sweep with every row fetched as two 8-byte halves (.xy / .zw) that are consumed - and therefore re-fetched for
+// the next block - at different stages: `stage(xy, zw, verdicts, prefetch_xy, prefetch_zw)`.  The halves of the two rows
+// of a block travel in one ds_read2_b64 each, so the number of LDS instructions is that of the 16-byte form.
+template <int A, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks_halves(const float4 *rows, S &&stage)
+{
+    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
+    constexpr int NB = A / C;
+    uint32_t word = 0, hi = 0;
+    const float2 *h = reinterpret_cast<const float2 *>(rows);
+    float2 xy[C], zw[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { xy[j] = h[2 * j]; zw[j] = h[2 * j + 1]; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float v[C];
+        stage(xy, zw, v,
+              [&]() {
+                  if (b + 1 < NB) {
+#pragma unroll
+                      for (int j = 0; j < C; ++j) xy[j] = h[2 * ((b + 1) * C + j)];
+                  }
+              },
+              [&]() {
+                  if (b + 1 < NB) {
+#pragma unroll
+                      for (int j = 0; j < C; ++j) zw[j] = h[2 * ((b + 1) * C + j) + 1];
+                  }
+              });
+#pragma unroll
+        for (int j = 0; j < C; ++j) word = push_sign(word, v[j]);
+        if (A == 64 && (b + 1) * C == 32) { hi = word; word = 0; }
+    }
+    if constexpr (A == 64) return ((unsigned long long)hi << 32) | word;
+    else return word;
+}
+
 TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
 {
     a.x = st.x[g]; a.y = st.y[g]; a.psi = st.psi[g]; a.v = st.v[g];
@@ -289,19 +325,22 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
         const float nP = 0.01f - (ag.x * cp + ag.y * sp), nQ = -(ag.y * cp - ag.x * sp);
         const float L = (g_far + hl_i) + 0.07f;
         const float kc = fmaxf(cfg.npc_cone_k, 0.0f);
-        cand = sweep_blocks<A>(ra, [&](float4 (&r)[C], float (&v)[C], auto &&prefetch) {
+        cand = sweep_blocks_halves<A>(ra, [&](float2 (&xy)[C], float2 (&zw)[C], float (&v)[C], auto &&prefetch_xy, auto &&prefetch_zw) {
             float f[C], l[C], n[C], w[C];
 #pragma unroll
-            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].y, sp, nP); l[j] = __builtin_fmaf(-r[j].x, sp, nQ); }
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(xy[j].y, sp, nP); l[j] = __builtin_fmaf(-xy[j].x, sp, nQ); }
             pin(f, l);
 #pragma unroll
-            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].x, cp, f[j]); l[j] = __builtin_fmaf(r[j].y, cp, l[j]); }
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(xy[j].x, cp, f[j]); l[j] = __builtin_fmaf(xy[j].y, cp, l[j]); }
             pin(f, l);
+            pin_memory();
+            prefetch_xy();                                     // the positions are consumed: fetch the next block's
+            pin_memory();
 #pragma unroll
-            for (int j = 0; j < C; ++j) { n[j] = r[j].z - f[j]; w[j] = __builtin_fmaf(kc, f[j], r[j].w); }
+            for (int j = 0; j < C; ++j) { n[j] = zw[j].x - f[j]; w[j] = __builtin_fmaf(kc, f[j], zw[j].y); }
             pin(n, w);
             pin_memory();
-            prefetch();                                        // the rows are consumed: fetch the next block's
+            prefetch_zw();
             pin_memory();
 #pragma unroll
             for (int j = 0; j < C; ++j) { n[j] = n[j] + L; w[j] = w[j] - fabsf(l[j]); }
