@@ -161,7 +161,14 @@ TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, flo
     return w.cell_word[m.cell_base + (tile << 6) + ((iy & 7) << 3) + (ix & 7)];
 }
 
-#define TDE_SEL4(i, a0, a1, a2, a3) ((i) == 0 ? (a0) : (i) == 1 ? (a1) : (i) == 2 ? (a2) : (a3))
+// two-level select on the bits of i (three v_cndmask; the comparison chain was compiled into nested exec-mask branches)
+template <typename T> TDE_DEV T sel4(int i, T a0, T a1, T a2, T a3)
+{
+    const bool b0 = (i & 1) != 0, b1 = (i & 2) != 0;
+    const T lo = b0 ? a1 : a0, hi = b0 ? a3 : a2;
+    return b1 ? hi : lo;
+}
+#define TDE_SEL4(i, a0, a1, a2, a3) sel4((i), (a0), (a1), (a2), (a3))
 
 // compute_offroad() > 0 for one box: any of the corners FL, FR, RR, RL farther than sqrt(thr2) from the mesh.
 // Split in two so that the four dependent cell-word loads are in flight while other work (the collision sweep) runs:
@@ -194,11 +201,11 @@ TDE_DEV void offroad_issue(const tde_world &w, const tde_map &m, bool live, floa
 TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
 {
     const uint32_t w0 = k.w0, w1 = k.w1, w2 = k.w2, w3 = k.w3;
-    bool off = ((w0 & 3u) == TDE_CELL_EMPTY) || ((w1 & 3u) == TDE_CELL_EMPTY) || ((w2 & 3u) == TDE_CELL_EMPTY) ||
-               ((w3 & 3u) == TDE_CELL_EMPTY);
-    uint32_t pending = off ? 0u
-                           : (((w0 & 3u) == TDE_CELL_MIXED) ? 1u : 0u) | (((w1 & 3u) == TDE_CELL_MIXED) ? 2u : 0u) |
-                                 (((w2 & 3u) == TDE_CELL_MIXED) ? 4u : 0u) | (((w3 & 3u) == TDE_CELL_MIXED) ? 8u : 0u);
+    // classes are 0 (EMPTY), 1 (MIXED), 2 (FULL): any EMPTY <=> the minimum class is 0; MIXED <=> bit 0.  Plain integer
+    // arithmetic: the four compare / select pairs this replaces each went through VCC (tde_kernels.hip, sweep notes).
+    static_assert(TDE_CELL_EMPTY == 0u && TDE_CELL_MIXED == 1u && TDE_CELL_FULL == 2u, "cell classes");
+    bool off = min(min(w0 & 3u, w1 & 3u), min(w2 & 3u, w3 & 3u)) == 0u;
+    uint32_t pending = off ? 0u : ((w0 & 1u) | ((w1 & 1u) << 1) | ((w2 & 1u) << 2) | ((w3 & 1u) << 3));
     bool work = false;
     uint32_t cur = 0, end = 0;
     float qx = 0.0f, qy = 0.0f;
@@ -271,6 +278,42 @@ TDE_DEV bool sqrt_ge(double s, double r)
     return sqrt(s) >= r;
 }
 
+// float64 cosine of a heading change for the reward's psi term (gym_env.py:403: math.cos on the float64 of an fp32
+// difference, |x| < 2 pi + rounding).  OCML's cos carries the full-range argument reduction (v_trig_preop_f64, ~170
+// float64 instructions in the kernel image, a few dozen on the common path) on a wavefront where only the ego lanes
+// compute it; this is the fdlibm kernel pair restricted to the range that can occur: |x| < pi/4 - every step without a
+// wrap of psi - evaluates one degree-12 polynomial, anything else goes through a two-term Cody-Waite reduction
+// (pi/2 = pio2_1 + pio2_1t, the product k * pio2_1 is exact for |k| <= 2^20).  Faithfully rounded like OCML's and
+// glibc's: against glibc it differs in the last bit on 1.2 % of random arguments (2e7 samples, max 1.1e-16) and never
+// after the reward's rounding to fp32 (tests/test_gpu_parity.py::test_reward_cos_bits_agree_between_libm_and_ocml).
+TDE_DEV double cos_kernel_f64(double x, double y)
+{
+    const double z = x * x;
+    const double r = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
+                         -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                         2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+TDE_DEV double sin_kernel_f64(double x, double y)
+{
+    const double z = x * x, v = z * x;
+    const double r = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
+                         -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                         8.33333333332248946124e-03);
+    return x - ((z * (0.5 * y - v * r) - y) - v * -1.66666666666666324348e-01);
+}
+TDE_DEV double cos_heading_f64(double x)
+{
+    if (__builtin_fabs(x) < 0.78539816339744830962) return cos_kernel_f64(x, 0.0);
+    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+    const int n = (int)fn;
+    const double r = x - fn * 1.57079632673412561417e+00, w = fn * 6.07710050650619224932e-11;
+    const double y0 = r - w, y1 = (r - y0) - w;
+    const double v = (n & 1) ? sin_kernel_f64(y0, y1) : cos_kernel_f64(y0, y1);
+    return (((n + 1) & 2) != 0) ? -v : v;                  // n & 3: 0 cos, 1 -sin, 2 -cos, 3 sin
+}
+
 // Kernel arguments that only the rare paths (reset, waypoint switches) or the few ego lanes read.  They are parked in
 // LDS at kernel start: by-value argument structs of this path need ~110 SGPRs, more than the 102-SGPR file, and what
 // does not fit is spilled to VGPR lanes and re-read with v_readlane on every use inside the step loop.
@@ -312,7 +355,7 @@ TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, 
     double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
     o.dist_r = sqrt_gt(ddx * ddx + ddy * ddy, cfg.distance_cutoff) ? cfg.distance_bonus : 0.0;
     float dpsi = psi - lpsi;
-    o.psi_r = (1.0 - cos((double)dpsi)) * (-cfg.heading_penalty);
+    o.psi_r = (1.0 - cos_heading_f64((double)dpsi)) * (-cfg.heading_penalty);
     bool reach = false;
     int ti = target_idx;
     if (ti < n_wp) {
