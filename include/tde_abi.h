@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 5
+#define TDE_ABI_VERSION 6
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -85,15 +85,16 @@ typedef struct tde_map {
     float ox, oy;               /* grid origin (lower-left corner of cell (0,0)) */
     float cell;                 /* cell edge [m] */
     float inv_cell;             /* 1/cell */
-    int32_t nx, ny;             /* grid size in cells, multiples of 8: cell words are stored in 8x8-cell tiles,
-                                   word of cell (ix,iy) at ((iy>>3)*(nx>>3) + (ix>>3))*64 + (iy&7)*8 + (ix&7) */
-    int32_t cell_base;          /* first cell of this map in cell_class / cell_start */
+    int32_t nx, ny;             /* grid size in cells */
+    int32_t cell_base;          /* first cell word of this map in tde_world.cell_word; rows are stored with a pitch of
+                                   2^row_shift >= nx words: word of cell (ix,iy) at cell_base + (iy << row_shift) + ix */
     int32_t tri_base;           /* first triangle of this map in tri */
     int32_t n_tri;
     int32_t stop_base, n_stop;  /* stop lines of this map in tde_world.stoplines */
     int32_t phase_base, n_phase;/* traffic-light cycle of this map in tde_world.phases */
     int32_t cycle_steps;        /* length of the cycle in env steps (0: no lights) */
-    int32_t _pad0, _pad1;
+    int32_t row_shift;          /* log2 of the row pitch of the map's cell words */
+    int32_t _pad1;
 } tde_map;
 
 /* A stop line: an oriented box across an inbound lane, governed by traffic light `light` of its map

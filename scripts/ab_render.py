@@ -37,8 +37,17 @@ torch.cuda.synchronize()
 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 handles = []
 ref = None
+dw_new, dw_tiled = dw, None
 for path in args.libs:
     L = C.CDLL(os.path.abspath(path))
+    L.tde_abi_version.restype = C.c_int
+    dw = dw_new
+    if L.tde_abi_version() <= 5:                          # 8x8-tile cell order (see scripts/ab_rollout.py)
+        if dw_tiled is None:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from ab_layout import tiled_world
+            dw_tiled = tiled_world(world).to_device(dev)
+        dw = dw_tiled
     L.tde_render_ego.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld), C.POINTER(_abi.TdeState),
                                  C.POINTER(_abi.TdeRender), C.c_void_p]
     out = torch.zeros((B, 3 * ns, 64, 64), dtype=torch.uint8, device=dev)
@@ -50,9 +59,9 @@ for path in args.libs:
     if ref is None:
         ref = out.clone()
     same = bool(torch.equal(out, ref))
-    handles.append((path, L, rd, out, layers, [], same))
+    handles.append((path, L, rd, out, layers, [], same, dw))
 for r in range(args.launches):
-    for path, L, rd, out, layers, ts, same in handles:
+    for path, L, rd, out, layers, ts, same, dw in handles:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.tde_render_ego(C.byref(cfg), C.byref(dw.struct), C.byref(st.struct), C.byref(rd), stream)
@@ -60,6 +69,6 @@ for r in range(args.launches):
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
 print(f"{B} views, {A} agents per env, n_stack {ns}, lights={int(args.lights)}, {args.launches} interleaved launches per library")
-for path, L, rd, out, layers, ts, same in handles:
+for path, L, rd, out, layers, ts, same, dw in handles:
     print(f"  {path:28s} median {statistics.median(ts):7.2f}  min {min(ts):7.2f}  mean {statistics.mean(ts):7.2f} us   "
           f"pixels equal to the first library: {same}")

@@ -12,6 +12,7 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 
 from torchdriveenv_amd import _abi
@@ -31,6 +32,11 @@ B, A, K = args.envs, args.agents, args.steps
 dev = torch.device("cuda:0")
 world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
+
+
+from ab_layout import tiled_world  # noqa: E402
+
+dw_tiled = None
 g = torch.Generator().manual_seed(0)
 actions = torch.stack([torch.rand(K, B, generator=g) * 2 - 1, torch.rand(K, B, generator=g) * 0.6 - 0.3], -1)
 actions = actions.float().contiguous().to(dev)
@@ -55,20 +61,25 @@ for spec in args.libs:
     L.tde_env_reset.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld), C.POINTER(_abi.TdeState),
                                 C.c_void_p, C.c_void_p]
     st = EnvState(B, A, device=dev, with_info=False)           # every library steps its own copy of the batch
-    assert L.tde_env_reset(C.byref(cfg), C.byref(dw.struct), C.byref(st.struct), None, stream) == 0
+    L.tde_abi_version.restype = C.c_int
+    wd = dw
+    if L.tde_abi_version() <= 5:
+        dw_tiled = dw_tiled or tiled_world(world).to_device(dev)
+        wd = dw_tiled
+    assert L.tde_env_reset(C.byref(cfg), C.byref(wd.struct), C.byref(st.struct), None, stream) == 0
     for _ in range(2):                                          # warm-up; latches the TDE_ROLLOUT choice of this handle
-        assert L.tde_env_rollout(C.byref(cfg), C.byref(dw.struct), C.byref(st.struct), C.byref(ro), stream) == 0
+        assert L.tde_env_rollout(C.byref(cfg), C.byref(wd.struct), C.byref(st.struct), C.byref(ro), stream) == 0
     torch.cuda.synchronize()
-    handles.append((spec, L, st, []))
+    handles.append((spec, L, st, [], wd))
 
 for r in range(args.launches):
-    for spec, L, st, ts in handles:
+    for spec, L, st, ts, wd in handles:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.tde_env_rollout(C.byref(cfg), C.byref(dw.struct), C.byref(st.struct), C.byref(ro), stream)
+        L.tde_env_rollout(C.byref(cfg), C.byref(wd.struct), C.byref(st.struct), C.byref(ro), stream)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / K)
 print(f"{B} envs x {A} agents, {K} steps per launch, {args.launches} interleaved launches per library, lights={int(args.lights)}")
-for spec, L, st, ts in handles:
+for spec, L, st, ts, wd in handles:
     print(f"  {spec:40s} median {statistics.median(ts):6.3f}  min {min(ts):6.3f}  mean {statistics.mean(ts):6.3f} us/step")

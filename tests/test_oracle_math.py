@@ -96,8 +96,7 @@ def grid_offroad_numpy(world, map_id, px, py, thr):
             out[i] = True
             continue
         ix, iy = int(fx), int(fy)
-        tile = (iy >> 3) * (m["nx"] >> 3) + (ix >> 3)
-        wd = int(words[m["cell_base"] + (tile << 6) + ((iy & 7) << 3) + (ix & 7)])
+        wd = int(words[m["cell_base"] + (iy << m["row_shift"]) + ix])
         cls = wd & 3
         if cls != _abi.CELL_MIXED:
             out[i] = cls == _abi.CELL_EMPTY

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 5
+TDE_ABI_VERSION = 6
 TDE_MAX_AGENTS = 64
 
 F_NPC = 1 << 0
@@ -56,13 +56,13 @@ class TdeMap(C.Structure):
         ("ox", C.c_float), ("oy", C.c_float), ("cell", C.c_float), ("inv_cell", C.c_float),
         ("nx", C.c_int32), ("ny", C.c_int32), ("cell_base", C.c_int32), ("tri_base", C.c_int32),
         ("n_tri", C.c_int32), ("stop_base", C.c_int32), ("n_stop", C.c_int32), ("phase_base", C.c_int32),
-        ("n_phase", C.c_int32), ("cycle_steps", C.c_int32), ("_pad0", C.c_int32), ("_pad1", C.c_int32),
+        ("n_phase", C.c_int32), ("cycle_steps", C.c_int32), ("row_shift", C.c_int32), ("_pad1", C.c_int32),
     ]
 
 
 MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "f4"), ("nx", "i4"), ("ny", "i4"),
                       ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("stop_base", "i4"), ("n_stop", "i4"),
-                      ("phase_base", "i4"), ("n_phase", "i4"), ("cycle_steps", "i4"), ("_pad0", "i4"), ("_pad1", "i4")])
+                      ("phase_base", "i4"), ("n_phase", "i4"), ("cycle_steps", "i4"), ("row_shift", "i4"), ("_pad1", "i4")])
 STOPLINE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("c", "f4"), ("s", "f4"), ("hl", "f4"), ("hw", "f4"),
                            ("light", "i4"), ("_pad0", "i4")])
 PHASE_DTYPE = np.dtype([("end_step", "i4"), ("red_mask", "u4")])

@@ -149,16 +149,14 @@ TDE_DEV float point_tri_d2_packed(float px, float py, const float4 *__restrict__
 // oracle's brute force over every triangle.
 TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, float py)
 {
-    // The grid is padded by >= 2 EMPTY cells on every side, so clamping the cell index to the grid (v_med3) replaces
-    // the four bounds tests: anything outside lands in an EMPTY border cell (the float->int conversion saturates for
-    // +-inf and returns 0 for NaN, both of which clamp to the border as well).
-    const float fx = (px - m.ox) * m.inv_cell;
-    const float fy = (py - m.oy) * m.inv_cell;
-    const int ix = min(max((int)fx, 0), m.nx - 1);
-    const int iy = min(max((int)fy, 0), m.ny - 1);
-    // cell words are stored in 8x8-cell tiles (256 B) so that neighbouring points share cache lines
-    const int tile = (iy >> 3) * (m.nx >> 3) + (ix >> 3);
-    return w.cell_word[m.cell_base + (tile << 6) + ((iy & 7) << 3) + (ix & 7)];
+    // The grid is padded by >= 2 EMPTY cells on every side, so clamping the cell coordinate to the grid (one v_med3_f32
+    // per axis, ahead of the conversion) replaces the four bounds tests: anything outside lands in an EMPTY border cell
+    // (+-inf clamp like any other value; a NaN coordinate comes out of v_med3_f32 as the minimum of the other two, 0).
+    // Truncation after the clamp equals the clamp after truncation: (-1, 0) truncates to cell 0 either way.
+    const float fx = __builtin_amdgcn_fmed3f((px - m.ox) * m.inv_cell, 0.0f, (float)(m.nx - 1));
+    const float fy = __builtin_amdgcn_fmed3f((py - m.oy) * m.inv_cell, 0.0f, (float)(m.ny - 1));
+    // rows are stored with a power-of-two pitch: the index is one shift-add
+    return w.cell_word[(uint32_t)m.cell_base + (((uint32_t)(int)fy << m.row_shift) + (uint32_t)(int)fx)];
 }
 
 // two-level select on the bits of i (three v_cndmask; the comparison chain was compiled into nested exec-mask branches)

@@ -18,15 +18,23 @@ from . import _abi
 
 # margin that makes the grid classification robust to fp32 evaluation and to the fp32 cell lookup
 GRID_MARGIN = 0.05
-# cell words are stored in tiles of GRID_TILE x GRID_TILE cells (256 B): lookups of neighbouring points (the four
-# corners of a box, the pixels of an image row) then share cache lines instead of touching one line per grid row
+# grid sizes are rounded up to multiples of GRID_TILE cells
 GRID_TILE = 8
 
 
-def tile_cells(a, nx, ny):
-    """row-major [ny*nx] cell array -> tiled order: ((iy//T)*(nx//T) + ix//T)*T*T + (iy%T)*T + ix%T"""
-    T = GRID_TILE
-    return np.ascontiguousarray(a.reshape(ny // T, T, nx // T, T).transpose(0, 2, 1, 3)).reshape(-1)
+def row_shift_of(nx):
+    """log2 of the row pitch the cell words of an nx-cell-wide grid are stored with (next power of two >= nx)"""
+    return max(0, int(nx) - 1).bit_length()
+
+
+def pitch_cells(a, nx, ny):
+    """row-major [ny*nx] cell array -> rows of 2^row_shift words (the padding holds EMPTY cells): the kernels form a
+    cell's index as (iy << row_shift) + ix, one instruction (round 1 stored 8x8-cell tiles: ten per lookup with a
+    quarter-rate integer multiply, for a cache-line saving that the 4-byte words of a 140 x 140-cell view never showed)"""
+    pitch = 1 << row_shift_of(nx)
+    out = np.full((ny, pitch), _abi.CELL_EMPTY, dtype=a.dtype)
+    out[:, :nx] = a.reshape(ny, nx)
+    return out.reshape(-1)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -81,7 +89,6 @@ def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4
     hi = tri.reshape(-1, 2).max(0) + (R + 2 * cell)
     # the origin must be exactly representable in fp32 (the kernel subtracts it in fp32)
     ox, oy = float(np.float32(math.floor(lo[0]))), float(np.float32(math.floor(lo[1])))
-    # grid sizes are multiples of GRID_TILE: the cell words are stored tile by tile (tile_cells)
     nx = GRID_TILE * int(math.ceil((hi[0] - ox) / cell / GRID_TILE))
     ny = GRID_TILE * int(math.ceil((hi[1] - oy) / cell / GRID_TILE))
     h = (cell + 2 * margin) / lattice
@@ -362,7 +369,8 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
                 cycle += int(n_steps)
                 phase_all.append((cycle, sum(1 << int(i) for i in red)))
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
-                   tri_base, len(tri), len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle, 0, 0)
+                   tri_base, len(tri), len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle,
+                   row_shift_of(g["nx"]), 0)
         packed = pack_triangles(tri32)
         counts = np.diff(g["cell_start"]).astype(np.int64)
         # FULL / EMPTY cells carry no candidate list: their count field holds a clearance instead (quarter metres,
@@ -372,12 +380,12 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         assert counts.max(initial=0) <= 255, "more than 255 candidate triangles in one grid cell: use a smaller cell"
         start = g["cell_start"][:-1].astype(np.int64) + rec_base
         assert start.max(initial=0) < (1 << 22), "grid index too large for the 22-bit record offset"
-        word_all.append(tile_cells((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
+        word_all.append(pitch_cells((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
                                     (start.astype(np.uint32) << 10)).astype(np.uint32), g["nx"], g["ny"]))
         rec_all.append(packed[g["cell_tris"]])          # per-cell copies: one dependent load less in the kernel
         tri_all.append(tri32.reshape(-1, 6))
         tri_base += len(tri)
-        cell_base += g["nx"] * g["ny"]
+        cell_base += (1 << row_shift_of(g["nx"])) * g["ny"]
         rec_base += len(g["cell_tris"])
     S = len(scenarios)
     NW = max(2, max(len(s["waypoints"]) for s in scenarios))
