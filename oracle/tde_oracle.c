@@ -106,7 +106,7 @@ static inline float tde_clampf(float v, float lo, float hi)
 /* ------------------------------------------------------------------------------------------------ */
 /* R4: KinematicBicycle.step (torchdrivesim/kinematic.py, called through simulator.step, gym_env.py:117) */
 /*     a, beta = action; v += a*dt; x += v*cos(psi+beta)*dt; y += v*sin(psi+beta)*dt;               */
-/*     psi += v/lr*sin(beta)*dt; psi = (pi + psi) % (2*pi) - pi.   left_handed=False (gym_env.py:245). */
+/*     psi += v*(1/lr)*sin(beta)*dt; psi = (pi + psi) % (2*pi) - pi.   left_handed=False (gym_env.py:245). */
 /* ------------------------------------------------------------------------------------------------ */
 TDE_EXPORT void tde_oracle_bicycle(float *x, float *y, float *psi, float *v, float lr, float a, float beta, float dt)
 {
@@ -118,7 +118,9 @@ TDE_EXPORT void tde_oracle_bicycle(float *x, float *y, float *psi, float *v, flo
     float sb, cb;
     tde_oracle_sincosf(beta, &sb, &cb);
     (void)cb;
-    float p1 = *psi + ((v1 / lr) * sb) * dt;
+    float inv_lr = 1.0f / lr;                      /* one rounding of the reciprocal, then products: the kernels keep
+                                                    * inv_lr per agent instead of dividing every step */
+    float p1 = *psi + ((v1 * inv_lr) * sb) * dt;
     p1 = tde_pymodf(TDE_PI_F + p1, TDE_TWO_PI_F) - TDE_PI_F;
     *x = x1; *y = y1; *psi = p1; *v = v1;
 }

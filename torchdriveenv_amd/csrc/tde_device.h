@@ -82,8 +82,27 @@ TDE_DEV float pymodf_pos(float a, float b)
     return r;
 }
 
+// Correctly rounded square root for x == 0 or x in [2^-96, FLT_MAX]: v_sqrt_f32 (1 ulp) and the usual one-ulp
+// correction - of y - 1ulp, y, y + 1ulp the one whose neighbours' residuals x - n * y change sign - with the two
+// decisions taken from the SIGN BITS of the (negated) residuals and added to the bit pattern: 8 instructions and no
+// compare / select pair, against the 17 (+ four round trips through VCC) of the compiler's sqrtf, which also rescales
+// arguments below 2^-96 and passes inf / NaN through.  The controller's two arguments cannot be in those ranges: a
+// squared distance whose root only matters above 1e-3 m, and amax * max(gap - s0, 0), which is zero or a multiple of
+// an ulp of a length of metres.  x == 0: y - 1ulp saturates at 0 and every residual is +0, so the result is 0.
+TDE_DEV float sqrt_cr_f32(float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const uint32_t yb = __float_as_uint(y);
+    const uint32_t dn = __builtin_elementwise_sub_sat(yb, 1u), up = yb + 1u;
+    const float t1 = __builtin_fmaf(__uint_as_float(dn), y, -x);      // -(x - dn * y): sign set <=> y - 1ulp is too small
+    const float t2 = __builtin_fmaf(__uint_as_float(up), y, -x);      // -(x - up * y): sign set <=> y is too small
+    return __uint_as_float(dn + (__float_as_uint(t1) >> 31) + (__float_as_uint(t2) >> 31));
+}
+
 // R4: KinematicBicycle.step — called through simulator.step(action), ref gym_env.py:117; model built at :245-247.
-TDE_DEV void bicycle(float &x, float &y, float &psi, float &v, float lr, float a, float beta, float dt)
+// `inv_lr` = 1.0f / rear_axis_offset, one correctly rounded division per agent and episode instead of one per step (the
+// persistent kernels keep it in a register; the oracle forms the same product).
+TDE_DEV void bicycle(float &x, float &y, float &psi, float &v, float inv_lr, float a, float beta, float dt)
 {
     float v1 = v + a * dt;
     float sn, cs;
@@ -91,7 +110,7 @@ TDE_DEV void bicycle(float &x, float &y, float &psi, float &v, float lr, float a
     float x1 = x + (v1 * cs) * dt;
     float y1 = y + (v1 * sn) * dt;
     float sb = sin_small_f32(beta);                  // steering is bounded by 0.3 rad in the action space
-    float p1 = psi + ((v1 / lr) * sb) * dt;
+    float p1 = psi + ((v1 * inv_lr) * sb) * dt;
     p1 = pymodf_pos(kPi + p1, kTwoPi) - kPi;
     x = x1; y = y1; psi = p1; v = v1;
 }

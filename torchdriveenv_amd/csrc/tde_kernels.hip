@@ -38,6 +38,7 @@ TDE_DEV void store_nt16(void *dst, const uint4 &v)
 // ------------------------------------------------------------------------------------------------------------------
 struct Agent {
     float x, y, psi, v, len, wid, lr, vdes;
+    float inv_lr;               // 1.0f / lr (bicycle)
     int route, route_wp, replay;
     bool present;
 };
@@ -180,6 +181,7 @@ TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
 {
     a.x = st.x[g]; a.y = st.y[g]; a.psi = st.psi[g]; a.v = st.v[g];
     a.len = st.len[g]; a.wid = st.wid[g]; a.lr = st.lr[g]; a.vdes = st.vdes[g];
+    a.inv_lr = 1.0f / a.lr;
     a.route_wp = st.route_wp[g];
     a.route = -1; a.replay = -1;        // filled from the spawn record by load_ctx
     a.present = st.present[g] != 0;
@@ -294,6 +296,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
             ag.lr = (float)(u01(r1.y) * (0.97 - 0.82) + 0.82);
         }
     }
+    ag.inv_lr = 1.0f / ag.lr;
 }
 
 // heuristic NPC controller (R14 slot), mirrors tde_npc_action of the oracle; reads the tile (= pre-step state).
@@ -381,11 +384,11 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
     const float dx = tgx - ag.x, dy = tgy - ag.y;
     const float fwd = dx * cp + dy * sp;
     const float lat = dy * cp - dx * sp;
-    const float dist = sqrtf(dx * dx + dy * dy);
+    const float dist = sqrt_cr_f32(dx * dx + dy * dy);
     const float sin_err = lat / fmaxf(dist, 1e-3f);
     beta = (fwd < 0.0f) ? copysignf(smax, lat) : clampf(cfg.npc_k_steer * sin_err, -smax, smax);
     gap = fminf(gap, red_gap);
-    const float vd = fminf(ag.vdes, sqrtf(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
+    const float vd = fminf(ag.vdes, sqrt_cr_f32(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
     acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
 }
 
@@ -592,7 +595,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     }
 
     if (live) {
-        bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);          // :117
+        bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);          // :117
         if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
     }
     bool switched = false;
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 }
                 nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
                 if (live) {
-                    bicycle(nx, ny, npsi, nv, ag.lr, acc, beta, cfg.dt);                      // :117
+                    bicycle(nx, ny, npsi, nv, ag.inv_lr, acc, beta, cfg.dt);                      // :117
                     if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
                 }
                 switched = false;
@@ -1116,10 +1119,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     load_ctx<A>(cfg, cold, a, ag, er, cx);
 
     // done(i-1) of every ego lane from the judges' masks of that step (k = its environment_steps): R8 / R11
+    uint4 m0, m1;                                            // the masks done_of last read (judge C's done byte)
     auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
         const unsigned long long ego = __ballot(a == 0 && valid);
-        const uint4 m0 = *reinterpret_cast<const uint4 *>(&sh.hit_mask);          // hit, off
-        const uint4 m1 = *reinterpret_cast<const uint4 *>(&sh.tl_mask);           // tl, max_steps, term_at_infraction
+        m0 = *reinterpret_cast<const uint4 *>(&sh.hit_mask);                      // hit, off
+        m1 = *reinterpret_cast<const uint4 *>(&sh.tl_mask);                       // tl, max_steps, term_at_infraction
         const unsigned long long infr = (((unsigned long long)(m0.y | m0.w | m1.y)) << 32) | (m0.x | m0.z | m1.x);
         term_m = ((F & TDE_F_REWARD) && m1.w) ? (infr & ego) : 0ull;
         trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= (int)m1.z) : 0ull;
@@ -1165,7 +1169,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 }
                 nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
                 if (live) {
-                    bicycle(nx, ny, npsi, nv, ag.lr, acc, beta, cfg.dt);                      // :117
+                    bicycle(nx, ny, npsi, nv, ag.inv_lr, acc, beta, cfg.dt);                      // :117
                     if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
                 }
                 switched = false;
@@ -1224,10 +1228,14 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             const unsigned long long dn = done_of(er.steps, term_m, trunc_m);
             if (a == 0 && valid) {
                 last_term = (uint8_t)((term_m >> lane) & 1ull); last_trunc = (uint8_t)((trunc_m >> lane) & 1ull);
-                if (ro.done)
-                    ro.done[(int64_t)i * B + e] = (uint8_t)(
-                        last_term | (last_trunc << 1) | (((sh.off_mask >> lane) & 1ull) << 2) |
-                        (((sh.hit_mask >> lane) & 1ull) << 3) | (((sh.tl_mask >> lane) & 1ull) << 4));
+                if (ro.done) {
+                    // this lane's bit of the masks done_of just read: the half that holds it, one 32-bit shift each
+                    const bool up = lane >= 32;
+                    const uint32_t sft = (uint32_t)lane & 31u;
+                    const uint32_t hb = ((up ? m0.y : m0.x) >> sft) & 1u, ob = ((up ? m0.w : m0.z) >> sft) & 1u,
+                                   tb = ((up ? m1.y : m1.x) >> sft) & 1u;
+                    ro.done[(int64_t)i * B + e] = (uint8_t)(last_term | (last_trunc << 1) | (ob << 2) | (hb << 3) | (tb << 4));
+                }
             }
             return dn;
         };
@@ -1481,7 +1489,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             }
         }
         if (live) {
-            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);     // :117
+            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117
             if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
         }
         bool switched = false;
@@ -1713,7 +1721,7 @@ __global__ __launch_bounds__(kBlock) void kinematics_kernel(int64_t n, float *x,
     if (present && !present[i]) return;
     float2 act = reinterpret_cast<const float2 *>(action)[i];
     float X = x[i], Y = y[i], P = psi[i], V = v[i];
-    bicycle(X, Y, P, V, lr[i], act.x, act.y, dt);
+    bicycle(X, Y, P, V, 1.0f / lr[i], act.x, act.y, dt);
     x[i] = X; y[i] = Y; psi[i] = P; v[i] = V;
 }
 
@@ -1737,7 +1745,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
     if (KIN && live) {
         float V = v[gs];
         float2 act = reinterpret_cast<const float2 *>(action)[gs];
-        bicycle(X, Y, P, V, lr[gs], act.x, act.y, dt);
+        bicycle(X, Y, P, V, 1.0f / lr[gs], act.x, act.y, dt);
         x[g] = X; y[g] = Y; psi[g] = P; v[g] = V;
     }
     float s1, c1;
