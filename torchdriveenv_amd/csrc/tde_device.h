@@ -280,18 +280,19 @@ TDE_DEV double u01(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 // 1e-12 (relative) from the boundary, i.e. farther than any rounding of the correctly rounded square root could
 // matter; the exact sqrt is only evaluated inside that sliver.  Same truth value as the reference's
 // `math.dist(..) > cutoff` / `math.dist(..) < 3` (gym_env.py:394,402) at a fraction of the instructions.
-TDE_DEV bool sqrt_gt(double s, double r)
+// `lo` / `hi` = r*r*(1 -+ 1e-12): the sliver, formed once (Cold) instead of with three float64 multiplies per call
+struct Sliver { double lo, hi; };
+TDE_DEV Sliver sliver_of(double r) { const double r2 = r * r; return Sliver{r2 * (1.0 - 1e-12), r2 * (1.0 + 1e-12)}; }
+TDE_DEV bool sqrt_gt(double s, double r, const Sliver &v)
 {
-    const double r2 = r * r;
-    if (s > r2 * (1.0 + 1e-12)) return true;
-    if (s < r2 * (1.0 - 1e-12)) return false;
+    if (s > v.hi) return true;
+    if (s < v.lo) return false;
     return sqrt(s) > r;
 }
-TDE_DEV bool sqrt_ge(double s, double r)
+TDE_DEV bool sqrt_ge(double s, double r, const Sliver &v)
 {
-    const double r2 = r * r;
-    if (s > r2 * (1.0 + 1e-12)) return true;
-    if (s < r2 * (1.0 - 1e-12)) return false;
+    if (s > v.hi) return true;
+    if (s < v.lo) return false;
     return sqrt(s) >= r;
 }
 
@@ -331,11 +332,22 @@ TDE_DEV double cos_heading_f64(double x)
     return (((n + 1) & 2) != 0) ? -v : v;                  // n & 3: 0 cos, 1 -sin, 2 -cos, 3 sin
 }
 
+// fp32 bounds of reward_core's pre-test: r^2 * (1 -+ 1e-6); a cut-off whose square leaves the normal fp32 range (or a NaN)
+// gets (0, +inf), which sends every step to the float64 path
+TDE_DEV void cut2f_bounds(double r, float &lo, float &hi)
+{
+    const double r2 = r * r;
+    lo = 0.0f; hi = __builtin_inff();
+    if (r2 > 1e-30 && r2 < 1e30) { lo = (float)(r2 * (1.0 - 1e-6)); hi = (float)(r2 * (1.0 + 1e-6)); }
+}
+
 // Kernel arguments that only the rare paths (reset, waypoint switches) or the few ego lanes read.  They are parked in
 // LDS at kernel start: by-value argument structs of this path need ~110 SGPRs, more than the 102-SGPR file, and what
 // does not fit is spilled to VGPR lanes and re-read with v_readlane on every use inside the step loop.
 struct Cold {
     double waypoint_bonus, heading_penalty, distance_bonus, distance_cutoff, reach_radius;
+    Sliver cut_sliver, reach_sliver;     // of distance_cutoff / reach_radius (sqrt_gt / sqrt_ge)
+    float cut2f_lo, cut2f_hi;            // distance_cutoff^2 * (1 -+ 1e-6) in fp32 (reward_core's fp32 pre-test)
     uint64_t seed;
     const tde_spawn *spawn;
     const tde_scenario *scn;
@@ -351,9 +363,22 @@ TDE_DEV void fill_cold(Cold &c, const tde_config &cfg, const tde_world &w)
     c.waypoint_bonus = cfg.waypoint_bonus; c.heading_penalty = cfg.heading_penalty;
     c.distance_bonus = cfg.distance_bonus; c.distance_cutoff = cfg.distance_cutoff;
     c.reach_radius = cfg.reach_radius; c.seed = cfg.seed;
+    c.cut_sliver = sliver_of(cfg.distance_cutoff); c.reach_sliver = sliver_of(cfg.reach_radius);
+    cut2f_bounds(cfg.distance_cutoff, c.cut2f_lo, c.cut2f_hi);
     c.spawn = w.spawn; c.scn = w.scn; c.wp_xy = w.wp_xy; c.maps = w.maps; c.route_xy = w.route_xy;
     c.env_base = cfg.env_base; c.n_scn = w.n_scn; c.NW = w.NW; c.RW = w.RW;
     c.max_steps = cfg.max_steps; c.terminated_at_infraction = cfg.terminated_at_infraction;
+}
+
+// the thresholds of reward_core from either carrier: the LDS block holds them precomputed, the operator kernel that takes
+// tde_config forms them per call
+struct RewardBounds { Sliver cut, reach; float cut2f_lo, cut2f_hi; };
+TDE_DEV RewardBounds reward_bounds(const Cold &c) { return RewardBounds{c.cut_sliver, c.reach_sliver, c.cut2f_lo, c.cut2f_hi}; }
+TDE_DEV RewardBounds reward_bounds(const tde_config &c)
+{
+    RewardBounds b{sliver_of(c.distance_cutoff), sliver_of(c.reach_radius), 0.0f, 0.0f};
+    cut2f_bounds(c.distance_cutoff, b.cut2f_lo, b.cut2f_hi);
+    return b;
 }
 
 struct RewardOut {
@@ -369,15 +394,25 @@ TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, 
                               int &target_idx, int &reached, bool want_info = true)
 {
     RewardOut o;
-    double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
-    o.dist_r = sqrt_gt(ddx * ddx + ddy * ddy, cfg.distance_cutoff) ? cfg.distance_bonus : 0.0;
+    const RewardBounds rb = reward_bounds(cfg);
+    // math.dist(..) > cutoff (:402) decided in fp32 whenever that is safe: each fp32 difference is correctly rounded and
+    // the sum of the two squares is within 4 * 2^-24 of the float64 value the reference forms from the same fp32 state, so
+    // outside +-1e-6 (relative) of cutoff^2 the fp32 comparison cannot disagree with it; inside, the float64 path decides
+    const float fdx = x - lx, fdy = y - ly;
+    const float s32 = fdx * fdx + fdy * fdy;
+    bool moved = s32 > rb.cut2f_hi;
+    if (!moved && !(s32 < rb.cut2f_lo)) {
+        const double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
+        moved = sqrt_gt(ddx * ddx + ddy * ddy, cfg.distance_cutoff, rb.cut);
+    }
+    o.dist_r = moved ? cfg.distance_bonus : 0.0;
     float dpsi = psi - lpsi;
     o.psi_r = (1.0 - cos_heading_f64((double)dpsi)) * (-cfg.heading_penalty);
     bool reach = false;
     int ti = target_idx;
     if (ti < n_wp) {
         double tx = (double)x - wtx, ty = (double)y - wty;
-        reach = !sqrt_ge(tx * tx + ty * ty, cfg.reach_radius);
+        reach = !sqrt_ge(tx * tx + ty * ty, cfg.reach_radius, rb.reach);
     }
     double reach_r = 0.0;
     if (reach) { reach_r = cfg.waypoint_bonus; reached += 1; }

@@ -355,27 +355,98 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
         cand &= ~bit_of_row<A>(i);
     }
     float gap = 1e30f;
+#ifndef TDE_NPC_PAIR
+#define TDE_NPC_PAIR 1
+#endif
+    // exact tests of the candidates; every lane walks its own list, so the wavefront makes max-over-lanes(count) trips
+    // (3.8 on average for 0.9 candidates per lane: the busiest lane of 64 follows a platoon).  TWO candidates per trip:
+    // two independent chains per lane - a lone wavefront issues independent instructions twice as fast as dependent
+    // ones - and ceil(count / 2) trips (2.2).  A lane with fewer candidates tests its own row instead, which cannot be
+    // taken (fj = 0).
+    auto exact = [&](int j) {
+        const float4 pj = ra[j], qj = rb[j];
+        const float ex = pj.x - ag.x, ey = pj.y - ag.y;
+        const float fj = ex * cp + ey * sp;
+        const float lj = ey * cp - ex * sp;
+        const float halfw = cfg.npc_lane_half + qj.w;  // = npc_lane_half + 0.5f * wid_j (qj.w = hw_j = 0.5f * wid_j)
+        const float hl_j = qj.z;
+        const float al = fabsf(lj);
+        const float hd = cp * qj.x + sp * qj.y;
+        // branch-free: bitwise and/or of the predicates (no short-circuit control flow around a handful of ops)
+        const bool inlane = al < halfw;
+        const bool cone = (j < i) & (fj < cfg.npc_cone_range) & (al < halfw + cfg.npc_cone_k * fj) & (hd > -0.5f);
+        // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit (scaling by 2 commutes with rounding)
+        const float g = fj - (hl_i + hl_j);
+        const bool take = (fj > 0.0f) & (inlane | cone);
+        return take ? g : 1e30f;
+    };
+#if TDE_NPC_PAIR
+    while (__ballot(cand != 0)) {
+        const mask_t c1 = cand & (cand - 1);
+        int j[2];
+        j[0] = cand ? row_of_bit<A>(lowest_bit(cand)) : i;
+        j[1] = c1 ? row_of_bit<A>(lowest_bit(c1)) : i;
+        cand = c1 & (c1 - 1);
+        // the two tests stage by stage (pins as in the sweeps: left alone, the scheduler runs them one after the other)
+        float4 pj[2], qj[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { pj[u] = ra[j[u]]; qj[u] = rb[j[u]]; }
+        float ex[2], ey[2], fj[2], lj[2], hd[2], halfw[2], t0[2], t1[2], g[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { ex[u] = pj[u].x - ag.x; ey[u] = pj[u].y - ag.y; }
+        pin(ex, ey);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { fj[u] = ex[u] * cp; t0[u] = ey[u] * sp; lj[u] = ey[u] * cp; t1[u] = ex[u] * sp; }
+        pin(fj, t0);
+        pin(lj, t1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            fj[u] = fj[u] + t0[u]; lj[u] = lj[u] - t1[u];
+            hd[u] = cp * qj[u].x; t0[u] = sp * qj[u].y;
+            halfw[u] = cfg.npc_lane_half + qj[u].w;        // = npc_lane_half + 0.5f * wid_j (qj.w = hw_j = 0.5f * wid_j)
+            g[u] = hl_i + qj[u].z;                         // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit
+        }
+        pin(fj, lj);
+        pin(hd, t0);
+        pin(halfw, g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { hd[u] = hd[u] + t0[u]; t1[u] = cfg.npc_cone_k * fj[u]; g[u] = fj[u] - g[u]; }
+        pin(hd, t1);
+        pin(g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) t1[u] = halfw[u] + t1[u];
+        pin(t1);
+        // the predicates as SIGN BITS of correctly rounded differences (a < b <=> sign(a - b); exact, gradual underflow),
+        // combined with bitwise and / or and blended in with v_bfi: a v_cmp -> s_and -> v_cndmask chain through SGPR
+        // pairs costs a lone wavefront ~24 cycles per link, six compares per candidate
+        int tk[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float al = fabsf(lj[u]);
+            const int inlane = __float_as_int(al - halfw[u]);                  // al < halfw
+            const int c1 = __float_as_int(al - t1[u]);                         // al < halfw + cone_k * fj
+            const int c2 = __float_as_int(fj[u] - cfg.npc_cone_range);         // fj < cone_range
+            const int c3 = __float_as_int(-0.5f - hd[u]);                      // hd > -0.5
+            const int c4 = j[u] - i;                                           // j < i
+            const int ahead = __float_as_int(0.0f - fj[u]);                    // fj > 0 (0 - fj: +0 for fj = +-0)
+            tk[u] = (((c1 & c2) & (c3 & c4)) | inlane) & ahead;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t m = (uint32_t)(tk[u] >> 31);                        // all ones: taken
+            g[u] = __uint_as_float((m & __float_as_uint(g[u])) | (~m & __float_as_uint(1e30f)));
+        }
+        gap = fminf(gap, fminf(g[0], g[1]));
+    }
+#else
     while (__ballot(cand != 0)) {
         if (cand) {
             const int j = row_of_bit<A>(lowest_bit(cand));
             cand &= cand - 1;
-            const float4 pj = ra[j], qj = rb[j];
-            const float ex = pj.x - ag.x, ey = pj.y - ag.y;
-            const float fj = ex * cp + ey * sp;
-            const float lj = ey * cp - ex * sp;
-            const float halfw = cfg.npc_lane_half + qj.w;  // = npc_lane_half + 0.5f * wid_j (qj.w = hw_j = 0.5f * wid_j)
-            const float hl_j = qj.z;
-            const float al = fabsf(lj);
-            const float hd = cp * qj.x + sp * qj.y;
-            // branch-free: bitwise and/or of the predicates (no short-circuit control flow around a handful of ops)
-            const bool inlane = al < halfw;
-            const bool cone = (j < i) & (fj < cfg.npc_cone_range) & (al < halfw + cfg.npc_cone_k * fj) & (hd > -0.5f);
-            // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit (scaling by 2 commutes with rounding)
-            const float g = fj - (hl_i + hl_j);
-            const bool take = (fj > 0.0f) & (inlane | cone);
-            gap = take ? fminf(gap, g) : gap;
+            gap = fminf(gap, exact(j));
         }
     }
+#endif
     if (!has_target) {
         acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
         beta = 0.0f;
