@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/tde_hip.h"
 #include "tde_device.h"
@@ -328,6 +329,10 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
         const float nP = 0.01f - (ag.x * cp + ag.y * sp), nQ = -(ag.y * cp - ag.x * sp);
         const float L = (g_far + hl_i) + 0.07f;
         const float kc = fmaxf(cfg.npc_cone_k, 0.0f);
+#ifndef TDE_NPC_HALVES
+#define TDE_NPC_HALVES 1
+#endif
+#if TDE_NPC_HALVES
         cand = sweep_blocks_halves<A>(ra, [&](float2 (&xy)[C], float2 (&zw)[C], float (&v)[C], auto &&prefetch_xy, auto &&prefetch_zw) {
             float f[C], l[C], n[C], w[C];
 #pragma unroll
@@ -352,6 +357,29 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
             for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
             pin(v);
         });
+#else
+        cand = sweep_blocks<A>(ra, [&](float4 (&r)[C], float (&v)[C], auto &&prefetch) {
+            float f[C], l[C], n[C], w[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].y, sp, nP); l[j] = __builtin_fmaf(-r[j].x, sp, nQ); }
+            pin(f, l);
+#pragma unroll
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].x, cp, f[j]); l[j] = __builtin_fmaf(r[j].y, cp, l[j]); }
+            pin(f, l);
+#pragma unroll
+            for (int j = 0; j < C; ++j) { n[j] = r[j].z - f[j]; w[j] = __builtin_fmaf(kc, f[j], r[j].w); }
+            pin(n, w);
+            pin_memory();
+            prefetch();                                        // the rows are consumed: fetch the next block's
+            pin_memory();
+#pragma unroll
+            for (int j = 0; j < C; ++j) { n[j] = n[j] + L; w[j] = w[j] - fabsf(l[j]); }
+            pin(n, w);
+#pragma unroll
+            for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
+            pin(v);
+        });
+#endif
         cand &= ~bit_of_row<A>(i);
     }
     float gap = 1e30f;
@@ -468,6 +496,9 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
 // or in fp32 arithmetic (the 1.001 is folded into the radii, kReach).  Phase 1 marks the pairs inside that radius
 // (branch-free, free to fuse its multiply-adds), phase 2 runs the 4-axis SAT test on the marked ones only.
 // Called by all lanes of the wavefront, converged.
+#ifndef TDE_COLLIDE_B128
+#define TDE_COLLIDE_B128 1
+#endif
 template <int A>
 TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
                           float hl, float hw, float ri)
@@ -481,6 +512,12 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
             float dx[C], dy[C], rr[C];
 #pragma unroll
             for (int j = 0; j < C; ++j) { dx[j] = r[j].x - x; dy[j] = r[j].y - y; rr[j] = ri + r[j].z; }
+#if TDE_COLLIDE_B128
+            // the fourth component is not needed, but a 12-byte ds_read_b96 occupies the LDS array for 8 cycles per
+            // wavefront and a 16-byte ds_read_b128 for 4: keep the row a full 16-byte read
+#pragma unroll
+            for (int j = 0; j < C; ++j) asm volatile("" :: "v"(r[j].w));
+#endif
             pin(dx, dy);
             pin(rr);
             pin_memory();
@@ -503,6 +540,55 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
         if (cand) {
             const int j = row_of_bit<A>(lowest_bit(cand));
             cand &= cand - 1;
+            const float4 pj = ra[j], qj = rb[j];
+            hit = hit | obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
+        }
+    }
+    return hit;
+}
+
+// The same for 16 slots per env when the wavefront's lane l holds slot l % 16 of its env, i.e. an env is one 16-lane DPP
+// row (three-role kernels).  The circumradius test of a pair is symmetric - both lanes would compute the same bits - so
+// each lane tests only the eight slots AHEAD of it in the row (offsets 1..8, slot index mod 16) and hands the verdict to
+// the partner: the neighbour's (x, y, reach) arrive through the DPP row-rotate operand of the subtract / add itself
+// (v_sub_f32_dpp ... row_ror), the partner's copy of the verdict through one v_mov_b32_dpp.  8 x 6 + 15 x 1 + 7 VALU
+// instead of 16 x 7, and no LDS read (16 ds_read_b128 = 64 LDS-array cycles per wavefront and step).
+// Candidate mask: bit 15 - o for offsets o = 1..8, bit o - 9 for o = 9..15 (the order the verdicts become available).
+// The exact tests read the candidate's rows from LDS as before.  All 64 lanes must be active.
+#ifndef TDE_COLLIDE_DPP
+#define TDE_COLLIDE_DPP 1
+#endif
+template <int N> TDE_DEV float dpp_row_ror(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
+}
+TDE_DEV bool collide_rows_dpp16(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
+                                float hl, float hw, float ri)
+{
+    uint32_t fwd = 0, bwd = 0;
+    auto offset = [&](auto dtag) {
+        constexpr int D = decltype(dtag)::value;
+        // lane l receives the registers of lane l + D of its row: rotate right by 16 - D
+        const float dx = dpp_row_ror<16 - D>(x) - x, dy = dpp_row_ror<16 - D>(y) - y, rr = dpp_row_ror<16 - D>(ri) + ri;
+        const float dy2 = dy * dy;
+        const float d2 = __builtin_fmaf(dx, dx, dy2);
+        const float v = __builtin_fmaf(-rr, rr, d2);       // negative <=> inside the sum of the (padded) circumradii
+        fwd = push_sign(fwd, v);
+        if constexpr (D < 8) bwd = push_sign(bwd, dpp_row_ror<D>(v));   // the verdict of the pair (l - D, l), for lane l
+    };
+    offset(std::integral_constant<int, 1>{}); offset(std::integral_constant<int, 2>{});
+    offset(std::integral_constant<int, 3>{}); offset(std::integral_constant<int, 4>{});
+    offset(std::integral_constant<int, 5>{}); offset(std::integral_constant<int, 6>{});
+    offset(std::integral_constant<int, 7>{}); offset(std::integral_constant<int, 8>{});
+    // fwd: offset D at bit 8 - D; bwd: offset 16 - D at bit 7 - D
+    uint32_t cand = live ? ((fwd << 7) | bwd) : 0u;
+    bool hit = false;
+    while (__ballot(cand != 0)) {
+        if (cand) {
+            const int b = lowest_bit(cand);
+            cand &= cand - 1;
+            const int o = b < 7 ? 9 + b : 15 - b;
+            const int j = (a + o) & 15;
             const float4 pj = ra[j], qj = rb[j];
             hit = hit | obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
         }
@@ -1326,7 +1412,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             er.steps += 1;
             const int k = er.steps;
             const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
-            hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
+            if constexpr (A == 16 && TDE_COLLIDE_DPP)
+                hit = collide_rows_dpp16(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
+            else
+                hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
             const unsigned long long m = __ballot(hit);
             if (lane == 0) sh.hit_mask = m;
             if (a == 0 && valid) {
@@ -1642,7 +1731,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         er.steps += 1;
         const int k = er.steps;
         const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
-        const bool hit = collide_rows<A>(&sh.a[0][base], &sh.b[0][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
+        bool hit;
+        if constexpr (A == 16 && TDE_COLLIDE_DPP)
+            hit = collide_rows_dpp16(&sh.a[0][base], &sh.b[0][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
+        else
+            hit = collide_rows<A>(&sh.a[0][base], &sh.b[0][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
         const unsigned long long hm = __ballot(hit);
         if (lane == 0) sh.hit_mask = hm;
         RewardOut rw{};
