@@ -19,7 +19,8 @@ python scripts/launch_cost.py > $O/launch_cost.txt 2>/dev/null; TDE_STEP=solo py
 # interleaved same-process A/B: round-1 library vs this build; duo vs trio per group shape (two copies of the library: the
 # TDE_ROLLOUT choice is latched per loaded library)
 cp torchdriveenv_amd/libtde_hip.so ab/libcur_duo.so; cp torchdriveenv_amd/libtde_hip.so ab/libcur_trio.so
-python scripts/ab_rollout.py ab/libA_r01.so torchdriveenv_amd/libtde_hip.so > $O/ab_r01_vs_r02.txt 2>/dev/null; cat $O/ab_r01_vs_r02.txt
+# (the round-1 library cannot be loaded next to this build any more: tde_state / tde_map changed with ABI 5 and 6; the
+#  recorded A/B is profiles/r02_a_ab_r01_vs_r02.txt, later steps are A/B-ed build against build in profiles/r02_d_*.txt)
 : > $O/rollout_matrix.txt
 for shape in "8 16384" "16 8192" "32 4096" "64 2048"; do set -- $shape
   python scripts/ab_rollout.py --agents $1 --envs $2 duo:ab/libcur_duo.so trio:ab/libcur_trio.so >> $O/rollout_matrix.txt 2>/dev/null

@@ -1245,6 +1245,11 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 // wait for each other.  What depends on the other judge's mask (the done byte, terminated, C's own re-spawn
 // bookkeeping) is settled by C after the next barrier A.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef TDE_PRIO_D
+#define TDE_PRIO_D 2
+#define TDE_PRIO_C 1
+#define TDE_PRIO_O 0
+#endif
 template <int A, bool LIGHTS>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_rollout_trio_kernel(tde_config cfg, tde_world w, tde_state st,
                                                                     tde_rollout ro)
@@ -1292,7 +1297,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         RedCache redc; redc.invalidate();
         // issue priority in the order of the roles' chains: driver (the serial chain of the simulation) > judge C > judge O;
         // same-box A/B: (3,0,0) 4.00 us, (3,2,0) 3.84, (2,1,0) 3.81, none 4.4-4.8
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(TDE_PRIO_D);
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
         write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
@@ -1372,7 +1377,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         store_agent_static(st, g, ag);
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs, waypoint advance =====================
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(TDE_PRIO_C);
         TDE_ROLE_PROLOGUE
         RedCache redc; redc.invalidate();
         bool hit = false;
@@ -1453,7 +1458,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         }
     } else {
         // ===================== judge O: offroad, stop lines =====================
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(TDE_PRIO_O);
         TDE_ROLE_PROLOGUE
         RedCache redc; redc.invalidate();
         const float thr2 = thr2_of(cfg);
