@@ -158,9 +158,29 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # a rank that dies (no GPU for it, RCCL initialisation error ...) leaves the others waiting in the rendezvous or in
+    # the barrier: poll, and when one has failed stop the rest (the exact processes started above) instead of hanging
+    import time
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = max(rc, abs(code))
+        if rc and live:
+            time.sleep(5.0)                                      # let the failing rank's siblings report, then stop them
+            for p in live:
+                if p.poll() is None:
+                    p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
     return rc
 
 
@@ -228,11 +248,13 @@ def main():
         local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":                     # no silent fallback: an RCCL failure fails the run
-            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, timeout=datetime.timedelta(seconds=300),
                                     device_id=torch.device(f"cuda:{local_rank}"))
         else:
             with _StdoutToStderr():
-                dist.init_process_group("gloo", rank=rank, world_size=world_size)
+                import datetime
+                dist.init_process_group("gloo", rank=rank, world_size=world_size, timeout=datetime.timedelta(seconds=300))
                 dist.barrier()
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)

@@ -276,6 +276,13 @@ def test_config_rejections_and_world_threshold_on_the_env(small_world):
         BatchedWaypointEnv(EnvConfig(simulator=SimulatorConfig(collision_metric="iou")), small_world, num_envs=2, device=DEV)
     with pytest.raises(ValueError):                        # the prebuilt World's grid index was built for 0.5 m
         BatchedWaypointEnv(EnvConfig(simulator=SimulatorConfig(offroad_threshold=0.8)), small_world, num_envs=2, device=DEV)
+    with pytest.raises(ValueError):                        # outside the controller's sqrt domain (tde_env_* reject it too)
+        BatchedWaypointEnv(EnvConfig(simulator=SimulatorConfig(npc_max_accel=1e-9)), small_world, num_envs=2, device=DEV)
+    raw = _abi.default_config(seed=1)
+    raw.npc_max_accel = 1e-9
+    st = EnvState(2, small_world.A, device=DEV)
+    with pytest.raises(RuntimeError, match="npc_max_accel"):
+        ops.env_reset(raw, small_world.to_device(DEV), st)
     # left-handed (the reference's default) vs right-handed observation of the same state: mirror images
     lh = BatchedWaypointEnv(EnvConfig(seed=5), small_world, num_envs=8, device=DEV)
     rh = BatchedWaypointEnv(EnvConfig(seed=5, simulator=SimulatorConfig(
