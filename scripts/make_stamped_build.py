@@ -121,11 +121,11 @@ def patch_trio(s):
     # ---- judge C
     k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
             "        lds_barrier();\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 12);\n")
-    k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            hit = collide_rows",
-            "            tde_mark(&stl, 13);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 14);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            hit = collide_rows")
+    k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)",
+            "            tde_mark(&stl, 13);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 14);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)")
     k = sub(k, "            if (lane == 0) sh.hit_mask = m;\n", "            if (lane == 0) sh.hit_mask = m;\n            tde_mark(&stl, 15);\n")
-    k = sub(k, "                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;\n            }\n        }\n        lds_barrier();                                       // A'",
-            "                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;\n            }\n            tde_mark(&stl, 16);\n        }\n        tde_flush(12, 17);\n        lds_barrier();                                       // A'")
+    k = sub(k, "                ro.reward[(int64_t)i * B + e] = 0.0f;\n            }\n        }\n        lds_barrier();                                       // A'",
+            "                ro.reward[(int64_t)i * B + e] = 0.0f;\n            }\n            tde_mark(&stl, 16);\n        }\n        tde_flush(12, 17);\n        lds_barrier();                                       // A'")
     # ---- judge O
     k = sub(k, "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
             "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 18);\n")

@@ -387,14 +387,13 @@ struct RewardOut {
     double psi_smooth, speed_smooth, psi_r, dist_r;
 };
 
-// (wtx, wty) = waypoint[target_idx], only read when target_idx < n_wp (current_target is not None, :394).
+// The pieces of get_reward (:396-411), shared by reward_core (one step of one env) and by the three-role rollout
+// kernel's batched evaluation (judge C: a window of steps of an env at once, one lane per step).
+// dist_r (:402) and psi_r (:403): independent of the waypoint target.
 template <typename CFG>
-TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, float lx, float ly, float lpsi,
-                              float lv, float x, float y, float psi, float v, bool off, bool col, bool tl, int k,
-                              int &target_idx, int &reached, bool want_info = true)
+TDE_DEV void reward_motion_terms(const CFG &cfg, const RewardBounds &rb, float lx, float ly, float lpsi, float x, float y,
+                                 float psi, double &dist_r, double &psi_r)
 {
-    RewardOut o;
-    const RewardBounds rb = reward_bounds(cfg);
     // math.dist(..) > cutoff (:402) decided in fp32 whenever that is safe: each fp32 difference is correctly rounded and
     // the sum of the two squares is within 4 * 2^-24 of the float64 value the reference forms from the same fp32 state, so
     // outside +-1e-6 (relative) of cutoff^2 the fp32 comparison cannot disagree with it; inside, the float64 path decides
@@ -405,18 +404,36 @@ TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, 
         const double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
         moved = sqrt_gt(ddx * ddx + ddy * ddy, cfg.distance_cutoff, rb.cut);
     }
-    o.dist_r = moved ? cfg.distance_bonus : 0.0;
-    float dpsi = psi - lpsi;
-    o.psi_r = (1.0 - cos_heading_f64((double)dpsi)) * (-cfg.heading_penalty);
-    bool reach = false;
-    int ti = target_idx;
-    if (ti < n_wp) {
-        double tx = (double)x - wtx, ty = (double)y - wty;
-        reach = !sqrt_ge(tx * tx + ty * ty, cfg.reach_radius, rb.reach);
-    }
-    double reach_r = 0.0;
-    if (reach) { reach_r = cfg.waypoint_bonus; reached += 1; }
-    o.reward = (float)((reach_r + o.dist_r) + o.psi_r);
+    dist_r = moved ? cfg.distance_bonus : 0.0;
+    const float dpsi = psi - lpsi;
+    psi_r = (1.0 - cos_heading_f64((double)dpsi)) * (-cfg.heading_penalty);
+}
+// check_reach_target (:391-394) for a target that exists (target_idx < n_wp)
+template <typename CFG>
+TDE_DEV bool reward_reach(const CFG &cfg, const RewardBounds &rb, float x, float y, double wtx, double wty)
+{
+    const double tx = (double)x - wtx, ty = (double)y - wty;
+    return !sqrt_ge(tx * tx + ty * ty, cfg.reach_radius, rb.reach);
+}
+// the sum of :409-411, rounded to fp32 once
+template <typename CFG> TDE_DEV float reward_sum(const CFG &cfg, bool reach, double dist_r, double psi_r)
+{
+    return (float)(((reach ? cfg.waypoint_bonus : 0.0) + dist_r) + psi_r);
+}
+
+// (wtx, wty) = waypoint[target_idx], only read when target_idx < n_wp (current_target is not None, :394).
+template <typename CFG>
+TDE_DEV RewardOut reward_core(const CFG &cfg, int n_wp, double wtx, double wty, float lx, float ly, float lpsi,
+                              float lv, float x, float y, float psi, float v, bool off, bool col, bool tl, int k,
+                              int &target_idx, int &reached, bool want_info = true)
+{
+    RewardOut o;
+    const RewardBounds rb = reward_bounds(cfg);
+    reward_motion_terms(cfg, rb, lx, ly, lpsi, x, y, psi, o.dist_r, o.psi_r);
+    const int ti = target_idx;
+    const bool reach = ti < n_wp && reward_reach(cfg, rb, x, y, wtx, wty);
+    if (reach) reached += 1;
+    o.reward = reward_sum(cfg, reach, o.dist_r, o.psi_r);
     o.terminated = (uint8_t)(cfg.terminated_at_infraction && (off || col || tl));
     o.truncated = (uint8_t)(k >= cfg.max_steps);
     o.psi_smooth = o.speed_smooth = 0.0;

@@ -228,6 +228,14 @@ TDE_DEV void load_ego_target(const Cold &w, const EnvRegs &er, Ctx &cx)
     }
 }
 
+// the ego's reward context (number of waypoints, current target) on EVERY lane of the env (batched reward, judge C)
+TDE_DEV void load_ego_ctx(const Cold &w, const EnvRegs &er, Ctx &cx)
+{
+    cx.n_wp = reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
+    cx.wtx = cx.wty = 0.0;
+    load_ego_target(w, er, cx);
+}
+
 // sp4 = the slot's spawn record as four 16-B words (tde_spawn), or nullptr to fetch it here
 template <int A>
 TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, const EnvRegs &er, Ctx &cx)
@@ -1001,6 +1009,9 @@ struct DuoShared {
     // three-role kernel: the ego actions of the next two steps, relayed by judge O (slot = step & 1, indexed by the ego's
     // lane): the driver's loop then issues no global load of its own, so nothing in it ever waits on vmcnt
     float2 act[2][kWave];
+    // three-role rollout kernel, judge C: the ego poses (x, y, psi, v) before / after the last up to A steps of every env
+    // of the group, slot (env's first lane + step) - the reward arithmetic runs on a whole window at once (see there)
+    float4 ring_pre[kWave], ring_post[kWave];
 };
 constexpr int kStopCache = 8;
 
@@ -1381,8 +1392,61 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         TDE_ROLE_PROLOGUE
         RedCache redc; redc.invalidate();
         bool hit = false;
-        RewardOut rw{};
         uint8_t last_term = 0, last_trunc = 0;
+        // Reward (R6 / R7 / R12), batched.  Only the ego lane of an env has a reward to compute - one lane in A - and the
+        // arithmetic (float64 cosine, the reach and cut-off tests) cost this wavefront ~110 instructions per step for 64 / A
+        // useful lanes.  Instead the ego lane only RECORDS its pose before / after each step in an LDS ring, and the
+        // arithmetic runs when the ring holds A steps (or an env of the wavefront finished, or the launch ends), one lane
+        // per (env, step): lane `a` of an env evaluates the env's pending step `a`.  What couples the steps - the
+        // waypoint target advances when a step reaches it - is resolved by passes: every pending step is tested against
+        // the current target, the FIRST reaching step of an env (ballot + ffs) closes the steps up to it, the target
+        // advances, and the steps behind it are tested again (a second pass is common, a third needs two waypoints
+        // within a window).  Per-step results are identical to the step-by-step evaluation: same operands, same
+        // operations (reward_motion_terms / reward_reach / reward_sum are what reward_core is made of).
+        int npend = 0, ipend0 = 0;                           // pending steps [ipend0, ipend0 + npend) (wavefront-uniform)
+        const bool batch = (F & TDE_F_REWARD) != 0;
+        if (batch) load_ego_ctx(cold, er, cx);
+        auto flush = [&](bool final) {
+            const int n = npend;
+            if (n == 0) return;
+            const bool act = valid && a < n;
+            const float4 r0 = sh.ring_pre[lane], r1 = sh.ring_post[lane];
+            const RewardBounds rbn = reward_bounds(cold);
+            double dist_r = 0.0, psi_r = 0.0;
+            if (act) reward_motion_terms(cold, rbn, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, dist_r, psi_r);
+            int from = 0;                                    // first pending step of this env that is not closed yet
+            for (;;) {
+                bool reach = false;
+                if (act && a >= from && er.target_idx < cx.n_wp) reach = reward_reach(cold, rbn, r1.x, r1.y, cx.wtx, cx.wty);
+                const unsigned long long rm = __ballot(reach);
+                const uint32_t envbits = (uint32_t)(rm >> base) & (A >= 32 ? 0xffffffffu : ((1u << (A & 31)) - 1u));
+                const int s1 = envbits ? __ffs((int)envbits) - 1 : A;      // first reaching step of this env (A: none)
+                if (act && a >= from && a <= s1) {
+                    const float rwd = reward_sum(cold, a == s1, dist_r, psi_r);
+                    if (ro.reward) ro.reward[(int64_t)(ipend0 + a) * B + e] = rwd;
+                    if (final && a == n - 1) {               // the launch's last step: the per-env outputs
+                        st.reward[e] = rwd;
+                        if (st.info) {
+                            double *inf = st.info + 4 * (int64_t)e;
+                            inf[0] = (double)fabsf((r0.z - r1.z) / 0.1f); inf[1] = (double)fabsf((r0.w - r1.w) / 0.1f);
+                            inf[2] = psi_r; inf[3] = dist_r;
+                        }
+                    }
+                }
+                bool more = false;
+                if (s1 < A) {
+                    er.target_idx += 1; er.reached += 1;
+                    load_ego_target(cold, er, cx);
+                    from = s1 + 1;
+                    more = valid && from < n;
+                } else {
+                    from = n;
+                }
+                if (!__ballot(more)) break;
+            }
+            if (final && a == 0 && valid && st.info_reached) st.info_reached[e] = er.reached;
+            ipend0 += n; npend = 0;
+        };
         // what needs the other judge's masks (terminated, the done byte, this wavefront's own re-spawn bookkeeping) is
         // settled after the next barrier A
         auto settle = [&](int i) {           // i = the step whose masks are complete now
@@ -1407,9 +1471,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             lds_barrier();                                   // A: masks of step i-1 are complete
             if (i > 0) {
                 const unsigned long long dn = settle(i - 1);
+                if (dn && batch) flush(false);               // the finished episode's steps, before its env re-spawns
                 if (dn && ((dn >> base) & 1ull) && valid) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    if (batch) load_ego_ctx(cold, er, cx);
                     redc.invalidate();
                 }
             }
@@ -1423,25 +1489,21 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
             const unsigned long long m = __ballot(hit);
             if (lane == 0) sh.hit_mask = m;
-            if (a == 0 && valid) {
-                if (F & TDE_F_REWARD) {
+            if (batch) {
+                if (a == 0 && valid) {
                     const float4 pa = sh.a[q][lane], pc = sh.c[q][lane];      // state before the step (:371-375)
-                    const int ti0 = er.target_idx;
-                    // the infraction flags arrive later: this call settles everything but `terminated`
-                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, pa.x, pa.y, pc.x, pc.y, ra.x, ra.y, rc.x, rc.y, false,
-                                     false, false, k, er.target_idx, er.reached, st.info != nullptr);
-                    if (st.info) {
-                        double *inf = st.info + 4 * (int64_t)e;
-                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
-                    }
-                    if (st.info_reached) st.info_reached[e] = er.reached;
-                    if (er.target_idx != ti0) load_ego_target(cold, er, cx);
+                    sh.ring_pre[lane + npend] = make_float4(pa.x, pa.y, pc.x, pc.y);
+                    sh.ring_post[lane + npend] = make_float4(ra.x, ra.y, rc.x, rc.y);
                 }
-                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;
+                npend += 1;
+                if (npend == A && i + 1 < ro.K) flush(false);        // (the launch's last step is closed by the final flush)
+            } else if (a == 0 && valid && ro.reward) {
+                ro.reward[(int64_t)i * B + e] = 0.0f;
             }
         }
         lds_barrier();                                       // A'
         settle(ro.K - 1);
+        if (batch) flush(true);
         lds_barrier();                                       // done(K-1) is in sh.done
         const bool respawned = ((sh.done >> base) & 1ull) != 0;
         if (respawned && valid) reset_lane<A>(cfg, cold, e, a, ag, er);
@@ -1452,7 +1514,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             st.steps[e] = er.steps;
             st.target_idx[e] = er.target_idx;
             st.reached[e] = er.reached;
-            st.reward[e] = rw.reward;
+            if (!batch) st.reward[e] = 0.0f;
             st.terminated[e] = last_term;
             st.truncated[e] = last_trunc;
         }
