@@ -1356,6 +1356,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 lds_barrier();                               // A: the judges' masks of step i-1 are published
                 unsigned long long term_m, trunc_m;
                 const unsigned long long dn = i > 0 ? done_of(er.steps, term_m, trunc_m) : 0ull;
+                if (lane == 0) sh.done = dn;                 // judge O takes it from here (behind barrier B)
                 if (!dn) break;
                 // an env of this wavefront finished at step i-1: re-spawn its lanes (as step_lane does in place),
                 // put their rows into buffer q and recompute the step
@@ -1539,16 +1540,17 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             float2 act2 = make_float2(0.0f, 0.0f);
             if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step
             lds_barrier();                                   // A: masks of step i-1 are complete
+            lds_barrier();                                   // B: rows of step i are in buffer p
             if (i > 0) {
-                unsigned long long term_m, trunc_m;
-                const unsigned long long dn = done_of(er.steps, term_m, trunc_m);
+                // done(i-1) as the driver formed it between the two barriers (one 8-byte read instead of the three masks
+                // and the ballots of done_of): this role only needs it for its own re-spawn bookkeeping
+                const unsigned long long dn = sh.done;
                 if (dn && ((dn >> base) & 1ull) && valid) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     redc.invalidate();
                 }
             }
-            lds_barrier();                                   // B: rows of step i are in buffer p
             er.steps += 1;
             const int k = er.steps;
             const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
