@@ -131,8 +131,11 @@ def patch_trio(s):
             "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 18);\n")
     k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            float2 act2",
             "        lds_barrier();\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            float2 act2")
-    k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            const bool live = rc.z != 0.0f;\n            off = false;",
-            "            tde_mark(&stl, 19);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 20);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            const bool live = rc.z != 0.0f;\n            off = false;")
+    # (the done test moved behind barrier B: "done test + re-spawn" = slot 19 is what runs between B and the row reads)
+    k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            if (i > 0) {\n                // done(i-1) as the driver formed it",
+            "            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 20);\n            if (i > 0) {\n                // done(i-1) as the driver formed it")
+    k = sub(k, "            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            const bool live = rc.z != 0.0f;\n            off = false;",
+            "            tde_mark(&stl, 19);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            const bool live = rc.z != 0.0f;\n            off = false;")
     k = sub(k, "            if (ego) sh.act[p][lane] = act2;", "            if (ego) sh.act[p][lane] = act2;\n            tde_mark(&stl, 21);")
     k = sub(k, "        lds_barrier();                                       // A'\n        lds_barrier();                                       // done(K-1) is in sh.done\n        if (!valid) return;\n        st.offroad[g]",
             "        tde_flush(18, 22);\n        lds_barrier();                                       // A'\n        lds_barrier();                                       // done(K-1) is in sh.done\n        if (!valid) return;\n        st.offroad[g]")

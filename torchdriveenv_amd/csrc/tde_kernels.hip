@@ -1256,6 +1256,35 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 // wait for each other.  What depends on the other judge's mask (the done byte, terminated, C's own re-spawn
 // bookkeeping) is settled by C after the next barrier A.
 // ------------------------------------------------------------------------------------------------------------------
+// sensitivity probe (scripts/build_variant.sh -DTDE_DUMMY_D=100 ...): N extra dependent / independent VALU instructions per
+// step in one role, results discarded - which role's instructions cost how much
+#ifndef TDE_DUMMY_D
+#define TDE_DUMMY_D 0
+#endif
+#ifndef TDE_DUMMY_C
+#define TDE_DUMMY_C 0
+#endif
+#ifndef TDE_DUMMY_O
+#define TDE_DUMMY_O 0
+#endif
+#ifndef TDE_DUMMY_ILP
+#define TDE_DUMMY_ILP 1
+#endif
+template <int N> TDE_DEV void dummy_valu(float seed)
+{
+    if constexpr (N > 0) {
+        float v[TDE_DUMMY_ILP];
+#pragma unroll
+        for (int u = 0; u < TDE_DUMMY_ILP; ++u) v[u] = seed + (float)u;
+#pragma unroll
+        for (int n = 0; n < N / TDE_DUMMY_ILP; ++n) {
+#pragma unroll
+            for (int u = 0; u < TDE_DUMMY_ILP; ++u) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < TDE_DUMMY_ILP; ++u) asm volatile("" :: "v"(v[u]));
+    }
+}
 #ifndef TDE_PRIO_D
 #define TDE_PRIO_D 2
 #define TDE_PRIO_C 1
@@ -1352,6 +1381,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
                 }
                 sincos_f32(npsi, ns, nc);
+                dummy_valu<TDE_DUMMY_D>(nx);
                 if (pass) break;
                 lds_barrier();                               // A: the judges' masks of step i-1 are published
                 unsigned long long term_m, trunc_m;
@@ -1490,6 +1520,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
             const unsigned long long m = __ballot(hit);
             if (lane == 0) sh.hit_mask = m;
+            dummy_valu<TDE_DUMMY_C>(ra.x);
             if (batch) {
                 if (a == 0 && valid) {
                     const float4 pa = sh.a[q][lane], pc = sh.c[q][lane];      // state before the step (:371-375)
@@ -1560,6 +1591,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
                 tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+            dummy_valu<TDE_DUMMY_O>(ra.x);
             const unsigned long long om = __ballot(off), tm = __ballot(tl);
             if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
             if (ego) sh.act[p][lane] = act2;                 // step i+2 -> slot i & 1 (step i's action is consumed: B passed)
