@@ -2790,18 +2790,18 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
     // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (TDE_ROLLOUT=solo|duo|trio forces
     // one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median
-    // us per step (scripts/ab_rollout.py duo:... trio:..., profiles/r02_d_rollout_matrix.txt): three roles win at 8 and 16
-    // agents per env, without traffic lights (3.19 vs 3.49, 3.20 vs 3.62) and with them (5.18 vs 5.55, 4.44 vs 4.99); at
-    // 32 agents per env the 32-row sweeps of the three-role kernel spill 71 VGPRs under its 80-VGPR cap and the
-    // two-role kernel (128 VGPRs, four wavefronts per SIMD) is faster (4.14 vs 4.65; with lights 5.18 vs 7.80); at 64
-    // the two are equal (5.02) and two roles run.
+    // us per step (scripts/ab_rollout.py duo:... trio:..., profiles/r02_e_rollout_matrix.txt): three roles win at 8 and 16
+    // agents per env, without traffic lights (3.17 vs 3.50, 3.06 vs 3.54) and with them (5.32 vs 5.55, 4.55 vs 5.01), and
+    // at 32 without lights (3.70 vs 4.11); at 32 WITH lights the 32-row sweeps plus the stop-line loops spill under the
+    // 80-VGPR cap and the two-role kernel (128 VGPRs, four wavefronts per SIMD) is faster (5.18 vs 7.66); at 64 the two
+    // are equal (5.03) and two roles run.
     static const int forced = [] {
         const char *v = getenv("TDE_ROLLOUT");
         return !v ? 0 : !strcmp(v, "solo") ? 1 : !strcmp(v, "duo") ? 2 : !strcmp(v, "trio") ? 3 : 0;
     }();
     const bool lights0 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
-    const int team = forced ? forced : (st->A == 8 || st->A == 16) ? 3 : 2;
+    const int team = forced ? forced : (st->A == 8 || st->A == 16 || (st->A == 32 && !lights0)) ? 3 : 2;
     const bool solo = team == 1;
     if (team == 3 && trio_shape) {
 #define TDE_LAUNCH_TRIO(AA)                                                                                              \
