@@ -90,6 +90,8 @@ def validate(cfg: EnvConfig):
         raise ValueError("simulator.npc_cone_k must be >= 0")
     if sim.offroad_threshold <= 0:
         raise ValueError("simulator.offroad_threshold must be > 0")
+    if not sim.npc_max_steer >= 0:
+        raise ValueError("simulator.npc_max_steer must be >= 0")
     if not 1e-3 <= sim.npc_max_accel <= 1e3:
         raise ValueError("simulator.npc_max_accel must be in [1e-3, 1e3] m/s^2 (tde_env_* reject anything else)")
 

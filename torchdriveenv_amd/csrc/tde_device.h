@@ -67,7 +67,9 @@ TDE_DEV float thr2_of(const tde_config &cfg)
     return cfg.offroad_threshold_squared ? cfg.offroad_threshold : cfg.offroad_threshold * cfg.offroad_threshold;
 }
 
-TDE_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// fminf(fmaxf(v, lo), hi) for lo <= hi as ONE v_med3_f32 (the two-instruction form also canonicalises each operand first:
+// four instructions per clamp with SGPR bounds).  Same value for every v including NaN (both return lo).
+TDE_DEV float clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 
 // torch.remainder(a, b) for b > 0: result in [0, b).  fmodf is exact, so the two fast paths (|a| < b: a itself;
 // b <= |a| < 2b: a -+ b, exact by Sterbenz) return the very same bits as the generic call.

@@ -2734,6 +2734,10 @@ static int check_env_args(const char *fn, const tde_config *cfg, const tde_world
     if (w->A != st->A) { snprintf(g_err, sizeof(g_err), "%s: world.A (%d) != state.A (%d)", fn, w->A, st->A); return (int)hipErrorInvalidValue; }
     // sqrt_cr_f32 (the controller's braking-distance speed) is exact for arguments that are zero or in the normal fp32
     // range: amax times a length difference of metres is, for any sensible amax
+    if ((cfg->flags & TDE_F_NPC) && !(cfg->npc_max_steer >= 0.0f)) {          // clampf(v, -smax, smax) needs lo <= hi
+        snprintf(g_err, sizeof(g_err), "%s: config.npc_max_steer must be >= 0 (got %g)", fn, (double)cfg->npc_max_steer);
+        return (int)hipErrorInvalidValue;
+    }
     if ((cfg->flags & TDE_F_NPC) && !(cfg->npc_max_accel >= 1e-3f && cfg->npc_max_accel <= 1e3f)) {
         snprintf(g_err, sizeof(g_err), "%s: config.npc_max_accel must be in [1e-3, 1e3] m/s^2 (got %g)", fn, (double)cfg->npc_max_accel);
         return (int)hipErrorInvalidValue;
