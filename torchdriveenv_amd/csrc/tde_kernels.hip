@@ -356,10 +356,8 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
         const float nP = 0.01f - (ag.x * cp + ag.y * sp), nQ = -(ag.y * cp - ag.x * sp);
         const float L = (g_far + hl_i) + 0.07f;
         const float kc = fmaxf(cfg.npc_cone_k, 0.0f);
-#ifndef TDE_NPC_HALVES
-#define TDE_NPC_HALVES 1
-#endif
-#if TDE_NPC_HALVES
+        // (the rows as two 8-byte halves fetched at different stages: 3.63 vs 3.67 us; with 16-byte reads like the
+        //  collision sweep 3.25 vs 3.19, profiles/r02_d_ab_diet_steps.txt H1 / Q2)
         cand = sweep_blocks_halves<A>(ra, [&](float2 (&xy)[C], float2 (&zw)[C], float (&v)[C], auto &&prefetch_xy, auto &&prefetch_zw) {
             float f[C], l[C], n[C], w[C];
 #pragma unroll
@@ -384,58 +382,14 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
             for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
             pin(v);
         });
-#else
-        cand = sweep_blocks<A>(ra, [&](float4 (&r)[C], float (&v)[C], auto &&prefetch) {
-            float f[C], l[C], n[C], w[C];
-#pragma unroll
-            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].y, sp, nP); l[j] = __builtin_fmaf(-r[j].x, sp, nQ); }
-            pin(f, l);
-#pragma unroll
-            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(r[j].x, cp, f[j]); l[j] = __builtin_fmaf(r[j].y, cp, l[j]); }
-            pin(f, l);
-#pragma unroll
-            for (int j = 0; j < C; ++j) { n[j] = r[j].z - f[j]; w[j] = __builtin_fmaf(kc, f[j], r[j].w); }
-            pin(n, w);
-            pin_memory();
-            prefetch();                                        // the rows are consumed: fetch the next block's
-            pin_memory();
-#pragma unroll
-            for (int j = 0; j < C; ++j) { n[j] = n[j] + L; w[j] = w[j] - fabsf(l[j]); }
-            pin(n, w);
-#pragma unroll
-            for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
-            pin(v);
-        });
-#endif
         cand &= ~bit_of_row<A>(i);
     }
     float gap = 1e30f;
-#ifndef TDE_NPC_PAIR
-#define TDE_NPC_PAIR 1
-#endif
     // exact tests of the candidates; every lane walks its own list, so the wavefront makes max-over-lanes(count) trips
     // (3.8 on average for 0.9 candidates per lane: the busiest lane of 64 follows a platoon).  TWO candidates per trip:
     // two independent chains per lane - a lone wavefront issues independent instructions twice as fast as dependent
     // ones - and ceil(count / 2) trips (2.2).  A lane with fewer candidates tests its own row instead, which cannot be
     // taken (fj = 0).
-    auto exact = [&](int j) {
-        const float4 pj = ra[j], qj = rb[j];
-        const float ex = pj.x - ag.x, ey = pj.y - ag.y;
-        const float fj = ex * cp + ey * sp;
-        const float lj = ey * cp - ex * sp;
-        const float halfw = cfg.npc_lane_half + qj.w;  // = npc_lane_half + 0.5f * wid_j (qj.w = hw_j = 0.5f * wid_j)
-        const float hl_j = qj.z;
-        const float al = fabsf(lj);
-        const float hd = cp * qj.x + sp * qj.y;
-        // branch-free: bitwise and/or of the predicates (no short-circuit control flow around a handful of ops)
-        const bool inlane = al < halfw;
-        const bool cone = (j < i) & (fj < cfg.npc_cone_range) & (al < halfw + cfg.npc_cone_k * fj) & (hd > -0.5f);
-        // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit (scaling by 2 commutes with rounding)
-        const float g = fj - (hl_i + hl_j);
-        const bool take = (fj > 0.0f) & (inlane | cone);
-        return take ? g : 1e30f;
-    };
-#if TDE_NPC_PAIR
     while (__ballot(cand != 0)) {
         const mask_t c1 = cand & (cand - 1);
         int j[2];
@@ -493,15 +447,6 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
         }
         gap = fminf(gap, fminf(g[0], g[1]));
     }
-#else
-    while (__ballot(cand != 0)) {
-        if (cand) {
-            const int j = row_of_bit<A>(lowest_bit(cand));
-            cand &= cand - 1;
-            gap = fminf(gap, exact(j));
-        }
-    }
-#endif
     if (!has_target) {
         acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
         beta = 0.0f;
@@ -523,9 +468,6 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
 // or in fp32 arithmetic (the 1.001 is folded into the radii, kReach).  Phase 1 marks the pairs inside that radius
 // (branch-free, free to fuse its multiply-adds), phase 2 runs the 4-axis SAT test on the marked ones only.
 // Called by all lanes of the wavefront, converged.
-#ifndef TDE_COLLIDE_B128
-#define TDE_COLLIDE_B128 1
-#endif
 template <int A>
 TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
                           float hl, float hw, float ri)
@@ -539,12 +481,10 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
             float dx[C], dy[C], rr[C];
 #pragma unroll
             for (int j = 0; j < C; ++j) { dx[j] = r[j].x - x; dy[j] = r[j].y - y; rr[j] = ri + r[j].z; }
-#if TDE_COLLIDE_B128
             // the fourth component is not needed, but a 12-byte ds_read_b96 occupies the LDS array for 8 cycles per
             // wavefront and a 16-byte ds_read_b128 for 4: keep the row a full 16-byte read
 #pragma unroll
             for (int j = 0; j < C; ++j) asm volatile("" :: "v"(r[j].w));
-#endif
             pin(dx, dy);
             pin(rr);
             pin_memory();
