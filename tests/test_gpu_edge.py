@@ -292,7 +292,7 @@ def test_every_rollout_kernel_matches_the_oracle(mode):
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TDE_ROLLOUT=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
-                        "-m", "gpu", "-k", "rollout_matches or full_size"], env=env, cwd=ROOT, capture_output=True,
+                        "-m", "gpu", "-k", "rollout_matches or full_size or window_lengths"], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout

@@ -243,6 +243,30 @@ def test_env_rollout_matches_oracle(small_world):
     assert (hd & 1).sum() > 0
 
 
+@pytest.mark.parametrize("A,K,lights", [(8, 45, False), (8, 45, True), (32, 75, False), (32, 40, True), (16, 37, False),
+                                        (4, 30, False), (64, 30, False)])
+def test_env_rollout_other_agent_counts_and_window_lengths(A, K, lights):
+    """The persistent kernels at other group shapes, launch lengths that are no multiple of the reward window (judge C
+    evaluates the reward in windows of up to A steps, flushed early when an env finishes and at the launch's end), a second
+    launch continuing the first, with the float64 info terms: rewards, done bits and the whole state equal the oracle's."""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=6, A=A, seed=100 + A, n_maps=2)
+    flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0)
+    cfg = _abi.default_config(seed=7 + A, distance_cutoff=0.25, flags=flags, max_steps=60)
+    B = 24 if A >= 32 else 72
+    hs, ds, dw = _pair(world, B, A, cfg)
+    rng = np.random.default_rng(A + K)
+    for launch in range(2):
+        actions = np.stack([rng.uniform(-0.2, 1, (K, B)), rng.uniform(-0.15, 0.15, (K, B))], -1).astype(np.float32)
+        hr, hd = oracle.env_rollout(cfg, world, hs, actions)
+        dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+        assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)), (A, launch)
+        assert np.array_equal(dd.cpu().numpy(), hd), (A, launch)
+        assert_state_equal(hs.host(), ds.host(), f"A={A} launch {launch}")
+    assert (hd & 3).any() and hs["reached"].max() >= 1       # episodes ended and waypoints were reached on the way
+
+
 def test_env_rollout_without_autoreset_runs_past_termination(small_world):
     """no TDE_F_AUTORESET: finished envs keep being stepped (no re-spawn); the ego target advanced on the terminal step
     must be the one the following steps use (the one-role persistent kernel kept a stale one)"""
