@@ -26,6 +26,7 @@ ap.add_argument("--agents", type=int, default=16)
 ap.add_argument("--launches", type=int, default=40)
 ap.add_argument("--steps", type=int, default=250)
 ap.add_argument("--lights", action="store_true")
+ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawns")
 args = ap.parse_args()
 
 B, A, K = args.envs, args.agents, args.steps
@@ -44,6 +45,9 @@ reward = torch.empty((K, B), device=dev)
 done = torch.empty((K, B), dtype=torch.uint8, device=dev)
 flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0)
 cfg = _abi.default_config(seed=1, distance_cutoff=0.25, flags=flags)
+if args.endless:
+    cfg.terminated_at_infraction = 0
+    cfg.max_steps = 1 << 30
 ro = _abi.TdeRollout(actions.data_ptr(), reward.data_ptr(), done.data_ptr(), K, 0)
 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
