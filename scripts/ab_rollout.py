@@ -27,6 +27,8 @@ ap.add_argument("--launches", type=int, default=40)
 ap.add_argument("--steps", type=int, default=250)
 ap.add_argument("--lights", action="store_true")
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawns")
+ap.add_argument("--truncate-only", type=int, default=0, metavar="N",
+                help="no termination at infractions, truncation after N steps: every env re-spawns every N steps")
 args = ap.parse_args()
 
 B, A, K = args.envs, args.agents, args.steps
@@ -48,6 +50,9 @@ cfg = _abi.default_config(seed=1, distance_cutoff=0.25, flags=flags)
 if args.endless:
     cfg.terminated_at_infraction = 0
     cfg.max_steps = 1 << 30
+if args.truncate_only:
+    cfg.terminated_at_infraction = 0
+    cfg.max_steps = args.truncate_only
 ro = _abi.TdeRollout(actions.data_ptr(), reward.data_ptr(), done.data_ptr(), K, 0)
 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
