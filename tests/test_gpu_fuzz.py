@@ -1,0 +1,50 @@
+"""Randomised shapes for the persistent kernels (`-m gpu`): agents per env, launch lengths from 1 step to several reward
+windows, feature flags, short episodes (re-spawns at consecutive steps), consecutive launches - rewards, done bits and the
+whole state equal the oracle's after every launch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle  # noqa: E402
+from torchdriveenv_amd import _abi, ops  # noqa: E402
+from torchdriveenv_amd.state import EnvState  # noqa: E402
+from tests.test_gpu_parity import assert_state_equal, dev  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDE_FUZZ_CASES", "12"))))
+def test_rollout_fuzz(seed):
+    from torchdriveenv_amd.synth import synthetic_world
+
+    rng = np.random.default_rng(1000 + seed)
+    A = int(rng.choice([8, 16, 16, 16, 32]))
+    world = synthetic_world(n_scn=5, A=A, seed=200 + seed, n_maps=2)
+    flags = _abi.F_ALL
+    if rng.random() < 0.3:
+        flags |= _abi.F_TRAFFIC_LIGHTS
+    if rng.random() < 0.25:
+        flags &= ~_abi.F_AUTORESET
+    if rng.random() < 0.2:
+        flags &= ~_abi.F_OFFROAD
+    cfg = _abi.default_config(seed=seed, distance_cutoff=0.25, flags=flags, max_steps=int(rng.choice([1, 2, 3, 7, 40, 200])))
+    B = int(rng.integers(1, 60)) if A < 32 else int(rng.integers(1, 20))
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    for launch in range(3):
+        K = int(rng.choice([1, 2, A - 1, A, A + 1, 2 * A + 3, 50]))
+        actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+        hr, hd = oracle.env_rollout(cfg, world, hs, actions)
+        dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+        tag = f"seed {seed} A={A} B={B} K={K} flags={flags:#x} max_steps={cfg.max_steps} launch {launch}"
+        assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)), tag
+        assert np.array_equal(dd.cpu().numpy(), hd), tag
+        assert_state_equal(hs.host(), ds.host(), tag)
