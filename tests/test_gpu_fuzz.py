@@ -48,3 +48,34 @@ def test_rollout_fuzz(seed):
         assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)), tag
         assert np.array_equal(dd.cpu().numpy(), hd), tag
         assert_state_equal(hs.host(), ds.host(), tag)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDE_FUZZ_CASES", "8"))))
+def test_step_fuzz(seed):
+    """the closed-loop kernels (one launch per step; with the lookup caches: three roles, without: one) over random shapes,
+    flags and episode lengths, compared with the oracle after EVERY step"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    rng = np.random.default_rng(5000 + seed)
+    A = int(rng.choice([4, 8, 16, 16, 32]))
+    world = synthetic_world(n_scn=5, A=A, seed=300 + seed, n_maps=2)
+    flags = _abi.F_ALL
+    if rng.random() < 0.3:
+        flags |= _abi.F_TRAFFIC_LIGHTS
+    if rng.random() < 0.25:
+        flags &= ~_abi.F_AUTORESET
+    cfg = _abi.default_config(seed=seed, distance_cutoff=0.25, flags=flags, max_steps=int(rng.choice([1, 2, 5, 30, 200])))
+    B = int(rng.integers(1, 50)) if A < 32 else int(rng.integers(1, 16))
+    hs = EnvState(B, A)
+    ds = EnvState(B, A, device=DEV, with_cache=bool(rng.random() < 0.7))
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    for t in range(45):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+        if t % 5 == 4 or t < 3:
+            assert_state_equal(hs.host(), ds.host(), f"seed {seed} A={A} B={B} flags={flags:#x} max_steps={cfg.max_steps} step {t}")
