@@ -1244,10 +1244,18 @@ template <int N> TDE_DEV void dummy_valu(float seed)
         for (int u = 0; u < TDE_DUMMY_ILP; ++u) asm volatile("" :: "v"(v[u]));
     }
 }
+// issue priorities of the three roles.  Round 1: driver > judge C > judge O (2, 1, 0).  After round 2's diet of judge C
+// (windowed reward, DPP collision prefilter) judge O's chain - four dependent cell-word loads per slot - is the longer one
+// of the two: (2, 0, 1) 2.93 us per step against (2, 1, 0) 3.00, (3, 0, 2) 2.93, (2, 0, 2) 2.99, (1, 0, 1) 2.99
+// (profiles/r02_d_ab_diet_steps.txt, tail)
+#ifndef TDE_SPRIO_C             // the one-step three-role kernel's judges (its driver: 2)
+#define TDE_SPRIO_C 0
+#define TDE_SPRIO_O 1
+#endif
 #ifndef TDE_PRIO_D
 #define TDE_PRIO_D 2
-#define TDE_PRIO_C 1
-#define TDE_PRIO_O 0
+#define TDE_PRIO_C 0
+#define TDE_PRIO_O 1
 #endif
 template <int A, bool LIGHTS>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_rollout_trio_kernel(tde_config cfg, tde_world w, tde_state st,
@@ -1294,8 +1302,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         // ================================ drive ================================
         TDE_ROLE_PROLOGUE
         RedCache redc; redc.invalidate();
-        // issue priority in the order of the roles' chains: driver (the serial chain of the simulation) > judge C > judge O;
-        // same-box A/B: (3,0,0) 4.00 us, (3,2,0) 3.84, (2,1,0) 3.81, none 4.4-4.8
+        // issue priority in the order of the roles' chains (TDE_PRIO_* above); round 1, same-box A/B: (3,0,0) 4.00 us,
+        // (3,2,0) 3.84, (2,1,0) 3.81, none 4.4-4.8
         __builtin_amdgcn_s_setprio(TDE_PRIO_D);
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
@@ -1761,7 +1769,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                                                                   __float_as_int(na2), __float_as_int(nb2));
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(TDE_SPRIO_C);
         EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
         // the ego's pose before the step (:371-375), read before the driver commits the new one at the end of the launch
         float lx = 0.0f, ly = 0.0f, lpsi = 0.0f, lv = 0.0f;
@@ -1881,7 +1889,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         }
     } else {
         // ===================== judge O: offroad, stop lines =====================
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(TDE_SPRIO_O);
         const int scn = st.scn[es];
         const int k = st.steps[es] + 1;
         int4 e0 = make_int4(0, 0, 0, 0);
