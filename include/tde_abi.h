@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 6
+#define TDE_ABI_VERSION 7
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -47,6 +47,7 @@ extern "C" {
 #define TDE_CELL_EMPTY 0u  /* every point of the cell is farther than threshold from every triangle  */
 #define TDE_CELL_MIXED 1u  /* test the cell's candidate triangles                                    */
 #define TDE_CELL_FULL  2u  /* every point of the cell is within threshold of some triangle            */
+#define TDE_CELL_SUB   4   /* a MIXED cell carries TDE_CELL_SUB x TDE_CELL_SUB sub-cell classes (tde_world.cell_tri) */
 
 typedef struct tde_config {
     /* reward constants are Python floats (float64) in the reference: EnvConfig, gym_env.py:34-54 */
@@ -93,8 +94,8 @@ typedef struct tde_map {
     int32_t stop_base, n_stop;  /* stop lines of this map in tde_world.stoplines */
     int32_t phase_base, n_phase;/* traffic-light cycle of this map in tde_world.phases */
     int32_t cycle_steps;        /* length of the cycle in env steps (0: no lights) */
-    int32_t row_shift;          /* log2 of the row pitch of the map's cell words */
-    int32_t _pad1;
+    int32_t row_shift;          /* log2 of the row pitch of the map's cell words (>= 5) */
+    int32_t cls2_base;          /* first 128-byte tile of this map in tde_world.cell_cls2 (in tiles) */
 } tde_map;
 
 /* A stop line: an oriented box across an inbound lane, governed by traffic light `light` of its map
@@ -144,7 +145,15 @@ typedef struct tde_world {
                                    cells: bits 2-9 clearance in units of TDE_CLEARANCE_UNIT (every point that close to the cell
                                    lies in a cell of the same class) */
     const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
-                                   ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 */
+                                   ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,sub,0,0
+                                   sub (ABI 7; only in the FIRST record of a MIXED cell, as a uint32 bit pattern): 2-bit
+                                   TDE_CELL_* class of each of the cell's 4 x 4 sub-cells, sub-cell (sx, sy) at bits
+                                   2 * (4 * sy + sx); conservative like the cell classes (2 mm margin) */
+    const uint32_t *cell_cls2;  /* (ABI 7, rasteriser) the cell classes alone, 2 bits per cell, in 128-byte tiles of 32 x 16 cells
+                                   (8 m x 4 m at 0.25 m cells: a 35 m view touches ~50 cache lines of it, against one line per
+                                   look-up in cell_word).  Tile (tx, ty) = cells [32 tx, 32 tx + 32) x [16 ty, 16 ty + 16) of a
+                                   map is tile cls2_base + (ty << (row_shift - 5)) + tx; inside a tile word 2 * (iy & 15) +
+                                   ((ix >> 4) & 1) holds the 16 cells ix & ~15 .. of row iy, cell ix at bits 2 * (ix & 15) */
     const tde_scenario *scn;    /* [S] */
     const double *wp_xy;        /* [S][NW][2] ego waypoints, float64 like the YAML lists (gym_env.py:314,394) */
     const tde_spawn *spawn;     /* [S][A] */

@@ -709,35 +709,58 @@ static void tde_render_env(const tde_config *cfg, const tde_world *w, const tde_
     const uint32_t red = lights ? tde_red_mask(w, m, st->steps[e]) : 0u;     /* light state at the env's current step */
     const float lsign = (rd->flags & TDE_RENDER_LEFT_HANDED) ? -1.0f : 1.0f;
     const uint8_t *ego_col = (rd->flags & TDE_RENDER_PLAIN_EGO) ? NPC : EGO;
-    float ca[TDE_MAX_AGENTS], sa[TDE_MAX_AGENTS];
-    for (int32_t a = 0; a < A; ++a) tde_oracle_sincosf(st->psi[g0 + a], &sa[a], &ca[a]);
-    const float ex = st->x[g0], ey = st->y[g0], ce = ca[0], se = sa[0];
+    /* Pixel -> world as ONE affine map per view, evaluated with explicit fused multiply-adds (round 3; the unfused chain
+     * cost the rasteriser ~10 operations per pixel and object):
+     *     u = (H/2 - 0.5) - r,   v = (W/2 - 0.5) - c          (exact: small half-integers)
+     *     world = ego + u * (ax, ay) + v * (bx, by),  (ax, ay) = res * (cos, sin) of the ego's heading (one image row up),
+     *                                                 (bx, by) = (-rs * sin, rs * cos), rs = res * lsign (one column left)
+     * and every per-object quantity tested per pixel (box-frame coordinates p, q; offset to a waypoint) is the affine
+     * function of (u, v) it is in exact arithmetic, its three coefficients formed once per object (plain fp32
+     * operations, written out below) and then evaluated as fmaf(v, cb, fmaf(u, ca, c0)).  The HIP rasteriser evaluates
+     * the same expressions (csrc/tde_raster.h), so pixels are bit-identical. */
+    const float ex = st->x[g0], ey = st->y[g0];
+    float ce, se;
+    tde_oracle_sincosf(st->psi[g0], &se, &ce);
     const float res = rd->fov / (float)W;
+    const float rs = res * lsign;
+    const float ax = res * ce, ay = res * se, bx = (-rs) * se, by = rs * ce;
+    const float hu = 0.5f * (float)H - 0.5f, hv = 0.5f * (float)W - 0.5f;
+    /* box-frame coefficients of agent / stop-line boxes: p = along the box, q = across it */
+    float bp0[TDE_MAX_AGENTS], bpa[TDE_MAX_AGENTS], bpb[TDE_MAX_AGENTS], bq0[TDE_MAX_AGENTS], bqa[TDE_MAX_AGENTS],
+        bqb[TDE_MAX_AGENTS];
+    for (int32_t a = 0; a < A; ++a) {
+        float cb, sb;
+        tde_oracle_sincosf(st->psi[g0 + a], &sb, &cb);
+        const float dx = ex - st->x[g0 + a], dy = ey - st->y[g0 + a];
+        bp0[a] = dx * cb + dy * sb; bpa[a] = ax * cb + ay * sb; bpb[a] = bx * cb + by * sb;
+        bq0[a] = dy * cb - dx * sb; bqa[a] = ay * cb - ax * sb; bqb[a] = by * cb - bx * sb;
+    }
     const double *wp = w->wp_xy + (int64_t)scn * w->NW * 2;
     const int32_t n_wp = w->scn[scn].wp_n, ti = st->target_idx[e];
     for (int32_t r = 0; r < H; ++r)
         for (int32_t c = 0; c < W; ++c) {
-            float f = (0.5f * (float)H - ((float)r + 0.5f)) * res;
-            float l = ((0.5f * (float)W - ((float)c + 0.5f)) * res) * lsign;
-            float wx = (ex + f * ce) - l * se;
-            float wy = (ey + f * se) + l * ce;
+            const float u = hu - (float)r, v = hv - (float)c;
+            const float wx = fmaf(v, bx, fmaf(u, ax, ex));
+            const float wy = fmaf(v, by, fmaf(u, ay, ey));
             const uint8_t *col = BG;
             if (!(tde_oracle_point_mesh_d2(wx, wy, tri, m->n_tri) > thr2)) col = ROAD;
             if (lights)
                 for (int32_t k = 0; k < m->n_stop; ++k) {
                     const tde_stopline *sl = &w->stoplines[m->stop_base + k];
-                    float dx = wx - sl->x, dy = wy - sl->y;
-                    float p = dx * sl->c + dy * sl->s, q = dy * sl->c - dx * sl->s;
+                    const float dx = ex - sl->x, dy = ey - sl->y;
+                    const float p0 = dx * sl->c + dy * sl->s, pa = ax * sl->c + ay * sl->s, pb = bx * sl->c + by * sl->s;
+                    const float q0 = dy * sl->c - dx * sl->s, qa = ay * sl->c - ax * sl->s, qb = by * sl->c - bx * sl->s;
+                    const float p = fmaf(v, pb, fmaf(u, pa, p0)), q = fmaf(v, qb, fmaf(u, qa, q0));
                     if (fabsf(p) <= sl->hl && fabsf(q) <= sl->hw) col = ((red >> sl->light) & 1u) ? STOP_RED : STOP_GO;
                 }
             for (int32_t k = ti; k < n_wp; ++k) {
-                float dx = wx - (float)wp[2 * k], dy = wy - (float)wp[2 * k + 1];
-                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) col = WP;
+                const float dx0 = ex - (float)wp[2 * k], dy0 = ey - (float)wp[2 * k + 1];
+                const float dx = fmaf(v, bx, fmaf(u, ax, dx0)), dy = fmaf(v, by, fmaf(u, ay, dy0));
+                if (fmaf(dx, dx, dy * dy) <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) col = WP;
             }
             for (int32_t a = A - 1; a >= 0; --a) {
                 if (!st->present[g0 + a]) continue;
-                float dx = wx - st->x[g0 + a], dy = wy - st->y[g0 + a];
-                float p = dx * ca[a] + dy * sa[a], q = dy * ca[a] - dx * sa[a];
+                const float p = fmaf(v, bpb[a], fmaf(u, bpa[a], bp0[a])), q = fmaf(v, bqb[a], fmaf(u, bqa[a], bq0[a]));
                 if (fabsf(p) <= 0.5f * st->len[g0 + a] && fabsf(q) <= 0.5f * st->wid[g0 + a]) col = a ? NPC : ego_col;
             }
             for (int ch = 0; ch < 3; ++ch) img[ch * plane + (int64_t)r * W + c] = col[ch];

@@ -237,7 +237,7 @@ def test_render_other_sizes_and_bad_sizes(small_world):
     hs, ds = EnvState(5, 16), EnvState(5, 16, device=DEV)
     oracle.env_reset(cfg, small_world, hs)
     ops.env_reset(cfg, dw, ds)
-    for (H, W, fov) in ((32, 32, 35.0), (64, 32, 20.0), (48, 64, 50.0)):
+    for (H, W, fov) in ((32, 32, 35.0), (64, 32, 20.0), (48, 64, 50.0), (36, 36, 35.0), (60, 64, 28.0), (8, 256, 90.0)):
         want = oracle.render_ego(cfg, small_world, hs, H=H, W=W, fov=fov)
         got = ops.render_ego(cfg, dw, ds, H=H, W=W, fov=fov).cpu().numpy()
         assert np.array_equal(got, want), (H, W, int((got != want).sum()))

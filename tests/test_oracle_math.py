@@ -84,7 +84,7 @@ def test_philox_known_answer():
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def grid_offroad_numpy(world, map_id, px, py, thr):
+def grid_offroad_numpy(world, map_id, px, py, thr, use_sub=False):
     """float32 emulation of the kernel's cell lookup + candidate test (tde_device.h: cell_lookup / box_offroad)"""
     f = np.float32
     m = world.arrays["maps"][map_id]
@@ -101,6 +101,13 @@ def grid_offroad_numpy(world, map_id, px, py, thr):
         if cls != _abi.CELL_MIXED:
             out[i] = cls == _abi.CELL_EMPTY
             continue
+        if use_sub:                                        # sub-cell classes of the MIXED cell (world.py: subcell_classes)
+            bm = int(recs[wd >> 10, 9:10].view(np.uint32)[0])
+            sx, sy = min(int((fx - f(ix)) * f(4)), 3), min(int((fy - f(iy)) * f(4)), 3)
+            sc = (bm >> (2 * (4 * sy + sx))) & 3
+            if sc != _abi.CELL_MIXED:
+                out[i] = sc == _abi.CELL_EMPTY
+                continue
         ok = False
         for k in range(wd >> 10, (wd >> 10) + ((wd >> 2) & 255)):
             if oracle.point_mesh_d2(x, y, recs[k, :6]) <= f(thr) * f(thr):
@@ -126,5 +133,7 @@ def test_grid_index_equals_brute_force(small_world):
         want = np.array([oracle.point_mesh_d2(x, y, tri) > np.float32(0.5) * np.float32(0.5)
                          for x, y in zip(px.astype(np.float32), py.astype(np.float32))])
         got = grid_offroad_numpy(w, map_id, px, py, 0.5)
+        assert np.array_equal(got, want)
+        got = grid_offroad_numpy(w, map_id, px, py, 0.5, use_sub=True)     # what the rasteriser does in MIXED cells
         assert np.array_equal(got, want)
         assert 0.2 < want.mean() < 0.95

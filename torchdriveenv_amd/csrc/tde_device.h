@@ -12,6 +12,8 @@
 
 #define TDE_DEV __device__ __forceinline__
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
 namespace tde {
 
 constexpr float kPi = 3.14159265358979323846f;      // float(np.pi)
@@ -147,6 +149,20 @@ TDE_DEV float seg_d2_inv(float px, float py, float ax, float ay, float bx, float
     t = clampf(t, 0.0f, 1.0f);
     float qx = apx - t * abx, qy = apy - t * aby;
     return qx * qx + qy * qy;
+}
+
+// (the record as three 16-byte words held in registers)
+TDE_DEV float point_tri_d2_words(float px, float py, const float4 &t0, const float4 &t1, const float4 &t2)
+{
+    const float ax = t0.x, ay = t0.y, bx = t0.z, by = t0.w, cx = t1.x, cy = t1.y;
+    float e0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+    float e1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
+    float e2 = (ax - cx) * (py - cy) - (ay - cy) * (px - cx);
+    if ((e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) || (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f)) return 0.0f;
+    float d = seg_d2_inv(px, py, ax, ay, bx, by, t1.z);
+    d = fminf(d, seg_d2_inv(px, py, bx, by, cx, cy, t1.w));
+    d = fminf(d, seg_d2_inv(px, py, cx, cy, ax, ay, t2.x));
+    return d;
 }
 
 TDE_DEV float point_tri_d2_packed(float px, float py, const float4 *__restrict__ T)

@@ -17,6 +17,7 @@
 
 #include "../../include/tde_hip.h"
 #include "tde_device.h"
+#include "tde_raster.h"
 
 namespace tde {
 
@@ -26,7 +27,6 @@ constexpr int kWave = 64;
 // 16-byte streaming store as ONE global_store_dwordx4 ... nt.  (__builtin_nontemporal_store on the members of HIP's uint4
 // struct gives four dword stores whose lanes interleave at 16-byte stride: four times the store instructions, each
 // writing a quarter of every cache line it touches.)
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 TDE_DEV void store_nt16(void *dst, const uint4 &v)
 {
     u32x4_t t;
@@ -2042,19 +2042,6 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(
     if (info_reached) info_reached[i] = rc;
 }
 
-// ---- R13: ego-centred birdview raster (get_obs -> render_egocentric, ref gym_env.py:122-124; layers: tde_abi.h) ----
-// One workgroup per env view (render_layers_kernel below).  pass 0: agents / remaining waypoints are culled against
-// the view circle into LDS lists with conservative pixel-space spans (a typical 35 m view holds 1-3 of the 16-32
-// agents).  Every shortcut is conservative (supersets / clearance margins), so each pixel equals the per-pixel
-// specification.
-constexpr int kRenderMaxWp = 64;
-constexpr int kRenderMaxPix = 4096;               // H*W limit (LDS layer plane, one byte per pixel)
-constexpr int kRenderWork = 2048;                 // exact-pixel queue (a view that needs more takes the all-pixels path)
-constexpr int kRenderMixed = 1024;                // of which in MIXED cells (more: all-pixels path); LDS per view stays
-                                                  // under 20 KiB = 8 workgroups per CU, the wavefront limit
-constexpr int kRenderMaxBox = 40;                 // agent boxes kept per view (more: all-pixels path)
-constexpr int kRenderMaxStop = 16;                // stop lines kept per view (more: all-pixels path)
-
 // compact observation of the ego (obs_mode "state" of the host mirror): one lane per env
 __global__ __launch_bounds__(kBlock) void state_obs_kernel(tde_world w, tde_state st, float *__restrict__ out)
 {
@@ -2079,7 +2066,6 @@ __global__ __launch_bounds__(kBlock) void state_obs_kernel(tde_world w, tde_stat
     o[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)st.steps[e]);
 }
 
-struct RenderBox { float x, y, c, s, hl, hw; int rmin, rmax, cmin, cmax; };
 
 // Frame stack (VecFrameStack(n_stack, channels_order="first"), ref examples/rl_training.py:160): the older frames of
 // every view move down by one frame, in place, before the new frame is rasterised.  A launch of its own: as a pure
@@ -2110,25 +2096,11 @@ __global__ __launch_bounds__(kBlock) void frame_shift_kernel(uint8_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Layer-plane rasteriser (tde_render_ego), organised by object instead of by pixel:
-//   the LDS image is ONE byte per pixel holding the layer (0 background, 1 road, 2 waypoint, 3 NPC, 4 ego);
-//   pass 1  base layer per 2x2 block from the grid class + clearance of its centre cell (four independent lookups per
-//           thread); only the pixels of blocks that straddle a road edge are queued,
-//   pass 2  queued pixels: their own cell word; those in MIXED cells are compacted (with the word) and get their
-//           candidate-triangle tests densely,
-//   pass 3  objects paint over the base in layer order - waypoint discs, NPC boxes, the ego - the workgroup covering
-//           each object's conservative pixel span as a 16 x 16 tile: sum-of-spans tests instead of
-//           (queued pixels) x (objects),
-//   pass 4  16 layer bytes -> 3 x 16 colour bytes with one v_perm_b32 per dword and channel, 16-B coalesced stores.
-// The per-pixel expressions (pixel centre -> world point, disc / box tests) are the specification's, so every pixel
-// equals the all-pixels path below and the oracle.
+// R13: ego-centred birdview raster (get_obs -> render_egocentric, ref gym_env.py:122-124; layers: tde_abi.h), stand-alone
+// form: one wavefront per view (tde_raster.h: raster_view), agent poses read from the state arrays.
 // ------------------------------------------------------------------------------------------------------------------
-struct PixelSpan { int rmin, rmax, cmin, cmax; };
-
-// Kernel arguments of the rasteriser: only what it reads.  Passing tde_config + tde_world + tde_state + tde_render by value
-// (about 120 SGPRs of arguments) left the kernel at 98-106 SGPRs, and 256-thread workgroups are admitted per CU up to
-// floor(800 / (ceil(sgpr / 16) * 16 + 16)) (MI355X_MICROARCH.md, "Residency"): 6 per CU instead of the 8 that the
-// wavefront limit allows.  With the slim block the kernel stays at or below 80 SGPRs.
+// Kernel arguments of the rasteriser: only what it reads (tde_config + tde_world + tde_state + tde_render by value are
+// about 120 SGPRs of arguments).
 struct RenderArgs {
     const tde_map *maps;
     const uint32_t *cell_word;
@@ -2144,430 +2116,70 @@ struct RenderArgs {
     float thr2;
     uint32_t flags;
     int32_t NW, A;
+    const uint32_t *cell_cls2;
+    int32_t K8, K4;                     // raster_block_clearance(8 / 4, res)
 };
 
+// agent poses from the state arrays (slot j of the view's env)
+struct StateAgents {
+    const float *x, *y, *psi, *len, *wid;
+    const uint8_t *present;
+    int64_t g0;
+    TDE_DEV bool operator()(int j, float &ox, float &oy, float &oc, float &os, float &hl, float &hw) const
+    {
+        const int64_t g = g0 + j;
+        ox = x[g]; oy = y[g];
+        sincos_f32(psi[g], os, oc);
+        hl = 0.5f * len[g]; hw = 0.5f * wid[g];
+        return present[g] != 0;
+    }
+};
+
+// Eight views (wavefronts) per SIMD: at most 64 VGPRs, 80 SGPRs and 5 KB of LDS per view.  8192 views are then ONE residency
+// round of the chip (32 per CU); at 23 per CU (7 KB of LDS, the first form of this kernel) the second round ran nearly
+// empty: 53 us against 33 for 4096 views (profiles/r03_a_render_scale_views.txt)
+#ifndef TDE_RENDER_WAVES
+#define TDE_RENDER_WAVES 8
+#endif
 #ifndef TDE_RENDER_SGPRS
-#define TDE_RENDER_SGPRS 96
+#define TDE_RENDER_SGPRS 80
 #endif
-#ifndef TDE_RENDER_BLOCK
-#define TDE_RENDER_BLOCK 256
-#endif
-// threads per view: 256 = four wavefronts; 128 = two (twice the views in flight per CU at the same wavefront count)
-constexpr int kRB = TDE_RENDER_BLOCK;
-__global__ __launch_bounds__(kRB) __attribute__((amdgpu_num_sgpr(TDE_RENDER_SGPRS))) void render_layers_kernel(RenderArgs ra)
+template <int SIZE>   // 64: 64 x 64 images (the reference's observation; every stride a constant); 0: rd.H x rd.W
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TDE_RENDER_WAVES, TDE_RENDER_WAVES), amdgpu_num_sgpr(TDE_RENDER_SGPRS)))
+void render_views_kernel(RenderArgs ra)
 {
-    // views of the argument block under the names the body uses (only the members set here are ever read)
-    tde_world w{};
-    w.maps = ra.maps; w.cell_word = ra.cell_word; w.cell_tri = ra.cell_tri; w.scn = ra.scn_tab; w.wp_xy = ra.wp_xy;
-    w.stoplines = ra.stoplines; w.phases = ra.phases; w.NW = ra.NW;
-    tde_state st{};
-    st.x = const_cast<float *>(ra.x); st.y = const_cast<float *>(ra.y); st.psi = const_cast<float *>(ra.psi);
-    st.len = const_cast<float *>(ra.len); st.wid = const_cast<float *>(ra.wid);
-    st.present = const_cast<uint8_t *>(ra.present); st.scn = const_cast<int32_t *>(ra.scn);
-    st.steps = const_cast<int32_t *>(ra.steps); st.target_idx = const_cast<int32_t *>(ra.target_idx); st.A = ra.A;
+    __shared__ RasterScratch S;
     const tde_render &rd = ra.rd;
-    __shared__ uint32_t s_layer[kRenderMaxPix / 4];
-    __shared__ RenderBox s_box[kRenderMaxBox];           // NPC boxes in view, ego kept separately
-    __shared__ float2 s_wp[kRenderMaxWp];
-    __shared__ PixelSpan s_wpbb[kRenderMaxWp];
-    __shared__ RenderBox s_ego;
-    __shared__ RenderBox s_stop[kRenderMaxStop];         // stop lines in view
-    __shared__ uint8_t s_stopl[kRenderMaxStop];          // their layer (TDE_LAYER_STOP_RED / _GO)
-    __shared__ uint16_t s_work[kRenderWork];             // pixels whose base layer needs the exact test (r * W + c)
-    __shared__ uint32_t s_mixed[kRenderMixed];           // cell words of the queued pixels that lie in MIXED cells
-    __shared__ int s_nbox, s_nwp, s_nwork, s_nmixed, s_nstop;
-    const int tid = threadIdx.x;
-    const int A = st.A, H = rd.H, W = rd.W;
-    const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
-    const int plane = H * W;
-    const int e = blockIdx.x;      // (frame stack: see pass 4; without a layer ring frame_shift_kernel ran before this launch)
+    const int e = blockIdx.x;
     if (rd.only && !rd.only[e]) return;            // masked call: this view keeps its pixels and its ring
-    uint8_t *out = rd.out + (int64_t)e * 3 * ns * plane;
-    const int64_t g0 = (int64_t)e * A;
-    const int scn = st.scn[e];
-    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[scn];
-    const tde_map m = w.maps[sc.x];
-    // (a per-view cache of these two records - one round of loads instead of the chain scenario -> map - was measured and
-    // buys nothing: 66.4 vs 65.8 us; other workgroups cover a view's start-up latency, the kernel is bound by issue)
-    const float thr2 = ra.thr2;
-    const bool lights = (ra.flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-    const float lsign = (rd.flags & TDE_RENDER_LEFT_HANDED) ? -1.0f : 1.0f;   // left-handed world: lateral image axis mirrored
-    const int ego_layer = (rd.flags & TDE_RENDER_PLAIN_EGO) ? TDE_LAYER_NPC : TDE_LAYER_EGO;
-    const float res = rd.fov / (float)W;
-    const float inv_res = 1.0f / res;
-    const float halfH = 0.5f * (float)H, halfW = 0.5f * (float)W;
-    const float rview = 0.75f * res * (float)(H > W ? H : W) + 1.0f;   // view circle: lists are supersets
-    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; s_nstop = 0; }
-    const float ex = st.x[g0], ey = st.y[g0];
-    float se, ce;
-    sincos_f32(st.psi[g0], se, ce);
-    __syncthreads();
-
-    // conservative pixel bounding boxes (inclusive, one pixel of slack for rounding), clipped to the image
-    auto clip = [=](float rlo, float rhi, float clo, float chi) -> PixelSpan {
-        PixelSpan b;
-        b.rmin = max((int)floorf(rlo), 0); b.rmax = min((int)ceilf(rhi), H - 1);
-        b.cmin = max((int)floorf(clo), 0); b.cmax = min((int)ceilf(chi), W - 1);
-        return b;
-    };
-    auto disc_span = [=](float x, float y, float rad) -> PixelSpan {
-        const float dx = x - ex, dy = y - ey;
-        const float f = dx * ce + dy * se, l = (dy * ce - dx * se) * lsign;
-        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f, pr = rad * inv_res + 1.0f;
-        return clip(rc - pr, rc + pr, cc - pr, cc + pr);
-    };
-    auto box_span = [=](float x, float y, float cb, float sb, float hl, float hw) -> PixelSpan {
-        const float dx = x - ex, dy = y - ey;
-        const float f = dx * ce + dy * se, l = (dy * ce - dx * se) * lsign;
-        const float cr = cb * ce + sb * se, sr = sb * ce - cb * se;      // box heading relative to the ego's
-        const float ef = fabsf(cr) * hl + fabsf(sr) * hw, el = fabsf(sr) * hl + fabsf(cr) * hw;
-        const float rc = halfH - f * inv_res - 0.5f, cc = halfW - l * inv_res - 0.5f;
-        const float pr = ef * inv_res + 1.0f, pc = el * inv_res + 1.0f;
-        return clip(rc - pr, rc + pr, cc - pc, cc + pc);
-    };
-    // ---- pass 0: cull agents, waypoints and stop lines to the view.  Each kind is handled by a DIFFERENT wavefront (its
-    // dependent loads then overlap with the others' instead of queueing up in wavefront 0, which used to hold the whole
-    // workgroup at the barrier behind pass 1), and the wavefronts without culling work start pass 1 at once.
-    constexpr int kCullAgents = kRB >= 128 ? 64 : 0, kCullWp = kRB >= 256 ? 128 : 0, kCullStop = kRB >= 256 ? 192 : 0;
-    if (tid >= kCullAgents && tid < kCullAgents + A) {
-        const int ai = tid - kCullAgents;
-        const int64_t g = g0 + ai;
-        float sa, ca;
-        sincos_f32(st.psi[g], sa, ca);
-        const float bx = st.x[g], by = st.y[g], bhl = 0.5f * st.len[g], bhw = 0.5f * st.wid[g];
-        RenderBox *dstb = nullptr;
-        if (ai == 0) {
-            dstb = &s_ego;
-        } else if (st.present[g]) {
-            const float dx = bx - ex, dy = by - ey, rr = rview + (bhl + bhw);
-            if (dx * dx + dy * dy <= rr * rr) {
-                const int k = atomicAdd(&s_nbox, 1);
-                if (k < kRenderMaxBox) dstb = &s_box[k];        // beyond: the view takes the all-pixels path
-            }
-        }
-        if (dstb) {
-            const PixelSpan bb = box_span(bx, by, ca, sa, bhl, bhw);
-            dstb->x = bx; dstb->y = by; dstb->c = ca; dstb->s = sa; dstb->hl = bhl; dstb->hw = bhw;
-            dstb->rmin = bb.rmin; dstb->rmax = bb.rmax; dstb->cmin = bb.cmin; dstb->cmax = bb.cmax;
-        }
+    const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
+    const int plane = rd.H * rd.W;
+    const int64_t g0 = (int64_t)e * ra.A;
+    const int scn = ra.scn[e];
+    const int4 sc = reinterpret_cast<const int4 *>(ra.scn_tab)[scn];            // map, wp_n, start_heading, pad
+    RasterJob J;
+    J.cell_word = ra.cell_word; J.cell_tri = ra.cell_tri; J.cell_cls2 = ra.cell_cls2;
+    J.m = ra.maps[sc.x];
+    J.stoplines = ra.stoplines + J.m.stop_base;
+    J.wp = ra.wp_xy + (int64_t)scn * ra.NW * 2;
+    J.lights = (ra.flags & TDE_F_TRAFFIC_LIGHTS) != 0 && J.m.n_stop > 0;
+    J.red = 0u;
+    if (J.lights) {
+        // the light state at the env's current step (oracle: tde_red_mask)
+        tde_world w{};
+        w.phases = ra.phases;
+        J.red = red_mask(w, J.m, ra.steps[e]);
     }
-    {
-        const int ti = st.target_idx[e], n_wp = sc.y;
-        for (int k = ti + (tid - kCullWp); k < n_wp && tid >= kCullWp; k += kRB - kCullWp) {
-            const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
-            const float tx = (float)t.x, ty = (float)t.y;
-            const float dx = tx - ex, dy = ty - ey, rr = rview + TDE_WAYPOINT_RADIUS;
-            if (dx * dx + dy * dy <= rr * rr) {
-                const int q = atomicAdd(&s_nwp, 1);
-                if (q < kRenderMaxWp) { s_wp[q] = make_float2(tx, ty); s_wpbb[q] = disc_span(tx, ty, TDE_WAYPOINT_RADIUS); }
-            }
-        }
-    }
-    if (lights && m.n_stop > 0) {
-        // stop lines of the map, coloured by the state of their light at the env's current step (oracle: tde_red_mask)
-        const uint32_t red = red_mask(w, m, st.steps[e]);
-        for (int q = tid - kCullStop; q < m.n_stop && tid >= kCullStop; q += kRB - kCullStop) {
-            const float4 la = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[0];
-            const float4 lb = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[1];   // hl, hw, light, -
-            const float dx = la.x - ex, dy = la.y - ey, rr = rview + (lb.x + lb.y);
-            if (dx * dx + dy * dy <= rr * rr) {
-                const int at = atomicAdd(&s_nstop, 1);
-                if (at < kRenderMaxStop) {
-                    const PixelSpan bb = box_span(la.x, la.y, la.z, la.w, lb.x, lb.y);
-                    RenderBox &d = s_stop[at];
-                    d.x = la.x; d.y = la.y; d.c = la.z; d.s = la.w; d.hl = lb.x; d.hw = lb.y;
-                    d.rmin = bb.rmin; d.rmax = bb.rmax; d.cmin = bb.cmin; d.cmax = bb.cmax;
-                    s_stopl[at] = ((red >> __float_as_int(lb.z)) & 1u) ? TDE_LAYER_STOP_RED : TDE_LAYER_STOP_GO;
-                }
-            }
-        }
-    }
-    // no barrier here: pass 1 does not read the lists, so the wavefronts without culling work start it at once and the
-    // few culling lanes' dependent loads hide behind it (the lists are complete at the barrier that ends pass 1)
-    uint8_t *lay8 = reinterpret_cast<uint8_t *>(s_layer);
-    uint16_t *lay16 = reinterpret_cast<uint16_t *>(s_layer);
-    const int Wq = W / 4;                                 // dwords per image row
-    auto pixel_world = [=](int r, int c, float &wx, float &wy) {
-        const float f = (halfH - ((float)r + 0.5f)) * res;
-        const float l = ((halfW - ((float)c + 0.5f)) * res) * lsign;
-        wx = (ex + f * ce) - l * se;
-        wy = (ey + f * se) + l * ce;
-    };
-    auto base_layer = [&](float wx, float wy) -> int {   // 1 on the drivable surface (within the threshold), else 0
-        const uint32_t wd = cell_lookup(w, m, wx, wy);
-        const uint32_t cls = wd & 3u;
-        bool road = cls == TDE_CELL_FULL;
-        if (cls == TDE_CELL_MIXED) {
-            const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
-            const int n = (int)((wd >> 2) & 255u);
-            for (int k = 0; k < n && !road; ++k) road = point_tri_d2_packed(wx, wy, recs + 3 * k) <= thr2;
-        }
-        return road ? 1 : 0;
-    };
-
-    {
-        // ---- pass 1: base layer of 2x2 blocks (four per thread: the four cell words are in flight together) -------
-        const int bw = W / 4, nblk = (H / 4) * bw;
-        const float rsub = 0.5f * 1.41421356f * res * 1.01f + 0.02f;     // pixel centres of a 2x2 block lie this close to its centre
-        for (int bi = tid; bi < nblk; bi += kRB) {
-            const int r0 = (bi / bw) * 4, c0 = (bi % bw) * 4;
-            uint32_t ws[4];
-#pragma unroll
-            for (int sb = 0; sb < 4; ++sb) {
-                const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
-                const float fs = (halfH - ((float)(r0 + dr) + 1.0f)) * res, ls = ((halfW - ((float)(c0 + dc) + 1.0f)) * res) * lsign;
-                ws[sb] = cell_lookup(w, m, (ex + fs * ce) - ls * se, (ey + fs * se) + ls * ce);
-            }
-            uint32_t need = 0;                                     // bit sb: the 2x2 sub-block needs the exact test
-#pragma unroll
-            for (int sb = 0; sb < 4; ++sb) {
-                const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
-                const uint32_t cs = ws[sb] & 3u;
-                if ((cs != TDE_CELL_MIXED) && (TDE_CLEARANCE_UNIT * (float)((ws[sb] >> 2) & 255u) >= rsub)) {
-                    const uint16_t v = (cs == TDE_CELL_FULL) ? (uint16_t)0x0101u : (uint16_t)0u;
-                    lay16[((r0 + dr) * W + c0 + dc) >> 1] = v;
-                    lay16[((r0 + dr + 1) * W + c0 + dc) >> 1] = v;
-                } else {
-                    need |= 1u << sb;
-                }
-            }
-            if (need) {
-                // queue the four pixels of every flagged sub-block: one LDS counter bump per thread, then two packed
-                // 32-bit stores (two 16-bit pixel ids each) per sub-block at its rank among the flagged ones - no
-                // per-pixel loop (the wavefront used to iterate max-over-lanes(popcount) = 16 times almost always)
-                const int n = 4 * __popc(need);
-                const int at = atomicAdd(&s_nwork, n);             // multiples of 4: the 32-bit stores stay aligned
-                if (at + n <= kRenderWork) {                       // (else: queue full, the view takes the all-pixels path)
-                    uint32_t *q32 = reinterpret_cast<uint32_t *>(s_work);
-#pragma unroll
-                    for (int sb = 0; sb < 4; ++sb) {
-                        if ((need >> sb) & 1u) {
-                            const int dr = (sb >> 1) * 2, dc = (sb & 1) * 2;
-                            const int rank = __popc(need & ((1u << sb) - 1u));
-                            const uint32_t p0 = (uint32_t)((r0 + dr) * W + c0 + dc), p1 = p0 + (uint32_t)W;
-                            q32[(at >> 1) + 2 * rank] = p0 | ((p0 + 1u) << 16);
-                            q32[(at >> 1) + 2 * rank + 1] = p1 | ((p1 + 1u) << 16);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const bool crowded = s_nbox > kRenderMaxBox || s_nwp > kRenderMaxWp || s_nstop > kRenderMaxStop;
-    const int nbox = crowded ? 0 : s_nbox, nwp = crowded ? 0 : s_nwp, nstop = crowded ? 0 : s_nstop;
-    const bool all_pixels = crowded || s_nwork > kRenderWork;
-    if (all_pixels) {
-        // rare fallback (more boxes / waypoints / edge pixels in view than the LDS lists hold): every pixel is shaded
-        // from the global tables, literally as the specification reads
-        const int ti = st.target_idx[e], n_wp = sc.y;
-        for (int pix = tid; pix < plane; pix += kRB) {
-            float wx, wy;
-            pixel_world(pix / W, pix % W, wx, wy);
-            int layer = base_layer(wx, wy);
-            if (lights) {
-                const uint32_t red = red_mask(w, m, st.steps[e]);
-                for (int q = 0; q < m.n_stop; ++q) {
-                    const float4 la = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[0];
-                    const float4 lb = reinterpret_cast<const float4 *>(w.stoplines + m.stop_base + q)[1];
-                    const float dx = wx - la.x, dy = wy - la.y;
-                    const float p = dx * la.z + dy * la.w, q2 = dy * la.z - dx * la.w;
-                    if (fabsf(p) <= lb.x && fabsf(q2) <= lb.y)
-                        layer = ((red >> __float_as_int(lb.z)) & 1u) ? TDE_LAYER_STOP_RED : TDE_LAYER_STOP_GO;
-                }
-            }
-            for (int k = ti; k < n_wp; ++k) {
-                const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + k];
-                const float dx = wx - (float)t.x, dy = wy - (float)t.y;
-                if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) layer = 2;
-            }
-            for (int a = A - 1; a >= 0; --a) {
-                const int64_t g = g0 + a;
-                if (!st.present[g]) continue;
-                float sa, ca;
-                sincos_f32(st.psi[g], sa, ca);
-                const float dx = wx - st.x[g], dy = wy - st.y[g];
-                const float p = dx * ca + dy * sa, q = dy * ca - dx * sa;
-                if (fabsf(p) <= 0.5f * st.len[g] && fabsf(q) <= 0.5f * st.wid[g]) layer = a ? TDE_LAYER_NPC : ego_layer;
-            }
-            lay8[pix] = (uint8_t)layer;
-        }
-    } else {
-        // ---- pass 2a: queued road-edge pixels: their own cell word; pixels in MIXED cells are compacted ... ---------
-        const int npix = s_nwork;
-        for (int base = 0; base < npix; base += 2 * kRB) {          // two pixels per thread and trip: both cell words in flight
-            int pix[2] = {0, 0};
-            uint32_t wd[2] = {0, 0};
-            bool have[2], defer[2] = {false, false};
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int wi = base + u * kRB + tid;
-                have[u] = wi < npix;
-                if (have[u]) {
-                    pix[u] = s_work[wi];
-                    float wx, wy;
-                    pixel_world(pix[u] / W, pix[u] % W, wx, wy);
-                    wd[u] = cell_lookup(w, m, wx, wy);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (have[u]) {
-                    const uint32_t cls = wd[u] & 3u;
-                    if (cls == TDE_CELL_MIXED) defer[u] = true;
-                    else lay8[pix[u]] = (cls == TDE_CELL_FULL) ? 1 : 0;
-                }
-            }
-            __syncthreads();                                  // every lane has read its entries of this chunk:
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (defer[u]) {                               // the compacted list may overwrite them
-                    const int at = atomicAdd(&s_nmixed, 1);
-                    if (at < kRenderMixed) {
-                        s_work[at] = (uint16_t)pix[u];
-                        s_mixed[at] = wd[u];                  // its cell word travels along: no second lookup
-                    } else {                                  // list full (never seen on the synthetic maps): resolve in place
-                        float wx, wy;
-                        pixel_world(pix[u] / W, pix[u] % W, wx, wy);
-                        lay8[pix[u]] = (uint8_t)base_layer(wx, wy);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // ---- pass 2b: ... and get their candidate-triangle tests here, densely.  Two candidate records are fetched per
-        // trip before either is tested: the loop is a chain of dependent L2 round trips (one per candidate), and two in
-        // flight halve it; the second test runs only when the first did not already settle the pixel.
-        const int nmixed = min(s_nmixed, kRenderMixed);
-        for (int wi = tid; wi < nmixed; wi += kRB) {
-            const int pix = s_work[wi];
-            const uint32_t wd = s_mixed[wi];
-            float wx, wy;
-            pixel_world(pix / W, pix % W, wx, wy);
-            const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(wd >> 10);
-            const int n = (int)((wd >> 2) & 255u);
-            bool road = false;
-            for (int k = 0; k < n && !road; k += 2) {
-                const float4 *r0 = recs + 3 * k, *r1 = recs + 3 * (k + 1 < n ? k + 1 : k);
-                const float4 a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
-                const float4 ta[3] = {a0, a1, a2};
-                road = point_tri_d2_packed(wx, wy, ta) <= thr2;
-                if (!road && k + 1 < n) {
-                    const float4 tb[3] = {b0, b1, b2};
-                    road = point_tri_d2_packed(wx, wy, tb) <= thr2;
-                }
-            }
-            lay8[pix] = road ? 1 : 0;
-        }
-        __syncthreads();
-        // ---- pass 3: objects over the base, in layer order (waypoint discs, NPC boxes, the ego): the workgroup covers
-        // an object's conservative pixel span as a 16 x 16 tile of threads (one pixel per thread at 64 x 64) ------------
-        const int tr = tid >> 4, tc = tid & 15;       // a (kRB / 16) x 16 tile of threads walks an object's pixel span
-        constexpr int TR = kRB / 16;
-        for (int k = 0; k < nstop; ++k) {                     // stop lines lie on the road, under everything else
-            const RenderBox &b = s_stop[k];
-            const float bx = b.x, by = b.y, bc = b.c, bs = b.s, bhl = b.hl, bhw = b.hw;
-            const int rmax = b.rmax, cmin = b.cmin, cmax = b.cmax;
-            const uint8_t lay = s_stopl[k];
-            for (int r = b.rmin + tr; r <= rmax; r += TR)
-                for (int c = cmin + tc; c <= cmax; c += 16) {
-                    float wx, wy;
-                    pixel_world(r, c, wx, wy);
-                    const float dx = wx - bx, dy = wy - by;
-                    const float p = dx * bc + dy * bs, q = dy * bc - dx * bs;
-                    if (fabsf(p) <= bhl && fabsf(q) <= bhw) lay8[r * W + c] = lay;
-                }
-        }
-        if (nstop > 0) __syncthreads();
-        for (int k = 0; k < nwp; ++k) {
-            const PixelSpan b = s_wpbb[k];
-            const float2 t = s_wp[k];
-            for (int r = b.rmin + tr; r <= b.rmax; r += TR)
-                for (int c = b.cmin + tc; c <= b.cmax; c += 16) {
-                    float wx, wy;
-                    pixel_world(r, c, wx, wy);
-                    const float dx = wx - t.x, dy = wy - t.y;
-                    if (dx * dx + dy * dy <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS) lay8[r * W + c] = 2;
-                }
-        }
-        if (nwp > 0) __syncthreads();
-        for (int k = 0; k < nbox; ++k) {
-            const RenderBox &b = s_box[k];
-            const float bx = b.x, by = b.y, bc = b.c, bs = b.s, bhl = b.hl, bhw = b.hw;
-            const int rmax = b.rmax, cmin = b.cmin, cmax = b.cmax;
-            for (int r = b.rmin + tr; r <= rmax; r += TR)
-                for (int c = cmin + tc; c <= cmax; c += 16) {
-                    float wx, wy;
-                    pixel_world(r, c, wx, wy);
-                    const float dx = wx - bx, dy = wy - by;
-                    const float p = dx * bc + dy * bs, q = dy * bc - dx * bs;
-                    if (fabsf(p) <= bhl && fabsf(q) <= bhw) lay8[r * W + c] = 3;
-                }
-        }
-        if (nbox > 0) __syncthreads();
-        {
-            const float ehl = s_ego.hl, ehw = s_ego.hw;
-            const int rmax = s_ego.rmax, cmin = s_ego.cmin, cmax = s_ego.cmax;
-            for (int r = s_ego.rmin + tr; r <= rmax; r += TR)
-                for (int c = cmin + tc; c <= cmax; c += 16) {
-                    float wx, wy;
-                    pixel_world(r, c, wx, wy);
-                    const float dx = wx - ex, dy = wy - ey;
-                    const float p = dx * ce + dy * se, q = dy * ce - dx * se;
-                    if (fabsf(p) <= ehl && fabsf(q) <= ehw) lay8[r * W + c] = (uint8_t)ego_layer;
-                }
-        }
-    }
-    __syncthreads();
-
-    // ---- pass 4: layers -> colours, streamed out ---------------------------------------------------------------
-    // v_perm_b32 is a byte look-up in an 8-entry table: entries 0-4 the palette, 5 = TDE_LAYER_BLANK (0, 0, 0).
-    const uint32_t BG[3] = {TDE_RGB_BACKGROUND}, ROAD[3] = {TDE_RGB_ROAD}, WP[3] = {TDE_RGB_WAYPOINT},
-                   NPC[3] = {TDE_RGB_NPC}, EGO[3] = {TDE_RGB_EGO}, SRED[3] = {TDE_RGB_STOP_RED}, SGO[3] = {TDE_RGB_STOP_GO};
-    auto expand = [&](const uint4 &v, uint8_t *frame, int i) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const uint32_t lo = BG[ch] | (ROAD[ch] << 8) | (WP[ch] << 16) | (NPC[ch] << 24);
-            const uint32_t hi = EGO[ch] | (SRED[ch] << 16) | (SGO[ch] << 24);          // entry 5 = TDE_LAYER_BLANK = 0
-            uint4 o;
-            o.x = __builtin_amdgcn_perm(hi, lo, v.x); o.y = __builtin_amdgcn_perm(hi, lo, v.y);
-            o.z = __builtin_amdgcn_perm(hi, lo, v.z); o.w = __builtin_amdgcn_perm(hi, lo, v.w);
-            // streaming stores: the observation is consumed by the policy, not by this kernel (n_stack 3: 150 -> 95 us)
-            uint4 *dstp = reinterpret_cast<uint4 *>(frame + ch * plane) + i;
-            store_nt16(dstp, o);
-        }
-    };
-    const uint4 *src = reinterpret_cast<const uint4 *>(s_layer);
-    const int nv = plane / 16;
-    const bool fresh = rd.fresh && (rd.fresh[e] & 3);   // the episode of this view just (re)started: older frames are blank
-    if (ns > 1 && rd.layers) {
-        // frame stack from the ring of layer planes: slot of the new frame = phase % ns; output frame j (oldest first)
-        // is ring slot (phase + 1 + j) % ns.  Nothing is shifted: every frame of `out` is written from its layer plane.
-        uint8_t *ring = rd.layers + (int64_t)e * ns * plane;
-        const int slot_new = rd.phase % ns;
-        for (int i = tid; i < nv; i += kRB) {
-            const uint4 v = src[i];
-            reinterpret_cast<uint4 *>(ring + (int64_t)slot_new * plane)[i] = v;
-            expand(v, out + 3 * (ns - 1) * plane, i);
-        }
-        const uint32_t bl = TDE_LAYER_BLANK * 0x01010101u;
-        for (int j = 0; j < ns - 1; ++j) {
-            const int slot = (rd.phase + 1 + j) % ns;
-            uint4 *old = reinterpret_cast<uint4 *>(ring + (int64_t)slot * plane);
-            for (int i = tid; i < nv; i += kRB) {
-                uint4 v;
-                if (fresh) { v = make_uint4(bl, bl, bl, bl); old[i] = v; }     // VecFrameStack: the stack restarts blank
-                else v = old[i];
-                expand(v, out + 3 * j * plane, i);
-            }
-        }
-    } else {
-        for (int i = tid; i < nv; i += kRB) expand(src[i], out + 3 * (ns - 1) * plane, i);
-        if (fresh && ns > 1) {                       // in-place stack (no ring): blank the older frames of this view
-            uint4 *o4 = reinterpret_cast<uint4 *>(out);
-            for (int i = tid; i < 3 * (ns - 1) * nv; i += kRB) o4[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
+    J.n_wp = sc.y; J.ti = ra.target_idx[e]; J.A = ra.A;
+    J.ex = ra.x[g0]; J.ey = ra.y[g0];
+    sincos_f32(ra.psi[g0], J.se, J.ce);
+    J.H = rd.H; J.W = rd.W; J.ns = ns; J.phase = rd.phase; J.flags = rd.flags;
+    J.res = rd.fov / (float)rd.W; J.inv_res = 1.0f / J.res; J.thr2 = ra.thr2;
+    J.K8 = ra.K8; J.K4 = ra.K4;
+    J.out = rd.out + (int64_t)e * 3 * ns * plane;
+    J.ring = rd.layers ? rd.layers + (int64_t)e * ns * plane : nullptr;
+    J.fresh = rd.fresh && (rd.fresh[e] & 3);       // the episode of this view just (re)started: older frames are blank
+    raster_view<SIZE>(S, J, StateAgents{ra.x, ra.y, ra.psi, ra.len, ra.wid, ra.present, g0});
 }
 
 }  // namespace tde
@@ -2807,9 +2419,11 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     int rc = check_env_args("tde_render_ego", cfg, world, st);
     if (rc) return rc;
     if (!rd || !rd->out) return bad("tde_render_ego: render/out is NULL");
+    // (the layer plane in LDS holds the image rounded up to multiples of 8 in both directions)
     if (rd->H <= 0 || rd->W <= 0 || (rd->W % 4) != 0 || (rd->H % 4) != 0 || (rd->H * rd->W) % 16 != 0 ||
-        rd->H * rd->W > tde::kRenderMaxPix)
-        return bad("tde_render_ego: H and W must be positive multiples of 4 with H*W <= 4096");
+        ((rd->H + 7) & ~7) * ((rd->W + 7) & ~7) > tde::kRasterMaxPix || rd->H > 256 || rd->W > 256)
+        return bad("tde_render_ego: H and W must be positive multiples of 4 (at most 256) whose product, each rounded up "
+                   "to a multiple of 8, is <= 4096");
     if (rd->phase < 0) return bad("tde_render_ego: phase must be >= 0 (keep it reduced modulo n_stack)");
     if (st->B <= 0) return 0;
     if (rd->n_stack > 1 && !rd->layers && !rd->only)       // (a masked call re-renders the newest frame in place)
@@ -2822,7 +2436,11 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     ra.rd = *rd;
     ra.thr2 = cfg->offroad_threshold_squared ? cfg->offroad_threshold : cfg->offroad_threshold * cfg->offroad_threshold;
     ra.flags = cfg->flags; ra.NW = world->NW; ra.A = st->A;
-    tde::render_layers_kernel<<<st->B, tde::kRB, 0, (hipStream_t)stream>>>(ra);
+    const float res = rd->fov / (float)rd->W;
+    ra.K8 = tde::raster_block_clearance(8, res); ra.K4 = tde::raster_block_clearance(4, res);
+    ra.cell_cls2 = world->cell_cls2;
+    if (rd->H == 64 && rd->W == 64) tde::render_views_kernel<64><<<st->B, tde::kWave, 0, (hipStream_t)stream>>>(ra);
+    else tde::render_views_kernel<0><<<st->B, tde::kWave, 0, (hipStream_t)stream>>>(ra);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
 }

@@ -23,8 +23,25 @@ GRID_TILE = 8
 
 
 def row_shift_of(nx):
-    """log2 of the row pitch the cell words of an nx-cell-wide grid are stored with (next power of two >= nx)"""
-    return max(0, int(nx) - 1).bit_length()
+    """log2 of the row pitch the cell words of an nx-cell-wide grid are stored with (next power of two >= nx, at least 32:
+    the 2-bit class tiles are 32 cells wide)"""
+    return max(5, max(0, int(nx) - 1).bit_length())
+
+
+CLS2_TILE_W, CLS2_TILE_H = 32, 16          # cells per 128-byte tile of tde_world.cell_cls2
+
+
+def class_tiles(cls, nx, ny):
+    """cell classes [ny * nx] -> uint32 words of the 2-bit class map in 32 x 16-cell tiles (tde_abi.h: cell_cls2); the
+    padding holds EMPTY cells.  Returns (words, number of tiles)."""
+    pitch = 1 << row_shift_of(nx)
+    tx, ty = pitch // CLS2_TILE_W, -(-ny // CLS2_TILE_H)
+    full = np.full((ty * CLS2_TILE_H, pitch), _abi.CELL_EMPTY, dtype=np.uint32)
+    full[:ny, :nx] = np.asarray(cls, dtype=np.uint32).reshape(ny, nx)
+    # 16 cells -> one word, cell ix at bits 2 * (ix & 15)
+    w = (full.reshape(ty * CLS2_TILE_H, pitch // 16, 16) << (2 * np.arange(16, dtype=np.uint32))[None, None]).sum(2)
+    w = w.astype(np.uint32).reshape(ty, CLS2_TILE_H, tx, 2)                 # [tile row][row in tile][tile col][word]
+    return np.ascontiguousarray(w.transpose(0, 2, 1, 3)).reshape(-1), tx * ty
 
 
 def pitch_cells(a, nx, ny):
@@ -147,6 +164,57 @@ def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4
     start[1:] = np.cumsum(counts)
     return dict(ox=ox, oy=oy, cell=float(cell), nx=nx, ny=ny, cell_class=cls, cell_start=start,
                 cell_tris=pt.astype(np.int32))
+
+
+# MIXED cells are split once more: SUB x SUB sub-cells, each with a 2-bit class of its own (EMPTY / MIXED / FULL) packed
+# into one word, bits 2 * (sy * SUB + sx), stored in pad word 9 of the cell's FIRST candidate record (cell_tri).  The
+# rasteriser resolves most pixels of a MIXED cell from it without a triangle test (the band of truly undecided points
+# shrinks from ~0.6 m to ~0.15 m around the road edge at 0.25 m cells).  SUB_MARGIN absorbs the fp32 evaluation of the
+# sub-cell coordinate and of the distances (both ~1e-4 m at |coordinates| of a few hundred metres).
+SUB = 4
+SUB_MARGIN = 0.002
+
+
+def subcell_classes(tri, g, threshold):
+    """uint32 per MIXED cell (in cell order): the classes of its SUB x SUB sub-cells.  Conservative like the cell classes:
+    a 3 x 3 lattice over the sub-cell grown by SUB_MARGIN, the 1-Lipschitz slack between lattice points and SUB_MARGIN
+    on both decisions; distances are taken to the cell's candidate triangles, which hold every triangle within
+    `threshold` (+ the cell margin) of any point of the cell."""
+    cell, nx = g["cell"], g["nx"]
+    cls = g["cell_class"]
+    start = g["cell_start"]
+    mixed = np.nonzero(cls == _abi.CELL_MIXED)[0]
+    if len(mixed) == 0:
+        return np.zeros(0, np.uint32)
+    counts = np.diff(start)[mixed]
+    row = np.repeat(np.arange(len(mixed)), counts)                      # candidate entry -> index into `mixed`
+    ent = np.concatenate([np.arange(start[c], start[c + 1]) for c in mixed]) if len(mixed) < 4096 else \
+        (np.repeat(start[mixed], counts) + (np.arange(counts.sum()) - np.repeat(np.cumsum(counts) - counts, counts)))
+    tri_of = g["cell_tris"][ent]
+    sub = cell / SUB
+    h = (sub + 2 * SUB_MARGIN) / 2.0
+    slack = h * math.sqrt(2.0) / 2.0
+    gl = np.array([-SUB_MARGIN, 0.5 * sub, sub + SUB_MARGIN])
+    # lattice offsets inside the cell: [SUB*SUB sub-cells][9 points][2]
+    lat = np.zeros((SUB * SUB, 9, 2))
+    for sy in range(SUB):
+        for sx in range(SUB):
+            xs, ys = np.meshgrid(sx * sub + gl, sy * sub + gl, indexing="xy")
+            lat[sy * SUB + sx] = np.stack([xs.ravel(), ys.ravel()], -1)
+    lat = lat.reshape(-1, 2)
+    dmin = np.full((len(mixed), lat.shape[0]), np.inf)
+    CH = 100_000
+    for s0 in range(0, len(row), CH):
+        r_, t_ = row[s0:s0 + CH], tri_of[s0:s0 + CH]
+        c_ = mixed[r_]
+        org = np.stack([g["ox"] + (c_ % nx) * cell, g["oy"] + (c_ // nx) * cell], -1)
+        d = _pairs_point_tri_dist(org[:, None, :] + lat[None], tri[t_])
+        np.minimum.at(dmin, r_, d)
+    dm = dmin.reshape(len(mixed), SUB * SUB, 9)
+    full = (dm <= (threshold - SUB_MARGIN) - slack).all(2)
+    empty = (dm > (threshold + SUB_MARGIN) + slack).all(2)
+    code = np.where(full, _abi.CELL_FULL, np.where(empty, _abi.CELL_EMPTY, _abi.CELL_MIXED)).astype(np.uint32)
+    return (code << (2 * np.arange(SUB * SUB, dtype=np.uint32))[None]).sum(1).astype(np.uint32)
 
 
 CLEARANCE_UNIT = 0.125   # metres per count of the clearance field
@@ -351,8 +419,8 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
     lights = lights or [None] * len(meshes)
     stop_all, phase_all = [], []
     maps = np.zeros(len(meshes), dtype=_abi.MAP_DTYPE)
-    tri_all, word_all, rec_all = [], [], []
-    tri_base = cell_base = rec_base = 0
+    tri_all, word_all, rec_all, cls2_all = [], [], [], []
+    tri_base = cell_base = rec_base = cls2_base = 0
     for m, tri in enumerate(meshes):
         tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
         # the kernels see fp32 vertices: index the fp32-rounded mesh
@@ -370,7 +438,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
                 phase_all.append((cycle, sum(1 << int(i) for i in red)))
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
                    tri_base, len(tri), len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle,
-                   row_shift_of(g["nx"]), 0)
+                   row_shift_of(g["nx"]), cls2_base)
         packed = pack_triangles(tri32)
         counts = np.diff(g["cell_start"]).astype(np.int64)
         # FULL / EMPTY cells carry no candidate list: their count field holds a clearance instead (quarter metres,
@@ -382,7 +450,14 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         assert start.max(initial=0) < (1 << 22), "grid index too large for the 22-bit record offset"
         word_all.append(pitch_cells((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
                                     (start.astype(np.uint32) << 10)).astype(np.uint32), g["nx"], g["ny"]))
-        rec_all.append(packed[g["cell_tris"]])          # per-cell copies: one dependent load less in the kernel
+        recs = packed[g["cell_tris"]]                   # per-cell copies: one dependent load less in the kernel
+        mixed = np.nonzero(g["cell_class"] == _abi.CELL_MIXED)[0]
+        if len(mixed):                                  # sub-cell classes ride in pad word 9 of a cell's first record
+            recs[g["cell_start"][mixed], 9] = subcell_classes(tri32.astype(np.float64), g, threshold).view(np.float32)
+        rec_all.append(recs)
+        c2, ntile = class_tiles(g["cell_class"], g["nx"], g["ny"])
+        cls2_all.append(c2)
+        cls2_base += ntile
         tri_all.append(tri32.reshape(-1, 6))
         tri_base += len(tri)
         cell_base += (1 << row_shift_of(g["nx"])) * g["ny"]
@@ -428,6 +503,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         replay_states[i, :len(r)] = r
     rec_cat = np.concatenate(rec_all, 0) if rec_base else np.zeros((1, 12), np.float32)
     arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_word=np.concatenate(word_all), cell_tri=rec_cat,
+                  cell_cls2=np.concatenate(cls2_all),
                   scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states,
                   stoplines=np.asarray(stop_all, dtype=_abi.STOPLINE_DTYPE) if stop_all
                   else np.zeros(1, _abi.STOPLINE_DTYPE),
