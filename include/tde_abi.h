@@ -145,15 +145,17 @@ typedef struct tde_world {
                                    cells: bits 2-9 clearance in units of TDE_CLEARANCE_UNIT (every point that close to the cell
                                    lies in a cell of the same class) */
     const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
-                                   ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,sub,0,0
-                                   sub (ABI 7; only in the FIRST record of a MIXED cell, as a uint32 bit pattern): 2-bit
-                                   TDE_CELL_* class of each of the cell's 4 x 4 sub-cells, sub-cell (sx, sy) at bits
-                                   2 * (4 * sy + sx); conservative like the cell classes (2 mm margin) */
+                                   ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 */
     const uint32_t *cell_cls2;  /* (ABI 7, rasteriser) the cell classes alone, 2 bits per cell, in 128-byte tiles of 32 x 16 cells
                                    (8 m x 4 m at 0.25 m cells: a 35 m view touches ~50 cache lines of it, against one line per
                                    look-up in cell_word).  Tile (tx, ty) = cells [32 tx, 32 tx + 32) x [16 ty, 16 ty + 16) of a
                                    map is tile cls2_base + (ty << (row_shift - 5)) + tx; inside a tile word 2 * (iy & 15) +
                                    ((ix >> 4) & 1) holds the 16 cells ix & ~15 .. of row iy, cell ix at bits 2 * (ix & 15) */
+    const uint32_t *cell_sub;   /* (ABI 7, rasteriser) one word per cell, meaningful for MIXED cells: the 2-bit TDE_CELL_* class
+                                   of each of the cell's 4 x 4 sub-cells, sub-cell (sx, sy) at bits 2 * (4 * sy + sx),
+                                   conservative like the cell classes (2 mm margin).  Same number of words per map as
+                                   cell_word, in 128-byte tiles of 8 x 4 cells: cell (ix, iy) at
+                                   cell_base + ((((iy >> 2) << (row_shift - 3)) + (ix >> 3)) << 5) + ((iy & 3) << 3) + (ix & 7) */
     const tde_scenario *scn;    /* [S] */
     const double *wp_xy;        /* [S][NW][2] ego waypoints, float64 like the YAML lists (gym_env.py:314,394) */
     const tde_spawn *spawn;     /* [S][A] */

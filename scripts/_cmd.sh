@@ -1,5 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python scripts/ab_render.py torchdriveenv_amd/libtde_hip.so ab/libskip1.so ab/libskip2.so ab/libskip4.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_render_ablate4.txt
-python scripts/ab_render.py --agents 16 torchdriveenv_amd/libtde_hip.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_render_ablate4.txt
-python scripts/ab_render.py --lights torchdriveenv_amd/libtde_hip.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_render_ablate4.txt
-python scripts/ab_render.py --stack 3 torchdriveenv_amd/libtde_hip.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r03_render_ablate4.txt
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python scripts/ab_render.py ab/libvpw8.so torchdriveenv_amd/libtde_hip.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_render_qorder.txt

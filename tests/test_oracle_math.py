@@ -102,7 +102,8 @@ def grid_offroad_numpy(world, map_id, px, py, thr, use_sub=False):
             out[i] = cls == _abi.CELL_EMPTY
             continue
         if use_sub:                                        # sub-cell classes of the MIXED cell (world.py: subcell_classes)
-            bm = int(recs[wd >> 10, 9:10].view(np.uint32)[0])
+            tile = ((iy >> 2) << (int(m["row_shift"]) - 3)) + (ix >> 3)
+            bm = int(world.arrays["cell_sub"][m["cell_base"] + ((tile << 5) | ((iy & 3) << 3) | (ix & 7))])
             sx, sy = min(int((fx - f(ix)) * f(4)), 3), min(int((fy - f(iy)) * f(4)), 3)
             sc = (bm >> (2 * (4 * sy + sx))) & 3
             if sc != _abi.CELL_MIXED:

@@ -74,7 +74,7 @@ SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("
 SCN_DTYPE = np.dtype([("map", "i4"), ("wp_n", "i4"), ("start_heading", "f4"), ("_pad0", "i4")])
 assert SPAWN_DTYPE.itemsize == 64 and SCN_DTYPE.itemsize == 16
 
-WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "cell_cls2", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
+WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "cell_cls2", "cell_sub", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
               "stoplines", "phases"]
 WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT"]
 
@@ -158,7 +158,7 @@ def default_config(**over):
 
 
 WORLD_DTYPES = {
-    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "cell_cls2": np.uint32, "scn": SCN_DTYPE,
+    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "cell_cls2": np.uint32, "cell_sub": np.uint32, "scn": SCN_DTYPE,
     "wp_xy": np.float64, "spawn": SPAWN_DTYPE, "route_xy": np.float32, "replay_states": np.float32,
     "stoplines": STOPLINE_DTYPE, "phases": PHASE_DTYPE,
 }

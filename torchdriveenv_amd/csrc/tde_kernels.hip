@@ -2116,7 +2116,7 @@ struct RenderArgs {
     float thr2;
     uint32_t flags;
     int32_t NW, A;
-    const uint32_t *cell_cls2;
+    const uint32_t *cell_cls2, *cell_sub;
     int32_t K8, K4;                     // raster_block_clearance(8 / 4, res)
 };
 
@@ -2144,13 +2144,22 @@ struct StateAgents {
 #ifndef TDE_RENDER_SGPRS
 #define TDE_RENDER_SGPRS 80
 #endif
+// TDE_RENDER_VPW views per workgroup, one wavefront each (they share nothing: no barrier): fewer, larger workgroups for the
+// dispatcher to place
+#ifndef TDE_RENDER_VPW
+#define TDE_RENDER_VPW 4
+#endif
+constexpr int kViewsPerGroup = TDE_RENDER_VPW;
 template <int SIZE>   // 64: 64 x 64 images (the reference's observation; every stride a constant); 0: rd.H x rd.W
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(TDE_RENDER_WAVES, TDE_RENDER_WAVES), amdgpu_num_sgpr(TDE_RENDER_SGPRS)))
-void render_views_kernel(RenderArgs ra)
+__global__ __launch_bounds__(kWave * kViewsPerGroup) __attribute__((amdgpu_waves_per_eu(TDE_RENDER_WAVES, TDE_RENDER_WAVES), amdgpu_num_sgpr(TDE_RENDER_SGPRS)))
+void render_views_kernel(RenderArgs ra, int B)
 {
-    __shared__ RasterScratch S;
+    __shared__ RasterScratch Sall[kViewsPerGroup];
     const tde_render &rd = ra.rd;
-    const int e = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RasterScratch &S = Sall[wv];
+    const int e = blockIdx.x * kViewsPerGroup + wv;
+    if (e >= B) return;
     if (rd.only && !rd.only[e]) return;            // masked call: this view keeps its pixels and its ring
     const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
     const int plane = rd.H * rd.W;
@@ -2158,7 +2167,7 @@ void render_views_kernel(RenderArgs ra)
     const int scn = ra.scn[e];
     const int4 sc = reinterpret_cast<const int4 *>(ra.scn_tab)[scn];            // map, wp_n, start_heading, pad
     RasterJob J;
-    J.cell_word = ra.cell_word; J.cell_tri = ra.cell_tri; J.cell_cls2 = ra.cell_cls2;
+    J.cell_word = ra.cell_word; J.cell_tri = ra.cell_tri; J.cell_cls2 = ra.cell_cls2; J.cell_sub = ra.cell_sub;
     J.m = ra.maps[sc.x];
     J.stoplines = ra.stoplines + J.m.stop_base;
     J.wp = ra.wp_xy + (int64_t)scn * ra.NW * 2;
@@ -2438,9 +2447,10 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     ra.flags = cfg->flags; ra.NW = world->NW; ra.A = st->A;
     const float res = rd->fov / (float)rd->W;
     ra.K8 = tde::raster_block_clearance(8, res); ra.K4 = tde::raster_block_clearance(4, res);
-    ra.cell_cls2 = world->cell_cls2;
-    if (rd->H == 64 && rd->W == 64) tde::render_views_kernel<64><<<st->B, tde::kWave, 0, (hipStream_t)stream>>>(ra);
-    else tde::render_views_kernel<0><<<st->B, tde::kWave, 0, (hipStream_t)stream>>>(ra);
+    ra.cell_cls2 = world->cell_cls2; ra.cell_sub = world->cell_sub;
+    const unsigned ng = (unsigned)((st->B + tde::kViewsPerGroup - 1) / tde::kViewsPerGroup);
+    if (rd->H == 64 && rd->W == 64) tde::render_views_kernel<64><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
+    else tde::render_views_kernel<0><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
 }

@@ -68,6 +68,7 @@ struct RasterJob {
     const uint32_t *cell_word;
     const float *cell_tri;
     const uint32_t *cell_cls2;
+    const uint32_t *cell_sub;
     const tde_stopline *stoplines;               // of the env's map (already offset by stop_base)
     const double *wp;                            // waypoints of the env's scenario
     tde_map m;
@@ -152,11 +153,13 @@ TDE_DEV uint32_t raster_lookup(const RasterJob &J, const RasterView &V, float u,
     return raster_lookup(J, V, u, v, fx, fy);
 }
 
-// class of the sub-cell of a MIXED cell that holds cell coordinates (fx, fy): two bits of the bitmap kept in pad word 9 of
-// the cell's first candidate record (tde_abi.h: tde_world.cell_tri; world.py: subcell_classes)
-TDE_DEV uint32_t subcell_class(const RasterJob &J, uint32_t wd, float fx, float fy)
+// class of the sub-cell of a MIXED cell that holds the clamped cell coordinates (fx, fy): two bits of the cell's word in
+// the tiled sub-cell array (tde_abi.h: tde_world.cell_sub; world.py: subcell_classes)
+TDE_DEV uint32_t subcell_class(const RasterJob &J, float fx, float fy)
 {
-    const uint32_t bm = __float_as_uint(reinterpret_cast<const float4 *>(J.cell_tri)[3 * (size_t)(wd >> 10) + 2].y);
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+    const uint32_t tile = ((iy >> 2) << (J.m.row_shift - 3)) + (ix >> 3);
+    const uint32_t bm = J.cell_sub[(uint32_t)J.m.cell_base + ((tile << 5) | (((iy & 3u) << 3) | (ix & 7u)))];
     const int sx = min((int)(__builtin_amdgcn_fractf(fx) * (float)TDE_CELL_SUB), TDE_CELL_SUB - 1);
     const int sy = min((int)(__builtin_amdgcn_fractf(fy) * (float)TDE_CELL_SUB), TDE_CELL_SUB - 1);
     return (bm >> (2 * (sy * TDE_CELL_SUB + sx))) & 3u;
@@ -313,14 +316,20 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
                 }
             }
         }
-        // ---- list the 4x4 blocks that straddle a road edge (ballot / mbcnt compaction, one bit of need1 per round) -----
-        int nq = 0;
+        // ---- list the 4x4 blocks that straddle a road edge, lane by lane (the blocks of one 8x8 parent stay adjacent: the 64
+        // pixels of a trip then share two or three lines of the class map): wave prefix sum of popc(need1) (0..4) from the
+        // ballots of its three bits --------------------------------------------------------------------------------------
+        int nq;
+        {
+            const uint32_t n = (uint32_t)__popc(need1);
+            const unsigned long long b0 = __ballot((n & 1u) != 0u), b1 = __ballot((n & 2u) != 0u), b2 = __ballot((n & 4u) != 0u);
+            const int at = lane_prefix(b0) + 2 * lane_prefix(b1) + 4 * lane_prefix(b2);
+            nq = (int)__popcll(b0) + 2 * (int)__popcll(b1) + 4 * (int)__popcll(b2);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const bool f = (need1 >> s4) & 1u;
-            const unsigned long long fm = __ballot(f);
-            if (f) S.q.blockq[nq + lane_prefix(fm)] = (uint16_t)(((r8 + 4 * (s4 >> 1)) << 8) | (c8 + 4 * (s4 & 1)));
-            nq += (int)__popcll(fm);
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if ((need1 >> s4) & 1u)
+                    S.q.blockq[at + __popc(need1 & ((1u << s4) - 1u))] = (uint16_t)(((r8 + 4 * (s4 >> 1)) << 8) | (c8 + 4 * (s4 & 1)));
+            }
         }
         wave_phase();
         // ---- their pixels, 16 consecutive lanes per block (two blocks per lane and trip: both look-ups in flight): the
@@ -356,14 +365,13 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
                     const uint32_t px = S.q.mixq[i];
                     const int rr = (int)(px >> 8), cc = (int)(px & 255u);
                     const float u = V.hu - (float)rr, v = V.hv - (float)cc;
-                    float fx, fy;
-                    const uint32_t wm = raster_lookup(J, V, u, v, fx, fy);
-                    // (the class map said MIXED; should the two affine evaluations ever disagree by a cell, the word's own
-                    //  class decides - every cell within the margin of the point is a valid witness)
-                    uint32_t cm = wm & 3u;
-                    if (cm == TDE_CELL_MIXED) cm = subcell_class(J, wm, fx, fy);
+                    // the class of the pixel's sub-cell (its cell is MIXED: the same clamped cell coordinates gave the class
+                    // map's entry); only a pixel in a MIXED sub-cell needs the cell word and its candidate triangles
+                    const float fx = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cbx, __builtin_fmaf(u, V.cax, V.c0x)), 0.0f, V.nxm1);
+                    const float fy = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cby, __builtin_fmaf(u, V.cay, V.c0y)), 0.0f, V.nym1);
+                    const uint32_t cm = subcell_class(J, fx, fy);
                     bool road = cm == TDE_CELL_FULL;
-                    if (cm == TDE_CELL_MIXED) road = raster_mixed_pixel(J, V, u, v, wm);
+                    if (cm == TDE_CELL_MIXED) road = raster_mixed_pixel(J, V, u, v, raster_lookup(J, V, u, v));
                     p8[rr * Wp + cc] = (uint8_t)(road ? 1 : 0);
                 }
                 nmix = first;

@@ -31,6 +31,16 @@ def row_shift_of(nx):
 CLS2_TILE_W, CLS2_TILE_H = 32, 16          # cells per 128-byte tile of tde_world.cell_cls2
 
 
+def sub_tiles(a, nx, ny):
+    """row-major per-cell words [ny * nx] -> the same words in 8 x 4-cell tiles (tde_abi.h: cell_sub), as many as
+    pitch_cells() gives (ny is a multiple of GRID_TILE)"""
+    assert ny % 4 == 0
+    pitch = 1 << row_shift_of(nx)
+    full = np.zeros((ny, pitch), dtype=a.dtype)
+    full[:, :nx] = a.reshape(ny, nx)
+    return np.ascontiguousarray(full.reshape(ny // 4, 4, pitch // 8, 8).transpose(0, 2, 1, 3)).reshape(-1)
+
+
 def class_tiles(cls, nx, ny):
     """cell classes [ny * nx] -> uint32 words of the 2-bit class map in 32 x 16-cell tiles (tde_abi.h: cell_cls2); the
     padding holds EMPTY cells.  Returns (words, number of tiles)."""
@@ -167,7 +177,7 @@ def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4
 
 
 # MIXED cells are split once more: SUB x SUB sub-cells, each with a 2-bit class of its own (EMPTY / MIXED / FULL) packed
-# into one word, bits 2 * (sy * SUB + sx), stored in pad word 9 of the cell's FIRST candidate record (cell_tri).  The
+# into one word, bits 2 * (sy * SUB + sx), kept in a tiled per-cell array of its own (tde_world.cell_sub).  The
 # rasteriser resolves most pixels of a MIXED cell from it without a triangle test (the band of truly undecided points
 # shrinks from ~0.6 m to ~0.15 m around the road edge at 0.25 m cells).  SUB_MARGIN absorbs the fp32 evaluation of the
 # sub-cell coordinate and of the distances (both ~1e-4 m at |coordinates| of a few hundred metres).
@@ -419,7 +429,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
     lights = lights or [None] * len(meshes)
     stop_all, phase_all = [], []
     maps = np.zeros(len(meshes), dtype=_abi.MAP_DTYPE)
-    tri_all, word_all, rec_all, cls2_all = [], [], [], []
+    tri_all, word_all, rec_all, cls2_all, sub_all = [], [], [], [], []
     tri_base = cell_base = rec_base = cls2_base = 0
     for m, tri in enumerate(meshes):
         tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
@@ -450,11 +460,12 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         assert start.max(initial=0) < (1 << 22), "grid index too large for the 22-bit record offset"
         word_all.append(pitch_cells((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
                                     (start.astype(np.uint32) << 10)).astype(np.uint32), g["nx"], g["ny"]))
-        recs = packed[g["cell_tris"]]                   # per-cell copies: one dependent load less in the kernel
+        rec_all.append(packed[g["cell_tris"]])          # per-cell copies: one dependent load less in the kernel
+        sub = np.zeros(g["nx"] * g["ny"], np.uint32)    # sub-cell classes of the MIXED cells, tiled 8 x 4 cells per line
         mixed = np.nonzero(g["cell_class"] == _abi.CELL_MIXED)[0]
-        if len(mixed):                                  # sub-cell classes ride in pad word 9 of a cell's first record
-            recs[g["cell_start"][mixed], 9] = subcell_classes(tri32.astype(np.float64), g, threshold).view(np.float32)
-        rec_all.append(recs)
+        if len(mixed):
+            sub[mixed] = subcell_classes(tri32.astype(np.float64), g, threshold)
+        sub_all.append(sub_tiles(sub, g["nx"], g["ny"]))
         c2, ntile = class_tiles(g["cell_class"], g["nx"], g["ny"])
         cls2_all.append(c2)
         cls2_base += ntile
@@ -503,7 +514,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         replay_states[i, :len(r)] = r
     rec_cat = np.concatenate(rec_all, 0) if rec_base else np.zeros((1, 12), np.float32)
     arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_word=np.concatenate(word_all), cell_tri=rec_cat,
-                  cell_cls2=np.concatenate(cls2_all),
+                  cell_cls2=np.concatenate(cls2_all), cell_sub=np.concatenate(sub_all),
                   scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states,
                   stoplines=np.asarray(stop_all, dtype=_abi.STOPLINE_DTYPE) if stop_all
                   else np.zeros(1, _abi.STOPLINE_DTYPE),
