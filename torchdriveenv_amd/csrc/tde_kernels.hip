@@ -2125,19 +2125,25 @@ struct StateAgents {
     const float *x, *y, *psi, *len, *wid;
     const uint8_t *present;
     int64_t g0;
-    TDE_DEV bool operator()(int j, float &ox, float &oy, float &oc, float &os, float &hl, float &hw) const
+    struct Raw { float x, y, psi, len, wid; uint8_t present; };
+    TDE_DEV Raw fetch(int j) const
     {
         const int64_t g = g0 + j;
-        ox = x[g]; oy = y[g];
-        sincos_f32(psi[g], os, oc);
-        hl = 0.5f * len[g]; hw = 0.5f * wid[g];
-        return present[g] != 0;
+        return Raw{x[g], y[g], psi[g], len[g], wid[g], present[g]};
+    }
+    TDE_DEV bool unpack(const Raw &r, float &ox, float &oy, float &oc, float &os, float &hl, float &hw) const
+    {
+        ox = r.x; oy = r.y;
+        sincos_f32(r.psi, os, oc);
+        hl = 0.5f * r.len; hw = 0.5f * r.wid;
+        return r.present != 0;
     }
 };
 
-// Eight views (wavefronts) per SIMD: at most 64 VGPRs, 80 SGPRs and 5 KB of LDS per view.  8192 views are then ONE residency
-// round of the chip (32 per CU); at 23 per CU (7 KB of LDS, the first form of this kernel) the second round ran nearly
-// empty: 53 us against 33 for 4096 views (profiles/r03_a_render_scale_views.txt)
+// Eight views (wavefronts) per SIMD: at most 64 VGPRs, 80 SGPRs and 5 KB of LDS per view, so that 8192 views are ONE
+// residency round of the chip (32 per CU).  A view is bound by the latency of its chain of dependent memory round trips, so
+// the more views in flight the better: 7 per SIMD 47.6 us, 6 per SIMD 48.3, 8 per SIMD 44.4; two views per wavefront, one
+// after the other, 79 us (profiles/r03_b_render_views_per_wave.txt)
 #ifndef TDE_RENDER_WAVES
 #define TDE_RENDER_WAVES 8
 #endif
@@ -2158,9 +2164,13 @@ void render_views_kernel(RenderArgs ra, int B)
     const tde_render &rd = ra.rd;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     RasterScratch &S = Sall[wv];
-    const int e = blockIdx.x * kViewsPerGroup + wv;
+#ifndef TDE_RENDER_VPWAVE
+#define TDE_RENDER_VPWAVE 1
+#endif
+  for (int rep = 0; rep < TDE_RENDER_VPWAVE; ++rep) {
+    const int e = (blockIdx.x * kViewsPerGroup + wv) * TDE_RENDER_VPWAVE + rep;
     if (e >= B) return;
-    if (rd.only && !rd.only[e]) return;            // masked call: this view keeps its pixels and its ring
+    if (rd.only && !rd.only[e]) continue;          // masked call: this view keeps its pixels and its ring
     const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
     const int plane = rd.H * rd.W;
     const int64_t g0 = (int64_t)e * ra.A;
@@ -2189,6 +2199,7 @@ void render_views_kernel(RenderArgs ra, int B)
     J.ring = rd.layers ? rd.layers + (int64_t)e * ns * plane : nullptr;
     J.fresh = rd.fresh && (rd.fresh[e] & 3);       // the episode of this view just (re)started: older frames are blank
     raster_view<SIZE>(S, J, StateAgents{ra.x, ra.y, ra.psi, ra.len, ra.wid, ra.present, g0});
+  }
 }
 
 }  // namespace tde
@@ -2448,7 +2459,8 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     const float res = rd->fov / (float)rd->W;
     ra.K8 = tde::raster_block_clearance(8, res); ra.K4 = tde::raster_block_clearance(4, res);
     ra.cell_cls2 = world->cell_cls2; ra.cell_sub = world->cell_sub;
-    const unsigned ng = (unsigned)((st->B + tde::kViewsPerGroup - 1) / tde::kViewsPerGroup);
+    const int vpg = tde::kViewsPerGroup * TDE_RENDER_VPWAVE;
+    const unsigned ng = (unsigned)((st->B + vpg - 1) / vpg);
     if (rd->H == 64 && rd->W == 64) tde::render_views_kernel<64><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
     else tde::render_views_kernel<0><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
     hipError_t e = hipGetLastError();

@@ -25,6 +25,8 @@
 //     the fp32 world point by ~1e-4 m, which the 5 cm classification margin of the grid absorbs;
 //   * objects are culled to the view circle and painted over conservative pixel spans, in layer order.
 #pragma once
+#include <type_traits>
+
 #include "tde_device.h"
 
 namespace tde {
@@ -38,14 +40,14 @@ namespace tde {
 
 constexpr int kRasterMaxPix = 4096;              // padded H * W limit: the view is staged in LDS as one layer byte per pixel
 constexpr int kRasterBlockQ = 256;               // listed 4x4 blocks (an image has at most 256)
-constexpr int kRasterMixQ = 192;                 // pixels in MIXED cells awaiting their sub-cell class / triangle tests; 64
-                                                 // are processed whenever 64 are waiting (a trip appends <= 128)
+constexpr int kRasterMixQ = 384;                 // pixels in MIXED cells awaiting their sub-cell class / triangle tests (a trip
+                                                 // of the pixel stage appends <= 256: resolved early when that might not fit)
 constexpr int kRasterBatch = 16;                 // objects culled and painted per round (any number per view: rounds)
 
 // LDS of one view: 5120 B = 160 KiB / 32, i.e. eight wavefronts (views) per SIMD.  The queues of the base layer and the
 // object records of the paint passes are never live together.
 struct RasterQueues {
-    uint16_t blockq[kRasterBlockQ];              // (r0 << 8) | c0 of a 4x4 block
+    uint8_t blockq[kRasterBlockQ];               // index of a 4x4 block: (r0 / 4) * (padded W / 4) + c0 / 4
     uint16_t mixq[kRasterMixQ];                  // (r << 8) | c of a pixel
 };
 struct RasterObjects {
@@ -264,8 +266,8 @@ TDE_DEV void raster_expand(const uint4 &v, uint8_t *frame, int plane, int i)
     }
 }
 
-// One view by one wavefront; every lane of the wavefront calls it, converged.  `agent(j, x, y, c, s, hl, hw)` -> present:
-// pose and half extents of slot j of the env (slot 0 = the ego; an absent slot returns false).
+// One view by one wavefront; every lane of the wavefront calls it, converged.  `agent.fetch(j)` -> Raw (the loads of slot j of
+// the env, slot 0 = the ego), `agent.unpack(raw, x, y, c, s, hl, hw)` -> present: its pose and half extents.
 // SIZE: 64 = the image is 64 x 64 (the reference's observation, every stride a constant); 0 = J.H x J.W.
 template <int SIZE, typename AgentSrc>
 TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
@@ -282,7 +284,7 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
 
     // ---- base layer, 8x8 -> 4x4 -> 2x2 blocks -> pixels; lane b owns 8x8 block b ---------------------------------------
     {
-        const int nbw = Wp >> 3, nblk = (Hp >> 3) * nbw;                      // <= 64
+        const int nbw = Wp >> 3, nblk = (Hp >> 3) * nbw, nb4w = Wp >> 2;      // nblk <= 64
         const bool have = lane < nblk;
         const int br = SIZE ? lane >> 3 : (have ? lane / nbw : 0), bc = SIZE ? lane & 7 : (have ? lane - br * nbw : 0);
         const int r8 = br * 8, c8 = bc * 8;
@@ -328,55 +330,82 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if ((need1 >> s4) & 1u)
-                    S.q.blockq[at + __popc(need1 & ((1u << s4) - 1u))] = (uint16_t)(((r8 + 4 * (s4 >> 1)) << 8) | (c8 + 4 * (s4 & 1)));
+                    S.q.blockq[at + __popc(need1 & ((1u << s4) - 1u))] = (uint8_t)((2 * br + (s4 >> 1)) * nb4w + 2 * bc + (s4 & 1));
             }
         }
         wave_phase();
-        // ---- their pixels, 16 consecutive lanes per block (two blocks per lane and trip: both look-ups in flight): the
-        // class of the pixel's own cell; pixels in MIXED cells are compacted once more (mixq) and resolved 64 at a time:
-        // their cell word, the class of their sub-cell, and for what is still undecided the candidate triangles -----------
+        // A view under load is bound by the LATENCY of its chain of dependent memory round trips (8192 views in flight: a
+        // round trip costs 1 - 2 us; profiles/r03_b_render_views_per_wave.txt), so every stage below keeps as many
+        // independent look-ups in flight per lane as registers allow and the stages are few.
+        // ---- the pixels of the listed blocks, 16 consecutive lanes per block, kPx blocks per lane and trip: the class of
+        // the pixel's own cell; pixels in MIXED cells are compacted once more (mixq) ------------------------------------
+        constexpr int kPx = 4;
         int nmix = 0;
         const int nitems = (TDE_RASTER_SKIP & 2) ? 0 : 16 * nq;
-        for (int base = 0; base < nitems || nmix > 0; base += 128) {
-            bool act[2];
-            int r[2], c[2];
-            uint32_t cls[2];
+        // mixq entries [0, n): sub-cell classes, kPx entries per lane in flight; what is still undecided is compacted to
+        // the front of the queue and gets its cell word and candidate triangles, one pixel per lane
+        auto resolve_mixed = [&](int n) {
+            for (int base = 0; base < n; base += 64 * kPx) {
+                uint32_t px[kPx], cm[kPx];
+                bool act[kPx];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < kPx; ++h) {
+                    const int i = base + 64 * h + lane;
+                    act[h] = i < n;
+                    px[h] = S.q.mixq[act[h] ? i : 0];
+                    const float u = V.hu - (float)(px[h] >> 8), v = V.hv - (float)(px[h] & 255u);
+                    const float fx = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cbx, __builtin_fmaf(u, V.cax, V.c0x)), 0.0f, V.nxm1);
+                    const float fy = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cby, __builtin_fmaf(u, V.cay, V.c0y)), 0.0f, V.nym1);
+                    cm[h] = subcell_class(J, fx, fy);
+                }
+                wave_phase();                                     // every lane has read its entries: the front may be reused
+                int ns = 0;
+#pragma unroll
+                for (int h = 0; h < kPx; ++h) {
+                    const bool und = act[h] && cm[h] == TDE_CELL_MIXED;
+                    if (act[h] && !und) p8[(int)(px[h] >> 8) * Wp + (int)(px[h] & 255u)] = cm[h] == TDE_CELL_FULL ? 1 : 0;
+                    const unsigned long long um = __ballot(und);
+                    if (und) S.q.mixq[base + ns + lane_prefix(um)] = (uint16_t)px[h];      // (ns + prefix <= entries read so far)
+                    ns += (int)__popcll(um);
+                }
+                wave_phase();
+                for (int b2 = 0; b2 < ns; b2 += 64) {
+                    const int i = b2 + lane;
+                    if (i < ns) {
+                        const uint32_t q = S.q.mixq[base + i];
+                        const int rr = (int)(q >> 8), cc = (int)(q & 255u);
+                        const float u = V.hu - (float)rr, v = V.hv - (float)cc;
+                        p8[rr * Wp + cc] = (uint8_t)(raster_mixed_pixel(J, V, u, v, raster_lookup(J, V, u, v)) ? 1 : 0);
+                    }
+                }
+                wave_phase();
+            }
+        };
+        for (int base = 0; base < nitems; base += 64 * kPx) {
+            if (nmix > kRasterMixQ - 64 * kPx) { resolve_mixed(nmix); nmix = 0; }     // (room for a whole trip)
+            bool act[kPx];
+            int r[kPx], c[kPx];
+            uint32_t cls[kPx];
+#pragma unroll
+            for (int h = 0; h < kPx; ++h) {
                 const int item = base + 64 * h + lane;
                 act[h] = item < nitems;
-                const uint32_t blk = S.q.blockq[act[h] ? (item >> 4) : 0];
-                r[h] = (int)(blk >> 8) + ((item >> 2) & 3); c[h] = (int)(blk & 255u) + (item & 3);
+                const int blk = S.q.blockq[act[h] ? (item >> 4) : 0];
+                const int b4r = SIZE ? blk >> 4 : blk / nb4w, b4c = SIZE ? blk & 15 : blk - b4r * nb4w;
+                r[h] = 4 * b4r + ((item >> 2) & 3); c[h] = 4 * b4c + (item & 3);
                 cls[h] = raster_class(J, V, V.hu - (float)r[h], V.hv - (float)c[h]);
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < kPx; ++h) {
                 const bool mx = act[h] && cls[h] == TDE_CELL_MIXED;
                 if (act[h] && !mx) p8[r[h] * Wp + c[h]] = cls[h] == TDE_CELL_FULL ? 1 : 0;
                 const unsigned long long mm = __ballot(mx);
                 if (mx) S.q.mixq[nmix + lane_prefix(mm)] = (uint16_t)((r[h] << 8) | c[h]);
                 nmix += (int)__popcll(mm);
             }
-            const bool last = base + 128 >= nitems;
-            while (nmix >= 64 || (last && nmix > 0)) {
-                const int first = nmix > 64 ? nmix - 64 : 0;
-                const int i = first + lane;
-                if (i < nmix) {
-                    const uint32_t px = S.q.mixq[i];
-                    const int rr = (int)(px >> 8), cc = (int)(px & 255u);
-                    const float u = V.hu - (float)rr, v = V.hv - (float)cc;
-                    // the class of the pixel's sub-cell (its cell is MIXED: the same clamped cell coordinates gave the class
-                    // map's entry); only a pixel in a MIXED sub-cell needs the cell word and its candidate triangles
-                    const float fx = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cbx, __builtin_fmaf(u, V.cax, V.c0x)), 0.0f, V.nxm1);
-                    const float fy = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cby, __builtin_fmaf(u, V.cay, V.c0y)), 0.0f, V.nym1);
-                    const uint32_t cm = subcell_class(J, fx, fy);
-                    bool road = cm == TDE_CELL_FULL;
-                    if (cm == TDE_CELL_MIXED) road = raster_mixed_pixel(J, V, u, v, raster_lookup(J, V, u, v));
-                    p8[rr * Wp + cc] = (uint8_t)(road ? 1 : 0);
-                }
-                nmix = first;
-            }
         }
+        wave_phase();
+        resolve_mixed(nmix);
     }
     wave_phase();
 
@@ -401,6 +430,17 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
             km = __ballot(keep);
         }
     };
+    // the first 64 candidates of every kind are fetched together, ahead of the first use (one memory round trip instead of
+    // three on the view's chain)
+    float4 la0 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), lb0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (J.lights && lane < J.m.n_stop) {
+        la0 = reinterpret_cast<const float4 *>(J.stoplines + lane)[0];
+        lb0 = reinterpret_cast<const float4 *>(J.stoplines + lane)[1];
+    }
+    double2 wp0 = make_double2(0.0, 0.0);
+    if (J.ti + lane < J.n_wp) wp0 = reinterpret_cast<const double2 *>(J.wp)[J.ti + lane];
+    typename std::remove_reference<AgentSrc>::type::Raw raw0{};
+    if (lane < J.A) raw0 = agent.fetch(lane);
     if (J.lights) {
         for (int q0 = 0; q0 < J.m.n_stop; q0 += 64) {
             const int q = q0 + lane;
@@ -408,8 +448,11 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
             float4 P = make_float4(0.0f, 0.0f, 0.0f, 0.0f), Q = P;
             uint32_t span = 255u, lay = 0u;
             if (q < J.m.n_stop) {
-                const float4 la = reinterpret_cast<const float4 *>(J.stoplines + q)[0];
-                const float4 lb = reinterpret_cast<const float4 *>(J.stoplines + q)[1];           // hl, hw, light, -
+                float4 la = la0, lb = lb0;                                                        // hl, hw, light, -
+                if (q0 > 0) {
+                    la = reinterpret_cast<const float4 *>(J.stoplines + q)[0];
+                    lb = reinterpret_cast<const float4 *>(J.stoplines + q)[1];
+                }
                 const float dx = la.x - J.ex, dy = la.y - J.ey, rr = rview + (lb.x + lb.y);
                 keep = dx * dx + dy * dy <= rr * rr;
                 box_coeffs(V, la.x, la.y, la.z, la.w, P, Q);
@@ -425,7 +468,8 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
         bool keep = false;
         float tx = 0.0f, ty = 0.0f;
         if (k < J.n_wp) {
-            const double2 t = reinterpret_cast<const double2 *>(J.wp)[k];
+            double2 t = wp0;
+            if (k0 > J.ti) t = reinterpret_cast<const double2 *>(J.wp)[k];
             tx = (float)t.x; ty = (float)t.y;
             const float dx = tx - J.ex, dy = ty - J.ey, rr = rview + TDE_WAYPOINT_RADIUS;
             keep = dx * dx + dy * dy <= rr * rr;
@@ -463,7 +507,7 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
     {
         // NPC boxes (slots 1 .. A-1; A <= 64), then the ego
         float x = 0.0f, y = 0.0f, cb = 1.0f, sb = 0.0f, hl = 0.0f, hw = 0.0f;
-        const bool pres = lane < J.A && agent(lane, x, y, cb, sb, hl, hw);
+        const bool pres = lane < J.A && agent.unpack(raw0, x, y, cb, sb, hl, hw);
         bool keep = false;
         if (pres && lane > 0) {
             const float dx = x - J.ex, dy = y - J.ey, rr = rview + (hl + hw);
