@@ -216,6 +216,10 @@ def main():
     ap.add_argument("--binding", default="ext", choices=["ext", "ctypes"],
                     help="step mode / config 5: launches through the PyTorch-ROCm C++ extension (default) or through "
                          "the ctypes binding of the same C-ABI")
+    ap.add_argument("--rollout-kernel", default=None, choices=["solo", "duo", "trio"],
+                    help="force a form of the rollout kernel (A/B runs; default: the library's choice by group shape)")
+    ap.add_argument("--step-kernel", default=None, choices=["solo", "trio"],
+                    help="force a form of the one-step kernel (A/B runs; default: the library's choice by batch size)")
     args = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,6 +263,7 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     _lib.load()
+    _lib.kernel_override(rollout=args.rollout_kernel, step=args.step_kernel)
 
     C = CONFIGS[args.config]
     B, A = (args.envs or C["envs"]), C["agents"]
@@ -382,17 +387,17 @@ def main():
         bpes = bytes_per_env_step(args.config, A)
         env_steps = B * n * total
         # dominant kernel: rollout = tde::env_rollout_trio_kernel<A> (drive + two judge wavefronts per 64 agent slots;
-        # TDE_ROLLOUT=duo|solo force the two- / one-wavefront forms), one launch per <= CH timesteps;
+        # --rollout-kernel duo|solo force the two- / one-wavefront forms), one launch per <= CH timesteps;
         # step mode = tde::env_step_kernel<A>; config 5 = step + tde::render_layers_kernel per timestep
         if args.config == 5:
             kernel = f"tde::env_step_kernel<{A}> + tde::render_layers_kernel"
         elif stepwise:
             trio = st["slot_cache"] is not None and A in (8, 16, 32) and (
-                os.environ.get("TDE_STEP") == "trio" or (os.environ.get("TDE_STEP") is None and B * A <= 65536))
+                args.step_kernel == "trio" or (args.step_kernel is None and B * A <= 65536))
             kernel = f"tde::env_step_trio_kernel<{A}, false, false>" if trio else f"tde::env_step_kernel<{A}, false, false>"
         else:
             team = {"solo": "", "duo": "_duo", "trio": "_trio"}.get(
-                os.environ.get("TDE_ROLLOUT", ""), "_trio" if A in (8, 16, 32) else "_duo")
+                args.rollout_kernel, "_trio" if A in (8, 16, 32) else "_duo")
             kernel = f"tde::env_rollout{team}_kernel<{A}, false>"
         # per-step-equivalent durations of the timed launches (a launch of k steps: its duration / k * spl)
         per = sorted(d / k * spl for d, k in zip(dur_us, lens)) if not stepwise else sorted(d / k for d, k in zip(dur_us, lens))

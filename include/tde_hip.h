@@ -28,6 +28,12 @@ TDE_API int tde_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 TDE_API const char *tde_last_error(void);
 
+/* Test / tuning hook (no reference counterpart): tde_env_rollout and tde_env_step each have several kernel forms (one, two
+ * or three wavefronts per 64 agent slots) and pick one by group shape and batch size; this forces a form for the calling
+ * process - 0 = automatic (default), rollout_team 1 | 2 | 3, step_team 1 | 3 - so that every form can be held against the
+ * oracle and A/B-timed.  A forced three-wavefront form still needs 8, 16 or 32 agents per env. */
+TDE_API int tde_kernel_override(int rollout_team, int step_team);
+
 /* ---- operator level: the SimulatorInterface methods GymEnv calls ------------------------------------ */
 
 /* simulator.step(action) restricted to the kinematic model — KinematicBicycle.step for n agents.

@@ -3,7 +3,7 @@ launch): every library is dlopen'ed in THIS process and the launches alternate l
 state are shared.  Reports median / min / mean us per step over >= 40 launches per library.
 
     python scripts/ab_rollout.py [--envs 8192] [--agents 16] [--launches 40] [--lights] [--env NAME=VAL:lib] libA.so libB.so ...
-A library argument may be prefixed with rollout kernel choice, e.g. duo:path.so (sets TDE_ROLLOUT for that handle's
+A library argument may be prefixed with rollout kernel choice, e.g. duo:path.so (tde_kernel_override on that handle's
 first call; the choice is latched per library at first use)."""
 import argparse
 import ctypes as C
@@ -60,11 +60,9 @@ handles = []
 for spec in args.libs:
     mode, _, path = spec.rpartition(":")
     path = os.path.abspath(path)
-    if mode:
-        os.environ["TDE_ROLLOUT"] = mode
-    else:
-        os.environ.pop("TDE_ROLLOUT", None)
     L = C.CDLL(path)
+    if mode and hasattr(L, "tde_kernel_override"):              # (per loaded library copy: its own choice)
+        assert L.tde_kernel_override({"solo": 1, "duo": 2, "trio": 3}[mode], 0) == 0
     L.tde_env_rollout.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld), C.POINTER(_abi.TdeState),
                                   C.POINTER(_abi.TdeRollout), C.c_void_p]
     L.tde_env_reset.argtypes = [C.POINTER(_abi.TdeConfig), C.POINTER(_abi.TdeWorld), C.POINTER(_abi.TdeState),
@@ -76,7 +74,7 @@ for spec in args.libs:
         dw_tiled = dw_tiled or tiled_world(world).to_device(dev)
         wd = dw_tiled
     assert L.tde_env_reset(C.byref(cfg), C.byref(wd.struct), C.byref(st.struct), None, stream) == 0
-    for _ in range(2):                                          # warm-up; latches the TDE_ROLLOUT choice of this handle
+    for _ in range(2):                                          # warm-up; warm-up
         assert L.tde_env_rollout(C.byref(cfg), C.byref(wd.struct), C.byref(st.struct), C.byref(ro), stream) == 0
     torch.cuda.synchronize()
     handles.append((spec, L, st, [], wd))

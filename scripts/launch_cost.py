@@ -1,7 +1,8 @@
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
-from torchdriveenv_amd import _abi, ops
+from torchdriveenv_amd import _abi, _lib, ops
+_lib.kernel_override(step=os.environ.get('TDE_STEP'))   # (the scripts' own switch; the library reads no environment)
 from torchdriveenv_amd.state import EnvState
 from torchdriveenv_amd.synth import synthetic_world
 dev = torch.device("cuda:0")

@@ -4,8 +4,8 @@ O=gpurun_out/r01g; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 python bench.py --mode step --steps 4000 --warmup 500 --no-cpu-baseline > $O/bench_stepmode.json 2>> $O/bench.err
-TDE_ROLLOUT=solo python bench.py --no-cpu-baseline > $O/bench_solo.json 2>> $O/bench.err
-TDE_ROLLOUT=duo python bench.py --no-cpu-baseline > $O/bench_duo.json 2>> $O/bench.err
+python bench.py --rollout-kernel solo --no-cpu-baseline > $O/bench_solo.json 2>> $O/bench.err
+python bench.py --rollout-kernel duo --no-cpu-baseline > $O/bench_duo.json 2>> $O/bench.err
 python scripts/rollout_matrix.py > $O/rollout_matrix_default.txt 2>/dev/null
 TDE_ROLLOUT=duo python scripts/rollout_matrix.py > $O/rollout_matrix_duo.txt 2>/dev/null
 python scripts/ablate.py > $O/ablation.txt 2>/dev/null

@@ -2,7 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from torchdriveenv_amd import _abi, ops
+from torchdriveenv_amd import _abi, _lib, ops
+_lib.kernel_override(rollout=os.environ.get('TDE_ROLLOUT'))   # (the scripts' own switch; the library reads no environment)
 from torchdriveenv_amd.state import EnvState
 from torchdriveenv_amd.synth import synthetic_world
 

@@ -1,5 +1,7 @@
 """Turn the golden cases (tests/golden/reward_golden.json, produced by oracle/gen_golden.py from the reference's
 own gym_env.py) into flat per-step operator inputs and expected outputs."""
+import os
+
 import numpy as np
 
 from torchdriveenv_amd import _abi
@@ -42,3 +44,32 @@ def case_expected(case):
                 info=np.asarray([[x["psi_smoothness"], x["speed_smoothness"], x["psi_reward"], x["dist_reward"]]
                                  for x in s], np.float64),
                 is_success=np.asarray([x["is_success"] for x in s], np.uint8))
+
+
+def write_validation_suite_yaml(path):
+    """tests/golden/validation_suite.json (the data of the reference's five validation cases, oracle/gen_validation_fixture.py)
+    written back as a YAML file in the reference's WaypointSuite schema (ref env_utils.py:20-28), so that tests go through
+    `load_waypoint_suite_data` exactly as a user's file would"""
+    import json
+    import os
+
+    import yaml
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "validation_suite.json")) as f:
+        d = json.load(f)
+
+    def unpack(v):
+        return [list(v["row"]) for _ in range(v["repeat"])] if isinstance(v, dict) else v
+
+    d["car_sequence_suite"] = [None if c is None else {int(k): unpack(v) for k, v in c.items()} for c in d["car_sequence_suite"]]
+    for s in d["scenarios"]:
+        if s is not None:
+            s["recurrent_states"] = None
+    with open(path, "w") as f:
+        yaml.safe_dump(d, f)
+    return path
+
+
+# a background-traffic file in the reference's schema (made by oracle/gen_validation_fixture.py, not a reference file)
+BACKGROUND_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "background_traffic")

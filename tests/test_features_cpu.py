@@ -201,6 +201,13 @@ def test_lazy_infos_behave_like_a_list_of_dicts():
     assert infos.column("offroad") is cols["offroad"]
     with pytest.raises(IndexError):
         infos[3]
+    # what SB3's wrappers do in step_wait (VecNormalize / VecTransposeImage / VecFrameStack): rewrite an entry through
+    # infos[i][key] and read it back later - the same dict must come back on every access
+    infos[2]["terminal_observation"] = "rewritten"
+    assert infos[2]["terminal_observation"] == "rewritten" and infos[2] is infos[2]
+    infos[0] = {"replaced": 1}
+    assert infos[0] == {"replaced": 1} and [i.get("replaced") for i in infos] == [1, None, None]
+    assert infos.columns is cols and infos.terminal is term
 
 
 # The abstract interface of stable_baselines3.common.vec_env.base_vec_env.VecEnv (SB3 2.x): name -> parameter names.

@@ -282,20 +282,18 @@ def test_frame_stack_other_sizes_ring_and_in_place(small_world, H, W, n_stack):
 
 
 @pytest.mark.parametrize("mode", ["solo", "duo", "trio"])
-def test_every_rollout_kernel_matches_the_oracle(mode):
-    """tde_env_rollout picks a one-, two- or three-wavefront kernel by group shape; TDE_ROLLOUT forces one (read once
-    per process, hence the subprocess).  Each of them must reproduce the oracle bit for bit."""
-    import os
-    import subprocess
-    import sys
+def test_every_rollout_kernel_matches_the_oracle(mode, small_world):
+    """tde_env_rollout picks a one-, two- or three-wavefront kernel by group shape; tde_kernel_override forces one.  Each
+    of them must reproduce the oracle bit for bit (the parity module's rollout tests, run under the forced form)."""
+    from tests import test_gpu_parity as P
 
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TDE_ROLLOUT=mode)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
-                        "-m", "gpu", "-k", "rollout_matches or full_size or window_lengths"], env=env, cwd=ROOT, capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "passed" in r.stdout
+    _lib.kernel_override(rollout=mode)
+    try:
+        P.test_env_rollout_matches_oracle(small_world)
+        for (A, K, lights) in ((8, 37, False), (16, 50, True), (32, 21, False)):
+            P.test_env_rollout_other_agent_counts_and_window_lengths(A, K, lights)
+    finally:
+        _lib.kernel_override()
 
 
 def test_configs3_partitioning_at_full_size_on_one_gpu():

@@ -198,3 +198,53 @@ def test_step_writes_the_same_observation_as_state_obs(small_world, flags):
         ops.env_step(cfg, dw, st, action=a)
         want = ops.state_obs(dw, st)
         assert torch.equal(st["obs"], want), (t, int((st["obs"] != want).any(1).sum()))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
+def test_loader_built_validation_worlds_hip_vs_oracle(case, tmp_path):
+    """the reference's validation cases go load_waypoint_suite_data -> (pick_background_traffic) ->
+    world_from_waypoint_suite -> the HIP step, 200 steps of 64 envs with in-place re-spawns, against the oracle on the same
+    world: every state array and output bit for bit, and the birdview of the last step pixel for pixel.  Case 2 (Town03)
+    also takes background agents from a background-traffic file in the reference's schema (ref gym_env.py:200-235)."""
+    from tests.golden_util import BACKGROUND_DIR, write_validation_suite_yaml
+    from torchdriveenv_amd import ops
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+    from torchdriveenv_amd.loaders import load_waypoint_suite_data, pick_background_traffic
+
+    val = load_waypoint_suite_data(write_validation_suite_yaml(str(tmp_path / "validation_cases.yml")))
+    one = WaypointSuite(locations=val.locations[case:case + 1], waypoint_suite=val.waypoint_suite[case:case + 1],
+                        scenarios=val.scenarios[case:case + 1], car_sequence_suite=val.car_sequence_suite[case:case + 1])
+    bg = None
+    if case == 2:
+        bt = pick_background_traffic(one.locations[0], BACKGROUND_DIR)
+        assert bt is not None and len(bt["agent_states"]) == 24
+        bg = lambda loc: bt                                                   # noqa: E731
+    world = world_from_waypoint_suite(one, agents_per_env=8, background=bg, background_radius=250.0)
+    n_present = int(world.arrays["spawn"]["present"].sum())
+    if case == 2:
+        assert n_present == 8                                                 # ego + 2 scenario agents + 5 background agents
+    if case == 1:
+        assert world.arrays["spawn"][0, 1]["replay_len"] == 300              # the parked replay car
+    B, A, DEV = 64, 8, "cuda:0"
+    cfg = _abi.default_config(seed=5 + case, distance_cutoff=0.25, max_steps=60)
+    dw = world.to_device(DEV)
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    rng = np.random.default_rng(case)
+    for t in range(200):
+        # mostly forward with some steering noise: episodes end by truncation, by leaving the corridor and by collisions
+        act = np.stack([rng.uniform(0.0, 1.0, B), rng.normal(0.0, 0.05, B).clip(-0.3, 0.3)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(torch.from_numpy(act).to(DEV))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+        if t % 40 == 39 or t == 199:
+            h, d = hs.host(), ds.host()
+            for k in h:
+                if k != "action":
+                    assert np.array_equal(h[k].view(np.uint8), d[k].view(np.uint8)), (case, t, k)
+    assert hs["episode"].max() >= 3                                           # re-spawns happened
+    want = oracle.render_ego(cfg, world, hs)
+    got = ops.render_ego(cfg, dw, ds).cpu().numpy()
+    assert np.array_equal(got, want), int((got != want).sum())

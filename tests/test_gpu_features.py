@@ -69,6 +69,120 @@ def test_render_with_lights_and_flags_bit_exact(A, flags):
     assert seen[RED] > 50 and seen[GO] > 50               # both light states were on screen
 
 
+def test_render_overlapping_stop_lines_paint_in_index_order():
+    """two stop lines that overlap and show different light states: the oracle paints them in index order (the later one
+    wins where they overlap); the rasteriser culls them with an order-preserving compaction and paints one after the
+    other inside one wavefront, so it must give the same pixels whatever the lights show"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=4, A=16, seed=3, n_maps=2)
+    st = world.arrays["stoplines"]
+    maps = world.arrays["maps"]
+    for m in maps:                                        # line 1 of every map is laid across line 0, rotated by 0.5 rad
+        a, b = st[m["stop_base"]], st[m["stop_base"] + 1]
+        b["x"], b["y"] = a["x"] + 0.4, a["y"] - 0.3
+        ang = np.arctan2(a["s"], a["c"]) + 0.5
+        b["c"], b["s"] = np.cos(ang), np.sin(ang)
+    world._host_struct = None
+    cfg = _abi.default_config(seed=2, flags=_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS, terminated_at_infraction=0, max_steps=10**6)
+    B, A = 16, 16
+    hs, ds, dw = _pair(world, B, A, cfg)
+    scn_map = world.arrays["scn"]["map"]
+    RED, GO = _abi.PALETTE[_abi.LAYER_STOP_RED], _abi.PALETTE[_abi.LAYER_STOP_GO]
+    both = 0
+    for k in (3, 85, 100, 150):                           # different phases of the cycle: (red, go), (red, red), (go, red) ...
+        for e in range(B):
+            m = maps[scn_map[hs["scn"][e]]]
+            sl = st[m["stop_base"]]
+            g = e * A
+            hs["x"][g], hs["y"][g] = sl["x"] - 3.0 * sl["c"], sl["y"] - 3.0 * sl["s"]
+            hs["psi"][g] = np.arctan2(sl["s"], sl["c"]) + 0.1 * e
+            hs["steps"][e] = k + e
+        ds.load(hs.host())
+        want = oracle.render_ego(cfg, world, hs)
+        got = ops.render_ego(cfg, dw, ds).cpu().numpy()
+        assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ at k={k}"
+        px = want.transpose(0, 2, 3, 1).reshape(B, -1, 3)
+        both += sum(int((p == np.array(RED)).all(1).any() and (p == np.array(GO)).all(1).any()) for p in px)
+    assert both > 4                                       # views showing a red and a green line at once
+
+
+def test_state_load_of_an_edited_device_snapshot_drops_the_step_caches(small_world):
+    """`h = st.host(); h['x'] += ...; st.load(h)`: the snapshot of a DEVICE state carries its lookup / action caches, keyed
+    by the episode / step counters only - reloading them would apply NPC actions computed for the old poses"""
+    cfg = _abi.default_config(seed=4, distance_cutoff=0.25)
+    B, A = 64, 16
+    hs, ds, dw = _pair(small_world, B, A, cfg)
+    rng = np.random.default_rng(1)
+    _step_both(cfg, small_world, dw, hs, ds, rng, 5)      # (the three-role step kernel fills the caches)
+    assert int((ds["act_cache"][:, 0] >= 0).sum()) > 0
+    h = ds.host()
+    shift = rng.uniform(-1.5, 1.5, B * A).astype(np.float32)
+    h["x"] = h["x"] + shift
+    ds.load(h)
+    assert int((ds["act_cache"][:, 0] >= 0).sum()) == 0   # invalidated, not restored
+    hs["x"][...] = hs["x"] + shift
+    _step_both(cfg, small_world, dw, hs, ds, rng, 3)
+    for k in ("x", "y", "psi", "v", "collided", "offroad", "reward"):
+        assert np.array_equal(ds[k].cpu().numpy().view(np.uint8), hs[k].view(np.uint8)), k
+
+
+def test_operator_level_entry_points_through_the_extension(small_world, golden):
+    """the four SimulatorInterface-level entry points bound in the PyTorch-ROCm extension (kinematics_step,
+    compute_collision, compute_offroad, waypoint_reward) give the bits of the ctypes binding and of the oracle"""
+    import ctypes as C
+
+    from tests.golden_util import case_config, case_expected, case_inputs
+    from torchdriveenv_amd import _ext
+
+    X = _ext.load()
+    cfg = _abi.default_config(seed=9)
+    B, A = 48, 16
+    hs, ds, dw = _pair(small_world, B, A, cfg)
+    rng = np.random.default_rng(3)
+    _step_both(cfg, small_world, dw, hs, ds, rng, 8)
+    h = hs.host()
+    n = B * A
+    # kinematics
+    act = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.3, 0.3, n)], -1).astype(np.float32)
+    a1 = [dev(h[k].copy()) for k in ("x", "y", "psi", "v")]
+    a2 = [dev(h[k].copy()) for k in ("x", "y", "psi", "v")]
+    X.kinematics_step(*a1, dev(h["lr"]), dev(act), dev(h["present"]), 0.1)
+    ops.kinematics_step(*a2, dev(h["lr"]), dev(act), present=dev(h["present"]), dt=0.1)
+    want = [h[k].copy() for k in ("x", "y", "psi", "v")]
+    oracle.kinematics_step(*want, h["lr"], h["present"], act, 0.1)
+    for t1, t2, w in zip(a1, a2, want):
+        assert torch.equal(t1, t2) and np.array_equal(t1.cpu().numpy().view(np.uint32), w.view(np.uint32))
+    # collision / offroad
+    args = [dev(h[k]) for k in ("x", "y", "psi", "len", "wid", "present")]
+    c1, c2 = X.compute_collision(B, A, *args), ops.compute_collision(B, A, *args)
+    assert torch.equal(c1, c2) and np.array_equal(c1.cpu().numpy(), oracle.compute_collision(B, A, *[h[k] for k in ("x", "y", "psi", "len", "wid", "present")]))
+    mo = np.ascontiguousarray(small_world.arrays["scn"]["map"][h["scn"]].astype(np.int32))
+    o1 = X.compute_offroad(B, A, *args, C.addressof(dw.struct), dev(mo), 0.5)
+    o2 = ops.compute_offroad(B, A, *args, dw, dev(mo), threshold=0.5)
+    assert torch.equal(o1, o2) and np.array_equal(o1.cpu().numpy(), oracle.compute_offroad(B, A, *[h[k] for k in ("x", "y", "psi", "len", "wid", "present")], small_world, mo, threshold=0.5))
+    # the reference-owned reward logic on a golden case
+    case = golden["cases"][0]
+    ccfg, inp, exp = case_config(case), case_inputs(case), case_expected(case)
+    steps, target, reached = dev(inp["steps"].copy()), dev(inp["target"].copy()), dev(inp["reached"].copy())
+    out = X.waypoint_reward(C.addressof(ccfg), dev(np.ascontiguousarray(inp["pre"].T)), dev(np.ascontiguousarray(inp["post"].T)),
+                            dev(inp["off"]), dev(inp["col"]), dev(inp["tl"]), dev(inp["wp"]), dev(inp["wp_n"]), dev(inp["scn"]),
+                            steps, target, reached)
+    reward, term, trunc, info, info_reached = [t.cpu().numpy() for t in out]
+    assert np.array_equal(reward.astype(np.float64), exp["reward"]) and np.array_equal(term, exp["terminated"])
+    assert np.array_equal(trunc, exp["truncated"]) and np.array_equal(target.cpu().numpy(), exp["target_after"])
+    assert np.array_equal(info_reached, exp["reached"]) and np.allclose(info, exp["info"], rtol=1e-12, atol=1e-15)
+    with pytest.raises(RuntimeError):
+        X.compute_collision(B, A, *[t.cpu() for t in args])                   # host tensors are refused, not dereferenced
+
+
+def test_sharded_env_argument_checks(small_world):
+    from torchdriveenv_amd.sharding import ShardedBatchedEnv
+
+    with pytest.raises(ValueError, match="n_shards"):
+        ShardedBatchedEnv(EnvConfig(seed=1), small_world, total_envs=3, n_shards=4)
+
+
 def test_render_masked_and_fresh_calls_match_oracle(small_world):
     """tde_render.only / .fresh with the in-place stack and with the layer ring: same pixels as the oracle"""
     cfg = _abi.default_config(seed=12, flags=_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS)

@@ -81,15 +81,15 @@ def test_shard_ranges_partition_the_batch():
 REF_DATA = "/root/reference/torchdriveenv/data"
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DATA, "validation_cases.yml")),
-                    reason="reference data files are only present in the build container")
-def test_reference_suites_load_and_step_with_the_oracle():
-    """the reference's own validation / training suites go through the loaders and the world builder unchanged"""
+def test_reference_suites_load_and_step_with_the_oracle(tmp_path):
+    """the reference's own validation suite (its DATA, committed as tests/golden/validation_suite.json) goes through the
+    loaders and the world builder unchanged; runs anywhere (no /root/reference)"""
     from oracle import oracle
+    from tests.golden_util import write_validation_suite_yaml
     from torchdriveenv_amd.env import world_from_waypoint_suite
     from torchdriveenv_amd.state import EnvState
 
-    val = load_waypoint_suite_data(os.path.join(REF_DATA, "validation_cases.yml"))
+    val = load_waypoint_suite_data(write_validation_suite_yaml(str(tmp_path / "validation_cases.yml")))
     assert val.locations == ["Town07", "Town07", "Town03", "Town03", "Town01"] and len(val.waypoint_suite) == 5
     assert list(val.car_sequence_suite[1].keys()) == [1] and len(val.car_sequence_suite[1][1]) == 300
     assert len(val.scenarios[0].agent_states) == 2
@@ -107,6 +107,22 @@ def test_reference_suites_load_and_step_with_the_oracle():
     e = int(np.nonzero(st["scn"] == 1)[0][0]) if (st["scn"] == 1).any() else None
     if e is not None:
         assert abs(st["x"][e * 8 + 1] - (-55.70970916748047)) < 1e-4 and st["v"][e * 8 + 1] == 0.0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DATA, "validation_cases.yml")),
+                    reason="reference data files are only present in the build container")
+def test_committed_validation_fixture_equals_the_reference_file(tmp_path):
+    """the committed fixture is the reference's data, value for value (and the 100-case training suite still loads)"""
+    from tests.golden_util import write_validation_suite_yaml
+
+    ref = load_waypoint_suite_data(os.path.join(REF_DATA, "validation_cases.yml"))
+    got = load_waypoint_suite_data(write_validation_suite_yaml(str(tmp_path / "v.yml")))
+    assert got.locations == ref.locations and got.waypoint_suite == ref.waypoint_suite
+    assert got.car_sequence_suite == ref.car_sequence_suite
+    for a, b in zip(got.scenarios, ref.scenarios):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.agent_states == b.agent_states and a.agent_attributes == b.agent_attributes
     train = load_waypoint_suite_data(os.path.join(REF_DATA, "training_cases.yml"))
     assert len(train.waypoint_suite) == 100 and all(5 <= len(wp) <= 20 for wp in train.waypoint_suite)
     assert all(s is None for s in train.scenarios)

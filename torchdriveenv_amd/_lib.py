@@ -8,7 +8,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TDE_HIP_LIB") or os.path.join(_PKG, "libtde_hip.so")   # override: A/B builds only
 
 # every symbol include/tde_hip.h declares
-SYMBOLS = ["tde_abi_version", "tde_last_error", "tde_kinematics_step", "tde_compute_collision",
+SYMBOLS = ["tde_abi_version", "tde_last_error", "tde_kernel_override", "tde_kinematics_step", "tde_compute_collision",
            "tde_compute_offroad", "tde_kin_collide_step", "tde_waypoint_reward", "tde_env_reset", "tde_env_step",
            "tde_env_rollout", "tde_render_ego", "tde_state_obs"]
 
@@ -50,6 +50,7 @@ def load():
     L.tde_env_rollout.argtypes = [cfgp, wp, sp, C.POINTER(_abi.TdeRollout), vp]
     L.tde_render_ego.argtypes = [cfgp, wp, sp, C.POINTER(_abi.TdeRender), vp]
     L.tde_state_obs.argtypes = [wp, sp, vp, vp]
+    L.tde_kernel_override.argtypes = [C.c_int, C.c_int]
     for s in SYMBOLS:
         if s != "tde_last_error":
             getattr(L, s).restype = C.c_int
@@ -61,6 +62,15 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().tde_last_error().decode() or f"error {rc}"
         raise TdeError(f"{what}: {msg}" if what else msg)
+
+
+TEAMS = {None: 0, "auto": 0, "solo": 1, "duo": 2, "trio": 3}
+
+
+def kernel_override(rollout=None, step=None):
+    """force a kernel form of tde_env_rollout ("solo" | "duo" | "trio") / tde_env_step ("solo" | "trio"); None = the
+    library's own choice (tde_hip.h: tde_kernel_override).  Process-wide; tests and A/B scripts only."""
+    check(load().tde_kernel_override(TEAMS[rollout], TEAMS[step]), "tde_kernel_override")
 
 
 def current_stream(device):

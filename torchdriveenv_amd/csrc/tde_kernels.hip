@@ -1215,8 +1215,9 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 // wait for each other.  What depends on the other judge's mask (the done byte, terminated, C's own re-spawn
 // bookkeeping) is settled by C after the next barrier A.
 // ------------------------------------------------------------------------------------------------------------------
-// sensitivity probe (scripts/build_variant.sh -DTDE_DUMMY_D=100 ...): N extra dependent / independent VALU instructions per
-// step in one role, results discarded - which role's instructions cost how much
+// sensitivity probe of tuning builds only (scripts/build_variant.sh -DTDE_DEBUG -DTDE_DUMMY_D=100 ...): N extra dependent /
+// independent VALU instructions per step in one role, results discarded - which role's instructions cost how much
+#ifdef TDE_DEBUG
 #ifndef TDE_DUMMY_D
 #define TDE_DUMMY_D 0
 #endif
@@ -1244,6 +1245,10 @@ template <int N> TDE_DEV void dummy_valu(float seed)
         for (int u = 0; u < TDE_DUMMY_ILP; ++u) asm volatile("" :: "v"(v[u]));
     }
 }
+#define TDE_PROBE(N, seed) dummy_valu<N>(seed)
+#else
+#define TDE_PROBE(N, seed) ((void)0)
+#endif
 // issue priorities of the three roles.  Round 1: driver > judge C > judge O (2, 1, 0).  After round 2's diet of judge C
 // (windowed reward, DPP collision prefilter) judge O's chain - four dependent cell-word loads per slot - is the longer one
 // of the two: (2, 0, 1) 2.93 us per step against (2, 1, 0) 3.00, (3, 0, 2) 2.93, (2, 0, 2) 2.99, (1, 0, 1) 2.99
@@ -1348,7 +1353,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
                 }
                 sincos_f32(npsi, ns, nc);
-                dummy_valu<TDE_DUMMY_D>(nx);
+                TDE_PROBE(TDE_DUMMY_D, nx);
                 if (pass) break;
                 lds_barrier();                               // A: the judges' masks of step i-1 are published
                 unsigned long long term_m, trunc_m;
@@ -1487,7 +1492,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
             const unsigned long long m = __ballot(hit);
             if (lane == 0) sh.hit_mask = m;
-            dummy_valu<TDE_DUMMY_C>(ra.x);
+            TDE_PROBE(TDE_DUMMY_C, ra.x);
             if (batch) {
                 if (a == 0 && valid) {
                     const float4 pa = sh.a[q][lane], pc = sh.c[q][lane];      // state before the step (:371-375)
@@ -1558,7 +1563,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
                 tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
-            dummy_valu<TDE_DUMMY_O>(ra.x);
+            TDE_PROBE(TDE_DUMMY_O, ra.x);
             const unsigned long long om = __ballot(off), tm = __ballot(tl);
             if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
             if (ego) sh.act[p][lane] = act2;                 // step i+2 -> slot i & 1 (step i's action is consumed: B passed)
@@ -2237,9 +2242,22 @@ static bool pow2_le64(int A) { return A >= 1 && A <= TDE_MAX_AGENTS && (A & (A -
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + tde::kBlock - 1) / tde::kBlock); }
 
+// which kernel form tde_env_rollout / tde_env_step launch: 0 = by group shape and batch size (the measured choice), else
+// forced (tde_kernel_override: parity tests of every form, A/B runs)
+static int g_force_rollout = 0, g_force_step = 0;
+
 extern "C" {
 
 int tde_abi_version(void) { return TDE_ABI_VERSION; }
+
+int tde_kernel_override(int rollout_team, int step_team)
+{
+    if (rollout_team < 0 || rollout_team > 3 || !(step_team == 0 || step_team == 1 || step_team == 3))
+        return bad("tde_kernel_override: rollout_team in {0, 1, 2, 3}, step_team in {0, 1, 3}");
+    g_force_rollout = rollout_team;
+    g_force_step = step_team;
+    return 0;
+}
 
 const char *tde_last_error(void) { return g_err; }
 
@@ -2345,15 +2363,15 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     if (!st->action) return bad("tde_env_step: state.action is NULL");
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     // With the lookup caches present (and a group shape the three-role kernels are built for) the step runs as three
-    // wavefronts per 64 agent slots; TDE_STEP=solo forces the one-role kernel (A/B runs).
+    // wavefronts per 64 agent slots; tde_kernel_override forces one form (A/B runs).
     // Which one wins is a matter of load (same-box, scripts/launch_cost.py, us per launch at 16 agents per env):
     //   envs      512   1024   2048   4096   8192   16384
     //   3 roles   8.5    8.7    9.1   10.1   12.3    19.3      (<= 2048: bounded by the ctypes host floor of 7.2)
     //   1 role   10.2   10.2   10.3   10.5   11.9    16.4
     // a launch costs ~5 us of fixed latency (dispatch + one wavefront's dependent chain, which the role split and the
     // caches shorten) plus ~0.85 us per 1024 envs of issue time (which the two extra prologues lengthen): three roles
-    // up to 65 536 agent slots, one role above.  TDE_STEP=solo|trio forces one.
-    static const int force = [] { const char *v = getenv("TDE_STEP"); return !v ? 0 : !strcmp(v, "solo") ? 1 : !strcmp(v, "trio") ? 3 : 0; }();
+    // up to 65 536 agent slots, one role above.  tde_kernel_override(0, 1 | 3) forces one.
+    const int force = g_force_step;
     const bool trio_ok = st->slot_cache && st->env_cache && (st->A == 8 || st->A == 16 || st->A == 32);
     const bool want_trio = force == 3 || (force == 0 && (int64_t)st->B * st->A <= 65536);
     if (trio_ok && want_trio) {
@@ -2391,17 +2409,14 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (st->B <= 0 || ro->K <= 0) return 0;
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-    // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (TDE_ROLLOUT=solo|duo|trio forces
-    // one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median
+    // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
+    // forces one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median
     // us per step (scripts/ab_rollout.py duo:... trio:..., profiles/r02_e_rollout_matrix.txt): three roles win at 8 and 16
     // agents per env, without traffic lights (3.17 vs 3.50, 3.06 vs 3.54) and with them (5.32 vs 5.55, 4.55 vs 5.01), and
     // at 32 without lights (3.70 vs 4.11); at 32 WITH lights the 32-row sweeps plus the stop-line loops spill under the
     // 80-VGPR cap and the two-role kernel (128 VGPRs, four wavefronts per SIMD) is faster (5.18 vs 7.66); at 64 the two
     // are equal (5.03) and two roles run.
-    static const int forced = [] {
-        const char *v = getenv("TDE_ROLLOUT");
-        return !v ? 0 : !strcmp(v, "solo") ? 1 : !strcmp(v, "duo") ? 2 : !strcmp(v, "trio") ? 3 : 0;
-    }();
+    const int forced = g_force_rollout;
     const bool lights0 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
     const int team = forced ? forced : (st->A == 8 || st->A == 16 || (st->A == 32 && !lights0)) ? 3 : 2;

@@ -15,6 +15,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "tde_hip.h"
 
@@ -118,12 +119,108 @@ class EnvHandle {
     at::Device dev_;
 };
 
+// ---- operator level: the SimulatorInterface methods GymEnv calls (include/tde_hip.h, first block), torch tensors in / out ----
+template <typename T> T *ptr(const at::Tensor &t, at::ScalarType dt, int64_t numel, const char *name, const at::Device &dev)
+{
+    return static_cast<T *>(const_cast<void *>(dev_ptr(t, dt, numel, name, dev)));
+}
+void *cur_stream(const at::Device &dev) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
+
+// tde_kinematics_step: KinematicBicycle.step for n agents, in place (ref gym_env.py:117)
+void kinematics_step(const at::Tensor &x, const at::Tensor &y, const at::Tensor &psi, const at::Tensor &v, const at::Tensor &lr,
+                     const at::Tensor &action, const std::optional<at::Tensor> &present, double dt)
+{
+    const int64_t n = x.numel();
+    const at::Device dev = x.device();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    check_rc(tde_kinematics_step(n, ptr<float>(x, at::kFloat, n, "x", dev), ptr<float>(y, at::kFloat, n, "y", dev),
+                                 ptr<float>(psi, at::kFloat, n, "psi", dev), ptr<float>(v, at::kFloat, n, "v", dev),
+                                 ptr<float>(lr, at::kFloat, n, "lr", dev),
+                                 present ? ptr<uint8_t>(*present, at::kByte, n, "present", dev) : nullptr,
+                                 ptr<float>(action, at::kFloat, 2 * n, "action", dev), (float)dt, cur_stream(dev)),
+             "tde_kinematics_step");
+}
+
+// tde_compute_collision: compute_collision() > 0 per agent -> uint8 [B * A] (ref gym_env.py:143)
+at::Tensor compute_collision(int64_t B, int64_t A, const at::Tensor &x, const at::Tensor &y, const at::Tensor &psi,
+                             const at::Tensor &length, const at::Tensor &width, const at::Tensor &present)
+{
+    const int64_t n = B * A;
+    const at::Device dev = x.device();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    at::Tensor out = at::empty({n}, at::TensorOptions().dtype(at::kByte).device(dev));
+    check_rc(tde_compute_collision((int32_t)B, (int32_t)A, ptr<float>(x, at::kFloat, n, "x", dev), ptr<float>(y, at::kFloat, n, "y", dev),
+                                   ptr<float>(psi, at::kFloat, n, "psi", dev), ptr<float>(length, at::kFloat, n, "length", dev),
+                                   ptr<float>(width, at::kFloat, n, "width", dev), ptr<uint8_t>(present, at::kByte, n, "present", dev),
+                                   out.data_ptr<uint8_t>(), cur_stream(dev)),
+             "tde_compute_collision");
+    return out;
+}
+
+// tde_compute_offroad: compute_offroad() > 0 per agent -> uint8 [B * A] (ref gym_env.py:142); world_addr = the ctypes tde_world
+at::Tensor compute_offroad(int64_t B, int64_t A, const at::Tensor &x, const at::Tensor &y, const at::Tensor &psi,
+                           const at::Tensor &length, const at::Tensor &width, const at::Tensor &present, uintptr_t world_addr,
+                           const at::Tensor &map_of_env, double threshold)
+{
+    const int64_t n = B * A;
+    const at::Device dev = x.device();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    at::Tensor out = at::empty({n}, at::TensorOptions().dtype(at::kByte).device(dev));
+    check_rc(tde_compute_offroad((int32_t)B, (int32_t)A, ptr<float>(x, at::kFloat, n, "x", dev), ptr<float>(y, at::kFloat, n, "y", dev),
+                                 ptr<float>(psi, at::kFloat, n, "psi", dev), ptr<float>(length, at::kFloat, n, "length", dev),
+                                 ptr<float>(width, at::kFloat, n, "width", dev), ptr<uint8_t>(present, at::kByte, n, "present", dev),
+                                 reinterpret_cast<const tde_world *>(world_addr), ptr<int32_t>(map_of_env, at::kInt, B, "map_of_env", dev),
+                                 (float)threshold, out.data_ptr<uint8_t>(), cur_stream(dev)),
+             "tde_compute_offroad");
+    return out;
+}
+
+// tde_waypoint_reward (ref gym_env.py:391-437): pre / post = (x, y, psi, v) stacked [4][n]; steps / target_idx / reached
+// int32 [n], updated in place; -> (reward f32 [n], terminated u8 [n], truncated u8 [n], info f64 [n][4], info_reached i32 [n])
+std::vector<at::Tensor> waypoint_reward(uintptr_t cfg_addr, const at::Tensor &pre, const at::Tensor &post, const at::Tensor &offroad,
+                                        const at::Tensor &collided, const std::optional<at::Tensor> &tl, const at::Tensor &wp_xy,
+                                        const at::Tensor &wp_n, const at::Tensor &scn, const at::Tensor &steps,
+                                        const at::Tensor &target_idx, const at::Tensor &reached)
+{
+    TORCH_CHECK(pre.dim() == 2 && pre.size(0) == 4 && post.dim() == 2 && post.size(0) == 4, "pre / post must be [4][n]");
+    TORCH_CHECK(wp_xy.dim() == 3 && wp_xy.size(2) == 2, "wp_xy must be [S][NW][2]");
+    const int64_t n = pre.size(1), S = wp_xy.size(0), NW = wp_xy.size(1);
+    const at::Device dev = pre.device();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const float *p0 = ptr<float>(pre, at::kFloat, 4 * n, "pre", dev), *p1 = ptr<float>(post, at::kFloat, 4 * n, "post", dev);
+    const auto opt = at::TensorOptions().device(dev);
+    at::Tensor reward = at::empty({n}, opt.dtype(at::kFloat)), term = at::empty({n}, opt.dtype(at::kByte)),
+               trunc = at::empty({n}, opt.dtype(at::kByte)), info = at::empty({n, 4}, opt.dtype(at::kDouble)),
+               info_reached = at::empty({n}, opt.dtype(at::kInt));
+    check_rc(tde_waypoint_reward(reinterpret_cast<const tde_config *>(cfg_addr), (int32_t)n, p0, p0 + n, p0 + 2 * n, p0 + 3 * n, p1,
+                                 p1 + n, p1 + 2 * n, p1 + 3 * n, ptr<uint8_t>(offroad, at::kByte, n, "offroad", dev),
+                                 ptr<uint8_t>(collided, at::kByte, n, "collided", dev),
+                                 tl ? ptr<uint8_t>(*tl, at::kByte, n, "tl", dev) : nullptr,
+                                 ptr<double>(wp_xy, at::kDouble, S * NW * 2, "wp_xy", dev), ptr<int32_t>(wp_n, at::kInt, S, "wp_n", dev),
+                                 (int32_t)NW, ptr<int32_t>(scn, at::kInt, n, "scn", dev), ptr<int32_t>(steps, at::kInt, n, "steps", dev),
+                                 ptr<int32_t>(target_idx, at::kInt, n, "target_idx", dev), ptr<int32_t>(reached, at::kInt, n, "reached", dev),
+                                 reward.data_ptr<float>(), term.data_ptr<uint8_t>(), trunc.data_ptr<uint8_t>(), info.data_ptr<double>(),
+                                 info_reached.data_ptr<int32_t>(), cur_stream(dev)),
+             "tde_waypoint_reward");
+    return {reward, term, trunc, info, info_reached};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "PyTorch-ROCm C++ extension over the C-ABI of libtde_hip.so (include/tde_hip.h)";
     m.def("abi_version", []() { return tde_abi_version(); });
+    m.def("kinematics_step", &kinematics_step, py::arg("x"), py::arg("y"), py::arg("psi"), py::arg("v"), py::arg("lr"),
+          py::arg("action"), py::arg("present") = py::none(), py::arg("dt") = 0.1);
+    m.def("compute_collision", &compute_collision, py::arg("B"), py::arg("A"), py::arg("x"), py::arg("y"), py::arg("psi"),
+          py::arg("length"), py::arg("width"), py::arg("present"));
+    m.def("compute_offroad", &compute_offroad, py::arg("B"), py::arg("A"), py::arg("x"), py::arg("y"), py::arg("psi"),
+          py::arg("length"), py::arg("width"), py::arg("present"), py::arg("world_addr"), py::arg("map_of_env"),
+          py::arg("threshold") = 0.5);
+    m.def("waypoint_reward", &waypoint_reward, py::arg("cfg_addr"), py::arg("pre"), py::arg("post"), py::arg("offroad"),
+          py::arg("collided"), py::arg("tl"), py::arg("wp_xy"), py::arg("wp_n"), py::arg("scn"), py::arg("steps"),
+          py::arg("target_idx"), py::arg("reached"));
     py::class_<EnvHandle>(m, "EnvHandle")
         .def(py::init<uintptr_t, uintptr_t, uintptr_t, int64_t>(), py::arg("cfg_addr"), py::arg("world_addr"), py::arg("state_addr"),
              py::arg("device_index"))

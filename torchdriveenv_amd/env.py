@@ -419,6 +419,7 @@ class LazyInfos:
 
     def __init__(self, n, cols, terminal):
         self._n, self._cols, self._terminal = n, cols, terminal   # cols: name -> [n] array; terminal: env -> extra entries
+        self._made = {}                                           # env -> the dict handed out (writes to it stick)
 
     def __len__(self):
         return self._n
@@ -430,11 +431,33 @@ class LazyInfos:
             i += self._n
         if not 0 <= i < self._n:
             raise IndexError(i)
-        d = {k: v[i].item() for k, v in self._cols.items()}
-        extra = self._terminal.get(i)
-        if extra:
-            d.update(extra)
+        d = self._made.get(i)
+        if d is None:
+            # the SAME dict on every access: SB3 wrappers rewrite infos[i]["terminal_observation"] in step_wait
+            # (VecNormalize, VecTransposeImage, VecFrameStack) and read it back through infos[i] later
+            d = {k: v[i].item() for k, v in self._cols.items()}
+            extra = self._terminal.get(i)
+            if extra:
+                d.update(extra)
+            self._made[i] = d
         return d
+
+    def __setitem__(self, i, d):
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        self._made[i] = d
+
+    @property
+    def columns(self):
+        """name -> per-env array of every info column (what ShardedBatchedEnv concatenates)"""
+        return self._cols
+
+    @property
+    def terminal(self):
+        """env -> the extra entries of the envs that finished at this step (terminal_observation, episode)"""
+        return self._terminal
 
     def __iter__(self):
         return (self[i] for i in range(self._n))
@@ -457,7 +480,10 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
 
     def __init__(self, env, copy_obs=True, info_keywords=("offroad", "collision", "traffic_light_violation", "is_success",
                                                            "reached_waypoint_num", "psi_smoothness", "speed_smoothness",
-                                                           "psi_reward", "dist_reward")):
+                                                           "psi_reward", "dist_reward"), obs_buffers=None):
+        """obs_buffers: optional list of host tensors (pinned, or page-locked by the caller with hipHostRegister) of the
+        observation's shape to use as the ring the device-to-host copies land in - how a shard of ShardedBatchedEnv lets
+        its observations arrive directly in its slice of the gathered buffer"""
         import time
 
         self.env = env
@@ -475,8 +501,14 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
         self._t_start = time.time()
         self._pending = None
         shape = (env.num_envs,) + tuple(env.observation_space.shape)
-        self._obs_ring = [torch.empty(shape, dtype=torch.uint8 if env.obs_mode == "birdview" else torch.float32,
-                                      pin_memory=True) for _ in range(1 if copy_obs else 3)]
+        odt = torch.uint8 if env.obs_mode == "birdview" else torch.float32
+        if obs_buffers is not None:
+            for b in obs_buffers:
+                if tuple(b.shape) != shape or b.dtype != odt or b.is_cuda or not b.is_contiguous():
+                    raise ValueError(f"obs_buffers must be contiguous host tensors of shape {shape} and dtype {odt}")
+            self._obs_ring = list(obs_buffers)
+        else:
+            self._obs_ring = [torch.empty(shape, dtype=odt, pin_memory=True) for _ in range(1 if copy_obs else 3)]
         self._turn = 0
 
     # ---- helpers

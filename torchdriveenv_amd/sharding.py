@@ -47,22 +47,26 @@ def _shard_worker(rank, n_shards, device, cfg, world, total, kw, conn, shm):
         torch.cuda.set_device(device)
         lo, hi = shard_range(rank, n_shards, total)
         env = BatchedWaypointEnv(cfg, world, num_envs=hi - lo, device=f"cuda:{device}", env_base=lo, **kw)
-        venv = env.as_vec_env(copy_obs=False)
-        obs_all = shm["obs"].numpy()
+        # The shard's observations land directly in its slice of the gathered buffer: the shared segment is page-locked
+        # in this process (hipHostRegister), so the device-to-host copy is ONE pass over the bytes (a pageable target
+        # costs a staging copy inside the runtime, and the former pinned ring + memcpy a second pass over 100 MB per
+        # shard and step for birdview observations).  Registration failing (rlimit) only loses the speed.
+        mine = shm["obs"][lo:hi]
+        pinned = page_lock(mine)
+        venv = env.as_vec_env(copy_obs=False, obs_buffers=[mine])
         rew_all, done_all = shm["reward"].numpy(), shm["done"].numpy()
-        conn.send(("ready", lo, hi))
+        conn.send(("ready", lo, hi, pinned))
         while True:
             cmd, arg = conn.recv()
             if cmd == "reset":
-                obs_all[lo:hi] = venv.reset()
+                venv.reset()                              # (written in place: the ring is the shared slice)
                 conn.send(("ok", None))
             elif cmd == "step":
                 obs, rew, done, infos = venv.step(shm["action"].numpy()[lo:hi])
-                obs_all[lo:hi] = obs                      # the shard's slice of the gathered (shared, host) buffers
                 rew_all[lo:hi] = rew
                 done_all[lo:hi] = done
-                cols = {k: np.asarray(v) for k, v in infos._cols.items()}
-                conn.send(("ok", (cols, {lo + i: ex for i, ex in infos._terminal.items()})))
+                cols = {k: np.asarray(v) for k, v in infos.columns.items()}
+                conn.send(("ok", (cols, {lo + i: ex for i, ex in infos.terminal.items()})))
             elif cmd == "state":
                 conn.send(("ok", {k: v.cpu().numpy() for k, v in env.state.arrays.items() if v is not None}))
             elif cmd == "close":
@@ -74,14 +78,30 @@ def _shard_worker(rank, n_shards, device, cfg, world, total, kw, conn, shm):
         conn.send(("error", f"shard {rank}: {exc}\n{traceback.format_exc()}"))
 
 
+def page_lock(t):
+    """hipHostRegister the storage of a host tensor (so that copies from a device into it are true DMA); False if the
+    runtime refuses"""
+    import torch
+
+    try:
+        rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
+        return int(rc) == 0
+    except Exception:
+        return False
+
+
 class ShardedBatchedEnv:
     """`total_envs` envs cut into `n_shards` contiguous shards, one process per shard (one per GPU; several shards may
-    share a GPU), no data-path collective: the reset RNG is keyed by the GLOBAL env index (tde_config.env_base), so the
-    sharded batch is bit for bit the unsharded one.  Every step the shards write their slices of the shared host
+    share a GPU), no data-path collective: the reset RNG is keyed by the GLOBAL env index (tde_config.env_base) and the seed is
+    resolved once, here, so the sharded batch is bit for bit the unsharded one with that seed (`.config.seed`).  Every step the shards write their slices of the shared host
     buffers (observations, rewards, dones) - the host gather - and the caller gets VecEnv-shaped numpy results for the
     whole batch: step(actions [total, 2]) -> (obs, rewards, dones, infos)."""
 
-    def __init__(self, cfg, world, total_envs, n_shards=None, devices=None, **env_kw):
+    def __init__(self, cfg, world, total_envs, n_shards=None, devices=None, copy_obs=True, **env_kw):
+        """copy_obs=False: reset / step hand out VIEWS of the gathered host buffers (valid until the next step) instead
+        of fresh arrays - 100 MB per 8192 birdview envs and step that nobody has to copy"""
+        import dataclasses
+
         import numpy as np
         import torch
         import torch.multiprocessing as mp
@@ -92,6 +112,14 @@ class ShardedBatchedEnv:
         if ndev < 1:
             raise RuntimeError("ShardedBatchedEnv needs at least one HIP device")
         self.n_shards = int(n_shards or ndev)
+        if self.n_shards < 1 or self.n_shards > int(total_envs):
+            raise ValueError(f"n_shards must be in [1, total_envs]: {self.n_shards} shards for {total_envs} envs")
+        if cfg.seed is None:
+            # one seed for the whole batch, drawn here: shards that each drew their own would neither reproduce the
+            # unsharded batch nor each other's runs (ref helpers.py:39-41 draws one per process)
+            cfg = dataclasses.replace(cfg, seed=int(np.random.randint(0, 2**31 - 1)))
+        self.config = cfg
+        self.copy_obs = bool(copy_obs)
         self.devices = list(devices) if devices is not None else [r % ndev for r in range(self.n_shards)]
         self.num_envs = int(total_envs)
         obs_mode = env_kw.get("obs_mode", "birdview")
@@ -112,9 +140,11 @@ class ShardedBatchedEnv:
             p.start()
             self._conns.append(parent)
             self._procs.append(p)
+        self.pinned = []
         for c in self._conns:
-            tag, lo, hi = self._recv(c)
+            tag, lo, hi, pinned = self._recv(c)
             self.ranges.append((lo, hi))
+            self.pinned.append(bool(pinned))
         self._np = np
 
     @staticmethod
@@ -127,11 +157,21 @@ class ShardedBatchedEnv:
     def _all(self, cmd, arg=None):
         for c in self._conns:
             c.send((cmd, arg))
-        return [self._recv(c)[1] for c in self._conns]
+        # every reply is read before an error is raised: a reply left in a pipe would be taken for the answer to the
+        # next command (close() reading a stale "ok")
+        msgs = [c.recv() for c in self._conns]
+        errs = [m[1] for m in msgs if m[0] == "error"]
+        if errs:
+            raise RuntimeError("\n".join(errs))
+        return [m[1] for m in msgs]
+
+    def _obs(self):
+        o = self._shm["obs"].numpy()
+        return o.copy() if self.copy_obs else o
 
     def reset(self):
         self._all("reset")
-        return self._shm["obs"].numpy().copy()
+        return self._obs()
 
     def step(self, actions):
         from .env import LazyInfos
@@ -143,7 +183,7 @@ class ShardedBatchedEnv:
         terminal = {}
         for p in parts:
             terminal.update(p[1])
-        return (self._shm["obs"].numpy().copy(), self._shm["reward"].numpy().copy(), self._shm["done"].numpy().copy(),
+        return (self._obs(), self._shm["reward"].numpy().copy(), self._shm["done"].numpy().copy(),
                 LazyInfos(self.num_envs, cols, terminal))
 
     def gather_state(self):

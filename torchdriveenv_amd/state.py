@@ -104,8 +104,9 @@ class EnvState:
         self.invalidate_caches()
         for n, a in host_arrays.items():
             dst = self.arrays.get(n)
-            if dst is None:
-                continue
+            if dst is None or n in ("slot_cache", "env_cache", "act_cache"):
+                continue       # (a dict taken from a device state's .host() carries its caches: they are keyed by counters
+                               #  only and would come back "valid" for the poses the caller has just edited)
             if isinstance(dst, np.ndarray):
                 dst[...] = a
             else:
