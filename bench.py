@@ -142,6 +142,97 @@ def cpu_baseline(world, cfg, A, budget_s=12.0):
                       f"(brute-force mesh distance, OpenMP over envs), {dt:.1f} s"}
 
 
+def secondary(dev, region_s=0.3):
+    """The other operating points of the path, timed in the same process after the headline region (rank 0, N = 1), each for
+    >= `region_s` of back-to-back launches bracketed by HIP events on the launch stream: BASELINE configs[4] (full step +
+    birdview raster, two launches per timestep), the closed loop at the headline shape (one launch per timestep), configs[1]
+    (kinematics + collision only), the headline with the traffic-light term, and the headline with episodes that only
+    end by truncation at 200 steps (the long-episode regime of SURVEY 8d; the headline's uniformly random ego leaves the
+    road after ~50 steps)."""
+    import ctypes
+
+    import torch
+
+    from torchdriveenv_amd import _abi, _ext, ops
+    from torchdriveenv_amd.state import EnvState
+    from torchdriveenv_amd.synth import synthetic_world
+
+    worlds = {}
+
+    def world_of(A):
+        if A not in worlds:
+            w = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+            worlds[A] = (w, w.to_device(dev))
+        return worlds[A]
+
+    def run(name, config, B, A, stepwise, flags, render=False, **cfg_over):
+        w, dw = world_of(A)
+        cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=flags, **cfg_over)
+        st = EnvState(B, A, device=dev, with_info=False)
+        ops.env_reset(cfg, dw, st)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        actions = torch.stack([torch.rand(CH, B, generator=g) * 2 - 1, torch.rand(CH, B, generator=g) * 0.6 - 0.3], -1)
+        actions = actions.to(torch.float32).contiguous().to(dev)
+        reward = torch.empty((CH, B), dtype=torch.float32, device=dev)
+        done = torch.empty((CH, B), dtype=torch.uint8, device=dev)
+        rows = [actions[i] for i in range(CH)]
+        img = ops.render_ego(cfg, dw, st) if render else None
+        h = None
+        if stepwise:
+            h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct), dev.index or 0)
+
+        def block():                                   # CH consecutive timesteps
+            if not stepwise:
+                ops.env_rollout(cfg, dw, st, actions, reward, done)
+                return
+            for i in range(CH):
+                h.step(rows[i], int(cfg.flags))
+                if render:
+                    h.render(img, 64, 64, 35.0, 1, None, 0, 0, None, None)
+
+        t0 = time.perf_counter()
+        block()
+        torch.cuda.synchronize()
+        per_block = max(time.perf_counter() - t0, 1e-6)
+        block()                                        # (second warm block: clocks, caches)
+        n = max(1, int(-(-region_s // per_block)))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            block()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (n * CH)
+        bpes = bytes_per_env_step(config, A)
+        ach = bpes * B / (us * 1e-6) / 1e9
+        return {"workload": name, "envs": B, "agents_per_env": A, "us_per_step": us, "env_steps_per_s": B / us * 1e6,
+                "agent_steps_per_s": B * A / us * 1e6, "timed_steps": n * CH, "launches_per_step": (2 if render else 1) if stepwise else 1.0 / CH,
+                "roofline": {"bound": "hbm", "bytes_per_env_step": bpes, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": ach / HBM_PEAK_GBPS},
+                "done_frac_last_step": float((st["terminated"] | st["truncated"]).float().mean())}
+
+    F = _abi.F_ALL
+    out = {}
+    for key, kw in (
+        ("config5", dict(name="configs[4]: 8192 envs x 32 agents, full step + 64x64x3 birdview (step launch + raster launch per timestep)",
+                         config=5, B=8192, A=32, stepwise=True, flags=F, render=True)),
+        ("closed_loop", dict(name="configs[2] shape, closed loop: one tde_env_step launch per timestep through the extension",
+                             config=3, B=8192, A=16, stepwise=True, flags=F)),
+        ("config2", dict(name="configs[1]: 1024 envs x 8 agents, kinematics + collision only, 250 steps per launch",
+                         config=2, B=1024, A=8, stepwise=False, flags=0)),
+        ("lights", dict(name="configs[2] + traffic-light / stop-line term (TDE_F_TRAFFIC_LIGHTS), rollout",
+                        config=3, B=8192, A=16, stepwise=False, flags=F | _abi.F_TRAFFIC_LIGHTS)),
+        ("long_episodes", dict(name="configs[2] with episodes that end by truncation at 200 steps only (terminated_at_infraction = 0), rollout",
+                               config=3, B=8192, A=16, stepwise=False, flags=F, terminated_at_infraction=0)),
+    ):
+        try:
+            out[key] = run(**kw)
+        except Exception as exc:                       # pragma: no cover
+            out[key] = {"error": repr(exc)}
+    return out
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -208,6 +299,9 @@ def main():
                          "5 = 32 agents + birdview raster")
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary operating points (config 5, closed loop, config 2, lights, long episodes) that a "
+                         "default N = 1 headline run reports under `secondary`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process group of the N>1 barrier / timing reduce (nccl = RCCL, one rank per GPU; gloo for "
                          "tests that put several ranks on one GPU)")
@@ -404,7 +498,10 @@ def main():
         kern_us = sum(dur_us) / max(1, sum(lens)) * spl               # average duration per launch of `spl` steps
         alg_launch = float(bpes * B * spl)
         achieved = alg_launch / (kern_us * 1e-6) / 1e9
-        traffic = None
+        # HBM traffic per launch: NOT measured in this run (PMC counters need rocprofv3) - the figure of the builder's own
+        # separate --pmc passes over the same shape (profiles/traffic.json), labelled as such
+        traffic = traffic_source = None
+        issue = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.config == 3 and not stepwise:
             try:
@@ -412,6 +509,17 @@ def main():
                 full = [k for k in lens if k == CH]
                 if tj.get("steps_per_launch") == CH and tj.get("envs") == B and len(full) >= len(lens) - 1 and full:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
+                    # the bound that describes this kernel: VALU issue.  insts per 64-slot group and step from the
+                    # builder's SQ_INSTS_VALU pass; a SIMD issues one wave64 VALU instruction per 2 cycles
+                    vi = tj.get("valu_insts_per_group_step")
+                    if vi:
+                        groups_per_simd = B * A / 64.0 / 1024.0
+                        floor_us = vi * groups_per_simd * 2.0 / (tj.get("clock_ghz", 2.4) * 1e3)
+                        issue = {"insts_per_group_step": vi, "groups_per_simd": groups_per_simd, "cycles_per_inst": 2,
+                                 "clock_ghz": tj.get("clock_ghz", 2.4), "floor_us_per_step": floor_us,
+                                 "frac": floor_us / (kern_us / spl),
+                                 "source": "profiles/traffic.json (builder's SQ_INSTS_VALU pass)"}
             except Exception:
                 traffic = None
         out = {
@@ -428,7 +536,9 @@ def main():
                                    "no data-path collective",
                        "timing_backend": (args.backend if n > 1 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kernel,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "measured_hbm_GBps": (traffic / (kern_us * 1e-6) / 1e9 if traffic else None),
+                         "valu_issue": issue, "kernel": kernel,
                          "kernel_avg_us": kern_us, "kernel_min_us": per[0] if per else None,
                          "kernel_median_us": per[len(per) // 2] if per else None,
                          "launches": (sum(lens) if stepwise else len(lens)), "steps_per_launch": spl,
@@ -437,6 +547,8 @@ def main():
                          "timer": "HIP events on the launch stream around every timed launch (rank 0)"},
             "check": chk,
         }
+        if n == 1 and args.config == 3 and not stepwise and not args.no_secondary:
+            out["secondary"] = secondary(dev)
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, base_cfg, A)
         print(json.dumps(out), flush=True)

@@ -253,7 +253,8 @@ typedef struct tde_rollout {
     uint8_t *done;              /* [K][B] bit0 terminated, bit1 truncated, bit2 ego offroad, bit3 ego collided,
                                    bit4 ego red-light violation */
     int32_t K;
-    int32_t _pad0;
+    int32_t ldb;                /* row pitch of the three [K][..] buffers in envs; 0 = B (how a shard [e0, e0 + n) of a larger
+                                   batch is stepped on buffers of the whole batch: pointers advanced by e0, ldb = the batch) */
 } tde_rollout;
 
 /* ego-centred, ego-aligned birdview raster (R13; BASELINE config 5).  Observation space (3,64,64) uint8, channels

@@ -97,7 +97,7 @@ class TdeState(C.Structure):
 
 
 class TdeRollout(C.Structure):
-    _fields_ = [("actions", _p), ("reward", _p), ("done", _p), ("K", C.c_int32), ("_pad0", C.c_int32)]
+    _fields_ = [("actions", _p), ("reward", _p), ("done", _p), ("K", C.c_int32), ("ldb", C.c_int32)]
 
 
 class TdeRender(C.Structure):

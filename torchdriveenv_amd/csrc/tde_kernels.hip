@@ -893,6 +893,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     const int64_t g = (int64_t)blockIdx.x * kWave + threadIdx.x;
     const int e = (int)(g / A), a = (int)(g % A);
     const int B = st.B;
+    const int LB = ro.ldb;                                  // row pitch of the [K][..] action / reward / done buffers
     const bool valid = e < B;
     const int64_t gs = valid ? g : 0;
     const int es = valid ? e : 0;
@@ -911,12 +912,12 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
-        const float2 act_next = acts[(int64_t)kn * B + es];      // in flight during this step
+        const float2 act_next = acts[(int64_t)kn * LB + es];      // in flight during this step
         o = step_lane<A, kWave, LIGHTS>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
         if (valid && a == 0) {
-            if (ro.reward) ro.reward[(int64_t)k * B + e] = o.reward;
+            if (ro.reward) ro.reward[(int64_t)k * LB + e] = o.reward;
             if (ro.done)
-                ro.done[(int64_t)k * B + e] =
+                ro.done[(int64_t)k * LB + e] =
                     (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
         }
         act = act_next;
@@ -1021,6 +1022,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
     const int B = st.B;
+    const int LB = ro.ldb;                                  // row pitch of the [K][..] action / reward / done buffers
     const bool valid = e < B;
     const int64_t gs = valid ? g : 0;
     const int es = valid ? e : 0;
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1, q = p ^ 1;
             const int kn = (i + 1 < ro.K) ? i + 1 : i;
-            const float2 act_next = acts[(int64_t)kn * B + es];
+            const float2 act_next = acts[(int64_t)kn * LB + es];
             float nx, ny, npsi, nv, nc, ns;
             int nwp, k, n_target = er.target_idx, n_reached = er.reached;
             bool switched, live;
@@ -1128,7 +1130,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                     if (st.info_reached) st.info_reached[e] = er.reached;
                     if (advanced) load_ego_target(cold, er, cx);   // (a finished env reloads it when it re-spawns)
                 }
-                if (ro.reward) ro.reward[(int64_t)i * B + e] = rw.reward;
+                if (ro.reward) ro.reward[(int64_t)i * LB + e] = rw.reward;
             }
             act = act_next;
         }
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             }
             if (lane == 0) sh.done = any;
             if (valid && a == 0 && ro.done)
-                ro.done[(int64_t)i * B + e] =
+                ro.done[(int64_t)i * LB + e] =
                     (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
             if (any && ((any >> base) & 1ull) && valid) {
                 reset_lane<A>(cfg, cold, e, a, ag, er);
@@ -1278,6 +1280,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
     const int B = st.B;
+    const int LB = ro.ldb;                                  // row pitch of the [K][..] action / reward / done buffers
     const bool valid = e < B;
     const int64_t gs = valid ? g : 0;
     const int es = valid ? e : 0;
@@ -1426,7 +1429,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 const int s1 = envbits ? __ffs((int)envbits) - 1 : A;      // first reaching step of this env (A: none)
                 if (act && a >= from && a <= s1) {
                     const float rwd = reward_sum(cold, a == s1, dist_r, psi_r);
-                    if (ro.reward) ro.reward[(int64_t)(ipend0 + a) * B + e] = rwd;
+                    if (ro.reward) ro.reward[(int64_t)(ipend0 + a) * LB + e] = rwd;
                     if (final && a == n - 1) {               // the launch's last step: the per-env outputs
                         st.reward[e] = rwd;
                         if (st.info) {
@@ -1463,7 +1466,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     const uint32_t sft = (uint32_t)lane & 31u;
                     const uint32_t hb = ((up ? m0.y : m0.x) >> sft) & 1u, ob = ((up ? m0.w : m0.z) >> sft) & 1u,
                                    tb = ((up ? m1.y : m1.x) >> sft) & 1u;
-                    ro.done[(int64_t)i * B + e] = (uint8_t)(last_term | (last_trunc << 1) | (ob << 2) | (hb << 3) | (tb << 4));
+                    ro.done[(int64_t)i * LB + e] = (uint8_t)(last_term | (last_trunc << 1) | (ob << 2) | (hb << 3) | (tb << 4));
                 }
             }
             return dn;
@@ -1502,7 +1505,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 npend += 1;
                 if (npend == A && i + 1 < ro.K) flush(false);        // (the launch's last step is closed by the final flush)
             } else if (a == 0 && valid && ro.reward) {
-                ro.reward[(int64_t)i * B + e] = 0.0f;
+                ro.reward[(int64_t)i * LB + e] = 0.0f;
             }
         }
         lds_barrier();                                       // A'
@@ -1535,13 +1538,13 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         const bool ego = a == 0 && valid;
         if (ego) {
             sh.act[0][lane] = acts[e];
-            sh.act[1][lane] = acts[(int64_t)(ro.K > 1 ? 1 : 0) * B + e];
+            sh.act[1][lane] = acts[(int64_t)(ro.K > 1 ? 1 : 0) * LB + e];
         }
         lds_barrier();
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1;
             float2 act2 = make_float2(0.0f, 0.0f);
-            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step
+            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * LB + e];   // in flight during this step
             lds_barrier();                                   // A: masks of step i-1 are complete
             lds_barrier();                                   // B: rows of step i are in buffer p
             if (i > 0) {
@@ -2400,38 +2403,49 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     return e == hipSuccess ? 0 : fail("tde_env_step", e);
 }
 
-int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro,
-                    void *stream)
+// number of CUs of the current device (cached per device)
+static int cu_count()
 {
-    int rc = check_env_args("tde_env_rollout", cfg, world, st);
-    if (rc) return rc;
-    if (!ro) return bad("tde_env_rollout: rollout is NULL");
-    if (st->B <= 0 || ro->K <= 0) return 0;
-    if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        cached = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
+// env arrays advanced by e0 envs, agent arrays by e0 * A slots: the shard [e0, e0 + n) of a batch as a tde_state of its own
+static tde_state state_slice(const tde_state &s, int64_t e0, int32_t n)
+{
+    tde_state t = s;
+    const int64_t g0 = e0 * s.A;
+#define TDE_ADV(p, k) if (t.p) t.p += (k)
+    TDE_ADV(x, g0); TDE_ADV(y, g0); TDE_ADV(psi, g0); TDE_ADV(v, g0); TDE_ADV(len, g0); TDE_ADV(wid, g0); TDE_ADV(lr, g0);
+    TDE_ADV(vdes, g0); TDE_ADV(route_wp, g0); TDE_ADV(present, g0); TDE_ADV(collided, g0); TDE_ADV(offroad, g0);
+    TDE_ADV(scn, e0); TDE_ADV(steps, e0); TDE_ADV(target_idx, e0); TDE_ADV(reached, e0); TDE_ADV(episode, e0);
+    TDE_ADV(action, 2 * e0); TDE_ADV(reward, e0); TDE_ADV(terminated, e0); TDE_ADV(truncated, e0); TDE_ADV(tl_violation, e0);
+    TDE_ADV(info, 4 * e0); TDE_ADV(info_reached, e0); TDE_ADV(done_bits, e0); TDE_ADV(obs, 8 * e0); TDE_ADV(ep_return, e0);
+    TDE_ADV(ep_final, e0); TDE_ADV(ep_final_len, e0); TDE_ADV(slot_cache, g0); TDE_ADV(env_cache, e0); TDE_ADV(act_cache, g0);
+#undef TDE_ADV
+    t.B = n;
+    return t;
+}
+
+static int rollout_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, int team,
+                          void *stream)
+{
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-    // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
-    // forces one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median
-    // us per step (scripts/ab_rollout.py duo:... trio:..., profiles/r02_e_rollout_matrix.txt): three roles win at 8 and 16
-    // agents per env, without traffic lights (3.17 vs 3.50, 3.06 vs 3.54) and with them (5.32 vs 5.55, 4.55 vs 5.01), and
-    // at 32 without lights (3.70 vs 4.11); at 32 WITH lights the 32-row sweeps plus the stop-line loops spill under the
-    // 80-VGPR cap and the two-role kernel (128 VGPRs, four wavefronts per SIMD) is faster (5.18 vs 7.66); at 64 the two
-    // are equal (5.03) and two roles run.
-    const int forced = g_force_rollout;
-    const bool lights0 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-    const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
-    const int team = forced ? forced : (st->A == 8 || st->A == 16 || (st->A == 32 && !lights0)) ? 3 : 2;
-    const bool solo = team == 1;
-    if (team == 3 && trio_shape) {
+    const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    if (team == 3) {
 #define TDE_LAUNCH_TRIO(AA)                                                                                              \
-    if (lights0) tde::env_rollout_trio_kernel<AA, true><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro); \
+    if (lights) tde::env_rollout_trio_kernel<AA, true><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro); \
     else tde::env_rollout_trio_kernel<AA, false><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
         if (st->A == 8) { TDE_LAUNCH_TRIO(8); } else if (st->A == 16) { TDE_LAUNCH_TRIO(16); } else { TDE_LAUNCH_TRIO(32); }
 #undef TDE_LAUNCH_TRIO
-        hipError_t e3 = hipGetLastError();
-        return e3 == hipSuccess ? 0 : fail("tde_env_rollout", e3);
-    }
-    const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-    if (solo) {
+    } else if (team == 1) {
         if (lights) {
             TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, true><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
         } else {
@@ -2446,6 +2460,54 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
+}
+
+int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro,
+                    void *stream)
+{
+    int rc = check_env_args("tde_env_rollout", cfg, world, st);
+    if (rc) return rc;
+    if (!ro) return bad("tde_env_rollout: rollout is NULL");
+    if (st->B <= 0 || ro->K <= 0) return 0;
+    if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
+    if (ro->ldb != 0 && ro->ldb < st->B) return bad("tde_env_rollout: rollout.ldb must be 0 (= B) or >= B");
+    // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
+    // forces one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median
+    // us per step (scripts/ab_rollout.py duo:... trio:..., profiles/r02_e_rollout_matrix.txt): three roles win at 8 and 16
+    // agents per env, without traffic lights (3.17 vs 3.50, 3.06 vs 3.54) and with them (5.32 vs 5.55, 4.55 vs 5.01), and
+    // at 32 without lights (3.70 vs 4.11); at 32 WITH lights the 32-row sweeps plus the stop-line loops spill under the
+    // 80-VGPR cap and the two-role kernel (128 VGPRs, four wavefronts per SIMD) is faster (5.18 vs 7.66); at 64 the two
+    // are equal (5.03) and two roles run.
+    const int forced = g_force_rollout;
+    const bool lights0 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
+    int team = forced ? forced : (st->A == 8 || st->A == 16 || (st->A == 32 && !lights0)) ? 3 : 2;
+    if (team == 3 && !trio_shape) team = 2;
+    tde_rollout r = *ro;
+    if (r.ldb == 0) r.ldb = st->B;
+    // The two- and three-role kernels are tuned for ONE residency round of the chip: 8 workgroups (groups of 64 agent slots)
+    // per CU - 8192 envs x 16 agents on 256 CUs.  A larger batch as one grid runs its later rounds badly (16 384 envs:
+    // 1784 us per 250-step launch against 2 x 737; profiles/r03_c_scale_envs.txt), so it is cut into consecutive launches
+    // of one round each on the same stream: envs are independent, every launch runs at the tuned shape, and the last,
+    // partial one is simply a smaller batch.  (A batch of less than 1.5 rounds stays one launch: its few extra workgroups
+    // slip in as the first ones finish.)
+    const int64_t groups = ((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave;
+    const int64_t round = 8 * (int64_t)cu_count();
+    if (team == 1 || 2 * groups < 3 * round) return rollout_launch(cfg, world, st, &r, team, stream);
+    const int64_t envs_per_round = round * (tde::kWave / st->A);
+    for (int64_t e0 = 0; e0 < st->B; e0 += envs_per_round) {
+        const int32_t n = (int32_t)((st->B - e0 < envs_per_round) ? st->B - e0 : envs_per_round);
+        tde_config c = *cfg;
+        c.env_base = cfg->env_base + (uint32_t)e0;                           // the reset RNG is keyed by the global env index
+        const tde_state s = state_slice(*st, e0, n);
+        tde_rollout rr = r;
+        rr.actions = r.actions + 2 * e0;
+        if (rr.reward) rr.reward += e0;
+        if (rr.done) rr.done += e0;
+        rc = rollout_launch(&c, world, &s, &rr, team, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_render *rd,

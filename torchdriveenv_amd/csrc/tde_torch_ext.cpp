@@ -77,7 +77,7 @@ class EnvHandle {
         ro.reward = static_cast<float *>(const_cast<void *>(dev_ptr(reward, at::kFloat, K * state_.B, "reward", dev_)));
         ro.done = static_cast<uint8_t *>(const_cast<void *>(dev_ptr(done, at::kByte, K * state_.B, "done", dev_)));
         ro.K = static_cast<int32_t>(K);
-        ro._pad0 = 0;
+        ro.ldb = 0;
         const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
         check_rc(tde_env_rollout(&cfg_, &world_, &state_, &ro, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_env_rollout");
     }
