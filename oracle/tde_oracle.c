@@ -293,6 +293,40 @@ TDE_EXPORT void tde_oracle_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint3
 /* uniform in [0,1) with 24 random bits, exact in fp32 and fp64 */
 static inline double tde_u01(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 
+/* Natural logarithm of a normal fp32 u > 0 - ONE specification shared with the HIP kernels (tde_device.h: log_f32), like
+ * tde_oracle_sincosf: u = m * 2^e with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m - 1) / (m + 1) (one IEEE division),
+ * odd polynomial of degree 9 in s evaluated with explicit fmaf, e * ln 2 added in two parts.  Absolute error < 2e-7 on
+ * (0, 1]; what matters here is that CPU and GPU return the same bits. */
+TDE_EXPORT float tde_oracle_logf(float u)
+{
+    uint32_t b;
+    memcpy(&b, &u, 4);
+    int32_t e = (int32_t)(b >> 23) - 127;
+    uint32_t mb = (b & 0x007fffffu) | 0x3f800000u;           /* m in [1, 2) */
+    if (mb > 0x3fb504f3u) { mb -= 0x00800000u; e += 1; }     /* m > sqrt(2): halve it */
+    float m;
+    memcpy(&m, &mb, 4);
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    float p = fmaf(z, 0.11111111f, 0.14285715f);
+    p = fmaf(p, z, 0.2f);
+    p = fmaf(p, z, 0.33333334f);
+    p = fmaf(p, z, 1.0f);
+    const float lm = (s + s) * p;
+    const float fe = (float)e;
+    return fmaf(fe, 6.9314575195e-1f, fmaf(fe, 1.4286067653e-6f, lm));      /* ln 2 = hi + lo, e * hi exact */
+}
+
+/* standard normal from two 32-bit random words (Box-Muller, fp32; ref gym_env.py:361 np.random.normal): |z| < 5.8 */
+static float tde_normal(uint32_t ra, uint32_t rb)
+{
+    const float u1 = ((float)(ra >> 8) + 0.5f) * (1.0f / 16777216.0f);       /* (0, 1): the logarithm is finite */
+    const float u2 = (float)(rb >> 8) * (1.0f / 16777216.0f);                /* [0, 1) */
+    float sn, cs;
+    tde_oracle_sincosf(TDE_TWO_PI_F * u2, &sn, &cs);
+    return sqrtf(-2.0f * tde_oracle_logf(u1)) * cs;
+}
+
 /* WaypointSuiteEnv.reset (gym_env.py:319-349) + set_start_pos (:351-367) + build_simulator's initial
  * tensors (:192-198, :241-247) for one env. */
 static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *st, int32_t e)
@@ -300,7 +334,7 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
     const int32_t A = st->A;
     uint32_t ep = (uint32_t)st->episode[e];
     const uint32_t ge = cfg->env_base + (uint32_t)e;   /* global env index keys the stream */
-    uint32_t r0[4], r1[4], rn[4];
+    uint32_t r0[4], r1[4];
     tde_oracle_philox(cfg->seed, ge, ep, 0u, 0x7DEu, r0);
     tde_oracle_philox(cfg->seed, ge, ep, 1u, 0x7DEu, r1);
     /* np.random.randint(len(waypoint_suite))  :320 */
@@ -311,13 +345,9 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
     double sx = wp[0] + f * (wp[2] - wp[0]);
     double sy = wp[1] + f * (wp[3] - wp[1]);
     double speed = tde_u01(r0[2]) * 10.0;
-    /* start_orientation = lanelet direction + normal(0, 0.1)  :359-361; normal = Irwin-Hall(12) - 6 */
-    double acc = 0.0;
-    for (uint32_t b = 0; b < 3; ++b) {
-        tde_oracle_philox(cfg->seed, ge, ep, 2u + b, 0x7DEu, rn);
-        for (int k = 0; k < 4; ++k) acc += tde_u01(rn[k]);
-    }
-    double psi0 = (double)w->scn[scn].start_heading + (acc - 6.0) * 0.1;
+    /* start_orientation = lanelet direction + normal(0, 0.1)  :359-361 (round 3: a true Gaussian, Box-Muller on the shared
+     * fp32 log / sincos specifications; rounds 1-2 used Irwin-Hall(12) - 6, whose tails end at +-0.6 rad) */
+    double psi0 = (double)w->scn[scn].start_heading + (double)tde_normal(r1[2], r1[3]) * 0.1;
 
     st->scn[e] = scn;
     st->steps[e] = 0;          /* :339 */

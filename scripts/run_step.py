@@ -1,0 +1,26 @@
+"""N closed-loop steps (one tde_env_step launch each) for rocprofv3 passes.
+usage: python3 scripts/run_step.py [steps] [solo|trio] [agents] [envs]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torchdriveenv_amd import _abi, _lib, ops
+from torchdriveenv_amd.state import EnvState
+from torchdriveenv_amd.synth import synthetic_world
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+kern = sys.argv[2] if len(sys.argv) > 2 else None
+A = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 8192
+dev = torch.device("cuda:0")
+world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+dw = world.to_device(dev)
+cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
+_lib.kernel_override(step=kern if kern in ("solo", "trio") else None)
+st = EnvState(B, A, device=dev, with_info=False)
+ops.env_reset(cfg, dw, st)
+g = torch.Generator().manual_seed(0)
+acts = torch.stack([torch.rand(250, B, generator=g) * 2 - 1, torch.rand(250, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)
+ops.env_rollout(cfg, dw, st, acts)                      # a steady-state mix of episode ages
+for i in range(n):
+    ops.env_step(cfg, dw, st, action=acts[i % 250])
+torch.cuda.synchronize()
+print("ok", n, "steps", kern)

@@ -63,6 +63,36 @@ TDE_DEV float sin_small_f32(float x)
     return s;
 }
 
+// Natural logarithm of a normal fp32 u > 0, the specification shared with the CPU checker (its logf): same
+// operations, every multiply-add an explicit fmaf, one IEEE division.
+TDE_DEV float log_f32(float u)
+{
+    const uint32_t b = __float_as_uint(u);
+    int e = (int)(b >> 23) - 127;
+    uint32_t mb = (b & 0x007fffffu) | 0x3f800000u;
+    if (mb > 0x3fb504f3u) { mb -= 0x00800000u; e += 1; }
+    const float m = __uint_as_float(mb);
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float z = s * s;
+    float p = __builtin_fmaf(z, 0.11111111f, 0.14285715f);
+    p = __builtin_fmaf(p, z, 0.2f);
+    p = __builtin_fmaf(p, z, 0.33333334f);
+    p = __builtin_fmaf(p, z, 1.0f);
+    const float lm = (s + s) * p;
+    const float fe = (float)e;
+    return __builtin_fmaf(fe, 6.9314575195e-1f, __builtin_fmaf(fe, 1.4286067653e-6f, lm));
+}
+
+// standard normal from two 32-bit random words (Box-Muller on the shared log / sincos specifications; tde_normal of the checker)
+TDE_DEV float normal_f32(uint32_t ra, uint32_t rb)
+{
+    const float u1 = ((float)(ra >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(rb >> 8) * (1.0f / 16777216.0f);
+    float sn, cs;
+    sincos_f32(kTwoPi * u2, sn, cs);
+    return __builtin_sqrtf(-2.0f * log_f32(u1)) * cs;
+}
+
 // the squared threshold d^2 is compared with (tde_config.offroad_threshold_squared selects the reading of upstream)
 TDE_DEV float thr2_of(const tde_config &cfg)
 {

@@ -263,11 +263,10 @@ TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, co
 
 // WaypointSuiteEnv.reset + set_start_pos + build_simulator's initial tensors for one env (ref gym_env.py:319-367,
 // 192-198, 241-247); every lane of the env runs it for its own slot.  Mirrors tde_reset_env of the oracle.
-// SPREAD (every caller: the lanes of an env enter together - the condition is per env): with A >= 8 the ego needs
-// five Philox blocks (counter words 0..4) and every other lane block 0; evaluated one after the other that is ~450
-// instructions for a wavefront in which an env re-spawns (7 % of the steps).  Instead lane a of the env computes block a -
-// ONE evaluation - and the words travel by wavefront shuffles (ds_bpermute): block 0 to every lane of the env, blocks
-// 1..4 to its ego.  Same counters, same words, same arithmetic behind them.
+// SPREAD (every caller: the lanes of an env enter together - the condition is per env): with A >= 8 the ego needs two
+// Philox blocks (counter words 0, 1) and every other lane block 0; lane a of the env computes block a - ONE evaluation -
+// and the words travel by wavefront shuffles (ds_bpermute): block 0 to every lane of the env, block 1 to its ego.  Same
+// counters, same words, same arithmetic behind them.
 template <int A, bool SPREAD = true>
 TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er)
 {
@@ -275,7 +274,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
     const uint32_t ge = w.env_base + (uint32_t)e;       // global env index keys the stream
     const uint64_t seed = w.seed;
     constexpr bool spread = SPREAD && A >= 8;
-    uint4 r0, r1s = make_uint4(0, 0, 0, 0), rn[3];
+    uint4 r0, r1s = make_uint4(0, 0, 0, 0);
     if constexpr (spread) {
         const uint4 mine = philox(seed, ge, ep, (uint32_t)a, 0x7DEu);
         const int first = (int)(threadIdx.x & 63) - a;   // the env's first lane in the wavefront
@@ -283,7 +282,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
             return make_uint4((uint32_t)__shfl((int)mine.x, first + k), (uint32_t)__shfl((int)mine.y, first + k),
                               (uint32_t)__shfl((int)mine.z, first + k), (uint32_t)__shfl((int)mine.w, first + k));
         };
-        r0 = block(0); r1s = block(1); rn[0] = block(2); rn[1] = block(3); rn[2] = block(4);
+        r0 = block(0); r1s = block(1);
     } else {
         r0 = philox(seed, ge, ep, 0u, 0x7DEu);
     }
@@ -308,14 +307,8 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
         double sx = wp[0] + f * (wp[2] - wp[0]);
         double sy = wp[1] + f * (wp[3] - wp[1]);
         double speed = u01(r0.z) * 10.0;
-        double acc = 0.0;
-#pragma unroll
-        for (uint32_t b = 0; b < 3; ++b) {
-            uint4 rb = rn[b];
-            if constexpr (!spread) rb = philox(seed, ge, ep, 2u + b, 0x7DEu);
-            acc += u01(rb.x); acc += u01(rb.y); acc += u01(rb.z); acc += u01(rb.w);
-        }
-        double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (acc - 6.0) * 0.1;
+        // start heading + normal(0, 0.1) (ref gym_env.py:359-361): Box-Muller on the shared log / sincos specifications
+        double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (double)normal_f32(r1.z, r1.w) * 0.1;
         ag.x = (float)sx; ag.y = (float)sy; ag.psi = (float)psi0; ag.v = (float)speed;
         ag.present = true; ag.route = -1; ag.replay = -1; ag.vdes = 0.0f;
         if (cfg.flags & TDE_F_EGO_ONLY_ATTRS) {

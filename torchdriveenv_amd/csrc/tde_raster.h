@@ -291,7 +291,15 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
         const float u8 = V.hu - (float)r8 - 3.5f, v8 = V.hv - (float)c8 - 3.5f;   // the block's centre
         uint32_t need1 = 0;                                                   // bit s: 4x4 sub-block s needs splitting
         {
-            const uint32_t wd = have ? raster_lookup(J, V, u8, v8) : 0u;
+            // the block's own look-up and those of its four 4x4 sub-blocks are issued TOGETHER (the sub-blocks' are wasted
+            // when the 8x8 block turns out uniform - about half of them - but a dependent round trip is what a view pays for)
+            uint32_t wd = 0u, w4[4] = {0u, 0u, 0u, 0u};
+            if (have) {
+                wd = raster_lookup(J, V, u8, v8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    w4[s] = raster_lookup(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
+            }
             const uint32_t cls = wd & 3u;
             const bool uni = cls != TDE_CELL_MIXED && (int)((wd >> 2) & 255u) >= J.K8;
             if (have && uni) {
@@ -300,10 +308,6 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
                 for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2 *>(p8 + (r8 + i) * Wp + c8) = val;
             }
             if (have && !uni) {
-                uint32_t w4[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    w4[s] = raster_lookup(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const uint32_t c4 = w4[s] & 3u;
@@ -558,7 +562,15 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
             }
         }
     } else {
-        for (int i = lane; i < nv; i += 64) raster_expand(chunk(i), J.out + 3 * (ns - 1) * plane, plane, i);
+        if (SIZE == 64 && !(TDE_RASTER_SKIP & 8)) {          // the four 16-byte reads of a lane in flight together
+            uint4 ch[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ch[k] = reinterpret_cast<const uint4 *>(S.plane)[lane + 64 * k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) raster_expand(ch[k], J.out + 3 * (ns - 1) * plane, plane, lane + 64 * k);
+        } else {
+            for (int i = lane; i < nv; i += 64) raster_expand(chunk(i), J.out + 3 * (ns - 1) * plane, plane, i);
+        }
         if (J.fresh && ns > 1) {                     // in-place stack (no ring): blank the older frames of this view
             uint4 *o4 = reinterpret_cast<uint4 *>(J.out);
             for (int i = lane; i < 3 * (ns - 1) * nv; i += 64) o4[i] = make_uint4(0u, 0u, 0u, 0u);
