@@ -71,8 +71,9 @@ def test_rollout_equals_repeated_steps_and_reward_bounds(small_world):
         assert np.array_equal(b["terminated"] | (b["truncated"] << 1), d[k] & 3)
     ha, hb = a.host(), b.host()
     for k in ha:
-        # (the Monitor-style episode statistics belong to the closed-loop step API; a rollout leaves them alone)
-        if k != "action" and not k.startswith("ep_"):
+        # (the Monitor-style episode statistics and done_bits belong to the closed-loop step API; a rollout leaves them
+        #  alone: tde_abi.h, "tde_env_step only")
+        if k not in ("action", "done_bits") and not k.startswith("ep_"):
             assert np.array_equal(ha[k].view(np.uint8), hb[k].view(np.uint8)), k
     assert not ha["ep_return"].any() and hb["ep_final_len"].max() > 0
     # reward = waypoint_bonus*[reach] + distance_bonus*[moved] - heading_penalty*(1 - cos dpsi)
