@@ -482,9 +482,9 @@ def main():
         env_steps = B * n * total
         # dominant kernel: rollout = tde::env_rollout_trio_kernel<A> (drive + two judge wavefronts per 64 agent slots;
         # --rollout-kernel duo|solo force the two- / one-wavefront forms), one launch per <= CH timesteps;
-        # step mode = tde::env_step_kernel<A>; config 5 = step + tde::render_layers_kernel per timestep
+        # step mode = tde::env_step_kernel<A>; config 5 = step + tde::render_views_kernel per timestep
         if args.config == 5:
-            kernel = f"tde::env_step_kernel<{A}> + tde::render_layers_kernel"
+            kernel = f"tde::env_step_kernel<{A}> + tde::render_views_kernel<64>"
         elif stepwise:
             trio = st["slot_cache"] is not None and A in (8, 16, 32) and (
                 args.step_kernel == "trio" or (args.step_kernel is None and B * A <= 65536))

@@ -1,3 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python scripts/ab_rollout.py ab/libpre_bm.so torchdriveenv_amd/libtde_hip.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_ab_boxmuller.txt
+for B in 1024 4096 8192; do TDE_HIP_LIB=$PWD/ab/libS.so python scripts/phase_stamps.py trio $B 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r03_phase_stamps_trio.txt

@@ -114,7 +114,7 @@ def patch_trio(s):
     k = sub(k, "                                  cx.g_far, red_gap, na, nb);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                nx = ag.x;",
             "                                  cx.g_far, red_gap, na, nb, &stl);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                tde_mark(&stl, 3);\n                nx = ag.x;")
     k = sub(k, "                switched = false;\n                nwp = ag.route_wp;", "                tde_mark(&stl, 4);\n                switched = false;\n                nwp = ag.route_wp;")
-    k = sub(k, "                sincos_f32(npsi, ns, nc);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n",
+    k = sub(k, "                sincos_f32(npsi, ns, nc);\n                TDE_PROBE(TDE_DUMMY_D, nx);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n",
             "                sincos_f32(npsi, ns, nc);\n                tde_mark(&stl, 5);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n                tde_mark(&stl, 6);\n")
     k = sub(k, "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            if (switched) load_route_target(cold, ag, cx);\n        }\n",
             "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            tde_mark(&stl, 7);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 8);\n            if (switched) load_route_target(cold, ag, cx);\n            tde_mark(&stl, 9);\n        }\n        tde_flush(0, 10);\n")
@@ -124,11 +124,11 @@ def patch_trio(s):
     k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)",
             "            tde_mark(&stl, 13);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 14);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)")
     k = sub(k, "            if (lane == 0) sh.hit_mask = m;\n", "            if (lane == 0) sh.hit_mask = m;\n            tde_mark(&stl, 15);\n")
-    k = sub(k, "                ro.reward[(int64_t)i * B + e] = 0.0f;\n            }\n        }\n        lds_barrier();                                       // A'",
-            "                ro.reward[(int64_t)i * B + e] = 0.0f;\n            }\n            tde_mark(&stl, 16);\n        }\n        tde_flush(12, 17);\n        lds_barrier();                                       // A'")
+    k = sub(k, "                ro.reward[(int64_t)i * LB + e] = 0.0f;\n            }\n        }\n        lds_barrier();                                       // A'",
+            "                ro.reward[(int64_t)i * LB + e] = 0.0f;\n            }\n            tde_mark(&stl, 16);\n        }\n        tde_flush(12, 17);\n        lds_barrier();                                       // A'")
     # ---- judge O
-    k = sub(k, "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
-            "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * B + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 18);\n")
+    k = sub(k, "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * LB + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
+            "            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * LB + e];   // in flight during this step\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 18);\n")
     k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            float2 act2",
             "        lds_barrier();\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            float2 act2")
     # (the done test moved behind barrier B: "done test + re-spawn" = slot 19 is what runs between B and the row reads)
