@@ -1,2 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for B in 1024 4096 8192; do TDE_HIP_LIB=$PWD/ab/libS.so python scripts/phase_stamps.py trio $B 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r03_phase_stamps_trio.txt
+timeout 600 python -m pytest tests -x -q -m gpu -k "render or frame_stack or birdview or obs or config1 or loader" 2>&1 | tail -3
+python scripts/ab_render.py ab/libpaint1.so torchdriveenv_amd/libtde_hip.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_render_carry.txt

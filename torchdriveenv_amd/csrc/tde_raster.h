@@ -42,25 +42,16 @@ constexpr int kRasterMaxPix = 4096;              // padded H * W limit: the view
 constexpr int kRasterBlockQ = 256;               // listed 4x4 blocks (an image has at most 256)
 constexpr int kRasterMixQ = 384;                 // pixels in MIXED cells awaiting their sub-cell class / triangle tests (a trip
                                                  // of the pixel stage appends <= 256: resolved early when that might not fit)
-constexpr int kRasterBatch = 16;                 // objects culled and painted per round (any number per view: rounds)
 
-// LDS of one view: 5120 B = 160 KiB / 32, i.e. eight wavefronts (views) per SIMD.  The queues of the base layer and the
-// object records of the paint passes are never live together.
+// LDS of one view: 5120 B = 160 KiB / 32, i.e. eight wavefronts (views) per SIMD.  (Object records never touch LDS: the
+// paint passes broadcast them from the lane that formed them.)
 struct RasterQueues {
     uint8_t blockq[kRasterBlockQ];               // index of a 4x4 block: (r0 / 4) * (padded W / 4) + c0 / 4
     uint16_t mixq[kRasterMixQ];                  // (r << 8) | c of a pixel
 };
-struct RasterObjects {
-    // box: (p0, pa, pb, hl) (q0, qa, qb, hw) (span: rmin | rmax << 8 | cmin << 16 | cmax << 24, layer, -, -)
-    float4 box[kRasterBatch][3];
-    float4 wp[kRasterBatch];                     // disc: (dx0, dy0, span, -)
-};
 struct RasterScratch {
     uint32_t plane[kRasterMaxPix / 4];
-    union {
-        RasterQueues q;
-        RasterObjects o;
-    };
+    RasterQueues q;
 };
 static_assert(sizeof(RasterScratch) == 5120, "eight views per SIMD");
 
@@ -282,6 +273,20 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
     const int ego_layer = (J.flags & TDE_RENDER_PLAIN_EGO) ? TDE_LAYER_NPC : TDE_LAYER_EGO;
     const float rview = 0.75f * J.res * (float)(H > W ? H : W) + 1.0f;        // view circle: the culled lists are supersets
 
+    // the first 64 candidates of every kind of object (stop lines, waypoints, agent slots) are fetched together (one memory round
+    // trip instead of three).  (Issued earlier - ahead of the last MIXED-pixel resolution - their ten registers spill: 21 VGPR
+    // spills under the 64-VGPR cap of eight views per SIMD.)
+    float4 la0 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), lb0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    double2 wp0 = make_double2(0.0, 0.0);
+    typename std::remove_reference<AgentSrc>::type::Raw raw0{};
+    auto fetch_objects = [&]() {
+        if (J.lights && lane < J.m.n_stop) {
+            la0 = reinterpret_cast<const float4 *>(J.stoplines + lane)[0];
+            lb0 = reinterpret_cast<const float4 *>(J.stoplines + lane)[1];
+        }
+        if (J.ti + lane < J.n_wp) wp0 = reinterpret_cast<const double2 *>(J.wp)[J.ti + lane];
+        if (lane < J.A) raw0 = agent.fetch(lane);
+    };
     // ---- base layer, 8x8 -> 4x4 -> 2x2 blocks -> pixels; lane b owns 8x8 block b ---------------------------------------
     {
         const int nbw = Wp >> 3, nblk = (Hp >> 3) * nbw, nb4w = Wp >> 2;      // nblk <= 64
@@ -373,6 +378,8 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
                     ns += (int)__popcll(um);
                 }
                 wave_phase();
+                // (fetching the cell word beside the sub-cell word and carrying it through LDS - one dependent round trip
+                //  less for the undecided pixels, 130 more look-ups per view - is a wash: 39.1 vs 38.6 us)
                 for (int b2 = 0; b2 < ns; b2 += 64) {
                     const int i = b2 + lane;
                     if (i < ns) {
@@ -414,37 +421,22 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
     wave_phase();
 
     // ---- objects over the base, in layer order: stop lines (index order: a later line wins where two overlap), waypoint
-    // discs, NPC boxes, the ego.  Each kind is culled to the view circle 64 candidates at a time (ballot / mbcnt compaction
-    // keeps the index order) and painted kRasterBatch records per round --------------------------------------------------
+    // discs, NPC boxes, the ego.  Each kind is culled to the view circle 64 candidates at a time, every lane forming the
+    // record of its own candidate; the kept ones are then painted one after the other in lane (= index) order, their records
+    // broadcast from the owning lane with v_readlane - no LDS round trip, no list, any number of objects per view -------------
+    auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     auto paint_boxes = [&](bool keep, const float4 &P, const float4 &Q, uint32_t span, uint32_t lay) {
-        if (TDE_RASTER_SKIP & 4) keep = false;
-        unsigned long long km = __ballot(keep);
+        unsigned long long km = (TDE_RASTER_SKIP & 4) ? 0ull : __ballot(keep);
         while (km) {
-            const int idx = lane_prefix(km);
-            const bool mine = keep && idx < kRasterBatch;
-            if (mine) {
-                S.o.box[idx][0] = P; S.o.box[idx][1] = Q;
-                S.o.box[idx][2] = make_float4(__uint_as_float(span), __uint_as_float(lay), 0.0f, 0.0f);
-            }
-            const int n = min((int)__popcll(km), kRasterBatch);
-            wave_phase();
-            for (int k = 0; k < n; ++k) raster_paint_box(p8, V, Wp, S.o.box[k][0], S.o.box[k][1], S.o.box[k][2], lane);
-            wave_phase();
-            keep = keep && !mine;
-            km = __ballot(keep);
+            const int l = __ffsll((long long)km) - 1;
+            km &= km - 1ull;
+            const float4 Pb = make_float4(rl(P.x, l), rl(P.y, l), rl(P.z, l), rl(P.w, l));
+            const float4 Qb = make_float4(rl(Q.x, l), rl(Q.y, l), rl(Q.z, l), rl(Q.w, l));
+            const float4 Xb = make_float4(rl(__uint_as_float(span), l), rl(__uint_as_float(lay), l), 0.0f, 0.0f);
+            raster_paint_box(p8, V, Wp, Pb, Qb, Xb, lane);
         }
     };
-    // the first 64 candidates of every kind are fetched together, ahead of the first use (one memory round trip instead of
-    // three on the view's chain)
-    float4 la0 = make_float4(0.0f, 0.0f, 1.0f, 0.0f), lb0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (J.lights && lane < J.m.n_stop) {
-        la0 = reinterpret_cast<const float4 *>(J.stoplines + lane)[0];
-        lb0 = reinterpret_cast<const float4 *>(J.stoplines + lane)[1];
-    }
-    double2 wp0 = make_double2(0.0, 0.0);
-    if (J.ti + lane < J.n_wp) wp0 = reinterpret_cast<const double2 *>(J.wp)[J.ti + lane];
-    typename std::remove_reference<AgentSrc>::type::Raw raw0{};
-    if (lane < J.A) raw0 = agent.fetch(lane);
+    fetch_objects();
     if (J.lights) {
         for (int q0 = 0; q0 < J.m.n_stop; q0 += 64) {
             const int q = q0 + lane;
@@ -470,49 +462,42 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
     for (int k0 = J.ti; k0 < J.n_wp; k0 += 64) {
         const int k = k0 + lane;
         bool keep = false;
-        float tx = 0.0f, ty = 0.0f;
+        float dx0 = 0.0f, dy0 = 0.0f;
+        uint32_t span = 255u;
         if (k < J.n_wp) {
             double2 t = wp0;
             if (k0 > J.ti) t = reinterpret_cast<const double2 *>(J.wp)[k];
-            tx = (float)t.x; ty = (float)t.y;
+            const float tx = (float)t.x, ty = (float)t.y;
             const float dx = tx - J.ex, dy = ty - J.ey, rr = rview + TDE_WAYPOINT_RADIUS;
             keep = dx * dx + dy * dy <= rr * rr;
+            dx0 = V.ex - tx; dy0 = V.ey - ty;
+            span = raster_span(J, V, tx, ty, TDE_WAYPOINT_RADIUS, TDE_WAYPOINT_RADIUS);
         }
-        unsigned long long km = __ballot(keep && !(TDE_RASTER_SKIP & 4));
+        unsigned long long km = (TDE_RASTER_SKIP & 4) ? 0ull : __ballot(keep);
         while (km) {
-            const int idx = lane_prefix(km);
-            const bool mine = keep && idx < kRasterBatch;
-            if (mine)
-                S.o.wp[idx] = make_float4(V.ex - tx, V.ey - ty,
-                                          __uint_as_float(raster_span(J, V, tx, ty, TDE_WAYPOINT_RADIUS, TDE_WAYPOINT_RADIUS)), 0.0f);
-            const int n = min((int)__popcll(km), kRasterBatch);
-            wave_phase();
-            for (int j = 0; j < n; ++j) {
-                const float4 wq = S.o.wp[j];
-                const uint32_t span = __float_as_uint(wq.z);
-                const int rmin = (int)(span & 255u), rmax = (int)((span >> 8) & 255u), cmin = (int)((span >> 16) & 255u),
-                          cmax = (int)(span >> 24);
-                for (int r = rmin + (lane >> 3); r <= rmax; r += 8) {
-                    const float u = V.hu - (float)r;
-                    const float xu = __builtin_fmaf(u, V.ax, wq.x), yu = __builtin_fmaf(u, V.ay, wq.y);
-                    for (int c = cmin + (lane & 7); c <= cmax; c += 8) {
-                        const float v = V.hv - (float)c;
-                        const float dx = __builtin_fmaf(v, V.bx, xu), dy = __builtin_fmaf(v, V.by, yu);
-                        if (__builtin_fmaf(dx, dx, dy * dy) <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS)
-                            p8[r * Wp + c] = TDE_LAYER_WAYPOINT;
-                    }
+            const int l = __ffsll((long long)km) - 1;
+            km &= km - 1ull;
+            const float wx0 = rl(dx0, l), wy0 = rl(dy0, l);
+            const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)span, l);
+            const int rmin = (int)(sp & 255u), rmax = (int)((sp >> 8) & 255u), cmin = (int)((sp >> 16) & 255u), cmax = (int)(sp >> 24);
+            for (int r = rmin + (lane >> 3); r <= rmax; r += 8) {
+                const float u = V.hu - (float)r;
+                const float xu = __builtin_fmaf(u, V.ax, wx0), yu = __builtin_fmaf(u, V.ay, wy0);
+                for (int c = cmin + (lane & 7); c <= cmax; c += 8) {
+                    const float v = V.hv - (float)c;
+                    const float dx = __builtin_fmaf(v, V.bx, xu), dy = __builtin_fmaf(v, V.by, yu);
+                    if (__builtin_fmaf(dx, dx, dy * dy) <= TDE_WAYPOINT_RADIUS * TDE_WAYPOINT_RADIUS)
+                        p8[r * Wp + c] = TDE_LAYER_WAYPOINT;
                 }
             }
-            wave_phase();
-            keep = keep && !mine;
-            km = __ballot(keep);
         }
     }
     {
-        // NPC boxes (slots 1 .. A-1; A <= 64), then the ego
+        // NPC boxes (slots 1 .. A-1; A <= 64) in one pass with the ego, which is painted last: its lane is moved to the end of
+        // the paint order by handling bit 0 of the mask after the others
         float x = 0.0f, y = 0.0f, cb = 1.0f, sb = 0.0f, hl = 0.0f, hw = 0.0f;
         const bool pres = lane < J.A && agent.unpack(raw0, x, y, cb, sb, hl, hw);
-        bool keep = false;
+        bool keep = lane == 0 && pres;                                        // (an absent ego is not painted: the oracle skips it)
         if (pres && lane > 0) {
             const float dx = x - J.ex, dy = y - J.ey, rr = rview + (hl + hw);
             keep = dx * dx + dy * dy <= rr * rr;
@@ -521,8 +506,9 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
         box_coeffs(V, x, y, cb, sb, P, Q);
         P.w = hl; Q.w = hw;
         const uint32_t span = box_span(J, V, x, y, cb, sb, hl, hw);
-        paint_boxes(keep, P, Q, span, TDE_LAYER_NPC);
-        paint_boxes(lane == 0 && pres, P, Q, span, (uint32_t)ego_layer);      // (an absent ego is not painted: the oracle skips it)
+        const uint32_t lay = lane == 0 ? (uint32_t)ego_layer : (uint32_t)TDE_LAYER_NPC;
+        paint_boxes(keep && lane > 0, P, Q, span, lay);
+        paint_boxes(keep && lane == 0, P, Q, span, lay);
     }
 
     // ---- layers -> colours, streamed out --------------------------------------------------------------------------
