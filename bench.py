@@ -487,7 +487,7 @@ def main():
             kernel = f"tde::env_step_kernel<{A}> + tde::render_views_kernel<64>"
         elif stepwise:
             trio = st["slot_cache"] is not None and A in (8, 16, 32) and (
-                args.step_kernel == "trio" or (args.step_kernel is None and B * A <= 65536))
+                args.step_kernel == "trio" or (args.step_kernel is None and B * A <= 131072))
             kernel = f"tde::env_step_trio_kernel<{A}, false, false>" if trio else f"tde::env_step_kernel<{A}, false, false>"
         else:
             team = {"solo": "", "duo": "_duo", "trio": "_trio"}.get(

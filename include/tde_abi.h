@@ -124,7 +124,9 @@ typedef struct tde_spawn {
     int32_t replay;             /* replay row id or -1 (car_sequence_suite, gym_env.py:275-283) */
     int32_t replay_len;         /* T of that replay row (0 if none) */
     int32_t present;            /* slot used by this scenario */
-    int32_t _pad0, _pad1;
+    float tgx0, tgy0;           /* (ABI 7) route_xy[route][route_wp]: the first route target (0 without a route), so that a
+                                   re-spawned slot has its controller target with the record itself - one dependent table
+                                   look-up less on the re-spawn path, which is the tail of every one-step launch */
 } tde_spawn;
 
 /* One WaypointSuite entry (gym_env.py:63-68). */

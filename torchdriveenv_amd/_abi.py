@@ -70,7 +70,7 @@ assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 64 and STOPLINE_DTYPE.itemsize 
 
 SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("len", "f4"), ("wid", "f4"),
                         ("lr", "f4"), ("vdes", "f4"), ("route", "i4"), ("route_wp", "i4"), ("route_n", "i4"),
-                        ("replay", "i4"), ("replay_len", "i4"), ("present", "i4"), ("_pad0", "i4"), ("_pad1", "i4")])
+                        ("replay", "i4"), ("replay_len", "i4"), ("present", "i4"), ("tgx0", "f4"), ("tgy0", "f4")])
 SCN_DTYPE = np.dtype([("map", "i4"), ("wp_n", "i4"), ("start_heading", "f4"), ("_pad0", "i4")])
 assert SPAWN_DTYPE.itemsize == 64 and SCN_DTYPE.itemsize == 16
 

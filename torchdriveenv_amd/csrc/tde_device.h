@@ -263,6 +263,11 @@ TDE_DEV void offroad_issue(const tde_world &w, const tde_map &m, bool live, floa
     }
 }
 
+// PAIR: two candidate records are fetched per trip of the MIXED-corner loop and the second one is tested only when the first
+// did not settle the corner - half the dependent memory round trips for six more registers.  For the one-step kernels,
+// whose launch ends with its slowest wavefront (a corner in a MIXED cell somewhere in the batch, every step); the
+// persistent kernels keep one record per trip (their 80-VGPR budget, and their wavefronts drift apart anyway).
+template <bool PAIR = false>
 TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
 {
     const uint32_t w0 = k.w0, w1 = k.w1, w2 = k.w2, w3 = k.w3;
@@ -288,20 +293,31 @@ TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
         }
         if (!__ballot(work)) break;
         if (work) {
-            const float d2 = point_tri_d2_packed(qx, qy, recs + 3 * (size_t)cur);
-            if (d2 <= thr2) work = false;                     // this corner is on the road
-            else if (++cur == end) { off = true; work = false; pending = 0u; }
+            if constexpr (PAIR) {
+                const float4 *r0 = recs + 3 * (size_t)cur, *r1 = recs + 3 * (size_t)(cur + 1 < end ? cur + 1 : cur);
+                const float4 a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+                bool on = point_tri_d2_words(qx, qy, a0, a1, a2) <= thr2;
+                if (!on && cur + 1 < end) on = point_tri_d2_words(qx, qy, b0, b1, b2) <= thr2;
+                cur += 2;
+                if (on) work = false;                         // this corner is on the road
+                else if (cur >= end) { off = true; work = false; pending = 0u; }
+            } else {
+                const float d2 = point_tri_d2_packed(qx, qy, recs + 3 * (size_t)cur);
+                if (d2 <= thr2) work = false;                     // this corner is on the road
+                else if (++cur == end) { off = true; work = false; pending = 0u; }
+            }
         }
     }
     return off;
 }
 
+template <bool PAIR = false>
 TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float x, float y, float c, float s, float hl,
                          float hw, float thr2)
 {
     Corners k;
     offroad_issue(w, m, live, x, y, c, s, hl, hw, k);
-    return offroad_resolve(w, k, thr2);
+    return offroad_resolve<PAIR>(w, k, thr2);
 }
 
 // Philox4x32-10, key = seed, counter = (c0,c1,c2,c3) — the reset RNG (R16).  Returned by value (uint4) so the four

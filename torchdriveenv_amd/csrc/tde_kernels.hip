@@ -320,6 +320,32 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
     ag.inv_lr = 1.0f / ag.lr;
 }
 
+// reset_lane + the slot's table entries (what load_ctx gives) for the one-step kernels' re-spawn path, which is the tail every
+// launch waits for: the spawn record carries the first route target (tde_spawn.tgx0 / tgy0) and the route / replay lengths, so
+// the only loads behind the scenario draw are the record itself, the scenario entry and - for the ego - its first waypoint
+// target: ONE round of independent loads instead of the chain record -> route table.  `want_map`: also the map descriptor.
+template <int A>
+TDE_DEV void respawn_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er, Ctx &cx, bool want_map)
+{
+    reset_lane<A>(cfg, w, e, a, ag, er);
+    const uint32_t F = cfg.flags;
+    cx.tgx = cx.tgy = cx.tgx2 = cx.tgy2 = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0;
+    cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
+    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[er.scn];          // map, wp_n, start_heading, pad
+    if (want_map && (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS))) cx.m = w.maps[sc.x];
+    const int route = ag.route, replay = ag.replay;
+    ag.route = -1; ag.replay = -1;
+    if (a > 0) {
+        const int4 *rec = reinterpret_cast<const int4 *>(w.spawn + ((int64_t)er.scn * A + a));   // (the lines reset_lane just read)
+        const int4 r2 = rec[2], r3 = rec[3];                                 // route, route_wp, route_n, replay | replay_len, present, tgx0, tgy0
+        if (F & TDE_F_NPC) { ag.route = route; cx.route_n = r2.z; cx.tgx = __int_as_float(r3.z); cx.tgy = __int_as_float(r3.w); }
+        if (F & TDE_F_REPLAY) { ag.replay = replay; cx.replay_len = r3.x; }
+    } else if (F & TDE_F_REWARD) {
+        cx.n_wp = sc.y;
+        load_ego_target(w, er, cx);
+    }
+}
+
 // heuristic NPC controller (R14 slot), mirrors tde_npc_action of the oracle; reads the tile (= pre-step state).
 // Two phases: a branch-free sweep over the A slots with the cheap tests that almost every slot fails (ahead of me?
 // close enough to cap my speed? inside the widest corridor?) builds a candidate bit mask; the exact lane / yield-cone
@@ -736,7 +762,8 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     if (switched) load_route_target(cold, ag, cx);
 
     bool off = false;
-    if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2_of(cfg));
+    // (one-step launches end with their slowest wavefront: two candidate records per trip there, tde_device.h)
+    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock>(w, corners, thr2_of(cfg));
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
@@ -772,8 +799,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
             if (any) {
                 const int lane = tid & 63;
                 if (((any >> (lane - a)) & 1ull) && valid) {
-                    reset_lane<A>(cfg, cold, e, a, ag, er);
-                    load_ctx<A>(cfg, cold, a, ag, er, cx);
+                    respawn_lane<A>(cfg, cold, e, a, ag, er, cx, true);
                     out.respawned = true;
                     live = ag.present;
                     sincos_f32(ag.psi, s0, c0);
@@ -1746,27 +1772,21 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         bool respawned = false;
         if (dn) {
             if (((dn >> base) & 1ull) && valid) {
-                reset_lane<A>(cfg, cold, e, a, ag, er);
-                load_ctx<A>(cfg, cold, a, ag, er, cx);
-                load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);
+                respawn_lane<A>(cfg, cold, e, a, ag, er, cx, LIGHTS);
+                load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);     // (only stored)
                 respawned = true;
-                sincos_f32(ag.psi, s0, c0);
-                write_rows(sh, 0, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges are done with the rows)
-                if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
             }
-            if ((F & TDE_F_NPC) && st.act_cache) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const bool npc2 = (F & TDE_F_NPC) && a > 0 && valid && ag.present;
-                has_target = npc2 && ag.route >= 0 && ag.route_wp < cx.route_n;
-                controller(0, er.steps + 1, na2, nb2);
-            }
+            // The re-spawn path is the tail every launch waits for (1.9 % of the envs finish per step, 7 % of the wavefronts
+            // hold one): the next step's controller is NOT recomputed here for the re-spawned envs - their action-cache
+            // entries are stored invalid and the next launch computes them in its prologue (env_step_trio_kernel, `stored`);
+            // the other envs of the wavefront keep the actions computed above, whose inputs did not change.
         }
         if (!valid) return;
         store_agent_dynamic(st, g, ag);
         if (respawned) store_agent_static(st, g, ag);
         if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);
         if (st.act_cache)
-            reinterpret_cast<int4 *>(st.act_cache)[g] = make_int4((F & TDE_F_NPC) ? er.episode : -1, er.steps,
+            reinterpret_cast<int4 *>(st.act_cache)[g] = make_int4(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, er.steps,
                                                                   __float_as_int(na2), __float_as_int(nb2));
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================
@@ -1906,7 +1926,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
         const bool live = rc.z != 0.0f;
         bool off = false, tl = false;
-        if (F & TDE_F_OFFROAD) off = box_offroad(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
+        if (F & TDE_F_OFFROAD) off = box_offroad<true>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
             tl = tl_violation(w, m, red_mask(w, m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
         const unsigned long long om = __ballot(off), tm = __ballot(tl);
@@ -2360,16 +2380,17 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     // With the lookup caches present (and a group shape the three-role kernels are built for) the step runs as three
     // wavefronts per 64 agent slots; tde_kernel_override forces one form (A/B runs).
-    // Which one wins is a matter of load (same-box, scripts/launch_cost.py, us per launch at 16 agents per env):
-    //   envs      512   1024   2048   4096   8192   16384
-    //   3 roles   8.5    8.7    9.1   10.1   12.3    19.3      (<= 2048: bounded by the ctypes host floor of 7.2)
-    //   1 role   10.2   10.2   10.3   10.5   11.9    16.4
-    // a launch costs ~5 us of fixed latency (dispatch + one wavefront's dependent chain, which the role split and the
-    // caches shorten) plus ~0.85 us per 1024 envs of issue time (which the two extra prologues lengthen): three roles
-    // up to 65 536 agent slots, one role above.  tde_kernel_override(0, 1 | 3) forces one.
+    // Which one wins is a matter of load (bench.py --mode step --step-kernel solo|trio, us per step at 16 agents per env,
+    // profiles/r03_d_step_matrix.txt):
+    //   envs     2048   4096   8192   16384   32768
+    //   3 roles  7.26   7.91   9.45   16.58   27.34
+    //   1 role   9.19   9.37  10.76   14.56   24.25
+    // (round 2: 3 roles 12.3 at 8192 envs - its re-spawn path, the tail every launch waits for, recomputed the next step's
+    //  controller and walked the record -> route table chain: +3.4 us with TDE_F_AUTORESET; now +1).  Three roles up to
+    // 131 072 agent slots, one role above (configs[4]: 8192 x 32).  tde_kernel_override(0, 1 | 3) forces one.
     const int force = g_force_step;
     const bool trio_ok = st->slot_cache && st->env_cache && (st->A == 8 || st->A == 16 || st->A == 32);
-    const bool want_trio = force == 3 || (force == 0 && (int64_t)st->B * st->A <= 65536);
+    const bool want_trio = force == 3 || (force == 0 && (int64_t)st->B * st->A <= 131072);
     if (trio_ok && want_trio) {
         const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
 #define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st)

@@ -501,6 +501,8 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
             if ag.get("route") is not None and len(ag["route"]) > 0:
                 r["route"], r["route_n"], r["route_wp"] = len(routes), len(ag["route"]), ag.get("route_wp", 0)
                 routes.append(np.asarray(ag["route"], np.float32))
+                if r["route_wp"] < r["route_n"]:
+                    r["tgx0"], r["tgy0"] = routes[-1][r["route_wp"]]          # the first target rides in the record
             if ag.get("replay") is not None and len(ag["replay"]) > 0:
                 r["replay"], r["replay_len"] = len(replays), len(ag["replay"])
                 replays.append(np.asarray(ag["replay"], np.float32))
