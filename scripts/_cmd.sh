@@ -1,4 +1,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu -k "step or env or cache or fuzz or offroad" 2>&1 | tail -3
-python bench.py --config 5 --steps 500 --warmup 50 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('config5', d['ms_per_step']*1e3, d['roofline']['frac'])"
-python bench.py --mode step --step-kernel solo --steps 4000 --warmup 500 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('step solo', d['ms_per_step']*1e3)"
+O=gpurun_out/r03_step_flags3; mkdir -p $O
+rocprofv3 --kernel-trace --output-format csv -d $O/solo32 -o tr -- python3 scripts/step_flags_rocprof.py 32 8192 solo > $O/solo32.log 2>&1
+python - <<PY
+import csv, glob
+rows = [r for f in glob.glob("$O/solo32/*kernel_trace.csv") for r in csv.DictReader(open(f)) if "env_step" in r["Kernel_Name"]]
+d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+for s in range(5):
+    seg = sorted(d[s*600+100:(s+1)*600])
+    print("solo A=32 subset", s, "kernel avg %.2f us  median %.2f  p10 %.2f p90 %.2f" % (sum(seg)/len(seg)/1e3, seg[len(seg)//2]/1e3, seg[len(seg)//10]/1e3, seg[9*len(seg)//10]/1e3))
+PY

@@ -143,22 +143,22 @@ def patch_trio(s):
 
 
 def patch_step3(s):
-    """milestones of env_step_trio_kernel per role (ticks since the wavefront entered its role): drive 0-5, C 8-12, O 16-19"""
+    """milestones of env_step_trio_kernel per role (ticks between marks): drive 0-5, C 8-12, O 16-19"""
     a, b = kernel_span(s, "env_step_trio_kernel")
     k = s[a:b]
-    k = sub(k, "    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.hit_mask = 0ull;",
-            "    unsigned long long stl = __builtin_amdgcn_s_memtime();\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.hit_mask = 0ull;")
+    k = sub(k, "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n    if (threadIdx.x == 0) {\n        fill_cold(cold, cfg, w); sh.hit_mask = 0ull;",
+            "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) {\n        fill_cold(cold, cfg, w); sh.hit_mask = 0ull;")
     # drive
-    k = sub(k, "        float c0, s0;\n        sincos_f32(ag.psi, s0, c0);\n        bool live = valid && ag.present;",
-            "        tde_mark(&stl, 0);\n        float c0, s0;\n        sincos_f32(ag.psi, s0, c0);\n        bool live = valid && ag.present;")
-    k = sub(k, "        if (live) {\n            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);     // :117",
-            "        tde_mark(&stl, 1);\n        if (live) {\n            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.lr, acc, beta, cfg.dt);     // :117")
+    k = sub(k, "        float c0, s0;\n        const bool live = valid && ag.present;\n        const int k = er.steps + 1;",
+            "        tde_mark(&stl, 0);\n        float c0, s0;\n        const bool live = valid && ag.present;\n        const int k = er.steps + 1;")
+    k = sub(k, "        if (live) {\n            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117",
+            "        tde_mark(&stl, 1);\n        if (live) {\n            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117")
     k = sub(k, "        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n",
             "        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);\n        tde_mark(&stl, 2);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(&stl, 3);\n")
     k = sub(k, "        lds_barrier();                                       // A: the judges' masks are published\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;",
-            "        lds_barrier();                                       // A: the judges' masks are published\n        tde_mark(&stl, 4);\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;")
+            "        tde_mark(&stl, 6);\n        lds_barrier();                                       // A: the judges' masks are published\n        tde_mark(&stl, 4);\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;")
     k = sub(k, "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);\n",
-            "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);\n        tde_mark(&stl, 5);\n        tde_flush(0, 6);\n")
+            "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);\n        tde_mark(&stl, 5);\n        tde_flush(0, 7);\n")
     # judge C
     k = sub(k, "        lds_barrier();                                       // B\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]",
             "        tde_mark(&stl, 8);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 9);\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]")

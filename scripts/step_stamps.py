@@ -16,7 +16,8 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
-cfg = _abi.default_config(seed=1, distance_cutoff=0.25)
+cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
+_lib.kernel_override(step="trio")
 st = EnvState(B, A, device=dev, with_info=False)
 ops.env_reset(cfg, dw, st)
 act = torch.zeros(B, 2, device=dev)
@@ -35,7 +36,7 @@ lib.tde_debug_stamps(out, 0)
 n = (B * A // 64) * N
 print(f"{e0.elapsed_time(e1) * 1e3 / N:.2f} us per step (stamped build)")
 names = {0: "D: entry -> state + cache loaded", 1: "D: controller", 2: "D: bicycle, route switch, sincos, rows", 3: "D: wait B",
-         4: "D: route reload + wait A", 5: "D: done test, re-spawn, stores",
+         6: "D: next-step controller (action cache)", 4: "D: wait A", 5: "D: done test, re-spawn, stores",
          8: "C: entry -> prologue done", 9: "C: wait B", 10: "C: collision + reward", 11: "C: wait A",
          16: "O: entry -> prologue done", 17: "O: wait B", 18: "O: offroad + stop lines", 19: "O: wait A"}
 for i, nm in names.items():
