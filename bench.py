@@ -535,7 +535,7 @@ def main():
                        "sharding": f"{n} contiguous shard(s) of one global batch (env_base = rank * {B}), "
                                    "no data-path collective",
                        "timing_backend": (args.backend if n > 1 else None)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "achieved": achieved, "algorithmic_GBps": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "measured_hbm_GBps": (traffic / (kern_us * 1e-6) / 1e9 if traffic else None),
                          "valu_issue": issue, "kernel": kernel,
