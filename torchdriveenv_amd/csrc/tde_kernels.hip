@@ -582,6 +582,9 @@ TDE_DEV bool collide_rows_dpp16(const float4 *ra, const float4 *rb, int a, bool 
     return hit;
 }
 
+// hl + hw bounds the circumradius; kReach^2 >= 1.001 keeps the circle test a superset of the SAT test in fp32
+constexpr float kReach = 1.0005f;
+
 struct StepOut {
     float reward;
     uint8_t terminated, truncated, collided, offroad, tl;
@@ -636,7 +639,13 @@ TDE_DEV bool tl_violation_of(L &&line, int n_stop, uint32_t red, float x, float 
         for (int i = 0; i < n_stop; ++i) {
             float4 a, b;
             line(i, a, b);
-            if ((red >> __float_as_int(b.z)) & 1u) v = v || obb_overlap(x, y, c, s, hl, hw, a.x, a.y, a.z, a.w, b.x, b.y);
+            if ((red >> __float_as_int(b.z)) & 1u) {
+                // circumradius reject first, as in collide_rows (overlapping boxes have centres closer than the sum of their
+                // padded circumradii, in exact and in fp32 arithmetic): the ego is rarely within reach of a stop line, and
+                // the four-axis test is 40 instructions that the contended judge wavefront then never issues
+                const float dx = a.x - x, dy = a.y - y, rr = ((hl + hw) + (b.x + b.y)) * kReach;
+                if (dx * dx + dy * dy < rr * rr) v = v || obb_overlap(x, y, c, s, hl, hw, a.x, a.y, a.z, a.w, b.x, b.y);
+            }
         }
     }
     return v;
@@ -683,9 +692,6 @@ TDE_DEV float red_line_gap(const tde_config &cfg, const tde_world &w, const tde_
 {
     return red_line_gap_of(cfg, GlobalLines{w.stoplines + m.stop_base}, m.n_stop, red, ag, cp, sp);
 }
-
-// hl + hw bounds the circumradius; kReach^2 >= 1.001 keeps the circle test a superset of the SAT test in fp32
-constexpr float kReach = 1.0005f;
 
 TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s, float lane_half)
 {
