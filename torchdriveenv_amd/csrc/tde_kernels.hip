@@ -2188,6 +2188,9 @@ __global__ __launch_bounds__(kWave * kViewsPerGroup) __attribute__((amdgpu_waves
 void render_views_kernel(RenderArgs ra, int B)
 {
     __shared__ RasterScratch Sall[kViewsPerGroup];
+#if TDE_RASTER_SKIP & 64          // tuning probe: the launch alone (what 8192 wavefronts with this footprint cost to place)
+    if (ra.rd.H != 12345) { if (threadIdx.x == 9999) Sall[0].plane[0] = 1; return; }
+#endif
     const tde_render &rd = ra.rd;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     RasterScratch &S = Sall[wv];
@@ -2225,7 +2228,19 @@ void render_views_kernel(RenderArgs ra, int B)
     J.out = rd.out + (int64_t)e * 3 * ns * plane;
     J.ring = rd.layers ? rd.layers + (int64_t)e * ns * plane : nullptr;
     J.fresh = rd.fresh && (rd.fresh[e] & 3);       // the episode of this view just (re)started: older frames are blank
+#if TDE_RASTER_SKIP & 128         // tuning probe: the view's own duration (s_memtime ticks) over its first 16 output bytes
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    int dbg[3] = {0, 0, 0};
+    raster_view<SIZE>(S, J, StateAgents{ra.x, ra.y, ra.psi, ra.len, ra.wid, ra.present, g0}, dbg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) {
+        reinterpret_cast<unsigned long long *>(J.out)[0] = t1 - t0;
+        reinterpret_cast<int *>(J.out)[2] = dbg[0]; reinterpret_cast<int *>(J.out)[3] = dbg[1]; reinterpret_cast<int *>(J.out)[4] = dbg[2];
+    }
+#else
     raster_view<SIZE>(S, J, StateAgents{ra.x, ra.y, ra.psi, ra.len, ra.wid, ra.present, g0});
+#endif
   }
 }
 

@@ -261,7 +261,7 @@ TDE_DEV void raster_expand(const uint4 &v, uint8_t *frame, int plane, int i)
 // the env, slot 0 = the ego), `agent.unpack(raw, x, y, c, s, hl, hw)` -> present: its pose and half extents.
 // SIZE: 64 = the image is 64 x 64 (the reference's observation, every stride a constant); 0 = J.H x J.W.
 template <int SIZE, typename AgentSrc>
-TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
+TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent, int *dbg = nullptr)
 {
     const int lane = (int)(threadIdx.x & 63u);
     const int H = SIZE ? SIZE : J.H, W = SIZE ? SIZE : J.W, plane = H * W;
@@ -393,7 +393,7 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
             }
         };
         for (int base = 0; base < nitems; base += 64 * kPx) {
-            if (nmix > kRasterMixQ - 64 * kPx) { resolve_mixed(nmix); nmix = 0; }     // (room for a whole trip)
+            if (nmix > kRasterMixQ - 64 * kPx) { if (dbg) dbg[1] += nmix; resolve_mixed(nmix); nmix = 0; }     // (room for a whole trip)
             bool act[kPx];
             int r[kPx], c[kPx];
             uint32_t cls[kPx];
@@ -416,6 +416,7 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
             }
         }
         wave_phase();
+        if (dbg) { dbg[0] = nq; dbg[1] += nmix; }
         resolve_mixed(nmix);
     }
     wave_phase();
@@ -427,6 +428,7 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent)
     auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     auto paint_boxes = [&](bool keep, const float4 &P, const float4 &Q, uint32_t span, uint32_t lay) {
         unsigned long long km = (TDE_RASTER_SKIP & 4) ? 0ull : __ballot(keep);
+        if (dbg) dbg[2] += (int)__popcll(km);
         while (km) {
             const int l = __ffsll((long long)km) - 1;
             km &= km - 1ull;
