@@ -246,6 +246,27 @@ struct Corners {
     uint32_t w0, w1, w2, w3;
 };
 
+// The class of the cell alone, from the 2-bit class map (tde_world.cell_cls2: 1/16 of the footprint of cell_word, so the maps of
+// a world stay resident in every XCD's L2 and the four corners of a box fall into one 128-byte tile), with the cell's index in
+// cell_word above it: class | index << 2.
+TDE_DEV uint32_t cell_class_lookup(const tde_world &w, const tde_map &m, float px, float py)
+{
+    const float fx = __builtin_amdgcn_fmed3f((px - m.ox) * m.inv_cell, 0.0f, (float)(m.nx - 1));
+    const float fy = __builtin_amdgcn_fmed3f((py - m.oy) * m.inv_cell, 0.0f, (float)(m.ny - 1));
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+    const uint32_t tile = (uint32_t)m.cls2_base + ((iy >> 4) << (m.row_shift - 5)) + (ix >> 5);
+    const uint32_t word = w.cell_cls2[(tile << 5) | (((iy & 15u) << 1) | ((ix >> 4) & 1u))];
+    return ((word >> ((ix & 15u) << 1)) & 3u) | (((uint32_t)m.cell_base + ((iy << m.row_shift) + ix)) << 2);
+}
+
+#ifndef TDE_STEP_CLS2
+#define TDE_STEP_CLS2 1
+#endif
+
+// CLS2 (the one-step kernels, whose state is not register-resident and whose every launch therefore pays the HBM / fabric
+// traffic of its lookups): the corners' classes come from the class map and only a corner in a MIXED cell fetches its cell word
+// (offroad_resolve).  k.w* = class | cell index << 2 then.
+template <bool CLS2 = false>
 TDE_DEV void offroad_issue(const tde_world &w, const tde_map &m, bool live, float x, float y, float c, float s, float hl,
                            float hw, Corners &k)
 {
@@ -256,10 +277,17 @@ TDE_DEV void offroad_issue(const tde_world &w, const tde_map &m, bool live, floa
     k.px3 = (x - lx) - wx; k.py3 = (y - ly) + wy;
     k.w0 = k.w1 = k.w2 = k.w3 = TDE_CELL_FULL;
     if (live) {
-        k.w0 = cell_lookup(w, m, k.px0, k.py0);
-        k.w1 = cell_lookup(w, m, k.px1, k.py1);
-        k.w2 = cell_lookup(w, m, k.px2, k.py2);
-        k.w3 = cell_lookup(w, m, k.px3, k.py3);
+        if constexpr (CLS2) {
+            k.w0 = cell_class_lookup(w, m, k.px0, k.py0);
+            k.w1 = cell_class_lookup(w, m, k.px1, k.py1);
+            k.w2 = cell_class_lookup(w, m, k.px2, k.py2);
+            k.w3 = cell_class_lookup(w, m, k.px3, k.py3);
+        } else {
+            k.w0 = cell_lookup(w, m, k.px0, k.py0);
+            k.w1 = cell_lookup(w, m, k.px1, k.py1);
+            k.w2 = cell_lookup(w, m, k.px2, k.py2);
+            k.w3 = cell_lookup(w, m, k.px3, k.py3);
+        }
     }
 }
 
@@ -267,7 +295,7 @@ TDE_DEV void offroad_issue(const tde_world &w, const tde_map &m, bool live, floa
 // did not settle the corner - half the dependent memory round trips for six more registers.  For the one-step kernels,
 // whose launch ends with its slowest wavefront (a corner in a MIXED cell somewhere in the batch, every step); the
 // persistent kernels keep one record per trip (their 80-VGPR budget, and their wavefronts drift apart anyway).
-template <bool PAIR = false>
+template <bool PAIR = false, bool CLS2 = false>
 TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
 {
     const uint32_t w0 = k.w0, w1 = k.w1, w2 = k.w2, w3 = k.w3;
@@ -284,7 +312,8 @@ TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
         if (!work && pending) {
             const int ci = __ffs((int)pending) - 1;
             pending &= pending - 1u;
-            const uint32_t wd = TDE_SEL4(ci, w0, w1, w2, w3);
+            uint32_t wd = TDE_SEL4(ci, w0, w1, w2, w3);
+            if constexpr (CLS2) wd = w.cell_word[wd >> 2];    // (one more dependent load, for the corners in MIXED cells only)
             cur = wd >> 10;
             end = cur + ((wd >> 2) & 255u);
             qx = TDE_SEL4(ci, k.px0, k.px1, k.px2, k.px3);
@@ -311,13 +340,13 @@ TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
     return off;
 }
 
-template <bool PAIR = false>
+template <bool PAIR = false, bool CLS2 = false>
 TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float x, float y, float c, float s, float hl,
                          float hw, float thr2)
 {
     Corners k;
-    offroad_issue(w, m, live, x, y, c, s, hl, hw, k);
-    return offroad_resolve<PAIR>(w, k, thr2);
+    offroad_issue<CLS2>(w, m, live, x, y, c, s, hl, hw, k);
+    return offroad_resolve<PAIR, CLS2>(w, k, thr2);
 }
 
 // Philox4x32-10, key = seed, counter = (c0,c1,c2,c3) — the reset RNG (R16).  Returned by value (uint4) so the four

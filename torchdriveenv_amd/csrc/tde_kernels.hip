@@ -759,7 +759,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     const float ri = (hl + hw) * kReach;
     Corners corners;                                // cell words of the four corners: loads stay in flight during
     if (F & TDE_F_OFFROAD)                          // the collision sweep
-        offroad_issue(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
+        offroad_issue<(BLOCK == kBlock) && TDE_STEP_CLS2>(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
     __syncthreads();                                // every lane is done reading the pre-step tile
     write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
@@ -769,7 +769,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 
     bool off = false;
     // (one-step launches end with their slowest wavefront: two candidate records per trip there, tde_device.h)
-    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock>(w, corners, thr2_of(cfg));
+    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock, (BLOCK == kBlock) && TDE_STEP_CLS2>(w, corners, thr2_of(cfg));
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
@@ -1932,7 +1932,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
         const bool live = rc.z != 0.0f;
         bool off = false, tl = false;
-        if (F & TDE_F_OFFROAD) off = box_offroad<true>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
+        if (F & TDE_F_OFFROAD) off = box_offroad<true, TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
             tl = tl_violation(w, m, red_mask(w, m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
         const unsigned long long om = __ballot(off), tm = __ballot(tl);
@@ -2398,6 +2398,7 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     if (rc) return rc;
     if (st->B <= 0) return 0;
     if (!st->action) return bad("tde_env_step: state.action is NULL");
+    if ((cfg->flags & TDE_F_OFFROAD) && TDE_STEP_CLS2 && !world->cell_cls2) return bad("tde_env_step: world.cell_cls2 is NULL (ABI 7 class map)");
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     // With the lookup caches present (and a group shape the three-role kernels are built for) the step runs as three
     // wavefronts per 64 agent slots; tde_kernel_override forces one form (A/B runs).

@@ -298,15 +298,25 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent,
         {
             // the block's own look-up and those of its four 4x4 sub-blocks are issued TOGETHER (the sub-blocks' are wasted
             // when the 8x8 block turns out uniform - about half of them - but a dependent round trip is what a view pays for)
+#ifndef TDE_RASTER_SPEC_L1
+#define TDE_RASTER_SPEC_L1 1
+#endif
             uint32_t wd = 0u, w4[4] = {0u, 0u, 0u, 0u};
             if (have) {
                 wd = raster_lookup(J, V, u8, v8);
+                if (TDE_RASTER_SPEC_L1) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        w4[s] = raster_lookup(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
+                }
+            }
+            const uint32_t cls = wd & 3u;
+            const bool uni = cls != TDE_CELL_MIXED && (int)((wd >> 2) & 255u) >= J.K8;
+            if (!TDE_RASTER_SPEC_L1 && have && !uni) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     w4[s] = raster_lookup(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
             }
-            const uint32_t cls = wd & 3u;
-            const bool uni = cls != TDE_CELL_MIXED && (int)((wd >> 2) & 255u) >= J.K8;
             if (have && uni) {
                 const uint2 val = cls == TDE_CELL_FULL ? make_uint2(0x01010101u, 0x01010101u) : make_uint2(0u, 0u);
 #pragma unroll
