@@ -53,7 +53,7 @@ CONFIGS = {
     2: dict(name="configs[1]", envs=1024, agents=8, what="bicycle kinematics + OBB collision only"),
     5: dict(name="configs[4]", envs=8192, agents=32,
             what="full step + 64x64x3 uint8 ego birdview per env (HIP rasteriser), one step launch + one raster "
-                 "launch per timestep"),
+                 "launch per timestep and sub-batch (--streams sub-batches, each on its own HIP stream)"),
 }
 
 
@@ -165,7 +165,7 @@ def secondary(dev, region_s=0.3):
             worlds[A] = (w, w.to_device(dev))
         return worlds[A]
 
-    def run(name, config, B, A, stepwise, flags, render=False, **cfg_over):
+    def run(name, config, B, A, stepwise, flags, render=False, n_streams=1, **cfg_over):
         w, dw = world_of(A)
         cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=flags, **cfg_over)
         st = EnvState(B, A, device=dev, with_info=False)
@@ -181,9 +181,18 @@ def secondary(dev, region_s=0.3):
         if stepwise:
             h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct), dev.index or 0)
 
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else []
+        ptrs = [s_.cuda_stream for s_ in streams]
+        if streams:
+            ops.fork_streams(streams, dev)
+
         def block():                                   # CH consecutive timesteps
             if not stepwise:
                 ops.env_rollout(cfg, dw, st, actions, reward, done)
+                return
+            if streams:
+                for i in range(CH):
+                    h.step_render(rows[i], int(cfg.flags), img, 64, 64, 35.0, 1, None, 0, 0, None, ptrs)
                 return
             for i in range(CH):
                 h.step(rows[i], int(cfg.flags))
@@ -198,16 +207,18 @@ def secondary(dev, region_s=0.3):
         n = max(1, int(-(-region_s // per_block)))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        e0.record()
+        e0.record(streams[0] if streams else None)
         for _ in range(n):
             block()
+        if streams:
+            ops.join_streams(streams, dev)             # the region ends when every sub-batch has finished
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (n * CH)
         bpes = bytes_per_env_step(config, A)
         ach = bpes * B / (us * 1e-6) / 1e9
         return {"workload": name, "envs": B, "agents_per_env": A, "us_per_step": us, "env_steps_per_s": B / us * 1e6,
-                "agent_steps_per_s": B * A / us * 1e6, "timed_steps": n * CH, "launches_per_step": (2 if render else 1) if stepwise else 1.0 / CH,
+                "agent_steps_per_s": B * A / us * 1e6, "timed_steps": n * CH, "launches_per_step": ((2 if render else 1) * max(1, n_streams)) if stepwise else 1.0 / CH, "streams": max(1, n_streams),
                 "roofline": {"bound": "hbm", "bytes_per_env_step": bpes, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": ach / HBM_PEAK_GBPS},
                 "done_frac_last_step": float((st["terminated"] | st["truncated"]).float().mean())}
@@ -215,8 +226,13 @@ def secondary(dev, region_s=0.3):
     F = _abi.F_ALL
     out = {}
     for key, kw in (
-        ("config5", dict(name="configs[4]: 8192 envs x 32 agents, full step + 64x64x3 birdview (step launch + raster launch per timestep)",
-                         config=5, B=8192, A=32, stepwise=True, flags=F, render=True)),
+        ("config5", dict(name="configs[4]: 8192 envs x 32 agents, full step + 64x64x3 birdview; three sub-batches on three HIP "
+                              "streams (tde_env_step_render: step launch + raster launch per sub-batch and timestep)",
+                         config=5, B=8192, A=32, stepwise=True, flags=F, render=True, n_streams=3)),
+        ("config5_one_stream", dict(name="configs[4] on one stream: step launch + raster launch per timestep",
+                                    config=5, B=8192, A=32, stepwise=True, flags=F, render=True)),
+        ("config5_16384", dict(name="configs[4] shape at 16 384 envs x 32 agents: three sub-batches on three HIP streams",
+                               config=5, B=16384, A=32, stepwise=True, flags=F, render=True, n_streams=3)),
         ("closed_loop", dict(name="configs[2] shape, closed loop: one tde_env_step launch per timestep through the extension",
                              config=3, B=8192, A=16, stepwise=True, flags=F)),
         ("config2", dict(name="configs[1]: 1024 envs x 8 agents, kinematics + collision only, 250 steps per launch",
@@ -310,6 +326,10 @@ def main():
     ap.add_argument("--binding", default="ext", choices=["ext", "ctypes"],
                     help="step mode / config 5: launches through the PyTorch-ROCm C++ extension (default) or through "
                          "the ctypes binding of the same C-ABI")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="config 5 only: run each timestep as this many sub-batches on their own HIP streams "
+                         "(tde_env_step_render: the step of one sub-batch overlaps the rasteriser of another); default 3 "
+                         "(us per timestep by stream count: profiles/r03_f_config5_streams_matrix.txt; more than 3 needs GPU_MAX_HW_QUEUES > 4), 1 = one stream")
     ap.add_argument("--rollout-kernel", default=None, choices=["solo", "duo", "trio"],
                     help="force a form of the rollout kernel (A/B runs; default: the library's choice by group shape)")
     ap.add_argument("--step-kernel", default=None, choices=["solo", "trio"],
@@ -389,11 +409,24 @@ def main():
                                        local_rank)
     cfg_flags = int(cfg.flags)
     act_rows = [actions[i] for i in range(CH)]      # views made once: slicing a tensor costs microseconds of host time
+    n_streams = (args.streams or 3) if args.config == 5 else 1
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else []
+    stream_ptrs = [s_.cuda_stream for s_ in streams]
+    ev_stream = streams[0] if streams else None     # the stream the per-launch events are recorded on
+    if streams:
+        ops.fork_streams(streams, dev)              # (the reset and the first birdview above ran on the current stream)
 
     def launch(k, row):
         """k consecutive timesteps (k <= CH); `row` = first row of the action buffer to use"""
         if not stepwise:
             ops.env_rollout(cfg, dw, st, actions[:k], reward[:k], done[:k])
+            return
+        if streams:                                 # config 5 as sub-batches on their own streams: one call per timestep
+            for i in range(k):
+                if handle is not None:
+                    handle.step_render(act_rows[(row + i) % CH], cfg_flags, img, 64, 64, 35.0, 1, None, 0, 0, None, stream_ptrs)
+                else:
+                    ops.env_step_render(cfg, dw, st, streams, action=act_rows[(row + i) % CH], out=img)
             return
         if handle is not None:
             for i in range(k):
@@ -412,7 +445,8 @@ def main():
             k = min(CH, left)
             if events is not None and len(events) < 8192:
                 ev = torch.cuda.Event(enable_timing=True)
-                ev.record()                        # on torch's current stream == the stream the kernels are launched on
+                ev.record(ev_stream)               # on the stream the kernels are launched on (torch's current one; with
+                                                   # sub-batch streams: the first sub-batch's)
                 events.append((ev, k))
             launch(k, row)
             left -= k
@@ -447,7 +481,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(total, events)
-    ev_end.record()
+    ev_end.record(ev_stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -485,6 +519,8 @@ def main():
         # step mode = tde::env_step_kernel<A>; config 5 = step + tde::render_views_kernel per timestep
         if args.config == 5:
             kernel = f"tde::env_step_kernel<{A}> + tde::render_views_kernel<64>"
+            if streams:
+                kernel += f" as {n_streams} sub-batches on {n_streams} streams (tde_env_step_render)"
         elif stepwise:
             trio = st["slot_cache"] is not None and A in (8, 16, 32) and (
                 args.step_kernel == "trio" or (args.step_kernel is None and B * A <= 131072))
@@ -531,7 +567,7 @@ def main():
             "config": {"workload": f"{C['name']}: {B} envs x {A} agents per GPU, {C['what']}",
                        "envs_per_gpu": B, "agents_per_env": A, "global_envs": B * n, "mode": args.mode,
                        "binding": (args.binding if stepwise else "ctypes"),
-                       "steps_per_call": spl, "timed_steps": total, "untimed_warmup_steps": warm_steps + CH,
+                       "streams": max(1, n_streams), "steps_per_call": spl, "timed_steps": total, "untimed_warmup_steps": warm_steps + CH,
                        "sharding": f"{n} contiguous shard(s) of one global batch (env_base = rank * {B}), "
                                    "no data-path collective",
                        "timing_backend": (args.backend if n > 1 else None)},
@@ -544,7 +580,10 @@ def main():
                          "launches": (sum(lens) if stepwise else len(lens)), "steps_per_launch": spl,
                          "launch_lengths": ([1] if stepwise else sorted(set(lens))), "algorithmic_bytes_per_launch": alg_launch,
                          "bytes_per_env_step": bpes, "us_per_step": dev_ms * 1e3 / total,
-                         "timer": "HIP events on the launch stream around every timed launch (rank 0)"},
+                         "streams": max(1, n_streams),
+                         "timer": ("HIP events on the launch stream around every timed launch (rank 0)" if not streams else
+                                   "HIP events on the first sub-batch's stream around every timed timestep (rank 0); the "
+                                   "sub-batches' kernels overlap, so a timestep's duration is the period of that stream")},
             "check": chk,
         }
         if n == 1 and args.config == 3 and not stepwise and not args.no_secondary:

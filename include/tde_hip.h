@@ -101,6 +101,17 @@ TDE_API int tde_env_rollout(const tde_config *cfg, const tde_world *world, const
 TDE_API int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *state,
                            const tde_render *render, void *stream);
 
+/* One timestep + (render != NULL) the birdview of every env, as n_streams contiguous sub-batches of the batch, sub-batch i
+ * launched on streams[i] (hipStream_t; the step, then the rasteriser): GymEnv.step followed by get_obs (gym_env.py:115-124)
+ * for every env, the step of one sub-batch overlapping the rasteriser of another - both kernels are latency-bound alone
+ * (DESIGN.md section 5, round 3).  Results are those of tde_env_step + tde_render_ego on the whole batch (envs are independent
+ * and the reset RNG is keyed by the global env index: each sub-batch runs with env_base advanced to its first env).
+ * Sub-batches are cut at multiples of 64 envs.  The caller orders the streams against the producer of state->action and the
+ * consumer of the outputs (events); consecutive calls on the same streams are ordered per sub-batch, which is all the
+ * path needs.  n_streams in [1, 16]. */
+TDE_API int tde_env_step_render(const tde_config *cfg, const tde_world *world, const tde_state *state,
+                                const tde_render *render, void *const *streams, int32_t n_streams);
+
 /* Compact kinematic observation of every env's ego, float32 [B][8] (no reference counterpart; the reference only has
  * the birdview of gym_env.py:122-124): x, y, psi, v, offset of the current target waypoint in the ego frame (forward,
  * left; 0 when the route is finished, gym_env.py:378-383), 1 while a target exists, environment_steps.  One launch

@@ -541,3 +541,73 @@ def test_step_three_role_kernel_and_caches_bit_exact(A, flags):
                 ds.load(hs.host())
     check("end")
     assert hs["episode"].max() > 1 and bool((fast["slot_cache"][:, 7] & (1 << 30)).any())
+
+
+@pytest.mark.parametrize("B,n_streams", [(256, 2), (200, 2), (320, 3), (96, 4), (256, 1)])
+def test_step_render_on_streams_equals_whole_batch_and_oracle(small_world, B, n_streams):
+    """tde_env_step_render (sub-batches on their own HIP streams: step, then the birdview) against tde_env_step + tde_render_ego
+    on the whole batch and against the oracle, over re-spawns; through ctypes and through the extension; single frames and the
+    layer-ring frame stack with `fresh` = the step's done bits"""
+    import ctypes
+
+    from torchdriveenv_amd import _ext
+
+    A = small_world.A
+    cfg = _abi.default_config(seed=33, distance_cutoff=0.25, max_steps=30)
+    hs, whole, dw = _pair(small_world, B, A, cfg)
+    split, viaext = EnvState(B, A, device=DEV), EnvState(B, A, device=DEV)
+    split.load(hs.host()); viaext.load(hs.host())
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(n_streams)]
+    h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(viaext.struct), 0)
+    img_w = torch.zeros((B, 3, 64, 64), dtype=torch.uint8, device=DEV)
+    img_s, img_e = torch.zeros_like(img_w), torch.zeros_like(img_w)
+    # frame stack of 3 through the layer ring (split path) vs the same on the whole batch
+    ring_w = torch.full((B, 3, 64 * 64), 5, dtype=torch.uint8, device=DEV)
+    ring_s = ring_w.clone()
+    stk_w = torch.zeros((B, 9, 64, 64), dtype=torch.uint8, device=DEV)
+    stk_s = torch.zeros_like(stk_w)
+    rng = np.random.default_rng(12)
+    n_done = 0
+    for t in range(70):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        a = dev(act)
+        hs["action"][...] = act
+        oracle.env_step(cfg, small_world, hs)
+        ops.env_step(cfg, dw, whole, action=a)
+        ops.render_ego(cfg, dw, whole, out=img_w)
+        ops.render_ego(cfg, dw, whole, n_stack=3, out=stk_w, layers=ring_w, phase=t % 3, fresh=whole["done_bits"])
+        ops.fork_streams(streams, DEV)
+        ops.env_step_render(cfg, dw, split, streams, action=a, out=img_s)
+        ops.join_streams(streams, DEV)
+        # (the stacked call re-renders the state the step above produced: render-only would need a second step, so the stack
+        #  goes through plain render_ego on the sub-batch streams' joined state)
+        ops.render_ego(cfg, dw, split, n_stack=3, out=stk_s, layers=ring_s, phase=t % 3, fresh=split["done_bits"])
+        ops.fork_streams(streams, DEV)
+        h.step_render(a, int(cfg.flags), img_e, 64, 64, 35.0, 1, None, 0, 0, None, [s.cuda_stream for s in streams])
+        ops.join_streams(streams, DEV)
+        assert torch.equal(img_w, img_s) and torch.equal(img_w, img_e) and torch.equal(stk_w, stk_s), t
+        n_done += int((hs["terminated"] | hs["truncated"]).sum())
+        if t % 10 == 9:
+            want = oracle.render_ego(cfg, small_world, hs)
+            assert np.array_equal(img_s.cpu().numpy(), want), t
+    assert n_done > B // 2
+    host = hs.host()
+    for ds in (whole, split, viaext):
+        d = ds.host()
+        for k, v in host.items():
+            if k not in ("action", "info"):
+                assert np.array_equal(v.view(np.uint8), d[k].view(np.uint8)), k
+    # the step alone (render = NULL) and the stacked render inside the call
+    ops.fork_streams(streams, DEV)
+    ops.env_step_render(cfg, dw, split, streams, action=a, render=False)
+    ops.join_streams(streams, DEV)
+    ops.env_step(cfg, dw, whole, action=a)
+    assert torch.equal(split["x"], whole["x"]) and torch.equal(split["reward"], whole["reward"])
+    ops.fork_streams(streams, DEV)
+    ops.env_step_render(cfg, dw, split, streams, action=a, out=stk_s, n_stack=3, layers=ring_s, phase=1, fresh=split["done_bits"])
+    ops.join_streams(streams, DEV)
+    ops.env_step(cfg, dw, whole, action=a)
+    ops.render_ego(cfg, dw, whole, n_stack=3, out=stk_w, layers=ring_w, phase=1, fresh=whole["done_bits"])
+    assert torch.equal(stk_w, stk_s) and torch.equal(ring_w, ring_s)
+    with pytest.raises(Exception):
+        ops.env_step_render(cfg, dw, split, [], action=a)

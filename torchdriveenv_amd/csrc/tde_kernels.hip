@@ -757,9 +757,13 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     sincos_f32(ag.psi, s0, c0);
     const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
     const float ri = (hl + hw) * kReach;
+    // One-step launches of up to 16 slots per env read the corners' classes from the 2-bit class map (tde_device.h: 17.0 -> 12.1 MB
+    // of HBM / fabric traffic per step at 8192 x 16, same time); at 32 slots per env the extra round trip of the MIXED corners
+    // costs 0.55 us of the launch's tail (15.85 -> 16.43 us, profiles/r03_f_step_cls2_ab.txt) and the cell words stay.
+    constexpr bool kStepCls2 = (BLOCK == kBlock) && TDE_STEP_CLS2 && A <= 16;
     Corners corners;                                // cell words of the four corners: loads stay in flight during
     if (F & TDE_F_OFFROAD)                          // the collision sweep
-        offroad_issue<(BLOCK == kBlock) && TDE_STEP_CLS2>(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
+        offroad_issue<kStepCls2>(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
     __syncthreads();                                // every lane is done reading the pre-step tile
     write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
@@ -769,7 +773,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 
     bool off = false;
     // (one-step launches end with their slowest wavefront: two candidate records per trip there, tde_device.h)
-    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock, (BLOCK == kBlock) && TDE_STEP_CLS2>(w, corners, thr2_of(cfg));
+    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock, kStepCls2>(w, corners, thr2_of(cfg));
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
@@ -2392,7 +2396,9 @@ int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state
     return e == hipSuccess ? 0 : fail("tde_env_reset", e);
 }
 
-int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream)
+// `load_slots`: the agent slots stepping on the device at the same time - the batch's own, or the whole batch's when this is one
+// of the sub-batches tde_env_step_render runs side by side (the choice of kernel form is a matter of load)
+static int env_step_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream, int64_t load_slots)
 {
     int rc = check_env_args("tde_env_step", cfg, world, st);
     if (rc) return rc;
@@ -2412,7 +2418,7 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
     // 131 072 agent slots, one role above (configs[4]: 8192 x 32).  tde_kernel_override(0, 1 | 3) forces one.
     const int force = g_force_step;
     const bool trio_ok = st->slot_cache && st->env_cache && (st->A == 8 || st->A == 16 || st->A == 32);
-    const bool want_trio = force == 3 || (force == 0 && (int64_t)st->B * st->A <= 131072);
+    const bool want_trio = force == 3 || (force == 0 && load_slots <= 131072);
     if (trio_ok && want_trio) {
         const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
 #define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st)
@@ -2437,6 +2443,11 @@ int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state 
 #undef TDE_LAUNCH_STEP
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_step", e);
+}
+
+int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream)
+{
+    return env_step_launch(cfg, world, st, stream, st ? (int64_t)st->B * st->A : 0);
 }
 
 // number of CUs of the current device (cached per device)
@@ -2578,6 +2589,39 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     else tde::render_views_kernel<0><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
+}
+
+int tde_env_step_render(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_render *rd,
+                        void *const *streams, int32_t n_streams)
+{
+    int rc = check_env_args("tde_env_step_render", cfg, world, st);
+    if (rc) return rc;
+    if (!streams || n_streams < 1 || n_streams > 16) return bad("tde_env_step_render: streams is NULL or n_streams not in [1, 16]");
+    if (st->B <= 0) return 0;
+    // equal shares rounded up to whole groups of 64 envs (any A: slices start on wavefront and workgroup boundaries)
+    const int64_t share = ((((int64_t)st->B + n_streams - 1) / n_streams) + 63) & ~(int64_t)63;
+    int i = 0;
+    for (int64_t e0 = 0; e0 < st->B; e0 += share, ++i) {
+        const int32_t n = (int32_t)((st->B - e0 < share) ? st->B - e0 : share);
+        tde_config c = *cfg;
+        c.env_base = cfg->env_base + (uint32_t)e0;                           // the reset RNG is keyed by the global env index
+        const tde_state s = state_slice(*st, e0, n);
+        // (the sub-batches run side by side: configs[4] in two halves, us per timestep: one-role steps 46.0, three-role 49.1,
+        //  profiles/r03_f_config5_streams_matrix.txt - the kernel form follows the whole batch's load)
+        rc = env_step_launch(&c, world, &s, streams[i], (int64_t)st->B * st->A);
+        if (rc) return rc;
+        if (rd) {
+            tde_render r = *rd;
+            const int64_t ns = rd->n_stack > 1 ? rd->n_stack : 1, plane = (int64_t)rd->H * rd->W;
+            if (r.out) r.out += e0 * 3 * ns * plane;
+            if (r.layers) r.layers += e0 * ns * plane;
+            if (r.fresh) r.fresh += e0;
+            if (r.only) r.only += e0;
+            rc = tde_render_ego(&c, world, &s, &r, streams[i]);
+            if (rc) return rc;
+        }
+    }
+    return 0;
 }
 
 int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void *stream)

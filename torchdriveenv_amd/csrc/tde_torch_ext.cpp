@@ -82,6 +82,36 @@ class EnvHandle {
         check_rc(tde_env_rollout(&cfg_, &world_, &state_, &ro, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_env_rollout");
     }
 
+    // tde_env_step_render: the timestep + the birdview as streams.size() sub-batches, each on its own stream (raw hipStream_t
+    // values, e.g. torch.cuda.Stream.cuda_stream); `out` = None: the step only
+    void step_render(const at::Tensor &action, int64_t flags, const std::optional<at::Tensor> &out, int64_t H, int64_t W, double fov,
+                     int64_t n_stack, const std::optional<at::Tensor> &layers, int64_t phase, int64_t rflags,
+                     const std::optional<at::Tensor> &fresh, const std::vector<int64_t> &streams)
+    {
+        tde_state st = state_;
+        st.action = static_cast<const float *>(dev_ptr(action, at::kFloat, 2 * (int64_t)state_.B, "action", dev_));
+        cfg_.flags = static_cast<uint32_t>(flags);
+        const int64_t ns = n_stack > 1 ? n_stack : 1;
+        tde_render rd{};
+        if (out) {
+            rd.out = static_cast<uint8_t *>(const_cast<void *>(dev_ptr(*out, at::kByte, state_.B * 3 * ns * H * W, "out", dev_)));
+            rd.H = static_cast<int32_t>(H);
+            rd.W = static_cast<int32_t>(W);
+            rd.fov = static_cast<float>(fov);
+            rd.n_stack = static_cast<int32_t>(n_stack);
+            rd.layers = layers ? static_cast<uint8_t *>(const_cast<void *>(dev_ptr(*layers, at::kByte, state_.B * ns * H * W, "layers", dev_))) : nullptr;
+            rd.phase = static_cast<int32_t>(phase);
+            rd.flags = static_cast<int32_t>(rflags);
+            rd.fresh = fresh ? static_cast<const uint8_t *>(dev_ptr(*fresh, at::kByte, state_.B, "fresh", dev_)) : nullptr;
+            rd.only = nullptr;
+        }
+        TORCH_CHECK(!streams.empty() && streams.size() <= 16, "streams: 1 to 16 raw stream handles");
+        void *sv[16];
+        for (size_t i = 0; i < streams.size(); ++i) sv[i] = reinterpret_cast<void *>(static_cast<uintptr_t>(streams[i]));
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_env_step_render(&cfg_, &world_, &st, out ? &rd : nullptr, sv, static_cast<int32_t>(streams.size())), "tde_env_step_render");
+    }
+
     void render(const at::Tensor &out, int64_t H, int64_t W, double fov, int64_t n_stack, const std::optional<at::Tensor> &layers,
                 int64_t phase, int64_t flags, const std::optional<at::Tensor> &fresh, const std::optional<at::Tensor> &only)
     {
@@ -229,6 +259,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         .def("rollout", &EnvHandle::rollout, py::arg("actions"), py::arg("reward"), py::arg("done"), py::arg("flags"))
         .def("render", &EnvHandle::render, py::arg("out"), py::arg("H"), py::arg("W"), py::arg("fov"), py::arg("n_stack"),
              py::arg("layers"), py::arg("phase"), py::arg("flags"), py::arg("fresh"), py::arg("only"))
+        .def("step_render", &EnvHandle::step_render, py::arg("action"), py::arg("flags"), py::arg("out"), py::arg("H"), py::arg("W"),
+             py::arg("fov"), py::arg("n_stack"), py::arg("layers"), py::arg("phase"), py::arg("rflags"), py::arg("fresh"), py::arg("streams"))
         .def("state_obs", &EnvHandle::state_obs)
         .def_property_readonly("flags", &EnvHandle::flags)
         .def_property_readonly("num_envs", &EnvHandle::num_envs)

@@ -204,6 +204,49 @@ def render_ego(cfg, dworld, state, H=64, W=64, fov=35.0, n_stack=1, out=None, la
     return out
 
 
+def fork_streams(streams, device=None):
+    """order `streams` (torch.cuda.Stream) after the work already queued on the current stream (before the first
+    env_step_render call / after the action tensor was produced)"""
+    cur = torch.cuda.current_stream(device)
+    for s in streams:
+        s.wait_stream(cur)
+
+
+def join_streams(streams, device=None):
+    """order the current stream after the work queued on `streams` (before the outputs are consumed)"""
+    cur = torch.cuda.current_stream(device)
+    for s in streams:
+        cur.wait_stream(s)
+
+
+def env_step_render(cfg, dworld, state, streams, action=None, out=None, H=64, W=64, fov=35.0, n_stack=1, layers=None, phase=0,
+                    flags=0, fresh=None, render=True):
+    """tde_env_step_render: one timestep + (render) the birdview of every env as len(streams) contiguous sub-batches, each on
+    its own HIP stream, so that the step of one sub-batch overlaps the rasteriser of another.  Same results as env_step +
+    render_ego.  `streams`: torch.cuda.Stream objects; the caller orders them against the current stream (fork_streams /
+    join_streams) - open-loop drivers join once, at the end.  Returns `out` (None without render)."""
+    L = _lib.load()
+    dev = state.device
+    st = state.struct
+    if action is not None:
+        st = _abi.TdeState.from_buffer_copy(state.struct)
+        st.action = _chk(action, torch.float32, 2 * state.B, "action", torch.device(dev))
+    rdp = None
+    if render:
+        ns = max(1, n_stack)
+        if out is None:
+            out = torch.zeros((state.B, 3 * ns, H, W), dtype=torch.uint8, device=dev)
+        pl = _chk(layers, torch.uint8, state.B * ns * H * W, "layers", optional=True) if ns > 1 else None
+        pf = _chk(fresh, torch.uint8, state.B, "fresh", optional=True)
+        rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack, pl, int(phase),
+                            int(flags), pf, None)
+        rdp = C.byref(rd)
+    arr = (C.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+    _lib.check(_call(dev, L.tde_env_step_render, C.byref(cfg), C.byref(dworld.struct), C.byref(st), rdp, arr,
+                     len(streams)), "tde_env_step_render")
+    return out
+
+
 class FrameStack:
     """Device-side VecFrameStack(n_stack, channels_order="first") (ref examples/rl_training.py:160) kept as a ring of
     one-byte-per-pixel layer planes: every call writes all n_stack frames of `obs` (oldest first) from the ring, so no
