@@ -2,11 +2,13 @@
 # Round-3 measurement pass on the GPU box: gpurun -- bash scripts/measure_r03.sh <tag>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-r03m}
+exec < /dev/null
 O=gpurun_out/$TAG; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_driver_shape.json 2>> $O/bench.err
 python bench.py --config 5 --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_config5.json 2>> $O/bench.err
+python bench.py --config 5 --streams 1 --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_config5_1stream.json 2>> $O/bench.err
 python bench.py --mode step --steps 4000 --warmup 500 --no-cpu-baseline > $O/bench_stepmode.json 2>> $O/bench.err
 python bench.py --mode step --step-kernel trio --steps 4000 --warmup 500 --no-cpu-baseline > $O/bench_stepmode_trio.json 2>> $O/bench.err
 python bench.py --config 2 --steps 20000 --warmup 500 --no-cpu-baseline > $O/bench_config2.json 2>> $O/bench.err
@@ -15,7 +17,8 @@ L=torchdriveenv_amd/libtde_hip.so
 python scripts/ab_render.py $L > $O/render.txt 2>/dev/null; python scripts/ab_render.py --stack 3 $L >> $O/render.txt 2>/dev/null; python scripts/ab_render.py --lights $L >> $O/render.txt 2>/dev/null; python scripts/ab_render.py --agents 16 $L >> $O/render.txt 2>/dev/null
 grep -v amdgpu $O/render.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config5 -o st -- python3 bench.py --config 5 --steps 300 --warmup 30 --no-cpu-baseline > $O/stats5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config5 -o st -- python3 bench.py --config 5 --streams 1 --steps 300 --warmup 30 --no-cpu-baseline > $O/stats5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config5_streams -o st -- python3 bench.py --config 5 --steps 300 --warmup 30 --no-cpu-baseline > $O/stats5s.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_step -o st -- python3 bench.py --mode step --steps 2000 --warmup 200 --no-cpu-baseline > $O/stats_step.log 2>&1
 sleep 2
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc --output-format csv -- python3 scripts/run_rollout.py 31 3 > $O/pmc_fetch.log 2>&1
