@@ -182,7 +182,8 @@ typedef struct tde_slot_cache {
     int32_t replay, replay_len; /* replay row id (-1: none) and its length; bit 30 of replay_len = entry valid */
     float tgx2, tgy2;           /* NPC: the route waypoint after the current one (a waypoint switch then needs no look-up
                                    on the step's dependent chain); undefined when route_wp + 1 >= route_n */
-    int32_t _pad0, _pad1;
+    int32_t key_flags;          /* key: config.flags & (TDE_F_NPC | TDE_F_REPLAY) of the launch that formed the entry */
+    int32_t _pad1;
 } tde_slot_cache;
 
 /* The NPC controller's action for the NEXT step of a slot, computed at the end of a step behind the judges (it only

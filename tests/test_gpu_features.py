@@ -611,3 +611,69 @@ def test_step_render_on_streams_equals_whole_batch_and_oracle(small_world, B, n_
     assert torch.equal(stk_w, stk_s) and torch.equal(ring_w, ring_s)
     with pytest.raises(Exception):
         ops.env_step_render(cfg, dw, split, [], action=a)
+
+
+@pytest.mark.parametrize("A", [16, 32])
+def test_step_forms_alternating_on_one_state_and_flag_changes_bit_exact(A):
+    """a state stepped by the one-role kernel alone (it ignores the lookup caches), and one stepped by the one- and three-role
+    forms in alternation (tde_kernel_override: the three-role kernel finds entries keyed for a state the other form has moved
+    on), over re-spawns, masked resets, a rollout in between, a host-side overwrite and a change of the NPC / REPLAY flags
+    between launches (part of the slot entries' key), equal the oracle bit for bit at every checkpoint"""
+    from torchdriveenv_amd import _lib
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=8, A=A, seed=3, n_maps=2)
+    F = _abi.F_ALL | _abi.F_TRAFFIC_LIGHTS
+    cfg = _abi.default_config(seed=29, distance_cutoff=0.25, flags=F, max_steps=40)
+    cfg_b = _abi.default_config(seed=29, distance_cutoff=0.25, flags=F & ~_abi.F_NPC, max_steps=40)
+    B = 100
+    hs = EnvState(B, A)
+    solo, mixed = EnvState(B, A, device=DEV, with_obs=True), EnvState(B, A, device=DEV, with_obs=True)
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    for ds in (solo, mixed):
+        ops.env_reset(cfg, dw, ds)
+    rng = np.random.default_rng(5)
+
+    def check(tag):
+        h = hs.host()
+        for ds in (solo, mixed):
+            d = ds.host()
+            for k, v in h.items():
+                if k == "info":
+                    assert np.array_equal(v[:, [0, 1, 3]], d[k][:, [0, 1, 3]]) and np.abs(v[:, 2] - d[k][:, 2]).max() < 1e-14, (tag, ds is solo)
+                elif k != "action":
+                    assert np.array_equal(v.view(np.uint8), d[k].view(np.uint8)), (tag, k, ds is solo)
+        assert torch.equal(solo["obs"], mixed["obs"]) and torch.equal(solo["obs"], ops.state_obs(dw, solo)), tag
+
+    try:
+        for t in range(150):
+            c = cfg_b if 70 <= t < 80 else cfg                 # ten steps without the NPC controller, then with it again
+            act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            oracle.env_step(c, world, hs)
+            _lib.kernel_override(step="solo")
+            solo["action"].copy_(dev(act))
+            ops.env_step(c, dw, solo)
+            _lib.kernel_override(step="solo" if (t // 3) % 2 else "trio")
+            mixed["action"].copy_(dev(act))
+            ops.env_step(c, dw, mixed)
+            if t % 7 == 6 or t in (70, 71, 80, 81):
+                check(t)
+            if t % 40 == 39:
+                m = ((hs["terminated"] | hs["truncated"]) | (rng.uniform(size=B) < 0.1)).astype(np.uint8)
+                oracle.env_reset(cfg, world, hs, m)
+                for ds in (solo, mixed):
+                    ops.env_reset(cfg, dw, ds, dev(m))
+            if t == 55:
+                acts = np.stack([rng.uniform(-1, 1, (9, B)), rng.uniform(-0.3, 0.3, (9, B))], -1).astype(np.float32)
+                oracle.env_rollout(cfg, world, hs, acts)
+                for ds in (solo, mixed):
+                    ops.env_rollout(cfg, dw, ds, dev(acts))
+            if t == 100:
+                for ds in (solo, mixed):
+                    ds.load(hs.host())
+        check("end")
+    finally:
+        _lib.kernel_override()
+    assert hs["episode"].max() > 1 and bool((mixed["slot_cache"][:, 7] & (1 << 30)).any())

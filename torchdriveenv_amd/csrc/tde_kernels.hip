@@ -847,6 +847,10 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     if (!valid) ag.present = false;
     EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
     Ctx cx;
+    // (the one-role kernel does not use the lookup caches even when they are there: read in its prologue and kept like the
+    //  three-role kernel keeps them they made it SLOWER - 8192 x 16: 10.4 -> 11.0 us, configs[4] on three streams 42.4 -> 44.3 -
+    //  for 6 MB more traffic per step: its wavefronts have the whole serial step ahead of them, the table chain is not what
+    //  they wait for.  profiles/r03_f_solo_with_caches.txt)
     load_ctx<A>(cfg, cold, a, ag, er, cx);
     const float2 act = reinterpret_cast<const float2 *>(action)[es];
     float c0, s0;
@@ -1634,13 +1638,15 @@ TDE_DEV void load_next_target(const Cold &w, const Agent &ag, int route_n, float
     }
 }
 
+constexpr uint32_t kSlotKeyFlags = TDE_F_NPC | TDE_F_REPLAY;   // part of a slot entry's key (store_slot_cache)
+
 template <int A>
 TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_state &st, int64_t g, int a, bool valid,
                              const int4 &s0, const int4 &s1, const int4 &s2, Agent &ag, const EnvRegs &er, Ctx &cx,
                              bool want_map, bool &rebuilt)
 {
     const uint32_t F = cfg.flags;
-    const bool hit = !valid || ((s1.w & TDE_CACHE_VALID) && s0.x == er.scn && s0.y == ag.route_wp);
+    const bool hit = !valid || ((s1.w & TDE_CACHE_VALID) && s0.x == er.scn && s0.y == ag.route_wp && s2.z == (int)(F & kSlotKeyFlags));
     rebuilt = !hit;
     cx.wtx = cx.wty = 0.0; cx.n_wp = 0;                   // (the ego's target is judge C's business)
     cx.tgx2 = cx.tgy2 = 0.0f;
@@ -1663,12 +1669,14 @@ TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_
     }
 }
 
-TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, const EnvRegs &er, const Ctx &cx)
+// (the route / replay ids of an entry are those load_ctx found under the NPC / REPLAY flags of the launch that wrote it: the
+//  two flag bits are part of the key, so a caller that switches them between launches gets a rebuilt entry, not a stale one)
+TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, const EnvRegs &er, const Ctx &cx, uint32_t F)
 {
     int4 *sc4 = reinterpret_cast<int4 *>(st.slot_cache + g);
     sc4[0] = make_int4(er.scn, ag.route_wp, __float_as_int(cx.tgx), __float_as_int(cx.tgy));
     sc4[1] = make_int4(ag.route, cx.route_n, ag.replay, cx.replay_len | TDE_CACHE_VALID);
-    sc4[2] = make_int4(__float_as_int(cx.tgx2), __float_as_int(cx.tgy2), 0, 0);
+    sc4[2] = make_int4(__float_as_int(cx.tgx2), __float_as_int(cx.tgy2), (int)(F & kSlotKeyFlags), 0);
 }
 
 template <int A, bool LIGHTS, bool OBS>
@@ -1794,7 +1802,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (!valid) return;
         store_agent_dynamic(st, g, ag);
         if (respawned) store_agent_static(st, g, ag);
-        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);
+        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx, cfg.flags);
         if (st.act_cache)
             reinterpret_cast<int4 *>(st.act_cache)[g] = make_int4(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, er.steps,
                                                                   __float_as_int(na2), __float_as_int(nb2));
