@@ -677,3 +677,40 @@ def test_step_forms_alternating_on_one_state_and_flag_changes_bit_exact(A):
     finally:
         _lib.kernel_override()
     assert hs["episode"].max() > 1 and bool((mixed["slot_cache"][:, 7] & (1 << 30)).any())
+
+
+def test_step_render_on_streams_at_configs4_size_and_odd_shapes():
+    """tde_env_step_render at BASELINE configs[4]'s full size (8192 envs x 32 agents, three streams, as bench.py runs it) against
+    tde_env_step + tde_render_ego on the whole batch: state, outputs and every pixel equal after 12 steps with re-spawns; and
+    at shapes that do not divide (1, 63, 65 envs; more streams than 64-env groups)"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    def run(world, B, n_streams, steps, seed):
+        A = world.A
+        cfg = _abi.default_config(seed=seed, distance_cutoff=0.25, max_steps=8)
+        dw = world.to_device(DEV)
+        whole, split = EnvState(B, A, device=DEV), EnvState(B, A, device=DEV)
+        ops.env_reset(cfg, dw, whole)
+        ops.env_reset(cfg, dw, split)
+        streams = [torch.cuda.Stream(device=DEV) for _ in range(n_streams)]
+        img_w = torch.zeros((B, 3, 64, 64), dtype=torch.uint8, device=DEV)
+        img_s = torch.zeros_like(img_w)
+        g = torch.Generator().manual_seed(seed)
+        ops.fork_streams(streams, DEV)
+        for t in range(steps):
+            a = torch.stack([torch.rand(B, generator=g) * 2 - 1, torch.rand(B, generator=g) * 0.6 - 0.3], -1).to(DEV)
+            ops.env_step(cfg, dw, whole, action=a)
+            ops.render_ego(cfg, dw, whole, out=img_w)
+            ops.env_step_render(cfg, dw, split, streams, action=a, out=img_s)      # (consecutive calls: ordered per sub-batch)
+        ops.join_streams(streams, DEV)
+        torch.cuda.synchronize()
+        assert torch.equal(img_w, img_s)
+        for k in ("x", "y", "psi", "v", "route_wp", "collided", "offroad", "scn", "steps", "episode", "reward", "terminated",
+                  "truncated", "target_idx", "reached", "done_bits"):
+            assert torch.equal(whole[k], split[k]), (B, n_streams, k)
+        assert int(whole["episode"].max()) >= 1
+
+    run(synthetic_world(n_scn=64, A=32, seed=0, n_maps=4), 8192, 3, 12, 5)
+    small = synthetic_world(n_scn=8, A=8, seed=1, n_maps=2)
+    for B, n in ((1, 2), (63, 3), (65, 2), (130, 16)):
+        run(small, B, n, 12, 7 + B)
