@@ -558,6 +558,16 @@ def main():
                                  "source": "profiles/traffic.json (builder's SQ_INSTS_VALU pass)"}
             except Exception:
                 traffic = None
+        t5path = os.path.join(ROOT, "profiles", "traffic_config5.json")
+        if args.config == 5 and os.path.exists(t5path):
+            try:
+                t5 = json.load(open(t5path))
+                if t5.get("envs") == B and t5.get("agents") == A:
+                    traffic = t5.get("hbm_bytes_per_timestep")
+                    traffic_source = ("profiles/traffic_config5.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the two "
+                                      "kernels at this shape, summed per timestep; not this run)")
+            except Exception:
+                traffic = None
         out = {
             "metric": "env-steps/sec", "value": env_steps / wall, "unit": "env-steps/s",
             "agent_steps_per_sec": env_steps * A / wall,
