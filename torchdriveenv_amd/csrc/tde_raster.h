@@ -4,10 +4,12 @@
 // Round 3 rewrite.  The round-2 kernel gave a view to a 256-thread workgroup: five barrier-separated passes, 16 KB of
 // LDS lists per view (7 views per CU in flight) and every wavefront repeating the per-view set-up; it sat at 60 us per
 // 8192 views with two thirds of its wave-cycles parked at barriers and waitcnts.  Here a view belongs to one wavefront:
-// no barrier anywhere (LDS operations of a wavefront execute in program order), 7 KB of LDS per view (20+ views per CU
-// in flight, each an independent instruction stream that hides the others' memory phases), and the same function is
-// called by the stand-alone kernel (render_views_kernel) and by the judges of the fused step + observation kernel
-// (env_step_obs_kernel), which hand over the post-step rows they already hold in LDS.
+// no barrier anywhere (LDS operations of a wavefront execute in program order), 5 KB of LDS and at most 64 VGPRs per view
+// (32 views per CU in flight - all 8192 of BASELINE configs[4] at once - each an independent instruction stream that hides
+// the others' memory phases).  raster_view() takes its agents through a small source interface (fetch / unpack), so the
+// caller decides where the poses come from; render_views_kernel (tde_kernels.hip) reads them from the state arrays.  (A
+// step kernel rendering from the rows it holds in LDS was costed and dropped: DESIGN.md section 5, round 3 - the step and
+// the rasteriser run side by side on HIP streams instead, tde_env_step_render.)
 //
 // Specification (shared with oracle/tde_oracle.c: tde_render_env): pixel (r, c) is sampled at its centre,
 //     u = (H/2 - 0.5) - r,  v = (W/2 - 0.5) - c,  world = ego + u * (ax, ay) + v * (bx, by)
