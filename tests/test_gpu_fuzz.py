@@ -79,3 +79,52 @@ def test_step_fuzz(seed):
         ops.env_step(cfg, dw, ds)
         if t % 5 == 4 or t < 3:
             assert_state_equal(hs.host(), ds.host(), f"seed {seed} A={A} B={B} flags={flags:#x} max_steps={cfg.max_steps} step {t}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDE_FUZZ_CASES", "8"))))
+def test_render_and_streams_fuzz(seed):
+    """the rasteriser and tde_env_step_render over random shapes: image sizes (multiples of 4, padded planes, non-square),
+    field of view, render flags, traffic lights, agents per env, forced step kernel, stream counts - pixels equal the oracle's,
+    state equal the oracle's, after steps taken through the stream form"""
+    from torchdriveenv_amd import _lib
+    from torchdriveenv_amd.synth import synthetic_world
+
+    rng = np.random.default_rng(9000 + seed)
+    A = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+    from torchdriveenv_amd.world import effective_offroad_distance
+
+    squared = bool(rng.random() < 0.3)              # (the grid index is built for the effective distance of the reading)
+    world = synthetic_world(n_scn=5, A=A, seed=400 + seed, n_maps=2, threshold=effective_offroad_distance(0.5, squared))
+    flags = _abi.F_ALL
+    if rng.random() < 0.4:
+        flags |= _abi.F_TRAFFIC_LIGHTS
+    cfg = _abi.default_config(seed=seed, distance_cutoff=0.25, flags=flags, max_steps=int(rng.choice([3, 10, 60])),
+                              offroad_threshold_squared=int(squared))
+    B = int(rng.integers(1, 40)) if A <= 16 else int(rng.integers(1, 12))
+    H, W = [(64, 64), (64, 64), (32, 32), (36, 36), (60, 64), (8, 256), (64, 32), (16, 128), (4, 4)][int(rng.integers(0, 9))]
+    fov = float(rng.choice([35.0, 20.0, 70.0]))
+    rflags = int(rng.choice([0, _abi.RENDER_LEFT_HANDED, _abi.RENDER_PLAIN_EGO, _abi.RENDER_LEFT_HANDED | _abi.RENDER_PLAIN_EGO]))
+    n_streams = int(rng.choice([1, 2, 3, 5]))
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV, with_cache=bool(rng.random() < 0.7))
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(n_streams)]
+    img = torch.zeros((B, 3, H, W), dtype=torch.uint8, device=DEV)
+    tag = f"seed {seed} A={A} B={B} {H}x{W} fov={fov} rflags={rflags} flags={flags:#x} streams={n_streams}"
+    try:
+        _lib.kernel_override(step=[None, "solo", "trio"][int(rng.integers(0, 3))])
+        for t in range(24):
+            act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            oracle.env_step(cfg, world, hs)
+            ops.fork_streams(streams, DEV)
+            ops.env_step_render(cfg, dw, ds, streams, action=dev(act), out=img, H=H, W=W, fov=fov, flags=rflags)
+            ops.join_streams(streams, DEV)
+            if t % 6 == 5 or t < 2:
+                want = oracle.render_ego(cfg, world, hs, H=H, W=W, fov=fov, flags=rflags)
+                got = img.cpu().numpy()
+                assert np.array_equal(got, want), (tag, t, int((got != want).sum()))
+                assert_state_equal(hs.host(), ds.host(), f"{tag} step {t}")
+    finally:
+        _lib.kernel_override()
