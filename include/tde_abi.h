@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 7
+#define TDE_ABI_VERSION 8
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -175,21 +175,24 @@ typedef struct tde_world {
  * Each entry carries the key it was formed for; the kernel uses it only when the key equals the current state and
  * rebuilds it otherwise, so any writer of the state (reset, rollout, host edits) leaves the caches correct by
  * construction.  An entry is valid when its TDE_CACHE_VALID bit is set (zero-initialised memory is invalid). */
-typedef struct tde_slot_cache {
-    int32_t scn, route_wp;      /* key: the env's scenario and this slot's route waypoint index */
+typedef struct tde_slot_cache {  /* 32 bytes (ABI 8; 48 before) */
+    int32_t scn;                /* key: the env's scenario */
+    int32_t key;                /* key: this slot's route waypoint index (bits 0-15) | (config.flags & (TDE_F_NPC | TDE_F_REPLAY)) << 16
+                                   (the ids below are what the launch that formed the entry found under those flags) | TDE_CACHE_VALID */
     float tgx, tgy;             /* NPC: current route waypoint */
-    int32_t route, route_n;     /* NPC: route id (-1: none) and its length */
-    int32_t replay, replay_len; /* replay row id (-1: none) and its length; bit 30 of replay_len = entry valid */
+    uint32_t route;             /* NPC: route id + 1 (bits 0-19; 0: none) | route length << 20 */
+    uint32_t replay;            /* replay row id + 1 (bits 0-19; 0: none) | replay length << 20 */
     float tgx2, tgy2;           /* NPC: the route waypoint after the current one (a waypoint switch then needs no look-up
-                                   on the step's dependent chain); undefined when route_wp + 1 >= route_n */
-    int32_t key_flags;          /* key: config.flags & (TDE_F_NPC | TDE_F_REPLAY) of the launch that formed the entry */
-    int32_t _pad1;
+                                   on the step's dependent chain); undefined when route_wp + 1 >= route length */
 } tde_slot_cache;
+/* (ids below 2^20 - 1 and lengths below 4096: tde_env_step uses its one-role kernel, which needs no caches, for a world beyond) */
+#define TDE_CACHE_ID_BITS 20
 
-/* The NPC controller's action for the NEXT step of a slot, computed at the end of a step behind the judges (it only
- * needs the state after the step), keyed by the (episode, environment_steps) pair of the state it was computed from. */
+/* The NPC controller's actions for the NEXT step, computed at the end of a step behind the judges (they only need the state
+ * after the step).  [B * (A + 1)] entries of 8 bytes: env e's slots at e * (A + 1) + a, then ONE key entry for the env at
+ * e * (A + 1) + A holding, as two int32, the (episode, environment_steps) pair of the state the actions were computed from
+ * (episode < 0: invalid).  (ABI 8; 16 bytes per slot with a key each before.) */
 typedef struct tde_act_cache {
-    int32_t episode, steps;     /* key; episode < 0: invalid */
     float acc, beta;
 } tde_act_cache;
 
@@ -242,7 +245,7 @@ typedef struct tde_state {
     tde_slot_cache *slot_cache; /* in/out [B*A], tde_env_step only, may be NULL (with env_cache): see above.  With both caches
                                    present (and 8, 16 or 32 agents per env) tde_env_step runs its three-role kernel */
     tde_env_cache *env_cache;   /* in/out [B] */
-    tde_act_cache *act_cache;   /* in/out [B*A], may be NULL: with it the three-role step applies the stored NPC actions at once
+    tde_act_cache *act_cache;   /* in/out [B*(A+1)], may be NULL: with it the three-role step applies the stored NPC actions at once
                                    and computes the next step's behind the judges.  The key cannot see a state that was edited
                                    from outside with its counters unchanged: zero / invalidate the cache after such an edit
                                    (EnvState.load does) */

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 7
+TDE_ABI_VERSION = 8
 TDE_MAX_AGENTS = 64
 
 F_NPC = 1 << 0
@@ -178,7 +178,7 @@ def state_shapes(B, A):
     sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "tl_violation": (B,),
                "info": (B, 4),
                "info_reached": (B,), "done_bits": (B,), "obs": (B, 8), "ep_return": (B,), "ep_final": (B,),
-               "ep_final_len": (B,), "slot_cache": (B * A, 12), "env_cache": (B, 8), "act_cache": (B * A, 4)})
+               "ep_final_len": (B,), "slot_cache": (B * A, 8), "env_cache": (B, 8), "act_cache": (B * (A + 1), 2)})
     return sh
 
 

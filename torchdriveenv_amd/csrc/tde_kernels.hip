@@ -1640,13 +1640,19 @@ TDE_DEV void load_next_target(const Cold &w, const Agent &ag, int route_n, float
 
 constexpr uint32_t kSlotKeyFlags = TDE_F_NPC | TDE_F_REPLAY;   // part of a slot entry's key (store_slot_cache)
 
+// key word of a slot entry (tde_slot_cache.key)
+TDE_DEV int slot_key(const Agent &ag, uint32_t F)
+{
+    return (ag.route_wp & 0xFFFF) | (int)((F & kSlotKeyFlags) << 16) | TDE_CACHE_VALID;
+}
+
 template <int A>
 TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_state &st, int64_t g, int a, bool valid,
-                             const int4 &s0, const int4 &s1, const int4 &s2, Agent &ag, const EnvRegs &er, Ctx &cx,
+                             const int4 &s0, const int4 &s1, Agent &ag, const EnvRegs &er, Ctx &cx,
                              bool want_map, bool &rebuilt)
 {
     const uint32_t F = cfg.flags;
-    const bool hit = !valid || ((s1.w & TDE_CACHE_VALID) && s0.x == er.scn && s0.y == ag.route_wp && s2.z == (int)(F & kSlotKeyFlags));
+    const bool hit = !valid || (s0.x == er.scn && s0.y == slot_key(ag, F));
     rebuilt = !hit;
     cx.wtx = cx.wty = 0.0; cx.n_wp = 0;                   // (the ego's target is judge C's business)
     cx.tgx2 = cx.tgy2 = 0.0f;
@@ -1658,8 +1664,10 @@ TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_
     }
     if (hit) {
         cx.tgx = __int_as_float(s0.z); cx.tgy = __int_as_float(s0.w);
-        ag.route = s1.x; cx.route_n = s1.y; ag.replay = s1.z; cx.replay_len = s1.w & ~TDE_CACHE_VALID;
-        cx.tgx2 = __int_as_float(s2.x); cx.tgy2 = __int_as_float(s2.y);
+        constexpr uint32_t idm = (1u << TDE_CACHE_ID_BITS) - 1u;
+        ag.route = (int)((uint32_t)s1.x & idm) - 1; cx.route_n = (int)((uint32_t)s1.x >> TDE_CACHE_ID_BITS);
+        ag.replay = (int)((uint32_t)s1.y & idm) - 1; cx.replay_len = (int)((uint32_t)s1.y >> TDE_CACHE_ID_BITS);
+        cx.tgx2 = __int_as_float(s1.z); cx.tgy2 = __int_as_float(s1.w);
         cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
         if (want_map && (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS))) {
             const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + (g / A))[0];     // scn, target_idx, n_wp, map
@@ -1673,10 +1681,12 @@ TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_
 //  two flag bits are part of the key, so a caller that switches them between launches gets a rebuilt entry, not a stale one)
 TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, const EnvRegs &er, const Ctx &cx, uint32_t F)
 {
+    static_assert(sizeof(tde_slot_cache) == 32, "two 16-byte words per slot");
     int4 *sc4 = reinterpret_cast<int4 *>(st.slot_cache + g);
-    sc4[0] = make_int4(er.scn, ag.route_wp, __float_as_int(cx.tgx), __float_as_int(cx.tgy));
-    sc4[1] = make_int4(ag.route, cx.route_n, ag.replay, cx.replay_len | TDE_CACHE_VALID);
-    sc4[2] = make_int4(__float_as_int(cx.tgx2), __float_as_int(cx.tgy2), (int)(F & kSlotKeyFlags), 0);
+    sc4[0] = make_int4(er.scn, slot_key(ag, F), __float_as_int(cx.tgx), __float_as_int(cx.tgy));
+    sc4[1] = make_int4((int)((uint32_t)(ag.route + 1) | ((uint32_t)cx.route_n << TDE_CACHE_ID_BITS)),
+                       (int)((uint32_t)(ag.replay + 1) | ((uint32_t)cx.replay_len << TDE_CACHE_ID_BITS)),
+                       __float_as_int(cx.tgx2), __float_as_int(cx.tgy2));
 }
 
 template <int A, bool LIGHTS, bool OBS>
@@ -1720,13 +1730,19 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         EnvRegs er{st.scn[es], st.steps[es], 0, 0, st.episode[es]};
         const float2 act = reinterpret_cast<const float2 *>(st.action)[es];
         const int4 *sc4 = reinterpret_cast<const int4 *>(st.slot_cache + gs);
-        const int4 sc0 = sc4[0], sc1 = sc4[1], sc2 = sc4[2];
-        int4 ac = make_int4(-1, 0, 0, 0);                                    // episode, steps, acc, beta
-        if (st.act_cache) ac = reinterpret_cast<const int4 *>(st.act_cache)[gs];
+        const int4 sc0 = sc4[0], sc1 = sc4[1];
+        // the stored action of this slot and the key of its env's entries (tde_act_cache: A + 1 entries per env)
+        float2 ac = make_float2(0.0f, 0.0f);
+        int2 akey = make_int2(-1, 0);                                        // episode, steps
+        if (st.act_cache) {
+            const float2 *ap = reinterpret_cast<const float2 *>(st.act_cache) + (int64_t)es * (A + 1);
+            ac = ap[a];
+            akey = reinterpret_cast<const int2 *>(ap)[A];
+        }
         lds_barrier();                                                       // cold is published
         Ctx cx;
         bool rebuilt;
-        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, sc2, ag, er, cx, LIGHTS, rebuilt);
+        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, ag, er, cx, LIGHTS, rebuilt);
         float c0, s0;
         const bool live = valid && ag.present;
         const int k = er.steps + 1;                                          // :116
@@ -1749,7 +1765,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                           red_gap, na, nb);
         };
         if (F & TDE_F_NPC) {
-            const bool stored = !npc || (ac.x == er.episode && ac.y == er.steps);
+            const bool stored = !npc || (akey.x == er.episode && akey.y == er.steps);
             if (__ballot(!stored)) {
                 sincos_f32(ag.psi, s0, c0);
                 write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
@@ -1758,7 +1774,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 controller(1, k, na, nb);
                 if (npc) { acc = na; beta = nb; }
             } else if (npc) {
-                acc = __int_as_float(ac.z); beta = __int_as_float(ac.w);
+                acc = ac.x; beta = ac.y;
             }
         }
         if (live) {
@@ -1803,9 +1819,12 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         store_agent_dynamic(st, g, ag);
         if (respawned) store_agent_static(st, g, ag);
         if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx, cfg.flags);
-        if (st.act_cache)
-            reinterpret_cast<int4 *>(st.act_cache)[g] = make_int4(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, er.steps,
-                                                                  __float_as_int(na2), __float_as_int(nb2));
+        if (st.act_cache) {
+            float2 *ap = reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1);
+            ap[a] = make_float2(na2, nb2);
+            if (a == 0)     // (re-spawn is per env: the ego lane's flag is the env's)
+                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, er.steps);
+        }
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================
         __builtin_amdgcn_s_setprio(TDE_SPRIO_C);
@@ -2425,7 +2444,10 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     //  controller and walked the record -> route table chain: +3.4 us with TDE_F_AUTORESET; now +1).  Three roles up to
     // 131 072 agent slots, one role above (configs[4]: 8192 x 32).  tde_kernel_override(0, 1 | 3) forces one.
     const int force = g_force_step;
-    const bool trio_ok = st->slot_cache && st->env_cache && (st->A == 8 || st->A == 16 || st->A == 32);
+    // (slot entries pack route / replay ids into 20 bits and their lengths into 12: tde_abi.h)
+    const int32_t id_max = (1 << TDE_CACHE_ID_BITS) - 1, len_max = 1 << (32 - TDE_CACHE_ID_BITS);
+    const bool packable = world->n_routes < id_max && world->n_replay < id_max && world->RW < len_max && world->RT < len_max;
+    const bool trio_ok = st->slot_cache && st->env_cache && packable && (st->A == 8 || st->A == 16 || st->A == 32);
     const bool want_trio = force == 3 || (force == 0 && load_slots <= 131072);
     if (trio_ok && want_trio) {
         const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
@@ -2483,7 +2505,7 @@ static tde_state state_slice(const tde_state &s, int64_t e0, int32_t n)
     TDE_ADV(scn, e0); TDE_ADV(steps, e0); TDE_ADV(target_idx, e0); TDE_ADV(reached, e0); TDE_ADV(episode, e0);
     TDE_ADV(action, 2 * e0); TDE_ADV(reward, e0); TDE_ADV(terminated, e0); TDE_ADV(truncated, e0); TDE_ADV(tl_violation, e0);
     TDE_ADV(info, 4 * e0); TDE_ADV(info_reached, e0); TDE_ADV(done_bits, e0); TDE_ADV(obs, 8 * e0); TDE_ADV(ep_return, e0);
-    TDE_ADV(ep_final, e0); TDE_ADV(ep_final_len, e0); TDE_ADV(slot_cache, g0); TDE_ADV(env_cache, e0); TDE_ADV(act_cache, g0);
+    TDE_ADV(ep_final, e0); TDE_ADV(ep_final_len, e0); TDE_ADV(slot_cache, g0); TDE_ADV(env_cache, e0); TDE_ADV(act_cache, g0 + e0);
 #undef TDE_ADV
     t.B = n;
     return t;

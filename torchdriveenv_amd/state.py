@@ -60,8 +60,7 @@ class EnvState:
                     self.arrays[n] = self._arena[o:o + nb].view(dt).view(sh)
                 else:
                     self.arrays[n] = torch.zeros(sh, dtype=dt, device=device)
-        if self.arrays.get("act_cache") is not None:
-            self.arrays["act_cache"][:, 0] = -1                   # episode key < 0: invalid
+        self._invalidate_act_keys()
         self.struct = _abi.fill_state_struct(self.arrays, B, A)
 
     def fetch_outputs(self):
@@ -89,6 +88,12 @@ class EnvState:
             out[n] = a.copy() if isinstance(a, np.ndarray) else a.detach().cpu().numpy()
         return out
 
+    def _invalidate_act_keys(self):
+        """the per-env key entries of the action cache (tde_act_cache: entry A of every group of A + 1): episode < 0 = invalid"""
+        a = self.arrays.get("act_cache")
+        if a is not None:
+            a.reshape(self.B, self.A + 1, 2)[:, self.A, 0] = -1
+
     def invalidate_caches(self):
         """forget the step's lookup / action caches (call after editing state arrays by hand: the action cache is keyed by
         the episode / step counters only)"""
@@ -96,8 +101,7 @@ class EnvState:
             a = self.arrays.get(n)
             if a is not None:
                 a.fill(0) if isinstance(a, np.ndarray) else a.zero_()
-                if n == "act_cache":
-                    (a[:, 0].fill(-1) if isinstance(a, np.ndarray) else a[:, 0].fill_(-1))
+        self._invalidate_act_keys()
 
     def load(self, host_arrays):
         """overwrite from a dict of numpy arrays (e.g. another state's .host()); the caches are invalidated"""
