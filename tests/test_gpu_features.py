@@ -715,3 +715,29 @@ def test_step_render_on_streams_at_configs4_size_and_odd_shapes():
     small = synthetic_world(n_scn=8, A=8, seed=1, n_maps=2)
     for B, n in ((1, 2), (63, 3), (65, 2), (130, 16)):
         run(small, B, n, 12, 7 + B)
+
+
+def test_world_beyond_the_packed_cache_entry_takes_the_one_role_kernel(small_world):
+    """a world whose route / replay ids or lengths do not fit tde_slot_cache's packed words (>= 2^20 - 1 ids, >= 4096 entries) is
+    stepped by the one-role kernel although the caches are present: results equal the oracle's, no cache entry is ever written"""
+    import copy
+
+    cfg = _abi.default_config(seed=8, distance_cutoff=0.25, max_steps=20)
+    B, A = 64, small_world.A
+    hs, ds, dw = _pair(small_world, B, A, cfg)
+    big = copy.copy(dw)
+    big.struct = type(dw.struct).from_buffer_copy(dw.struct)
+    big.struct.n_routes = 1 << 20                          # (a count only: nothing indexes with it)
+    rng = np.random.default_rng(2)
+    for t in range(30):
+        act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, small_world, hs)
+        ops.env_step(cfg, big, ds)
+    h, d = hs.host(), ds.host()
+    for k in ("x", "y", "psi", "v", "steps", "episode", "reward", "collided", "offroad", "terminated", "truncated"):
+        assert np.array_equal(h[k].view(np.uint8), d[k].view(np.uint8)), k
+    assert not bool((ds["slot_cache"][:, 1] & (1 << 30)).any())
+    ops.env_step(cfg, dw, ds)                              # the same state under the real counts: three roles, entries appear
+    assert bool((ds["slot_cache"][:, 1] & (1 << 30)).any())
