@@ -409,6 +409,8 @@ def main():
                                        local_rank)
     cfg_flags = int(cfg.flags)
     act_rows = [actions[i] for i in range(CH)]      # views made once: slicing a tensor costs microseconds of host time
+    if args.streams is not None and (args.config != 5 or not 1 <= args.streams <= 16):
+        raise SystemExit("--streams applies to --config 5 only and must be in [1, 16]")
     n_streams = (args.streams or 3) if args.config == 5 else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else []
     stream_ptrs = [s_.cuda_stream for s_ in streams]
