@@ -890,11 +890,13 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
             // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it.  The cached
             // ego target is current unless the reward path is off or the episode just ended without a re-spawn.
             const bool ended = (o.terminated | o.truncated) && !o.respawned;
-            bool has;
-            double tx, ty;
-            if ((cfg.flags & TDE_F_REWARD) && !ended) {
-                has = er.target_idx < cx.n_wp; tx = cx.wtx; ty = cx.wty;
-            } else {
+            // (the target from cx as VALUES behind an empty asm: left to itself the compiler turns "cx.wtx or the table entry" into
+            //  ONE load through a select of ADDRESSES, which pins cx in scratch memory - 24 B of private segment, and a one-step
+            //  launch with a private segment costs 1.3 us more to dispatch, profiles/r03_g_step_outputs_cost.txt)
+            bool has = er.target_idx < cx.n_wp;
+            double tx = cx.wtx, ty = cx.wty;
+            asm volatile("" : "+v"(tx), "+v"(ty));            // (values, not loads from cx: nothing to merge with the load below)
+            if (!(cfg.flags & TDE_F_REWARD) || ended) {
                 has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
                 const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
                 tx = t2.x; ty = t2.y;
@@ -1925,11 +1927,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             }
             if (OBS && st.obs) {
                 const bool ended = (term | trunc) && !respawned;
-                bool has;
-                double tx, ty;
-                if ((F & TDE_F_REWARD) && !ended) {
-                    has = er.target_idx < cx.n_wp; tx = cx.wtx; ty = cx.wty;
-                } else {
+                bool has = er.target_idx < cx.n_wp;          // (one-armed, values pinned: see env_step_kernel)
+                double tx = cx.wtx, ty = cx.wty;
+                asm volatile("" : "+v"(tx), "+v"(ty));
+                if (!(F & TDE_F_REWARD) || ended) {
                     has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
                     const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
                     tx = t2.x; ty = t2.y;
