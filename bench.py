@@ -155,18 +155,19 @@ def secondary(dev, region_s=0.3):
 
     from torchdriveenv_amd import _abi, _ext, ops
     from torchdriveenv_amd.state import EnvState
-    from torchdriveenv_amd.synth import synthetic_world
+    from torchdriveenv_amd.synth import synthetic_town, synthetic_world
 
     worlds = {}
 
-    def world_of(A):
-        if A not in worlds:
-            w = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
-            worlds[A] = (w, w.to_device(dev))
-        return worlds[A]
+    def world_of(A, town=False):
+        if (A, town) not in worlds:
+            worlds.clear()                             # one world resident at a time (a town's tables are ~140 MB)
+            w = synthetic_town(n_scn=256, A=A, seed=0) if town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+            worlds[(A, town)] = (w, w.to_device(dev))
+        return worlds[(A, town)]
 
-    def run(name, config, B, A, stepwise, flags, render=False, n_streams=1, with_info=False, **cfg_over):
-        w, dw = world_of(A)
+    def run(name, config, B, A, stepwise, flags, render=False, n_streams=1, with_info=False, town=False, **cfg_over):
+        w, dw = world_of(A, town)
         cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=flags, **cfg_over)
         st = EnvState(B, A, device=dev, with_info=with_info, with_obs=with_info)
         ops.env_reset(cfg, dw, st)
@@ -244,6 +245,14 @@ def secondary(dev, region_s=0.3):
                         config=3, B=8192, A=16, stepwise=False, flags=F | _abi.F_TRAFFIC_LIGHTS)),
         ("long_episodes", dict(name="configs[2] with episodes that end by truncation at 200 steps only (terminated_at_infraction = 0), rollout",
                                config=3, B=8192, A=16, stepwise=False, flags=F, terminated_at_infraction=0)),
+        # the reference's map size (a CARLA town's drivable mesh): ONE 1 km x 1 km map of 5.7e4 triangles, 100
+        # junctions, 256 scenarios spread over it (synth.synthetic_town) instead of four 200-triangle junction maps
+        ("town", dict(name="configs[2] on the town map (1 km^2, 5.7e4 triangles, 256 scenarios), rollout",
+                      config=3, B=8192, A=16, stepwise=False, flags=F, town=True)),
+        ("town_closed_loop", dict(name="configs[2] shape on the town map, closed loop: one tde_env_step launch per timestep",
+                                  config=3, B=8192, A=16, stepwise=True, flags=F, town=True)),
+        ("town_config5", dict(name="configs[4] on the town map: 8192 envs x 32 agents, full step + birdview, three sub-batches on three streams",
+                              config=5, B=8192, A=32, stepwise=True, flags=F, render=True, n_streams=3, town=True)),
     ):
         try:
             out[key] = run(**kw)
@@ -333,6 +342,9 @@ def main():
                     help="config 5 only: run each timestep as this many sub-batches on their own HIP streams "
                          "(tde_env_step_render: the step of one sub-batch overlaps the rasteriser of another); default 3 "
                          "(us per timestep by stream count: profiles/r03_f_config5_streams_matrix.txt; more than 3 needs GPU_MAX_HW_QUEUES > 4), 1 = one stream")
+    ap.add_argument("--world", default="junctions", choices=["junctions", "town"],
+                    help="junctions: four ~200-triangle junction maps, 64 scenarios (the SURVEY 8d recipe; default); town: one "
+                         "1 km x 1 km map of 5.7e4 triangles with 256 scenarios (the reference's map size, SURVEY R10)")
     ap.add_argument("--rollout-kernel", default=None, choices=["solo", "duo", "trio"],
                     help="force a form of the rollout kernel (A/B runs; default: the library's choice by group shape)")
     ap.add_argument("--step-kernel", default=None, choices=["solo", "trio"],
@@ -351,7 +363,7 @@ def main():
     from torchdriveenv_amd import _abi, _lib, ops
     from torchdriveenv_amd.sharding import shard_config, shard_range
     from torchdriveenv_amd.state import EnvState
-    from torchdriveenv_amd.synth import synthetic_world
+    from torchdriveenv_amd.synth import synthetic_town, synthetic_world
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -385,7 +397,10 @@ def main():
     C = CONFIGS[args.config]
     B, A = (args.envs or C["envs"]), C["agents"]
     n = world_size
-    world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)          # same tables on every GPU (replicated)
+    if args.world == "town":
+        world = synthetic_town(n_scn=256, A=A, seed=0)
+    else:
+        world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)      # same tables on every GPU (replicated)
     flags = 0 if args.config == 2 else _abi.F_ALL
     base_cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=flags)   # shipped reward constants
     cfg, nb = shard_config(base_cfg, rank, n, B * n)                  # env_base = rank * B: shard of the global batch
@@ -544,7 +559,7 @@ def main():
         traffic = traffic_source = None
         issue = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.config == 3 and not stepwise:
+        if os.path.exists(tpath) and args.config == 3 and not stepwise and args.world == "junctions":
             try:
                 tj = json.load(open(tpath))
                 full = [k for k in lens if k == CH]
@@ -564,7 +579,7 @@ def main():
             except Exception:
                 traffic = None
         t5path = os.path.join(ROOT, "profiles", "traffic_config5.json")
-        if args.config == 5 and os.path.exists(t5path):
+        if args.config == 5 and os.path.exists(t5path) and args.world == "junctions":
             try:
                 t5 = json.load(open(t5path))
                 if t5.get("envs") == B and t5.get("agents") == A:
@@ -579,7 +594,9 @@ def main():
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "repeats": repeats,
             "ms_per_step": wall * 1e3 / total,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{C['name']}: {B} envs x {A} agents per GPU, {C['what']}",
+            "config": {"workload": f"{C['name']}: {B} envs x {A} agents per GPU, {C['what']}" +
+                                   (" [town map: 1 km^2, 5.7e4 triangles, 256 scenarios]" if args.world == "town" else ""),
+                       "world": args.world,
                        "envs_per_gpu": B, "agents_per_env": A, "global_envs": B * n, "mode": args.mode,
                        "binding": (args.binding if stepwise else "ctypes"),
                        "streams": max(1, n_streams), "steps_per_call": spl, "timed_steps": total, "untimed_warmup_steps": warm_steps + CH,

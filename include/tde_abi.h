@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 8
+#define TDE_ABI_VERSION 9
 #define TDE_MAX_AGENTS 64
 
 /* feature bits of tde_config.flags */
@@ -96,6 +96,11 @@ typedef struct tde_map {
     int32_t cycle_steps;        /* length of the cycle in env steps (0: no lights) */
     int32_t row_shift;          /* log2 of the row pitch of the map's cell words (>= 5) */
     int32_t cls2_base;          /* first 128-byte tile of this map in tde_world.cell_cls2 (in tiles) */
+    int32_t rec_base;           /* (ABI 9) first candidate record of this map in tde_world.cell_tri: the 22-bit record offset of a
+                                   cell word counts from here, so every map has 2^22 records of its own (a town mesh of 6e4
+                                   triangles needs ~2e5 after identical lists are shared; one global offset ran out at the
+                                   second town) */
+    int32_t _pad0[3];           /* 80 bytes: the kernels read the struct with 16-byte loads */
 } tde_map;
 
 /* A stop line: an oriented box across an inbound lane, governed by traffic light `light` of its map
@@ -143,7 +148,8 @@ typedef struct tde_world {
     const tde_map *maps;        /* [n_maps] */
     const float *tri;           /* [n_tri_total][6]  ax,ay,bx,by,cx,cy (what the oracle's brute force reads) */
     const uint32_t *cell_word;  /* [n_cells_total] grid index (kernels): bits 0-1 TDE_CELL_*; MIXED cells: bits 2-9
-                                   number of candidate triangles, bits 10-31 first record in cell_tri; FULL / EMPTY
+                                   number of candidate triangles, bits 10-31 first record in cell_tri counted from the map's
+                                   rec_base (cells with the same candidates share their records); FULL / EMPTY
                                    cells: bits 2-9 clearance in units of TDE_CLEARANCE_UNIT (every point that close to the cell
                                    lies in a cell of the same class) */
     const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
@@ -168,6 +174,22 @@ typedef struct tde_world {
     int32_t n_maps, n_scn, NW, A;
     int32_t n_routes, RW, n_replay, RT;
 } tde_world;
+
+/* What tde_grid_build (include/tde_hip.h) returns for ONE map: the offroad grid index of a drivable mesh, row-major
+ * [ny * nx] HOST arrays owned by the library (tde_grid_free).  The caller packs them into the tde_world tables: a cell's word
+ * = cell_class | cell_count << 2 | cell_first << 10, rows at a pitch of 2^row_shift; cell_cls2 / cell_sub in their tiles;
+ * cell_tri = the packed records of triangles rec_tri[] (torchdriveenv_amd/world.py: assemble_world). */
+typedef struct tde_grid {
+    float ox, oy, cell;         /* grid origin (integers) and cell edge */
+    int32_t nx, ny;             /* multiples of 8; >= 2 EMPTY cells on every side of the mesh */
+    int64_t n_lists;            /* distinct candidate lists */
+    int64_t n_records;          /* their total length (< 2^22) */
+    uint8_t *cell_class;        /* TDE_CELL_* */
+    uint8_t *cell_count;        /* MIXED: number of candidates (<= TDE_CELL_MAX_TRIS); FULL / EMPTY: clearance in TDE_CLEARANCE_UNITs */
+    uint32_t *cell_first;       /* MIXED: first record of the cell's list in rec_tri (map-relative) */
+    uint32_t *cell_sub;         /* MIXED: the 2-bit classes of the cell's TDE_CELL_SUB x TDE_CELL_SUB sub-cells */
+    int32_t *rec_tri;           /* [n_records] triangle index (into the mesh handed in) of every record */
+} tde_grid;
 
 /* Optional lookup caches of the closed-loop step (tde_env_step): what the step needs from the scenario tables for a
  * slot / an env, kept next to the state so that a one-step launch starts with independent loads instead of the chain

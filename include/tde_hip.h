@@ -118,6 +118,20 @@ TDE_API int tde_env_step_render(const tde_config *cfg, const tde_world *world, c
  * instead of a dozen framework ops per step in closed-loop use. */
 TDE_API int tde_state_obs(const tde_world *world, const tde_state *state, float *out, void *stream);
 
+/* ---- host side: static tables ------------------------------------------------------------------------------------ */
+
+/* Offroad grid index of ONE drivable mesh - what the simulator prepares once per map from the road mesh it is constructed
+ * with (Simulator(road_mesh=map_cfg.road_mesh), gym_env.py:184, 260) so that compute_offroad (:142) is a cell look-up plus a
+ * few candidate triangles instead of a pass over the mesh.  HOST pointers, no GPU involved, synchronous, n_threads host
+ * threads (0 = all).  tri = [n_tri][6] fp32 vertices ax,ay,bx,by,cx,cy (the fp32 values the kernels and the oracle see);
+ * threshold = the effective offroad distance in metres (sqrt of the threshold under offroad_threshold_squared); cell = cell
+ * edge; margin = classification margin (0.05: absorbs fp32 evaluation at coordinates of kilometres).  Classes and lists are
+ * conservative (csrc/tde_gridbuild.h), so the kernels' masks equal a brute-force pass over every triangle.  The result is
+ * owned by the library until tde_grid_free. */
+TDE_API int tde_grid_build(const float *tri, int32_t n_tri, float threshold, float cell, float margin, int32_t n_threads,
+                           tde_grid **out);
+TDE_API void tde_grid_free(tde_grid *grid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,8 @@ def lib():
         L.tde_oracle_point_tri_d2.restype = C.c_float
         L.tde_oracle_point_mesh_d2.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_int32]
         L.tde_oracle_point_mesh_d2.restype = C.c_float
+        L.tde_oracle_point_near_mesh.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_float]
+        L.tde_oracle_point_near_mesh.restype = C.c_int
         L.tde_oracle_compute_offroad.argtypes = ([C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
                                                  [C.POINTER(_abi.TdeWorld), C.c_void_p, C.c_float, C.c_void_p])
         L.tde_oracle_compute_offroad.restype = None
@@ -139,6 +141,12 @@ def compute_offroad(B, A, x, y, psi, length, width, present, world, map_of_env, 
 def point_mesh_d2(px, py, tri):
     tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 6)
     return lib().tde_oracle_point_mesh_d2(float(px), float(py), _p(tri), len(tri))
+
+
+def point_near_mesh(px, py, tri, thr2):
+    """the predicate the oracle's offroad test and raster use (bounding-box reject + exact distance): == point_mesh_d2 <= thr2"""
+    tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 6)
+    return bool(lib().tde_oracle_point_near_mesh(float(px), float(py), _p(tri), len(tri), float(thr2)))
 
 
 def philox(seed, c0, c1, c2, c3):

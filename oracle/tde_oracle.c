@@ -221,6 +221,26 @@ TDE_EXPORT float tde_oracle_point_mesh_d2(float px, float py, const float *tri, 
     return best;
 }
 
+/* Whether some triangle of the mesh lies within sqrt(thr2) of the point: the truth value of
+ * `tde_oracle_point_mesh_d2(...) <= thr2`, still a pass over EVERY triangle (no index), with one exact shortcut that makes a
+ * town mesh (6e4 triangles) affordable: a triangle whose bounding box is more than R = sqrt(thr2) + 1 cm away from the point
+ * along an axis is farther than R from it, and its computed d2 (relative error ~1e-6, coordinates of kilometres rounded to
+ * ~1e-4 m) exceeds thr2 - it could not have been the triangle that decides.  tests/test_oracle_math.py holds the two forms
+ * against each other on points around the road edges of the junction maps and of the town. */
+TDE_EXPORT int tde_oracle_point_near_mesh(float px, float py, const float *tri, int32_t n_tri, float thr2)
+{
+    const float R = sqrtf(thr2) + 0.01f;
+    const float xl = px - R, xh = px + R, yl = py - R, yh = py + R;
+    for (int32_t k = 0; k < n_tri; ++k) {
+        const float *t = tri + 6 * (int64_t)k;
+        if ((t[0] < xl && t[2] < xl && t[4] < xl) || (t[0] > xh && t[2] > xh && t[4] > xh) ||
+            (t[1] < yl && t[3] < yl && t[5] < yl) || (t[1] > yh && t[3] > yh && t[5] > yh))
+            continue;
+        if (tde_oracle_point_tri_d2(px, py, t) <= thr2) return 1;
+    }
+    return 0;
+}
+
 /* the four box corners, in the order FL, FR, RR, RL */
 static inline void tde_corners(float x, float y, float c, float s, float hl, float hw, float *cx, float *cy)
 {
@@ -239,7 +259,7 @@ static int tde_agent_offroad(const tde_world *w, int32_t map_id, float x, float 
     float cx[4], cy[4];
     tde_corners(x, y, c, s, hl, hw, cx, cy);
     for (int k = 0; k < 4; ++k)
-        if (tde_oracle_point_mesh_d2(cx[k], cy[k], tri, m->n_tri) > thr2) return 1;
+        if (!tde_oracle_point_near_mesh(cx[k], cy[k], tri, m->n_tri, thr2)) return 1;
     return 0;
 }
 
@@ -773,7 +793,7 @@ static void tde_render_env(const tde_config *cfg, const tde_world *w, const tde_
             const float wx = fmaf(v, bx, fmaf(u, ax, ex));
             const float wy = fmaf(v, by, fmaf(u, ay, ey));
             const uint8_t *col = BG;
-            if (!(tde_oracle_point_mesh_d2(wx, wy, tri, m->n_tri) > thr2)) col = ROAD;
+            if (tde_oracle_point_near_mesh(wx, wy, tri, m->n_tri, thr2)) col = ROAD;
             if (lights)
                 for (int32_t k = 0; k < m->n_stop; ++k) {
                     const tde_stopline *sl = &w->stoplines[m->stop_base + k];

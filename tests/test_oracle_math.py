@@ -110,7 +110,8 @@ def grid_offroad_numpy(world, map_id, px, py, thr, use_sub=False):
                 out[i] = sc == _abi.CELL_EMPTY
                 continue
         ok = False
-        for k in range(wd >> 10, (wd >> 10) + ((wd >> 2) & 255)):
+        first = int(m["rec_base"]) + (wd >> 10)         # record offsets count from the map's rec_base (ABI 9)
+        for k in range(first, first + ((wd >> 2) & 255)):
             if oracle.point_mesh_d2(x, y, recs[k, :6]) <= f(thr) * f(thr):
                 ok = True
                 break
@@ -138,3 +139,43 @@ def test_grid_index_equals_brute_force(small_world):
         got = grid_offroad_numpy(w, map_id, px, py, 0.5, use_sub=True)     # what the rasteriser does in MIXED cells
         assert np.array_equal(got, want)
         assert 0.2 < want.mean() < 0.95
+
+
+def _edge_points(tri, n, rng, spread=0.6):
+    """points scattered around the mesh's vertices and edge midpoints (where the offroad predicate flips) plus a few far ones"""
+    t = np.asarray(tri, np.float64).reshape(-1, 3, 2)
+    k = rng.integers(len(t), size=n)
+    a, b = t[k, rng.integers(3, size=n)], t[k, rng.integers(3, size=n)]
+    p = a + (b - a) * rng.uniform(size=(n, 1)) + rng.normal(0, spread, (n, 2))
+    far = rng.uniform(size=n) < 0.1
+    lo, hi = t.reshape(-1, 2).min(0) - 5, t.reshape(-1, 2).max(0) + 5
+    p[far] = rng.uniform(lo, hi, (int(far.sum()), 2))
+    return p[:, 0].astype(np.float32), p[:, 1].astype(np.float32)
+
+
+def test_near_mesh_predicate_equals_brute_force_minimum(small_world, small_town):
+    """the oracle's offroad predicate (bounding-box reject, early exit) == min over EVERY triangle of d2 <= thr2, for both
+    readings of the threshold, on points around the road edges of a junction map and of the town"""
+    rng = np.random.default_rng(11)
+    for w, n in ((small_world, 3000), (small_town, 1500)):
+        m = w.arrays["maps"][0]
+        tri = w.arrays["tri"][m["tri_base"]:m["tri_base"] + m["n_tri"]]
+        px, py = _edge_points(tri, n, rng)
+        for thr2 in (np.float32(0.25), np.float32(0.5)):
+            want = np.array([oracle.point_mesh_d2(x, y, tri) <= thr2 for x, y in zip(px, py)])
+            got = np.array([oracle.point_near_mesh(x, y, tri, thr2) for x, y in zip(px, py)])
+            assert np.array_equal(got, want)
+            assert 0.15 < want.mean() < 0.95
+
+
+def test_town_grid_index_equals_brute_force(small_town):
+    """the natively built index (tde_grid_build: shared candidate lists, per-map record base) of a warped street grid gives
+    the brute-force mask, through the cell words alone and through the sub-cell classes"""
+    w = small_town
+    m = w.arrays["maps"][0]
+    tri = w.arrays["tri"][m["tri_base"]:m["tri_base"] + m["n_tri"]]
+    px, py = _edge_points(tri, 5000, np.random.default_rng(5))
+    want = np.array([oracle.point_mesh_d2(x, y, tri) > np.float32(0.25) for x, y in zip(px, py)])
+    assert np.array_equal(grid_offroad_numpy(w, 0, px, py, 0.5), want)
+    assert np.array_equal(grid_offroad_numpy(w, 0, px, py, 0.5, use_sub=True), want)
+    assert 0.1 < want.mean() < 0.9

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 8
+TDE_ABI_VERSION = 9
 TDE_MAX_AGENTS = 64
 
 F_NPC = 1 << 0
@@ -57,16 +57,28 @@ class TdeMap(C.Structure):
         ("nx", C.c_int32), ("ny", C.c_int32), ("cell_base", C.c_int32), ("tri_base", C.c_int32),
         ("n_tri", C.c_int32), ("stop_base", C.c_int32), ("n_stop", C.c_int32), ("phase_base", C.c_int32),
         ("n_phase", C.c_int32), ("cycle_steps", C.c_int32), ("row_shift", C.c_int32), ("cls2_base", C.c_int32),
+        ("rec_base", C.c_int32), ("_pad0", C.c_int32 * 3),
+    ]
+
+
+class TdeGrid(C.Structure):
+    """tde_grid: what tde_grid_build returns for one map (host arrays owned by the library)"""
+    _fields_ = [
+        ("ox", C.c_float), ("oy", C.c_float), ("cell", C.c_float), ("nx", C.c_int32), ("ny", C.c_int32),
+        ("n_lists", C.c_int64), ("n_records", C.c_int64),
+        ("cell_class", C.POINTER(C.c_uint8)), ("cell_count", C.POINTER(C.c_uint8)),
+        ("cell_first", C.POINTER(C.c_uint32)), ("cell_sub", C.POINTER(C.c_uint32)), ("rec_tri", C.POINTER(C.c_int32)),
     ]
 
 
 MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "f4"), ("nx", "i4"), ("ny", "i4"),
                       ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("stop_base", "i4"), ("n_stop", "i4"),
-                      ("phase_base", "i4"), ("n_phase", "i4"), ("cycle_steps", "i4"), ("row_shift", "i4"), ("cls2_base", "i4")])
+                      ("phase_base", "i4"), ("n_phase", "i4"), ("cycle_steps", "i4"), ("row_shift", "i4"), ("cls2_base", "i4"),
+                      ("rec_base", "i4"), ("_pad0", "i4", (3,))])
 STOPLINE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("c", "f4"), ("s", "f4"), ("hl", "f4"), ("hw", "f4"),
                            ("light", "i4"), ("_pad0", "i4")])
 PHASE_DTYPE = np.dtype([("end_step", "i4"), ("red_mask", "u4")])
-assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 64 and STOPLINE_DTYPE.itemsize == 32 and PHASE_DTYPE.itemsize == 8
+assert MAP_DTYPE.itemsize == C.sizeof(TdeMap) == 80 and STOPLINE_DTYPE.itemsize == 32 and PHASE_DTYPE.itemsize == 8
 
 SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("len", "f4"), ("wid", "f4"),
                         ("lr", "f4"), ("vdes", "f4"), ("route", "i4"), ("route_wp", "i4"), ("route_n", "i4"),

@@ -212,7 +212,7 @@ TDE_DEV float point_tri_d2_packed(float px, float py, const float4 *__restrict__
 
 // ---- offroad through the grid index ---------------------------------------------------------------------------------
 // cell word: bits 0-1 class (EMPTY / MIXED / FULL), bits 2-9 number of candidate triangles, bits 10-31 first record in
-// w.cell_tri.  The classification is conservative by GRID_MARGIN (world.py: build_grid_index), so the mask equals the
+// w.cell_tri counted from the map's rec_base (ABI 9).  The classification is conservative by GRID_MARGIN (world.py: build_grid_index), so the mask equals the
 // oracle's brute force over every triangle.
 TDE_DEV uint32_t cell_lookup(const tde_world &w, const tde_map &m, float px, float py)
 {
@@ -295,8 +295,9 @@ TDE_DEV void offroad_issue(const tde_world &w, const tde_map &m, bool live, floa
 // did not settle the corner - half the dependent memory round trips for six more registers.  For the one-step kernels,
 // whose launch ends with its slowest wavefront (a corner in a MIXED cell somewhere in the batch, every step); the
 // persistent kernels keep one record per trip (their 80-VGPR budget, and their wavefronts drift apart anyway).
+// rec_base = the map's first record in w.cell_tri (tde_map.rec_base): a cell word's record offset counts from there.
 template <bool PAIR = false, bool CLS2 = false>
-TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
+TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2, int rec_base)
 {
     const uint32_t w0 = k.w0, w1 = k.w1, w2 = k.w2, w3 = k.w3;
     // classes are 0 (EMPTY), 1 (MIXED), 2 (FULL): any EMPTY <=> the minimum class is 0; MIXED <=> bit 0.  Plain integer
@@ -314,7 +315,7 @@ TDE_DEV bool offroad_resolve(const tde_world &w, const Corners &k, float thr2)
             pending &= pending - 1u;
             uint32_t wd = TDE_SEL4(ci, w0, w1, w2, w3);
             if constexpr (CLS2) wd = w.cell_word[wd >> 2];    // (one more dependent load, for the corners in MIXED cells only)
-            cur = wd >> 10;
+            cur = (wd >> 10) + (uint32_t)rec_base;
             end = cur + ((wd >> 2) & 255u);
             qx = TDE_SEL4(ci, k.px0, k.px1, k.px2, k.px3);
             qy = TDE_SEL4(ci, k.py0, k.py1, k.py2, k.py3);
@@ -346,7 +347,7 @@ TDE_DEV bool box_offroad(const tde_world &w, const tde_map &m, bool live, float 
 {
     Corners k;
     offroad_issue<CLS2>(w, m, live, x, y, c, s, hl, hw, k);
-    return offroad_resolve<PAIR, CLS2>(w, k, thr2);
+    return offroad_resolve<PAIR, CLS2>(w, k, thr2, m.rec_base);
 }
 
 // Philox4x32-10, key = seed, counter = (c0,c1,c2,c3) — the reset RNG (R16).  Returned by value (uint4) so the four

@@ -773,7 +773,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 
     bool off = false;
     // (one-step launches end with their slowest wavefront: two candidate records per trip there, tde_device.h)
-    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock, kStepCls2>(w, corners, thr2_of(cfg));
+    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock, kStepCls2>(w, corners, thr2_of(cfg), cx.m.rec_base);
     out.collided = hit ? 1 : 0;
     out.offroad = off ? 1 : 0;
 
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (F & TDE_F_OFFROAD) offroad_issue(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
             const bool hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, live, x, y, c0, s0, hl, hw, ra.z);
             bool off = false;
-            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2);
+            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2, cx.m.rec_base);
             bool tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
                 tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
@@ -2667,3 +2667,6 @@ int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void 
 }
 
 }  // extern "C"
+
+// host-side table build (no kernels): tde_grid_build / tde_grid_free
+#include "tde_gridbuild.h"

@@ -178,7 +178,7 @@ TDE_DEV bool raster_mixed_pixel(const RasterJob &J, const RasterView &V, float u
     if (TDE_RASTER_SKIP & 1) return false;
     float wx, wy;
     raster_world(V, u, v, wx, wy);
-    const float4 *recs = reinterpret_cast<const float4 *>(J.cell_tri) + 3 * (size_t)(wd >> 10);
+    const float4 *recs = reinterpret_cast<const float4 *>(J.cell_tri) + 3 * (size_t)((wd >> 10) + (uint32_t)J.m.rec_base);
     const int n = (int)((wd >> 2) & 255u);
     bool road = false;
     for (int k = 0; k < n && !road; k += 2) {

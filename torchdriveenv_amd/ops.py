@@ -235,7 +235,14 @@ def env_step_render(cfg, dworld, state, streams, action=None, out=None, H=64, W=
     if render:
         ns = max(1, n_stack)
         if out is None:
+            # allocated (and zero-filled) on the CURRENT stream: the side streams must see the fill before they write, and
+            # the caching allocator must not hand the block out again while their kernels are pending.  Callers that pass
+            # `out` / `layers` / `action` own that ordering (fork_streams before, join_streams or record_stream after).
             out = torch.zeros((state.B, 3 * ns, H, W), dtype=torch.uint8, device=dev)
+            cur = torch.cuda.current_stream(torch.device(dev))
+            for s_ in streams:
+                s_.wait_stream(cur)
+                out.record_stream(s_)
         pl = _chk(layers, torch.uint8, state.B * ns * H * W, "layers", optional=True) if ns > 1 else None
         pf = _chk(fresh, torch.uint8, state.B, "fresh", optional=True)
         rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack, pl, int(phase),

@@ -49,6 +49,12 @@ class Junction:
         parts.append(disc_mesh((0.0, 0.0), 0.5 * ROAD_W + 5.5, 12))  # widened junction box
         return np.concatenate(parts, 0)
 
+    def pose(self, arm, outbound, s, off):
+        """point `s` metres out on an arm, `off` metres to the right of the travel direction; -> (position, heading)"""
+        d = self.d[arm]
+        t = d if outbound else -d
+        return d * s + _right(t) * off, math.atan2(t[1], t[0])
+
     def lights(self, s_stop=11.0):
         """one light per arm with a stop line across its inbound lane; the first two arms (the main road) share a
         green, the side arm(s) get the other one, with all-red clearance phases (10 Hz steps)"""
@@ -85,6 +91,67 @@ def _attrs(rng):
     return (L, W, lr)
 
 
+def _junction_scenario(J, m, rng, A, n_parked):
+    """one WaypointSuite-like scenario around junction `J` (a Junction or a TownJunction) of map `m`: the ego's waypoints
+    through the junction, A - 1 NPCs on the lanes of its arms (>= 10 m apart at spawn, lane-following routes), the first
+    `n_parked` of them parked at the kerb as constant replay rows"""
+    n_arm = len(J.len)
+    a_in = int(rng.integers(n_arm))
+    a_out = int((a_in + 1 + rng.integers(n_arm - 1)) % n_arm)
+    n_wp = int(rng.integers(5, 21))
+    spacing = float(rng.uniform(13.0, 15.0))
+    s_start = float(min(J.len[a_in] - 5.0, rng.uniform(60.0, 100.0)))
+    ego_path = J.path(a_in, a_out, s_start)
+    wps = _resample(ego_path, spacing)[:n_wp]
+    if len(wps) < 2:
+        wps = _resample(ego_path, spacing)[:2]
+    heading = math.atan2(wps[1, 1] - wps[0, 1], wps[1, 0] - wps[0, 0])
+    # spawn slots: every 12 m on every lane
+    slots = []
+    for arm in range(n_arm):
+        for outbound in (False, True):
+            s = 14.0
+            while s < J.len[arm] - 45.0:
+                slots.append((arm, outbound, s))
+                s += 12.0
+    order = rng.permutation(len(slots))
+    agents = []
+    used = []
+    ego_seg = np.stack([wps[0], wps[1]])
+    for idx in order:
+        if len(agents) >= A - 1:
+            break
+        arm, outbound, s = slots[idx]
+        pos, psi = J.pose(arm, outbound, s, 0.5 * LANE)
+        # keep clear of the ego's start segment and of other spawns
+        ap = pos - ego_seg[0]
+        ab = ego_seg[1] - ego_seg[0]
+        tt = np.clip((ap @ ab) / (ab @ ab), 0, 1)
+        if np.hypot(*(ap - tt * ab)) < 12.0:
+            continue
+        if any(np.hypot(*(pos - u)) < 10.0 for u in used):
+            continue
+        used.append(pos)
+        parked = len(agents) < n_parked
+        if parked:
+            # a parked car hugging the road edge, recorded as a constant replay row (env_utils.py:86-91)
+            pos, psi = J.pose(arm, outbound, s, LANE - 1.1)
+            st = (float(pos[0]), float(pos[1]), psi, 0.0)
+            agents.append(dict(state=st, attr=(4.6, 1.9, 1.8), vdes=0.0, route=None, replay=[st] * 220))
+            continue
+        speed = float(np.clip(abs(rng.normal(6.3, 4.3)), 0.0, 24.4))
+        speed = min(speed, 9.0)
+        if outbound:
+            route = J.lane(arm, True, s + 8.0, J.len[arm] - 30.0)
+        else:
+            out_arm = int((arm + 1 + rng.integers(n_arm - 1)) % n_arm)
+            route = J.path(arm, out_arm, max(8.0, s - 8.0))
+        route = _resample(route, 6.0)[:32]
+        agents.append(dict(state=(float(pos[0]), float(pos[1]), psi, speed), attr=_attrs(rng), vdes=max(speed, 3.0),
+                           route=route, replay=None))
+    return dict(map=m, waypoints=wps, start_heading=heading, agents=agents, ego_attr=_attrs(rng))
+
+
 def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.25, threshold=0.5, lights=True):
     """World with `n_scn` scenarios of A-1 NPCs each on `n_maps` junction maps.  Deterministic in `seed`."""
     rng = np.random.default_rng(seed)
@@ -97,67 +164,100 @@ def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.25, thr
             ang = [0.0, 180.0, rng.uniform(75.0, 105.0), rng.uniform(255.0, 285.0)]
         juncs.append(Junction(ang, [rng.uniform(110.0, 140.0) for _ in ang]))
     meshes = [j.mesh() for j in juncs]
-    scenarios = []
-    for si in range(n_scn):
-        m = si % n_maps
-        J = juncs[m]
-        n_arm = len(J.d)
-        a_in = int(rng.integers(n_arm))
-        a_out = int((a_in + 1 + rng.integers(n_arm - 1)) % n_arm)
-        n_wp = int(rng.integers(5, 21))
-        spacing = float(rng.uniform(13.0, 15.0))
-        s_start = float(min(J.len[a_in] - 5.0, rng.uniform(60.0, 100.0)))
-        ego_path = J.path(a_in, a_out, s_start)
-        wps = _resample(ego_path, spacing)[:n_wp]
-        if len(wps) < 2:
-            wps = _resample(ego_path, spacing)[:2]
-        heading = math.atan2(wps[1, 1] - wps[0, 1], wps[1, 0] - wps[0, 0])
-        # spawn slots: every 12 m on every lane
-        slots = []
-        for arm in range(n_arm):
-            for outbound in (False, True):
-                s = 14.0
-                while s < J.len[arm] - 45.0:
-                    slots.append((arm, outbound, s))
-                    s += 12.0
-        order = rng.permutation(len(slots))
-        agents = []
-        used = []
-        ego_seg = np.stack([wps[0], wps[1]])
-        for idx in order:
-            if len(agents) >= A - 1:
-                break
-            arm, outbound, s = slots[idx]
-            d = J.d[arm]
-            t = d if outbound else -d
-            pos = d * s + _right(t) * (0.5 * LANE)
-            # keep clear of the ego's start segment and of other spawns
-            ap = pos - ego_seg[0]
-            ab = ego_seg[1] - ego_seg[0]
-            tt = np.clip((ap @ ab) / (ab @ ab), 0, 1)
-            if np.hypot(*(ap - tt * ab)) < 12.0:
-                continue
-            if any(np.hypot(*(pos - u)) < 10.0 for u in used):
-                continue
-            used.append(pos)
-            psi = math.atan2(t[1], t[0])
-            parked = len(agents) < n_parked
-            if parked:
-                # a parked car hugging the road edge, recorded as a constant replay row (env_utils.py:86-91)
-                pos = d * s + _right(t) * (LANE - 1.1)
-                st = (float(pos[0]), float(pos[1]), psi, 0.0)
-                agents.append(dict(state=st, attr=(4.6, 1.9, 1.8), vdes=0.0, route=None, replay=[st] * 220))
-                continue
-            speed = float(np.clip(abs(rng.normal(6.3, 4.3)), 0.0, 24.4))
-            speed = min(speed, 9.0)
-            if outbound:
-                route = J.lane(arm, True, s + 8.0, J.len[arm] - 30.0)
-            else:
-                out_arm = int((arm + 1 + rng.integers(n_arm - 1)) % n_arm)
-                route = J.path(arm, out_arm, max(8.0, s - 8.0))
-            route = _resample(route, 6.0)[:32]
-            agents.append(dict(state=(float(pos[0]), float(pos[1]), psi, speed), attr=_attrs(rng), vdes=max(speed, 3.0),
-                               route=route, replay=None))
-        scenarios.append(dict(map=m, waypoints=wps, start_heading=heading, agents=agents, ego_attr=_attrs(rng)))
+    scenarios = [_junction_scenario(juncs[si % n_maps], si % n_maps, rng, A, n_parked) for si in range(n_scn)]
     return assemble_world(meshes, scenarios, A, threshold=threshold, cell=cell,
                           lights=[j.lights() for j in juncs] if lights else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# a town: the operating size of the reference's maps (a CARLA town's drivable mesh, 1e4 - 1e5 triangles: gym_env.py:184, 260)
+# ------------------------------------------------------------------------------------------------
+class Town:
+    """n x n streets `spacing` metres apart (n^2 four-way junctions) under a smooth warp, so that no street is straight or
+    axis-aligned, plus one diagonal avenue; every street is a ribbon of two lane strips cut every `ds` metres."""
+
+    def __init__(self, n=10, spacing=100.0, ext=45.0, amp=6.0, wavelength=430.0, ds=1.5):
+        self.n, self.spacing, self.ext, self.amp, self.k, self.ds = n, spacing, ext, amp, 2.0 * math.pi / wavelength, ds
+        self.span = (n - 1) * spacing
+
+    def F(self, u, v):
+        """street coordinates (metres along the two street families) -> world"""
+        u, v = np.asarray(u, np.float64), np.asarray(v, np.float64)
+        return np.stack([u + self.amp * np.sin(self.k * v), v + self.amp * np.sin(self.k * u + 1.0)], -1)
+
+    def ribbon(self, pts, width=ROAD_W, strips=2):
+        """triangulated ribbon around a polyline: vertices offset along the (averaged) normals, so bends leave no gaps"""
+        pts = np.asarray(pts, np.float64)
+        t = np.gradient(pts, axis=0)
+        t /= np.hypot(t[:, 0], t[:, 1])[:, None]
+        nrm = np.stack([-t[:, 1], t[:, 0]], -1)
+        lat = np.linspace(-0.5 * width, 0.5 * width, strips + 1)
+        G = pts[:, None, :] + lat[None, :, None] * nrm[:, None, :]            # [N][strips + 1][2]
+        a, b, c, d = G[:-1, :-1], G[1:, :-1], G[1:, 1:], G[:-1, 1:]
+        return np.concatenate([np.stack([a, b, c], -2).reshape(-1, 3, 2), np.stack([a, c, d], -2).reshape(-1, 3, 2)], 0)
+
+    def mesh(self):
+        s = np.arange(-self.ext, self.span + self.ext + 1e-9, self.ds)
+        parts = []
+        for i in range(self.n):
+            c = np.full_like(s, i * self.spacing)
+            parts.append(self.ribbon(self.F(s, c)))          # a street along u
+            parts.append(self.ribbon(self.F(c, s)))          # a street along v
+        parts.append(self.ribbon(self.F(s, s)))              # the diagonal avenue
+        for i in range(self.n):
+            for j in range(self.n):
+                parts.append(disc_mesh(self.F(i * self.spacing, j * self.spacing), 0.5 * ROAD_W + 5.5, 16))
+        return np.concatenate(parts, 0)
+
+
+class TownJunction:
+    """the four arms of junction (i, j) of a Town, with the interface of Junction (len, pose, lane, path)"""
+    DIRS = ((1.0, 0.0), (-1.0, 0.0), (0.0, 1.0), (0.0, -1.0))
+
+    def __init__(self, town, i, j, max_len=240.0):
+        self.town, self.u0, self.v0 = town, i * town.spacing, j * town.spacing
+        lo, hi = -town.ext, town.span + town.ext
+        self.len = [min(max_len, (hi - self.u0) if du > 0 else (self.u0 - lo) if du < 0 else
+                        (hi - self.v0) if dv > 0 else (self.v0 - lo)) for du, dv in self.DIRS]
+
+    def _frame(self, arm, s):
+        """centre line point(s) `s` metres out on an arm and the unit tangent pointing outwards"""
+        du, dv = self.DIRS[arm]
+        s = np.asarray(s, np.float64)
+        p = self.town.F(self.u0 + s * du, self.v0 + s * dv)
+        e = 0.05
+        t = self.town.F(self.u0 + (s + e) * du, self.v0 + (s + e) * dv) - self.town.F(self.u0 + (s - e) * du, self.v0 + (s - e) * dv)
+        return p, t / np.hypot(t[..., 0], t[..., 1])[..., None]
+
+    def pose(self, arm, outbound, s, off):
+        p, d = self._frame(arm, s)
+        t = d if outbound else -d
+        return p + _right(t) * off, math.atan2(t[1], t[0])
+
+    def lane(self, arm, outbound, s0, s1, step=2.0):
+        n = max(2, int(abs(s1 - s0) / step) + 1)
+        p, d = self._frame(arm, np.linspace(s0, s1, n))
+        t = d if outbound else -d
+        return p + np.stack([t[:, 1], -t[:, 0]], -1) * (0.5 * LANE)
+
+    def path(self, arm_in, arm_out, s_start, s_end=None):
+        if s_end is None:
+            s_end = self.len[arm_out] - 30.0
+        return np.concatenate([self.lane(arm_in, False, s_start, 7.0), self.lane(arm_out, True, 7.0, s_end)], 0)
+
+
+def synthetic_town(n_scn=256, A=16, seed=0, n_streets=10, spacing=100.0, ext=45.0, ds=1.5, n_parked=1, cell=0.25,
+                   threshold=0.5):
+    """ONE map of town size - n_streets^2 junctions on ~((n_streets - 1) * spacing + 2 * ext)^2 metres, >= 5e4 triangles at the
+    defaults (1 km x 1 km, 100 junctions) - with `n_scn` scenarios spread over its interior junctions, each built like a
+    synthetic_world scenario (A - 1 NPCs on the arms around its junction).  No traffic lights (the kernels walk all stop
+    lines of a map).  Deterministic in `seed`."""
+    rng = np.random.default_rng(seed)
+    town = Town(n_streets, spacing, ext, ds=ds)
+    inner = [(i, j) for i in range(1, n_streets - 1) for j in range(1, n_streets - 1)]
+    order = rng.permutation(len(inner))
+    scenarios = []
+    for si in range(n_scn):
+        i, j = inner[order[si % len(inner)]]
+        scenarios.append(_junction_scenario(TownJunction(town, i, j), 0, rng, A, n_parked))
+    return assemble_world([town.mesh()], scenarios, A, threshold=threshold, cell=cell)

@@ -65,187 +65,42 @@ def pitch_cells(a, nx, ny):
 
 
 # ------------------------------------------------------------------------------------------------
-# geometry helpers (float64, host, build time only)
+# grid index of a drivable mesh: built by the library's host code (csrc/tde_gridbuild.h)
 # ------------------------------------------------------------------------------------------------
-def _pairs_point_tri_dist(p, tri, want_depth=False):
-    """p [P,L,2], tri [P,3,2] -> distance [P,L] of every lattice point to its pair's triangle (0 inside); with
-    `want_depth` also the distance of inside points to the triangle's boundary (0 outside).
-    Component-wise (x and y as separate arrays): reductions over a length-2 axis are what numpy is slowest at."""
-    px, py = p[..., 0], p[..., 1]
-    vx = [tri[:, k, 0][:, None] for k in range(3)]
-    vy = [tri[:, k, 1][:, None] for k in range(3)]
-    d2 = None
-    pos = neg = None
-    depth2 = None
-    for k in range(3):
-        ax, ay, bx, by = vx[k], vy[k], vx[(k + 1) % 3], vy[(k + 1) % 3]
-        abx, aby = bx - ax, by - ay
-        apx, apy = px - ax, py - ay
-        e = abx * apy - aby * apx
-        pos = (e >= 0) if pos is None else pos & (e >= 0)
-        neg = (e <= 0) if neg is None else neg & (e <= 0)
-        l2 = abx * abx + aby * aby
-        t = np.clip((apx * abx + apy * aby) / np.where(l2 > 0, l2, 1.0), 0.0, 1.0)
-        qx, qy = apx - t * abx, apy - t * aby
-        s = qx * qx + qy * qy
-        d2 = s if d2 is None else np.minimum(d2, s)
-        if want_depth:
-            h2 = e * e / np.where(l2 > 0, l2, 1.0)
-            depth2 = h2 if depth2 is None else np.minimum(depth2, h2)
-    inside = pos | neg
-    if want_depth:
-        return np.where(inside, 0.0, np.sqrt(d2)), np.where(inside, np.sqrt(depth2), 0.0)
-    return np.where(inside, 0.0, np.sqrt(d2))
+CLEARANCE_UNIT = 0.125   # metres per count of the clearance field (TDE_CLEARANCE_UNIT)
+SUB = 4                  # a MIXED cell carries SUB x SUB sub-cell classes (TDE_CELL_SUB)
 
 
-def build_grid_index(tri, threshold=0.5, cell=0.5, margin=GRID_MARGIN, lattice=4):
-    """Uniform-grid index over a triangle soup `tri` [n,3,2] for the offroad test.
+def build_grid_index(tri32, threshold=0.5, cell=0.5, margin=GRID_MARGIN, n_threads=0):
+    """Uniform-grid index over a triangle soup `tri32` [n,3,2] (fp32 vertices, what kernels and oracle see) for the offroad
+    test, through `tde_grid_build` (include/tde_hip.h; rounds 1-3 did this in numpy, seconds per 200-triangle junction).
 
-    For every cell: the list of triangles that can be within `threshold` of some point of the cell, and a class:
-      EMPTY  no such triangle  -> every corner falling in the cell is offroad,
-      FULL   every point of the cell is within `threshold` of the mesh -> never offroad,
-      MIXED  test the candidates.
-    Both classifications are conservative: distances are sampled on a (lattice+1)^2 lattice spanning the cell grown
-    by `margin` (which absorbs the fp32 cell lookup), and the distance field is 1-Lipschitz, so between lattice points
-    it moves by at most h*sqrt(2)/2; on top of that `margin` (>> fp32 evaluation error at |coords| <~ 1e3 m) is kept
-    on both decisions.  Hence the HIP kernel's mask equals the oracle's brute-force mask.
-    """
-    tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
-    R = threshold + margin
-    lo = tri.reshape(-1, 2).min(0) - (R + 2 * cell)
-    hi = tri.reshape(-1, 2).max(0) + (R + 2 * cell)
-    # the origin must be exactly representable in fp32 (the kernel subtracts it in fp32)
-    ox, oy = float(np.float32(math.floor(lo[0]))), float(np.float32(math.floor(lo[1])))
-    nx = GRID_TILE * int(math.ceil((hi[0] - ox) / cell / GRID_TILE))
-    ny = GRID_TILE * int(math.ceil((hi[1] - oy) / cell / GRID_TILE))
-    h = (cell + 2 * margin) / lattice
-    slack = h * math.sqrt(2.0) / 2.0
-    # (triangle, cell) pairs from dilated triangle bounding boxes
-    pt, pc = [], []
-    for k, t in enumerate(tri):
-        bx0, by0 = t.min(0) - (R + slack)
-        bx1, by1 = t.max(0) + (R + slack)
-        ix0 = max(0, int(math.floor((bx0 - ox) / cell)) - 1)
-        ix1 = min(nx - 1, int(math.floor((bx1 - ox) / cell)) + 1)
-        iy0 = max(0, int(math.floor((by0 - oy) / cell)) - 1)
-        iy1 = min(ny - 1, int(math.floor((by1 - oy) / cell)) + 1)
-        iy, ix = np.mgrid[iy0:iy1 + 1, ix0:ix1 + 1]
-        c = (iy * nx + ix).ravel()
-        pc.append(c)
-        pt.append(np.full(c.shape, k, dtype=np.int64))
-    pt, pc = np.concatenate(pt), np.concatenate(pc)
-    g = np.arange(lattice + 1, dtype=np.float64) * h - margin
-    lat = np.stack(np.meshgrid(g, g, indexing="xy"), -1).reshape(-1, 2)          # [L,2] offsets inside a cell
-    L = lat.shape[0]
-    ucell, row = np.unique(pc, return_inverse=True)                             # lattice minima only for touched cells
-    dmin = np.full((len(ucell), L), np.inf)
-    keep = np.zeros(pt.shape, dtype=bool)
-    covered = np.zeros(nx * ny, dtype=bool)
-    # the lattice is only evaluated for pairs the cell centre cannot decide: with r = half diagonal of the grown cell,
-    # a centre farther than R + slack + r keeps every lattice point beyond R + slack (the pair matters to neither
-    # decision); a centre at depth >= r inside the triangle puts the whole grown cell inside it (cell is FULL)
-    r = (0.5 * cell + margin) * math.sqrt(2.0) + 1e-9
-    ctr = np.array([[0.5 * cell, 0.5 * cell]])
-    CH = 400_000
-    for s0 in range(0, len(pt), CH):
-        t_, c_ = pt[s0:s0 + CH], pc[s0:s0 + CH]
-        org = np.stack([ox + (c_ % nx) * cell, oy + (c_ // nx) * cell], -1)      # [P,2]
-        dc, depth = _pairs_point_tri_dist(org[:, None, :] + ctr[None], tri[t_], want_depth=True)
-        dc, depth = dc[:, 0], depth[:, 0]
-        deep = depth >= r
-        covered[c_[deep]] = True
-        band = np.nonzero(~deep & (dc <= R + slack + r))[0]
-        if len(band):
-            d = _pairs_point_tri_dist(org[band][:, None, :] + lat[None], tri[t_[band]])   # [P',L]
-            keep[s0 + band] = d.min(1) <= R + slack
-            np.minimum.at(dmin, row[s0 + band], d)
-    full = covered
-    full[ucell] |= (dmin <= (threshold - margin) - slack).all(1)
-    pt, pc = pt[keep], pc[keep]
-    order = np.lexsort((pt, pc))
-    pt, pc = pt[order], pc[order]
-    has = np.zeros(nx * ny, dtype=bool)
-    has[pc] = True
-    cls = np.where(full, _abi.CELL_FULL, np.where(has, _abi.CELL_MIXED, _abi.CELL_EMPTY)).astype(np.uint8)
-    mixed_pair = cls[pc] == _abi.CELL_MIXED                                       # FULL cells need no list
-    pt, pc = pt[mixed_pair], pc[mixed_pair]
-    counts = np.bincount(pc, minlength=nx * ny)
-    start = np.zeros(nx * ny + 1, dtype=np.int32)
-    start[1:] = np.cumsum(counts)
-    return dict(ox=ox, oy=oy, cell=float(cell), nx=nx, ny=ny, cell_class=cls, cell_start=start,
-                cell_tris=pt.astype(np.int32))
+    Per cell a class - EMPTY: every corner falling in the cell is offroad; FULL: never offroad; MIXED: test the cell's
+    candidate triangles - plus, for MIXED cells, the candidate list (identical lists share their records) and the classes
+    of its SUB x SUB sub-cells, and for FULL / EMPTY cells a clearance.  All conservative by `margin`, so the HIP kernels'
+    masks equal the oracle's brute force (tests/test_oracle_math.py::test_grid_index_equals_brute_force).
+    Returns row-major [ny * nx] numpy arrays (copies) and `rec_tri`, the triangle of every record."""
+    import ctypes as C
 
+    from . import _lib
 
-# MIXED cells are split once more: SUB x SUB sub-cells, each with a 2-bit class of its own (EMPTY / MIXED / FULL) packed
-# into one word, bits 2 * (sy * SUB + sx), kept in a tiled per-cell array of its own (tde_world.cell_sub).  The
-# rasteriser resolves most pixels of a MIXED cell from it without a triangle test (the band of truly undecided points
-# shrinks from ~0.6 m to ~0.15 m around the road edge at 0.25 m cells).  SUB_MARGIN absorbs the fp32 evaluation of the
-# sub-cell coordinate and of the distances (both ~1e-4 m at |coordinates| of a few hundred metres).
-SUB = 4
-SUB_MARGIN = 0.002
-
-
-def subcell_classes(tri, g, threshold):
-    """uint32 per MIXED cell (in cell order): the classes of its SUB x SUB sub-cells.  Conservative like the cell classes:
-    a 3 x 3 lattice over the sub-cell grown by SUB_MARGIN, the 1-Lipschitz slack between lattice points and SUB_MARGIN
-    on both decisions; distances are taken to the cell's candidate triangles, which hold every triangle within
-    `threshold` (+ the cell margin) of any point of the cell."""
-    cell, nx = g["cell"], g["nx"]
-    cls = g["cell_class"]
-    start = g["cell_start"]
-    mixed = np.nonzero(cls == _abi.CELL_MIXED)[0]
-    if len(mixed) == 0:
-        return np.zeros(0, np.uint32)
-    counts = np.diff(start)[mixed]
-    row = np.repeat(np.arange(len(mixed)), counts)                      # candidate entry -> index into `mixed`
-    ent = np.concatenate([np.arange(start[c], start[c + 1]) for c in mixed]) if len(mixed) < 4096 else \
-        (np.repeat(start[mixed], counts) + (np.arange(counts.sum()) - np.repeat(np.cumsum(counts) - counts, counts)))
-    tri_of = g["cell_tris"][ent]
-    sub = cell / SUB
-    h = (sub + 2 * SUB_MARGIN) / 2.0
-    slack = h * math.sqrt(2.0) / 2.0
-    gl = np.array([-SUB_MARGIN, 0.5 * sub, sub + SUB_MARGIN])
-    # lattice offsets inside the cell: [SUB*SUB sub-cells][9 points][2]
-    lat = np.zeros((SUB * SUB, 9, 2))
-    for sy in range(SUB):
-        for sx in range(SUB):
-            xs, ys = np.meshgrid(sx * sub + gl, sy * sub + gl, indexing="xy")
-            lat[sy * SUB + sx] = np.stack([xs.ravel(), ys.ravel()], -1)
-    lat = lat.reshape(-1, 2)
-    dmin = np.full((len(mixed), lat.shape[0]), np.inf)
-    CH = 100_000
-    for s0 in range(0, len(row), CH):
-        r_, t_ = row[s0:s0 + CH], tri_of[s0:s0 + CH]
-        c_ = mixed[r_]
-        org = np.stack([g["ox"] + (c_ % nx) * cell, g["oy"] + (c_ // nx) * cell], -1)
-        d = _pairs_point_tri_dist(org[:, None, :] + lat[None], tri[t_])
-        np.minimum.at(dmin, r_, d)
-    dm = dmin.reshape(len(mixed), SUB * SUB, 9)
-    full = (dm <= (threshold - SUB_MARGIN) - slack).all(2)
-    empty = (dm > (threshold + SUB_MARGIN) + slack).all(2)
-    code = np.where(full, _abi.CELL_FULL, np.where(empty, _abi.CELL_EMPTY, _abi.CELL_MIXED)).astype(np.uint32)
-    return (code << (2 * np.arange(SUB * SUB, dtype=np.uint32))[None]).sum(1).astype(np.uint32)
-
-
-CLEARANCE_UNIT = 0.125   # metres per count of the clearance field
-
-
-def cell_clearance(g, cell):
-    """per cell, floor(rho / CLEARANCE_UNIT) clipped to 255, where rho is the distance between the cell's rectangle and
-    the nearest cell rectangle of another class (FULL or EMPTY cells; 0 for MIXED): every point within rho of any
-    point of the cell lies in a cell of the same class.  Exact rectangle-to-rectangle distance = centre distance to
-    the other-class set dilated by one cell (Chebyshev), from a Euclidean distance transform."""
-    from scipy.ndimage import binary_dilation, distance_transform_edt
-
-    cls = g["cell_class"].reshape(g["ny"], g["nx"])
-    out = np.zeros(cls.shape, np.float64)
-    for c in (_abi.CELL_FULL, _abi.CELL_EMPTY):
-        m = cls == c
-        if m.any():
-            other = binary_dilation(~m, structure=np.ones((3, 3), bool))
-            d = distance_transform_edt(~other) * cell - 1e-3
-            out = np.where(m, d, out)
-    return np.clip(np.floor(np.maximum(out, 0.0) / CLEARANCE_UNIT), 0, 255).astype(np.int64).reshape(-1)
+    L = _lib.load()
+    tri32 = np.ascontiguousarray(np.asarray(tri32, dtype=np.float32).reshape(-1, 6))
+    gp = C.POINTER(_abi.TdeGrid)()
+    _lib.check(L.tde_grid_build(tri32.ctypes.data, len(tri32), float(threshold), float(cell), float(margin), int(n_threads),
+                                C.byref(gp)), "tde_grid_build")
+    try:
+        g = gp.contents
+        n = g.nx * g.ny
+        out = dict(ox=float(g.ox), oy=float(g.oy), cell=float(g.cell), nx=int(g.nx), ny=int(g.ny), n_lists=int(g.n_lists),
+                   cell_class=np.ctypeslib.as_array(g.cell_class, (n,)).copy(),
+                   cell_count=np.ctypeslib.as_array(g.cell_count, (n,)).copy(),
+                   cell_first=np.ctypeslib.as_array(g.cell_first, (n,)).copy(),
+                   cell_sub=np.ctypeslib.as_array(g.cell_sub, (n,)).copy(),
+                   rec_tri=np.ctypeslib.as_array(g.rec_tri, (max(1, int(g.n_records)),))[:int(g.n_records)].copy())
+    finally:
+        L.tde_grid_free(gp)
+    return out
 
 
 def pack_triangles(tri32):
@@ -435,7 +290,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
         # the kernels see fp32 vertices: index the fp32-rounded mesh
         tri32 = tri.astype(np.float32)
-        g = build_grid_index(tri32.astype(np.float64), threshold, cell)
+        g = build_grid_index(tri32, threshold, cell)
         lt = lights[m]
         n_stop = n_phase = cycle = 0
         if lt:
@@ -448,31 +303,23 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
                 phase_all.append((cycle, sum(1 << int(i) for i in red)))
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
                    tri_base, len(tri), len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle,
-                   row_shift_of(g["nx"]), cls2_base)
-        packed = pack_triangles(tri32)
-        counts = np.diff(g["cell_start"]).astype(np.int64)
-        # FULL / EMPTY cells carry no candidate list: their count field holds a clearance instead (quarter metres,
-        # rounded down): every point within that distance of ANY point of the cell lies in a cell of the same class.
-        # The rasteriser uses it to classify a whole 4x4 pixel block with one lookup.
-        counts = np.where(g["cell_class"] == _abi.CELL_MIXED, counts, cell_clearance(g, cell))
-        assert counts.max(initial=0) <= 255, "more than 255 candidate triangles in one grid cell: use a smaller cell"
-        start = g["cell_start"][:-1].astype(np.int64) + rec_base
-        assert start.max(initial=0) < (1 << 22), "grid index too large for the 22-bit record offset"
-        word_all.append(pitch_cells((g["cell_class"].astype(np.uint32) | (counts.astype(np.uint32) << 2) |
-                                    (start.astype(np.uint32) << 10)).astype(np.uint32), g["nx"], g["ny"]))
-        rec_all.append(packed[g["cell_tris"]])          # per-cell copies: one dependent load less in the kernel
-        sub = np.zeros(g["nx"] * g["ny"], np.uint32)    # sub-cell classes of the MIXED cells, tiled 8 x 4 cells per line
-        mixed = np.nonzero(g["cell_class"] == _abi.CELL_MIXED)[0]
-        if len(mixed):
-            sub[mixed] = subcell_classes(tri32.astype(np.float64), g, threshold)
-        sub_all.append(sub_tiles(sub, g["nx"], g["ny"]))
+                   row_shift_of(g["nx"]), cls2_base, rec_base, (0, 0, 0))
+        # cell word = class | count << 2 | first record << 10: the count of a MIXED cell is the length of its candidate list
+        # (records from the map's rec_base + first on), that of a FULL / EMPTY cell its clearance (TDE_CLEARANCE_UNITs, rounded
+        # down): every point within that distance of ANY point of the cell lies in a cell of the same class - the rasteriser
+        # classifies a whole block of pixels with one look-up
+        word_all.append(pitch_cells(g["cell_class"].astype(np.uint32) | (g["cell_count"].astype(np.uint32) << 2) |
+                                    (g["cell_first"] << 10), g["nx"], g["ny"]))
+        rec_all.append(pack_triangles(tri32)[g["rec_tri"]])   # per-list copies: one dependent load less in the kernel
+        sub_all.append(sub_tiles(g["cell_sub"], g["nx"], g["ny"]))   # sub-cell classes of the MIXED cells, 8 x 4 cells per line
         c2, ntile = class_tiles(g["cell_class"], g["nx"], g["ny"])
         cls2_all.append(c2)
         cls2_base += ntile
         tri_all.append(tri32.reshape(-1, 6))
         tri_base += len(tri)
         cell_base += (1 << row_shift_of(g["nx"])) * g["ny"]
-        rec_base += len(g["cell_tris"])
+        rec_base += len(g["rec_tri"])
+        assert cell_base < (1 << 30) and cls2_base < (1 << 26), "world too large for 32-bit cell indices"
     S = len(scenarios)
     NW = max(2, max(len(s["waypoints"]) for s in scenarios))
     wp_xy = np.zeros((S, NW, 2), np.float64)
