@@ -48,6 +48,8 @@ extern "C" {
 #define TDE_CELL_MIXED 1u  /* test the cell's candidate triangles                                    */
 #define TDE_CELL_FULL  2u  /* every point of the cell is within threshold of some triangle            */
 #define TDE_CELL_SUB   4   /* a MIXED cell carries TDE_CELL_SUB x TDE_CELL_SUB sub-cell classes (tde_world.cell_tri) */
+#define TDE_COARSE_CELLS 4 /* a coarse tile of tde_world.cell_coarse is TDE_COARSE_CELLS x TDE_COARSE_CELLS cells */
+#define TDE_COARSE_UNIT 0.25f /* metres per count of a coarse tile's clearance */
 
 typedef struct tde_config {
     /* reward constants are Python floats (float64) in the reference: EnvConfig, gym_env.py:34-54 */
@@ -94,13 +96,14 @@ typedef struct tde_map {
     int32_t stop_base, n_stop;  /* stop lines of this map in tde_world.stoplines */
     int32_t phase_base, n_phase;/* traffic-light cycle of this map in tde_world.phases */
     int32_t cycle_steps;        /* length of the cycle in env steps (0: no lights) */
-    int32_t row_shift;          /* log2 of the row pitch of the map's cell words (>= 5) */
+    int32_t row_shift;          /* log2 of the row pitch of the map's cell words (>= 7) */
     int32_t cls2_base;          /* first 128-byte tile of this map in tde_world.cell_cls2 (in tiles) */
     int32_t rec_base;           /* (ABI 9) first candidate record of this map in tde_world.cell_tri: the 22-bit record offset of a
                                    cell word counts from here, so every map has 2^22 records of its own (a town mesh of 6e4
                                    triangles needs ~2e5 after identical lists are shared; one global offset ran out at the
                                    second town) */
-    int32_t _pad0[3];           /* 80 bytes: the kernels read the struct with 16-byte loads */
+    int32_t coarse_base;        /* (ABI 9) first 128-byte line of this map in tde_world.cell_coarse (in lines) */
+    int32_t _pad0[2];           /* 80 bytes: the kernels read the struct with 16-byte loads */
 } tde_map;
 
 /* A stop line: an oriented box across an inbound lane, governed by traffic light `light` of its map
@@ -164,6 +167,14 @@ typedef struct tde_world {
                                    conservative like the cell classes (2 mm margin).  Same number of words per map as
                                    cell_word, in 128-byte tiles of 8 x 4 cells: cell (ix, iy) at
                                    cell_base + ((((iy >> 2) << (row_shift - 3)) + (ix >> 3)) << 5) + ((iy & 3) << 3) + (ix & 7) */
+    const uint8_t *cell_coarse; /* (ABI 9, rasteriser) one byte per coarse tile of 4 x 4 cells: bits 0-1 TDE_CELL_FULL / TDE_CELL_EMPTY when
+                                   all 16 cells have that class, else TDE_CELL_MIXED; bits 2-7 the tile's clearance in
+                                   TDE_COARSE_UNITs, rounded down (every point that close to ANY point of the tile lies in a cell of
+                                   the tile's class; 0 for MIXED).  In 128-byte lines of 16 x 8 tiles (16 m x 8 m at 0.25 m
+                                   cells): tile (cx, cy) = cells [4 cx, 4 cx + 4) x [4 cy, 4 cy + 4) of a map is byte
+                                   ((coarse_base + ((cy >> 3) << (row_shift - 6)) + (cx >> 4)) << 7) + ((cy & 7) << 4) + (cx & 15).
+                                   The block pyramid of a 35 m view reads ~20 lines of it (1 MB per km^2) where the clearance
+                                   field of cell_word cost one line per look-up (66 MB per km^2) */
     const tde_scenario *scn;    /* [S] */
     const double *wp_xy;        /* [S][NW][2] ego waypoints, float64 like the YAML lists (gym_env.py:314,394) */
     const tde_spawn *spawn;     /* [S][A] */
@@ -173,7 +184,14 @@ typedef struct tde_world {
     const tde_light_phase *phases;   /* [n_phase_total] */
     int32_t n_maps, n_scn, NW, A;
     int32_t n_routes, RW, n_replay, RT;
+    int32_t hints;              /* (ABI 9) TDE_WORLD_*: properties of the tables that select a kernel form (never results) */
+    int32_t _pad0;
 } tde_world;
+/* tde_world.hints: some map's grid is large (more than 2^21 cells, ~360 m x 360 m at 0.25 m cells): the persistent rollout kernels
+ * and the 32- / 64-slot one-step kernel then take the corner classes from the 2-bit class map (cell_cls2, 1/16 of cell_word's
+ * footprint) and fetch a cell word only for a corner in a MIXED cell.  Same masks either way; on a 1 km^2 town 3.98 -> 3.02 us
+ * per rollout step, on 280 m junction maps 2.92 -> 2.99 (profiles/r04_b_*). */
+#define TDE_WORLD_LARGE_GRID (1 << 0)
 
 /* What tde_grid_build (include/tde_hip.h) returns for ONE map: the offroad grid index of a drivable mesh, row-major
  * [ny * nx] HOST arrays owned by the library (tde_grid_free).  The caller packs them into the tde_world tables: a cell's word
@@ -213,7 +231,9 @@ typedef struct tde_slot_cache {  /* 32 bytes (ABI 8; 48 before) */
 /* The NPC controller's actions for the NEXT step, computed at the end of a step behind the judges (they only need the state
  * after the step).  [B * (A + 1)] entries of 8 bytes: env e's slots at e * (A + 1) + a, then ONE key entry for the env at
  * e * (A + 1) + A holding, as two int32, the (episode, environment_steps) pair of the state the actions were computed from
- * (episode < 0: invalid).  (ABI 8; 16 bytes per slot with a key each before.) */
+ * (episode < 0: invalid); bits 20-31 of the second word carry a hash of what else the controller depends on - config.flags &
+ * (NPC | REPLAY | TRAFFIC_LIGHTS) and the npc_* constants (ABI 9) - so a caller that changes those between two launches gets
+ * the actions recomputed, not replayed.  (ABI 8: 16 bytes per slot with a key each before.) */
 typedef struct tde_act_cache {
     float acc, beta;
 } tde_act_cache;

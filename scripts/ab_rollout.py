@@ -17,7 +17,7 @@ import torch
 
 from torchdriveenv_amd import _abi
 from torchdriveenv_amd.state import EnvState
-from torchdriveenv_amd.synth import synthetic_world
+from torchdriveenv_amd.synth import synthetic_town, synthetic_world
 
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs="+")
@@ -26,6 +26,7 @@ ap.add_argument("--agents", type=int, default=16)
 ap.add_argument("--launches", type=int, default=40)
 ap.add_argument("--steps", type=int, default=250)
 ap.add_argument("--lights", action="store_true")
+ap.add_argument("--town", action="store_true", help="the 1 km x 1 km town map (synth.synthetic_town) instead of the junction maps")
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawns")
 ap.add_argument("--truncate-only", type=int, default=0, metavar="N",
                 help="no termination at infractions, truncation after N steps: every env re-spawns every N steps")
@@ -33,7 +34,7 @@ args = ap.parse_args()
 
 B, A, K = args.envs, args.agents, args.steps
 dev = torch.device("cuda:0")
-world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+world = synthetic_town(n_scn=256, A=A, seed=0) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
 
 

@@ -24,7 +24,7 @@ for G in groups:
     st = EnvState(B, A, device=dev, with_info=False)
     ops.env_reset(cfg, dw, st)
     img = ops.render_ego(cfg, dw, st)
-    h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct), 0)
+    h = _ext.env_handle(cfg, dw, st)
     streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
     ptrs = [s.cuda_stream for s in streams]
     flags = int(cfg.flags)

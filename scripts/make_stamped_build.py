@@ -2,11 +2,11 @@
 `tde_debug_stamps` that scripts/phase_stamps.py, render_stamps.py and trip_counts.py read.  The instrumentation is
 applied to a copy of csrc/tde_kernels.hip by text substitution (asserted), so the shipped kernels stay clean.
 
-    python scripts/make_stamped_build.py duo|trio|render|trips      # then  TDE_HIP_LIB=$PWD/ab/libS.so python scripts/...
+    python scripts/make_stamped_build.py duo|trio|step3|trips      # then  TDE_HIP_LIB=$PWD/ab/libS.so python scripts/...
 
 duo    : driver / judge phases of env_rollout_duo_kernel        -> scripts/phase_stamps.py
 trio   : driver / judge C / judge O phases of env_rollout_trio_kernel -> scripts/phase_stamps.py trio
-render : passes of render_layers_kernel                         -> scripts/render_stamps.py
+step3  : driver / judge C / judge O milestones of env_step_trio_kernel -> scripts/step_stamps.py
 trips  : exact-loop trip counts of the controller / collision   -> scripts/trip_counts.py
 The stamps cost 10-40 % themselves: read the shares, not the totals.
 """
@@ -85,8 +85,8 @@ def patch_duo(s):
     k = sub(k, "            act = act_next;\n        }\n", "            act = act_next;\n        }\n        if (lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[i], stp.acc[i]);\n")
     k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            lds_barrier();                                   // A\n            lds_barrier();                                   // B: rows of step i are in buffer p\n",
             "        lds_barrier();\n        Stamps stp; stp.start();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1;\n            lds_barrier();                                   // A\n            stp.mark(0);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            stp.mark(1);\n")
-    k = sub(k, "            bool off = false;\n            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2);\n",
-            "            stp.mark(2);\n            bool off = false;\n            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2);\n            stp.mark(3);\n")
+    k = sub(k, "            bool off = false;\n            if (F & TDE_F_OFFROAD) off = offroad_resolve<false, BIG || TDE_ROLLOUT_CLS2>(w, corners, thr2, cx.m.rec_base);\n",
+            "            stp.mark(2);\n            bool off = false;\n            if (F & TDE_F_OFFROAD) off = offroad_resolve<false, BIG || TDE_ROLLOUT_CLS2>(w, corners, thr2, cx.m.rec_base);\n            stp.mark(3);\n")
     k = sub(k, "            if (lane == 0) sh.done = any;\n", "            stp.mark(4);\n            if (lane == 0) sh.done = any;\n")
     k = sub(k, "                o.respawned = true;\n            }\n        }\n",
             "                o.respawned = true;\n            }\n            stp.mark(5);\n        }\n        if (lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_stamps[12 + i], stp.acc[i]);\n")
@@ -157,8 +157,8 @@ def patch_step3(s):
             "        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);\n        tde_mark(&stl, 2);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(&stl, 3);\n")
     k = sub(k, "        lds_barrier();                                       // A: the judges' masks are published\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;",
             "        tde_mark(&stl, 6);\n        lds_barrier();                                       // A: the judges' masks are published\n        tde_mark(&stl, 4);\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;")
-    k = sub(k, "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);\n",
-            "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx);\n        tde_mark(&stl, 5);\n        tde_flush(0, 7);\n")
+    k = sub(k, "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx, cfg.flags);\n",
+            "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx, cfg.flags);\n        tde_mark(&stl, 5);\n        tde_flush(0, 7);\n")
     # judge C
     k = sub(k, "        lds_barrier();                                       // B\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]",
             "        tde_mark(&stl, 8);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 9);\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]")
@@ -173,45 +173,33 @@ def patch_step3(s):
     return s[:a] + k + s[b:]
 
 
-def patch_render(s):
-    a, b = kernel_span(s, "render_layers_kernel")
-    k = s[a:b]
-
-    def mark(n):
-        return ("    { unsigned long long tn = __builtin_amdgcn_s_memtime(); if (tid == 0) g_loc[%d] += tn - tlast; "
-                "tlast = tn; }\n" % n)
-    k = sub(k, "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; s_nstop = 0; }\n",
-            "    unsigned long long tlast = __builtin_amdgcn_s_memtime();\n    unsigned long long g_loc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};\n"
-            "    if (tid == 0) { s_nbox = 0; s_nwp = 0; s_nwork = 0; s_nmixed = 0; s_nstop = 0; }\n")
-    # split the first phase: the cull (pass 0) ends where the block pass begins
-    k = sub(k, "        // ---- pass 1: base layer of 2x2 blocks", mark(6) + "        // ---- pass 1: base layer of 2x2 blocks")
-    k = sub(k, "    __syncthreads();\n    const bool crowded =", mark(1) + "    __syncthreads();\n    const bool crowded =")
-    k = sub(k, "        // ---- pass 2b:", mark(2) + "        // ---- pass 2b:")
-    k = sub(k, "        // ---- pass 3: objects over the base", mark(3) + "        // ---- pass 3: objects over the base")
-    k = sub(k, "    __syncthreads();\n\n    // ---- pass 4:", mark(4) + "    __syncthreads();\n\n    // ---- pass 4:")
-    k = k[:k.rindex("}")] + mark(5) + ("    if (tid == 0 && (blockIdx.x & 15) == 0) { for (int i = 0; i < 7; ++i) atomicAdd(&g_stamps[i], g_loc[i]); "
-                                       "atomicAdd(&g_stamps[10], 1ull); atomicAdd(&g_stamps[11], (unsigned long long)s_nwork); "
-                                       "atomicAdd(&g_stamps[12], (unsigned long long)s_nmixed); }\n}\n")
-    return s[:a] + k + s[b:]
-
-
 def patch_trips(s):
-    s = sub(s, "    float gap = 1e30f;\n    while (__ballot(cand != 0)) {\n",
-            "    float gap = 1e30f;\n    if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[1], 1ull);\n"
+    """exact-loop trip counts: controller (g_stamps 0 trips, 1 calls, 3 candidates) and collision sweep (4, 5, 6)"""
+    s = sub(s, "    // taken (fj = 0).\n    while (__ballot(cand != 0)) {\n",
+            "    // taken (fj = 0).\n    if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[1], 1ull);\n"
             "    atomicAdd(&g_stamps[3], (unsigned long long)__popcll((unsigned long long)cand));\n"
             "    while (__ballot(cand != 0)) {\n        if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[0], 1ull);\n")
-    s = sub(s, "    bool hit = false;\n    while (__ballot(cand != 0)) {\n",
+    s = sub(s, "    bool hit = false;\n    while (__ballot(cand != 0)) {\n        if (cand) {\n            const int j = row_of_bit<A>(lowest_bit(cand));\n",
             "    bool hit = false;\n    if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[5], 1ull);\n"
             "    atomicAdd(&g_stamps[6], (unsigned long long)__popcll((unsigned long long)cand));\n"
-            "    while (__ballot(cand != 0)) {\n        if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[4], 1ull);\n")
+            "    while (__ballot(cand != 0)) {\n        if (threadIdx.x % 64 == 0) atomicAdd(&g_stamps[4], 1ull);\n        if (cand) {\n            const int j = row_of_bit<A>(lowest_bit(cand));\n")
     return s
+
+
+PATCHES = {"duo": patch_duo, "trio": patch_trio, "step3": patch_step3, "trips": patch_trips}
+
+
+def patched_source(mode):
+    """the kernel source with the stamps of `mode` applied (asserts that every anchor still exists:
+    tests/test_boundary.py::test_stamp_patches_apply_to_the_current_source)"""
+    s = open(SRC).read()
+    s = sub(s, ANCHOR, PRELUDE + ANCHOR)
+    return PATCHES[mode](s) + EPILOGUE
 
 
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "duo"
-    s = open(SRC).read()
-    s = sub(s, ANCHOR, PRELUDE + ANCHOR)
-    s = {"duo": patch_duo, "trio": patch_trio, "step3": patch_step3, "render": patch_render, "trips": patch_trips}[mode](s) + EPILOGUE
+    s = patched_source(mode)
     os.makedirs(os.path.join(ROOT, "ab"), exist_ok=True)
     tmp = os.path.join(ROOT, "ab", f"tde_kernels_{mode}_stamped.hip")
     open(tmp, "w").write(s)

@@ -32,7 +32,7 @@ for G in groups:
         ops.env_reset(cfg, dw, st)
         img = ops.render_ego(cfg, dw, st)
         s = torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream()
-        h = ext.EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct), 0)
+        h = _ext.env_handle(cfg, dw, st)
         rows = [actions[i, r * nb:(r + 1) * nb].contiguous() for i in range(CH)]
         parts.append(dict(cfg=cfg, st=st, img=img, s=s, h=h, rows=rows, flags=int(cfg.flags)))
     torch.cuda.synchronize()

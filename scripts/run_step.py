@@ -5,13 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torchdriveenv_amd import _abi, _lib, ops
 from torchdriveenv_amd.state import EnvState
-from torchdriveenv_amd.synth import synthetic_world
+from torchdriveenv_amd.synth import synthetic_town, synthetic_world
+TOWN = os.environ.get("TDE_WORLD") == "town"            # TDE_WORLD=town: the 1 km^2 town map instead of the junction maps
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 kern = sys.argv[2] if len(sys.argv) > 2 else None
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 8192
 dev = torch.device("cuda:0")
-world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+world = synthetic_town(n_scn=256, A=A, seed=0) if TOWN else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
 _lib.kernel_override(step=kern if kern in ("solo", "trio") else None)

@@ -20,7 +20,7 @@ for B in (512, 1024, 2048, 4096):
         _lib.kernel_override(step=kern)
         st = EnvState(B, A, device=dev, with_info=False)
         ops.env_reset(cfg, dw, st)
-        h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct), 0)
+        h = _ext.env_handle(cfg, dw, st)
         fl = int(cfg.flags)
         for i in range(1000): h.step(rows[i % 250], fl)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

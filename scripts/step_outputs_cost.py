@@ -18,7 +18,7 @@ rows = [actions[i] for i in range(250)]
 for info, obs, epi in ((False, False, False), (True, False, False), (False, True, False), (False, False, True), (True, False, True), (True, True, True)):
     st = EnvState(B, A, device=dev, with_info=info, with_obs=obs, with_episode=epi)
     ops.env_reset(cfg, dw, st)
-    h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct), 0)
+    h = _ext.env_handle(cfg, dw, st)
     fl = int(cfg.flags)
     for i in range(1000): h.step(rows[i % 250], fl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

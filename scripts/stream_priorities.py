@@ -20,7 +20,7 @@ for prios in ([0, 0, 0], [-1, 0, 0], [-1, -1, 0], [0, -1, 0], [-1, -1, -1], [0, 
     st = EnvState(B, A, device=dev, with_info=False)
     ops.env_reset(cfg, dw, st)
     img = ops.render_ego(cfg, dw, st)
-    h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(st.struct), 0)
+    h = _ext.env_handle(cfg, dw, st)
     streams = [torch.cuda.Stream(device=dev, priority=p) for p in prios]
     ptrs = [s.cuda_stream for s in streams]
     ops.fork_streams(streams, dev)

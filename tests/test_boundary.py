@@ -114,8 +114,25 @@ def test_torch_extension_builds_in_tree_and_binds_the_same_abi():
     assert "libtde_hip.so" in dyn and "$ORIGIN/.." in dyn
     m = _ext.load()
     assert m.abi_version() == _lib.load().tde_abi_version() == _abi.TDE_ABI_VERSION
-    for meth in ("step", "reset", "rollout", "render", "state_obs"):
+    for meth in ("step", "reset", "rollout", "render", "step_render", "state_obs"):
         assert hasattr(m.EnvHandle, meth)
+    assert hasattr(m, "Config") and hasattr(m, "World")             # typed carriers: no raw addresses cross the boundary
+    with pytest.raises(RuntimeError, match="bytes"):
+        m.Config(b"short")
+    m.Config(bytes(_abi.default_config()))
     # device code lives in libtde_hip.so only: the extension object defines no kernels
     syms = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
     assert "tde_env_step" not in syms and "PyInit_tde_torch_ext" in syms
+
+
+def test_stamp_patches_apply_to_the_current_source():
+    """scripts/make_stamped_build.py instruments a COPY of the kernel source by text substitution: every anchor of every
+    patch must still exist, or the stamp profiles DESIGN.md cites can no longer be regenerated from HEAD"""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import make_stamped_build as m
+
+    for mode in m.PATCHES:
+        src = m.patched_source(mode)
+        assert "tde_debug_stamps" in src and ("tde_mark(" in src or "stp.mark(" in src or mode == "trips"), mode

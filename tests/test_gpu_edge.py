@@ -181,6 +181,31 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["kernel_avg_us"] / 1e3) / rf["achieved"] < 1e-6
 
 
+def test_bench_one_rank_over_rccl():
+    """the RCCL leg of bench.py's N > 1 path on a one-GPU box: `--gpus 1 --force-dist --backend nccl` creates the process
+    group (init_process_group("nccl", device_id=...)), and the barrier, the MAX all_reduce and the all_gather of the
+    per-shard check sums run through RCCL with device tensors - once, here, before an 8-GPU node sees them.  A fresh
+    child process (nothing in it has touched the GPU before the rendezvous)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
+                          "--steps", "500", "--warmup", "250", "--envs", "2048", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["config"]["timing_backend"] == "nccl" and j["value"] > 0
+    assert isinstance(j["check"], list) and len(j["check"]) == 1 and j["check"][0]["env_base"] == 0     # the gathered form
+    assert "secondary" not in j
+
+
 def test_bench_nccl_refuses_ranks_sharing_a_gpu():
     """--backend nccl (the default) must fail, not fall back to gloo, when the ranks cannot each have a GPU"""
     import os
@@ -245,6 +270,29 @@ def test_render_other_sizes_and_bad_sizes(small_world):
         ops.render_ego(cfg, dw, ds, H=30, W=30)
     with pytest.raises(_lib.TdeError, match="4096"):
         ops.render_ego(cfg, dw, ds, H=128, W=64)
+
+
+def test_step_render_with_a_bad_render_request_advances_nothing(small_world):
+    """tde_env_step_render validates the render request BEFORE its first launch: a failing call leaves every sub-batch at
+    the timestep it was (round 3 launched sub-batch 0's step first and only then looked at H / W)"""
+    cfg = _abi.default_config(seed=4)
+    dw = small_world.to_device(DEV)
+    B = 192
+    ds = EnvState(B, 16, device=DEV)
+    ops.env_reset(cfg, dw, ds)
+    ds["action"][:, 0] = 0.7
+    before = ds.host()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(3)]
+    ops.fork_streams(streams, torch.device(DEV))
+    for kw, msg in ((dict(H=84, W=84), "4096"), (dict(H=30, W=30), "multiples of 4"), (dict(phase=-1), "phase")):
+        with pytest.raises(_lib.TdeError, match=msg):
+            img = torch.zeros(B, 3, kw.get("H", 64), kw.get("W", 64), dtype=torch.uint8, device=DEV)
+            ops.env_step_render(cfg, dw, ds, streams, out=img, **kw)
+    ops.join_streams(streams, torch.device(DEV))
+    torch.cuda.synchronize()
+    after = ds.host()
+    for k in ("x", "y", "psi", "v", "steps", "episode", "target_idx"):
+        assert np.array_equal(before[k].view(np.uint8), after[k].view(np.uint8)), k
 
 
 @pytest.mark.parametrize("H,W,n_stack", [(32, 32, 2), (48, 64, 4), (64, 64, 5)])

@@ -159,14 +159,14 @@ def test_operator_level_entry_points_through_the_extension(small_world, golden):
     c1, c2 = X.compute_collision(B, A, *args), ops.compute_collision(B, A, *args)
     assert torch.equal(c1, c2) and np.array_equal(c1.cpu().numpy(), oracle.compute_collision(B, A, *[h[k] for k in ("x", "y", "psi", "len", "wid", "present")]))
     mo = np.ascontiguousarray(small_world.arrays["scn"]["map"][h["scn"]].astype(np.int32))
-    o1 = X.compute_offroad(B, A, *args, C.addressof(dw.struct), dev(mo), 0.5)
+    o1 = X.compute_offroad(B, A, *args, _ext.world_of(dw), dev(mo), 0.5)
     o2 = ops.compute_offroad(B, A, *args, dw, dev(mo), threshold=0.5)
     assert torch.equal(o1, o2) and np.array_equal(o1.cpu().numpy(), oracle.compute_offroad(B, A, *[h[k] for k in ("x", "y", "psi", "len", "wid", "present")], small_world, mo, threshold=0.5))
     # the reference-owned reward logic on a golden case
     case = golden["cases"][0]
     ccfg, inp, exp = case_config(case), case_inputs(case), case_expected(case)
     steps, target, reached = dev(inp["steps"].copy()), dev(inp["target"].copy()), dev(inp["reached"].copy())
-    out = X.waypoint_reward(C.addressof(ccfg), dev(np.ascontiguousarray(inp["pre"].T)), dev(np.ascontiguousarray(inp["post"].T)),
+    out = X.waypoint_reward(_ext.config_of(ccfg), dev(np.ascontiguousarray(inp["pre"].T)), dev(np.ascontiguousarray(inp["post"].T)),
                             dev(inp["off"]), dev(inp["col"]), dev(inp["tl"]), dev(inp["wp"]), dev(inp["wp_n"]), dev(inp["scn"]),
                             steps, target, reached)
     reward, term, trunc, info, info_reached = [t.cpu().numpy() for t in out]
@@ -175,6 +175,21 @@ def test_operator_level_entry_points_through_the_extension(small_world, golden):
     assert np.array_equal(info_reached, exp["reached"]) and np.allclose(info, exp["info"], rtol=1e-12, atol=1e-15)
     with pytest.raises(RuntimeError):
         X.compute_collision(B, A, *[t.cpu() for t in args])                   # host tensors are refused, not dereferenced
+    # typed carriers: no raw address is accepted any more; wrong sizes / dtypes / unknown names are refused with the field's name
+    with pytest.raises(TypeError):
+        X.compute_offroad(B, A, *args, C.addressof(dw.struct), dev(mo), 0.5)
+    with pytest.raises(RuntimeError, match="bytes"):
+        X.Config(b"\0" * 8)
+    st = EnvState(B, A, device=DEV)
+    tens = {k: v for k, v in st.arrays.items() if v is not None}
+    with pytest.raises(RuntimeError, match="psi"):
+        X.EnvHandle(_ext.config_of(ccfg), _ext.world_of(dw), {**tens, "psi": tens["psi"][:-1]}, B, A)
+    with pytest.raises(RuntimeError, match="steps"):
+        X.EnvHandle(_ext.config_of(ccfg), _ext.world_of(dw), {**tens, "steps": tens["steps"].float()}, B, A)
+    with pytest.raises(RuntimeError, match="lacks"):
+        X.EnvHandle(_ext.config_of(ccfg), _ext.world_of(dw), {k: v for k, v in tens.items() if k != "x"}, B, A)
+    with pytest.raises(RuntimeError, match="no field"):
+        X.EnvHandle(_ext.config_of(ccfg), _ext.world_of(dw), {**tens, "bogus": tens["x"]}, B, A)
 
 
 def test_sharded_env_argument_checks(small_world):
@@ -559,7 +574,7 @@ def test_step_render_on_streams_equals_whole_batch_and_oracle(small_world, B, n_
     split, viaext = EnvState(B, A, device=DEV), EnvState(B, A, device=DEV)
     split.load(hs.host()); viaext.load(hs.host())
     streams = [torch.cuda.Stream(device=DEV) for _ in range(n_streams)]
-    h = _ext.load().EnvHandle(ctypes.addressof(cfg), ctypes.addressof(dw.struct), ctypes.addressof(viaext.struct), 0)
+    h = _ext.env_handle(cfg, dw, viaext)
     img_w = torch.zeros((B, 3, 64, 64), dtype=torch.uint8, device=DEV)
     img_s, img_e = torch.zeros_like(img_w), torch.zeros_like(img_w)
     # frame stack of 3 through the layer ring (split path) vs the same on the whole batch
@@ -627,6 +642,10 @@ def test_step_forms_alternating_on_one_state_and_flag_changes_bit_exact(A):
     F = _abi.F_ALL | _abi.F_TRAFFIC_LIGHTS
     cfg = _abi.default_config(seed=29, distance_cutoff=0.25, flags=F, max_steps=40)
     cfg_b = _abi.default_config(seed=29, distance_cutoff=0.25, flags=F & ~_abi.F_NPC, max_steps=40)
+    # what the stored NPC actions depend on besides the state (ABI 9: hashed into the action cache's key): the lights flag, a
+    # controller constant
+    cfg_c = _abi.default_config(seed=29, distance_cutoff=0.25, flags=F & ~_abi.F_TRAFFIC_LIGHTS, max_steps=40)
+    cfg_d = _abi.default_config(seed=29, distance_cutoff=0.25, flags=F, max_steps=40, npc_k_speed=1.5, npc_gap_s0=4.0)
     B = 100
     hs = EnvState(B, A)
     solo, mixed = EnvState(B, A, device=DEV, with_obs=True), EnvState(B, A, device=DEV, with_obs=True)
@@ -649,7 +668,8 @@ def test_step_forms_alternating_on_one_state_and_flag_changes_bit_exact(A):
 
     try:
         for t in range(150):
-            c = cfg_b if 70 <= t < 80 else cfg                 # ten steps without the NPC controller, then with it again
+            # ten steps without the NPC controller, six without the lights, six with other controller constants
+            c = cfg_b if 70 <= t < 80 else cfg_c if 90 <= t < 96 else cfg_d if 108 <= t < 114 else cfg
             act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
             hs["action"][...] = act
             oracle.env_step(c, world, hs)
@@ -659,7 +679,7 @@ def test_step_forms_alternating_on_one_state_and_flag_changes_bit_exact(A):
             _lib.kernel_override(step="solo" if (t // 3) % 2 else "trio")
             mixed["action"].copy_(dev(act))
             ops.env_step(c, dw, mixed)
-            if t % 7 == 6 or t in (70, 71, 80, 81):
+            if t % 7 == 6 or t in (70, 71, 80, 81, 90, 91, 96, 97, 108, 109, 114, 115):
                 check(t)
             if t % 40 == 39:
                 m = ((hs["terminated"] | hs["truncated"]) | (rng.uniform(size=B) < 0.1)).astype(np.uint8)

@@ -57,7 +57,7 @@ class TdeMap(C.Structure):
         ("nx", C.c_int32), ("ny", C.c_int32), ("cell_base", C.c_int32), ("tri_base", C.c_int32),
         ("n_tri", C.c_int32), ("stop_base", C.c_int32), ("n_stop", C.c_int32), ("phase_base", C.c_int32),
         ("n_phase", C.c_int32), ("cycle_steps", C.c_int32), ("row_shift", C.c_int32), ("cls2_base", C.c_int32),
-        ("rec_base", C.c_int32), ("_pad0", C.c_int32 * 3),
+        ("rec_base", C.c_int32), ("coarse_base", C.c_int32), ("_pad0", C.c_int32 * 2),
     ]
 
 
@@ -74,7 +74,7 @@ class TdeGrid(C.Structure):
 MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "f4"), ("nx", "i4"), ("ny", "i4"),
                       ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("stop_base", "i4"), ("n_stop", "i4"),
                       ("phase_base", "i4"), ("n_phase", "i4"), ("cycle_steps", "i4"), ("row_shift", "i4"), ("cls2_base", "i4"),
-                      ("rec_base", "i4"), ("_pad0", "i4", (3,))])
+                      ("rec_base", "i4"), ("coarse_base", "i4"), ("_pad0", "i4", (2,))])
 STOPLINE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("c", "f4"), ("s", "f4"), ("hl", "f4"), ("hw", "f4"),
                            ("light", "i4"), ("_pad0", "i4")])
 PHASE_DTYPE = np.dtype([("end_step", "i4"), ("red_mask", "u4")])
@@ -86,13 +86,14 @@ SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("
 SCN_DTYPE = np.dtype([("map", "i4"), ("wp_n", "i4"), ("start_heading", "f4"), ("_pad0", "i4")])
 assert SPAWN_DTYPE.itemsize == 64 and SCN_DTYPE.itemsize == 16
 
-WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "cell_cls2", "cell_sub", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
+WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "cell_cls2", "cell_sub", "cell_coarse", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
               "stoplines", "phases"]
-WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT"]
+WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT", "hints"]
+WORLD_LARGE_GRID = 1 << 0
 
 
 class TdeWorld(C.Structure):
-    _fields_ = [(n, _p) for n in WORLD_PTRS] + [(n, C.c_int32) for n in WORLD_INTS]
+    _fields_ = [(n, _p) for n in WORLD_PTRS] + [(n, C.c_int32) for n in WORLD_INTS] + [("_pad0", C.c_int32)]
 
 
 STATE_AGENT_F32 = ["x", "y", "psi", "v", "len", "wid", "lr", "vdes"]
@@ -170,7 +171,7 @@ def default_config(**over):
 
 
 WORLD_DTYPES = {
-    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "cell_cls2": np.uint32, "cell_sub": np.uint32, "scn": SCN_DTYPE,
+    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "cell_cls2": np.uint32, "cell_sub": np.uint32, "cell_coarse": np.uint8, "scn": SCN_DTYPE,
     "wp_xy": np.float64, "spawn": SPAWN_DTYPE, "route_xy": np.float32, "replay_states": np.float32,
     "stoplines": STOPLINE_DTYPE, "phases": PHASE_DTYPE,
 }

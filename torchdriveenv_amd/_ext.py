@@ -55,3 +55,25 @@ def load():
     sys.modules[NAME] = mod
     _mod = mod
     return mod
+
+
+# ---- typed construction of the extension's argument carriers (no raw addresses cross the boundary) --------------------
+def config_of(cfg):
+    """ext.Config from a ctypes tde_config (_abi.TdeConfig): its bytes, copied"""
+    return load().Config(bytes(cfg))
+
+
+def world_of(dworld):
+    """ext.World over the device tensors of a world.DeviceWorld (cached on it; the ext object keeps the tensors alive)"""
+    w = getattr(dworld, "_ext_world", None)
+    if w is None:
+        dev = next(iter(dworld.tensors.values())).device
+        w = load().World(dict(dworld.tensors), dict(dworld.ints), dev.index or 0)
+        dworld._ext_world = w
+    return w
+
+
+def env_handle(cfg, dworld, state):
+    """ext.EnvHandle for (tde_config, DeviceWorld, device EnvState): named tensors in, validated in C++"""
+    tens = {k: v for k, v in state.arrays.items() if v is not None}
+    return load().EnvHandle(config_of(cfg), world_of(dworld), tens, state.B, state.A)

@@ -262,6 +262,10 @@ TDE_DEV uint32_t cell_class_lookup(const tde_world &w, const tde_map &m, float p
 #ifndef TDE_STEP_CLS2
 #define TDE_STEP_CLS2 1
 #endif
+// the same choice for the judges of the two- and three-role rollout kernels (A/B on the town map, profiles/r04_*)
+#ifndef TDE_ROLLOUT_CLS2
+#define TDE_ROLLOUT_CLS2 0
+#endif
 
 // CLS2 (the one-step kernels, whose state is not register-resident and whose every launch therefore pays the HBM / fabric
 // traffic of its lookups): the corners' classes come from the class map and only a corner in a MIXED cell fetches its cell word

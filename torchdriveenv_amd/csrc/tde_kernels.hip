@@ -708,7 +708,7 @@ TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag,
 // Called by all BLOCK lanes of the workgroup, converged (contains barriers and wave ballots).
 // LIGHTS: compiled with the traffic-light code (stop-line violation of the ego, NPCs stopping at red lines); the
 // kernels without it serve configs that have no lights at zero cost.
-template <int A, int BLOCK, bool LIGHTS>
+template <int A, int BLOCK, bool LIGHTS, bool BIG = false>
 TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold &cold, const tde_state &st,
                           Tiles<BLOCK> &t, int e, int a, bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0,
                           float &s0, float act_acc, float act_steer)
@@ -760,7 +760,8 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     // One-step launches of up to 16 slots per env read the corners' classes from the 2-bit class map (tde_device.h: 17.0 -> 12.1 MB
     // of HBM / fabric traffic per step at 8192 x 16, same time); at 32 slots per env the extra round trip of the MIXED corners
     // costs 0.55 us of the launch's tail (15.85 -> 16.43 us, profiles/r03_f_step_cls2_ab.txt) and the cell words stay.
-    constexpr bool kStepCls2 = (BLOCK == kBlock) && TDE_STEP_CLS2 && A <= 16;
+    // (BIG - a large grid, tde_world.hints: the cell words of a town are 66 MB per km^2 and the class map wins at any A)
+    constexpr bool kStepCls2 = (BLOCK == kBlock) && TDE_STEP_CLS2 && (A <= 16 || BIG);
     Corners corners;                                // cell words of the four corners: loads stay in flight during
     if (F & TDE_F_OFFROAD)                          // the collision sweep
         offroad_issue<kStepCls2>(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
@@ -828,7 +829,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 // one launch = one timestep of every env
 // OBS: also writes the compact observation (tde_state.obs); a template flag because the code, taken or not, costs the
 // plain kernel 0.9 us per launch (it keeps the ego target and the heading's sin/cos alive to the end)
-template <int A, bool LIGHTS, bool OBS>
+template <int A, bool LIGHTS, bool OBS, bool BIG = false>
 __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
                                                           const float *__restrict__ action, float *reward_k,
                                                           uint8_t *done_k)
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
-    StepOut o = step_lane<A, kBlock, LIGHTS>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
+    StepOut o = step_lane<A, kBlock, LIGHTS, BIG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
     if (!valid) return;
     store_agent_dynamic(st, g, ag);
     if (o.respawned) store_agent_static(st, g, ag);
@@ -1044,7 +1045,8 @@ TDE_DEV void write_rows(DuoShared &sh, int buf, int lane, bool live, const Agent
     sh.c[buf][lane] = make_float4(ag.psi, ag.v, live ? 1.0f : 0.0f, 0.0f);
 }
 
-template <int A, bool LIGHTS>
+// BIG (tde_world.hints & TDE_WORLD_LARGE_GRID): the judges take the corner classes from the 2-bit class map
+template <int A, bool LIGHTS, bool BIG>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_rollout_duo_kernel(tde_config cfg, tde_world w, tde_state st,
                                                                     tde_rollout ro)
 {
@@ -1197,10 +1199,10 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             const bool live = rc.z != 0.0f;
             const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
             Corners corners;
-            if (F & TDE_F_OFFROAD) offroad_issue(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+            if (F & TDE_F_OFFROAD) offroad_issue<BIG || TDE_ROLLOUT_CLS2>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
             const bool hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, live, x, y, c0, s0, hl, hw, ra.z);
             bool off = false;
-            if (F & TDE_F_OFFROAD) off = offroad_resolve(w, corners, thr2, cx.m.rec_base);
+            if (F & TDE_F_OFFROAD) off = offroad_resolve<false, BIG || TDE_ROLLOUT_CLS2>(w, corners, thr2, cx.m.rec_base);
             bool tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
                 tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
@@ -1299,7 +1301,7 @@ template <int N> TDE_DEV void dummy_valu(float seed)
 #define TDE_PRIO_C 0
 #define TDE_PRIO_O 1
 #endif
-template <int A, bool LIGHTS>
+template <int A, bool LIGHTS, bool BIG>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_rollout_trio_kernel(tde_config cfg, tde_world w, tde_state st,
                                                                     tde_rollout ro)
 {
@@ -1597,7 +1599,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
             const bool live = rc.z != 0.0f;
             off = false;
-            if (F & TDE_F_OFFROAD) off = box_offroad(w, cx.m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
+            if (F & TDE_F_OFFROAD) off = box_offroad<false, BIG || TDE_ROLLOUT_CLS2>(w, cx.m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
             tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
                 tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
@@ -1691,6 +1693,20 @@ TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, c
                        __float_as_int(cx.tgx2), __float_as_int(cx.tgy2));
 }
 
+// What a stored NPC action depends on besides the state it was computed from: the feature flags the controller sees and its
+// constants.  12 bits of a hash of them ride in the key entry of the action cache above the step counter (tde_act_cache), so a
+// caller that changes TDE_F_TRAFFIC_LIGHTS / TDE_F_NPC / TDE_F_REPLAY or an npc_* constant between two launches gets the
+// actions recomputed in the next launch's prologue instead of replayed.  Wave-uniform: scalar ALU only.
+TDE_DEV int act_key_steps(const tde_config &cfg, int steps)
+{
+    uint32_t h = cfg.flags & (TDE_F_NPC | TDE_F_REPLAY | TDE_F_TRAFFIC_LIGHTS);
+    const float c[10] = {cfg.npc_k_steer, cfg.npc_k_speed, cfg.npc_gap_s0, cfg.npc_cone_k, cfg.npc_lane_half, cfg.npc_reach,
+                         cfg.npc_max_accel, cfg.npc_max_steer, cfg.npc_cone_range, cfg.dt};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) h = (h ^ __float_as_uint(c[i])) * 0x9E3779B1u;
+    return (int)(((uint32_t)steps & 0xFFFFFu) | (h & 0xFFF00000u));
+}
+
 template <int A, bool LIGHTS, bool OBS>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_step_trio_kernel(
     tde_config cfg, tde_world w, tde_state st)
@@ -1767,7 +1783,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                           red_gap, na, nb);
         };
         if (F & TDE_F_NPC) {
-            const bool stored = !npc || (akey.x == er.episode && akey.y == er.steps);
+            const bool stored = !npc || (akey.x == er.episode && akey.y == act_key_steps(cfg, er.steps));
             if (__ballot(!stored)) {
                 sincos_f32(ag.psi, s0, c0);
                 write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
@@ -1825,7 +1841,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             float2 *ap = reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1);
             ap[a] = make_float2(na2, nb2);
             if (a == 0)     // (re-spawn is per env: the ego lane's flag is the env's)
-                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, er.steps);
+                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(cfg, er.steps));
         }
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================
@@ -2176,6 +2192,7 @@ struct RenderArgs {
     uint32_t flags;
     int32_t NW, A;
     const uint32_t *cell_cls2, *cell_sub;
+    const uint8_t *cell_coarse;
     int32_t K8, K4;                     // raster_block_clearance(8 / 4, res)
 };
 
@@ -2240,6 +2257,7 @@ void render_views_kernel(RenderArgs ra, int B)
     const int4 sc = reinterpret_cast<const int4 *>(ra.scn_tab)[scn];            // map, wp_n, start_heading, pad
     RasterJob J;
     J.cell_word = ra.cell_word; J.cell_tri = ra.cell_tri; J.cell_cls2 = ra.cell_cls2; J.cell_sub = ra.cell_sub;
+    J.cell_coarse = ra.cell_coarse;
     J.m = ra.maps[sc.x];
     J.stoplines = ra.stoplines + J.m.stop_base;
     J.wp = ra.wp_xy + (int64_t)scn * ra.NW * 2;
@@ -2463,6 +2481,17 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
         return e3 == hipSuccess ? 0 : fail("tde_env_step", e3);
     }
     const unsigned nb = blocks_for((int64_t)st->B * st->A);
+    if ((world->hints & TDE_WORLD_LARGE_GRID) && (st->A == 32 || st->A == 64)) {      // (up to 16 slots per env the class map is read anyway)
+#define TDE_LAUNCH_STEP_BIG(AA, L, O) tde::env_step_kernel<AA, L, O, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits)
+#define TDE_LAUNCH_STEP_BIG_A(AA)                                                                              \
+    if (st->obs) { if (lights) TDE_LAUNCH_STEP_BIG(AA, true, true); else TDE_LAUNCH_STEP_BIG(AA, false, true); } \
+    else { if (lights) TDE_LAUNCH_STEP_BIG(AA, true, false); else TDE_LAUNCH_STEP_BIG(AA, false, false); }
+        if (st->A == 32) { TDE_LAUNCH_STEP_BIG_A(32) } else { TDE_LAUNCH_STEP_BIG_A(64) }
+#undef TDE_LAUNCH_STEP_BIG_A
+#undef TDE_LAUNCH_STEP_BIG
+        hipError_t eb = hipGetLastError();
+        return eb == hipSuccess ? 0 : fail("tde_env_step", eb);
+    }
 #define TDE_LAUNCH_STEP(L, O)                                                                                          \
     TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                 \
                               *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits))
@@ -2517,12 +2546,15 @@ static int rollout_launch(const tde_config *cfg, const tde_world *world, const t
 {
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+    const bool big = (world->hints & TDE_WORLD_LARGE_GRID) != 0;      // corner classes from the 2-bit class map (tde_abi.h)
     if (team == 3) {
-#define TDE_LAUNCH_TRIO(AA)                                                                                              \
-    if (lights) tde::env_rollout_trio_kernel<AA, true><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro); \
-    else tde::env_rollout_trio_kernel<AA, false><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
-        if (st->A == 8) { TDE_LAUNCH_TRIO(8); } else if (st->A == 16) { TDE_LAUNCH_TRIO(16); } else { TDE_LAUNCH_TRIO(32); }
+#define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
+#define TDE_LAUNCH_TRIO(AA)                                                                          \
+    if (lights) { if (big) TDE_LAUNCH_TRIO2(AA, true, true); else TDE_LAUNCH_TRIO2(AA, true, false); } \
+    else { if (big) TDE_LAUNCH_TRIO2(AA, false, true); else TDE_LAUNCH_TRIO2(AA, false, false); }
+        if (st->A == 8) { TDE_LAUNCH_TRIO(8) } else if (st->A == 16) { TDE_LAUNCH_TRIO(16) } else { TDE_LAUNCH_TRIO(32) }
 #undef TDE_LAUNCH_TRIO
+#undef TDE_LAUNCH_TRIO2
     } else if (team == 1) {
         if (lights) {
             TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, true><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
@@ -2530,11 +2562,10 @@ static int rollout_launch(const tde_config *cfg, const tde_world *world, const t
             TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, false><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
         }
     } else {
-        if (lights) {
-            TDE_DISPATCH_A(st->A, tde::env_rollout_duo_kernel<kA, true><<<nb, 2 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
-        } else {
-            TDE_DISPATCH_A(st->A, tde::env_rollout_duo_kernel<kA, false><<<nb, 2 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
-        }
+#define TDE_LAUNCH_DUO(L, G) TDE_DISPATCH_A(st->A, tde::env_rollout_duo_kernel<kA, L, G><<<nb, 2 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro))
+        if (lights) { if (big) { TDE_LAUNCH_DUO(true, true); } else { TDE_LAUNCH_DUO(true, false); } }
+        else { if (big) { TDE_LAUNCH_DUO(false, true); } else { TDE_LAUNCH_DUO(false, false); } }
+#undef TDE_LAUNCH_DUO
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
@@ -2588,18 +2619,30 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     return 0;
 }
 
+// the argument checks of a render request, without launching anything (tde_render_ego; tde_env_step_render runs them before
+// its first launch, so that a bad request leaves the state of every sub-batch untouched)
+static int check_render_args(const char *who, const tde_world *world, const tde_render *rd)
+{
+    char msg[200];
+    auto say = [&](const char *what) { snprintf(msg, sizeof(msg), "%s: %s", who, what); return bad(msg); };
+    if (!rd || !rd->out) return say("render/out is NULL");
+    // (the layer plane in LDS holds the image rounded up to multiples of 8 in both directions)
+    if (rd->H <= 0 || rd->W <= 0 || (rd->W % 4) != 0 || (rd->H % 4) != 0 || (rd->H * rd->W) % 16 != 0 ||
+        ((rd->H + 7) & ~7) * ((rd->W + 7) & ~7) > tde::kRasterMaxPix || rd->H > 256 || rd->W > 256)
+        return say("H and W must be positive multiples of 4 (at most 256) whose product, each rounded up to a multiple of 8, is <= 4096");
+    if (rd->phase < 0) return say("phase must be >= 0 (keep it reduced modulo n_stack)");
+    if (!(rd->fov > 0.0f)) return say("fov must be positive");
+    if (!world->cell_cls2 || !world->cell_sub || !world->cell_word || !world->cell_tri || !world->cell_coarse) return say("the world has no grid index tables");
+    return 0;
+}
+
 int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_render *rd,
                    void *stream)
 {
     int rc = check_env_args("tde_render_ego", cfg, world, st);
     if (rc) return rc;
-    if (!rd || !rd->out) return bad("tde_render_ego: render/out is NULL");
-    // (the layer plane in LDS holds the image rounded up to multiples of 8 in both directions)
-    if (rd->H <= 0 || rd->W <= 0 || (rd->W % 4) != 0 || (rd->H % 4) != 0 || (rd->H * rd->W) % 16 != 0 ||
-        ((rd->H + 7) & ~7) * ((rd->W + 7) & ~7) > tde::kRasterMaxPix || rd->H > 256 || rd->W > 256)
-        return bad("tde_render_ego: H and W must be positive multiples of 4 (at most 256) whose product, each rounded up "
-                   "to a multiple of 8, is <= 4096");
-    if (rd->phase < 0) return bad("tde_render_ego: phase must be >= 0 (keep it reduced modulo n_stack)");
+    rc = check_render_args("tde_render_ego", world, rd);
+    if (rc) return rc;
     if (st->B <= 0) return 0;
     if (rd->n_stack > 1 && !rd->layers && !rd->only)       // (a masked call re-renders the newest frame in place)
         tde::frame_shift_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(rd->out, rd->H * rd->W, rd->n_stack);
@@ -2613,7 +2656,7 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     ra.flags = cfg->flags; ra.NW = world->NW; ra.A = st->A;
     const float res = rd->fov / (float)rd->W;
     ra.K8 = tde::raster_block_clearance(8, res); ra.K4 = tde::raster_block_clearance(4, res);
-    ra.cell_cls2 = world->cell_cls2; ra.cell_sub = world->cell_sub;
+    ra.cell_cls2 = world->cell_cls2; ra.cell_sub = world->cell_sub; ra.cell_coarse = world->cell_coarse;
     const int vpg = tde::kViewsPerGroup * TDE_RENDER_VPWAVE;
     const unsigned ng = (unsigned)((st->B + vpg - 1) / vpg);
     if (rd->H == 64 && rd->W == 64) tde::render_views_kernel<64><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
@@ -2628,6 +2671,10 @@ int tde_env_step_render(const tde_config *cfg, const tde_world *world, const tde
     int rc = check_env_args("tde_env_step_render", cfg, world, st);
     if (rc) return rc;
     if (!streams || n_streams < 1 || n_streams > 16) return bad("tde_env_step_render: streams is NULL or n_streams not in [1, 16]");
+    if (rd) {                                              // before the first launch: a failing call advances no sub-batch
+        rc = check_render_args("tde_env_step_render", world, rd);
+        if (rc) return rc;
+    }
     if (st->B <= 0) return 0;
     // equal shares rounded up to whole groups of 64 envs (any A: slices start on wavefront and workgroup boundaries)
     const int64_t share = ((((int64_t)st->B + n_streams - 1) / n_streams) + 63) & ~(int64_t)63;

@@ -16,8 +16,8 @@
 // evaluated as fmaf(v, b, fmaf(u, a, e)); every per-object quantity tested per pixel is the affine function of (u, v) it
 // is in exact arithmetic, coefficients formed once per object (box_coeffs below = the oracle's expressions), evaluated
 // the same way.  Everything else here is a result-preserving shortcut:
-//   * base layer hierarchically: an 8x8 block of pixel centres is uniform when the grid cell under its centre is FULL /
-//     EMPTY with a clearance of at least the block's half diagonal (world.py: cell_clearance); blocks that are not split
+//   * base layer hierarchically: an 8x8 block of pixel centres is uniform when the coarse tile (4 x 4 grid cells) under its
+//     centre is FULL / EMPTY with a clearance of at least the block's half diagonal (tde_world.cell_coarse); blocks that are not split
 //     into 4x4; the 4x4 blocks that still straddle a road edge are listed and their pixels take the class of their own
 //     cell from the 2-bit class map (tde_world.cell_cls2: 128-byte tiles of 8 m x 4 m, so the 16 pixels of a block share
 //     one or two cache lines - the rasteriser is bound by the cache lines its look-ups touch, ~2 cycles of the CU's L1 per
@@ -64,6 +64,7 @@ struct RasterJob {
     const float *cell_tri;
     const uint32_t *cell_cls2;
     const uint32_t *cell_sub;
+    const uint8_t *cell_coarse;
     const tde_stopline *stoplines;               // of the env's map (already offset by stop_base)
     const double *wp;                            // waypoints of the env's scenario
     tde_map m;
@@ -76,19 +77,27 @@ struct RasterJob {
     // image
     int H, W, ns, phase, flags;
     float res, inv_res, thr2;
-    int K8, K4;                                  // clearance units that make an 8x8 / 4x4 block of pixel centres uniform
+    int K8, K4;                                  // clearance units that make an 8x8 / 4x4 block of pixel centres uniform (in
+                                                 // TDE_COARSE_UNITs; TDE_CLEARANCE_UNITs in the TDE_RASTER_COARSE=0 tuning build)
     uint8_t *out;                                // this view's [3 * ns][H][W]
     uint8_t *ring;                               // this view's [ns][H * W] layer planes, or nullptr
     bool fresh;
 };
 
-// clearance (in TDE_CLEARANCE_UNITs, rounded up) at which an n x n block of pixel centres is uniform: the centres lie
+// Round 4: the block pyramid reads the COARSE table (tde_world.cell_coarse: one byte per 4 x 4 cells, 16 x 8 tiles per 128-byte
+// line) instead of the clearance field of the cell words: its 320 look-ups per view touched ~320 cache lines of a table of
+// 66 MB per km^2, now ~20 lines of a table of 1 MB per km^2.  TDE_RASTER_COARSE=0 keeps the cell-word form (A/B builds).
+#ifndef TDE_RASTER_COARSE
+#define TDE_RASTER_COARSE 1
+#endif
+
+// clearance (in units of `unit` metres, rounded up) at which an n x n block of pixel centres is uniform: the centres lie
 // within half a diagonal of the block's centre; 1 % + 2 cm cover the fp32 evaluation of both
-inline int raster_block_clearance(int n, float res)
+inline int raster_block_clearance(int n, float res, float unit = TDE_RASTER_COARSE ? TDE_COARSE_UNIT : TDE_CLEARANCE_UNIT)
 {
     const float r = 0.5f * (float)(n - 1) * 1.41421356f * res * 1.01f + 0.02f;
-    int k = (int)(r / TDE_CLEARANCE_UNIT);
-    while ((float)k * TDE_CLEARANCE_UNIT < r) ++k;
+    int k = (int)(r / unit);
+    while ((float)k * unit < r) ++k;
     return k;
 }
 
@@ -146,6 +155,21 @@ TDE_DEV uint32_t raster_lookup(const RasterJob &J, const RasterView &V, float u,
 {
     float fx, fy;
     return raster_lookup(J, V, u, v, fx, fy);
+}
+
+// class | clearance << 2 of the coarse tile under pixel (u, v) (tde_abi.h: tde_world.cell_coarse); the pyramid's look-up
+TDE_DEV uint32_t raster_coarse(const RasterJob &J, const RasterView &V, float u, float v)
+{
+#if TDE_RASTER_COARSE
+    const float fx = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cbx, __builtin_fmaf(u, V.cax, V.c0x)), 0.0f, V.nxm1);
+    const float fy = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, V.cby, __builtin_fmaf(u, V.cay, V.c0y)), 0.0f, V.nym1);
+    const uint32_t cx = (uint32_t)(int)fx >> 2, cy = (uint32_t)(int)fy >> 2;
+    static_assert(TDE_COARSE_CELLS == 4, "coarse tiles of 4 x 4 cells");
+    const uint32_t line = (uint32_t)J.m.coarse_base + ((cy >> 3) << (J.m.row_shift - 6)) + (cx >> 4);
+    return J.cell_coarse[(line << 7) | (((cy & 7u) << 4) | (cx & 15u))];
+#else
+    return raster_lookup(J, V, u, v) & 1023u;
+#endif
 }
 
 // class of the sub-cell of a MIXED cell that holds the clamped cell coordinates (fx, fy): two bits of the cell's word in
@@ -305,19 +329,19 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent,
 #endif
             uint32_t wd = 0u, w4[4] = {0u, 0u, 0u, 0u};
             if (have) {
-                wd = raster_lookup(J, V, u8, v8);
+                wd = raster_coarse(J, V, u8, v8);
                 if (TDE_RASTER_SPEC_L1) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-                        w4[s] = raster_lookup(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
+                        w4[s] = raster_coarse(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
                 }
             }
             const uint32_t cls = wd & 3u;
-            const bool uni = cls != TDE_CELL_MIXED && (int)((wd >> 2) & 255u) >= J.K8;
+            const bool uni = cls != TDE_CELL_MIXED && (int)(wd >> 2) >= J.K8;
             if (!TDE_RASTER_SPEC_L1 && have && !uni) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    w4[s] = raster_lookup(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
+                    w4[s] = raster_coarse(J, V, u8 + ((s >> 1) ? -2.0f : 2.0f), v8 + ((s & 1) ? -2.0f : 2.0f));
             }
             if (have && uni) {
                 const uint2 val = cls == TDE_CELL_FULL ? make_uint2(0x01010101u, 0x01010101u) : make_uint2(0u, 0u);
@@ -328,7 +352,7 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent,
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const uint32_t c4 = w4[s] & 3u;
-                    if (c4 != TDE_CELL_MIXED && (int)((w4[s] >> 2) & 255u) >= J.K4) {
+                    if (c4 != TDE_CELL_MIXED && (int)(w4[s] >> 2) >= J.K4) {
                         const uint32_t val = c4 == TDE_CELL_FULL ? 0x01010101u : 0u;
                         const int r4 = r8 + 4 * (s >> 1), c4o = c8 + 4 * (s & 1);
 #pragma unroll

@@ -12,6 +12,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <cstring>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -36,17 +37,132 @@ const void *dev_ptr(const at::Tensor &t, at::ScalarType dt, int64_t numel, const
     return t.data_ptr();
 }
 
-// The three argument structs of the env-level entry points, copied once from the Python side's ctypes structs (their
-// pointer members are device pointers of tensors the Python objects keep alive).
+// ---- typed carriers of the C-ABI's argument structs -----------------------------------------------------------------
+// Round 4: the extension no longer takes raw addresses.  A Config is built from the BYTES of a tde_config (length checked),
+// a World and an EnvHandle from NAMED device tensors (dtype / device / contiguity / size checked against the struct's
+// field), and both keep those tensors alive for as long as they exist: nothing here dereferences an integer that Python
+// passed, and a state buffer that Python re-allocates cannot leave the handle pointing at freed memory (the handle
+// still holds the old tensor; make a new handle for the new buffers).
+class Config {
+  public:
+    explicit Config(const py::bytes &raw)
+    {
+        const std::string b = raw;
+        TORCH_CHECK(b.size() == sizeof(tde_config), "tde_config is ", sizeof(tde_config), " bytes, got ", b.size());
+        std::memcpy(&c, b.data(), sizeof(c));
+    }
+    tde_config c;
+};
+
+struct Field {
+    const char *name;
+    size_t off;                 // offset of the pointer member in the struct
+    at::ScalarType dt;
+    int kind;                   // how many elements: see count_of
+    bool required;
+};
+enum { K_ANY = 0, K_AGENT, K_ENV, K_ENV2, K_ENV4, K_ENV8, K_SLOT8, K_ACT };
+
+#define WF(n, dt) {#n, offsetof(tde_world, n), dt, K_ANY, true}
+const Field kWorldFields[] = {WF(maps, at::kByte), WF(tri, at::kFloat), WF(cell_word, at::kUInt32), WF(cell_tri, at::kFloat),
+                              WF(cell_cls2, at::kUInt32), WF(cell_sub, at::kUInt32), WF(cell_coarse, at::kByte), WF(scn, at::kByte),
+                              WF(wp_xy, at::kDouble), WF(spawn, at::kByte), WF(route_xy, at::kFloat), WF(replay_states, at::kFloat),
+                              WF(stoplines, at::kByte), WF(phases, at::kByte)};
+#undef WF
+#define SF(n, dt, k, req) {#n, offsetof(tde_state, n), dt, k, req}
+const Field kStateFields[] = {
+    SF(x, at::kFloat, K_AGENT, true), SF(y, at::kFloat, K_AGENT, true), SF(psi, at::kFloat, K_AGENT, true), SF(v, at::kFloat, K_AGENT, true),
+    SF(len, at::kFloat, K_AGENT, true), SF(wid, at::kFloat, K_AGENT, true), SF(lr, at::kFloat, K_AGENT, true), SF(vdes, at::kFloat, K_AGENT, true),
+    SF(route_wp, at::kInt, K_AGENT, true), SF(present, at::kByte, K_AGENT, true), SF(collided, at::kByte, K_AGENT, true),
+    SF(offroad, at::kByte, K_AGENT, true), SF(scn, at::kInt, K_ENV, true), SF(steps, at::kInt, K_ENV, true),
+    SF(target_idx, at::kInt, K_ENV, true), SF(reached, at::kInt, K_ENV, true), SF(episode, at::kInt, K_ENV, true),
+    SF(action, at::kFloat, K_ENV2, true), SF(reward, at::kFloat, K_ENV, true), SF(terminated, at::kByte, K_ENV, true),
+    SF(truncated, at::kByte, K_ENV, true), SF(tl_violation, at::kByte, K_ENV, true), SF(info, at::kDouble, K_ENV4, false),
+    SF(info_reached, at::kInt, K_ENV, false), SF(done_bits, at::kByte, K_ENV, false), SF(obs, at::kFloat, K_ENV8, false),
+    SF(ep_return, at::kDouble, K_ENV, false), SF(ep_final, at::kDouble, K_ENV, false), SF(ep_final_len, at::kInt, K_ENV, false),
+    SF(slot_cache, at::kInt, K_SLOT8, false), SF(env_cache, at::kInt, K_ENV8, false), SF(act_cache, at::kInt, K_ACT, false)};
+#undef SF
+
+int64_t count_of(int kind, int64_t B, int64_t A)
+{
+    switch (kind) {
+        case K_AGENT: return B * A;
+        case K_ENV: return B;
+        case K_ENV2: return 2 * B;
+        case K_ENV4: return 4 * B;
+        case K_ENV8: return 8 * B;
+        case K_SLOT8: return 8 * B * A;
+        case K_ACT: return 2 * B * (A + 1);
+        default: return -1;
+    }
+}
+
+// fills the pointer members of a struct from a dict of named tensors; every tensor used is appended to `keep`
+template <size_t N>
+void fill_struct(void *st, const Field (&fields)[N], const py::dict &tensors, int64_t B, int64_t A, const at::Device &dev,
+                 std::vector<at::Tensor> &keep, const char *what)
+{
+    for (const Field &f : fields) {
+        const void *p = nullptr;
+        if (tensors.contains(f.name) && !tensors[f.name].is_none()) {
+            const at::Tensor t = py::cast<at::Tensor>(tensors[f.name]);
+            p = dev_ptr(t, f.dt, count_of(f.kind, B, A), f.name, dev);
+            TORCH_CHECK(t.numel() > 0, what, ".", f.name, " is empty");
+            keep.push_back(t);
+        } else {
+            TORCH_CHECK(!f.required, what, " lacks the tensor '", f.name, "'");
+        }
+        std::memcpy(static_cast<char *>(st) + f.off, &p, sizeof(p));
+    }
+    for (const auto &kv : tensors) {
+        const std::string k = py::cast<std::string>(kv.first);
+        bool known = false;
+        for (const Field &f : fields) known = known || k == f.name;
+        TORCH_CHECK(known, what, " has no field '", k, "'");
+    }
+}
+
+class World {
+  public:
+    World(const py::dict &tensors, const py::dict &ints, int64_t device_index) : dev(at::kCUDA, static_cast<c10::DeviceIndex>(device_index))
+    {
+        std::memset(&w, 0, sizeof(w));
+        fill_struct(&w, kWorldFields, tensors, 0, 0, dev, keep_, "world");
+        auto geti = [&](const char *k) {
+            TORCH_CHECK(ints.contains(k), "world lacks the size '", k, "'");
+            return static_cast<int32_t>(py::cast<int64_t>(ints[k]));
+        };
+        w.n_maps = geti("n_maps"); w.n_scn = geti("n_scn"); w.NW = geti("NW"); w.A = geti("A");
+        w.n_routes = geti("n_routes"); w.RW = geti("RW"); w.n_replay = geti("n_replay"); w.RT = geti("RT");
+        w.hints = geti("hints");
+        // the tables whose sizes the struct's integers imply
+        auto bytes_of = [&](const char *k) { const at::Tensor t = py::cast<at::Tensor>(tensors[k]); return (int64_t)t.numel() * (int64_t)t.element_size(); };
+        TORCH_CHECK(w.n_maps >= 1 && w.n_scn >= 1 && w.NW >= 2 && w.A >= 1, "world sizes out of range");
+        TORCH_CHECK(bytes_of("maps") == (int64_t)w.n_maps * (int64_t)sizeof(tde_map), "world.maps: expected n_maps * sizeof(tde_map) bytes");
+        TORCH_CHECK(bytes_of("scn") == (int64_t)w.n_scn * (int64_t)sizeof(tde_scenario), "world.scn: expected n_scn * sizeof(tde_scenario) bytes");
+        TORCH_CHECK(bytes_of("spawn") == (int64_t)w.n_scn * w.A * (int64_t)sizeof(tde_spawn), "world.spawn: expected n_scn * A * sizeof(tde_spawn) bytes");
+        TORCH_CHECK(bytes_of("wp_xy") == (int64_t)w.n_scn * w.NW * 16, "world.wp_xy: expected [n_scn][NW][2] float64");
+        TORCH_CHECK(bytes_of("route_xy") >= (int64_t)w.n_routes * w.RW * 8, "world.route_xy: smaller than [n_routes][RW][2] float32");
+        TORCH_CHECK(bytes_of("replay_states") >= (int64_t)w.n_replay * w.RT * 16, "world.replay_states: smaller than [n_replay][RT][4] float32");
+    }
+    tde_world w;
+    at::Device dev;
+
+  private:
+    std::vector<at::Tensor> keep_;
+};
+
 class EnvHandle {
   public:
-    EnvHandle(uintptr_t cfg_addr, uintptr_t world_addr, uintptr_t state_addr, int64_t device_index)
-        : dev_(at::kCUDA, static_cast<c10::DeviceIndex>(device_index))
+    EnvHandle(const Config &cfg, std::shared_ptr<World> world, const py::dict &state, int64_t B, int64_t A)
+        : cfg_(cfg.c), world_(world->w), wkeep_(std::move(world)), dev_(wkeep_->dev)
     {
-        std::memcpy(&cfg_, reinterpret_cast<const void *>(cfg_addr), sizeof(cfg_));
-        std::memcpy(&world_, reinterpret_cast<const void *>(world_addr), sizeof(world_));
-        std::memcpy(&state_, reinterpret_cast<const void *>(state_addr), sizeof(state_));
         TORCH_CHECK(tde_abi_version() == TDE_ABI_VERSION, "libtde_hip.so ABI ", tde_abi_version(), " != header ", TDE_ABI_VERSION);
+        TORCH_CHECK(B >= 0 && A >= 1 && A <= TDE_MAX_AGENTS && (A & (A - 1)) == 0, "A must be a power of two <= ", TDE_MAX_AGENTS);
+        std::memset(&state_, 0, sizeof(state_));
+        fill_struct(&state_, kStateFields, state, B, A, dev_, keep_, "state");
+        state_.B = static_cast<int32_t>(B);
+        state_.A = static_cast<int32_t>(A);
     }
 
     // tde_env_step: one timestep of every env; `action` float32 [B, 2] on the device, read in place
@@ -145,8 +261,10 @@ class EnvHandle {
   private:
     tde_config cfg_;
     tde_world world_;
+    std::shared_ptr<World> wkeep_;         // (owns the world's tensors)
     tde_state state_;
     at::Device dev_;
+    std::vector<at::Tensor> keep_;         // the state's tensors
 };
 
 // ---- operator level: the SimulatorInterface methods GymEnv calls (include/tde_hip.h, first block), torch tensors in / out ----
@@ -187,9 +305,9 @@ at::Tensor compute_collision(int64_t B, int64_t A, const at::Tensor &x, const at
     return out;
 }
 
-// tde_compute_offroad: compute_offroad() > 0 per agent -> uint8 [B * A] (ref gym_env.py:142); world_addr = the ctypes tde_world
+// tde_compute_offroad: compute_offroad() > 0 per agent -> uint8 [B * A] (ref gym_env.py:142)
 at::Tensor compute_offroad(int64_t B, int64_t A, const at::Tensor &x, const at::Tensor &y, const at::Tensor &psi,
-                           const at::Tensor &length, const at::Tensor &width, const at::Tensor &present, uintptr_t world_addr,
+                           const at::Tensor &length, const at::Tensor &width, const at::Tensor &present, const World &world,
                            const at::Tensor &map_of_env, double threshold)
 {
     const int64_t n = B * A;
@@ -199,7 +317,7 @@ at::Tensor compute_offroad(int64_t B, int64_t A, const at::Tensor &x, const at::
     check_rc(tde_compute_offroad((int32_t)B, (int32_t)A, ptr<float>(x, at::kFloat, n, "x", dev), ptr<float>(y, at::kFloat, n, "y", dev),
                                  ptr<float>(psi, at::kFloat, n, "psi", dev), ptr<float>(length, at::kFloat, n, "length", dev),
                                  ptr<float>(width, at::kFloat, n, "width", dev), ptr<uint8_t>(present, at::kByte, n, "present", dev),
-                                 reinterpret_cast<const tde_world *>(world_addr), ptr<int32_t>(map_of_env, at::kInt, B, "map_of_env", dev),
+                                 &world.w, ptr<int32_t>(map_of_env, at::kInt, B, "map_of_env", dev),
                                  (float)threshold, out.data_ptr<uint8_t>(), cur_stream(dev)),
              "tde_compute_offroad");
     return out;
@@ -207,7 +325,7 @@ at::Tensor compute_offroad(int64_t B, int64_t A, const at::Tensor &x, const at::
 
 // tde_waypoint_reward (ref gym_env.py:391-437): pre / post = (x, y, psi, v) stacked [4][n]; steps / target_idx / reached
 // int32 [n], updated in place; -> (reward f32 [n], terminated u8 [n], truncated u8 [n], info f64 [n][4], info_reached i32 [n])
-std::vector<at::Tensor> waypoint_reward(uintptr_t cfg_addr, const at::Tensor &pre, const at::Tensor &post, const at::Tensor &offroad,
+std::vector<at::Tensor> waypoint_reward(const Config &cfg, const at::Tensor &pre, const at::Tensor &post, const at::Tensor &offroad,
                                         const at::Tensor &collided, const std::optional<at::Tensor> &tl, const at::Tensor &wp_xy,
                                         const at::Tensor &wp_n, const at::Tensor &scn, const at::Tensor &steps,
                                         const at::Tensor &target_idx, const at::Tensor &reached)
@@ -222,7 +340,7 @@ std::vector<at::Tensor> waypoint_reward(uintptr_t cfg_addr, const at::Tensor &pr
     at::Tensor reward = at::empty({n}, opt.dtype(at::kFloat)), term = at::empty({n}, opt.dtype(at::kByte)),
                trunc = at::empty({n}, opt.dtype(at::kByte)), info = at::empty({n, 4}, opt.dtype(at::kDouble)),
                info_reached = at::empty({n}, opt.dtype(at::kInt));
-    check_rc(tde_waypoint_reward(reinterpret_cast<const tde_config *>(cfg_addr), (int32_t)n, p0, p0 + n, p0 + 2 * n, p0 + 3 * n, p1,
+    check_rc(tde_waypoint_reward(&cfg.c, (int32_t)n, p0, p0 + n, p0 + 2 * n, p0 + 3 * n, p1,
                                  p1 + n, p1 + 2 * n, p1 + 3 * n, ptr<uint8_t>(offroad, at::kByte, n, "offroad", dev),
                                  ptr<uint8_t>(collided, at::kByte, n, "collided", dev),
                                  tl ? ptr<uint8_t>(*tl, at::kByte, n, "tl", dev) : nullptr,
@@ -246,14 +364,17 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("compute_collision", &compute_collision, py::arg("B"), py::arg("A"), py::arg("x"), py::arg("y"), py::arg("psi"),
           py::arg("length"), py::arg("width"), py::arg("present"));
     m.def("compute_offroad", &compute_offroad, py::arg("B"), py::arg("A"), py::arg("x"), py::arg("y"), py::arg("psi"),
-          py::arg("length"), py::arg("width"), py::arg("present"), py::arg("world_addr"), py::arg("map_of_env"),
+          py::arg("length"), py::arg("width"), py::arg("present"), py::arg("world"), py::arg("map_of_env"),
           py::arg("threshold") = 0.5);
-    m.def("waypoint_reward", &waypoint_reward, py::arg("cfg_addr"), py::arg("pre"), py::arg("post"), py::arg("offroad"),
+    m.def("waypoint_reward", &waypoint_reward, py::arg("cfg"), py::arg("pre"), py::arg("post"), py::arg("offroad"),
           py::arg("collided"), py::arg("tl"), py::arg("wp_xy"), py::arg("wp_n"), py::arg("scn"), py::arg("steps"),
           py::arg("target_idx"), py::arg("reached"));
+    py::class_<Config>(m, "Config", "tde_config by value, from its bytes").def(py::init<const py::bytes &>(), py::arg("raw"));
+    py::class_<World, std::shared_ptr<World>>(m, "World", "tde_world over named device tensors (kept alive)")
+        .def(py::init<const py::dict &, const py::dict &, int64_t>(), py::arg("tensors"), py::arg("ints"), py::arg("device_index"));
     py::class_<EnvHandle>(m, "EnvHandle")
-        .def(py::init<uintptr_t, uintptr_t, uintptr_t, int64_t>(), py::arg("cfg_addr"), py::arg("world_addr"), py::arg("state_addr"),
-             py::arg("device_index"))
+        .def(py::init<const Config &, std::shared_ptr<World>, const py::dict &, int64_t, int64_t>(), py::arg("cfg"), py::arg("world"),
+             py::arg("state"), py::arg("B"), py::arg("A"))
         .def("step", &EnvHandle::step, py::arg("action"), py::arg("flags"))
         .def("reset", &EnvHandle::reset, py::arg("mask"), py::arg("flags"))
         .def("rollout", &EnvHandle::rollout, py::arg("actions"), py::arg("reward"), py::arg("done"), py::arg("flags"))

@@ -260,11 +260,8 @@ class BatchedWaypointEnv:
         self._vec = None
         self._h = None
         if binding == "ext":
-            import ctypes as C
-
             from . import _ext
-            self._h = _ext.load().EnvHandle(C.addressof(self.tde_cfg), C.addressof(self.dworld.struct),
-                                            C.addressof(self.state.struct), self.torch_device.index or 0)
+            self._h = _ext.env_handle(self.tde_cfg, self.dworld, self.state)
 
     @property
     def auto_reset(self):

@@ -23,12 +23,13 @@ GRID_TILE = 8
 
 
 def row_shift_of(nx):
-    """log2 of the row pitch the cell words of an nx-cell-wide grid are stored with (next power of two >= nx, at least 32:
-    the 2-bit class tiles are 32 cells wide)"""
-    return max(5, max(0, int(nx) - 1).bit_length())
+    """log2 of the row pitch the cell words of an nx-cell-wide grid are stored with (next power of two >= nx, at least 128:
+    a line of the coarse table is 64 cells wide, a 2-bit class tile 32)"""
+    return max(7, max(0, int(nx) - 1).bit_length())
 
 
 CLS2_TILE_W, CLS2_TILE_H = 32, 16          # cells per 128-byte tile of tde_world.cell_cls2
+CLEARANCE_UNIT = 0.125   # metres per count of the clearance field (TDE_CLEARANCE_UNIT)
 
 
 def sub_tiles(a, nx, ny):
@@ -54,6 +55,28 @@ def class_tiles(cls, nx, ny):
     return np.ascontiguousarray(w.transpose(0, 2, 1, 3)).reshape(-1), tx * ty
 
 
+COARSE, COARSE_UNIT = 4, 0.25               # TDE_COARSE_CELLS, TDE_COARSE_UNIT
+LARGE_GRID_CELLS = 1 << 21                  # a map with more cells sets TDE_WORLD_LARGE_GRID (tde_abi.h)
+
+
+def coarse_tiles(cls, count, nx, ny):
+    """cell classes and count fields [ny * nx] -> bytes of the coarse table (tde_abi.h: cell_coarse) in 128-byte lines of
+    16 x 8 coarse tiles, and the number of lines.  A tile of 4 x 4 cells is FULL / EMPTY when all its cells are, with the
+    smallest of their clearances (the distance between the tile and the nearest cell of another class), else MIXED / 0."""
+    pitch = 1 << row_shift_of(nx)
+    lx, ly = pitch // 64, -(-ny // 32)
+    c = np.full((ly * 32, pitch), _abi.CELL_EMPTY, np.uint8)
+    k = np.zeros((ly * 32, pitch), np.uint8)
+    c[:ny, :nx] = np.asarray(cls, np.uint8).reshape(ny, nx)
+    k[:ny, :nx] = np.asarray(count, np.uint8).reshape(ny, nx)
+    c4 = c.reshape(ly * 8, COARSE, pitch // COARSE, COARSE)
+    lo, hi = c4.min((1, 3)), c4.max((1, 3))
+    uni = (lo == hi) & (lo != _abi.CELL_MIXED)
+    clear = np.floor(k.reshape(ly * 8, COARSE, pitch // COARSE, COARSE).min((1, 3)) * (CLEARANCE_UNIT / COARSE_UNIT))
+    byte = np.where(uni, lo | (np.minimum(clear, 63).astype(np.uint8) << 2), _abi.CELL_MIXED).astype(np.uint8)
+    return np.ascontiguousarray(byte.reshape(ly, 8, lx, 16).transpose(0, 2, 1, 3)).reshape(-1), lx * ly
+
+
 def pitch_cells(a, nx, ny):
     """row-major [ny*nx] cell array -> rows of 2^row_shift words (the padding holds EMPTY cells): the kernels form a
     cell's index as (iy << row_shift) + ix, one instruction (round 1 stored 8x8-cell tiles: ten per lookup with a
@@ -67,7 +90,6 @@ def pitch_cells(a, nx, ny):
 # ------------------------------------------------------------------------------------------------
 # grid index of a drivable mesh: built by the library's host code (csrc/tde_gridbuild.h)
 # ------------------------------------------------------------------------------------------------
-CLEARANCE_UNIT = 0.125   # metres per count of the clearance field (TDE_CLEARANCE_UNIT)
 SUB = 4                  # a MIXED cell carries SUB x SUB sub-cell classes (TDE_CELL_SUB)
 
 
@@ -284,8 +306,8 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
     lights = lights or [None] * len(meshes)
     stop_all, phase_all = [], []
     maps = np.zeros(len(meshes), dtype=_abi.MAP_DTYPE)
-    tri_all, word_all, rec_all, cls2_all, sub_all = [], [], [], [], []
-    tri_base = cell_base = rec_base = cls2_base = 0
+    tri_all, word_all, rec_all, cls2_all, sub_all, coarse_all = [], [], [], [], [], []
+    tri_base = cell_base = rec_base = cls2_base = coarse_base = 0
     for m, tri in enumerate(meshes):
         tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
         # the kernels see fp32 vertices: index the fp32-rounded mesh
@@ -303,7 +325,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
                 phase_all.append((cycle, sum(1 << int(i) for i in red)))
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
                    tri_base, len(tri), len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle,
-                   row_shift_of(g["nx"]), cls2_base, rec_base, (0, 0, 0))
+                   row_shift_of(g["nx"]), cls2_base, rec_base, coarse_base, (0, 0))
         # cell word = class | count << 2 | first record << 10: the count of a MIXED cell is the length of its candidate list
         # (records from the map's rec_base + first on), that of a FULL / EMPTY cell its clearance (TDE_CLEARANCE_UNITs, rounded
         # down): every point within that distance of ANY point of the cell lies in a cell of the same class - the rasteriser
@@ -315,6 +337,9 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         c2, ntile = class_tiles(g["cell_class"], g["nx"], g["ny"])
         cls2_all.append(c2)
         cls2_base += ntile
+        cb, nline = coarse_tiles(g["cell_class"], g["cell_count"], g["nx"], g["ny"])
+        coarse_all.append(cb)
+        coarse_base += nline
         tri_all.append(tri32.reshape(-1, 6))
         tri_base += len(tri)
         cell_base += (1 << row_shift_of(g["nx"])) * g["ny"]
@@ -363,10 +388,12 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         replay_states[i, :len(r)] = r
     rec_cat = np.concatenate(rec_all, 0) if rec_base else np.zeros((1, 12), np.float32)
     arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_word=np.concatenate(word_all), cell_tri=rec_cat,
-                  cell_cls2=np.concatenate(cls2_all), cell_sub=np.concatenate(sub_all),
+                  cell_cls2=np.concatenate(cls2_all), cell_sub=np.concatenate(sub_all), cell_coarse=np.concatenate(coarse_all),
                   scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states,
                   stoplines=np.asarray(stop_all, dtype=_abi.STOPLINE_DTYPE) if stop_all
                   else np.zeros(1, _abi.STOPLINE_DTYPE),
                   phases=np.asarray(phase_all, dtype=_abi.PHASE_DTYPE) if phase_all else np.zeros(1, _abi.PHASE_DTYPE))
-    ints = dict(n_maps=len(meshes), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT)
+    large = bool((maps["nx"].astype(np.int64) * maps["ny"]).max() > LARGE_GRID_CELLS)
+    ints = dict(n_maps=len(meshes), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT,
+                hints=_abi.WORLD_LARGE_GRID if large else 0)
     return World(arrays, ints, threshold)
