@@ -218,6 +218,15 @@ def test_world_with_background_traffic(tmp_path):
     w4 = world_from_waypoint_suite(data, agents_per_env=4, background=str(tmp_path))
     sp4 = w4.arrays["spawn"].reshape(-1, 4)[0]
     assert list(sp4["present"]) == [1, 1, 1, 1] and np.allclose(sp4["x"][2:], [120.0, 0.0])
+    # more scenario agents than NPC slots (the reference assembles up to ~100 agents, gym_env.py:216-237): dropped LOUDLY
+    many = WaypointSuite(locations=["carla_Town03"], waypoint_suite=[[[0.0, 0.0], [15.0, 0.0], [30.0, 0.0]]],
+                         scenarios=[Scenario(agent_states=[[20.0 + 8 * k, 0.0, 0.0, 3.0] for k in range(5)],
+                                             agent_attributes=[[4.0, 1.9, 1.5]] * 5, recurrent_states=[[0] * 132] * 5)],
+                         car_sequence_suite=[None])
+    import pytest
+    with pytest.warns(UserWarning, match="5 non-ego agents but only 3 NPC slots"):
+        wm = world_from_waypoint_suite(many, agents_per_env=4)
+    assert list(wm.arrays["spawn"].reshape(-1, 4)[0]["present"]) == [1, 1, 1, 1]
     # no file for the town -> unchanged world; ego_only -> the ego alone
     w0 = world_from_waypoint_suite(data, agents_per_env=8, background=lambda loc: None)
     assert list(w0.arrays["spawn"].reshape(-1, 8)[0]["present"][:3]) == [1, 1, 0]
