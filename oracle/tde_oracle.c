@@ -614,7 +614,9 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
         if (!present[a]) continue;
         float acc = 0.0f, beta = 0.0f;
         if (a == 0) { acc = a_acc; beta = a_steer; }
-        else if (F & TDE_F_NPC)
+        else if ((F & TDE_F_NPC) && k > 1)
+            /* (k == 1, the first step of an episode: the NPCs coast with the zero action - the controller reads the scene of
+             * the previous step, which a fresh episode does not have) */
             tde_npc_action(cfg, w, A, a, px, py, pc, ps, pv, L, W, present, st->vdes[g0 + a], spawn[a].route,
                            spawn[a].route_n, st->route_wp[g0 + a], lights_map, red_now, &acc, &beta);
         float nx = px[a], ny = py[a], np_ = pp[a], nv = pv[a];

@@ -21,11 +21,12 @@ ap.add_argument("--agents", type=int, default=32)
 ap.add_argument("--launches", type=int, default=40)
 ap.add_argument("--stack", type=int, default=1)
 ap.add_argument("--lights", action="store_true")
+ap.add_argument("--cell", type=float, default=0.25, help="grid cell edge of the world's offroad index [m]")
 ap.add_argument("--town", action="store_true", help="the 1 km x 1 km town map (synth.synthetic_town) instead of the junction maps")
 args = ap.parse_args()
 B, A, ns = args.envs, args.agents, args.stack
 dev = torch.device("cuda:0")
-world = synthetic_town(n_scn=256, A=A, seed=0) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell)
 dw = world.to_device(dev)
 flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0)
 cfg = _abi.default_config(seed=1, distance_cutoff=0.25, flags=flags)

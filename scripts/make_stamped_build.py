@@ -109,10 +109,10 @@ def patch_trio(s):
     # ---- driver
     k = sub(k, "        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];",
             "        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];")
-    k = sub(k, "                if (F & TDE_F_NPC) {\n                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;",
-            "                tde_mark(&stl, 0);\n                if (F & TDE_F_NPC) {\n                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;")
-    k = sub(k, "                                  cx.g_far, red_gap, na, nb);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                nx = ag.x;",
-            "                                  cx.g_far, red_gap, na, nb, &stl);\n                    if (npc) { acc = na; beta = nb; }\n                }\n                tde_mark(&stl, 3);\n                nx = ag.x;")
+    k = sub(k, "                if (F & TDE_F_NPC) {\n                    // The controller runs in the first pass only.",
+            "                tde_mark(&stl, 0);\n                if (F & TDE_F_NPC) {\n                    // The controller runs in the first pass only.")
+    k = sub(k, "                                      cx.g_far, red_gap, na, nb);\n                    }\n                    if (npc && k > 1) { acc = na; beta = nb; }\n                }\n                nx = ag.x;",
+            "                                      cx.g_far, red_gap, na, nb, &stl);\n                    }\n                    if (npc && k > 1) { acc = na; beta = nb; }\n                }\n                tde_mark(&stl, 3);\n                nx = ag.x;")
     k = sub(k, "                switched = false;\n                nwp = ag.route_wp;", "                tde_mark(&stl, 4);\n                switched = false;\n                nwp = ag.route_wp;")
     k = sub(k, "                sincos_f32(npsi, ns, nc);\n                TDE_PROBE(TDE_DUMMY_D, nx);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n",
             "                sincos_f32(npsi, ns, nc);\n                tde_mark(&stl, 5);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n                tde_mark(&stl, 6);\n")
@@ -155,21 +155,25 @@ def patch_step3(s):
             "        tde_mark(&stl, 1);\n        if (live) {\n            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117")
     k = sub(k, "        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n",
             "        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);\n        tde_mark(&stl, 2);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(&stl, 3);\n")
-    k = sub(k, "        lds_barrier();                                       // A: the judges' masks are published\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;",
-            "        tde_mark(&stl, 6);\n        lds_barrier();                                       // A: the judges' masks are published\n        tde_mark(&stl, 4);\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        bool respawned = false;")
-    k = sub(k, "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx, cfg.flags);\n",
-            "        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx, cfg.flags);\n        tde_mark(&stl, 5);\n        tde_flush(0, 7);\n")
+    k = sub(k, "        lds_barrier();                                       // A: the judges' masks are published\n",
+            "        tde_mark(&stl, 6);\n        lds_barrier();                                       // A: the judges' masks are published\n        tde_mark(&stl, 4);\n")
+    k = sub(k, "        if (respawned || switched || rebuilt || need_tg2) store_slot_cache(st, g, ag, er, cx, cfg.flags, respawned);\n",
+            "        if (respawned || switched || rebuilt || need_tg2) store_slot_cache(st, g, ag, er, cx, cfg.flags, respawned);\n        tde_mark(&stl, 5);\n        tde_flush(0, 7);\n")
     # judge C
-    k = sub(k, "        lds_barrier();                                       // B\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]",
-            "        tde_mark(&stl, 8);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 9);\n        er.steps += 1;\n        const int k = er.steps;\n        const float4 ra = sh.a[0][lane]")
-    k = sub(k, "        lds_barrier();                                       // A: off / tl masks are in\n",
-            "        tde_mark(&stl, 10);\n        lds_barrier();                                       // A: off / tl masks are in\n        tde_mark(&stl, 11);\n")
+    k = sub(k, "        lds_barrier();                                       // B\n        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_C2);",
+            "        tde_mark(&stl, 8);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 9);\n        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_C2);")
+    k = sub(k, "        RewardOut rw{};\n        const int ti0 = er.target_idx;\n        bool reach = false;\n",
+            "        tde_mark(&stl, 12);\n        RewardOut rw{};\n        const int ti0 = er.target_idx;\n        bool reach = false;\n")
+    k = sub(k, "        lds_barrier();                                       // A: off / tl masks and the ego's psi term are in\n",
+            "        tde_mark(&stl, 10);\n        lds_barrier();                                       // A: off / tl masks and the ego's psi term are in\n        tde_mark(&stl, 11);\n")
     # judge O
     k = sub(k, "        const float thr2 = thr2_of(cfg);\n        lds_barrier();                                       // B\n",
             "        const float thr2 = thr2_of(cfg);\n        tde_mark(&stl, 16);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 17);\n")
-    k = sub(k, "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n        lds_barrier();                                       // A\n",
-            "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n        tde_mark(&stl, 18);\n        lds_barrier();                                       // A\n        tde_mark(&stl, 19);\n        tde_flush(16, 20);\n")
-    k = sub(k, "        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);", "        tde_flush(8, 12);\n        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);")
+    k = sub(k, "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n",
+            "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n        tde_mark(&stl, 18);\n")
+    k = sub(k, "reward_psi_term(cold, lpsi, rc.x);\n        lds_barrier();                                       // A\n",
+            "reward_psi_term(cold, lpsi, rc.x);\n        tde_mark(&stl, 20);\n        lds_barrier();                                       // A\n        tde_mark(&stl, 19);\n        tde_flush(16, 21);\n")
+    k = sub(k, "        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);", "        tde_flush(8, 13);\n        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);")
     return s[:a] + k + s[b:]
 
 

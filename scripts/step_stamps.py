@@ -37,7 +37,8 @@ n = (B * A // 64) * N
 print(f"{e0.elapsed_time(e1) * 1e3 / N:.2f} us per step (stamped build)")
 names = {0: "D: entry -> state + cache loaded", 1: "D: controller", 2: "D: bicycle, route switch, sincos, rows", 3: "D: wait B",
          6: "D: next-step controller (action cache)", 4: "D: wait A", 5: "D: done test, re-spawn, stores",
-         8: "C: entry -> prologue done", 9: "C: wait B", 10: "C: collision + reward", 11: "C: wait A",
-         16: "O: entry -> prologue done", 17: "O: wait B", 18: "O: offroad + stop lines", 19: "O: wait A"}
+         8: "C: entry -> prologue done", 9: "C: wait B", 12: "C: collision", 10: "C: reward (dist, reach, smoothness)", 11: "C: wait A",
+         16: "O: entry -> prologue done", 17: "O: wait B", 18: "O: offroad + stop lines", 20: "O: the ego's psi term (float64 cosine)",
+         19: "O: wait A"}
 for i, nm in names.items():
     print(f"  {nm:42s} {out[i] / n:8.0f} ticks")

@@ -488,9 +488,9 @@ struct RewardOut {
 // The pieces of get_reward (:396-411), shared by reward_core (one step of one env) and by the three-role rollout
 // kernel's batched evaluation (judge C: a window of steps of an env at once, one lane per step).
 // dist_r (:402) and psi_r (:403): independent of the waypoint target.
+// dist_r (:402)
 template <typename CFG>
-TDE_DEV void reward_motion_terms(const CFG &cfg, const RewardBounds &rb, float lx, float ly, float lpsi, float x, float y,
-                                 float psi, double &dist_r, double &psi_r)
+TDE_DEV double reward_dist_term(const CFG &cfg, const RewardBounds &rb, float lx, float ly, float x, float y)
 {
     // math.dist(..) > cutoff (:402) decided in fp32 whenever that is safe: each fp32 difference is correctly rounded and
     // the sum of the two squares is within 4 * 2^-24 of the float64 value the reference forms from the same fp32 state, so
@@ -502,9 +502,20 @@ TDE_DEV void reward_motion_terms(const CFG &cfg, const RewardBounds &rb, float l
         const double ddx = (double)x - (double)lx, ddy = (double)y - (double)ly;
         moved = sqrt_gt(ddx * ddx + ddy * ddy, cfg.distance_cutoff, rb.cut);
     }
-    dist_r = moved ? cfg.distance_bonus : 0.0;
+    return moved ? cfg.distance_bonus : 0.0;
+}
+// psi_r (:403): the subtraction in fp32 tensor arithmetic, the cosine in float64
+template <typename CFG> TDE_DEV double reward_psi_term(const CFG &cfg, float lpsi, float psi)
+{
     const float dpsi = psi - lpsi;
-    psi_r = (1.0 - cos_heading_f64((double)dpsi)) * (-cfg.heading_penalty);
+    return (1.0 - cos_heading_f64((double)dpsi)) * (-cfg.heading_penalty);
+}
+template <typename CFG>
+TDE_DEV void reward_motion_terms(const CFG &cfg, const RewardBounds &rb, float lx, float ly, float lpsi, float x, float y,
+                                 float psi, double &dist_r, double &psi_r)
+{
+    dist_r = reward_dist_term(cfg, rb, lx, ly, x, y);
+    psi_r = reward_psi_term(cfg, lpsi, psi);
 }
 // check_reach_target (:391-394) for a target that exists (target_idx < n_wp)
 template <typename CFG>

@@ -267,15 +267,38 @@ TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, co
 // Philox blocks (counter words 0, 1) and every other lane block 0; lane a of the env computes block a - ONE evaluation -
 // and the words travel by wavefront shuffles (ds_bpermute): block 0 to every lane of the env, block 1 to its ego.  Same
 // counters, same words, same arithmetic behind them.
-template <int A, bool SPREAD = true>
-TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er)
+// The ego's start (set_start_pos, ref gym_env.py:351-367) from the episode's random words: a point on the first waypoint segment,
+// a speed in [0, 10), the scenario's start heading + normal(0, 0.1) (:359-361: Box-Muller on the shared log / sincos
+// specifications); with TDE_F_EGO_ONLY_ATTRS also its attributes (:192-198).  pose = (x, y, psi, v), attr = (len, wid, lr, -).
+TDE_DEV void ego_spawn(const tde_config &cfg, const Cold &w, int scn, const uint4 &r0, const uint4 &r1, float4 &pose, float4 &attr)
+{
+    const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
+    const double f = u01(r0.y);
+    const double sx = wp[0] + f * (wp[2] - wp[0]);
+    const double sy = wp[1] + f * (wp[3] - wp[1]);
+    const double speed = u01(r0.z) * 10.0;
+    const double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (double)normal_f32(r1.z, r1.w) * 0.1;
+    pose = make_float4((float)sx, (float)sy, (float)psi0, (float)speed);
+    attr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (cfg.flags & TDE_F_EGO_ONLY_ATTRS)
+        attr = make_float4((float)(u01(r0.w) * (5.5 - 4.8) + 4.8), (float)(u01(r1.x) * (2.2 - 1.8) + 1.8),
+                           (float)(u01(r1.y) * (0.97 - 0.82) + 0.82), 0.0f);
+}
+
+// (DRAWN: the env's Philox blocks 0 and 1 for this episode were drawn by the caller - the one-step three-role kernel draws them
+//  ahead of the barrier behind which it learns whether the env finished, off the launch's tail)
+template <int A, bool SPREAD = true, bool DRAWN = false>
+TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er,
+                        uint4 d0 = make_uint4(0, 0, 0, 0), uint4 d1 = make_uint4(0, 0, 0, 0), const float4 *pre_ego = nullptr)
 {
     uint32_t ep = (uint32_t)er.episode;
     const uint32_t ge = w.env_base + (uint32_t)e;       // global env index keys the stream
     const uint64_t seed = w.seed;
-    constexpr bool spread = SPREAD && A >= 8;
+    constexpr bool spread = (SPREAD && A >= 8) || DRAWN;
     uint4 r0, r1s = make_uint4(0, 0, 0, 0);
-    if constexpr (spread) {
+    if constexpr (DRAWN) {
+        r0 = d0; r1s = d1;
+    } else if constexpr (spread) {
         const uint4 mine = philox(seed, ge, ep, (uint32_t)a, 0x7DEu);
         const int first = (int)(threadIdx.x & 63) - a;   // the env's first lane in the wavefront
         auto block = [&](int k) {
@@ -302,20 +325,12 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
     if (a == 0) {
         uint4 r1 = r1s;
         if constexpr (!spread) r1 = philox(seed, ge, ep, 1u, 0x7DEu);
-        const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
-        double f = u01(r0.y);
-        double sx = wp[0] + f * (wp[2] - wp[0]);
-        double sy = wp[1] + f * (wp[3] - wp[1]);
-        double speed = u01(r0.z) * 10.0;
-        // start heading + normal(0, 0.1) (ref gym_env.py:359-361): Box-Muller on the shared log / sincos specifications
-        double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (double)normal_f32(r1.z, r1.w) * 0.1;
-        ag.x = (float)sx; ag.y = (float)sy; ag.psi = (float)psi0; ag.v = (float)speed;
+        float4 pose, attr;
+        if (pre_ego) { pose = pre_ego[0]; attr = pre_ego[1]; }
+        else ego_spawn(cfg, w, scn, r0, r1, pose, attr);
+        ag.x = pose.x; ag.y = pose.y; ag.psi = pose.z; ag.v = pose.w;
         ag.present = true; ag.route = -1; ag.replay = -1; ag.vdes = 0.0f;
-        if (cfg.flags & TDE_F_EGO_ONLY_ATTRS) {
-            ag.len = (float)(u01(r0.w) * (5.5 - 4.8) + 4.8);
-            ag.wid = (float)(u01(r1.x) * (2.2 - 1.8) + 1.8);
-            ag.lr = (float)(u01(r1.y) * (0.97 - 0.82) + 0.82);
-        }
+        if (cfg.flags & TDE_F_EGO_ONLY_ATTRS) { ag.len = attr.x; ag.wid = attr.y; ag.lr = attr.z; }
     }
     ag.inv_lr = 1.0f / ag.lr;
 }
@@ -324,10 +339,11 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
 // launch waits for: the spawn record carries the first route target (tde_spawn.tgx0 / tgy0) and the route / replay lengths, so
 // the only loads behind the scenario draw are the record itself, the scenario entry and - for the ego - its first waypoint
 // target: ONE round of independent loads instead of the chain record -> route table.  `want_map`: also the map descriptor.
-template <int A>
-TDE_DEV void respawn_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er, Ctx &cx, bool want_map)
+template <int A, bool DRAWN = false>
+TDE_DEV void respawn_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er, Ctx &cx, bool want_map,
+                          uint4 d0 = make_uint4(0, 0, 0, 0), uint4 d1 = make_uint4(0, 0, 0, 0), const float4 *pre_ego = nullptr)
 {
-    reset_lane<A>(cfg, w, e, a, ag, er);
+    reset_lane<A, true, DRAWN>(cfg, w, e, a, ag, er, d0, d1, pre_ego);
     const uint32_t F = cfg.flags;
     cx.tgx = cx.tgy = cx.tgx2 = cx.tgy2 = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0;
     cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
@@ -740,7 +756,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
         float na, nb;
         const float red_gap = (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
         npc_action<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
-        if (npc) { acc = na; beta = nb; }
+        if (npc && k > 1) { acc = na; beta = nb; }    // (first step of an episode: the NPCs coast, kFirstStepCoast below)
     }
 
     if (live) {
@@ -1008,6 +1024,10 @@ struct DuoShared {
     // three-role rollout kernel, judge C: the ego poses (x, y, psi, v) before / after the last up to A steps of every env
     // of the group, slot (env's first lane + step) - the reward arithmetic runs on a whole window at once (see there)
     float4 ring_pre[kWave], ring_post[kWave];
+    // one-step three-role kernel: Philox blocks 0 and 1 of every env's NEXT episode (what a re-spawn at this step would draw),
+    // written by the driver's lanes 0 and 1 of the env ahead of barrier A
+    uint4 draw[8][2];
+    float4 ego_next[8][2];               // ... and the ego's start (pose, attributes) computed from them by judge C (ego_spawn)
 };
 constexpr int kStopCache = 8;
 
@@ -1093,6 +1113,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             const int kn = (i + 1 < ro.K) ? i + 1 : i;
             const float2 act_next = acts[(int64_t)kn * LB + es];
             float nx, ny, npsi, nv, nc, ns;
+            float na = 0.0f, nb = 0.0f;
             int nwp, k, n_target = er.target_idx, n_reached = er.reached;
             bool switched, live;
             for (int pass = 0;; ++pass) {
@@ -1107,13 +1128,19 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 float acc = 0.0f, beta = 0.0f;
                 if (a == 0) { acc = act.x; beta = act.y; }
                 if (F & TDE_F_NPC) {
-                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
-                    const float red_gap =
-                        (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-                    float na, nb;
-                    npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
-                                  cx.g_far, red_gap, na, nb);
-                    if (npc) { acc = na; beta = nb; }
+                    // The controller runs in the first pass only.  A second pass means that an env of this wavefront finished
+                    // and its lanes were re-spawned: they are at the first step of their episode, where the NPCs coast (zero
+                    // action: the controller reads the scene of the previous step, which a fresh episode does not have), and
+                    // the other envs' actions are those of the first pass - nothing to recompute (rounds 1-3 repeated the
+                    // whole sweep here, on 7 % of the wave-steps).
+                    if (pass == 0) {
+                        const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
+                        const float red_gap =
+                            (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+                        npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
+                                      cx.g_far, red_gap, na, nb);
+                    }
+                    if (npc && k > 1) { acc = na; beta = nb; }
                 }
                 nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
                 if (live) {
@@ -1146,7 +1173,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     redc.invalidate();
                     sincos_f32(ag.psi, s0, c0);
-                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);
+                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges' pre-step rows of the new episode)
                     if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
                 }
             }
@@ -1292,6 +1319,14 @@ template <int N> TDE_DEV void dummy_valu(float seed)
 // (windowed reward, DPP collision prefilter) judge O's chain - four dependent cell-word loads per slot - is the longer one
 // of the two: (2, 0, 1) 2.93 us per step against (2, 1, 0) 3.00, (3, 0, 2) 2.93, (2, 0, 2) 2.99, (1, 0, 1) 2.99
 // (profiles/r02_d_ab_diet_steps.txt, tail)
+#ifndef TDE_STEP_PRIO_SWITCH    // one-step three-role kernel: priorities follow the critical path (driver -> judges -> driver)
+#define TDE_STEP_PRIO_SWITCH 1
+#endif
+#ifndef TDE_STEP_PRIO_D2        // ... behind barrier B: driver (next step's controller), judge C, judge O
+#define TDE_STEP_PRIO_D2 0
+#define TDE_STEP_PRIO_C2 3
+#define TDE_STEP_PRIO_O2 2
+#endif
 #ifndef TDE_SPRIO_C             // the one-step three-role kernel's judges (its driver: 2)
 #define TDE_SPRIO_C 0
 #define TDE_SPRIO_O 1
@@ -1359,6 +1394,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             const int p = i & 1, q = p ^ 1;
             const float2 act = sh.act[p][base];              // ego action of step i (judge O fetched it two steps ago)
             float nx, ny, npsi, nv, nc, ns;
+            float na = 0.0f, nb = 0.0f;
             int nwp, k;
             bool switched, live;
             for (int pass = 0;; ++pass) {
@@ -1373,13 +1409,19 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 float acc = 0.0f, beta = 0.0f;
                 if (a == 0) { acc = act.x; beta = act.y; }
                 if (F & TDE_F_NPC) {
-                    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
-                    const float red_gap =
-                        (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-                    float na, nb;
-                    npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
-                                  cx.g_far, red_gap, na, nb);
-                    if (npc) { acc = na; beta = nb; }
+                    // The controller runs in the first pass only.  A second pass means that an env of this wavefront finished
+                    // and its lanes were re-spawned: they are at the first step of their episode, where the NPCs coast (zero
+                    // action: the controller reads the scene of the previous step, which a fresh episode does not have), and
+                    // the other envs' actions are those of the first pass - nothing to recompute (rounds 1-3 repeated the
+                    // whole sweep here, on 7 % of the wave-steps).
+                    if (pass == 0) {
+                        const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
+                        const float red_gap =
+                            (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+                        npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
+                                      cx.g_far, red_gap, na, nb);
+                    }
+                    if (npc && k > 1) { acc = na; beta = nb; }
                 }
                 nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
                 if (live) {
@@ -1407,7 +1449,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     redc.invalidate();
                     sincos_f32(ag.psi, s0, c0);
-                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);
+                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges' pre-step rows of the new episode)
                     if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
                 }
             }
@@ -1643,6 +1685,9 @@ TDE_DEV void load_next_target(const Cold &w, const Agent &ag, int route_n, float
 }
 
 constexpr uint32_t kSlotKeyFlags = TDE_F_NPC | TDE_F_REPLAY;   // part of a slot entry's key (store_slot_cache)
+// key bit: the entry's second target (tgx2, tgy2) has not been fetched yet - a re-spawn leaves that dependent look-up
+// (spawn record -> route table) to the next launch's driver, which has idle time behind barrier B; not part of the comparison
+constexpr int kSlotTg2Later = 1 << 29;
 
 // key word of a slot entry (tde_slot_cache.key)
 TDE_DEV int slot_key(const Agent &ag, uint32_t F)
@@ -1656,7 +1701,7 @@ TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_
                              bool want_map, bool &rebuilt)
 {
     const uint32_t F = cfg.flags;
-    const bool hit = !valid || (s0.x == er.scn && s0.y == slot_key(ag, F));
+    const bool hit = !valid || (s0.x == er.scn && (s0.y & ~kSlotTg2Later) == slot_key(ag, F));
     rebuilt = !hit;
     cx.wtx = cx.wty = 0.0; cx.n_wp = 0;                   // (the ego's target is judge C's business)
     cx.tgx2 = cx.tgy2 = 0.0f;
@@ -1683,33 +1728,28 @@ TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_
 
 // (the route / replay ids of an entry are those load_ctx found under the NPC / REPLAY flags of the launch that wrote it: the
 //  two flag bits are part of the key, so a caller that switches them between launches gets a rebuilt entry, not a stale one)
-TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, const EnvRegs &er, const Ctx &cx, uint32_t F)
+TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, const EnvRegs &er, const Ctx &cx, uint32_t F,
+                              bool tg2_later = false)
 {
     static_assert(sizeof(tde_slot_cache) == 32, "two 16-byte words per slot");
     int4 *sc4 = reinterpret_cast<int4 *>(st.slot_cache + g);
-    sc4[0] = make_int4(er.scn, slot_key(ag, F), __float_as_int(cx.tgx), __float_as_int(cx.tgy));
+    sc4[0] = make_int4(er.scn, slot_key(ag, F) | (tg2_later ? kSlotTg2Later : 0), __float_as_int(cx.tgx), __float_as_int(cx.tgy));
     sc4[1] = make_int4((int)((uint32_t)(ag.route + 1) | ((uint32_t)cx.route_n << TDE_CACHE_ID_BITS)),
                        (int)((uint32_t)(ag.replay + 1) | ((uint32_t)cx.replay_len << TDE_CACHE_ID_BITS)),
                        __float_as_int(cx.tgx2), __float_as_int(cx.tgy2));
 }
 
 // What a stored NPC action depends on besides the state it was computed from: the feature flags the controller sees and its
-// constants.  12 bits of a hash of them ride in the key entry of the action cache above the step counter (tde_act_cache), so a
-// caller that changes TDE_F_TRAFFIC_LIGHTS / TDE_F_NPC / TDE_F_REPLAY or an npc_* constant between two launches gets the
-// actions recomputed in the next launch's prologue instead of replayed.  Wave-uniform: scalar ALU only.
-TDE_DEV int act_key_steps(const tde_config &cfg, int steps)
-{
-    uint32_t h = cfg.flags & (TDE_F_NPC | TDE_F_REPLAY | TDE_F_TRAFFIC_LIGHTS);
-    const float c[10] = {cfg.npc_k_steer, cfg.npc_k_speed, cfg.npc_gap_s0, cfg.npc_cone_k, cfg.npc_lane_half, cfg.npc_reach,
-                         cfg.npc_max_accel, cfg.npc_max_steer, cfg.npc_cone_range, cfg.dt};
-#pragma unroll
-    for (int i = 0; i < 10; ++i) h = (h ^ __float_as_uint(c[i])) * 0x9E3779B1u;
-    return (int)(((uint32_t)steps & 0xFFFFFu) | (h & 0xFFF00000u));
-}
+// constants.  12 bits of a hash of them (formed on the host by env_step_launch: act_cfg_hash) ride in the key entry of the
+// action cache above the step counter (tde_act_cache), so a caller that changes TDE_F_TRAFFIC_LIGHTS / TDE_F_NPC /
+// TDE_F_REPLAY or an npc_* constant between two launches gets the actions recomputed in the next launch's prologue instead of
+// replayed.  (Formed in the kernel - twenty dependent scalar instructions, twice - it cost 0.29 us of the 9 us launch:
+// profiles/r04_d_ab_step_act_key.txt.)
+TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(((uint32_t)steps & 0xFFFFFu) | (cfg_hash & 0xFFF00000u)); }
 
 template <int A, bool LIGHTS, bool OBS>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_step_trio_kernel(
-    tde_config cfg, tde_world w, tde_state st)
+    tde_config cfg, tde_world w, tde_state st, uint32_t act_hash)
 {
     __shared__ DuoShared sh;
     __shared__ Cold cold;
@@ -1761,6 +1801,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         Ctx cx;
         bool rebuilt;
         load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, ag, er, cx, LIGHTS, rebuilt);
+        const bool need_tg2 = !rebuilt && valid && (sc0.y & kSlotTg2Later) != 0;   // (left by the re-spawn of the previous launch)
         float c0, s0;
         const bool live = valid && ag.present;
         const int k = er.steps + 1;                                          // :116
@@ -1783,7 +1824,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                           red_gap, na, nb);
         };
         if (F & TDE_F_NPC) {
-            const bool stored = !npc || (akey.x == er.episode && akey.y == act_key_steps(cfg, er.steps));
+            // (k == 1, the first step of an episode: the NPCs coast - nothing to look up or compute)
+            const bool stored = !npc || k == 1 || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
             if (__ballot(!stored)) {
                 sincos_f32(ag.psi, s0, c0);
                 write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
@@ -1794,6 +1836,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             } else if (npc) {
                 acc = ac.x; beta = ac.y;
             }
+            if (npc && k == 1) acc = beta = 0.0f;
         }
         if (live) {
             bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117
@@ -1811,22 +1854,32 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         er.steps = k;
         write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);
         lds_barrier();                                       // B: rows of this step are in buffer 0
-        if (switched) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);   // (only stored: the entry after the new one)
+        // behind B the critical path is the judges' (stamps: C 4.8 k, O 4.1 k cycles against 3.2 k for the controller below):
+        // the driver steps back until their masks are in
+        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_D2);
+        if (switched && need_tg2) load_route_target(cold, ag, cx);               // (the look-ahead entry was not there yet: rare)
+        if (switched || need_tg2) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);   // (only stored: the entry after the current one)
         // the controller of the NEXT step runs here, beside the judges of this one: it needs the state after this step
         // only.  Speculative like the rollout kernels' driver: an env that turns out to have finished is re-spawned below
         // and the wavefront repeats it on the new rows.
         float na2 = 0.0f, nb2 = 0.0f;
         has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
         if ((F & TDE_F_NPC) && st.act_cache) controller(0, k + 1, na2, nb2);
+        constexpr bool kDrawAhead = A >= 8;                  // (judge C has drawn the next episode's random words: sh.draw)
         lds_barrier();                                       // A: the judges' masks are published
+        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(3);                 // the launch's tail: re-spawn and stores
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
         bool respawned = false;
         if (dn) {
+#ifdef TDE_EXP_NO_D_RESPAWN           // timing experiment (WRONG results)
+            if (false) {
+#else
             if (((dn >> base) & 1ull) && valid) {
-                respawn_lane<A>(cfg, cold, e, a, ag, er, cx, LIGHTS);
-                load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);     // (only stored)
-                respawned = true;
+#endif
+                respawn_lane<A, kDrawAhead>(cfg, cold, e, a, ag, er, cx, LIGHTS, sh.draw[lane / A][0], sh.draw[lane / A][1],
+                                            kDrawAhead ? sh.ego_next[lane / A] : nullptr);
+                respawned = true;                                             // (its second route target: left to the next launch)
             }
             // The re-spawn path is the tail every launch waits for (1.9 % of the envs finish per step, 7 % of the wavefronts
             // hold one): the next step's controller is NOT recomputed here for the re-spawned envs - their action-cache
@@ -1836,12 +1889,12 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (!valid) return;
         store_agent_dynamic(st, g, ag);
         if (respawned) store_agent_static(st, g, ag);
-        if (respawned || switched || rebuilt) store_slot_cache(st, g, ag, er, cx, cfg.flags);
+        if (respawned || switched || rebuilt || need_tg2) store_slot_cache(st, g, ag, er, cx, cfg.flags, respawned);
         if (st.act_cache) {
             float2 *ap = reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1);
             ap[a] = make_float2(na2, nb2);
             if (a == 0)     // (re-spawn is per env: the ego lane's flag is the env's)
-                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(cfg, er.steps));
+                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));
         }
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================
@@ -1871,7 +1924,17 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 load_ego_target(cold, er, cx);
             }
         }
+        // What a re-spawn of this env would draw - the NEXT episode's Philox blocks 0 and 1, lanes 0 and 1 of the env, one
+        // evaluation each - goes to LDS here, in this judge's idle time ahead of barrier B: driver and judge C start their
+        // re-spawn paths (the tail every launch waits for) with the scenario index in hand instead of behind ten Philox rounds.
+        // (A judge that has seen the ego's infraction touching the spawn record ahead of barrier A - a software prefetch of
+        // what the re-spawn will load - made the launch 0.23 us LONGER: profiles/r04_j_ab_step_prefetch.txt.)
+        constexpr bool kDrawAhead = A >= 8;
+        const bool respawns = kDrawAhead && (F & TDE_F_AUTORESET) && (F & TDE_F_REWARD);
+        if (respawns && a < 2)
+            sh.draw[lane / A][a] = philox(cold.seed, cold.env_base + (uint32_t)es, (uint32_t)er.episode, (uint32_t)a, 0x7DEu);
         lds_barrier();                                       // B
+        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_C2);    // the longest chain behind B
         er.steps += 1;
         const int k = er.steps;
         const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
@@ -1882,24 +1945,52 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             hit = collide_rows<A>(&sh.a[0][base], &sh.b[0][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
         const unsigned long long hm = __ballot(hit);
         if (lane == 0) sh.hit_mask = hm;
+        // The ego's reward (R6 / R7 / R12).  Its float64 cosine (psi_reward, :403) is judge O's (it is the shorter of the two
+        // judges: stamps 5.1 k against 2.9 k cycles behind barrier B, profiles/r04_d_step_stamps.txt) and arrives through LDS at
+        // barrier A; the sum of :409-411 is formed here in the reference's order.
         RewardOut rw{};
         const int ti0 = er.target_idx;
+        bool reach = false;
         if (a == 0 && valid && (F & TDE_F_REWARD)) {
-            rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ra.x, ra.y, rc.x, rc.y, false, false, false, k,
-                             er.target_idx, er.reached, st.info != nullptr);
+            const RewardBounds rb = reward_bounds(cold);
+            rw.dist_r = reward_dist_term(cold, rb, lx, ly, ra.x, ra.y);
+            reach = ti0 < cx.n_wp && reward_reach(cold, rb, ra.x, ra.y, cx.wtx, cx.wty);
+            if (reach) { er.reached += 1; er.target_idx = ti0 + 1; }
+            if (st.info) {
+                rw.psi_smooth = (double)fabsf((lpsi - rc.x) / 0.1f);
+                rw.speed_smooth = (double)fabsf((lv - rc.y) / 0.1f);
+            }
             if (er.target_idx != ti0) load_ego_target(cold, er, cx);
         }
-        lds_barrier();                                       // A: off / tl masks are in
+        // The ego's start in the episode a re-spawn would open (its look-ups behind the scenario draw, the Gaussian heading
+        // noise: ~1.2 k cycles on ONE lane) is formed here, every step, in this judge's idle time ahead of barrier A - what is
+        // left on the re-spawn path, the tail every launch waits for, is the spawn records and the stores.
+        if (respawns && a == 0 && valid) {
+            const uint4 d0 = sh.draw[lane / A][0], d1 = sh.draw[lane / A][1];
+            float4 pose, attr;
+            ego_spawn(cfg, cold, (int)(((uint64_t)d0.x * (uint64_t)cold.n_scn) >> 32), d0, d1, pose, attr);
+            sh.ego_next[lane / A][0] = pose; sh.ego_next[lane / A][1] = attr;
+        }
+        lds_barrier();                                       // A: off / tl masks and the ego's psi term are in
+        if (a == 0 && valid && (F & TDE_F_REWARD)) {
+            rw.psi_r = reinterpret_cast<const double *>(sh.ring_pre)[lane];
+            rw.reward = reward_sum(cold, reach, rw.dist_r, rw.psi_r);
+        }
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
+#ifdef TDE_EXP_NO_C_RESPAWN           // timing experiment (WRONG results)
+        const bool respawned = false;
+#else
         const bool respawned = dn && ((dn >> base) & 1ull) && valid;
+#endif
         Agent ag;                                            // only filled (and used) when the env re-spawns
         ag.x = ra.x; ag.y = ra.y; ag.psi = rc.x; ag.v = rc.y;
         float oc = rb.x, os = rb.y;
         const int k_done = k;
         const int reached_out = er.reached;
         if (respawned) {
-            reset_lane<A>(cfg, cold, e, a, ag, er);
+            reset_lane<A, true, (A >= 8)>(cfg, cold, e, a, ag, er, sh.draw[lane / A][0], sh.draw[lane / A][1],
+                                          (A >= 8) ? sh.ego_next[lane / A] : nullptr);
             if (a == 0 && (F & TDE_F_REWARD)) {
                 cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
                 load_ego_target(cold, er, cx);
@@ -1969,6 +2060,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         const int k = st.steps[es] + 1;
         int4 e0 = make_int4(0, 0, 0, 0);
         if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) e0 = reinterpret_cast<const int4 *>(st.env_cache + es)[0];
+        float lpsi = 0.0f;                                   // the ego's heading before the step (:373), for its psi term
+        if (a == 0 && valid && (F & TDE_F_REWARD)) lpsi = st.psi[g];
         lds_barrier();                                       // cold is published
         tde_map m{};
         if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) {
@@ -1977,6 +2070,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         }
         const float thr2 = thr2_of(cfg);
         lds_barrier();                                       // B
+        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_O2);
         const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
         const bool live = rc.z != 0.0f;
         bool off = false, tl = false;
@@ -1985,6 +2079,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             tl = tl_violation(w, m, red_mask(w, m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
         const unsigned long long om = __ballot(off), tm = __ballot(tl);
         if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
+        // the ego's psi term for judge C (get_reward :403; ring_pre is the rollout kernel's, unused in a one-step launch)
+        if (a == 0 && valid && (F & TDE_F_REWARD)) reinterpret_cast<double *>(sh.ring_pre)[lane] = reward_psi_term(cold, lpsi, rc.x);
         lds_barrier();                                       // A
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
@@ -2444,6 +2540,23 @@ int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state
 
 // `load_slots`: the agent slots stepping on the device at the same time - the batch's own, or the whole batch's when this is one
 // of the sub-batches tde_env_step_render runs side by side (the choice of kernel form is a matter of load)
+// hash of what the NPC controller depends on besides the state (tde_act_cache; act_key_steps)
+static uint32_t act_cfg_hash(const tde_config &cfg)
+{
+#ifdef TDE_ACT_KEY_PLAIN          // (A/B builds: the round-3 key, the step counter alone)
+    return 0u;
+#endif
+    uint32_t h = cfg.flags & (TDE_F_NPC | TDE_F_REPLAY | TDE_F_TRAFFIC_LIGHTS);
+    const float c[10] = {cfg.npc_k_steer, cfg.npc_k_speed, cfg.npc_gap_s0, cfg.npc_cone_k, cfg.npc_lane_half, cfg.npc_reach,
+                         cfg.npc_max_accel, cfg.npc_max_steer, cfg.npc_cone_range, cfg.dt};
+    for (int i = 0; i < 10; ++i) {
+        uint32_t b;
+        memcpy(&b, &c[i], 4);
+        h = (h ^ b) * 0x9E3779B1u;
+    }
+    return h;
+}
+
 static int env_step_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream, int64_t load_slots)
 {
     int rc = check_env_args("tde_env_step", cfg, world, st);
@@ -2470,7 +2583,8 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     const bool want_trio = force == 3 || (force == 0 && load_slots <= 131072);
     if (trio_ok && want_trio) {
         const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-#define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st)
+        const uint32_t act_hash = act_cfg_hash(*cfg);
+#define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, act_hash)
 #define TDE_LAUNCH_STEP3_A(AA)                                                                       \
     if (st->obs) { if (lights) TDE_LAUNCH_STEP3(AA, true, true); else TDE_LAUNCH_STEP3(AA, false, true); } \
     else { if (lights) TDE_LAUNCH_STEP3(AA, true, false); else TDE_LAUNCH_STEP3(AA, false, false); }
