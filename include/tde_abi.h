@@ -16,7 +16,10 @@
  *   replay   pre-recorded NPC trajectory       (reference: replay_states/replay_mask, gym_env.py:275-283)
  *
  * Layout: struct-of-arrays, env-major.  Agent arrays have B*A elements, element (e,a) at e*A + a.
- * A must be a power of two, 1..64, so that an env never straddles a 64-lane wavefront.
+ * A must be a power of two, 1..128.  Up to 64 an env never straddles a 64-lane wavefront and every kernel form applies (the
+ * persistent rollout kernels, the three-role forms); A = 128 (the reference assembles up to ~100 agents per env,
+ * gym_env.py:216-237; pad with absent slots) spans two wavefronts of a workgroup: the one-role kernels' generic forms, which
+ * walk every row with the exact tests (same results, not tuned), and a rollout is a sequence of one-step launches.
  */
 #ifndef TDE_ABI_H
 #define TDE_ABI_H
@@ -28,7 +31,7 @@ extern "C" {
 #endif
 
 #define TDE_ABI_VERSION 9
-#define TDE_MAX_AGENTS 64
+#define TDE_MAX_AGENTS 128
 
 /* feature bits of tde_config.flags */
 #define TDE_F_NPC        (1u << 0)  /* heuristic NPC controller drives slots 1..A-1 (else they coast: zero action,

@@ -33,3 +33,11 @@ for W in junctions town; do
   python scripts/traffic_from_pmc.py $O/step_${W}_FETCH_SIZE $O/step_${W}_WRITE_SIZE env_step_trio_kernel 1 8192 $O/traffic_step_$W.json
 done
 ls $O
+# closed loop through a HIP graph (no host in the loop) with / without re-spawns, stamps of the three-role step kernel
+python scripts/ab_step.py $L > $O/ab_step.txt 2>&1; python scripts/ab_step.py --endless $L >> $O/ab_step.txt 2>&1
+python scripts/ab_step.py --town $L >> $O/ab_step.txt 2>&1; python scripts/ab_step.py --outputs $L >> $O/ab_step.txt 2>&1
+python scripts/ab_step.py --envs 1024 $L >> $O/ab_step.txt 2>&1; python scripts/ab_step.py --envs 4096 $L >> $O/ab_step.txt 2>&1
+grep -v amdgpu $O/ab_step.txt
+if [ -f ab/libS.so ]; then TDE_HIP_LIB=$PWD/ab/libS.so python scripts/step_stamps.py > $O/step_stamps.txt 2>&1; grep -v amdgpu $O/step_stamps.txt; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_step -o st -- python3 bench.py --mode step --steps 2000 --warmup 200 --no-cpu-baseline > $O/stats_step.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config5 -o st -- python3 bench.py --config 5 --streams 1 --steps 300 --warmup 30 --no-cpu-baseline > $O/stats5.log 2>&1

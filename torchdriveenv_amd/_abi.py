@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 TDE_ABI_VERSION = 9
-TDE_MAX_AGENTS = 64
+TDE_MAX_AGENTS = 128
 
 F_NPC = 1 << 0
 F_REPLAY = 1 << 1

@@ -59,11 +59,13 @@ template <int BLOCK>
 struct Tiles {
     float4 a[BLOCK];
     float4 b[BLOCK];
+    int wide_done[4];           // A > 64 (an env spans two wavefronts): the env's done flag, through LDS instead of a wave ballot
 };
 constexpr float kFar = 1e18f;
 
 template <int A> struct MaskOf { using type = uint32_t; };
 template <> struct MaskOf<64> { using type = unsigned long long; };
+template <> struct MaskOf<128> { using type = unsigned long long; };   // (A = 128 never builds a mask: the *_wide forms)
 TDE_DEV int lowest_bit(uint32_t m) { return __ffs((int)m) - 1; }
 TDE_DEV int lowest_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
 
@@ -294,7 +296,7 @@ TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agen
     uint32_t ep = (uint32_t)er.episode;
     const uint32_t ge = w.env_base + (uint32_t)e;       // global env index keys the stream
     const uint64_t seed = w.seed;
-    constexpr bool spread = (SPREAD && A >= 8) || DRAWN;
+    constexpr bool spread = (SPREAD && A >= 8 && A <= 64) || DRAWN;       // (A > 64: an env spans two wavefronts - no shuffles)
     uint4 r0, r1s = make_uint4(0, 0, 0, 0);
     if constexpr (DRAWN) {
         r0 = d0; r1s = d1;
@@ -549,6 +551,75 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
     return hit;
 }
 
+// ---- more than 64 slots per env (A = 128: the reference assembles up to ~100 agents, gym_env.py:216-237) -------------------
+// An env then spans two wavefronts of a 256-thread workgroup and the candidate masks of the sweeps above (one bit per row in
+// one or two registers) do not apply: these forms walk EVERY row with the exact tests - the very arithmetic of the tuned forms'
+// second phase, whose first phase only ever removes rows that the exact tests reject - so results are the same bits.  Generic,
+// not tuned: O(A) exact tests per slot (the one-role kernels only).
+TDE_DEV float npc_exact_gap(const tde_config &cfg, int i, int j, const Agent &ag, float cp, float sp, float hl_i, const float4 &pj,
+                            const float4 &qj)
+{
+    const float ex = pj.x - ag.x, ey = pj.y - ag.y;
+    float fj = ex * cp, t0 = ey * sp, lj = ey * cp, t1 = ex * sp;
+    fj = fj + t0; lj = lj - t1;
+    float hd = cp * qj.x;
+    t0 = sp * qj.y;
+    const float halfw = cfg.npc_lane_half + qj.w;
+    float g = hl_i + qj.z;
+    hd = hd + t0; t1 = cfg.npc_cone_k * fj; g = fj - g;
+    t1 = halfw + t1;
+    const float al = fabsf(lj);
+    const int inlane = __float_as_int(al - halfw), c1 = __float_as_int(al - t1), c2 = __float_as_int(fj - cfg.npc_cone_range),
+              c3 = __float_as_int(-0.5f - hd), c4 = j - i, ahead = __float_as_int(0.0f - fj);
+    const int tk = (((c1 & c2) & (c3 & c4)) | inlane) & ahead;
+    return tk < 0 ? g : 1e30f;
+}
+
+template <int A>
+TDE_DEV void npc_action_wide(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp, float sp,
+                             bool has_target, float tgx, float tgy, float red_gap, float &acc, float &beta)
+{
+    const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
+    if (!has_target) {
+        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
+        beta = 0.0f;
+        return;
+    }
+    const float hl_i = 0.5f * ag.len;
+    float gap = 1e30f;
+    for (int j = 0; j < A; ++j) {
+        const float4 pj = ra[j], qj = rb[j];
+        if (j != i) gap = fminf(gap, npc_exact_gap(cfg, i, j, ag, cp, sp, hl_i, pj, qj));
+    }
+    const float dx = tgx - ag.x, dy = tgy - ag.y;
+    const float fwd = dx * cp + dy * sp;
+    const float lat = dy * cp - dx * sp;
+    const float dist = sqrt_cr_f32(dx * dx + dy * dy);
+    const float sin_err = lat / fmaxf(dist, 1e-3f);
+    beta = (fwd < 0.0f) ? copysignf(smax, lat) : clampf(cfg.npc_k_steer * sin_err, -smax, smax);
+    gap = fminf(gap, red_gap);
+    const float vd = fminf(ag.vdes, sqrt_cr_f32(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
+    acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
+}
+
+template <int A>
+TDE_DEV bool collide_rows_wide(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s, float hl,
+                               float hw, float ri)
+{
+    bool hit = false;
+    if (live) {
+        for (int j = 0; j < A; ++j) {
+            const float4 pj = ra[j];
+            const float dx = pj.x - x, dy = pj.y - y, rr = ri + pj.z;
+            if (j != a && dx * dx + dy * dy < rr * rr) {           // (inside the sum of the padded circumradii: see collide_rows)
+                const float4 qj = rb[j];
+                hit = hit | obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
+            }
+        }
+    }
+    return hit;
+}
+
 // The same for 16 slots per env when the wavefront's lane l holds slot l % 16 of its env, i.e. an env is one 16-lane DPP
 // row (three-role kernels).  The circumradius test of a pair is symmetric - both lanes would compute the same bits - so
 // each lane tests only the eight slots AHEAD of it in the row (offsets 1..8, slot index mod 16) and hands the verdict to
@@ -755,7 +826,8 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     if (F & TDE_F_NPC) {
         float na, nb;
         const float red_gap = (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
-        npc_action<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+        if constexpr (A > 64) npc_action_wide<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, red_gap, na, nb);
+        else npc_action<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
         if (npc && k > 1) { acc = na; beta = nb; }    // (first step of an episode: the NPCs coast, kFirstStepCoast below)
     }
 
@@ -784,7 +856,9 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     __syncthreads();                                // every lane is done reading the pre-step tile
     write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
     __syncthreads();
-    const bool hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
+    bool hit;
+    if constexpr (A > 64) hit = collide_rows_wide<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
+    else hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
     // the next route waypoint is fetched while the offroad test runs
     if (switched) load_route_target(cold, ag, cx);
 
@@ -822,10 +896,19 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
         if (F & TDE_F_AUTORESET) {
             // wave ballot of the ego lanes' termination flags: the reset path is skipped by wavefronts in which no
             // env finished; otherwise each lane looks up the bit of its env's ego lane
-            const unsigned long long any = __ballot(done);
+            unsigned long long any;
+            bool mine;
+            if constexpr (A > 64) {                 // the env spans two wavefronts: its flag travels through LDS
+                if (a == 0) t.wide_done[tid / A] = done;
+                __syncthreads();
+                mine = t.wide_done[tid / A] != 0;
+                any = mine ? 1ull : 0ull;
+            } else {
+                any = __ballot(done);
+                mine = ((any >> ((tid & 63) - a)) & 1ull) != 0;
+            }
             if (any) {
-                const int lane = tid & 63;
-                if (((any >> (lane - a)) & 1ull) && valid) {
+                if (mine && valid) {
                     respawn_lane<A>(cfg, cold, e, a, ag, er, cx, true);
                     out.respawned = true;
                     live = ag.present;
@@ -2159,7 +2242,9 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
     t.b[tid] = make_float4(c1, s1, hl, hw);
     __syncthreads();
     const int base = tid - a;
-    const bool hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, X, Y, c1, s1, hl, hw, ri);
+    bool hit;
+    if constexpr (A > 64) hit = collide_rows_wide<A>(&t.a[base], &t.b[base], a, live, X, Y, c1, s1, hl, hw, ri);
+    else hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, X, Y, c1, s1, hl, hw, ri);
     if (valid) out[g] = hit ? 1 : 0;
 }
 
@@ -2411,6 +2496,8 @@ static int bad(const char *msg)
 }
 
 static bool pow2_le64(int A) { return A >= 1 && A <= TDE_MAX_AGENTS && (A & (A - 1)) == 0; }
+// (up to 64 slots an env lives inside one wavefront and every kernel form applies; 128 = TDE_MAX_AGENTS: the one-role kernels'
+//  generic forms only - TDE_DISPATCH_A128 - and a rollout is a sequence of one-step launches)
 
 #define TDE_DISPATCH_A(A, ...)                                  \
     switch (A) {                                                \
@@ -2422,6 +2509,8 @@ static bool pow2_le64(int A) { return A >= 1 && A <= TDE_MAX_AGENTS && (A & (A -
         case 32: { constexpr int kA = 32; __VA_ARGS__; } break; \
         case 64: { constexpr int kA = 64; __VA_ARGS__; } break; \
     }
+#define TDE_DISPATCH_A128(A, ...)                               \
+    if ((A) == 128) { constexpr int kA = 128; __VA_ARGS__; } else TDE_DISPATCH_A(A, __VA_ARGS__)
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + tde::kBlock - 1) / tde::kBlock); }
 
@@ -2457,10 +2546,10 @@ int tde_kinematics_step(int64_t n, float *x, float *y, float *psi, float *v, con
 int tde_compute_collision(int32_t B, int32_t A, const float *x, const float *y, const float *psi, const float *len,
                           const float *wid, const uint8_t *present, uint8_t *out, void *stream)
 {
-    if (!pow2_le64(A)) return bad("tde_compute_collision: A must be a power of two in [1,64]");
+    if (!pow2_le64(A)) return bad("tde_compute_collision: A must be a power of two in [1,128]");
     if (B <= 0) return 0;
     const unsigned nb = blocks_for((int64_t)B * A);
-    TDE_DISPATCH_A(A, tde::collide_kernel<kA, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
+    TDE_DISPATCH_A128(A, tde::collide_kernel<kA, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
                           B, const_cast<float *>(x), const_cast<float *>(y), const_cast<float *>(psi), (float *)nullptr,
                           (const float *)nullptr, len, wid, present, (const float *)nullptr, 0.0f, out));
     hipError_t e = hipGetLastError();
@@ -2471,10 +2560,10 @@ int tde_kin_collide_step(int32_t B, int32_t A, float *x, float *y, float *psi, f
                          const float *len, const float *wid, const uint8_t *present, const float *action, float dt,
                          uint8_t *collided, void *stream)
 {
-    if (!pow2_le64(A)) return bad("tde_kin_collide_step: A must be a power of two in [1,64]");
+    if (!pow2_le64(A)) return bad("tde_kin_collide_step: A must be a power of two in [1,128]");
     if (B <= 0) return 0;
     const unsigned nb = blocks_for((int64_t)B * A);
-    TDE_DISPATCH_A(A, tde::collide_kernel<kA, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
+    TDE_DISPATCH_A128(A, tde::collide_kernel<kA, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
                           B, x, y, psi, v, lr, len, wid, present, action, dt, collided));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_kin_collide_step", e);
@@ -2511,7 +2600,7 @@ int tde_waypoint_reward(const tde_config *cfg, int32_t n, const float *pre_x, co
 static int check_env_args(const char *fn, const tde_config *cfg, const tde_world *w, const tde_state *st)
 {
     if (!cfg || !w || !st) { snprintf(g_err, sizeof(g_err), "%s: NULL argument", fn); return (int)hipErrorInvalidValue; }
-    if (!pow2_le64(st->A)) { snprintf(g_err, sizeof(g_err), "%s: A must be a power of two in [1,64]", fn); return (int)hipErrorInvalidValue; }
+    if (!pow2_le64(st->A)) { snprintf(g_err, sizeof(g_err), "%s: A must be a power of two in [1,128]", fn); return (int)hipErrorInvalidValue; }
     if (w->A != st->A) { snprintf(g_err, sizeof(g_err), "%s: world.A (%d) != state.A (%d)", fn, w->A, st->A); return (int)hipErrorInvalidValue; }
     // sqrt_cr_f32 (the controller's braking-distance speed) is exact for arguments that are zero or in the normal fp32
     // range: amax times a length difference of metres is, for any sensible amax
@@ -2533,7 +2622,7 @@ int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state
     if (rc) return rc;
     if (st->B <= 0) return 0;
     const unsigned nb = blocks_for((int64_t)st->B * st->A);
-    TDE_DISPATCH_A(st->A, tde::env_reset_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, mask));
+    TDE_DISPATCH_A128(st->A, tde::env_reset_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, mask));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_reset", e);
 }
@@ -2607,7 +2696,7 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
         return eb == hipSuccess ? 0 : fail("tde_env_step", eb);
     }
 #define TDE_LAUNCH_STEP(L, O)                                                                                          \
-    TDE_DISPATCH_A(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                 \
+    TDE_DISPATCH_A128(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                 \
                               *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits))
     if (st->obs) {
         if (lights) { TDE_LAUNCH_STEP(true, true); } else { TDE_LAUNCH_STEP(false, true); }
@@ -2694,6 +2783,24 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (st->B <= 0 || ro->K <= 0) return 0;
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     if (ro->ldb != 0 && ro->ldb < st->B) return bad("tde_env_rollout: rollout.ldb must be 0 (= B) or >= B");
+    if (st->A > 64) {
+        // 128 slots per env: the persistent kernels keep an env inside one wavefront, so the K timesteps run as K launches of
+        // the one-step kernel's generic form, each reading its row of the action buffer and writing its rows of reward / done
+        const int64_t ldb = ro->ldb ? ro->ldb : st->B;
+        const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+        const unsigned nb = blocks_for((int64_t)st->B * st->A);
+        tde_state s128 = *st;                                 // (a rollout does not maintain the closed loop's episode statistics)
+        s128.ep_return = nullptr; s128.ep_final = nullptr; s128.ep_final_len = nullptr;
+        for (int32_t i = 0; i < ro->K; ++i) {
+            const float *act = ro->actions + 2 * (int64_t)i * ldb;
+            float *rw = ro->reward ? ro->reward + (int64_t)i * ldb : nullptr;
+            uint8_t *dn = ro->done ? ro->done + (int64_t)i * ldb : nullptr;
+            if (lights) tde::env_step_kernel<128, true, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, s128, act, rw, dn);
+            else tde::env_step_kernel<128, false, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, s128, act, rw, dn);
+        }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
+    }
     // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
     // forces one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median
     // us per step (scripts/ab_rollout.py duo:... trio:..., profiles/r02_e_rollout_matrix.txt): three roles win at 8 and 16

@@ -313,6 +313,10 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent,
         if (J.ti + lane < J.n_wp) wp0 = reinterpret_cast<const double2 *>(J.wp)[J.ti + lane];
         if (lane < J.A) raw0 = agent.fetch(lane);
     };
+#ifndef TDE_RASTER_EARLY_OBJECTS
+#define TDE_RASTER_EARLY_OBJECTS 0     // 1: the object records' loads ahead of the pyramid (A/B: profiles/r04_raster_floor.md)
+#endif
+    if (TDE_RASTER_EARLY_OBJECTS) fetch_objects();
     // ---- base layer, 8x8 -> 4x4 -> 2x2 blocks -> pixels; lane b owns 8x8 block b ---------------------------------------
     {
         const int nbw = Wp >> 3, nblk = (Hp >> 3) * nbw, nb4w = Wp >> 2;      // nblk <= 64
@@ -474,7 +478,7 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent,
             raster_paint_box(p8, V, Wp, Pb, Qb, Xb, lane);
         }
     };
-    fetch_objects();
+    if (!TDE_RASTER_EARLY_OBJECTS) fetch_objects();
     if (J.lights) {
         for (int q0 = 0; q0 < J.m.n_stop; q0 += 64) {
             const int q = q0 + lane;
@@ -531,22 +535,31 @@ TDE_DEV void raster_view(RasterScratch &S, const RasterJob &J, AgentSrc &&agent,
         }
     }
     {
-        // NPC boxes (slots 1 .. A-1; A <= 64) in one pass with the ego, which is painted last: its lane is moved to the end of
-        // the paint order by handling bit 0 of the mask after the others
-        float x = 0.0f, y = 0.0f, cb = 1.0f, sb = 0.0f, hl = 0.0f, hw = 0.0f;
-        const bool pres = lane < J.A && agent.unpack(raw0, x, y, cb, sb, hl, hw);
-        bool keep = lane == 0 && pres;                                        // (an absent ego is not painted: the oracle skips it)
-        if (pres && lane > 0) {
-            const float dx = x - J.ex, dy = y - J.ey, rr = rview + (hl + hw);
-            keep = dx * dx + dy * dy <= rr * rr;
+        // NPC boxes (slots 1 .. A-1), 64 slots at a time, in one pass with the ego, which is painted last: its lane is moved to the
+        // end of the paint order by handling bit 0 of the first chunk's mask after everything else (the NPCs share one colour,
+        // so their order among themselves does not show)
+        float4 Pe = make_float4(0.0f, 0.0f, 0.0f, 0.0f), Qe = Pe;
+        uint32_t span_e = 255u;
+        bool keep_e = false;
+        for (int j0 = 0; j0 < J.A; j0 += 64) {
+            float x = 0.0f, y = 0.0f, cb = 1.0f, sb = 0.0f, hl = 0.0f, hw = 0.0f;
+            auto raw = raw0;
+            if (j0 > 0 && j0 + lane < J.A) raw = agent.fetch(j0 + lane);         // (more than 64 slots per env: a further fetch)
+            const bool pres = j0 + lane < J.A && agent.unpack(raw, x, y, cb, sb, hl, hw);
+            const bool ego = j0 == 0 && lane == 0;
+            bool keep = ego && pres;                                          // (an absent ego is not painted: the oracle skips it)
+            if (pres && !ego) {
+                const float dx = x - J.ex, dy = y - J.ey, rr = rview + (hl + hw);
+                keep = dx * dx + dy * dy <= rr * rr;
+            }
+            float4 P, Q;
+            box_coeffs(V, x, y, cb, sb, P, Q);
+            P.w = hl; Q.w = hw;
+            const uint32_t span = box_span(J, V, x, y, cb, sb, hl, hw);
+            paint_boxes(keep && !ego, P, Q, span, (uint32_t)TDE_LAYER_NPC);
+            if (j0 == 0) { Pe = P; Qe = Q; span_e = span; keep_e = keep && ego; }
         }
-        float4 P, Q;
-        box_coeffs(V, x, y, cb, sb, P, Q);
-        P.w = hl; Q.w = hw;
-        const uint32_t span = box_span(J, V, x, y, cb, sb, hl, hw);
-        const uint32_t lay = lane == 0 ? (uint32_t)ego_layer : (uint32_t)TDE_LAYER_NPC;
-        paint_boxes(keep && lane > 0, P, Q, span, lay);
-        paint_boxes(keep && lane == 0, P, Q, span, lay);
+        paint_boxes(keep_e, Pe, Qe, span_e, (uint32_t)ego_layer);
     }
 
     // ---- layers -> colours, streamed out --------------------------------------------------------------------------

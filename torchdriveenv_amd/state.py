@@ -19,7 +19,7 @@ class EnvState:
     """`arrays[name]` are numpy arrays (host; used with the CPU oracle in tests) or torch tensors (device)."""
 
     def __init__(self, B, A, device=None, with_info=True, with_obs=False, with_episode=None, with_cache=None):
-        assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
+        assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, f"A must be a power of two <= {_abi.TDE_MAX_AGENTS}"
         self.B, self.A, self.device = int(B), int(A), device
         with_episode = with_info if with_episode is None else with_episode
         shapes = _abi.state_shapes(B, A)

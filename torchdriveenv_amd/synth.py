@@ -91,10 +91,11 @@ def _attrs(rng):
     return (L, W, lr)
 
 
-def _junction_scenario(J, m, rng, A, n_parked):
+def _junction_scenario(J, m, rng, A, n_parked, min_gap=10.0):
     """one WaypointSuite-like scenario around junction `J` (a Junction or a TownJunction) of map `m`: the ego's waypoints
     through the junction, A - 1 NPCs on the lanes of its arms (>= 10 m apart at spawn, lane-following routes), the first
-    `n_parked` of them parked at the kerb as constant replay rows"""
+    `n_parked` of them parked at the kerb as constant replay rows.  `min_gap`: spacing of the spawns (3.4 m still separates the
+    two lanes of a road: the crowded scenes of tests/test_gpu_wide.py)"""
     n_arm = len(J.len)
     a_in = int(rng.integers(n_arm))
     a_out = int((a_in + 1 + rng.integers(n_arm - 1)) % n_arm)
@@ -129,7 +130,7 @@ def _junction_scenario(J, m, rng, A, n_parked):
         tt = np.clip((ap @ ab) / (ab @ ab), 0, 1)
         if np.hypot(*(ap - tt * ab)) < 12.0:
             continue
-        if any(np.hypot(*(pos - u)) < 10.0 for u in used):
+        if any(np.hypot(*(pos - u)) < min_gap for u in used):
             continue
         used.append(pos)
         parked = len(agents) < n_parked
@@ -247,7 +248,7 @@ class TownJunction:
 
 
 def synthetic_town(n_scn=256, A=16, seed=0, n_streets=10, spacing=100.0, ext=45.0, ds=1.5, n_parked=1, cell=0.25,
-                   threshold=0.5):
+                   threshold=0.5, min_gap=10.0):
     """ONE map of town size - n_streets^2 junctions on ~((n_streets - 1) * spacing + 2 * ext)^2 metres, >= 5e4 triangles at the
     defaults (1 km x 1 km, 100 junctions) - with `n_scn` scenarios spread over its interior junctions, each built like a
     synthetic_world scenario (A - 1 NPCs on the arms around its junction).  No traffic lights (the kernels walk all stop
@@ -259,5 +260,5 @@ def synthetic_town(n_scn=256, A=16, seed=0, n_streets=10, spacing=100.0, ext=45.
     scenarios = []
     for si in range(n_scn):
         i, j = inner[order[si % len(inner)]]
-        scenarios.append(_junction_scenario(TownJunction(town, i, j), 0, rng, A, n_parked))
+        scenarios.append(_junction_scenario(TownJunction(town, i, j), 0, rng, A, n_parked, min_gap))
     return assemble_world([town.mesh()], scenarios, A, threshold=threshold, cell=cell)

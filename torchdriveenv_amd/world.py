@@ -301,7 +301,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
                                          replay=[(x,y,psi,v)...] or None)
          ego_attr (L,W,lr)
     """
-    assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, "A must be a power of two <= 64"
+    assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, f"A must be a power of two <= {_abi.TDE_MAX_AGENTS}"
     # lights: per map None or dict(stoplines=[(x, y, psi, length, width, light)...], phases=[(n_steps, red_lights)...])
     lights = lights or [None] * len(meshes)
     stop_all, phase_all = [], []
