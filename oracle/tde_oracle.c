@@ -108,19 +108,35 @@ static inline float tde_clampf(float v, float lo, float hi)
 /*     a, beta = action; v += a*dt; x += v*cos(psi+beta)*dt; y += v*sin(psi+beta)*dt;               */
 /*     psi += v*(1/lr)*sin(beta)*dt; psi = (pi + psi) % (2*pi) - pi.   left_handed=False (gym_env.py:245). */
 /* ------------------------------------------------------------------------------------------------ */
+/* The two readings of upstream this restatement had to choose between (torchdrivesim's source is absent: SURVEY R4) are
+ * compile-time switches, spelled the same in csrc/tde_device.h (build both sides with the same -D and the parity suite holds):
+ *   TDE_KIN_EXPLICIT_EULER  0 (default): the position update uses the NEW speed v' = v + a*dt (semi-implicit Euler);
+ *                           1: it uses the old speed v (explicit Euler).
+ *   TDE_KIN_LEFT_HANDED     0 (default; KinematicBicycle() is built with its default arguments, gym_env.py:245): steering as
+ *                           given; 1: the steering angle is negated (a left-handed world frame).
+ * Not switchable because it needs a quantity the env does not pass: steering as a front-wheel angle delta with
+ * beta = atan(lr / (lf + lr) * tan(delta)) - the env hands over rear_axis_offset only (gym_env.py:246). */
+#ifndef TDE_KIN_EXPLICIT_EULER
+#define TDE_KIN_EXPLICIT_EULER 0
+#endif
+#ifndef TDE_KIN_LEFT_HANDED
+#define TDE_KIN_LEFT_HANDED 0
+#endif
 TDE_EXPORT void tde_oracle_bicycle(float *x, float *y, float *psi, float *v, float lr, float a, float beta, float dt)
 {
+    if (TDE_KIN_LEFT_HANDED) beta = -beta;
     float v1 = *v + a * dt;
+    float vp = TDE_KIN_EXPLICIT_EULER ? *v : v1;
     float sn, cs;
     tde_oracle_sincosf(*psi + beta, &sn, &cs);
-    float x1 = *x + (v1 * cs) * dt;
-    float y1 = *y + (v1 * sn) * dt;
+    float x1 = *x + (vp * cs) * dt;
+    float y1 = *y + (vp * sn) * dt;
     float sb, cb;
     tde_oracle_sincosf(beta, &sb, &cb);
     (void)cb;
     float inv_lr = 1.0f / lr;                      /* one rounding of the reciprocal, then products: the kernels keep
                                                     * inv_lr per agent instead of dividing every step */
-    float p1 = *psi + ((v1 * inv_lr) * sb) * dt;
+    float p1 = *psi + ((vp * inv_lr) * sb) * dt;
     p1 = tde_pymodf(TDE_PI_F + p1, TDE_TWO_PI_F) - TDE_PI_F;
     *x = x1; *y = y1; *psi = p1; *v = v1;
 }

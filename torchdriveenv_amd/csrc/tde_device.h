@@ -136,15 +136,25 @@ TDE_DEV float sqrt_cr_f32(float x)
 // R4: KinematicBicycle.step — called through simulator.step(action), ref gym_env.py:117; model built at :245-247.
 // `inv_lr` = 1.0f / rear_axis_offset, one correctly rounded division per agent and episode instead of one per step (the
 // persistent kernels keep it in a register; the oracle forms the same product).
+// TDE_KIN_EXPLICIT_EULER / TDE_KIN_LEFT_HANDED: the two readings of upstream that SURVEY R4 lists as undecidable here, as
+// compile-time switches spelled like the oracle's (oracle/tde_oracle.c: tde_oracle_bicycle); defaults = the documented choice.
+#ifndef TDE_KIN_EXPLICIT_EULER
+#define TDE_KIN_EXPLICIT_EULER 0
+#endif
+#ifndef TDE_KIN_LEFT_HANDED
+#define TDE_KIN_LEFT_HANDED 0
+#endif
 TDE_DEV void bicycle(float &x, float &y, float &psi, float &v, float inv_lr, float a, float beta, float dt)
 {
+    if (TDE_KIN_LEFT_HANDED) beta = -beta;
     float v1 = v + a * dt;
+    const float vp = TDE_KIN_EXPLICIT_EULER ? v : v1;
     float sn, cs;
     sincos_f32(psi + beta, sn, cs);
-    float x1 = x + (v1 * cs) * dt;
-    float y1 = y + (v1 * sn) * dt;
+    float x1 = x + (vp * cs) * dt;
+    float y1 = y + (vp * sn) * dt;
     float sb = sin_small_f32(beta);                  // steering is bounded by 0.3 rad in the action space
-    float p1 = psi + ((v1 * inv_lr) * sb) * dt;
+    float p1 = psi + ((vp * inv_lr) * sb) * dt;
     p1 = pymodf_pos(kPi + p1, kTwoPi) - kPi;
     x = x1; y = y1; psi = p1; v = v1;
 }
