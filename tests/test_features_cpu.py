@@ -245,3 +245,26 @@ def test_vecenv_adapter_walks_the_sb3_interface():
     # BatchedWaypointEnv keeps the old entry points as delegations
     for name in ("step_async", "step_wait", "vec_step", "vec_reset", "as_vec_env"):
         assert callable(getattr(E.BatchedWaypointEnv, name))
+
+
+def test_lazy_terminal_mapping_builds_entries_on_demand():
+    """the per-step `terminal` mapping of the VecEnv adapter (env -> terminal_observation + Monitor's episode): entries are
+    formed when read, the mapping interface is what LazyInfos and ShardedBatchedEnv use (get / items / in / len)"""
+    import numpy as np
+
+    from torchdriveenv_amd.env import LazyInfos, LazyTerminal
+
+    idx = np.array([2, 5])
+    obs = np.arange(6, dtype=np.float32).reshape(2, 3)
+    t = LazyTerminal(idx, obs, np.array([1.23456789, -2.0]), np.array([7, 9]), 0.5)
+    assert len(t) == 2 and 5 in t and 3 not in t and t.get(3) is None and sorted(t.keys()) == [2, 5]
+    e = t[5]
+    assert np.array_equal(e["terminal_observation"], obs[1]) and e["episode"] == {"r": -2.0, "l": 9, "t": 0.5}
+    assert t.get(2)["episode"]["r"] == 1.234568                       # Monitor rounds the return to 6 digits
+    assert dict(t.items()).keys() == {2, 5}
+    with __import__("pytest").raises(KeyError):
+        t[4]
+    infos = LazyInfos(8, {"offroad": np.zeros(8, np.float32)}, t)
+    assert infos[2]["episode"]["l"] == 7 and "terminal_observation" not in infos[3] and infos[2] is infos[2]
+    no_stats = LazyTerminal(idx, obs, None, None, 0.0)
+    assert "episode" not in no_stats[2]

@@ -471,6 +471,46 @@ class LazyInfos:
         return self._cols[key]
 
 
+class LazyTerminal:
+    """env -> the extra info entries of the envs that finished at a step (`terminal_observation`, Monitor's `episode`), as a
+    read-only mapping that builds an entry when it is asked for: at 8192 envs some env finishes at every step, and a dict per
+    finished env per step was a Python loop on the step's critical path."""
+
+    def __init__(self, idx, term_obs, ep_r, ep_l, t):
+        self._pos = {int(i): n for n, i in enumerate(idx)}
+        self._obs, self._r, self._l, self._t = term_obs, ep_r, ep_l, t
+
+    def get(self, i, default=None):
+        n = self._pos.get(i)
+        if n is None:
+            return default
+        ex = {"terminal_observation": self._obs[n]}
+        if self._r is not None:                                  # Monitor: round(sum(rewards), 6), len(rewards), elapsed
+            ex["episode"] = {"r": round(float(self._r[n]), 6), "l": int(self._l[n]), "t": self._t}
+        return ex
+
+    def __contains__(self, i):
+        return i in self._pos
+
+    def __len__(self):
+        return len(self._pos)
+
+    def __iter__(self):
+        return iter(self._pos)
+
+    def __getitem__(self, i):
+        ex = self.get(i)
+        if ex is None:
+            raise KeyError(i)
+        return ex
+
+    def keys(self):
+        return self._pos.keys()
+
+    def items(self):
+        return ((i, self.get(i)) for i in self._pos)
+
+
 class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
     """stable_baselines3 `VecEnv` over a BatchedWaypointEnv, replacing `SubprocVecEnv` + `Monitor` + `VecFrameStack` of the
     reference's trainer (ref examples/rl_training.py:121-129, 159-160): numpy actions in, (obs, rewards, dones, infos)
@@ -582,17 +622,27 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
             t = round(time.time() - self._t_start, 6)
             term_obs = obs_np[idx].copy()
             if auto:
-                # only the re-spawned envs are reset and re-rendered; only their first observations cross the bus
-                dmask = torch.from_numpy(done.astype(np.uint8)).to(env.torch_device, non_blocking=True)
-                new = env.reset(mask=dmask)
-                sel = new[torch.from_numpy(idx).to(env.torch_device)]
-                obs_np[idx] = sel.cpu().numpy()
-            for n, i in enumerate(idx):
-                ex = {"terminal_observation": term_obs[n]}
-                if ep_r is not None:                                 # Monitor: round(sum(rewards), 6), len(rewards), elapsed
-                    ex["episode"] = {"r": round(float(ep_r[n]), 6), "l": int(ep_l[n]), "t": t}
-                terminal[int(i)] = ex
+                # Only the re-spawned envs are reset and re-rendered; only their first observations cross the bus.  The reset
+                # mask is formed ON the device from the step's own outputs (no upload), the gathered rows land in a pinned
+                # staging buffer with an asynchronous copy, and the stream is synchronised once (round 3: a mask upload, a
+                # synchronous .cpu() and a dict per finished env at every step).
+                st = env.state
+                new = env.reset(mask=st["terminated"] | st["truncated"])
+                sel = new.index_select(0, torch.from_numpy(idx).to(env.torch_device, non_blocking=True))
+                pin = self._sel_staging(len(idx), sel)
+                pin.copy_(sel, non_blocking=True)
+                torch.cuda.current_stream(env.torch_device).synchronize()
+                obs_np[idx] = pin.numpy()
+            terminal = LazyTerminal(idx, term_obs, ep_r, ep_l, t)
         return obs_np, rew, done, LazyInfos(self.num_envs, cols, terminal)
+
+    def _sel_staging(self, n, like):
+        """pinned host rows for the first observations of the envs that re-spawned at this step (grown on demand)"""
+        cap = getattr(self, "_sel_pin", None)
+        if cap is None or cap.shape[0] < n:
+            rows = max(256, 1 << (int(n) - 1).bit_length())
+            self._sel_pin = cap = torch.empty((rows,) + tuple(like.shape[1:]), dtype=like.dtype, pin_memory=True)
+        return cap[:n]
 
     def step(self, actions):
         self.step_async(actions)
