@@ -89,6 +89,8 @@ def lib():
         L.tde_oracle_env_step.restype = C.c_int
         L.tde_oracle_env_rollout.argtypes = [cfgp, wp, sp, C.POINTER(_abi.TdeRollout)]
         L.tde_oracle_env_rollout.restype = C.c_int
+        L.tde_oracle_ego_infractions.argtypes = [cfgp, wp, sp, C.c_void_p]
+        L.tde_oracle_ego_infractions.restype = C.c_int
         L.tde_oracle_num_threads.restype = C.c_int
         L.tde_oracle_set_num_threads.argtypes = [C.c_int]
         L.tde_oracle_abi_version.restype = C.c_int
@@ -162,6 +164,13 @@ def env_reset(cfg, world, state, mask=None):
 
 def env_step(cfg, world, state):
     return lib().tde_oracle_env_step(C.byref(cfg), C.byref(world.host_struct()), C.byref(state.struct))
+
+
+def ego_infractions(cfg, world, state):
+    """float32 [B, 2]: the ego's offroad and collision MAGNITUDES of the current state (brute force over every triangle)"""
+    out = np.zeros((state.B, 2), np.float32)
+    assert lib().tde_oracle_ego_infractions(C.byref(cfg), C.byref(world.host_struct()), C.byref(state.struct), _p(out)) == 0
+    return out
 
 
 def env_rollout(cfg, world, state, actions):

@@ -842,6 +842,54 @@ TDE_EXPORT int tde_oracle_render_ego(const tde_config *cfg, const tde_world *w, 
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* Infraction MAGNITUDES of the ego (what info["offroad"] / info["collision"] hold in the reference,  */
+/* gym_env.py:427-428: simulator.compute_offroad() / compute_collision() for the exposed agent).       */
+/* PARITY UNPINNED (torchdrivesim absent); defined here:                                               */
+/*   offroad   = sum over the four corners of clamp(dist - threshold, min = 0), dist = distance of the   */
+/*               corner to the mesh (brute force over every triangle; the SQUARED distance under         */
+/*               offroad_threshold_squared), accumulated in fp32 in corner order FL, FR, RR, RL;         */
+/*   collision = number of other present agents whose box overlaps the ego's (strict SAT).              */
+/* out = float32 [B][2].                                                                              */
+/* ------------------------------------------------------------------------------------------------ */
+TDE_EXPORT int tde_oracle_ego_infractions(const tde_config *cfg, const tde_world *w, const tde_state *st, float *out)
+{
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int32_t e = 0; e < st->B; ++e) {
+        const int32_t A = st->A;
+        const int64_t g0 = (int64_t)e * A;
+        float omag = 0.0f, cmag = 0.0f;
+        if (st->present[g0]) {
+            float se, ce;
+            tde_oracle_sincosf(st->psi[g0], &se, &ce);
+            const float hl = 0.5f * st->len[g0], hw = 0.5f * st->wid[g0];
+            int n = 0;
+            for (int32_t j = 1; j < A; ++j) {
+                if (!st->present[g0 + j]) continue;
+                float sj, cj;
+                tde_oracle_sincosf(st->psi[g0 + j], &sj, &cj);
+                n += tde_oracle_obb_overlap(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj,
+                                            0.5f * st->len[g0 + j], 0.5f * st->wid[g0 + j]);
+            }
+            cmag = (float)n;
+            if (cfg->flags & TDE_F_OFFROAD) {
+                const tde_map *m = &w->maps[w->scn[st->scn[e]].map];
+                const float *tri = w->tri + 6 * (int64_t)m->tri_base;
+                float cx[4], cy[4];
+                tde_corners(st->x[g0], st->y[g0], ce, se, hl, hw, cx, cy);
+                for (int k = 0; k < 4; ++k) {
+                    const float d2 = tde_oracle_point_mesh_d2(cx[k], cy[k], tri, m->n_tri);
+                    const float dist = cfg->offroad_threshold_squared ? d2 : sqrtf(d2);
+                    omag = omag + fmaxf(dist - cfg->offroad_threshold, 0.0f);
+                }
+            }
+        }
+        out[2 * (int64_t)e] = omag;
+        out[2 * (int64_t)e + 1] = cmag;
+    }
+    return 0;
+}
+
 TDE_EXPORT int tde_oracle_num_threads(void)
 {
 #ifdef _OPENMP

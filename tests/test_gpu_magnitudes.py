@@ -1,0 +1,106 @@
+"""Infraction MAGNITUDES of the ego (tde_ego_infractions): what the reference's info dict holds under "offroad" / "collision"
+(ref gym_env.py:427-428: simulator.compute_offroad() / compute_collision() for the exposed agent; Monitor logs them,
+examples/rl_training.py:128).  Upstream's values are unpinned (torchdrivesim absent): the oracle defines them - sum over the ego's
+corners of clamp(distance to the mesh - threshold, 0), brute force over every triangle; number of agents the ego overlaps - and
+the kernel, which finds a corner's nearest triangle through the grid index (candidate lists, then a growing scan), must return
+the same bits, however far off the road the ego is."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle  # noqa: E402
+from tests.test_gpu_parity import dev  # noqa: E402
+from torchdriveenv_amd import _abi, ops  # noqa: E402
+from torchdriveenv_amd.state import EnvState  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _wander(world, cfg, B, A, steps, seed):
+    """B envs stepped `steps` times by the oracle with infractions that do not end the episode: egos end up anywhere"""
+    hs = EnvState(B, A)
+    oracle.env_reset(cfg, world, hs)
+    rng = np.random.default_rng(seed)
+    for _ in range(steps):
+        hs["action"][...] = np.stack([rng.uniform(-0.2, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        oracle.env_step(cfg, world, hs)
+    return hs
+
+
+@pytest.mark.parametrize("squared", [0, 1])
+def test_ego_infraction_magnitudes_bit_exact(small_world, squared):
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = small_world if not squared else synthetic_world(n_scn=8, A=16, seed=0, n_maps=2, threshold=float(np.sqrt(0.5)))
+    cfg = _abi.default_config(seed=3, flags=_abi.F_ALL & ~_abi.F_AUTORESET, terminated_at_infraction=0, max_steps=10_000,
+                              offroad_threshold_squared=squared)
+    B, A = 300, 16
+    dw = world.to_device(DEV)
+    ds = EnvState(B, A, device=DEV)
+    for steps in (15, 45):
+        hs = _wander(world, cfg, B, A, steps, seed=steps)
+        ds.load(hs.host())
+        want = oracle.ego_infractions(cfg, world, hs)
+        got = ops.ego_infractions(cfg, dw, ds).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+        off = hs["offroad"].reshape(B, A)[:, 0] > 0
+        assert np.array_equal(want[:, 0] > 0, off)                   # the magnitude is positive exactly where the mask is set
+        assert np.array_equal(want[:, 1] > 0, hs["collided"].reshape(B, A)[:, 0] > 0)
+    assert want[:, 0].max() > 20.0 and (want[:, 0] > 0).sum() > 50 and (want[:, 0] == 0).sum() > 20
+
+
+def test_ego_infraction_magnitudes_town_and_128_slots(town):
+    from torchdriveenv_amd.synth import synthetic_town
+
+    cfg = _abi.default_config(seed=5, flags=_abi.F_ALL & ~_abi.F_AUTORESET, terminated_at_infraction=0, max_steps=10_000)
+    for world, B, A in ((town, 96, 16), (synthetic_town(n_scn=4, A=128, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4), 16, 128)):
+        hs = _wander(world, cfg, B, A, 40, seed=A)
+        ds = EnvState(B, A, device=DEV)
+        ds.load(hs.host())
+        want = oracle.ego_infractions(cfg, world, hs)
+        got = ops.ego_infractions(cfg, world.to_device(DEV), ds).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (A, np.abs(got - want).max())
+        assert (want[:, 0] > 0).any()
+    assert want[:, 1].max() >= 1.0                                   # crowded scenes: the ego overlaps somebody
+
+
+def test_batched_env_info_magnitudes_equals_the_one_launch_step(small_world):
+    """BatchedWaypointEnv(info_magnitudes=True) - step without in-kernel re-spawn, tde_ego_infractions, masked reset - gives the
+    observations, rewards, flags and episodes of the one-launch step, and info["offroad"] / info["collision"] are the oracle's
+    magnitudes of the state the step left (the reference's info semantics) instead of 0 / 1"""
+    from torchdriveenv_amd.config import EnvConfig
+    from torchdriveenv_amd.env import BatchedWaypointEnv
+
+    B = 160
+    kw = dict(num_envs=B, agents_per_env=16, obs_mode="birdview", frame_stack=3)
+    plain = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, **kw)
+    mag = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, info_magnitudes=True, **kw)
+    hs = EnvState(B, 16)
+    cfg_na = _abi.TdeConfig.from_buffer_copy(plain.tde_cfg)
+    cfg_na.flags &= ~_abi.F_AUTORESET
+    oracle.env_reset(cfg_na, small_world, hs)
+    assert torch.equal(plain.reset(), mag.reset())
+    rng = np.random.default_rng(2)
+    seen = 0
+    for t in range(90):
+        act = np.stack([rng.uniform(-0.5, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        a = dev(act)
+        o1, r1, te1, tr1, i1 = plain.step(a)
+        o2, r2, te2, tr2, i2 = mag.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), t
+        hs["action"][...] = act
+        oracle.env_step(cfg_na, small_world, hs)
+        want = oracle.ego_infractions(cfg_na, small_world, hs)
+        assert np.array_equal(i2["offroad"].cpu().numpy().view(np.uint32), want[:, 0].view(np.uint32)), t
+        assert np.array_equal(i2["collision"].cpu().numpy().view(np.uint32), want[:, 1].view(np.uint32)), t
+        assert torch.equal(i1["offroad"] > 0, i2["offroad"] > 0) and torch.equal(i1["collision"] > 0, i2["collision"] > 0)
+        seen += int((want[:, 0] > 0).sum())
+        done = (hs["terminated"] | hs["truncated"]).astype(np.uint8)
+        if done.any():
+            oracle.env_reset(cfg_na, small_world, hs, done)
+    for k in ("x", "y", "psi", "v", "steps", "episode", "scn"):
+        assert torch.equal(plain.state[k], mag.state[k]), k
+    assert seen > 10 and int(plain.state["episode"].max()) > 1

@@ -5,7 +5,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(_PKG, "csrc", "tde_kernels.hip")]
 DEPS = SRC + [os.path.join(_PKG, "csrc", "tde_device.h"), os.path.join(_PKG, "csrc", "tde_raster.h"),
-              os.path.join(_PKG, "csrc", "tde_gridbuild.h"), os.path.join(_PKG, "..", "include", "tde_abi.h"),
+              os.path.join(_PKG, "csrc", "tde_gridbuild.h"), os.path.join(_PKG, "csrc", "tde_magnitudes.h"), os.path.join(_PKG, "..", "include", "tde_abi.h"),
               os.path.join(_PKG, "..", "include", "tde_hip.h")]
 OUT = os.path.join(_PKG, "libtde_hip.so")
 

@@ -2477,6 +2477,7 @@ void render_views_kernel(RenderArgs ra, int B)
 
 }  // namespace tde
 
+#include "tde_magnitudes.h"
 
 // ------------------------------------------------------------------------------------------------------------------
 // C-ABI
@@ -2921,6 +2922,18 @@ int tde_env_step_render(const tde_config *cfg, const tde_world *world, const tde
         }
     }
     return 0;
+}
+
+int tde_ego_infractions(const tde_config *cfg, const tde_world *world, const tde_state *st, float *out, void *stream)
+{
+    int rc = check_env_args("tde_ego_infractions", cfg, world, st);
+    if (rc) return rc;
+    if (!out) return bad("tde_ego_infractions: out is NULL");
+    if (st->B <= 0) return 0;
+    const unsigned nb = (unsigned)((st->B + (tde::kBlock / tde::kWave) - 1) / (tde::kBlock / tde::kWave));
+    tde::ego_infractions_kernel<<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_ego_infractions", e);
 }
 
 int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void *stream)

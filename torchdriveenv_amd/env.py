@@ -148,17 +148,22 @@ class _LazyInfo(dict):
     KEYS = ("offroad", "collision", "traffic_light_violation", "is_success")
     EXTRA = ("reached_waypoint_num", "psi_smoothness", "speed_smoothness", "psi_reward", "dist_reward")
 
-    def __init__(self, st, B, A):
+    def __init__(self, st, B, A, magnitudes=None):
         super().__init__()
         self._st, self._ego = st, slice(0, B * A, A)
         self._keys = self.KEYS + (self.EXTRA if st["info"] is not None else ())
+        self._mag = magnitudes                # float32 [B, 2] (offroad, collision) of tde_ego_infractions, or None: 0 / 1 indicators
 
     def _make(self, k):
         st = self._st
         bits = st["done_bits"]                # the ego's flags of this step, kept when the env re-spawned in place
         if k == "offroad":
+            if self._mag is not None:
+                return self._mag[:, 0]
             return ((bits >> 2) & 1).float() if bits is not None else st["offroad"][self._ego].float()
         if k == "collision":
+            if self._mag is not None:
+                return self._mag[:, 1]
             return ((bits >> 3) & 1).float() if bits is not None else st["collided"][self._ego].float()
         if k == "traffic_light_violation":
             return st["tl_violation"].float()
@@ -215,9 +220,14 @@ class BatchedWaypointEnv:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 10}   # ref gym_env.py:73-76
 
     def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
-                 frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0, binding="ext"):
+                 frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0, binding="ext",
+                 info_magnitudes=False):
         """binding: "ext" = launches go through the PyTorch-ROCm C++ extension (csrc/tde_torch_ext.cpp), "ctypes" = through
-        the ctypes binding of the same C-ABI (ops.py); both call the very same entry points of libtde_hip.so"""
+        the ctypes binding of the same C-ABI (ops.py); both call the very same entry points of libtde_hip.so.
+        info_magnitudes: info["offroad"] / info["collision"] hold the MAGNITUDES the reference reports there (ref
+        gym_env.py:427-428: sum over the ego's corners of clamp(distance - threshold, 0); number of agents the ego overlaps)
+        instead of 0 / 1 indicators.  They belong to the state BEFORE a finished env is re-spawned, so a step then is three
+        launches - the step without in-kernel re-spawn, tde_ego_infractions, the masked reset - instead of one."""
         validate(cfg)
         if binding not in ("ext", "ctypes"):
             raise ValueError("binding must be 'ext' or 'ctypes'")                                              # ref gym_env.py:79-80 and the fields this path rejects
@@ -266,6 +276,8 @@ class BatchedWaypointEnv:
         self.reward_range = (-float("inf"), float("inf"))           # ref gym_env.py:97
         self._vec = None
         self._h = None
+        self.info_magnitudes = bool(info_magnitudes)
+        self._mag = torch.zeros((self.num_envs, 2), dtype=torch.float32, device=self.torch_device) if info_magnitudes else None
         if binding == "ext":
             from . import _ext
             self._h = _ext.env_handle(self.tde_cfg, self.dworld, self.state)
@@ -301,6 +313,8 @@ class BatchedWaypointEnv:
         a = actions if torch.is_tensor(actions) and actions.device == self.torch_device else \
             torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device)
         a = a.to(torch.float32).reshape(self.num_envs, 2).contiguous()
+        if self.info_magnitudes:
+            return self._step_with_magnitudes(a)
         if self._h is not None:
             self._h.step(a, int(self.tde_cfg.flags))
         else:
@@ -318,6 +332,32 @@ class BatchedWaypointEnv:
         # uint8 0/1 flags seen as bool without a copy; info entries are only computed when they are read
         return (obs, st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool),
                 self.get_info())
+
+    def _step_with_magnitudes(self, a):
+        """step -> magnitudes of the ego's infractions on the state the step left -> re-spawn of the finished envs (masked reset,
+        their views re-rendered, their frame stacks restarted): the results of the one-launch step, plus info["offroad"] /
+        info["collision"] as the reference reports them"""
+        st = self.state
+        auto = self.auto_reset
+        flags = int(self.tde_cfg.flags) & ~_abi.F_AUTORESET
+        saved = self.tde_cfg.flags
+        self.tde_cfg.flags = flags
+        try:
+            if self._h is not None:
+                self._h.step(a, flags)
+            else:
+                ops.env_step(self.tde_cfg, self.dworld, st, action=a)
+            ops.ego_infractions(self.tde_cfg, self.dworld, st, self._mag)
+        finally:
+            self.tde_cfg.flags = saved
+        # (outputs of the step are kept by value: the reset below zeroes nothing of them but `obs` / counters move on)
+        reward, term, trunc = st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool)
+        info = _LazyInfo(st, self.num_envs, self.A, magnitudes=self._mag)
+        obs = self.get_obs()                                          # the frame of the state the step left (every view)
+        if auto:
+            # the finished envs re-spawn; only their views are rendered again, their frame stacks restart blank
+            obs = self.reset(mask=st["terminated"] | st["truncated"])
+        return obs, reward, term, trunc, info
 
     def rollout(self, actions):
         """K open-loop steps from a resident [K,B,2] action tensor -> (reward [K,B], done bits [K,B]).  (The Monitor-style
@@ -600,11 +640,12 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
         rew = out["reward"].copy()
         bits = out.get("done_bits")
         cols = {"TimeLimit.truncated": trunc & ~term}
+        mag = env._mag.cpu().numpy() if env.info_magnitudes else None   # (the reference's magnitudes: BatchedWaypointEnv(info_magnitudes=True))
         for k in self.info_keywords:
             if k == "offroad":
-                cols[k] = ((bits >> 2) & 1).astype(np.float32) if bits is not None else None
+                cols[k] = mag[:, 0].copy() if mag is not None else ((bits >> 2) & 1).astype(np.float32) if bits is not None else None
             elif k == "collision":
-                cols[k] = ((bits >> 3) & 1).astype(np.float32) if bits is not None else None
+                cols[k] = mag[:, 1].copy() if mag is not None else ((bits >> 3) & 1).astype(np.float32) if bits is not None else None
             elif k == "traffic_light_violation":
                 cols[k] = out["tl_violation"].astype(np.float32)
             elif k == "is_success":
