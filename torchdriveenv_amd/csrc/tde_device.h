@@ -137,7 +137,7 @@ TDE_DEV float sqrt_cr_f32(float x)
 // `inv_lr` = 1.0f / rear_axis_offset, one correctly rounded division per agent and episode instead of one per step (the
 // persistent kernels keep it in a register; the oracle forms the same product).
 // TDE_KIN_EXPLICIT_EULER / TDE_KIN_LEFT_HANDED: the two readings of upstream that SURVEY R4 lists as undecidable here, as
-// compile-time switches spelled like the oracle's (oracle/tde_oracle.c: tde_oracle_bicycle); defaults = the documented choice.
+// compile-time switches spelled like the CPU checker's (its bicycle restatement); defaults = the documented choice.
 #ifndef TDE_KIN_EXPLICIT_EULER
 #define TDE_KIN_EXPLICIT_EULER 0
 #endif

@@ -6,7 +6,7 @@
 //              mesh (0 inside); under tde_config.offroad_threshold_squared dist is the SQUARED distance, as the threshold then is;
 //   collision  number of other present agents whose box overlaps the ego's (strict SAT, the predicate of the collision mask).
 //
-// Upstream's values are unpinned here (torchdrivesim absent): the oracle defines them (tde_oracle_ego_infractions: brute force over
+// Upstream's values are unpinned here (torchdrivesim absent): the CPU checker defines them (its ego-infractions restatement: brute force over
 // every triangle) and this kernel returns the same bits.  Not on the step path: an env that wants magnitudes steps without
 // TDE_F_AUTORESET, calls this, then re-spawns the finished envs with tde_env_reset (BatchedWaypointEnv(info_magnitudes=True)).
 //
@@ -29,7 +29,7 @@ TDE_DEV float wave_min(float v)
 }
 
 // squared distance of the wave-uniform point (px, py) to the mesh of map m, exactly min over ALL its triangles of
-// point_tri_d2 (the oracle's tde_oracle_point_mesh_d2); -1 when the point lies in a FULL cell (within the threshold: the
+// point_tri_d2 (the CPU checker's brute-force minimum); -1 when the point lies in a FULL cell (within the threshold: the
 // caller's clamp is 0 and the exact value is not needed).  Every lane of the wavefront calls it.
 TDE_DEV float point_mesh_d2_wave(const tde_world &w, const tde_map &m, float px, float py, float band2, int lane)
 {
