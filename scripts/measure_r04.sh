@@ -41,3 +41,6 @@ grep -v amdgpu $O/ab_step.txt
 if [ -f ab/libS.so ]; then TDE_HIP_LIB=$PWD/ab/libS.so python scripts/step_stamps.py > $O/step_stamps.txt 2>&1; grep -v amdgpu $O/step_stamps.txt; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_step -o st -- python3 bench.py --mode step --steps 2000 --warmup 200 --no-cpu-baseline > $O/stats_step.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config5 -o st -- python3 bench.py --config 5 --streams 1 --steps 300 --warmup 30 --no-cpu-baseline > $O/stats5.log 2>&1
+# SQ counters of the headline rollout per 64-slot group and step (/ 512 000 = 2048 groups x 250 steps)
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/pmc_sq -o pmc --output-format csv -- python3 scripts/run_rollout.py 31 2 > $O/pmc_sq.log 2>&1
+python scripts/pmc_summary.py --div=512000 $O/pmc_sq | grep -A9 env_rollout_trio > $O/pmc_sq_per_group_step.txt 2>&1; cat $O/pmc_sq_per_group_step.txt

@@ -190,3 +190,43 @@ def test_town_config5_shape_8192x32_views_vs_oracle():
     want = oracle.render_ego(cfg, world, hs)
     got = img[:SUB].cpu().numpy()
     assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ"
+
+
+@pytest.mark.parametrize("team", ["trio", "duo"])
+def test_town_with_signalised_junctions_rollout_and_step(team):
+    """a town whose first two scenario junctions carry traffic lights: the LARGE_GRID forms of the kernels WITH the
+    traffic-light code (red stop lines as standing leaders, the ego's violation term, the lights in the birdview) == oracle"""
+    from torchdriveenv_amd.synth import synthetic_town
+
+    world = synthetic_town(n_scn=4, A=16, seed=3, n_streets=10, n_signals=2)          # full size: TDE_WORLD_LARGE_GRID is set
+    assert world.ints["hints"] & _abi.WORLD_LARGE_GRID and world.has_lights and world.arrays["maps"][0]["n_stop"] == 8
+    flags = _abi.F_ALL | _abi.F_TRAFFIC_LIGHTS
+    cfg = _abi.default_config(seed=61, distance_cutoff=0.25, flags=flags, max_steps=170)
+    B, A, K = 96, 16, 180
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    rng = np.random.default_rng(12)
+    actions = np.stack([rng.uniform(0.0, 0.8, (K, B)), rng.uniform(-0.03, 0.03, (K, B))], -1).astype(np.float32)
+    hr, hd = oracle.env_rollout(cfg, world, hs, actions)
+    _lib.kernel_override(rollout=team)
+    try:
+        dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+        torch.cuda.synchronize()
+    finally:
+        _lib.kernel_override()
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)) and np.array_equal(dd.cpu().numpy(), hd)
+    assert_state_equal(hs.host(), ds.host(), f"town with lights, rollout ({team})")
+    assert (hd & 16).any()                                            # some ego ran a red light on the way
+    for t in range(25):                                               # closed loop on from there (three-role step kernel with lights)
+        act = np.stack([rng.uniform(0.0, 0.8, B), rng.uniform(-0.03, 0.03, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+    assert_state_equal(hs.host(), ds.host(), "town with lights, closed loop")
+    want = oracle.render_ego(cfg, world, hs)
+    got = ops.render_ego(cfg, dw, ds).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert ((want[:, 0] == 255) & (want[:, 1] == 0) & (want[:, 2] == 0)).any() or ((want[:, 0] == 0) & (want[:, 1] == 255)).any()

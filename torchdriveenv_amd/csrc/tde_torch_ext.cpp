@@ -254,6 +254,15 @@ class EnvHandle {
         check_rc(tde_state_obs(&world_, &state_, p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_state_obs");
     }
 
+    // tde_ego_infractions: float32 [B, 2] = the ego's (offroad, collision) magnitudes of the state as it is (gym_env.py:427-428)
+    void ego_infractions(const at::Tensor &out, int64_t flags)
+    {
+        float *p = static_cast<float *>(const_cast<void *>(dev_ptr(out, at::kFloat, (int64_t)state_.B * 2, "out", dev_)));
+        cfg_.flags = static_cast<uint32_t>(flags);
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_ego_infractions(&cfg_, &world_, &state_, p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_ego_infractions");
+    }
+
     int64_t flags() const { return cfg_.flags; }
     int64_t num_envs() const { return state_.B; }
     int64_t agents_per_env() const { return state_.A; }
@@ -383,6 +392,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         .def("step_render", &EnvHandle::step_render, py::arg("action"), py::arg("flags"), py::arg("out"), py::arg("H"), py::arg("W"),
              py::arg("fov"), py::arg("n_stack"), py::arg("layers"), py::arg("phase"), py::arg("rflags"), py::arg("fresh"), py::arg("streams"))
         .def("state_obs", &EnvHandle::state_obs)
+        .def("ego_infractions", &EnvHandle::ego_infractions, py::arg("out"), py::arg("flags"))
         .def_property_readonly("flags", &EnvHandle::flags)
         .def_property_readonly("num_envs", &EnvHandle::num_envs)
         .def_property_readonly("agents_per_env", &EnvHandle::agents_per_env);

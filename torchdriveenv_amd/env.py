@@ -347,7 +347,10 @@ class BatchedWaypointEnv:
                 self._h.step(a, flags)
             else:
                 ops.env_step(self.tde_cfg, self.dworld, st, action=a)
-            ops.ego_infractions(self.tde_cfg, self.dworld, st, self._mag)
+            if self._h is not None:
+                self._h.ego_infractions(self._mag, flags)
+            else:
+                ops.ego_infractions(self.tde_cfg, self.dworld, st, self._mag)
         finally:
             self.tde_cfg.flags = saved
         # (outputs of the step are kept by value: the reset below zeroes nothing of them but `obs` / counters move on)

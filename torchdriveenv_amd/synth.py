@@ -246,13 +246,23 @@ class TownJunction:
             s_end = self.len[arm_out] - 30.0
         return np.concatenate([self.lane(arm_in, False, s_start, 7.0), self.lane(arm_out, True, 7.0, s_end)], 0)
 
+    def stoplines(self, light_main, light_side, s_stop=11.0):
+        """a stop line across the inbound lane of every arm; arms 0 / 1 (the street along u) obey `light_main`, 2 / 3 `light_side`"""
+        out = []
+        for arm in range(4):
+            pos, psi = self.pose(arm, False, s_stop, 0.5 * LANE)
+            out.append((float(pos[0]), float(pos[1]), psi, 1.0, LANE, light_main if arm < 2 else light_side))
+        return out
+
 
 def synthetic_town(n_scn=256, A=16, seed=0, n_streets=10, spacing=100.0, ext=45.0, ds=1.5, n_parked=1, cell=0.25,
-                   threshold=0.5, min_gap=10.0):
+                   threshold=0.5, min_gap=10.0, n_signals=0):
     """ONE map of town size - n_streets^2 junctions on ~((n_streets - 1) * spacing + 2 * ext)^2 metres, >= 5e4 triangles at the
     defaults (1 km x 1 km, 100 junctions) - with `n_scn` scenarios spread over its interior junctions, each built like a
-    synthetic_world scenario (A - 1 NPCs on the arms around its junction).  No traffic lights (the kernels walk all stop
-    lines of a map).  Deterministic in `seed`."""
+    synthetic_world scenario (A - 1 NPCs on the arms around its junction).  `n_signals` of the scenario junctions (the first ones in
+    scenario order) are signalised: a stop line per arm, main street / side street lights on one cycle for the whole map.  The
+    kernels walk ALL stop lines of a map for every ego and NPC, so keep it to a handful (<= 2 junctions stay inside the kernels'
+    8-line LDS cache); default none.  Deterministic in `seed`."""
     rng = np.random.default_rng(seed)
     town = Town(n_streets, spacing, ext, ds=ds)
     inner = [(i, j) for i in range(1, n_streets - 1) for j in range(1, n_streets - 1)]
@@ -261,4 +271,14 @@ def synthetic_town(n_scn=256, A=16, seed=0, n_streets=10, spacing=100.0, ext=45.
     for si in range(n_scn):
         i, j = inner[order[si % len(inner)]]
         scenarios.append(_junction_scenario(TownJunction(town, i, j), 0, rng, A, n_parked, min_gap))
-    return assemble_world([town.mesh()], scenarios, A, threshold=threshold, cell=cell)
+    lights = None
+    if n_signals:
+        assert 2 * n_signals <= 32, "light indices are bits of a 32-bit mask"
+        stop, main, side = [], [], []
+        for q in range(n_signals):
+            i, j = inner[order[q % len(inner)]]
+            stop += TownJunction(town, i, j).stoplines(2 * q, 2 * q + 1)
+            main.append(2 * q)
+            side.append(2 * q + 1)
+        lights = [dict(stoplines=stop, phases=[(80, side), (15, main + side), (50, main), (15, main + side)])]
+    return assemble_world([town.mesh()], scenarios, A, threshold=threshold, cell=cell, lights=lights)
