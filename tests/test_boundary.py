@@ -136,3 +136,30 @@ def test_stamp_patches_apply_to_the_current_source():
     for mode in m.PATCHES:
         src = m.patched_source(mode)
         assert "tde_debug_stamps" in src and ("tde_mark(" in src or "stp.mark(" in src or mode == "trips"), mode
+
+
+def test_grid_build_argument_errors_and_shared_lists():
+    """tde_grid_build (host side, no GPU): bad meshes are refused with a message, not a crash; cells with identical candidates
+    share their records (every record offset + count stays inside the map's record range)"""
+    import ctypes as C
+
+    import numpy as np
+
+    from torchdriveenv_amd import _abi, _lib
+    from torchdriveenv_amd.world import build_grid_index, strip_mesh
+
+    L = _lib.load()
+    gp = C.POINTER(_abi.TdeGrid)()
+    huge = np.array([[0, 0, 1e6, 0, 0, 1e6]], np.float32)
+    assert L.tde_grid_build(huge.ctypes.data, 1, 0.5, 0.25, 0.05, 0, C.byref(gp)) != 0 and b"larger cell" in L.tde_last_error()
+    nan = np.array([[np.nan, 0, 1, 0, 0, 1]], np.float32)
+    assert L.tde_grid_build(nan.ctypes.data, 1, 0.5, 0.25, 0.05, 0, C.byref(gp)) != 0 and b"non-finite" in L.tde_last_error()
+    assert L.tde_grid_build(nan.ctypes.data, 0, 0.5, 0.25, 0.05, 0, C.byref(gp)) != 0
+    assert L.tde_grid_build(huge.ctypes.data, 1, 0.5, 0.25, 0.6, 0, C.byref(gp)) != 0          # margin >= threshold
+    g = build_grid_index(strip_mesh([(0.0, 0.0), (60.0, 0.0)], 7.0, 5.0).astype(np.float32), 0.5, 0.25)
+    mixed = g["cell_class"] == _abi.CELL_MIXED
+    assert mixed.sum() > 500 and 0 < g["n_lists"] < mixed.sum() // 4           # a straight road: few distinct lists
+    assert (g["cell_first"][mixed].astype(np.int64) + g["cell_count"][mixed] <= len(g["rec_tri"])).all()
+    assert g["nx"] % 8 == 0 and g["ny"] % 8 == 0 and float(g["ox"]).is_integer()
+    one = build_grid_index(strip_mesh([(0.0, 0.0), (60.0, 0.0)], 7.0, 5.0).astype(np.float32), 0.5, 0.25, n_threads=1)
+    assert all(np.array_equal(g[k], one[k]) for k in ("cell_class", "cell_count", "cell_first", "cell_sub", "rec_tri"))   # thread count does not show

@@ -20,6 +20,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <exception>
+#include <new>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -97,8 +99,26 @@ void tde_grid_free(tde_grid *g)
     free(g);
 }
 
+static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, int32_t n_threads,
+                               tde_grid **out);
+
 int tde_grid_build(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, int32_t n_threads,
                    tde_grid **out)
+{
+    // no C++ exception crosses the C-ABI (host containers and threads are used inside)
+    try {
+        return tde_grid_build_impl(tri32, n_tri, threshold_f, cell_f, margin_f, n_threads, out);
+    } catch (const std::bad_alloc &) {
+        return bad("tde_grid_build: out of host memory");
+    } catch (const std::exception &e) {
+        char msg[200];
+        snprintf(msg, sizeof(msg), "tde_grid_build: %s", e.what());
+        return bad(msg);
+    }
+}
+
+static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, int32_t n_threads,
+                               tde_grid **out)
 {
     using namespace tde_grid_detail;
     if (!tri32 || !out || n_tri < 1) return bad("tde_grid_build: needs a mesh of at least one triangle");
