@@ -118,12 +118,13 @@ TDE_API int tde_env_step_render(const tde_config *cfg, const tde_world *world, c
  * instead of a dozen framework ops per step in closed-loop use. */
 TDE_API int tde_state_obs(const tde_world *world, const tde_state *state, float *out, void *stream);
 
-/* Infraction MAGNITUDES of every env's ego, float32 [B][2] = (offroad, collision): what the reference's info dict holds under
- * "offroad" / "collision" - simulator.compute_offroad() and compute_collision() for the exposed agent, gym_env.py:427-428 (Monitor
- * logs them, examples/rl_training.py:128) - where the step path only needs `> 0`.  offroad = sum over the four box corners of
- * clamp(dist - offroad_threshold, min = 0), dist = distance of the corner to the drivable mesh (the SQUARED distance under
- * tde_config.offroad_threshold_squared); collision = number of other present agents whose box overlaps the ego's.  Evaluated on
- * the state as it is: call it after a step WITHOUT TDE_F_AUTORESET and before tde_env_reset re-spawns the finished envs. */
+/* Infraction MAGNITUDES of every env's ego, float32 [B][4] = (offroad, collision, number of overlapping agents, 0): what the
+ * reference's info dict holds under "offroad" / "collision" - simulator.compute_offroad() and compute_collision() for the exposed
+ * agent, gym_env.py:427-428 (Monitor logs them, examples/rl_training.py:128) - where the step path only needs `> 0`.  offroad = sum
+ * over the four box corners of clamp(dist - offroad_threshold, min = 0), dist = distance of the corner to the drivable mesh (the
+ * SQUARED distance under tde_config.offroad_threshold_squared); collision = sum over the other present agents whose box overlaps
+ * the ego's of the IoU of the two boxes (CollisionMetric.nograd's published form, gym_env.py:48).  Evaluated on the state as it
+ * is: call it after a step WITHOUT TDE_F_AUTORESET and before tde_env_reset re-spawns the finished envs. */
 TDE_API int tde_ego_infractions(const tde_config *cfg, const tde_world *world, const tde_state *state, float *out, void *stream);
 
 /* ---- host side: static tables ------------------------------------------------------------------------------------ */

@@ -167,8 +167,9 @@ def env_step(cfg, world, state):
 
 
 def ego_infractions(cfg, world, state):
-    """float32 [B, 2]: the ego's offroad and collision MAGNITUDES of the current state (brute force over every triangle)"""
-    out = np.zeros((state.B, 2), np.float32)
+    """float32 [B, 4]: the ego's offroad magnitude, collision magnitude (sum of IoUs), number of overlapping agents, 0 - of the
+    current state (brute force over every triangle)"""
+    out = np.zeros((state.B, 4), np.float32)
     assert lib().tde_oracle_ego_infractions(C.byref(cfg), C.byref(world.host_struct()), C.byref(state.struct), _p(out)) == 0
     return out
 

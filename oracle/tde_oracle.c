@@ -849,16 +849,66 @@ TDE_EXPORT int tde_oracle_render_ego(const tde_config *cfg, const tde_world *w, 
 /*   offroad   = sum over the four corners of clamp(dist - threshold, min = 0), dist = distance of the   */
 /*               corner to the mesh (brute force over every triangle; the SQUARED distance under         */
 /*               offroad_threshold_squared), accumulated in fp32 in corner order FL, FR, RR, RL;         */
-/*   collision = number of other present agents whose box overlaps the ego's (strict SAT).              */
-/* out = float32 [B][2].                                                                              */
+/*   collision = sum over the other present agents whose box overlaps the ego's (strict SAT) of the IoU  */
+/*               of the two boxes (tde_oracle_box_iou), in slot order; also their number.               */
+/* out = float32 [B][4] = offroad, collision (sum of IoUs), number of overlapping agents, 0.           */
 /* ------------------------------------------------------------------------------------------------ */
+/* IoU of two oriented boxes by Sutherland-Hodgman clipping of box 0 by the four edges of box 1 and the shoelace formula, fp32, one
+ * operation at a time (the HIP kernel repeats it: csrc/tde_magnitudes.h).  The published form of torchdrivesim's
+ * CollisionMetric.nograd is this value summed over the other agents; tests/test_second_opinions.py holds a float64 version of
+ * the same construction against the SAT mask. */
+static void tde_box_corners_ccw(float x, float y, float c, float s, float hl, float hw, float *px, float *py)
+{
+    const float lx = hl * c, ly = hl * s, wx = hw * s, wy = hw * c;
+    px[0] = (x + lx) - wx; py[0] = (y + ly) + wy;       /* front left  */
+    px[1] = (x - lx) - wx; py[1] = (y - ly) + wy;       /* rear left   */
+    px[2] = (x - lx) + wx; py[2] = (y - ly) - wy;       /* rear right  */
+    px[3] = (x + lx) + wx; py[3] = (y + ly) - wy;       /* front right */
+}
+
+TDE_EXPORT float tde_oracle_box_iou(float x0, float y0, float c0, float s0, float hl0, float hw0, float x1, float y1, float c1,
+                                    float s1, float hl1, float hw1)
+{
+    float ax[8], ay[8], bx[8], by[8], qx[4], qy[4];
+    int n = 4;
+    tde_box_corners_ccw(x0, y0, c0, s0, hl0, hw0, ax, ay);
+    tde_box_corners_ccw(x1, y1, c1, s1, hl1, hw1, qx, qy);
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const float ex = qx[(e + 1) & 3] - qx[e], ey = qy[(e + 1) & 3] - qy[e];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int i2 = (i + 1 == n) ? 0 : i + 1;
+            const float sp = ex * (ay[i] - qy[e]) - ey * (ax[i] - qx[e]);
+            const float sq = ex * (ay[i2] - qy[e]) - ey * (ax[i2] - qx[e]);
+            if (sp >= 0.0f && m < 8) { bx[m] = ax[i]; by[m] = ay[i]; ++m; }
+            if (((sp > 0.0f && sq < 0.0f) || (sp < 0.0f && sq > 0.0f)) && m < 8) {
+                const float t = sp / (sp - sq);
+                bx[m] = ax[i] + t * (ax[i2] - ax[i]);
+                by[m] = ay[i] + t * (ay[i2] - ay[i]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) { ax[i] = bx[i]; ay[i] = by[i]; }
+    }
+    if (n < 3) return 0.0f;
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const int i2 = (i + 1 == n) ? 0 : i + 1;
+        acc = acc + (ax[i] * ay[i2] - ax[i2] * ay[i]);
+    }
+    const float ai = 0.5f * fabsf(acc);
+    const float a0 = (2.0f * hl0) * (2.0f * hw0), a1 = (2.0f * hl1) * (2.0f * hw1);
+    return ai / ((a0 + a1) - ai);
+}
+
 TDE_EXPORT int tde_oracle_ego_infractions(const tde_config *cfg, const tde_world *w, const tde_state *st, float *out)
 {
 #pragma omp parallel for schedule(dynamic, 1)
     for (int32_t e = 0; e < st->B; ++e) {
         const int32_t A = st->A;
         const int64_t g0 = (int64_t)e * A;
-        float omag = 0.0f, cmag = 0.0f;
+        float omag = 0.0f, cmag = 0.0f, nmag = 0.0f;
         if (st->present[g0]) {
             float se, ce;
             tde_oracle_sincosf(st->psi[g0], &se, &ce);
@@ -868,10 +918,13 @@ TDE_EXPORT int tde_oracle_ego_infractions(const tde_config *cfg, const tde_world
                 if (!st->present[g0 + j]) continue;
                 float sj, cj;
                 tde_oracle_sincosf(st->psi[g0 + j], &sj, &cj);
-                n += tde_oracle_obb_overlap(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj,
-                                            0.5f * st->len[g0 + j], 0.5f * st->wid[g0 + j]);
+                const float hlj = 0.5f * st->len[g0 + j], hwj = 0.5f * st->wid[g0 + j];
+                if (tde_oracle_obb_overlap(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj, hlj, hwj)) {
+                    n += 1;     /* (IoU only for pairs the mask's predicate calls overlapping: magnitude > 0 <=> collided) */
+                    cmag = cmag + tde_oracle_box_iou(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj, hlj, hwj);
+                }
             }
-            cmag = (float)n;
+            nmag = (float)n;
             if (cfg->flags & TDE_F_OFFROAD) {
                 const tde_map *m = &w->maps[w->scn[st->scn[e]].map];
                 const float *tri = w->tri + 6 * (int64_t)m->tri_base;
@@ -884,8 +937,10 @@ TDE_EXPORT int tde_oracle_ego_infractions(const tde_config *cfg, const tde_world
                 }
             }
         }
-        out[2 * (int64_t)e] = omag;
-        out[2 * (int64_t)e + 1] = cmag;
+        out[4 * (int64_t)e] = omag;
+        out[4 * (int64_t)e + 1] = cmag;
+        out[4 * (int64_t)e + 2] = nmag;
+        out[4 * (int64_t)e + 3] = 0.0f;
     }
     return 0;
 }

@@ -3,7 +3,8 @@
 examples/rl_training.py:128).  Upstream's values are unpinned (torchdrivesim absent): the oracle defines them - sum over the ego's
 corners of clamp(distance to the mesh - threshold, 0), brute force over every triangle; number of agents the ego overlaps - and
 the kernel, which finds a corner's nearest triangle through the grid index (candidate lists, then a growing scan), must return
-the same bits, however far off the road the ego is."""
+the same bits, however far off the road the ego is.  collision = sum of the IoUs (Sutherland-Hodgman clip, fp32) with the agents
+the ego overlaps - CollisionMetric.nograd's published form - plus their number."""
 import numpy as np
 import pytest
 
@@ -48,7 +49,8 @@ def test_ego_infraction_magnitudes_bit_exact(small_world, squared):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
         off = hs["offroad"].reshape(B, A)[:, 0] > 0
         assert np.array_equal(want[:, 0] > 0, off)                   # the magnitude is positive exactly where the mask is set
-        assert np.array_equal(want[:, 1] > 0, hs["collided"].reshape(B, A)[:, 0] > 0)
+        assert np.array_equal(want[:, 2] > 0, hs["collided"].reshape(B, A)[:, 0] > 0)      # overlap count <=> the collision mask
+        assert ((want[:, 1] > 0) <= (want[:, 2] > 0)).all() and (want[:, 1] <= want[:, 2]).all() and (want[:, 3] == 0).all()
     assert want[:, 0].max() > 20.0 and (want[:, 0] > 0).sum() > 50 and (want[:, 0] == 0).sum() > 20
 
 
@@ -64,7 +66,7 @@ def test_ego_infraction_magnitudes_town_and_128_slots(town):
         got = ops.ego_infractions(cfg, world.to_device(DEV), ds).cpu().numpy()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (A, np.abs(got - want).max())
         assert (want[:, 0] > 0).any()
-    assert want[:, 1].max() >= 1.0                                   # crowded scenes: the ego overlaps somebody
+    assert want[:, 2].max() >= 1.0 and 0.0 < want[:, 1].max() <= want[:, 2].max()   # crowded scenes: the ego overlaps somebody
 
 
 def test_batched_env_info_magnitudes_equals_the_one_launch_step(small_world):

@@ -211,3 +211,27 @@ def test_smoothness_terms_cpu_division_vs_cuda_reciprocal_multiply():
             n += len(d)
             differ += int((cpu != cuda).sum())
     assert n > 2000 and 0 < differ < 0.5 * n
+
+
+def test_oracle_box_iou_matches_the_float64_clip():
+    """the fp32 IoU the oracle (and the kernel) sum into the collision MAGNITUDE of info["collision"] - CollisionMetric.nograd's
+    published form - against the float64 Sutherland-Hodgman construction above, 20 000 random pairs"""
+    import ctypes as C
+
+    L = oracle.lib()
+    L.tde_oracle_box_iou.argtypes = [C.c_float] * 12
+    L.tde_oracle_box_iou.restype = C.c_float
+    rng = np.random.default_rng(0)
+    f = np.float32
+    worst, npos = 0.0, 0
+    for _ in range(20_000):
+        b = [tuple(float(f(v)) for v in (rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-3.1, 3.1), rng.uniform(3.8, 6.9),
+                                          rng.uniform(1.6, 3.1))) for _ in range(2)]
+        args = []
+        for q in b:
+            args += [q[0], q[1], f(math.cos(q[2])), f(math.sin(q[2])), f(0.5) * f(q[3]), f(0.5) * f(q[4])]
+        v, w = L.tde_oracle_box_iou(*args), iou(b[0], b[1])
+        worst = max(worst, abs(v - w))
+        npos += w > 0
+        assert 0.0 <= v <= 1.0 + 1e-6
+    assert worst < 2e-6 and 10_000 < npos < 19_000

@@ -4,7 +4,8 @@
 //
 //   offroad    sum over the four box corners of clamp(dist - threshold, min = 0), dist = distance of the corner to the drivable
 //              mesh (0 inside); under tde_config.offroad_threshold_squared dist is the SQUARED distance, as the threshold then is;
-//   collision  number of other present agents whose box overlaps the ego's (strict SAT, the predicate of the collision mask).
+//   collision  sum over the other present agents whose box overlaps the ego's (strict SAT, the predicate of the collision mask) of
+//              the IoU of the two boxes - the published form of CollisionMetric.nograd; also the number of such agents.
 //
 // Upstream's values are unpinned here (torchdrivesim absent): the CPU checker defines them (its ego-infractions restatement: brute force over
 // every triangle) and this kernel returns the same bits.  Not on the step path: an env that wants magnitudes steps without
@@ -20,6 +21,53 @@
 #include "tde_device.h"
 
 namespace tde {
+
+// IoU of two oriented boxes: Sutherland-Hodgman clipping of box 0 by the four edges of box 1 + the shoelace formula, fp32, the
+// CPU checker's expression trees (the published form of CollisionMetric.nograd sums this over the other agents)
+TDE_DEV void box_corners_ccw(float x, float y, float c, float s, float hl, float hw, float *px, float *py)
+{
+    const float lx = hl * c, ly = hl * s, wx = hw * s, wy = hw * c;
+    px[0] = (x + lx) - wx; py[0] = (y + ly) + wy;
+    px[1] = (x - lx) - wx; py[1] = (y - ly) + wy;
+    px[2] = (x - lx) + wx; py[2] = (y - ly) - wy;
+    px[3] = (x + lx) + wx; py[3] = (y + ly) - wy;
+}
+
+__device__ __noinline__ float box_iou(float x0, float y0, float c0, float s0, float hl0, float hw0, float x1, float y1, float c1,
+                                      float s1, float hl1, float hw1)
+{
+    float ax[8], ay[8], bx[8], by[8], qx[4], qy[4];
+    int n = 4;
+    box_corners_ccw(x0, y0, c0, s0, hl0, hw0, ax, ay);
+    box_corners_ccw(x1, y1, c1, s1, hl1, hw1, qx, qy);
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const float ex = qx[(e + 1) & 3] - qx[e], ey = qy[(e + 1) & 3] - qy[e];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int i2 = (i + 1 == n) ? 0 : i + 1;
+            const float sp = ex * (ay[i] - qy[e]) - ey * (ax[i] - qx[e]);
+            const float sq = ex * (ay[i2] - qy[e]) - ey * (ax[i2] - qx[e]);
+            if (sp >= 0.0f && m < 8) { bx[m] = ax[i]; by[m] = ay[i]; ++m; }
+            if (((sp > 0.0f && sq < 0.0f) || (sp < 0.0f && sq > 0.0f)) && m < 8) {
+                const float t = sp / (sp - sq);
+                bx[m] = ax[i] + t * (ax[i2] - ax[i]);
+                by[m] = ay[i] + t * (ay[i2] - ay[i]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) { ax[i] = bx[i]; ay[i] = by[i]; }
+    }
+    if (n < 3) return 0.0f;
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const int i2 = (i + 1 == n) ? 0 : i + 1;
+        acc = acc + (ax[i] * ay[i2] - ax[i2] * ay[i]);
+    }
+    const float ai = 0.5f * fabsf(acc);
+    const float a0 = (2.0f * hl0) * (2.0f * hw0), a1 = (2.0f * hl1) * (2.0f * hw1);
+    return ai / ((a0 + a1) - ai);
+}
 
 TDE_DEV float wave_min(float v)
 {
@@ -79,15 +127,16 @@ TDE_DEV float point_mesh_d2_wave(const tde_world &w, const tde_map &m, float px,
     return best;
 }
 
-// out[e] = (offroad magnitude, collision magnitude) of env e's ego; one wavefront per env
+// out[e] = (offroad magnitude, collision magnitude = sum of IoUs, number of overlapping agents, 0) of env e's ego; one wavefront per env
 __global__ __launch_bounds__(kBlock) void ego_infractions_kernel(tde_config cfg, tde_world w, tde_state st, float *__restrict__ out)
 {
+    __shared__ float iou_of[kBlock / kWave][TDE_MAX_AGENTS];     // per env: the IoU with every slot, summed in slot order by lane 0
     const int lane = (int)(threadIdx.x & 63u);
     const int e = (int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
     if (e >= st.B) return;                                           // (wave-uniform)
     const int A = st.A;
     const int64_t g0 = (int64_t)e * A;
-    float omag = 0.0f, cmag = 0.0f;
+    float omag = 0.0f, cmag = 0.0f, nmag = 0.0f;
     if (st.present[g0]) {
         const float ex = st.x[g0], ey = st.y[g0];
         float se, ce;
@@ -98,14 +147,20 @@ __global__ __launch_bounds__(kBlock) void ego_infractions_kernel(tde_config cfg,
         for (int j0 = 0; j0 < A; j0 += 64) {
             const int j = j0 + lane;
             bool hit = false;
+            float v = 0.0f;
             if (j > 0 && j < A && st.present[g0 + j]) {
                 float sj, cj;
                 sincos_f32(st.psi[g0 + j], sj, cj);
-                hit = obb_overlap(ex, ey, ce, se, hl, hw, st.x[g0 + j], st.y[g0 + j], cj, sj, 0.5f * st.len[g0 + j], 0.5f * st.wid[g0 + j]);
+                const float xj = st.x[g0 + j], yj = st.y[g0 + j], hlj = 0.5f * st.len[g0 + j], hwj = 0.5f * st.wid[g0 + j];
+                hit = obb_overlap(ex, ey, ce, se, hl, hw, xj, yj, cj, sj, hlj, hwj);
+                if (hit) v = box_iou(ex, ey, ce, se, hl, hw, xj, yj, cj, sj, hlj, hwj);
             }
+            if (j < A) iou_of[threadIdx.x >> 6][j] = v;
             nhit += (int)__popcll(__ballot(hit));
         }
-        cmag = (float)nhit;
+        nmag = (float)nhit;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wavefront's own LDS stores have landed
+        if (nhit) for (int j = 1; j < A; ++j) { const float v = iou_of[threadIdx.x >> 6][j]; if (v != 0.0f) cmag = cmag + v; }
         // offroad: the four corners one after the other, each by the whole wavefront
         if (cfg.flags & TDE_F_OFFROAD) {
             const tde_map m = w.maps[reinterpret_cast<const int4 *>(w.scn)[st.scn[e]].x];
@@ -124,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void ego_infractions_kernel(tde_config cfg,
             }
         }
     }
-    if (lane == 0) { out[2 * (int64_t)e] = omag; out[2 * (int64_t)e + 1] = cmag; }
+    if (lane == 0) reinterpret_cast<float4 *>(out)[e] = make_float4(omag, cmag, nmag, 0.0f);
 }
 
 }  // namespace tde

@@ -254,10 +254,10 @@ class EnvHandle {
         check_rc(tde_state_obs(&world_, &state_, p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_state_obs");
     }
 
-    // tde_ego_infractions: float32 [B, 2] = the ego's (offroad, collision) magnitudes of the state as it is (gym_env.py:427-428)
+    // tde_ego_infractions: float32 [B, 4] = the ego's (offroad, collision, overlap count, 0) magnitudes of the state as it is (gym_env.py:427-428)
     void ego_infractions(const at::Tensor &out, int64_t flags)
     {
-        float *p = static_cast<float *>(const_cast<void *>(dev_ptr(out, at::kFloat, (int64_t)state_.B * 2, "out", dev_)));
+        float *p = static_cast<float *>(const_cast<void *>(dev_ptr(out, at::kFloat, (int64_t)state_.B * 4, "out", dev_)));
         cfg_.flags = static_cast<uint32_t>(flags);
         const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
         check_rc(tde_ego_infractions(&cfg_, &world_, &state_, p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_ego_infractions");

@@ -152,7 +152,7 @@ class _LazyInfo(dict):
         super().__init__()
         self._st, self._ego = st, slice(0, B * A, A)
         self._keys = self.KEYS + (self.EXTRA if st["info"] is not None else ())
-        self._mag = magnitudes                # float32 [B, 2] (offroad, collision) of tde_ego_infractions, or None: 0 / 1 indicators
+        self._mag = magnitudes                # float32 [B, 4] (offroad, collision, count, -) of tde_ego_infractions, or None: 0 / 1 indicators
 
     def _make(self, k):
         st = self._st
@@ -225,7 +225,7 @@ class BatchedWaypointEnv:
         """binding: "ext" = launches go through the PyTorch-ROCm C++ extension (csrc/tde_torch_ext.cpp), "ctypes" = through
         the ctypes binding of the same C-ABI (ops.py); both call the very same entry points of libtde_hip.so.
         info_magnitudes: info["offroad"] / info["collision"] hold the MAGNITUDES the reference reports there (ref
-        gym_env.py:427-428: sum over the ego's corners of clamp(distance - threshold, 0); number of agents the ego overlaps)
+        gym_env.py:427-428: sum over the ego's corners of clamp(distance - threshold, 0); sum of the IoUs with the agents the ego overlaps)
         instead of 0 / 1 indicators.  They belong to the state BEFORE a finished env is re-spawned, so a step then is three
         launches - the step without in-kernel re-spawn, tde_ego_infractions, the masked reset - instead of one."""
         validate(cfg)
@@ -277,7 +277,7 @@ class BatchedWaypointEnv:
         self._vec = None
         self._h = None
         self.info_magnitudes = bool(info_magnitudes)
-        self._mag = torch.zeros((self.num_envs, 2), dtype=torch.float32, device=self.torch_device) if info_magnitudes else None
+        self._mag = torch.zeros((self.num_envs, 4), dtype=torch.float32, device=self.torch_device) if info_magnitudes else None
         if binding == "ext":
             from . import _ext
             self._h = _ext.env_handle(self.tde_cfg, self.dworld, self.state)

@@ -168,15 +168,16 @@ def env_rollout(cfg, dworld, state, actions, reward=None, done=None):
 
 
 def ego_infractions(cfg, dworld, state, out=None):
-    """tde_ego_infractions: float32 [B, 2] = the ego's (offroad, collision) MAGNITUDES of the current state - what the
-    reference's info dict holds (ref gym_env.py:427-428) where the step path only needs `> 0`.  Call it after a step made
+    """tde_ego_infractions: float32 [B, 4] = the ego's (offroad, collision = sum of IoUs, number of overlapping agents, 0)
+    MAGNITUDES of the current state - what the reference's info dict holds (ref gym_env.py:427-428) where the step path only
+    needs `> 0`.  Call it after a step made
     WITHOUT TDE_F_AUTORESET and before the finished envs are re-spawned."""
     L = _lib.load()
     dev = state.device
     if out is None:
-        out = torch.empty((state.B, 2), dtype=torch.float32, device=dev)
+        out = torch.empty((state.B, 4), dtype=torch.float32, device=dev)
     _lib.check(_call(dev, L.tde_ego_infractions, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct),
-                     _chk(out, torch.float32, 2 * state.B, "out", torch.device(dev)), _lib.current_stream(dev)), "tde_ego_infractions")
+                     _chk(out, torch.float32, 4 * state.B, "out", torch.device(dev)), _lib.current_stream(dev)), "tde_ego_infractions")
     return out
 
 
