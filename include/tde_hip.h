@@ -101,6 +101,14 @@ TDE_API int tde_env_rollout(const tde_config *cfg, const tde_world *world, const
 TDE_API int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *state,
                            const tde_render *render, void *stream);
 
+/* The re-spawn of the envs an SB3-style auto-reset has just seen finish, and their first observation, in ONE call: tde_env_reset
+ * for the envs with mask[e] != 0 (uint8 [B], required) followed by tde_render_ego of exactly those views - their newest frame
+ * rendered again in place, their older stack frames blanked (render->fresh and render->only are set to `mask` by the call; phase
+ * = the phase of the LAST full render).  Replaces: the reset() + get_obs() a VecEnv issues for finished envs
+ * (gym_env.py:319-349, 122-124; examples/rl_training.py:159-160). */
+TDE_API int tde_env_reset_render(const tde_config *cfg, const tde_world *world, const tde_state *state, const uint8_t *mask,
+                                 const tde_render *render, void *stream);
+
 /* One timestep + (render != NULL) the birdview of every env, as n_streams contiguous sub-batches of the batch, sub-batch i
  * launched on streams[i] (hipStream_t; the step, then the rasteriser): GymEnv.step followed by get_obs (gym_env.py:115-124)
  * for every env, the step of one sub-batch overlapping the rasteriser of another - both kernels are latency-bound alone

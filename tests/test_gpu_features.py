@@ -226,6 +226,21 @@ def test_render_masked_and_fresh_calls_match_oracle(small_world):
             dout = ops.render_ego(cfg, dw, ds, n_stack=3, out=dout, fresh=dev(mask), only=dev(mask))
             r = ring.rerender(cfg, dw, ds, dev(mask))
             assert np.array_equal(dout.cpu().numpy(), hout) and np.array_equal(r.cpu().numpy(), hout), t
+        if t % 3 == 0 and t:                              # the same as ONE call: tde_env_reset_render (in place and on the ring)
+            mask = np.zeros(B, np.uint8)
+            mask[rng.integers(0, B, 6)] = 1
+            ds2 = EnvState(B, A, device=DEV)              # a second device state for the in-place form
+            ds2.load(hs.host())
+            oracle.env_reset(cfg, small_world, hs, mask)
+            hout = oracle.render_ego(cfg, small_world, hs, n_stack=3, out=hout, fresh=mask, only=mask)
+            dout = ops.env_reset_render(cfg, dw, ds2, dev(mask), dout, n_stack=3)
+            r = ring.reset_rerender(cfg, dw, ds, dev(mask))
+            assert np.array_equal(dout.cpu().numpy(), hout) and np.array_equal(r.cpu().numpy(), hout), t
+            for k in ("x", "y", "psi", "v", "episode", "steps", "scn", "target_idx", "present", "route_wp"):
+                assert np.array_equal(ds[k].cpu().numpy().view(np.uint8), hs.host()[k].view(np.uint8)), k
+                assert np.array_equal(ds2[k].cpu().numpy().view(np.uint8), hs.host()[k].view(np.uint8)), k
+    with pytest.raises(Exception, match="mask"):
+        ops.env_reset_render(cfg, dw, ds, None, dout, n_stack=3)
     assert ring.phase in (0, 1, 2)
     with pytest.raises(Exception):
         ops.render_ego(cfg, dw, ds, n_stack=3, out=dout, layers=ring.layers, phase=-1)
@@ -499,6 +514,10 @@ def test_extension_equals_ctypes_equals_oracle(small_world):
     for t in range(50):
         a = torch.rand(16, 2, device=DEV) * 0.6 - 0.3
         assert torch.equal(b1.step(a)[0], b2.step(a)[0])
+        if t % 10 == 9:                                   # a caller's masked reset: tde_env_reset_render through both bindings
+            m = torch.rand(16, device=DEV) < 0.3
+            assert torch.equal(b1.reset(mask=m), b2.reset(mask=m))
+            assert torch.equal(b1.state["x"], b2.state["x"]) and torch.equal(b1.state["episode"], b2.state["episode"])
 
 
 @pytest.mark.parametrize("A", [8, 16, 32])

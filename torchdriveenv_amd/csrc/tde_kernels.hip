@@ -2887,6 +2887,22 @@ int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_stat
     return e == hipSuccess ? 0 : fail("tde_render_ego", e);
 }
 
+int tde_env_reset_render(const tde_config *cfg, const tde_world *world, const tde_state *st, const uint8_t *mask,
+                         const tde_render *rd, void *stream)
+{
+    int rc = check_env_args("tde_env_reset_render", cfg, world, st);
+    if (rc) return rc;
+    if (!mask) return bad("tde_env_reset_render: mask is NULL (a full reset renders with tde_render_ego)");
+    rc = check_render_args("tde_env_reset_render", world, rd);   // (before the reset: a bad request re-spawns nothing)
+    if (rc) return rc;
+    rc = tde_env_reset(cfg, world, st, mask, stream);
+    if (rc) return rc;
+    tde_render r = *rd;
+    r.fresh = mask;                                              // the re-spawned views' older frames restart blank,
+    r.only = mask;                                               // only their newest frame is rendered again, in place
+    return tde_render_ego(cfg, world, st, &r, stream);
+}
+
 int tde_env_step_render(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_render *rd,
                         void *const *streams, int32_t n_streams)
 {

@@ -247,6 +247,25 @@ class EnvHandle {
         check_rc(tde_render_ego(&cfg_, &world_, &state_, &rd, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_render_ego");
     }
 
+    // tde_env_reset_render: masked reset + the re-spawned views' first observation (their newest frame in place, older stack frames
+    // blank) in one call; `phase` = the phase of the last full render
+    void reset_render(const at::Tensor &mask, int64_t flags, const at::Tensor &out, int64_t H, int64_t W, double fov, int64_t n_stack,
+                      const std::optional<at::Tensor> &layers, int64_t phase, int64_t rflags)
+    {
+        cfg_.flags = static_cast<uint32_t>(flags);
+        const int64_t ns = n_stack > 1 ? n_stack : 1;
+        tde_render rd{};
+        rd.out = static_cast<uint8_t *>(const_cast<void *>(dev_ptr(out, at::kByte, state_.B * 3 * ns * H * W, "out", dev_)));
+        rd.H = static_cast<int32_t>(H); rd.W = static_cast<int32_t>(W); rd.fov = static_cast<float>(fov);
+        rd.n_stack = static_cast<int32_t>(n_stack);
+        rd.layers = layers ? static_cast<uint8_t *>(const_cast<void *>(dev_ptr(*layers, at::kByte, state_.B * ns * H * W, "layers", dev_))) : nullptr;
+        rd.phase = static_cast<int32_t>(phase);
+        rd.flags = static_cast<int32_t>(rflags);
+        const uint8_t *m = static_cast<const uint8_t *>(dev_ptr(mask, at::kByte, state_.B, "mask", dev_));
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_env_reset_render(&cfg_, &world_, &state_, m, &rd, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_env_reset_render");
+    }
+
     void state_obs(const at::Tensor &out)
     {
         float *p = static_cast<float *>(const_cast<void *>(dev_ptr(out, at::kFloat, (int64_t)state_.B * 8, "out", dev_)));
@@ -391,6 +410,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
              py::arg("layers"), py::arg("phase"), py::arg("flags"), py::arg("fresh"), py::arg("only"))
         .def("step_render", &EnvHandle::step_render, py::arg("action"), py::arg("flags"), py::arg("out"), py::arg("H"), py::arg("W"),
              py::arg("fov"), py::arg("n_stack"), py::arg("layers"), py::arg("phase"), py::arg("rflags"), py::arg("fresh"), py::arg("streams"))
+        .def("reset_render", &EnvHandle::reset_render, py::arg("mask"), py::arg("flags"), py::arg("out"), py::arg("H"), py::arg("W"), py::arg("fov"),
+             py::arg("n_stack"), py::arg("layers"), py::arg("phase"), py::arg("rflags"))
         .def("state_obs", &EnvHandle::state_obs)
         .def("ego_infractions", &EnvHandle::ego_infractions, py::arg("out"), py::arg("flags"))
         .def_property_readonly("flags", &EnvHandle::flags)

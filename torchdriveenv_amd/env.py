@@ -295,6 +295,16 @@ class BatchedWaypointEnv:
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.torch_device).to(torch.uint8).contiguous()
+        if m is not None and self.obs_mode == "birdview" and self._obs is not None:
+            # the SB3-style auto-reset: the re-spawn and the re-spawned views' first observation in ONE C-ABI call
+            if self._stack is not None:
+                self._obs = self._stack.reset_rerender(self.tde_cfg, self.dworld, self.state, m, self._fov)
+            elif self._h is not None:
+                self._h.reset_render(m, int(self.tde_cfg.flags), self._obs, self._res, self._res, self._fov, 1, None, 0, self._rflags)
+            else:
+                ops.env_reset_render(self.tde_cfg, self.dworld, self.state, m, self._obs, self._res, self._res, self._fov, 1,
+                                     flags=self._rflags)
+            return self._obs
         if self._h is not None:
             self._h.reset(m, int(self.tde_cfg.flags))
         else:

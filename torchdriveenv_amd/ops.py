@@ -233,6 +233,20 @@ def join_streams(streams, device=None):
         cur.wait_stream(s)
 
 
+def env_reset_render(cfg, dworld, state, mask, out, H=64, W=64, fov=35.0, n_stack=1, layers=None, phase=0, flags=0):
+    """tde_env_reset_render: masked reset + the re-spawned views' first observation in ONE call (their newest frame rendered in
+    place, their older stack frames blanked); `phase` = the phase of the last full render.  Returns `out`."""
+    L = _lib.load()
+    dev = state.device
+    ns = max(1, n_stack)
+    pl = _chk(layers, torch.uint8, state.B * ns * H * W, "layers", optional=True) if ns > 1 else None
+    rd = _abi.TdeRender(_chk(out, torch.uint8, state.B * 3 * ns * H * W, "out"), H, W, fov, n_stack, pl, int(phase), int(flags), None, None)
+    _lib.check(_call(dev, L.tde_env_reset_render, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct),
+                     _chk(mask, torch.uint8, state.B, "mask", torch.device(dev)), C.byref(rd), _lib.current_stream(dev)),
+               "tde_env_reset_render")
+    return out
+
+
 def env_step_render(cfg, dworld, state, streams, action=None, out=None, H=64, W=64, fov=35.0, n_stack=1, layers=None, phase=0,
                     flags=0, fresh=None, render=True):
     """tde_env_step_render: one timestep + (render) the birdview of every env as len(streams) contiguous sub-batches, each on
@@ -289,6 +303,15 @@ class FrameStack:
             render_ego(cfg, dworld, state, self.H, self.W, fov, self.n_stack, self.obs, self.layers, self.phase,
                        self.flags, fresh=fresh)
         self.phase = (self.phase + 1) % self.n_stack
+        return self.obs
+
+    def reset_rerender(self, cfg, dworld, state, mask, fov=35.0):
+        """masked reset + rerender() of the same views as one C-ABI call (tde_env_reset_render)"""
+        last = (self.phase - 1) % self.n_stack
+        if self.handle is not None:
+            self.handle.reset_render(mask, int(cfg.flags), self.obs, self.H, self.W, fov, self.n_stack, self.layers, last, self.flags)
+        else:
+            env_reset_render(cfg, dworld, state, mask, self.obs, self.H, self.W, fov, self.n_stack, self.layers, last, self.flags)
         return self.obs
 
     def rerender(self, cfg, dworld, state, mask, fov=35.0):
