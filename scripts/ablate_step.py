@@ -6,12 +6,12 @@ from torchdriveenv_amd import _abi, ops
 from torchdriveenv_amd.state import EnvState
 from torchdriveenv_amd.synth import synthetic_world
 
-A, N = 16, 2000
+A, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 2000
 dev = torch.device("cuda:0")
 world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
 F = _abi
-sets = {"none(kin+coll)": 0, "npc": F.F_NPC, "offroad": F.F_OFFROAD, "reward+reset": F.F_REWARD | F.F_AUTORESET, "all": F.F_ALL}
+sets = {"none(kin+coll)": 0, "npc": F.F_NPC, "offroad": F.F_OFFROAD, "reward+reset": F.F_REWARD | F.F_AUTORESET, "all-autoreset": F.F_ALL & ~F.F_AUTORESET, "all": F.F_ALL}
 for B in (1024, 8192):
     act = torch.zeros(B, 2, device=dev)
     for name, fl in sets.items():

@@ -12,7 +12,7 @@ _lib.load()
 world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
-for B in (512, 1024, 2048, 4096):
+for B in (512, 1024, 2048, 2752, 4096, 8192):
     g = torch.Generator().manual_seed(0)
     actions = torch.stack([torch.rand(250, B, generator=g) * 2 - 1, torch.rand(250, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)
     rows = [actions[i] for i in range(250)]

@@ -371,14 +371,15 @@ TDE_DEV void respawn_lane(const tde_config &cfg, const Cold &w, int e, int a, Ag
 // max-over-lanes(popcount) times, usually 0-2).  Skipped slots cannot change the result, so the action keeps every
 // bit of the oracle's full sweep.
 // ra / rb: the a / b tile rows of the lane's env (slot 0 first).
+// npc_gap: the leader gap over the A rows at ra / rb.  `i` = the lane's own slot RELATIVE to ra (outside [0, A) when the rows are
+// the other half of a 128-slot env: it is then only the "not taken" stand-in row and the j < i operand), `own_bit` = its bit in the
+// candidate mask (0 when it is not among these rows).
 template <int A>
-TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp,
-                        float sp, bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc,
-                        float &beta)
+TDE_DEV float npc_gap(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, typename MaskOf<A>::type own_bit, const Agent &ag,
+                      float cp, float sp, bool has_target, float g_far)
 {
     using mask_t = typename MaskOf<A>::type;
     constexpr int C = A < kSweepBlock ? A : kSweepBlock;
-    const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
     mask_t cand = 0;
     const float hl_i = 0.5f * ag.len;
     if (has_target) {
@@ -419,7 +420,7 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
             for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
             pin(v);
         });
-        cand &= ~bit_of_row<A>(i);
+        cand &= ~own_bit;
     }
     float gap = 1e30f;
     // exact tests of the candidates; every lane walks its own list, so the wavefront makes max-over-lanes(count) trips
@@ -484,6 +485,14 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
         }
         gap = fminf(gap, fminf(g[0], g[1]));
     }
+    return gap;
+}
+
+// the controller's action from the leader gap
+TDE_DEV void npc_act_of_gap(const tde_config &cfg, const Agent &ag, float cp, float sp, bool has_target, float tgx, float tgy, float gap,
+                            float red_gap, float &acc, float &beta)
+{
+    const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
     if (!has_target) {
         acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
         beta = 0.0f;
@@ -500,13 +509,23 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
     acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
 }
 
+template <int A>
+TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp,
+                        float sp, bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc,
+                        float &beta)
+{
+    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far);
+    npc_act_of_gap(cfg, ag, cp, sp, has_target, tgx, tgy, gap, red_gap, acc, beta);
+}
+
 // R9 for one slot against the A slots of its env (rows ra / rb).  Overlapping convex boxes have centres closer than the
 // sum of their circumradii; hl+hw >= circumradius, so a pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact
 // or in fp32 arithmetic (the 1.001 is folded into the radii, kReach).  Phase 1 marks the pairs inside that radius
 // (branch-free, free to fuse its multiply-adds), phase 2 runs the 4-axis SAT test on the marked ones only.
 // Called by all lanes of the wavefront, converged.
+// collide_part: against the A rows at ra / rb; `own_bit` = the lane's own slot's bit in the candidate mask (0: not among these rows)
 template <int A>
-TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
+TDE_DEV bool collide_part(const float4 *ra, const float4 *rb, typename MaskOf<A>::type own_bit, bool live, float x, float y, float c, float s,
                           float hl, float hw, float ri)
 {
     using mask_t = typename MaskOf<A>::type;
@@ -537,7 +556,7 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
             for (int j = 0; j < C; ++j) v[j] = __builtin_fmaf(-rr[j], rr[j], dx[j]);
             pin(v);
         });
-        cand &= ~bit_of_row<A>(a);
+        cand &= ~own_bit;
     }
     bool hit = false;
     while (__ballot(cand != 0)) {
@@ -551,73 +570,39 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
     return hit;
 }
 
-// ---- more than 64 slots per env (A = 128: the reference assembles up to ~100 agents, gym_env.py:216-237) -------------------
-// An env then spans two wavefronts of a 256-thread workgroup and the candidate masks of the sweeps above (one bit per row in
-// one or two registers) do not apply: these forms walk EVERY row with the exact tests - the very arithmetic of the tuned forms'
-// second phase, whose first phase only ever removes rows that the exact tests reject - so results are the same bits.  Generic,
-// not tuned: O(A) exact tests per slot (the one-role kernels only).
-TDE_DEV float npc_exact_gap(const tde_config &cfg, int i, int j, const Agent &ag, float cp, float sp, float hl_i, const float4 &pj,
-                            const float4 &qj)
+template <int A>
+TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
+                          float hl, float hw, float ri)
 {
-    const float ex = pj.x - ag.x, ey = pj.y - ag.y;
-    float fj = ex * cp, t0 = ey * sp, lj = ey * cp, t1 = ex * sp;
-    fj = fj + t0; lj = lj - t1;
-    float hd = cp * qj.x;
-    t0 = sp * qj.y;
-    const float halfw = cfg.npc_lane_half + qj.w;
-    float g = hl_i + qj.z;
-    hd = hd + t0; t1 = cfg.npc_cone_k * fj; g = fj - g;
-    t1 = halfw + t1;
-    const float al = fabsf(lj);
-    const int inlane = __float_as_int(al - halfw), c1 = __float_as_int(al - t1), c2 = __float_as_int(fj - cfg.npc_cone_range),
-              c3 = __float_as_int(-0.5f - hd), c4 = j - i, ahead = __float_as_int(0.0f - fj);
-    const int tk = (((c1 & c2) & (c3 & c4)) | inlane) & ahead;
-    return tk < 0 ? g : 1e30f;
+    return collide_part<A>(ra, rb, bit_of_row<A>(a), live, x, y, c, s, hl, hw, ri);
 }
 
+// ---- more than 64 slots per env (A = 128: the reference assembles up to ~100 agents, gym_env.py:216-237) -------------------
+// An env then spans two wavefronts of a workgroup and its rows are swept as TWO HALVES of 64 with the forms above (a 64-bit
+// candidate mask per half, the exact tests on the set bits): the lane's own slot is a bit of one of the halves, the leader gap
+// is the minimum over both (a minimum of the same values in another order: same bits), the collision flag their OR.
+// (round 4's first form walked every row with the exact tests: 43 us per step at ~ 120 agents per env against the masks' 11,
+//  profiles/r04_y_wide_times.txt)
 template <int A>
 TDE_DEV void npc_action_wide(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp, float sp,
-                             bool has_target, float tgx, float tgy, float red_gap, float &acc, float &beta)
+                             bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc, float &beta)
 {
-    const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
-    if (!has_target) {
-        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
-        beta = 0.0f;
-        return;
-    }
-    const float hl_i = 0.5f * ag.len;
-    float gap = 1e30f;
-    for (int j = 0; j < A; ++j) {
-        const float4 pj = ra[j], qj = rb[j];
-        if (j != i) gap = fminf(gap, npc_exact_gap(cfg, i, j, ag, cp, sp, hl_i, pj, qj));
-    }
-    const float dx = tgx - ag.x, dy = tgy - ag.y;
-    const float fwd = dx * cp + dy * sp;
-    const float lat = dy * cp - dx * sp;
-    const float dist = sqrt_cr_f32(dx * dx + dy * dy);
-    const float sin_err = lat / fmaxf(dist, 1e-3f);
-    beta = (fwd < 0.0f) ? copysignf(smax, lat) : clampf(cfg.npc_k_steer * sin_err, -smax, smax);
-    gap = fminf(gap, red_gap);
-    const float vd = fminf(ag.vdes, sqrt_cr_f32(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
-    acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
+    static_assert(A == 128, "two halves of 64 rows");
+    const unsigned long long own = 1ull << (63 - (i & 63));
+    const float g0 = npc_gap<64>(cfg, ra, rb, i, i < 64 ? own : 0ull, ag, cp, sp, has_target, g_far);
+    const float g1 = npc_gap<64>(cfg, ra + 64, rb + 64, i - 64, i < 64 ? 0ull : own, ag, cp, sp, has_target, g_far);
+    npc_act_of_gap(cfg, ag, cp, sp, has_target, tgx, tgy, fminf(g0, g1), red_gap, acc, beta);
 }
 
 template <int A>
 TDE_DEV bool collide_rows_wide(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s, float hl,
                                float hw, float ri)
 {
-    bool hit = false;
-    if (live) {
-        for (int j = 0; j < A; ++j) {
-            const float4 pj = ra[j];
-            const float dx = pj.x - x, dy = pj.y - y, rr = ri + pj.z;
-            if (j != a && dx * dx + dy * dy < rr * rr) {           // (inside the sum of the padded circumradii: see collide_rows)
-                const float4 qj = rb[j];
-                hit = hit | obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
-            }
-        }
-    }
-    return hit;
+    static_assert(A == 128, "two halves of 64 rows");
+    const unsigned long long own = 1ull << (63 - (a & 63));
+    const bool h0 = collide_part<64>(ra, rb, a < 64 ? own : 0ull, live, x, y, c, s, hl, hw, ri);
+    const bool h1 = collide_part<64>(ra + 64, rb + 64, a < 64 ? 0ull : own, live, x, y, c, s, hl, hw, ri);
+    return h0 | h1;
 }
 
 // The same for 16 slots per env when the wavefront's lane l holds slot l % 16 of its env, i.e. an env is one 16-lane DPP
@@ -826,7 +811,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     if (F & TDE_F_NPC) {
         float na, nb;
         const float red_gap = (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
-        if constexpr (A > 64) npc_action_wide<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, red_gap, na, nb);
+        if constexpr (A > 64) npc_action_wide<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
         else npc_action<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
         if (npc && k > 1) { acc = na; beta = nb; }    // (first step of an episode: the NPCs coast, kFirstStepCoast below)
     }
@@ -925,11 +910,15 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 // ------------------------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------------------------
+// (A = 128: wavefronts per SIMD the one-role kernels are compiled for - registers per lane 512 / that)
+#ifndef TDE_WIDE_WAVES
+#define TDE_WIDE_WAVES 3
+#endif
 // one launch = one timestep of every env
 // OBS: also writes the compact observation (tde_state.obs); a template flag because the code, taken or not, costs the
 // plain kernel 0.9 us per launch (it keeps the ego target and the heading's sin/cos alive to the end)
 template <int A, bool LIGHTS, bool OBS, bool BIG = false>
-__global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
+__global__ __launch_bounds__(kBlock, A > kWave ? TDE_WIDE_WAVES : 1) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
                                                           const float *__restrict__ action, float *reward_k,
                                                           uint8_t *done_k)
 {
@@ -1018,14 +1007,16 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(tde_config cfg, tde_wo
 // table entries (Ctx) live in registers across the K steps, the only per-step global traffic is the ego action
 // (prefetched one step ahead), the per-step reward/done outputs and the grid-index reads; wavefronts never wait for
 // each other, so a wave that takes the rare reset / mesh-boundary path does not stall the batch.
+// (A = 128: the workgroup is the env's two wavefronts)
 template <int A, bool LIGHTS>
-__global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
+__global__ __launch_bounds__(A > kWave ? A : kWave, A > kWave ? TDE_WIDE_WAVES : 1) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
 {
-    __shared__ Tiles<kWave> t;
+    constexpr int kGroup = A > kWave ? A : kWave;
+    __shared__ Tiles<kGroup> t;
     __shared__ Cold cold;
     if (threadIdx.x == 0) fill_cold(cold, cfg, w);
     __syncthreads();
-    const int64_t g = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * kGroup + threadIdx.x;
     const int e = (int)(g / A), a = (int)(g % A);
     const int B = st.B;
     const int LB = ro.ldb;                                  // row pitch of the [K][..] action / reward / done buffers
@@ -1048,7 +1039,7 @@ __global__ __launch_bounds__(kWave) void env_rollout_kernel(tde_config cfg, tde_
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
         const float2 act_next = acts[(int64_t)kn * LB + es];      // in flight during this step
-        o = step_lane<A, kWave, LIGHTS>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
+        o = step_lane<A, kGroup, LIGHTS>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
         if (valid && a == 0) {
             if (ro.reward) ro.reward[(int64_t)k * LB + e] = o.reward;
             if (ro.done)
@@ -2785,20 +2776,12 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
     if (ro->ldb != 0 && ro->ldb < st->B) return bad("tde_env_rollout: rollout.ldb must be 0 (= B) or >= B");
     if (st->A > 64) {
-        // 128 slots per env: the persistent kernels keep an env inside one wavefront, so the K timesteps run as K launches of
-        // the one-step kernel's generic form, each reading its row of the action buffer and writing its rows of reward / done
-        const int64_t ldb = ro->ldb ? ro->ldb : st->B;
-        const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-        const unsigned nb = blocks_for((int64_t)st->B * st->A);
-        tde_state s128 = *st;                                 // (a rollout does not maintain the closed loop's episode statistics)
-        s128.ep_return = nullptr; s128.ep_final = nullptr; s128.ep_final_len = nullptr;
-        for (int32_t i = 0; i < ro->K; ++i) {
-            const float *act = ro->actions + 2 * (int64_t)i * ldb;
-            float *rw = ro->reward ? ro->reward + (int64_t)i * ldb : nullptr;
-            uint8_t *dn = ro->done ? ro->done + (int64_t)i * ldb : nullptr;
-            if (lights) tde::env_step_kernel<128, true, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, s128, act, rw, dn);
-            else tde::env_step_kernel<128, false, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, s128, act, rw, dn);
-        }
+        // 128 slots per env: the one-role persistent kernel with the env's two wavefronts as its workgroup (the role-split kernels
+        // keep an env inside one wavefront)
+        tde_rollout r128 = *ro;
+        if (r128.ldb == 0) r128.ldb = st->B;
+        if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) tde::env_rollout_kernel<128, true><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
+        else tde::env_rollout_kernel<128, false><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
     }
