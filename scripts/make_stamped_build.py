@@ -96,12 +96,12 @@ def patch_duo(s):
 def patch_trio(s):
     """driver phases of env_rollout_trio_kernel (indices 0-9) and the two judges (12-16, 18-21)"""
     # npc_action gets an optional stamp cursor
-    s = sub(s, "float g_far, float red_gap, float &acc,\n                        float &beta)\n{",
-            "float g_far, float red_gap, float &acc,\n                        float &beta, unsigned long long *stl = nullptr)\n{")
-    s = sub(s, "        cand &= ~bit_of_row<A>(i);\n    }\n    float gap = 1e30f;\n",
-            "        cand &= ~bit_of_row<A>(i);\n    }\n    tde_mark(stl, 1);\n    float gap = 1e30f;\n")
-    s = sub(s, "    if (!has_target) {\n        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);",
-            "    tde_mark(stl, 2);\n    if (!has_target) {\n        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);")
+    s = sub(s, "float g_far, float red_gap, float &acc,\n                        float &beta)\n{\n    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far);\n",
+            "float g_far, float red_gap, float &acc,\n                        float &beta, unsigned long long *stl = nullptr)\n{\n    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far, stl);\n    tde_mark(stl, 2);\n")
+    s = sub(s, "                      float cp, float sp, bool has_target, float g_far)\n{\n    using mask_t = typename MaskOf<A>::type;",
+            "                      float cp, float sp, bool has_target, float g_far, unsigned long long *stl = nullptr)\n{\n    using mask_t = typename MaskOf<A>::type;")
+    s = sub(s, "        cand &= ~own_bit;\n    }\n    float gap = 1e30f;\n",
+            "        cand &= ~own_bit;\n    }\n    tde_mark(stl, 1);\n    float gap = 1e30f;\n")
     a, b = kernel_span(s, "env_rollout_trio_kernel")
     k = s[a:b]
     k = sub(k, "    if (threadIdx.x == 0) {\n        fill_cold(cold, cfg, w); sh.done = 0ull;",
