@@ -63,6 +63,23 @@ struct Tiles {
 };
 constexpr float kFar = 1e18f;
 
+// LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
+TDE_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Between a phase that writes tile rows and one that reads them in the ONE-role kernels.  Up to 64 slots per env the rows of
+// an env are written and read by ONE wavefront, whose LDS instructions execute in order: nothing to wait for - the four
+// wavefronts of a 256-thread workgroup are independent chains, and a __syncthreads() (s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier)
+// made each of them wait for the slowest at every phase AND for its own grid-index loads that were meant to stay in flight
+// across the collision sweep.  128 slots per env: the env's two wavefronts meet at an LDS-only barrier.
+#ifndef TDE_TILE_SYNC_WG
+#define TDE_TILE_SYNC_WG 0          // 1: the old __syncthreads() (A/B)
+#endif
+template <int A> TDE_DEV void tile_sync()
+{
+    if constexpr (TDE_TILE_SYNC_WG) __syncthreads();
+    else if constexpr (A > kWave) lds_barrier();
+    else { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+}
+
 template <int A> struct MaskOf { using type = uint32_t; };
 template <> struct MaskOf<64> { using type = unsigned long long; };
 template <> struct MaskOf<128> { using type = unsigned long long; };   // (A = 128 never builds a mask: the *_wide forms)
@@ -838,9 +855,9 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     Corners corners;                                // cell words of the four corners: loads stay in flight during
     if (F & TDE_F_OFFROAD)                          // the collision sweep
         offroad_issue<kStepCls2>(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
-    __syncthreads();                                // every lane is done reading the pre-step tile
+    tile_sync<A>();                                 // every lane is done reading the pre-step tile
     write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
-    __syncthreads();
+    tile_sync<A>();
     bool hit;
     if constexpr (A > 64) hit = collide_rows_wide<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
     else hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
@@ -885,7 +902,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
             bool mine;
             if constexpr (A > 64) {                 // the env spans two wavefronts: its flag travels through LDS
                 if (a == 0) t.wide_done[tid / A] = done;
-                __syncthreads();
+                lds_barrier();
                 mine = t.wide_done[tid / A] != 0;
                 any = mine ? 1ull : 0ull;
             } else {
@@ -903,7 +920,7 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
             }
         }
     }
-    __syncthreads();                                // ...so the tile is consistent for the next step's controller
+    tile_sync<A>();                                 // ...so the tile is consistent for the next step's controller
     return out;
 }
 
@@ -945,7 +962,7 @@ __global__ __launch_bounds__(kBlock, A > kWave ? TDE_WIDE_WAVES : 1) void env_st
     float c0, s0;
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
-    __syncthreads();
+    tile_sync<A>();
     StepOut o = step_lane<A, kBlock, LIGHTS, BIG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
     if (!valid) return;
     store_agent_dynamic(st, g, ag);
@@ -1034,7 +1051,7 @@ __global__ __launch_bounds__(A > kWave ? A : kWave, A > kWave ? TDE_WIDE_WAVES :
     float c0, s0;
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
-    __syncthreads();
+    tile_sync<A>();
     StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
     for (int k = 0; k < ro.K; ++k) {
         const int kn = (k + 1 < ro.K) ? k + 1 : k;
@@ -1130,8 +1147,6 @@ struct CachedLines {
     }
 };
 
-// LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
-TDE_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 TDE_DEV void write_rows(DuoShared &sh, int buf, int lane, bool live, const Agent &ag, float c, float s, float lane_half)
 {
@@ -2231,7 +2246,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float 
     const float ri = (hl + hw) * kReach;
     t.a[tid] = live ? make_float4(X, Y, ri, 0.0f) : make_float4(kFar, kFar, 0.0f, 0.0f);
     t.b[tid] = make_float4(c1, s1, hl, hw);
-    __syncthreads();
+    tile_sync<A>();
     const int base = tid - a;
     bool hit;
     if constexpr (A > 64) hit = collide_rows_wide<A>(&t.a[base], &t.b[base], a, live, X, Y, c1, s1, hl, hw, ri);
