@@ -26,6 +26,8 @@ ap.add_argument("--agents", type=int, default=16)
 ap.add_argument("--launches", type=int, default=40)
 ap.add_argument("--steps", type=int, default=250)
 ap.add_argument("--lights", action="store_true")
+ap.add_argument("--signal-reach", type=int, default=1, help="0: a scenario sees only its own junction's lights")
+ap.add_argument("--signals", type=int, default=0, help="--town: signalised junctions (light groups; up to 64)")
 ap.add_argument("--cell", type=float, default=0.25, help="grid cell edge of the world's offroad index [m]")
 ap.add_argument("--town", action="store_true", help="the 1 km x 1 km town map (synth.synthetic_town) instead of the junction maps")
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawns")
@@ -35,7 +37,7 @@ args = ap.parse_args()
 
 B, A, K = args.envs, args.agents, args.steps
 dev = torch.device("cuda:0")
-world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell)
+world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell, n_signals=args.signals, signal_reach=args.signal_reach) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell)
 dw = world.to_device(dev)
 
 

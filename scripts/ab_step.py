@@ -22,17 +22,20 @@ ap.add_argument("--envs", type=int, default=8192)
 ap.add_argument("--agents", type=int, default=16)
 ap.add_argument("--steps", type=int, default=100, help="launches per graph")
 ap.add_argument("--replays", type=int, default=30)
+ap.add_argument("--signal-reach", type=int, default=1, help="0: a scenario sees only its own junction's lights")
+ap.add_argument("--signals", type=int, default=0, help="--town: signalised junctions (light groups; up to 64)")
 ap.add_argument("--cell", type=float, default=0.25, help="grid cell edge of the world's offroad index [m]")
 ap.add_argument("--town", action="store_true")
+ap.add_argument("--lights", action="store_true", help="with TDE_F_TRAFFIC_LIGHTS")
 ap.add_argument("--kernel", default=None, choices=["solo", "trio"])
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawn tail")
 ap.add_argument("--outputs", action="store_true", help="with info / done bits / episode statistics / compact observation")
 args = ap.parse_args()
 B, A, K = args.envs, args.agents, args.steps
 dev = torch.device("cuda:0")
-world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell)
+world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell, n_signals=args.signals, signal_reach=args.signal_reach) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell)
 dw = world.to_device(dev)
-cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
+cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=_abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0))
 if args.endless:
     cfg.terminated_at_infraction = 0
     cfg.max_steps = 1 << 30

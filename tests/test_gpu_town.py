@@ -194,12 +194,17 @@ def test_town_config5_shape_8192x32_views_vs_oracle():
 
 @pytest.mark.parametrize("team", ["trio", "duo"])
 def test_town_with_signalised_junctions_rollout_and_step(team):
-    """a town whose first two scenario junctions carry traffic lights: the LARGE_GRID forms of the kernels WITH the
-    traffic-light code (red stop lines as standing leaders, the ego's violation term, the lights in the birdview) == oracle"""
+    """a town with signalised junctions - every one a light group of its own, i.e. a map descriptor that shares the town's grid
+    (assemble_world) - next to scenarios without lights: the LARGE_GRID forms of the kernels WITH the traffic-light code (red
+    stop lines as standing leaders, the ego's violation term, the lights in the birdview) == oracle"""
     from torchdriveenv_amd.synth import synthetic_town
 
-    world = synthetic_town(n_scn=4, A=16, seed=3, n_streets=10, n_signals=2)          # full size: TDE_WORLD_LARGE_GRID is set
-    assert world.ints["hints"] & _abi.WORLD_LARGE_GRID and world.has_lights and world.arrays["maps"][0]["n_stop"] == 8
+    world = synthetic_town(n_scn=6, A=16, seed=3, n_streets=10, n_signals=4)          # full size: TDE_WORLD_LARGE_GRID is set
+    maps = world.arrays["maps"]
+    assert world.ints["hints"] & _abi.WORLD_LARGE_GRID and world.has_lights and world.ints["n_maps"] == 6
+    assert maps[0]["n_stop"] == 0 and all(maps[k]["n_stop"] >= 4 and maps[k]["cell_base"] == maps[0]["cell_base"] for k in range(1, 6))
+    # (scenario 4: no signal in reach; scenario 5: its own junction is plain, two of its neighbours are signalised)
+    assert list(world.arrays["scn"]["map"]) == [1, 2, 3, 4, 0, 5] and maps[5]["n_stop"] == 8
     flags = _abi.F_ALL | _abi.F_TRAFFIC_LIGHTS
     cfg = _abi.default_config(seed=61, distance_cutoff=0.25, flags=flags, max_steps=170)
     B, A, K = 96, 16, 180

@@ -290,3 +290,46 @@ def test_reference_background_traffic_files_populate_the_world():
     for k in kept:
         assert 100.0 < math.dist(ego, (sp["x"][k], sp["y"][k])) <= 160.0
     assert np.allclose([sp["len"][0], sp["wid"][0], sp["lr"][0]], bt["agent_attributes"][0])
+
+
+def test_light_groups_share_the_grid_of_their_mesh():
+    """assemble_world(light_groups=): a town where EVERY scenario junction is signalised (more lights than the 32 bits of one map's
+    red mask) - one descriptor per group, the grid tables stored once, every scenario bound to its junction's descriptor; the
+    oracle sees red lights there and none at the plain scenarios"""
+    from oracle import oracle
+    from torchdriveenv_amd import _abi
+    from torchdriveenv_amd.state import EnvState
+    from torchdriveenv_amd.synth import synthetic_town
+
+    kw = dict(n_scn=40, A=8, seed=4, n_streets=8, spacing=100.0, cell=0.5)
+    plain, lit = synthetic_town(**kw), synthetic_town(n_signals=36, **kw)
+    assert plain.ints["n_maps"] == 1 and lit.ints["n_maps"] == 37 and not plain.has_lights and lit.has_lights
+    for k in ("cell_word", "cell_tri", "cell_cls2", "cell_sub", "cell_coarse", "tri", "spawn", "wp_xy"):
+        assert np.array_equal(np.asarray(plain.arrays[k]).view(np.uint8), np.asarray(lit.arrays[k]).view(np.uint8)), k
+    m = lit.arrays["maps"]
+    # a group = the scenario junction's four stop lines, then those of its signalised neighbours (3 - 5 junctions: 8 streets)
+    assert m["n_stop"][0] == 0 and set(m["n_stop"][1:]) <= {12, 16, 20} and len(lit.arrays["stoplines"]) == m["n_stop"].sum()
+    assert (m["stop_base"][1:] == np.cumsum(m["n_stop"])[:-1]).all() and len(set(m["cell_base"])) == 1 and len(set(m["rec_base"])) == 1
+    assert list(lit.arrays["scn"]["map"]) == [1 + (s % 36) for s in range(36)] + [1 + s for s in range(4)]
+    for s in range(36):
+        d = m[lit.arrays["scn"]["map"][s]]
+        sl = lit.arrays["stoplines"][d["stop_base"]:d["stop_base"] + d["n_stop"]]
+        assert sl["light"].max() == d["n_stop"] // 2 - 1 and sorted(set(sl["light"][:4])) == [0, 1]
+        c = np.array([sl["x"][:4].mean(), sl["y"][:4].mean()])                   # its own junction: the ego's route starts on an arm of it
+        w0 = lit.arrays["wp_xy"][s, 0]
+        assert 50.0 < np.hypot(*(w0 - c)) < 110.0
+        for k in range(1, d["n_stop"] // 4):                                     # the neighbours': one street spacing away
+            ck = np.array([sl["x"][4 * k:4 * k + 4].mean(), sl["y"][4 * k:4 * k + 4].mean()])
+            assert 80.0 < np.hypot(*(ck - c)) < 120.0
+    cfg = _abi.default_config(seed=2, distance_cutoff=0.25, flags=_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS, max_steps=150)
+    hs = EnvState(40, 8)
+    oracle.env_reset(cfg, lit, hs)
+    acts = np.zeros((160, 40, 2), np.float32)
+    acts[..., 0] = 0.6
+    _, done = oracle.env_rollout(cfg, lit, hs, acts)
+    assert (done & 16).any()                              # some ego crossed a red stop line of ITS junction
+    with pytest.raises(AssertionError, match="another mesh"):
+        from torchdriveenv_amd.world import assemble_world
+        sc = dict(map=0, waypoints=[(0, 0), (10, 0)], start_heading=0.0, lights=0)
+        tri = np.array([[[0, -5], [20, -5], [20, 5]]], np.float32)
+        assemble_world([tri, tri], [sc], 1, light_groups=[dict(map=1, stoplines=[(5, 0, 0, 1, 3, 0)], phases=[(10, [0])])])

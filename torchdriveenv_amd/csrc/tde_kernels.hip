@@ -1097,6 +1097,9 @@ __global__ __launch_bounds__(A > kWave ? A : kWave, A > kWave ? TDE_WIDE_WAVES :
 //   B: driver has committed the rows of step i (and any re-spawned rows of step i-1)
 // Same arithmetic in the same order per agent as step_lane, so results stay bit-identical to the oracle.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef TDE_STOP_CACHE
+#define TDE_STOP_CACHE 24
+#endif
 struct DuoShared {
     float4 a[2][kWave], b[2][kWave];
     float4 c[2][kWave];                  // (psi, v, live, -): what the judge's ego lane and liveness test need
@@ -1108,7 +1111,7 @@ struct DuoShared {
     int32_t max_steps_w, term_at_infraction_w;
     // the first kStopCache stop lines of every env's map (A >= 8, i.e. at most 8 envs per group): the per-step stop-line
     // loops read LDS instead of walking the global table with one exposed L2 round trip per line
-    float4 stop[8][8][2];
+    float4 stop[8][TDE_STOP_CACHE][2];
     // three-role kernel: the ego actions of the next two steps, relayed by judge O (slot = step & 1, indexed by the ego's
     // lane): the driver's loop then issues no global load of its own, so nothing in it ever waits on vmcnt
     float2 act[2][kWave];
@@ -1120,17 +1123,17 @@ struct DuoShared {
     uint4 draw[8][2];
     float4 ego_next[8][2];               // ... and the ego's start (pose, attributes) computed from them by judge C (ego_spawn)
 };
-constexpr int kStopCache = 8;
+constexpr int kStopCache = TDE_STOP_CACHE;
 
-// lanes a < min(n_stop, kStopCache) of an env fetch one line each (the driver calls it at start and after re-spawns)
+// the lanes of an env fetch its first min(n_stop, kStopCache) lines, one each per trip (the driver calls it at start and after re-spawns)
 template <int A>
 TDE_DEV void fill_stop_cache(DuoShared &sh, const tde_world &w, const tde_map &m, int lane, int a)
 {
     if constexpr (A >= 8) {
-        if (a < kStopCache && a < m.n_stop) {
-            const float4 *src = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + a));
-            sh.stop[lane / A][a][0] = src[0];
-            sh.stop[lane / A][a][1] = src[1];
+        for (int i = a; i < kStopCache && i < m.n_stop; i += A) {
+            const float4 *src = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i));
+            sh.stop[lane / A][i][0] = src[0];
+            sh.stop[lane / A][i][1] = src[1];
         }
     }
 }

@@ -256,29 +256,39 @@ class TownJunction:
 
 
 def synthetic_town(n_scn=256, A=16, seed=0, n_streets=10, spacing=100.0, ext=45.0, ds=1.5, n_parked=1, cell=0.25,
-                   threshold=0.5, min_gap=10.0, n_signals=0):
+                   threshold=0.5, min_gap=10.0, n_signals=0, signal_reach=1):
     """ONE map of town size - n_streets^2 junctions on ~((n_streets - 1) * spacing + 2 * ext)^2 metres, >= 5e4 triangles at the
     defaults (1 km x 1 km, 100 junctions) - with `n_scn` scenarios spread over its interior junctions, each built like a
     synthetic_world scenario (A - 1 NPCs on the arms around its junction).  `n_signals` of the scenario junctions (the first ones in
-    scenario order) are signalised: a stop line per arm, main street / side street lights on one cycle for the whole map.  The
-    kernels walk ALL stop lines of a map for every ego and NPC, so keep it to a handful (<= 2 junctions stay inside the kernels'
-    8-line LDS cache); default none.  Deterministic in `seed`."""
+    scenario order; up to all of them) are signalised: a stop line per arm, main street / side street lights, the same cycle
+    everywhere.  The scenarios at a junction see the lights of that junction and of its four neighbours - a LIGHT GROUP
+    (assemble_world: a map descriptor that shares the town's grid and carries <= 5 x 4 stop lines, <= 10 lights), since the
+    kernels walk every stop line of a scenario's descriptor and a light is a bit of a 32-bit mask (`signal_reach=0`: the junction's own
+    lights only - 4 stop lines, the cost of the junction maps).  Deterministic in `seed`."""
     rng = np.random.default_rng(seed)
     town = Town(n_streets, spacing, ext, ds=ds)
     inner = [(i, j) for i in range(1, n_streets - 1) for j in range(1, n_streets - 1)]
     order = rng.permutation(len(inner))
+    assert 0 <= n_signals <= len(inner), f"the town has {len(inner)} interior junctions"
+    signalised = {inner[order[q]] for q in range(n_signals)}
+    phases = lambda n: [(80, [2 * k + 1 for k in range(n)]), (15, list(range(2 * n))), (50, [2 * k for k in range(n)]), (15, list(range(2 * n)))]
+    groups, group_of = [], {}
+    for q in range(min(n_scn, len(inner)) if n_signals else 0):
+        i, j = inner[order[q]]
+        around = ((i, j), (i + 1, j), (i - 1, j), (i, j + 1), (i, j - 1))[:1 + 4 * signal_reach]
+        members = [ij for ij in around if ij in signalised]                                   # own junction first
+        if members:
+            stop = []
+            for k, (mi, mj) in enumerate(members):
+                stop += TownJunction(town, mi, mj).stoplines(2 * k, 2 * k + 1)
+            group_of[q] = len(groups)
+            groups.append(dict(map=0, stoplines=stop, phases=phases(len(members))))
     scenarios = []
     for si in range(n_scn):
-        i, j = inner[order[si % len(inner)]]
-        scenarios.append(_junction_scenario(TownJunction(town, i, j), 0, rng, A, n_parked, min_gap))
-    lights = None
-    if n_signals:
-        assert 2 * n_signals <= 32, "light indices are bits of a 32-bit mask"
-        stop, main, side = [], [], []
-        for q in range(n_signals):
-            i, j = inner[order[q % len(inner)]]
-            stop += TownJunction(town, i, j).stoplines(2 * q, 2 * q + 1)
-            main.append(2 * q)
-            side.append(2 * q + 1)
-        lights = [dict(stoplines=stop, phases=[(80, side), (15, main + side), (50, main), (15, main + side)])]
-    return assemble_world([town.mesh()], scenarios, A, threshold=threshold, cell=cell, lights=lights)
+        q = si % len(inner)
+        i, j = inner[order[q]]
+        sc = _junction_scenario(TownJunction(town, i, j), 0, rng, A, n_parked, min_gap)
+        if q in group_of:
+            sc["lights"] = group_of[q]
+        scenarios.append(sc)
+    return assemble_world([town.mesh()], scenarios, A, threshold=threshold, cell=cell, light_groups=groups)

@@ -294,18 +294,39 @@ class DeviceWorld:
         self.struct = _abi.fill_world_struct(tensors, ints)
 
 
-def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
+def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, light_groups=None):
     """meshes: list of [n,3,2] triangle arrays; scenarios: list of dicts with keys
          map (int), waypoints [(x,y)...], start_heading (float),
          agents: list (slots 1..) of dict(state=(x,y,psi,v), attr=(L,W,lr), vdes, route=[(x,y)..] or None,
                                          replay=[(x,y,psi,v)...] or None)
          ego_attr (L,W,lr)
+         lights (int, optional): index into `light_groups`
+       lights: per mesh None or dict(stoplines=[(x, y, psi, length, width, light)...], phases=[(n_steps, red_lights)...]) - the
+         traffic lights every scenario on that mesh sees.
+       light_groups: list of dict(map=mesh index, stoplines=..., phases=...) - the lights of ONE NEIGHBOURHOOD of a large map.  The
+         kernels walk all stop lines of a scenario's map descriptor and a light is a bit of a 32-bit mask, so a town with hundreds of
+         signals is cut up at build time: every group becomes a map descriptor of its own (tde_map: 80 bytes) that SHARES the mesh's
+         grid tables and carries only its stop lines and phases; a scenario with `lights=k` is bound to descriptor n_meshes + k.
     """
     assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, f"A must be a power of two <= {_abi.TDE_MAX_AGENTS}"
-    # lights: per map None or dict(stoplines=[(x, y, psi, length, width, light)...], phases=[(n_steps, red_lights)...])
     lights = lights or [None] * len(meshes)
+    light_groups = list(light_groups or [])
     stop_all, phase_all = [], []
-    maps = np.zeros(len(meshes), dtype=_abi.MAP_DTYPE)
+
+    def add_lights(lt):
+        """-> (stop_base, n_stop, phase_base, n_phase, cycle_steps) of one set of lights appended to the world's tables"""
+        if not lt:
+            return len(stop_all), 0, len(phase_all), 0, 0
+        n_stop, n_phase, cycle = len(lt["stoplines"]), len(lt["phases"]), 0
+        assert n_phase >= 1 and n_stop >= 1 and max(sl[5] for sl in lt["stoplines"]) < 32, "light indices are bits of a 32-bit mask"
+        for (x, y, psi, length, width, light) in lt["stoplines"]:
+            stop_all.append((x, y, math.cos(psi), math.sin(psi), 0.5 * length, 0.5 * width, light, 0))
+        for (n_steps, red) in lt["phases"]:
+            cycle += int(n_steps)
+            phase_all.append((cycle, sum(1 << int(i) for i in red)))
+        return len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle
+
+    maps = np.zeros(len(meshes) + len(light_groups), dtype=_abi.MAP_DTYPE)
     tri_all, word_all, rec_all, cls2_all, sub_all, coarse_all = [], [], [], [], [], []
     tri_base = cell_base = rec_base = cls2_base = coarse_base = 0
     for m, tri in enumerate(meshes):
@@ -313,18 +334,9 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         # the kernels see fp32 vertices: index the fp32-rounded mesh
         tri32 = tri.astype(np.float32)
         g = build_grid_index(tri32, threshold, cell)
-        lt = lights[m]
-        n_stop = n_phase = cycle = 0
-        if lt:
-            n_stop, n_phase = len(lt["stoplines"]), len(lt["phases"])
-            assert n_phase >= 1 and max(sl[5] for sl in lt["stoplines"]) < 32
-            for (x, y, psi, length, width, light) in lt["stoplines"]:
-                stop_all.append((x, y, math.cos(psi), math.sin(psi), 0.5 * length, 0.5 * width, light, 0))
-            for (n_steps, red) in lt["phases"]:
-                cycle += int(n_steps)
-                phase_all.append((cycle, sum(1 << int(i) for i in red)))
+        stop_base, n_stop, phase_base, n_phase, cycle = add_lights(lights[m])
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
-                   tri_base, len(tri), len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle,
+                   tri_base, len(tri), stop_base, n_stop, phase_base, n_phase, cycle,
                    row_shift_of(g["nx"]), cls2_base, rec_base, coarse_base, (0, 0))
         # cell word = class | count << 2 | first record << 10: the count of a MIXED cell is the length of its candidate list
         # (records from the map's rec_base + first on), that of a FULL / EMPTY cell its clearance (TDE_CLEARANCE_UNITs, rounded
@@ -345,6 +357,11 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         cell_base += (1 << row_shift_of(g["nx"])) * g["ny"]
         rec_base += len(g["rec_tri"])
         assert cell_base < (1 << 30) and cls2_base < (1 << 26), "world too large for 32-bit cell indices"
+    for k, lt in enumerate(light_groups):            # a descriptor per light group: the mesh's grid, the group's lights
+        assert 0 <= lt["map"] < len(meshes), "light group on an unknown mesh"
+        maps[len(meshes) + k] = maps[lt["map"]]
+        d = maps[len(meshes) + k:len(meshes) + k + 1]
+        d["stop_base"], d["n_stop"], d["phase_base"], d["n_phase"], d["cycle_steps"] = add_lights(lt)
     S = len(scenarios)
     NW = max(2, max(len(s["waypoints"]) for s in scenarios))
     wp_xy = np.zeros((S, NW, 2), np.float64)
@@ -357,7 +374,11 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
         w = np.asarray(s["waypoints"], np.float64)
         assert len(w) >= 2, "a scenario needs at least two waypoints (gym_env.py:353-354)"
         wp_xy[si, :len(w)] = w
-        scn[si] = (s["map"], len(w), s["start_heading"], 0)
+        m_of = s["map"]
+        if s.get("lights") is not None:
+            assert light_groups[s["lights"]]["map"] == s["map"], f"scenario {si}: its light group belongs to another mesh"
+            m_of = len(meshes) + s["lights"]
+        scn[si] = (m_of, len(w), s["start_heading"], 0)
         ego = spawn[si, 0]
         ego["present"] = 1
         ego["len"], ego["wid"], ego["lr"] = s.get("ego_attr", (5.0, 2.0, 1.9))
@@ -394,6 +415,6 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None):
                   else np.zeros(1, _abi.STOPLINE_DTYPE),
                   phases=np.asarray(phase_all, dtype=_abi.PHASE_DTYPE) if phase_all else np.zeros(1, _abi.PHASE_DTYPE))
     large = bool((maps["nx"].astype(np.int64) * maps["ny"]).max() > LARGE_GRID_CELLS)
-    ints = dict(n_maps=len(meshes), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT,
+    ints = dict(n_maps=len(maps), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT,
                 hints=_abi.WORLD_LARGE_GRID if large else 0)
     return World(arrays, ints, threshold)
