@@ -275,33 +275,57 @@ def python_boundary(B=8192, A=16):
     from torchdriveenv_amd.synth import synthetic_world
 
     world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
-    out = {"envs": B, "agents_per_env": A, "timer": "time.perf_counter around N calls, torch.cuda.synchronize at both ends"}
+    out = {"envs": B, "agents_per_env": A, "timer": "time.perf_counter around N calls, torch.cuda.synchronize at both ends; best of 3 passes"}
     for mode in ("state", "birdview"):
-        env = BatchedWaypointEnv(EnvConfig(seed=3), world, num_envs=B, obs_mode=mode, with_info=True)
+        env = BatchedWaypointEnv(EnvConfig(seed=3, distance_cutoff=0.25), world, num_envs=B, obs_mode=mode, with_info=True)
         env.reset()
-        act = torch.zeros(B, 2, device=env.torch_device)
-        act[:, 0] = 0.3
+        # the action rows of `secondary.closed_loop` (uniform acceleration in [-1, 1], steering in [-0.3, 0.3]): the step time
+        # depends on what the agents do (a constant push sends every ego off the road within 30 steps: 12.2 us instead of 9.4)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        rows_t = torch.stack([torch.rand(CH, B, generator=g) * 2 - 1, torch.rand(CH, B, generator=g) * 0.6 - 0.3], -1).float().contiguous()
+        rows = list(rows_t.to(env.torch_device))
+        rows_np = list(rows_t.numpy())
+        it = [0]
+
+        def act_dev():
+            it[0] += 1
+            return rows[it[0] % CH]
+
+        def act_host():
+            it[0] += 1
+            return rows_np[it[0] % CH]
 
         def timed(fn, n):
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e6
+            best = float("inf")
+            for rep in range(3):                                       # (best of three: the first pass also ramps the clocks)
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / n * 1e6)
+            return best
 
-        r = {"device_outputs_us_per_step": timed(lambda: env.step(act), 2000)}
-        act_np = np.zeros((B, 2), np.float32)
-        act_np[:, 0] = 0.3
-        r["numpy_copies_us_per_step"] = timed(lambda: env.vec_step(act_np), 200 if mode == "state" else 20)
+        timed(lambda: env.step(act_dev()), 500)                       # (a steady mix of episode ages first)
+        r = {"device_outputs_us_per_step": timed(lambda: env.step(act_dev()), 2000)}
+        r["numpy_copies_us_per_step"] = timed(lambda: env.vec_step(act_host()), 200 if mode == "state" else 10)
         env._vec = None
         venv = env.as_vec_env(copy_obs=False)
-        r["numpy_views_us_per_step"] = timed(lambda: venv.step(act_np), 200 if mode == "state" else 60)
+        r["numpy_views_us_per_step"] = timed(lambda: venv.step(act_host()), 200 if mode == "state" else 30)
         r["env_steps_per_s"] = {k[:-12]: B / v * 1e6 for k, v in r.items()}
         out[mode] = r
         del env, venv
+    # The env above steps WITH the traffic-light term (the maps have lights, as the reference's do: the closed-loop kernel then takes
+    # 11.1 us instead of 8.2, profiles/r04_z_town_lights.txt); the same call on maps without lights, for comparison with
+    # `secondary.closed_loop`:
+    out["traffic_lights"] = True
+    env = BatchedWaypointEnv(EnvConfig(seed=3, distance_cutoff=0.25), synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, lights=False),
+                             num_envs=B, obs_mode="state", with_info=True)
+    env.reset()
+    timed(lambda: env.step(act_dev()), 500)
+    out["state_no_lights_device_outputs_us_per_step"] = timed(lambda: env.step(act_dev()), 2000)
     return out
 
 

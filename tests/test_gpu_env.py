@@ -248,3 +248,43 @@ def test_loader_built_validation_worlds_hip_vs_oracle(case, tmp_path):
     want = oracle.render_ego(cfg, world, hs)
     got = ops.render_ego(cfg, dw, ds).cpu().numpy()
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+@pytest.mark.parametrize("obs_mode,frame_stack", [("state", 1), ("birdview", 1), ("birdview", 3)])
+def test_step_is_capturable_in_a_hip_graph(small_world, obs_mode, frame_stack):
+    """BatchedWaypointEnv.step makes no host synchronisation and no allocation whose address a later step depends on: ONE
+    timestep (policy stand-in -> step -> observation) captured as a HIP graph and replayed T times == T eager steps of a second env
+    on the same actions (state, rewards, flags, observations: same bits).  The frame-stack ring advances on the host
+    (its phase is a kernel argument), so n_stack > 1 is captured as one graph PER PHASE."""
+    cfg = EnvConfig(seed=23, distance_cutoff=0.25, max_environment_steps=40)
+    B, T = 96, 90
+    kw = dict(num_envs=B, device="cuda:0", obs_mode=obs_mode, frame_stack=frame_stack)
+    eager, graphed = BatchedWaypointEnv(cfg, small_world, **kw), BatchedWaypointEnv(cfg, small_world, **kw)
+    assert torch.equal(eager.reset(), graphed.reset())
+    g = torch.Generator().manual_seed(5)
+    acts = torch.stack([torch.rand(T, B, generator=g) * 1.4 - 0.4, torch.rand(T, B, generator=g) * 0.4 - 0.2], -1).to("cuda:0")
+    act = torch.zeros(B, 2, device="cuda:0")                 # the graph's action buffer
+    side = torch.cuda.Stream(device="cuda:0")
+    graphs, outs = [], []
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for ph in range(frame_stack):                        # (warm-up outside the capture, then one graph per ring phase)
+            act.copy_(acts[ph])
+            gr = torch.cuda.CUDAGraph()
+            if ph == 0:
+                snap = graphed.state_dict()
+            with torch.cuda.graph(gr, stream=side):
+                out = graphed.step(act)
+            graphs.append(gr)
+            outs.append(out)
+        graphed.load_state_dict(snap)                        # (capture does not execute: rewind the host-side ring phase too)
+        torch.cuda.synchronize()
+        for t in range(T):
+            act.copy_(acts[t])
+            graphs[t % frame_stack].replay()
+            o_g, r_g, te_g, tr_g, _ = outs[t % frame_stack]
+            o_e, r_e, te_e, tr_e, _ = eager.step(acts[t])
+            assert torch.equal(o_g, o_e) and torch.equal(r_g, r_e) and torch.equal(te_g, te_e) and torch.equal(tr_g, tr_e), t
+    for k in ("x", "y", "psi", "v", "steps", "episode", "scn", "target_idx"):
+        assert torch.equal(eager.state[k], graphed.state[k]), k
+    assert int(eager.state["episode"].max()) >= 2            # re-spawns happened inside the replays

@@ -148,11 +148,19 @@ class _LazyInfo(dict):
     KEYS = ("offroad", "collision", "traffic_light_violation", "is_success")
     EXTRA = ("reached_waypoint_num", "psi_smoothness", "speed_smoothness", "psi_reward", "dist_reward")
 
+    ALL = KEYS + EXTRA
+
     def __init__(self, st, B, A, magnitudes=None):
-        super().__init__()
-        self._st, self._ego = st, slice(0, B * A, A)
-        self._keys = self.KEYS + (self.EXTRA if st["info"] is not None else ())
+        self._st, self._BA = st, (B, A)
         self._mag = magnitudes                # float32 [B, 4] (offroad, collision, count, -) of tde_ego_infractions, or None: 0 / 1 indicators
+
+    @property
+    def _keys(self):
+        return self.ALL if self._st["info"] is not None else self.KEYS
+
+    @property
+    def _ego(self):
+        return slice(0, self._BA[0] * self._BA[1], self._BA[1])
 
     def _make(self, k):
         st = self._st
@@ -319,10 +327,20 @@ class BatchedWaypointEnv:
             self._render1(self._obs, only=m)
         return self._obs
 
+    def _flag_views(self):
+        """the state's terminated / truncated bytes seen as bool (no copy), formed once: the buffers never move"""
+        v = self.__dict__.get("_tt_views")
+        st = self.state
+        if v is None or v[0] is not st["terminated"]:
+            v = self._tt_views = (st["terminated"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool))
+        return v[1], v[2]
+
     def step(self, actions):
-        a = actions if torch.is_tensor(actions) and actions.device == self.torch_device else \
-            torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device)
-        a = a.to(torch.float32).reshape(self.num_envs, 2).contiguous()
+        # (the host side of a step is what a closed loop of small kernels waits for: no tensor op that is not needed)
+        a = actions
+        if not (torch.is_tensor(a) and a.dtype is torch.float32 and a.device == self.torch_device and a.dim() == 2
+                and a.shape[0] == self.num_envs and a.shape[1] == 2 and a.is_contiguous()):
+            a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).reshape(self.num_envs, 2).contiguous()
         if self.info_magnitudes:
             return self._step_with_magnitudes(a)
         if self._h is not None:
@@ -340,8 +358,8 @@ class BatchedWaypointEnv:
                 fresh = st["done_bits"] if st["done_bits"] is not None else (st["terminated"] | st["truncated"])
             obs = self.get_obs(fresh)
         # uint8 0/1 flags seen as bool without a copy; info entries are only computed when they are read
-        return (obs, st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool),
-                self.get_info())
+        term, trunc = self._flag_views()
+        return obs, st["reward"], term, trunc, _LazyInfo(st, self.num_envs, self.A)
 
     def _step_with_magnitudes(self, a):
         """step -> magnitudes of the ego's infractions on the state the step left -> re-spawn of the finished envs (masked reset,
