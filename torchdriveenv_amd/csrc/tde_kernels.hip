@@ -694,6 +694,29 @@ TDE_DEV uint32_t red_mask(const tde_world &w, const tde_map &m, int k)
     return red;
 }
 
+// red(k) and red(k + 1) with the phase table fetched as ONE round of independent loads (four entries per round): the one-step
+// kernels have no step loop to keep a window across, and red_mask's early-exit loop is a chain of dependent L2 round trips
+TDE_DEV void red_mask_pair(const tde_world &w, const tde_map &m, int k, uint32_t &r0, uint32_t &r1)
+{
+    r0 = r1 = 0u;
+    if (m.cycle_steps <= 0) return;
+    const int t0 = k % m.cycle_steps;
+    const int t1 = (t0 + 1 == m.cycle_steps) ? 0 : t0 + 1;
+    bool f0 = false, f1 = false;
+    for (int p = 0; p < m.n_phase; p += 4) {
+        tde_light_phase ph[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ph[u] = w.phases[m.phase_base + (p + u < m.n_phase ? p + u : m.n_phase - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p + u < m.n_phase) {
+                if (!f0 && t0 < ph[u].end_step) { r0 = ph[u].red_mask; f0 = true; }
+                if (!f1 && t1 < ph[u].end_step) { r1 = ph[u].red_mask; f1 = true; }
+            }
+        }
+    }
+}
+
 // The red mask only changes at phase boundaries: the persistent kernels keep it with the window of env steps [lo, hi)
 // it holds for (red is a function of the map and the env step; a re-spawn may change the map: invalidate()).
 struct RedCache {
@@ -1121,6 +1144,9 @@ struct DuoShared {
     // one-step three-role kernel: Philox blocks 0 and 1 of every env's NEXT episode (what a re-spawn at this step would draw),
     // written by the driver's lanes 0 and 1 of the env ahead of barrier A
     uint4 draw[8][2];
+    // one-step three-role kernel with lights: (red mask of this step, of the next step, stop_base, n_stop) of every env's map,
+    // formed by judge O ahead of barrier B together with the stop-line cache
+    int4 lights[8];
     float4 ego_next[8][2];               // ... and the ego's start (pose, attributes) computed from them by judge C (ego_spawn)
 };
 constexpr int kStopCache = TDE_STOP_CACHE;
@@ -1892,7 +1918,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         lds_barrier();                                                       // cold is published
         Ctx cx;
         bool rebuilt;
-        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, ag, er, cx, LIGHTS, rebuilt);
+        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, ag, er, cx, false, rebuilt);     // (no map: the lights are judge O's)
         const bool need_tg2 = !rebuilt && valid && (sc0.y & kSlotTg2Later) != 0;   // (left by the re-spawn of the previous launch)
         float c0, s0;
         const bool live = valid && ag.present;
@@ -1904,14 +1930,24 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
         float acc = 0.0f, beta = 0.0f;
         if (a == 0) { acc = act.x; beta = act.y; }
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
         // the controller's action for this step: stored by the previous launch (key = the state's episode / step counters)
-        // or, when some slot of this wavefront has none, computed here from the pre-step rows
-        auto controller = [&](int buf, int kk, float &na, float &nb) {
-            const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, kk) : 0u;
-            const float red_gap = (LIGHTS && red && has_target)
-                                      ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A},
-                                                        cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+        // or, when some slot of this wavefront has none, computed here from the pre-step rows.
+        // Lights: the red masks of this and the next step, the stop lines in LDS and where the rest of them lie come from judge O
+        // (sh.lights, sh.stop: written while it waits for barrier B - the driver's own path to B carries neither the phase table's
+        // nor the stop lines' loads); `early`: ahead of B the driver fetches what it needs itself (the rare recompute).
+        auto controller = [&](int buf, bool early, float &na, float &nb) {
+            float red_gap = 1e30f;
+            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) {
+                if (early) {
+                    const tde_map m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
+                    const uint32_t red = red_mask(w, m, k);
+                    if (red && has_target) red_gap = red_line_gap(cfg, w, m, red, ag, c0, s0);
+                } else {
+                    const int4 lw = sh.lights[lane / A];
+                    if (lw.y && has_target)
+                        red_gap = red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + lw.z, lane / A}, lw.w, (uint32_t)lw.y, ag, c0, s0);
+                }
+            }
             npc_action<A>(cfg, &sh.a[buf][base], &sh.b[buf][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far,
                           red_gap, na, nb);
         };
@@ -1923,7 +1959,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's own rows are in LDS
                 float na, nb;
-                controller(1, k, na, nb);
+                controller(1, true, na, nb);
                 if (npc) { acc = na; beta = nb; }
             } else if (npc) {
                 acc = ac.x; beta = ac.y;
@@ -1956,7 +1992,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         // and the wavefront repeats it on the new rows.
         float na2 = 0.0f, nb2 = 0.0f;
         has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-        if ((F & TDE_F_NPC) && st.act_cache) controller(0, k + 1, na2, nb2);
+        if ((F & TDE_F_NPC) && st.act_cache) controller(0, false, na2, nb2);
         constexpr bool kDrawAhead = A >= 8;                  // (judge C has drawn the next episode's random words: sh.draw)
         lds_barrier();                                       // A: the judges' masks are published
         if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(3);                 // the launch's tail: re-spawn and stores
@@ -1969,7 +2005,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
 #else
             if (((dn >> base) & 1ull) && valid) {
 #endif
-                respawn_lane<A, kDrawAhead>(cfg, cold, e, a, ag, er, cx, LIGHTS, sh.draw[lane / A][0], sh.draw[lane / A][1],
+                respawn_lane<A, kDrawAhead>(cfg, cold, e, a, ag, er, cx, false, sh.draw[lane / A][0], sh.draw[lane / A][1],
                                             kDrawAhead ? sh.ego_next[lane / A] : nullptr);
                 respawned = true;                                             // (its second route target: left to the next launch)
             }
@@ -2161,6 +2197,14 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             m = cold.maps[map];
         }
         const float thr2 = thr2_of(cfg);
+        uint32_t red_k = 0u;
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) {
+            // in the wait for barrier B: the env's stop lines into LDS, the red masks of this step and of the next one
+            fill_stop_cache<A>(sh, w, m, lane, a);
+            uint32_t red_n;
+            red_mask_pair(w, m, k, red_k, red_n);
+            if (a == 0) sh.lights[lane / A] = make_int4((int)red_k, (int)red_n, m.stop_base, m.n_stop);
+        }
         lds_barrier();                                       // B
         if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_O2);
         const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
@@ -2168,7 +2212,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         bool off = false, tl = false;
         if (F & TDE_F_OFFROAD) off = box_offroad<true, TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-            tl = tl_violation(w, m, red_mask(w, m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+            tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + m.stop_base, lane / A}, m.n_stop, red_k, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
         const unsigned long long om = __ballot(off), tm = __ballot(tl);
         if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
         // the ego's psi term for judge C (get_reward :403; ring_pre is the rollout kernel's, unused in a one-step launch)
