@@ -167,8 +167,8 @@ def patch_step3(s):
     k = sub(k, "        lds_barrier();                                       // A: off / tl masks and the ego's psi term are in\n",
             "        tde_mark(&stl, 10);\n        lds_barrier();                                       // A: off / tl masks and the ego's psi term are in\n        tde_mark(&stl, 11);\n")
     # judge O
-    k = sub(k, "        const float thr2 = thr2_of(cfg);\n        lds_barrier();                                       // B\n",
-            "        const float thr2 = thr2_of(cfg);\n        tde_mark(&stl, 16);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 17);\n")
+    k = sub(k, "        }\n        lds_barrier();                                       // B\n        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_O2);\n",
+            "        }\n        tde_mark(&stl, 16);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 17);\n        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_O2);\n")
     k = sub(k, "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n",
             "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n        tde_mark(&stl, 18);\n")
     k = sub(k, "reward_psi_term(cold, lpsi, rc.x);\n        lds_barrier();                                       // A\n",
