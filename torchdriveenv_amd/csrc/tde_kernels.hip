@@ -740,13 +740,41 @@ TDE_DEV uint32_t red_mask_cached(const tde_world &w, const tde_map &m, int k, Re
     return rc.red;
 }
 
+#ifndef TDE_RED_GAP_WIDE
+#define TDE_RED_GAP_WIDE 1          // 0: the stop-line loops a line at a time (A/B)
+#endif
 // compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
 // is red.  Mirrors tde_tl_violation of the oracle.
 // `line(i, a, b)` fetches stop line i of the map: (x, y, cos, sin) and (hl, hw, light, -)
 template <typename L>
-TDE_DEV bool tl_violation_of(L &&line, int n_stop, uint32_t red, float x, float y, float c, float s, float hl, float hw)
+TDE_DEV bool tl_violation_of(const L &line, int n_stop, uint32_t red, float x, float y, float c, float s, float hl, float hw)
 {
     bool v = false;
+#if TDE_RED_GAP_WIDE
+    if (red) {
+        // four lines per trip like red_line_gap_of: the reach tests side by side, the four-axis test for the lines in reach (rare)
+        for (int k0 = 0; k0 < n_stop; k0 += 4) {
+            float4 a[4], b[4];
+            if (k0 < L::kCached) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+            }
+            bool near[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dx = a[u].x - x, dy = a[u].y - y, rr = ((hl + hw) + (b[u].x + b[u].y)) * kReach;
+                near[u] = (k0 + u < n_stop) && ((red >> __float_as_int(b[u].z)) & 1u) && dx * dx + dy * dy < rr * rr;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (near[u]) v = v || obb_overlap(x, y, c, s, hl, hw, a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y);
+        }
+    }
+    return v;
+#endif
     if (red) {
         for (int i = 0; i < n_stop; ++i) {
             float4 a, b;
@@ -764,12 +792,15 @@ TDE_DEV bool tl_violation_of(L &&line, int n_stop, uint32_t red, float x, float 
 }
 
 struct GlobalLines {
+    static constexpr int kCached = 0;
     const tde_stopline *base;
     TDE_DEV void operator()(int i, float4 &a, float4 &b) const
     {
         a = reinterpret_cast<const float4 *>(base + i)[0];
         b = reinterpret_cast<const float4 *>(base + i)[1];
     }
+    TDE_DEV void global(int i, float4 &a, float4 &b) const { (*this)(i, a, b); }
+    TDE_DEV void cached(int i, float4 &a, float4 &b) const { (*this)(i, a, b); }
 };
 
 TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, uint32_t red, float x, float y, float c, float s,
@@ -781,10 +812,36 @@ TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, uint32_t red, fl
 // gap to a red stop line ahead in the own lane (same travel direction), treated as a standing leader by the NPC
 // controller.  Mirrors the stop-line loop of the oracle's tde_npc_action.
 template <typename L>
-TDE_DEV float red_line_gap_of(const tde_config &cfg, L &&line, int n_stop, uint32_t red, const Agent &ag, float cp,
+TDE_DEV float red_line_gap_of(const tde_config &cfg, const L &line, int n_stop, uint32_t red, const Agent &ag, float cp,
                               float sp)
 {
     float gap = 1e30f;
+#if TDE_RED_GAP_WIDE
+    // four lines per trip, all fetched first, the four tests side by side and branch-free (a minimum over the same values in
+    // another order: same bits): on the driver's chain a line at a time was four dependent LDS round trips with a branch each
+    for (int k0 = 0; k0 < n_stop; k0 += 4) {
+        float4 a[4], b[4];
+        // (a trip lies wholly inside or wholly outside the LDS cache - its size is a multiple of four: one address space per
+        //  trip.  Left to choose per line, the compiler forms a select of an LDS and a global ADDRESS and the backend rejects it)
+        if (k0 < L::kCached) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ex = a[u].x - ag.x, ey = a[u].y - ag.y;
+            const float fj = ex * cp + ey * sp;
+            const float lj = ey * cp - ex * sp;
+            const float hd = cp * a[u].z + sp * a[u].w;
+            const float g = fj - 0.5f * ag.len;
+            const bool on = (k0 + u < n_stop) && ((red >> __float_as_int(b[u].z)) & 1u) && g > 0.0f && fabsf(lj) < b[u].y && hd > 0.5f;
+            gap = on ? fminf(gap, g + cfg.npc_gap_s0 - 1.0f) : gap;
+        }
+    }
+#else
     for (int k = 0; k < n_stop; ++k) {
         float4 a, b;
         line(k, a, b);
@@ -796,6 +853,7 @@ TDE_DEV float red_line_gap_of(const tde_config &cfg, L &&line, int n_stop, uint3
         const float g = fj - 0.5f * ag.len;
         if (g > 0.0f && fabsf(lj) < b.y && hd > 0.5f) gap = fminf(gap, g + cfg.npc_gap_s0 - 1.0f);
     }
+#endif
     return gap;
 }
 
@@ -1174,6 +1232,10 @@ struct CachedLines {
         if (A >= 8 && i < kStopCache) { a = sh.stop[envw][i][0]; b = sh.stop[envw][i][1]; }
         else { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
     }
+    static constexpr int kCached = A >= 8 ? kStopCache : 0;
+    static_assert(kStopCache % 4 == 0, "red_line_gap_of walks the lines four at a time");
+    TDE_DEV void cached(int i, float4 &a, float4 &b) const { a = sh.stop[envw][i][0]; b = sh.stop[envw][i][1]; }
+    TDE_DEV void global(int i, float4 &a, float4 &b) const { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
 };
 
 
