@@ -163,7 +163,10 @@ def secondary(dev, region_s=0.3):
     def world_of(A, town=False):
         if (A, town) not in worlds:
             worlds.clear()                             # one world resident at a time (a town's tables are ~140 MB)
-            w = synthetic_town(n_scn=256, A=A, seed=0) if town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+            if town == "crowded":                      # ~122 agents in 128 slots per scenario: the reference's assembled scenes (gym_env.py:216-237)
+                w = synthetic_town(n_scn=32, A=A, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4)
+            else:
+                w = synthetic_town(n_scn=256, A=A, seed=0) if town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
             worlds[(A, town)] = (w, w.to_device(dev))
         return worlds[(A, town)]
 
@@ -244,6 +247,12 @@ def secondary(dev, region_s=0.3):
                          config=2, B=1024, A=8, stepwise=False, flags=0)),
         ("lights", dict(name="configs[2] + traffic-light / stop-line term (TDE_F_TRAFFIC_LIGHTS), rollout",
                         config=3, B=8192, A=16, stepwise=False, flags=F | _abi.F_TRAFFIC_LIGHTS)),
+        ("lights_closed_loop", dict(name="the same in closed loop: what BatchedWaypointEnv.step launches on maps that carry traffic lights",
+                                    config=3, B=8192, A=16, stepwise=True, flags=F | _abi.F_TRAFFIC_LIGHTS)),
+        ("agents_128", dict(name="1024 envs x 128 agent slots (~122 present per env: the reference's ~100-agent scenes), rollout",
+                            config=3, B=1024, A=128, stepwise=False, flags=F, town="crowded")),
+        ("agents_128_closed_loop", dict(name="the same in closed loop: one tde_env_step launch per timestep",
+                                        config=3, B=1024, A=128, stepwise=True, flags=F, town="crowded")),
         ("long_episodes", dict(name="configs[2] with episodes that end by truncation at 200 steps only (terminated_at_infraction = 0), rollout",
                                config=3, B=8192, A=16, stepwise=False, flags=F, terminated_at_infraction=0)),
         # the reference's map size (a CARLA town's drivable mesh): ONE 1 km x 1 km map of 5.7e4 triangles, 100

@@ -103,7 +103,7 @@ TDE_API int tde_render_ego(const tde_config *cfg, const tde_world *world, const 
 
 /* The re-spawn of the envs an SB3-style auto-reset has just seen finish, and their first observation, in ONE call: tde_env_reset
  * for the envs with mask[e] != 0 (uint8 [B], required) followed by tde_render_ego of exactly those views - their newest frame
- * rendered again in place, their older stack frames blanked (render->fresh and render->only are set to `mask` by the call; phase
+ * rendered again in place, their older stack frames blanked (render->fresh and render->only are set to `mask` by the call, so its entries must be 0 or 1: the rasteriser reads bits 0-1 of a fresh byte; phase
  * = the phase of the LAST full render).  Replaces: the reset() + get_obs() a VecEnv issues for finished envs
  * (gym_env.py:319-349, 122-124; examples/rl_training.py:159-160). */
 TDE_API int tde_env_reset_render(const tde_config *cfg, const tde_world *world, const tde_state *state, const uint8_t *mask,
