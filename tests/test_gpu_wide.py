@@ -39,11 +39,18 @@ def test_collision_mask_128_slots():
     assert np.array_equal(got, want) and 0 < want.sum() < want.size
 
 
-@pytest.mark.parametrize("lights", [False, True])
+@pytest.mark.parametrize("lights", [False, True, "crowded"])
 def test_env_step_rollout_and_birdview_128_slots(crowded_town, lights):
-    from torchdriveenv_amd.synth import synthetic_world
+    """lights = "crowded": ~100 agents per env AND every junction signalised (light groups of up to 20 stop lines: the NPCs queue
+    at red lines in platoons - the busiest form of the 128-slot sweeps and of the four-lines-per-trip stop-line loops)"""
+    from torchdriveenv_amd.synth import synthetic_town, synthetic_world
 
-    world = synthetic_world(n_scn=4, A=128, seed=9, n_maps=2) if lights else crowded_town
+    world = crowded_town
+    if lights == "crowded":
+        world = synthetic_town(n_scn=6, A=128, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4, n_signals=4)
+        assert world.ints["n_maps"] == 5 and world.arrays["maps"]["n_stop"].max() >= 12
+    elif lights:
+        world = synthetic_world(n_scn=4, A=128, seed=9, n_maps=2)
     flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0)
     cfg = _abi.default_config(seed=41, distance_cutoff=0.25, flags=flags, max_steps=50)
     B, A = 20, 128
