@@ -135,6 +135,17 @@ TDE_API int tde_state_obs(const tde_world *world, const tde_state *state, float 
  * is: call it after a step WITHOUT TDE_F_AUTORESET and before tde_env_reset re-spawns the finished envs. */
 TDE_API int tde_ego_infractions(const tde_config *cfg, const tde_world *world, const tde_state *state, float *out, void *stream);
 
+/* What follows a step that was launched WITHOUT TDE_F_AUTORESET, in one launch (one wavefront per env):
+ *  (a) magnitudes != NULL: magnitudes[e] = tde_ego_infractions' four values for the state that step left - computed only for the
+ *      envs whose ego the step flagged (state.collided / state.offroad of slot 0; a magnitude is zero without its flag), so the
+ *      flags in `state` must be those of that step;
+ *  (b) with TDE_F_AUTORESET in config->flags: tde_env_reset for the envs the step finished (terminated | truncated; the two
+ *      arrays keep the step's values) and, when state.obs is set, the compact observation of their new episode.
+ * step (no auto-reset) + this = the one-launch step's results, plus the reference's info["offroad" | "collision"] values
+ * (gym_env.py:427-428).  Replaces: simulator.compute_offroad() / compute_collision() for the exposed agent followed by the
+ * reset() a VecEnv issues for finished envs (gym_env.py:319-349; examples/rl_training.py:159-160). */
+TDE_API int tde_env_post_step(const tde_config *config, const tde_world *world, const tde_state *state, float *magnitudes, void *stream);
+
 /* ---- host side: static tables ------------------------------------------------------------------------------------ */
 
 /* Offroad grid index of ONE drivable mesh - what the simulator prepares once per map from the road mesh it is constructed

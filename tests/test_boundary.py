@@ -114,7 +114,7 @@ def test_torch_extension_builds_in_tree_and_binds_the_same_abi():
     assert "libtde_hip.so" in dyn and "$ORIGIN/.." in dyn
     m = _ext.load()
     assert m.abi_version() == _lib.load().tde_abi_version() == _abi.TDE_ABI_VERSION
-    for meth in ("step", "reset", "rollout", "render", "step_render", "state_obs", "ego_infractions", "reset_render"):
+    for meth in ("step", "reset", "rollout", "render", "step_render", "state_obs", "ego_infractions", "reset_render", "post_step"):
         assert hasattr(m.EnvHandle, meth)
     assert hasattr(m, "Config") and hasattr(m, "World")             # typed carriers: no raw addresses cross the boundary
     with pytest.raises(RuntimeError, match="bytes"):

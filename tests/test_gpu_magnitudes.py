@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from oracle import oracle  # noqa: E402
-from tests.test_gpu_parity import dev  # noqa: E402
+from tests.test_gpu_parity import assert_state_equal, dev  # noqa: E402
 from torchdriveenv_amd import _abi, ops  # noqa: E402
 from torchdriveenv_amd.state import EnvState  # noqa: E402
 
@@ -69,15 +69,63 @@ def test_ego_infraction_magnitudes_town_and_128_slots(town):
     assert want[:, 2].max() >= 1.0 and 0.0 < want[:, 1].max() <= want[:, 2].max()   # crowded scenes: the ego overlaps somebody
 
 
-def test_batched_env_info_magnitudes_equals_the_one_launch_step(small_world):
-    """BatchedWaypointEnv(info_magnitudes=True) - step without in-kernel re-spawn, tde_ego_infractions, masked reset - gives the
+@pytest.mark.parametrize("A,squared", [(16, 0), (16, 1), (128, 0)])
+def test_post_step_equals_magnitudes_then_masked_reset(small_world, A, squared):
+    """tde_env_post_step after a step without TDE_F_AUTORESET == tde_ego_infractions (every env, ungated) + tde_env_reset of the
+    finished envs + tde_state_obs, and == the oracle: magnitudes, state, compact observation, bit for bit - the gate (magnitudes
+    only for the envs the step flagged) never changes a value"""
+    from torchdriveenv_amd.synth import synthetic_town, synthetic_world
+
+    world = small_world
+    if squared:
+        world = synthetic_world(n_scn=8, A=16, seed=0, n_maps=2, threshold=float(np.sqrt(0.5)))
+    if A == 128:
+        world = synthetic_town(n_scn=4, A=128, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4)
+    B = 96 if A == 16 else 24
+    flags = _abi.F_ALL & ~_abi.F_AUTORESET
+    cfg = _abi.default_config(seed=17, flags=flags, max_steps=30, offroad_threshold_squared=squared, distance_cutoff=0.25)
+    cfg_post = _abi.TdeConfig.from_buffer_copy(cfg)
+    cfg_post.flags |= _abi.F_AUTORESET
+    dw = world.to_device(DEV)
+    hs = EnvState(B, A)
+    d1, d2 = EnvState(B, A, device=DEV, with_obs=True), EnvState(B, A, device=DEV, with_obs=True)
+    oracle.env_reset(cfg, world, hs)
+    d1.load(hs.host()); d2.load(hs.host())
+    rng = np.random.default_rng(4)
+    mag = torch.zeros(B, 4, device=DEV)
+    n_done = n_off = 0
+    for t in range(70):
+        act = np.stack([rng.uniform(-0.2, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        oracle.env_step(cfg, world, hs)
+        want = oracle.ego_infractions(cfg, world, hs)
+        done = (hs["terminated"] | hs["truncated"]).astype(np.uint8)
+        oracle.env_reset(cfg, world, hs, done)
+        for d in (d1, d2):
+            ops.env_step(cfg, dw, d, action=dev(act))
+        ops.env_post_step(cfg_post, dw, d1, mag)                                  # one launch
+        got2 = ops.ego_infractions(cfg, dw, d2)                                    # three
+        ops.env_reset(cfg, dw, d2, dev(done))
+        ops.state_obs(dw, d2, d2["obs"])
+        assert np.array_equal(mag.cpu().numpy().view(np.uint32), want.view(np.uint32)), t
+        assert torch.equal(mag, got2), t
+        assert torch.equal(d1["obs"], d2["obs"]), t
+        n_done += int(done.sum()); n_off += int((want[:, 0] > 0).sum())
+    assert_state_equal(hs.host(), d1.host(), "post_step vs oracle")
+    assert_state_equal(d2.host(), d1.host(), "post_step vs the three launches")
+    assert n_done > 20 and n_off > 5
+
+
+@pytest.mark.parametrize("obs_mode,frame_stack", [("birdview", 3), ("state", 1)])
+def test_batched_env_info_magnitudes_equals_the_one_launch_step(small_world, obs_mode, frame_stack):
+    """BatchedWaypointEnv(info_magnitudes=True) - step without in-kernel re-spawn, then tde_env_post_step - gives the
     observations, rewards, flags and episodes of the one-launch step, and info["offroad"] / info["collision"] are the oracle's
     magnitudes of the state the step left (the reference's info semantics) instead of 0 / 1"""
     from torchdriveenv_amd.config import EnvConfig
     from torchdriveenv_amd.env import BatchedWaypointEnv
 
     B = 160
-    kw = dict(num_envs=B, agents_per_env=16, obs_mode="birdview", frame_stack=3)
+    kw = dict(num_envs=B, agents_per_env=16, obs_mode=obs_mode, frame_stack=frame_stack)
     plain = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, **kw)
     mag = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, info_magnitudes=True, **kw)
     hs = EnvState(B, 16)

@@ -3059,6 +3059,18 @@ int tde_ego_infractions(const tde_config *cfg, const tde_world *world, const tde
     return e == hipSuccess ? 0 : fail("tde_ego_infractions", e);
 }
 
+int tde_env_post_step(const tde_config *cfg, const tde_world *world, const tde_state *st, float *magnitudes, void *stream)
+{
+    int rc = check_env_args("tde_env_post_step", cfg, world, st);
+    if (rc) return rc;
+    if (st->B <= 0) return 0;
+    if (!st->terminated || !st->truncated || !st->collided || !st->offroad) return bad("tde_env_post_step: the state lacks the step's flag arrays");
+    const unsigned nb = (unsigned)((st->B + (tde::kBlock / tde::kWave) - 1) / (tde::kBlock / tde::kWave));
+    TDE_DISPATCH_A128(st->A, tde::env_post_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, magnitudes));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("tde_env_post_step", e);
+}
+
 int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void *stream)
 {
     if (!world || !st || !out) return bad("tde_state_obs: world/state/out is NULL");

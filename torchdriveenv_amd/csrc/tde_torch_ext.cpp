@@ -282,6 +282,15 @@ class EnvHandle {
         check_rc(tde_ego_infractions(&cfg_, &world_, &state_, p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_ego_infractions");
     }
 
+    // tde_env_post_step: magnitudes (optional) of the state a step without TDE_F_AUTORESET left + the re-spawn of the envs it finished
+    void post_step(const std::optional<at::Tensor> &mag, int64_t flags)
+    {
+        float *p = mag ? static_cast<float *>(const_cast<void *>(dev_ptr(*mag, at::kFloat, (int64_t)state_.B * 4, "magnitudes", dev_))) : nullptr;
+        cfg_.flags = static_cast<uint32_t>(flags);
+        const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev_);
+        check_rc(tde_env_post_step(&cfg_, &world_, &state_, p, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev_.index()).stream()), "tde_env_post_step");
+    }
+
     int64_t flags() const { return cfg_.flags; }
     int64_t num_envs() const { return state_.B; }
     int64_t agents_per_env() const { return state_.A; }
@@ -414,6 +423,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
              py::arg("n_stack"), py::arg("layers"), py::arg("phase"), py::arg("rflags"))
         .def("state_obs", &EnvHandle::state_obs)
         .def("ego_infractions", &EnvHandle::ego_infractions, py::arg("out"), py::arg("flags"))
+        .def("post_step", &EnvHandle::post_step, py::arg("magnitudes"), py::arg("flags"))
         .def_property_readonly("flags", &EnvHandle::flags)
         .def_property_readonly("num_envs", &EnvHandle::num_envs)
         .def_property_readonly("agents_per_env", &EnvHandle::agents_per_env);

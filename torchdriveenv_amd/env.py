@@ -362,33 +362,35 @@ class BatchedWaypointEnv:
         return obs, st["reward"], term, trunc, _LazyInfo(st, self.num_envs, self.A)
 
     def _step_with_magnitudes(self, a):
-        """step -> magnitudes of the ego's infractions on the state the step left -> re-spawn of the finished envs (masked reset,
-        their views re-rendered, their frame stacks restarted): the results of the one-launch step, plus info["offroad"] /
-        info["collision"] as the reference reports them"""
+        """step without in-kernel re-spawn -> tde_env_post_step (the magnitudes of the infractions the step flagged + the re-spawn of
+        the envs it finished, one launch) -> the observation: the results of the one-launch step, plus info["offroad"] /
+        info["collision"] as the reference reports them (two launches per step, three with the birdview)"""
         st = self.state
-        auto = self.auto_reset
-        flags = int(self.tde_cfg.flags) & ~_abi.F_AUTORESET
-        saved = self.tde_cfg.flags
+        full = int(self.tde_cfg.flags)
+        flags = full & ~_abi.F_AUTORESET
+        post = flags | (_abi.F_AUTORESET if self.auto_reset else 0)
         self.tde_cfg.flags = flags
         try:
             if self._h is not None:
                 self._h.step(a, flags)
+                self._h.post_step(self._mag, post)
             else:
                 ops.env_step(self.tde_cfg, self.dworld, st, action=a)
-            if self._h is not None:
-                self._h.ego_infractions(self._mag, flags)
-            else:
-                ops.ego_infractions(self.tde_cfg, self.dworld, st, self._mag)
+                self.tde_cfg.flags = post
+                ops.env_post_step(self.tde_cfg, self.dworld, st, self._mag)
         finally:
-            self.tde_cfg.flags = saved
-        # (outputs of the step are kept by value: the reset below zeroes nothing of them but `obs` / counters move on)
-        reward, term, trunc = st["reward"], st["terminated"].view(torch.bool), st["truncated"].view(torch.bool)
+            self.tde_cfg.flags = full
+        term, trunc = self._flag_views()
         info = _LazyInfo(st, self.num_envs, self.A, magnitudes=self._mag)
-        obs = self.get_obs()                                          # the frame of the state the step left (every view)
-        if auto:
-            # the finished envs re-spawn; only their views are rendered again, their frame stacks restart blank
-            obs = self.reset(mask=st["terminated"] | st["truncated"])
-        return obs, reward, term, trunc, info
+        if self.obs_mode == "state":
+            obs = st["obs"]                                           # written by the step, refreshed by the re-spawn
+        else:
+            # the finished envs were re-spawned: their frame stacks restart blank (bits 0-1 of done_bits = the step's done flags)
+            fresh = None
+            if self.auto_reset and self.frame_stack > 1:
+                fresh = st["done_bits"] if st["done_bits"] is not None else (st["terminated"] | st["truncated"])
+            obs = self.get_obs(fresh)
+        return obs, st["reward"], term, trunc, info
 
     def rollout(self, actions):
         """K open-loop steps from a resident [K,B,2] action tensor -> (reward [K,B], done bits [K,B]).  (The Monitor-style

@@ -181,6 +181,18 @@ def ego_infractions(cfg, dworld, state, out=None):
     return out
 
 
+def env_post_step(cfg, dworld, state, magnitudes=None):
+    """tde_env_post_step, after a step made WITHOUT TDE_F_AUTORESET: `magnitudes` (float32 [B, 4], optional) = ego_infractions of the
+    state that step left, computed only for the envs it flagged; with TDE_F_AUTORESET in cfg.flags the envs it finished are
+    re-spawned (their compact observation refreshed when the state carries one).  One launch.  Returns `magnitudes`."""
+    L = _lib.load()
+    dev = state.device
+    p = None if magnitudes is None else _chk(magnitudes, torch.float32, 4 * state.B, "magnitudes", torch.device(dev))
+    _lib.check(_call(dev, L.tde_env_post_step, C.byref(cfg), C.byref(dworld.struct), C.byref(state.struct), p, _lib.current_stream(dev)),
+               "tde_env_post_step")
+    return magnitudes
+
+
 def state_obs(dworld, state, out=None):
     """compact kinematic observation of every ego -> float32 [B, 8] on device: x, y, psi, v, target waypoint offset in
     the ego frame (forward, left), target-exists flag, environment_steps"""
