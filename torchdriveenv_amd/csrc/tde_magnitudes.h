@@ -34,16 +34,16 @@ TDE_DEV void box_corners_ccw(float x, float y, float c, float s, float hl, float
     px[3] = (x + lx) + wx; py[3] = (y + ly) - wy;
 }
 
-// `poly`: this lane's column of a [32][64]-float LDS block (element k of the lane at poly[64 * k]): the two vertex lists of the
-// clipping.  As private arrays they are indexed dynamically and live in scratch MEMORY - every access a global-memory round trip
+// `poly`: 32 floats of LDS, the two vertex lists of the clipping (the overlapping pairs of a wavefront take turns: there is rarely
+// more than one).  As private arrays they are indexed dynamically and live in scratch MEMORY - every access a global-memory round trip
 // on a chain of ~300 of them: 15 us for one pair of boxes, which the whole launch then waits for (profiles/r04_z_magnitudes_cost.txt).
 TDE_DEV float box_iou(float x0, float y0, float c0, float s0, float hl0, float hw0, float x1, float y1, float c1,
                       float s1, float hl1, float hw1, float *poly)
 {
-#define TDE_AX(i) poly[64 * (i)]
-#define TDE_AY(i) poly[64 * (8 + (i))]
-#define TDE_BX(i) poly[64 * (16 + (i))]
-#define TDE_BY(i) poly[64 * (24 + (i))]
+#define TDE_AX(i) poly[(i)]
+#define TDE_AY(i) poly[8 + (i)]
+#define TDE_BX(i) poly[16 + (i)]
+#define TDE_BY(i) poly[24 + (i)]
     float px[4], py[4], qx[4], qy[4];
     int n = 4;
     box_corners_ccw(x0, y0, c0, s0, hl0, hw0, px, py);
@@ -137,7 +137,11 @@ TDE_DEV float point_mesh_d2_wave(const tde_world &w, const tde_map &m, float px,
             const bool dup = (lane >= 1 && cx > x0 && left == cw) || (nxs < 64 && lane >= nxs && up == cw);
             if ((cw & 3u) != TDE_CELL_MIXED || dup) continue;
             const int n = (int)((cw >> 2) & 255u);
-            for (int k = 0; k < n; ++k) b = fminf(b, point_tri_d2_packed(px, py, recs + 3 * (size_t)((cw >> 10) + (uint32_t)k)));
+            for (int k = 0; k < n; k += 2) {                         // two records per trip: their loads and tests side by side
+                const float d0 = point_tri_d2_packed(px, py, recs + 3 * (size_t)((cw >> 10) + (uint32_t)k));
+                const float d1 = point_tri_d2_packed(px, py, recs + 3 * (size_t)((cw >> 10) + (uint32_t)(k + 1 < n ? k + 1 : k)));
+                b = fminf(b, fminf(d0, d1));
+            }
         }
         best = fminf(best, wave_min(b));
         const bool whole = x0 == 0 && y0 == 0 && x1 == m.nx - 1 && y1 == m.ny - 1;
@@ -166,7 +170,7 @@ TDE_DEV EgoBox ego_box(const tde_state &st, int64_t g0)
     return b;
 }
 
-// collision: (sum of the IoUs with the overlapping agents, in slot order; their number).  iou_of: A floats, poly: 32 x 64 floats of
+// collision: (sum of the IoUs with the overlapping agents, in slot order; their number).  iou_of: A floats, poly: 32 floats of
 // LDS of this wavefront
 TDE_DEV float2 ego_collision_mag(const tde_state &st, int64_t g0, const EgoBox &eb, int lane, float *iou_of, float *poly)
 {
@@ -181,10 +185,17 @@ TDE_DEV float2 ego_collision_mag(const tde_state &st, int64_t g0, const EgoBox &
             sincos_f32(st.psi[g0 + j], sj, cj);
             const float xj = st.x[g0 + j], yj = st.y[g0 + j], hlj = 0.5f * st.len[g0 + j], hwj = 0.5f * st.wid[g0 + j];
             hit = obb_overlap(eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, xj, yj, cj, sj, hlj, hwj);
-            if (hit) v = box_iou(eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, xj, yj, cj, sj, hlj, hwj, poly + lane);
+        }
+        const unsigned long long hm = __ballot(hit);
+        for (unsigned long long rest = hm; rest; rest &= rest - 1) {    // one overlapping pair at a time through the 32 floats of LDS
+            if (lane == __ffsll((long long)rest) - 1) {
+                float sj, cj;
+                sincos_f32(st.psi[g0 + j], sj, cj);
+                v = box_iou(eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, st.x[g0 + j], st.y[g0 + j], cj, sj, 0.5f * st.len[g0 + j], 0.5f * st.wid[g0 + j], poly);
+            }
         }
         if (j < A) iou_of[j] = v;
-        nhit += (int)__popcll(__ballot(hit));
+        nhit += (int)__popcll(hm);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wavefront's own LDS stores have landed
     float cmag = 0.0f;
@@ -212,7 +223,7 @@ TDE_DEV float ego_corner_term(const tde_config &cfg, const tde_world &w, const t
 __global__ __launch_bounds__(kBlock) void ego_infractions_kernel(tde_config cfg, tde_world w, tde_state st, float *__restrict__ out)
 {
     __shared__ float iou_of[kBlock / kWave][TDE_MAX_AGENTS];     // per env: the IoU with every slot, summed in slot order
-    __shared__ float poly[kBlock / kWave][32 * 64];                // per wavefront: box_iou's vertex lists
+    __shared__ float poly[kBlock / kWave][32];                     // per wavefront: box_iou's vertex lists
     const int lane = (int)(threadIdx.x & 63u);
     const int e = (int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
     if (e >= st.B) return;                                           // (wave-uniform)
@@ -244,7 +255,7 @@ template <int A>
 __global__ __launch_bounds__(kBlock) void env_post_step_kernel(tde_config cfg, tde_world w, tde_state st, float *__restrict__ out)
 {
     __shared__ float iou_of[kBlock / kWave][TDE_MAX_AGENTS];
-    __shared__ float poly[kBlock / kWave][32 * 64];
+    __shared__ float poly[kBlock / kWave][32];
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
     const int e = (int)(blockIdx.x * (kBlock / kWave) + wv);
     if (e >= st.B) return;                                           // (wave-uniform, like every branch below but the slot guards)
