@@ -111,7 +111,7 @@ def test_iou_positive_iff_oracle_sat_overlap(b0, b1):
     gap = sat_gap(b0, b1)
     got = oracle_collides(b0, b1)
     if gap == 0.0:                     # exactly touching (representable): zero-area contact is not a collision on either side
-        assert iou(b0, b1) == 0.0 and got is False
+        assert iou(b0, b1) < 1e-12 and got is False        # (the float64 clip of a rotated touching pair may leave rounding dust)
         return
     if abs(gap) < 1e-4:                # the knife edge: fp32 rounding of either implementation may decide
         return
