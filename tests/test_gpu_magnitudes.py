@@ -154,3 +154,36 @@ def test_batched_env_info_magnitudes_equals_the_one_launch_step(small_world, obs
     for k in ("x", "y", "psi", "v", "steps", "episode", "scn"):
         assert torch.equal(plain.state[k], mag.state[k]), k
     assert seen > 10 and int(plain.state["episode"].max()) > 1
+
+
+def test_vecenv_with_info_magnitudes_equals_the_plain_vecenv(small_world):
+    """the SB3 path over BatchedWaypointEnv(info_magnitudes=True): WaypointVecEnv clears TDE_F_AUTORESET for its own masked reset,
+    so tde_env_post_step computes magnitudes and re-spawns NOTHING - observations, rewards, dones, terminal observations and
+    episode statistics equal the plain VecEnv's, and the info columns carry the magnitudes"""
+    from torchdriveenv_amd.config import EnvConfig
+    from torchdriveenv_amd.env import BatchedWaypointEnv, WaypointVecEnv
+
+    B = 96
+    cfg = EnvConfig(seed=12, distance_cutoff=0.25, max_environment_steps=40)
+    kw = dict(num_envs=B, agents_per_env=16, obs_mode="state")
+    v0 = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, **kw))
+    v1 = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, info_magnitudes=True, **kw))
+    assert np.array_equal(v0.reset(), v1.reset())
+    rng = np.random.default_rng(3)
+    n_done = n_mag = 0
+    for t in range(90):
+        acts = np.stack([rng.uniform(-0.5, 1, B), rng.uniform(-0.3, 0.3, B)], -1)
+        o0, r0, d0, i0 = v0.step(acts)
+        o1, r1, d1, i1 = v1.step(acts)
+        assert np.array_equal(o0, o1) and np.array_equal(r0, r1) and np.array_equal(d0, d1), t
+        for i in np.nonzero(d0)[0]:
+            a, b = i0[int(i)], i1[int(i)]
+            assert np.array_equal(a["terminal_observation"], b["terminal_observation"]) and a["episode"]["r"] == b["episode"]["r"] and a["episode"]["l"] == b["episode"]["l"]
+            assert (a["offroad"] > 0) == (b["offroad"] > 0) and (a["collision"] > 0) == (b["collision"] > 0)
+            if b["offroad"] > 0:
+                n_mag += 1
+                assert a["offroad"] == 1.0 and b["offroad"] != 1.0       # an indicator there, a distance here
+            n_done += 1
+    for k in ("x", "y", "psi", "episode", "scn", "steps"):
+        assert torch.equal(v0.env.state[k], v1.env.state[k]), k
+    assert n_done > 30 and n_mag > 3

@@ -368,7 +368,7 @@ class BatchedWaypointEnv:
         st = self.state
         full = int(self.tde_cfg.flags)
         flags = full & ~_abi.F_AUTORESET
-        post = flags | (_abi.F_AUTORESET if self.auto_reset else 0)
+        post = flags | (full & _abi.F_AUTORESET)            # (WaypointVecEnv.step_wait clears the flag: it re-spawns the envs itself)
         self.tde_cfg.flags = flags
         try:
             if self._h is not None:
@@ -387,7 +387,7 @@ class BatchedWaypointEnv:
         else:
             # the finished envs were re-spawned: their frame stacks restart blank (bits 0-1 of done_bits = the step's done flags)
             fresh = None
-            if self.auto_reset and self.frame_stack > 1:
+            if (full & _abi.F_AUTORESET) and self.frame_stack > 1:
                 fresh = st["done_bits"] if st["done_bits"] is not None else (st["terminated"] | st["truncated"])
             obs = self.get_obs(fresh)
         return obs, st["reward"], term, trunc, info
