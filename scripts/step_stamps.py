@@ -1,5 +1,5 @@
 """Milestones of the three-role one-step kernel (make_stamped_build.py step3): ticks since the wavefront entered the kernel.
-usage: python scripts/make_stamped_build.py step3 && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/step_stamps.py"""
+usage: python scripts/make_stamped_build.py step3 && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/step_stamps.py [--lights]"""
 import ctypes as C
 import os
 import sys
@@ -16,7 +16,8 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
-cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
+LIGHTS = "--lights" in sys.argv
+cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=_abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if LIGHTS else 0))
 _lib.kernel_override(step="trio")
 st = EnvState(B, A, device=dev, with_info=False)
 ops.env_reset(cfg, dw, st)
@@ -34,7 +35,7 @@ e1.record()
 torch.cuda.synchronize()
 lib.tde_debug_stamps(out, 0)
 n = (B * A // 64) * N
-print(f"{e0.elapsed_time(e1) * 1e3 / N:.2f} us per step (stamped build)")
+print(f"{e0.elapsed_time(e1) * 1e3 / N:.2f} us per step (stamped build, lights={int(LIGHTS)})")
 names = {0: "D: entry -> state + cache loaded", 1: "D: controller", 2: "D: bicycle, route switch, sincos, rows", 3: "D: wait B",
          6: "D: next-step controller (action cache)", 4: "D: wait A", 5: "D: done test, re-spawn, stores",
          8: "C: entry -> prologue done", 9: "C: wait B", 12: "C: collision", 10: "C: reward (dist, reach, smoothness)", 11: "C: wait A",
