@@ -28,19 +28,13 @@ def timed(fn, n=200):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
+import copy
+coll0, off0 = st["collided"].clone(), st["offroad"].clone()
 print(f"launch only (no magnitudes, no re-spawn) {timed(lambda: ops.env_post_step(na, dw, st, None)):.2f} us")
 print(f"magnitudes only                          {timed(lambda: ops.env_post_step(na, dw, st, mag)):.2f} us")
-print(f"tde_ego_infractions (every env)          {timed(lambda: ops.ego_infractions(na, dw, st, mag)):.2f} us")
+st["offroad"].zero_()
+print(f"magnitudes, collision flags only         {timed(lambda: ops.env_post_step(na, dw, st, mag)):.2f} us")
+st["offroad"].copy_(off0); st["collided"].zero_()
+print(f"magnitudes, offroad flags only           {timed(lambda: ops.env_post_step(na, dw, st, mag)):.2f} us   (max {float(mag[:, 0].max()):.2f} m)")
+st["collided"].copy_(coll0)
 print(f"re-spawn only                            {timed(lambda: ops.env_post_step(cfg, dw, st, None)):.2f} us")
-print(f"tde_env_reset(mask)                      {timed(lambda: ops.env_reset(cfg, dw, st, done)):.2f} us")
-print(f"tde_env_step                             {timed(lambda: ops.env_step(na, dw, st, action=acts[3])):.2f} us")
-nc = _abi.TdeConfig.from_buffer_copy(na); nc.flags &= ~_abi.F_OFFROAD
-print(f"magnitudes, collision only               {timed(lambda: ops.env_post_step(nc, dw, st, mag)):.2f} us")
-st["collided"].zero_()
-print(f"magnitudes, offroad only                 {timed(lambda: ops.env_post_step(na, dw, st, mag)):.2f} us")
-off = st["offroad"].view(B, A)[:, 0].clone()
-for keep in (1, 8, 32):
-    idx = off.nonzero().flatten()
-    st["offroad"].view(B, A)[:, 0] = 0
-    st["offroad"].view(B, A)[idx[:keep], 0] = 1
-    print(f"magnitudes, offroad only, {keep:2d} envs flagged {timed(lambda: ops.env_post_step(na, dw, st, mag)):.2f} us   max term {float(mag[:, 0].max()):.3f}")
