@@ -73,12 +73,19 @@ def test_env_step_rollout_and_birdview_128_slots(crowded_town, lights):
             got = ops.render_ego(cfg, dw, ds).cpu().numpy()
             assert np.array_equal(got, want), f"{(got != want).sum()} pixels differ at step {t}"
     assert hs["episode"].max() > 1 and hs["collided"].sum() >= 0
-    K = 25
-    actions = np.stack([rng.uniform(-0.3, 1, (K, B)), rng.uniform(-0.2, 0.2, (K, B))], -1).astype(np.float32)
-    hr, hd = oracle.env_rollout(cfg, world, hs, actions)
-    dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
-    assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)) and np.array_equal(dd.cpu().numpy(), hd)
-    assert_state_equal(hs.host(), ds.host(), "rollout, 128 slots")
+    from torchdriveenv_amd import _lib
+
+    try:
+        for team in ("duo", "solo", None):                            # two roles (four wavefronts per env), one role, the dispatch rule
+            _lib.kernel_override(rollout=team)
+            K = 25 if team else 60                                    # (60 steps: re-spawns inside the launch, max_steps = 50)
+            actions = np.stack([rng.uniform(-0.3, 1, (K, B)), rng.uniform(-0.2, 0.2, (K, B))], -1).astype(np.float32)
+            hr, hd = oracle.env_rollout(cfg, world, hs, actions)
+            dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+            assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)) and np.array_equal(dd.cpu().numpy(), hd), team
+            assert_state_equal(hs.host(), ds.host(), f"rollout, 128 slots, {team}")
+    finally:
+        _lib.kernel_override()
 
 
 def test_batched_env_with_128_slots(crowded_town):

@@ -1452,6 +1452,226 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 #undef TDE_ROLE_PROLOGUE
 
 // ------------------------------------------------------------------------------------------------------------------
+// The two-role rollout for 128 agent slots per env (the reference's ~100-agent scenes): ONE env per workgroup of four
+// wavefronts - drive (slots 0-63), drive (64-127), judge (0-63), judge (64-127).  The one-role kernel runs both 128-row
+// sweeps of a slot one behind the other in a single wavefront (3130 VALU per wave-step, 11 us per step with two wavefronts per
+// SIMD: a latency chain); here the controller's sweep and the collision sweep of a step run side by side as in the
+// narrower kernels, with the same two barriers per step.  What differs from env_rollout_duo_kernel: a lane's slot is
+// (wavefront & 1) * 64 + lane, the sweeps are the *_wide forms (two 64-row halves), and the env's done flag is one word
+// written by the judge's ego lane instead of a ballot (read by every wavefront behind the next barrier A, where the
+// judges also do their own re-spawn bookkeeping).  Same per-agent arithmetic in the same order: same bits.
+// ------------------------------------------------------------------------------------------------------------------
+struct WideShared {
+    float4 a[2][128], b[2][128], c[2][128];
+    int done;                            // the env finished at the last judged step (and auto-reset is on)
+    float4 stop[kStopCache][2];          // the first kStopCache stop lines of the env's map
+};
+struct WideLines {
+    const WideShared &sh;
+    const tde_stopline *base;
+    static constexpr int kCached = kStopCache;
+    TDE_DEV void cached(int i, float4 &a, float4 &b) const { a = sh.stop[i][0]; b = sh.stop[i][1]; }
+    TDE_DEV void global(int i, float4 &a, float4 &b) const { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
+    TDE_DEV void operator()(int i, float4 &a, float4 &b) const { if (i < kStopCache) cached(i, a, b); else global(i, a, b); }
+};
+TDE_DEV void fill_stop_cache_wide(WideShared &sh, const tde_world &w, const tde_map &m, int a)
+{
+    for (int i = a; i < kStopCache && i < m.n_stop; i += 128) {
+        const float4 *src = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i));
+        sh.stop[i][0] = src[0];
+        sh.stop[i][1] = src[1];
+    }
+}
+TDE_DEV void write_rows_wide(WideShared &sh, int buf, int a, bool live, const Agent &ag, float c, float s, float lane_half)
+{
+    write_tile_slot(sh.a[buf][a], sh.b[buf][a], live, ag, c, s, lane_half);
+    sh.c[buf][a] = make_float4(ag.psi, ag.v, live ? 1.0f : 0.0f, 0.0f);
+}
+
+#ifndef TDE_WIDE2_WAVES
+#define TDE_WIDE2_WAVES 4
+#endif
+template <bool LIGHTS>
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(tde_config cfg, tde_world w, tde_state st,
+                                                                     tde_rollout ro)
+{
+    constexpr int A = 128;
+    __shared__ WideShared sh;
+    __shared__ Cold cold;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = wv >> 1;                               // 0 = drive, 1 = judge
+    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
+    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0; }
+    const uint32_t F = cfg.flags;
+    const int e = (int)blockIdx.x;                          // (the grid is B workgroups: every env is valid)
+    const int64_t g = (int64_t)e * A + a;
+    const int LB = ro.ldb;
+    __syncthreads();                                         // cold is filled
+    // (every role loads its own copy of the per-lane state inside its branch: nothing live across the role switch)
+#define TDE_WIDE_PROLOGUE                                                                                 \
+    Agent ag;                                                                                             \
+    load_agent(st, g, ag);                                                                                \
+    EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};                   \
+    Ctx cx;                                                                                               \
+    load_ctx<A>(cfg, cold, a, ag, er, cx);                                                                \
+    RedCache redc; redc.invalidate();
+    if (role == 0) {
+        // ================================ drive ================================
+        TDE_WIDE_PROLOGUE
+        __builtin_amdgcn_s_setprio(3);
+        float c0, s0;
+        sincos_f32(ag.psi, s0, c0);
+        write_rows_wide(sh, 1, a, ag.present, ag, c0, s0, cfg.npc_lane_half);
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache_wide(sh, w, cx.m, a);
+        lds_barrier();                                       // rows of the launch state are in buffer 1
+        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
+        float2 act = acts[e];
+        RewardOut rw{};
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1, q = p ^ 1;
+            const int kn = (i + 1 < ro.K) ? i + 1 : i;
+            const float2 act_next = acts[(int64_t)kn * LB + e];
+            float nx, ny, npsi, nv, nc, ns;
+            float na = 0.0f, nb = 0.0f;
+            int nwp, k, n_target = er.target_idx, n_reached = er.reached;
+            bool switched, live;
+            for (int pass = 0;; ++pass) {
+                k = er.steps + 1;                                                            // :116
+                live = ag.present;
+                const bool npc = (F & TDE_F_NPC) && a > 0 && live;
+                const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
+                float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
+                const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                float acc = 0.0f, beta = 0.0f;
+                if (a == 0) { acc = act.x; beta = act.y; }
+                if (F & TDE_F_NPC) {
+                    if (pass == 0) {                         // (a second pass = a re-spawn: first step, the NPCs coast)
+                        const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
+                        const float red_gap =
+                            (LIGHTS && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+                        npc_action_wide<A>(cfg, &sh.a[q][0], &sh.b[q][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+                    }
+                    if (npc && k > 1) { acc = na; beta = nb; }
+                }
+                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
+                if (live) {
+                    bicycle(nx, ny, npsi, nv, ag.inv_lr, acc, beta, cfg.dt);                      // :117
+                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
+                }
+                switched = false;
+                nwp = ag.route_wp;
+                if (has_target) {
+                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;
+                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
+                }
+                sincos_f32(npsi, ns, nc);
+                if ((F & TDE_F_REWARD) && a == 0) {           // the ego's reward arithmetic (:391-411, :378-383), as in the duo kernel
+                    n_target = er.target_idx; n_reached = er.reached;
+                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, ag.x, ag.y, ag.psi, ag.v, nx, ny, npsi, nv, false,
+                                     false, false, k, n_target, n_reached, st.info != nullptr);
+                }
+                if (pass) break;
+                lds_barrier();                               // A: done(i-1) is published
+                if (!sh.done) break;
+                // the env finished at step i-1: re-spawn (as step_lane does in place), rows into buffer q, recompute the step
+                reset_lane<A>(cfg, cold, e, a, ag, er);
+                load_ctx<A>(cfg, cold, a, ag, er, cx);
+                redc.invalidate();
+                sincos_f32(ag.psi, s0, c0);
+                write_rows_wide(sh, q, a, ag.present, ag, c0, s0, cfg.npc_lane_half);
+                if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache_wide(sh, w, cx.m, a);
+            }
+            ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
+            c0 = nc; s0 = ns;
+            er.steps = k;
+            write_rows_wide(sh, p, a, live, ag, c0, s0, cfg.npc_lane_half);
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            if (switched) load_route_target(cold, ag, cx);
+            if (a == 0) {
+                if (F & TDE_F_REWARD) {
+                    const bool advanced = n_target != er.target_idx;
+                    er.target_idx = n_target; er.reached = n_reached;
+                    if (st.info) {
+                        double *inf = st.info + 4 * (int64_t)e;
+                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
+                    }
+                    if (st.info_reached) st.info_reached[e] = er.reached;
+                    if (advanced) load_ego_target(cold, er, cx);
+                }
+                if (ro.reward) ro.reward[(int64_t)i * LB + e] = rw.reward;
+            }
+            act = act_next;
+        }
+        lds_barrier();                                       // A of the step after the last: done(K-1)
+        if (sh.done) reset_lane<A>(cfg, cold, e, a, ag, er);
+        store_agent_dynamic(st, g, ag);
+        store_agent_static(st, g, ag);
+        if (a == 0) {
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = rw.reward;
+        }
+    } else {
+        // ================================ judge ================================
+        TDE_WIDE_PROLOGUE
+        StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
+        const float thr2 = thr2_of(cfg);
+        lds_barrier();
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1;
+            lds_barrier();                                   // A: done(i-1) is in sh.done (written behind barrier B of step i-1)
+            if (i > 0 && sh.done) {                          // this role's bookkeeping of the new episode
+                reset_lane<A>(cfg, cold, e, a, ag, er);
+                load_ctx<A>(cfg, cold, a, ag, er, cx);
+                redc.invalidate();
+            }
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            er.steps += 1;
+            const int k = er.steps;
+            const float4 ra = sh.a[p][a], rb = sh.b[p][a], rc = sh.c[p][a];
+            const bool live = rc.z != 0.0f;
+            const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
+            Corners corners;
+            if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+            const bool hit = collide_rows_wide<A>(&sh.a[p][0], &sh.b[p][0], a, live, x, y, c0, s0, hl, hw, ra.z);
+            bool off = false;
+            if (F & TDE_F_OFFROAD) off = offroad_resolve<false, false>(w, corners, thr2, cx.m.rec_base);
+            bool tl = false;
+            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0)
+                tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
+            o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
+            if (a == 0) {
+                int done = 0;
+                if (F & TDE_F_REWARD) {                      // R8 / R11: the flags settle here (reward: the driver)
+                    o.terminated = (uint8_t)(cold.terminated_at_infraction && (off || hit || tl));
+                    o.truncated = (uint8_t)(k >= cold.max_steps);
+                    done = (o.terminated | o.truncated) ? 1 : 0;
+                }
+                sh.done = ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? done : 0;
+                if (ro.done)
+                    ro.done[(int64_t)i * LB + e] =
+                        (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
+            }
+        }
+        lds_barrier();                                       // done(K-1) is in sh.done
+        const bool respawned = sh.done != 0;
+        if (respawned) reset_lane<A>(cfg, cold, e, a, ag, er);
+        st.collided[g] = respawned ? 0 : o.collided;
+        st.offroad[g] = respawned ? 0 : o.offroad;
+        if (a == 0) {
+            st.scn[e] = er.scn; st.episode[e] = er.episode;
+            st.steps[e] = er.steps;
+            st.terminated[e] = o.terminated;
+            st.truncated[e] = o.truncated;
+            if (st.tl_violation) st.tl_violation[e] = o.tl;
+        }
+    }
+}
+#undef TDE_WIDE_PROLOGUE
+
+// ------------------------------------------------------------------------------------------------------------------
 // Three roles per group: the same loop with the judge split in two wavefronts, six wavefronts per SIMD (80 VGPRs each):
 //   drive   : as above, without the reward arithmetic
 //   judge C : collision of all slots; the ego lane's reward arithmetic, waypoint advance, outputs
@@ -2904,8 +3124,19 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
         // keep an env inside one wavefront)
         tde_rollout r128 = *ro;
         if (r128.ldb == 0) r128.ldb = st->B;
-        if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) tde::env_rollout_kernel<128, true><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
-        else tde::env_rollout_kernel<128, false><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
+        const bool l128 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
+        // Two roles (four wavefronts per env, 4 per SIMD: 1024 envs per residency round) up to two rounds, the one-role kernel
+        // (two wavefronts per env, 3 per SIMD) above: us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs -
+        // two roles 6.8 / 9.2 / 20.5 / 39.2, one role 10.5 / 11.3 / 22.9 / 37.6 (profiles/r04_z_wide2_waves.txt).
+        // tde_kernel_override(1 | 2, 0) forces one.
+        const bool one_role = g_force_rollout == 1 || (g_force_rollout != 2 && st->B > 2 * 4 * cu_count());
+        if (one_role) {
+            if (l128) tde::env_rollout_kernel<128, true><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
+            else tde::env_rollout_kernel<128, false><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
+        } else {                                              // two roles, four wavefronts per env
+            if (l128) tde::env_rollout_wide_kernel<true><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
+            else tde::env_rollout_wide_kernel<false><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
+        }
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
     }
