@@ -97,7 +97,7 @@ box = st.tuples(st.floats(-8, 8, width=32), st.floats(-8, 8, width=32), st.float
                 st.floats(3.75, 7.0, width=32), st.floats(1.5, 3.125, width=32))
 
 
-@settings(max_examples=400, deadline=None)
+@settings(max_examples=400, deadline=None, derandomize=True, database=None)
 @given(box, box)
 @example((0.0, 0.0, 0.0, 4.0, 2.0), (4.0, 0.0, 0.0, 4.0, 2.0))                    # touching end to end: IoU == 0, no collision
 @example((0.0, 0.0, 0.0, 4.0, 2.0), (0.0, 2.0, 0.0, 4.0, 2.0))                    # touching side by side
