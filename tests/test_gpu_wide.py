@@ -107,3 +107,26 @@ def test_batched_env_with_128_slots(crowded_town):
         assert np.array_equal(rew.cpu().numpy().view(np.uint32), hs["reward"].view(np.uint32))
     want = oracle.render_ego(env.tde_cfg, crowded_town, hs, flags=env._rflags)
     assert np.array_equal(obs.cpu().numpy(), want)
+
+
+def test_step_128_slots_above_one_residency_round():
+    """tde_env_step at 128 slots and more than 1536 envs launches the form compiled for four wavefronts per SIMD (another register
+    allocation of the same source): 1600 envs, a few steps with re-spawns == oracle"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=4, A=128, seed=9, n_maps=2)
+    cfg = _abi.default_config(seed=5, distance_cutoff=0.25, flags=_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS, max_steps=3)
+    B, A = 1600, 128
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV, with_obs=True)
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    rng = np.random.default_rng(3)
+    for t in range(7):
+        act = np.stack([rng.uniform(-0.3, 1, B), rng.uniform(-0.2, 0.2, B)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(dev(act))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+    assert_state_equal(hs.host(), ds.host(), "1600 envs x 128 slots, step form for large batches")
+    assert torch.equal(ds["obs"], ops.state_obs(dw, ds)) and int(hs["episode"].max()) >= 3

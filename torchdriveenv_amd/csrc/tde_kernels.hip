@@ -1015,8 +1015,12 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 // one launch = one timestep of every env
 // OBS: also writes the compact observation (tde_state.obs); a template flag because the code, taken or not, costs the
 // plain kernel 0.9 us per launch (it keeps the ego target and the heading's sin/cos alive to the end)
-template <int A, bool LIGHTS, bool OBS, bool BIG = false>
-__global__ __launch_bounds__(kBlock, A > kWave ? TDE_WIDE_WAVES : 1) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
+// WAVES (A = 128 only): the wavefronts per SIMD the kernel is compiled for - 3 (133 VGPRs, no spills) for batches of one residency
+// round, 4 (128 VGPRs, 16 spilled) above 1536 envs, where a fourth resident wavefront is worth more than the spills cost
+// (us per step at 256 / 1024 / 2048 / 4096 envs of ~122 agents: 15.7 / 18.2 / 33.1 / 51.2 against 16.7 / 20.3 / 28.3 / 48.5,
+//  profiles/r04_z_wide_waves.txt)
+template <int A, bool LIGHTS, bool OBS, bool BIG = false, int WAVES = TDE_WIDE_WAVES>
+__global__ __launch_bounds__(kBlock, A > kWave ? WAVES : 1) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
                                                           const float *__restrict__ action, float *reward_k,
                                                           uint8_t *done_k)
 {
@@ -2982,6 +2986,7 @@ static uint32_t act_cfg_hash(const tde_config &cfg)
     return h;
 }
 
+static int cu_count();
 static int env_step_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream, int64_t load_slots)
 {
     int rc = check_env_args("tde_env_step", cfg, world, st);
@@ -3030,6 +3035,14 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
 #undef TDE_LAUNCH_STEP_BIG
         hipError_t eb = hipGetLastError();
         return eb == hipSuccess ? 0 : fail("tde_env_step", eb);
+    }
+    if (st->A == 128 && st->B > 6 * cu_count()) {            // (128 slots, more than a residency round of the 3-per-SIMD form: 4 per SIMD)
+#define TDE_LAUNCH_STEP_W4(L, O) tde::env_step_kernel<128, L, O, false, 4><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits)
+        if (st->obs) { if (lights) TDE_LAUNCH_STEP_W4(true, true); else TDE_LAUNCH_STEP_W4(false, true); }
+        else { if (lights) TDE_LAUNCH_STEP_W4(true, false); else TDE_LAUNCH_STEP_W4(false, false); }
+#undef TDE_LAUNCH_STEP_W4
+        hipError_t e4 = hipGetLastError();
+        return e4 == hipSuccess ? 0 : fail("tde_env_step", e4);
     }
 #define TDE_LAUNCH_STEP(L, O)                                                                                          \
     TDE_DISPATCH_A128(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                 \
