@@ -87,7 +87,11 @@ typedef struct tde_config {
                                    index of a World is built for the effective distance (thr or sqrt(thr)). */
 } tde_config;
 
-/* One drivable-surface map: triangle soup + uniform grid index. */
+/* One drivable-surface map: triangle soup + uniform grid index + its traffic lights.  A descriptor is 80 bytes that POINT into the
+ * world's tables, so several descriptors may share one mesh and grid (the same cell_base / tri_base / rec_base / cls2_base /
+ * coarse_base) and differ only in stop_base / n_stop / phase_base / n_phase / cycle_steps: the lights of ONE neighbourhood of a
+ * town each ("light groups": a light is a bit of a 32-bit mask and the kernels walk every stop line of a scenario's descriptor) -
+ * tde_scenario.map selects the descriptor. */
 typedef struct tde_map {
     float ox, oy;               /* grid origin (lower-left corner of cell (0,0)) */
     float cell;                 /* cell edge [m] */
