@@ -19,8 +19,8 @@
  * A must be a power of two, 1..128.  Up to 64 an env never straddles a 64-lane wavefront and every kernel form applies (the
  * persistent rollout kernels, the three-role forms); A = 128 (the reference assembles up to ~100 agents per env,
  * gym_env.py:216-237; pad with absent slots) spans two wavefronts of a workgroup: the one-role kernels, whose sweeps take the
- * env's rows as two halves of 64 with a 64-bit candidate mask each (same results), and persistent rollout kernels of their own (two
- * roles in four wavefronts per env up to 2048 envs, one role above).
+ * env's rows as two halves of 64 with a 64-bit candidate mask each (same results), and a persistent rollout kernel of their own (two roles
+ * in four wavefronts per env).
  */
 #ifndef TDE_ABI_H
 #define TDE_ABI_H

@@ -8,6 +8,7 @@ from torchdriveenv_amd.synth import synthetic_town, synthetic_world
 
 dev = torch.device("cuda:0")
 _lib.load()
+if os.environ.get("TDE_ROLLOUT_TEAM"): _lib.kernel_override(rollout=os.environ["TDE_ROLLOUT_TEAM"])   # solo | duo: force a rollout form
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
 for A, kind in ((128, "town"),) if os.environ.get("TDE_HIP_LIB") else ((64, "junctions"), (128, "town")):
     # (town: ~100 of 128 slots present per scenario, the reference's assembled scene; junctions: what fits on the arms)

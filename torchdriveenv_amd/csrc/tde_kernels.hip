@@ -1531,14 +1531,13 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
         lds_barrier();                                       // rows of the launch state are in buffer 1
         const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
         float2 act = acts[e];
-        RewardOut rw{};
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1, q = p ^ 1;
             const int kn = (i + 1 < ro.K) ? i + 1 : i;
             const float2 act_next = acts[(int64_t)kn * LB + e];
             float nx, ny, npsi, nv, nc, ns;
             float na = 0.0f, nb = 0.0f;
-            int nwp, k, n_target = er.target_idx, n_reached = er.reached;
+            int nwp, k;
             bool switched, live;
             for (int pass = 0;; ++pass) {
                 k = er.steps + 1;                                                            // :116
@@ -1571,11 +1570,6 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
                     if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
                 }
                 sincos_f32(npsi, ns, nc);
-                if ((F & TDE_F_REWARD) && a == 0) {           // the ego's reward arithmetic (:391-411, :378-383), as in the duo kernel
-                    n_target = er.target_idx; n_reached = er.reached;
-                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, ag.x, ag.y, ag.psi, ag.v, nx, ny, npsi, nv, false,
-                                     false, false, k, n_target, n_reached, st.info != nullptr);
-                }
                 if (pass) break;
                 lds_barrier();                               // A: done(i-1) is published
                 if (!sh.done) break;
@@ -1593,38 +1587,21 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
             write_rows_wide(sh, p, a, live, ag, c0, s0, cfg.npc_lane_half);
             lds_barrier();                                   // B: rows of step i are in buffer p
             if (switched) load_route_target(cold, ag, cx);
-            if (a == 0) {
-                if (F & TDE_F_REWARD) {
-                    const bool advanced = n_target != er.target_idx;
-                    er.target_idx = n_target; er.reached = n_reached;
-                    if (st.info) {
-                        double *inf = st.info + 4 * (int64_t)e;
-                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
-                    }
-                    if (st.info_reached) st.info_reached[e] = er.reached;
-                    if (advanced) load_ego_target(cold, er, cx);
-                }
-                if (ro.reward) ro.reward[(int64_t)i * LB + e] = rw.reward;
-            }
             act = act_next;
         }
         lds_barrier();                                       // A of the step after the last: done(K-1)
         if (sh.done) reset_lane<A>(cfg, cold, e, a, ag, er);
         store_agent_dynamic(st, g, ag);
         store_agent_static(st, g, ag);
-        if (a == 0) {
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            st.reward[e] = rw.reward;
-        }
     } else {
         // ================================ judge ================================
         TDE_WIDE_PROLOGUE
         StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
         const float thr2 = thr2_of(cfg);
+        RewardOut rw{};
         lds_barrier();
         for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1;
+            const int p = i & 1, q = p ^ 1;
             lds_barrier();                                   // A: done(i-1) is in sh.done (written behind barrier B of step i-1)
             if (i > 0 && sh.done) {                          // this role's bookkeeping of the new episode
                 reset_lane<A>(cfg, cold, e, a, ag, er);
@@ -1648,12 +1625,29 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
             o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
             if (a == 0) {
                 int done = 0;
-                if (F & TDE_F_REWARD) {                      // R8 / R11: the flags settle here (reward: the driver)
+                if (F & TDE_F_REWARD) {
+                    // The ego's reward arithmetic and waypoint bookkeeping (:391-411, :378-383) from its rows before (buffer q: the
+                    // previous step's, or the new episode's spawn rows after a re-spawn) and after the step - here, not on the
+                    // driver as in env_rollout_duo_kernel: the driver is the wavefront short of registers (its spills are on its path)
+                    const float4 pa = sh.a[q][0], pc = sh.c[q][0];
+                    int n_target = er.target_idx, n_reached = er.reached;
+                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, pa.x, pa.y, pc.x, pc.y, x, y, rc.x, rc.y, false, false, false, k,
+                                     n_target, n_reached, st.info != nullptr);
+                    const bool advanced = n_target != er.target_idx;
+                    er.target_idx = n_target; er.reached = n_reached;
+                    if (st.info) {
+                        double *inf = st.info + 4 * (int64_t)e;
+                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
+                    }
+                    if (st.info_reached) st.info_reached[e] = er.reached;
+                    if (advanced) load_ego_target(cold, er, cx);   // (a finished env reloads it when it re-spawns)
+                    // R8 / R11: the flags
                     o.terminated = (uint8_t)(cold.terminated_at_infraction && (off || hit || tl));
                     o.truncated = (uint8_t)(k >= cold.max_steps);
                     done = (o.terminated | o.truncated) ? 1 : 0;
                 }
                 sh.done = ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? done : 0;
+                if (ro.reward) ro.reward[(int64_t)i * LB + e] = rw.reward;
                 if (ro.done)
                     ro.done[(int64_t)i * LB + e] =
                         (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
@@ -1667,6 +1661,9 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
         if (a == 0) {
             st.scn[e] = er.scn; st.episode[e] = er.episode;
             st.steps[e] = er.steps;
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = rw.reward;
             st.terminated[e] = o.terminated;
             st.truncated[e] = o.truncated;
             if (st.tl_violation) st.tl_violation[e] = o.tl;
@@ -3138,11 +3135,10 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
         tde_rollout r128 = *ro;
         if (r128.ldb == 0) r128.ldb = st->B;
         const bool l128 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-        // Two roles (four wavefronts per env, 4 per SIMD: 1024 envs per residency round) up to two rounds, the one-role kernel
-        // (two wavefronts per env, 3 per SIMD) above: us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs -
-        // two roles 6.8 / 9.2 / 20.5 / 39.2, one role 10.5 / 11.3 / 22.9 / 37.6 (profiles/r04_z_wide2_waves.txt).
-        // tde_kernel_override(1 | 2, 0) forces one.
-        const bool one_role = g_force_rollout == 1 || (g_force_rollout != 2 && st->B > 2 * 4 * cu_count());
+        // Two roles (four wavefronts per env) at every batch size - us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs:
+        // two roles 6.2 / 8.9 / 18.0 / 34.7, one role 10.6 / 11.4 / 23.3 / 38.9 (profiles/r04_z_wide2_waves.txt).
+        // tde_kernel_override(1, 0) forces the one-role kernel.
+        const bool one_role = g_force_rollout == 1;
         if (one_role) {
             if (l128) tde::env_rollout_kernel<128, true><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
             else tde::env_rollout_kernel<128, false><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
