@@ -130,3 +130,37 @@ def test_step_128_slots_above_one_residency_round():
         ops.env_step(cfg, dw, ds)
     assert_state_equal(hs.host(), ds.host(), "1600 envs x 128 slots, step form for large batches")
     assert torch.equal(ds["obs"], ops.state_obs(dw, ds)) and int(hs["episode"].max()) >= 3
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rollout_fuzz_128_slots(seed, crowded_town):
+    """the two-role 128-slot rollout kernel over random flags (lights, no auto-reset, no offroad, no reward), launch lengths and
+    episode lengths, consecutive launches: rewards, done bits and the whole state equal the oracle's after every launch"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    rng = np.random.default_rng(700 + seed)
+    world = crowded_town if seed % 2 else synthetic_world(n_scn=4, A=128, seed=20 + seed, n_maps=2)
+    flags = _abi.F_ALL
+    if rng.random() < 0.5:
+        flags |= _abi.F_TRAFFIC_LIGHTS
+    if rng.random() < 0.3:
+        flags &= ~_abi.F_AUTORESET
+    if rng.random() < 0.25:
+        flags &= ~_abi.F_OFFROAD
+    if seed == 5:
+        flags &= ~_abi.F_REWARD
+    cfg = _abi.default_config(seed=seed, distance_cutoff=0.25, flags=flags, max_steps=int(rng.choice([1, 2, 7, 40])))
+    B, A = int(rng.integers(1, 14)), 128
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    for launch in range(3):
+        K = int(rng.choice([1, 2, 9, 33]))
+        actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+        hr, hd = oracle.env_rollout(cfg, world, hs, actions)
+        dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+        tag = f"seed {seed} B={B} K={K} flags={flags:#x} max_steps={cfg.max_steps} launch {launch}"
+        assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)), tag
+        assert np.array_equal(dd.cpu().numpy(), hd), tag
+        assert_state_equal(hs.host(), ds.host(), tag)
