@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 9
+#define TDE_ABI_VERSION 10
 #define TDE_MAX_AGENTS 128
 
 /* feature bits of tde_config.flags */
@@ -43,6 +43,12 @@ extern "C" {
 #define TDE_F_AUTORESET  (1u << 4)  /* envs that finished this step are re-spawned in place (VecEnv semantics) */
 #define TDE_F_EGO_ONLY_ATTRS (1u << 5) /* cfg.ego_only: random ego attrs at reset (gym_env.py:192-198) */
 #define TDE_F_TRAFFIC_LIGHTS (1u << 6) /* red-light stop-line violation, third term of is_terminated (gym_env.py:415) */
+#define TDE_F_NPC_FIRST_STEP (1u << 7) /* the NPC controller also acts on the FIRST step of an episode, as the reference's NPCs do
+                                          (gym_env.py:285-294: IAIWrapper predicts from step one).  Default (bit clear): the NPCs coast
+                                          through step one with the zero action - the controller reads the scene of the previous
+                                          step, which a fresh episode does not have - and the role-split kernels rely on that to
+                                          skip the controller after a re-spawn; with the bit set tde_env_step / tde_env_rollout run
+                                          their one-role kernels, which evaluate the controller on every step */
 #define TDE_F_ALL (TDE_F_NPC | TDE_F_REPLAY | TDE_F_OFFROAD | TDE_F_REWARD | TDE_F_AUTORESET)
 
 /* cell classes of the offroad grid index (HIP side only; the oracle is brute force over triangles) */
@@ -111,7 +117,9 @@ typedef struct tde_map {
                                    triangles needs ~2e5 after identical lists are shared; one global offset ran out at the
                                    second town) */
     int32_t coarse_base;        /* (ABI 9) first 128-byte line of this map in tde_world.cell_coarse (in lines) */
-    int32_t _pad0[2];           /* 80 bytes: the kernels read the struct with 16-byte loads */
+    int32_t near_base;          /* (ABI 10) first word of this map in tde_world.tile_near: the word of coarse tile (cx, cy) is
+                                   near_base + cy * (nx / TDE_COARSE_CELLS) + cx */
+    int32_t _pad0;              /* 80 bytes: the kernels read the struct with 16-byte loads */
 } tde_map;
 
 /* A stop line: an oriented box across an inbound lane, governed by traffic light `light` of its map
@@ -163,8 +171,11 @@ typedef struct tde_world {
                                    rec_base (cells with the same candidates share their records); FULL / EMPTY
                                    cells: bits 2-9 clearance in units of TDE_CLEARANCE_UNIT (every point that close to the cell
                                    lies in a cell of the same class) */
-    const float *cell_tri;      /* [n_records][12] per-cell candidate triangles, packed for 16-B loads:
-                                   ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,0,0,0 */
+    const float *cell_tri;      /* [n_records + 16][12] per-cell candidate triangles, packed for 16-B loads:
+                                   ax,ay,bx,by | cx,cy,1/|ab|^2,1/|bc|^2 | 1/|ca|^2,len,0,0 - `len` (ABI 10, the bits of an int32):
+                                   at the first record of a NEAR LIST (tile_near) the length of that list, else 0.  The table ends
+                                   with 16 zero records: the magnitude kernels fetch the first 16 records of a near list before
+                                   they know its length */
     const uint32_t *cell_cls2;  /* (ABI 7, rasteriser) the cell classes alone, 2 bits per cell, in 128-byte tiles of 32 x 16 cells
                                    (8 m x 4 m at 0.25 m cells: a 35 m view touches ~50 cache lines of it, against one line per
                                    look-up in cell_word).  Tile (tx, ty) = cells [32 tx, 32 tx + 32) x [16 ty, 16 ty + 16) of a
@@ -183,6 +194,13 @@ typedef struct tde_world {
                                    ((coarse_base + ((cy >> 3) << (row_shift - 6)) + (cx >> 4)) << 7) + ((cy & 7) << 4) + (cx & 15).
                                    The block pyramid of a 35 m view reads ~20 lines of it (1 MB per km^2) where the clearance
                                    field of cell_word cost one line per look-up (66 MB per km^2) */
+    const uint32_t *tile_near;  /* (ABI 10, infraction magnitudes) one word per coarse tile of 4 x 4 cells, row-major per map
+                                   (tde_map.near_base): 0 = the tile has no near list (farther than threshold + near_range from the
+                                   mesh: the kernels scan the grid); 0xFFFFFFFF = all 16 cells FULL (every point of the tile within
+                                   the threshold: the offroad magnitude's term is 0); else 1 + the first record, counted from the
+                                   map's rec_base, of the tile's NEAR LIST in cell_tri: a superset of the triangles one of which is
+                                   the nearest triangle of any point of the tile, so the minimum of the point-triangle distances
+                                   over the list IS the distance to the mesh (the CPU checker's brute-force minimum, same bits) */
     const tde_scenario *scn;    /* [S] */
     const double *wp_xy;        /* [S][NW][2] ego waypoints, float64 like the YAML lists (gym_env.py:314,394) */
     const tde_spawn *spawn;     /* [S][A] */
@@ -215,6 +233,9 @@ typedef struct tde_grid {
     uint32_t *cell_first;       /* MIXED: first record of the cell's list in rec_tri (map-relative) */
     uint32_t *cell_sub;         /* MIXED: the 2-bit classes of the cell's TDE_CELL_SUB x TDE_CELL_SUB sub-cells */
     int32_t *rec_tri;           /* [n_records] triangle index (into the mesh handed in) of every record */
+    uint32_t *tile_near;        /* (ABI 10) [(ny / 4) * (nx / 4)] row-major: the tde_world.tile_near word of every coarse tile */
+    int32_t *rec_len;           /* (ABI 10) [n_records] length of the near list that starts at this record, else 0 */
+    int64_t n_near_lists;       /* (ABI 10) tiles with a near list */
 } tde_grid;
 
 /* Optional lookup caches of the closed-loop step (tde_env_step): what the step needs from the scenario tables for a
@@ -299,6 +320,12 @@ typedef struct tde_state {
                                    and computes the next step's behind the judges.  The key cannot see a state that was edited
                                    from outside with its counters unchanged: zero / invalidate the cache after such an edit
                                    (EnvState.load does) */
+    float *magnitudes;          /* out [B][4], tde_env_step only, may be NULL (ABI 10): the MAGNITUDES of the ego's infractions at
+                                   THIS step - what the reference's info dict holds under "offroad" / "collision"
+                                   (gym_env.py:427-428: simulator.compute_offroad() / compute_collision() for the exposed agent) -
+                                   as tde_ego_infractions defines them: (sum over the box corners of clamp(distance to the mesh -
+                                   offroad_threshold, 0), sum of the IoUs with the agents the ego overlaps, their number, 0), of
+                                   the state the step left BEFORE any in-place re-spawn; zeros without the matching flag */
     int32_t B, A;
 } tde_state;
 

@@ -156,11 +156,14 @@ TDE_API int tde_env_post_step(const tde_config *config, const tde_world *world, 
  * few candidate triangles instead of a pass over the mesh.  HOST pointers, no GPU involved, synchronous, n_threads host
  * threads (0 = all).  tri = [n_tri][6] fp32 vertices ax,ay,bx,by,cx,cy (the fp32 values the kernels and the oracle see);
  * threshold = the effective offroad distance in metres (sqrt of the threshold under offroad_threshold_squared); cell = cell
- * edge; margin = classification margin (0.05: absorbs fp32 evaluation at coordinates of kilometres).  Classes and lists are
+ * edge; margin = classification margin (0.05: absorbs fp32 evaluation at coordinates of kilometres); near_range (ABI 10) = how far
+ * beyond the threshold, in metres, the coarse tiles carry a NEAR LIST (tde_world.tile_near: the triangles among which the nearest
+ * one of any point of the tile is found - what the MAGNITUDE of the offroad infraction needs, gym_env.py:427; 0 = none, the
+ * kernels then scan the grid around a corner; a few metres cover an ego that left the road within the last step or two).  Classes and lists are
  * conservative (csrc/tde_gridbuild.h), so the kernels' masks equal a brute-force pass over every triangle.  The result is
  * owned by the library until tde_grid_free. */
-TDE_API int tde_grid_build(const float *tri, int32_t n_tri, float threshold, float cell, float margin, int32_t n_threads,
-                           tde_grid **out);
+TDE_API int tde_grid_build(const float *tri, int32_t n_tri, float threshold, float cell, float margin, float near_range,
+                           int32_t n_threads, tde_grid **out);
 TDE_API void tde_grid_free(tde_grid *grid);
 
 #ifdef __cplusplus

@@ -630,9 +630,10 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
         if (!present[a]) continue;
         float acc = 0.0f, beta = 0.0f;
         if (a == 0) { acc = a_acc; beta = a_steer; }
-        else if ((F & TDE_F_NPC) && k > 1)
+        else if ((F & TDE_F_NPC) && (k > 1 || (F & TDE_F_NPC_FIRST_STEP)))
             /* (k == 1, the first step of an episode: the NPCs coast with the zero action - the controller reads the scene of
-             * the previous step, which a fresh episode does not have) */
+             * the previous step, which a fresh episode does not have; DESIGN.md section 2, R14 - unless TDE_F_NPC_FIRST_STEP asks
+             * for the reference's behaviour: its NPCs are driven from step one, gym_env.py:285-294) */
             tde_npc_action(cfg, w, A, a, px, py, pc, ps, pv, L, W, present, st->vdes[g0 + a], spawn[a].route,
                            spawn[a].route_n, st->route_wp[g0 + a], lights_map, red_now, &acc, &beta);
         float nx = px[a], ny = py[a], np_ = pp[a], nv = pv[a];
@@ -697,11 +698,22 @@ static tde_env_out tde_step_env(const tde_config *cfg, const tde_world *w, tde_s
     return out;
 }
 
+static void tde_ego_magnitudes(const tde_config *cfg, const tde_world *w, const tde_state *st, int32_t e, int do_coll, int do_off,
+                               float *out);
+
 TDE_EXPORT int tde_oracle_env_step(const tde_config *cfg, const tde_world *w, tde_state *st)
 {
 #pragma omp parallel for schedule(static)
     for (int32_t e = 0; e < st->B; ++e) {
         tde_env_out o = tde_step_env(cfg, w, st, e, st->action[2 * e], st->action[2 * e + 1]);
+        /* tde_state.magnitudes: what get_info reports under "offroad" / "collision" (gym_env.py:427-428), of the state the step
+         * left, before any re-spawn.  A magnitude is non-zero only under its flag (collision: the same predicate; offroad: a
+         * corner beyond the threshold has d^2 > thr^2 and sqrt(d^2) <= thr otherwise), so the brute-force pass over every
+         * triangle only runs for the egos the step flagged - the same values as tde_oracle_ego_infractions on every env
+         * (tests/test_oracle_properties.py) */
+        if (st->magnitudes)
+            tde_ego_magnitudes(cfg, w, st, e, st->collided[(int64_t)e * st->A], st->offroad[(int64_t)e * st->A],
+                               st->magnitudes + 4 * (int64_t)e);
         st->reward[e] = o.reward;
         st->terminated[e] = o.terminated;
         st->truncated[e] = o.truncated;
@@ -902,46 +914,48 @@ TDE_EXPORT float tde_oracle_box_iou(float x0, float y0, float c0, float s0, floa
     return ai / ((a0 + a1) - ai);
 }
 
+/* the four magnitude values of env e's ego on the CURRENT state; do_coll / do_off = 0 skips that magnitude (left 0) */
+static void tde_ego_magnitudes(const tde_config *cfg, const tde_world *w, const tde_state *st, int32_t e, int do_coll, int do_off,
+                               float *out)
+{
+    const int32_t A = st->A;
+    const int64_t g0 = (int64_t)e * A;
+    float omag = 0.0f, cmag = 0.0f, nmag = 0.0f;
+    if (st->present[g0]) {
+        float se, ce;
+        tde_oracle_sincosf(st->psi[g0], &se, &ce);
+        const float hl = 0.5f * st->len[g0], hw = 0.5f * st->wid[g0];
+        int n = 0;
+        for (int32_t j = 1; j < A && do_coll; ++j) {
+            if (!st->present[g0 + j]) continue;
+            float sj, cj;
+            tde_oracle_sincosf(st->psi[g0 + j], &sj, &cj);
+            const float hlj = 0.5f * st->len[g0 + j], hwj = 0.5f * st->wid[g0 + j];
+            if (tde_oracle_obb_overlap(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj, hlj, hwj)) {
+                n += 1;     /* (IoU only for pairs the mask's predicate calls overlapping: magnitude > 0 <=> collided) */
+                cmag = cmag + tde_oracle_box_iou(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj, hlj, hwj);
+            }
+        }
+        nmag = (float)n;
+        if (do_off && (cfg->flags & TDE_F_OFFROAD)) {
+            const tde_map *m = &w->maps[w->scn[st->scn[e]].map];
+            const float *tri = w->tri + 6 * (int64_t)m->tri_base;
+            float cx[4], cy[4];
+            tde_corners(st->x[g0], st->y[g0], ce, se, hl, hw, cx, cy);
+            for (int k = 0; k < 4; ++k) {
+                const float d2 = tde_oracle_point_mesh_d2(cx[k], cy[k], tri, m->n_tri);
+                const float dist = cfg->offroad_threshold_squared ? d2 : sqrtf(d2);
+                omag = omag + fmaxf(dist - cfg->offroad_threshold, 0.0f);
+            }
+        }
+    }
+    out[0] = omag; out[1] = cmag; out[2] = nmag; out[3] = 0.0f;
+}
+
 TDE_EXPORT int tde_oracle_ego_infractions(const tde_config *cfg, const tde_world *w, const tde_state *st, float *out)
 {
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int32_t e = 0; e < st->B; ++e) {
-        const int32_t A = st->A;
-        const int64_t g0 = (int64_t)e * A;
-        float omag = 0.0f, cmag = 0.0f, nmag = 0.0f;
-        if (st->present[g0]) {
-            float se, ce;
-            tde_oracle_sincosf(st->psi[g0], &se, &ce);
-            const float hl = 0.5f * st->len[g0], hw = 0.5f * st->wid[g0];
-            int n = 0;
-            for (int32_t j = 1; j < A; ++j) {
-                if (!st->present[g0 + j]) continue;
-                float sj, cj;
-                tde_oracle_sincosf(st->psi[g0 + j], &sj, &cj);
-                const float hlj = 0.5f * st->len[g0 + j], hwj = 0.5f * st->wid[g0 + j];
-                if (tde_oracle_obb_overlap(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj, hlj, hwj)) {
-                    n += 1;     /* (IoU only for pairs the mask's predicate calls overlapping: magnitude > 0 <=> collided) */
-                    cmag = cmag + tde_oracle_box_iou(st->x[g0], st->y[g0], ce, se, hl, hw, st->x[g0 + j], st->y[g0 + j], cj, sj, hlj, hwj);
-                }
-            }
-            nmag = (float)n;
-            if (cfg->flags & TDE_F_OFFROAD) {
-                const tde_map *m = &w->maps[w->scn[st->scn[e]].map];
-                const float *tri = w->tri + 6 * (int64_t)m->tri_base;
-                float cx[4], cy[4];
-                tde_corners(st->x[g0], st->y[g0], ce, se, hl, hw, cx, cy);
-                for (int k = 0; k < 4; ++k) {
-                    const float d2 = tde_oracle_point_mesh_d2(cx[k], cy[k], tri, m->n_tri);
-                    const float dist = cfg->offroad_threshold_squared ? d2 : sqrtf(d2);
-                    omag = omag + fmaxf(dist - cfg->offroad_threshold, 0.0f);
-                }
-            }
-        }
-        out[4 * (int64_t)e] = omag;
-        out[4 * (int64_t)e + 1] = cmag;
-        out[4 * (int64_t)e + 2] = nmag;
-        out[4 * (int64_t)e + 3] = 0.0f;
-    }
+    for (int32_t e = 0; e < st->B; ++e) tde_ego_magnitudes(cfg, w, st, e, 1, 1, out + 4 * (int64_t)e);
     return 0;
 }
 

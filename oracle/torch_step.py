@@ -101,7 +101,7 @@ def torch_env_step(cfg, world, tw, hs, oracle_reset=None):
         a_n = (cfg.npc_k_speed * (0.0 - v)).clamp(-amax, amax)
         acc = torch.where(has, a_t, torch.where(npc, a_n, acc))
         beta = torch.where(has, b_t, beta)
-        first = (k == 1)[:, None]                                             # first step of an episode: the NPCs coast
+        first = (k == 1)[:, None] & (not (F & _abi.F_NPC_FIRST_STEP))         # first step of an episode: the NPCs coast
         acc = torch.where(first, torch.zeros_like(acc), acc)
         beta = torch.where(first, torch.zeros_like(beta), beta)
     acc[:, 0], beta[:, 0] = act[:, 0], act[:, 1]

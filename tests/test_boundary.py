@@ -151,15 +151,26 @@ def test_grid_build_argument_errors_and_shared_lists():
     L = _lib.load()
     gp = C.POINTER(_abi.TdeGrid)()
     huge = np.array([[0, 0, 1e6, 0, 0, 1e6]], np.float32)
-    assert L.tde_grid_build(huge.ctypes.data, 1, 0.5, 0.25, 0.05, 0, C.byref(gp)) != 0 and b"larger cell" in L.tde_last_error()
+    assert L.tde_grid_build(huge.ctypes.data, 1, 0.5, 0.25, 0.05, 2.0, 0, C.byref(gp)) != 0 and b"larger cell" in L.tde_last_error()
     nan = np.array([[np.nan, 0, 1, 0, 0, 1]], np.float32)
-    assert L.tde_grid_build(nan.ctypes.data, 1, 0.5, 0.25, 0.05, 0, C.byref(gp)) != 0 and b"non-finite" in L.tde_last_error()
-    assert L.tde_grid_build(nan.ctypes.data, 0, 0.5, 0.25, 0.05, 0, C.byref(gp)) != 0
-    assert L.tde_grid_build(huge.ctypes.data, 1, 0.5, 0.25, 0.6, 0, C.byref(gp)) != 0          # margin >= threshold
+    assert L.tde_grid_build(nan.ctypes.data, 1, 0.5, 0.25, 0.05, 2.0, 0, C.byref(gp)) != 0 and b"non-finite" in L.tde_last_error()
+    assert L.tde_grid_build(nan.ctypes.data, 0, 0.5, 0.25, 0.05, 2.0, 0, C.byref(gp)) != 0
+    assert L.tde_grid_build(huge.ctypes.data, 1, 0.5, 0.25, 0.6, 2.0, 0, C.byref(gp)) != 0          # margin >= threshold
+    ok = np.array([[0, 0, 10, 0, 0, 10]], np.float32)
+    assert L.tde_grid_build(ok.ctypes.data, 1, 0.5, 0.25, 0.05, -1.0, 0, C.byref(gp)) != 0 and b"near_range" in L.tde_last_error()
     g = build_grid_index(strip_mesh([(0.0, 0.0), (60.0, 0.0)], 7.0, 5.0).astype(np.float32), 0.5, 0.25)
     mixed = g["cell_class"] == _abi.CELL_MIXED
     assert mixed.sum() > 500 and 0 < g["n_lists"] < mixed.sum() // 4           # a straight road: few distinct lists
     assert (g["cell_first"][mixed].astype(np.int64) + g["cell_count"][mixed] <= len(g["rec_tri"])).all()
     assert g["nx"] % 8 == 0 and g["ny"] % 8 == 0 and float(g["ox"]).is_integer()
     one = build_grid_index(strip_mesh([(0.0, 0.0), (60.0, 0.0)], 7.0, 5.0).astype(np.float32), 0.5, 0.25, n_threads=1)
-    assert all(np.array_equal(g[k], one[k]) for k in ("cell_class", "cell_count", "cell_first", "cell_sub", "rec_tri"))   # thread count does not show
+    assert all(np.array_equal(g[k], one[k]) for k in ("cell_class", "cell_count", "cell_first", "cell_sub", "rec_tri", "rec_len",
+                                                       "tile_near"))   # thread count does not show
+    # near lists (ABI 10): tiles along the road carry one, their records lie inside the table, the length sits at the first record
+    tn = g["tile_near"]
+    listed = (tn != 0) & (tn != 0xFFFFFFFF)
+    assert listed.sum() > 100 and (tn == 0xFFFFFFFF).sum() > 100 and g["n_near_lists"] == listed.sum()
+    first = tn[listed].astype(np.int64) - 1
+    assert (g["rec_len"][first] > 0).all() and (first + g["rec_len"][first] <= len(g["rec_tri"])).all()
+    none = build_grid_index(strip_mesh([(0.0, 0.0), (60.0, 0.0)], 7.0, 5.0).astype(np.float32), 0.5, 0.25, near_range=0.0)
+    assert ((none["tile_near"] == 0) | (none["tile_near"] == 0)).all() and none["n_near_lists"] == 0

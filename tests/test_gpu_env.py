@@ -62,7 +62,11 @@ def test_config1_threeway_b1_reference_api_vs_oracle():
             assert k in info
         assert np.float32(reward) == hs["reward"][0]
         assert terminated == bool(hs["terminated"][0]) and truncated == bool(hs["truncated"][0])
-        assert float(info["collision"]) == float(hs["collided"][0]) and float(info["offroad"]) == float(hs["offroad"][0])
+        # the reference's info semantics (gym_env.py:427-428): the MAGNITUDES of compute_offroad() / compute_collision()
+        mag = oracle.ego_infractions(ocfg, inner.world, hs)[0]
+        assert np.float32(info["offroad"]).view(np.uint32) == mag[0].view(np.uint32)
+        assert np.float32(info["collision"]).view(np.uint32) == mag[1].view(np.uint32)
+        assert (float(info["collision"]) > 0) == bool(hs["collided"][0]) and (float(info["offroad"]) > 0) == bool(hs["offroad"][0])
         assert info["reached_waypoint_num"] == hs["info_reached"][0]
         assert np.array_equal(inner.state["x"].cpu().numpy().view(np.uint32), hs["x"].view(np.uint32))
         assert np.array_equal(obs, oracle.render_ego(ocfg, inner.world, hs, flags=inner._rflags)[0])   # (left-handed raster: the reference default)
@@ -74,6 +78,95 @@ def test_config1_threeway_b1_reference_api_vs_oracle():
     assert env.env.reached_waypoint_num >= 1          # it drove through at least the first waypoint
     img = env.render()
     assert img.shape == (64, 64, 3) and img.dtype == np.uint8
+
+
+@pytest.mark.parametrize("terminate", [True, False])
+def test_make_step_info_carries_the_reference_magnitudes(terminate):
+    """make(...).step(): info["offroad"] / info["collision"] are the magnitudes the reference reports (gym_env.py:419-437: the
+    values of simulator.compute_offroad() / compute_collision() for the exposed agent, which Monitor logs,
+    examples/rl_training.py:128) - here the oracle's, bit for bit, over episodes whose ego leaves the road and runs into the
+    parked cars; with terminated_at_infraction the episode ends at the first non-zero one"""
+    cfg = EnvConfig(seed=5, distance_cutoff=0.25, terminated_at_infraction=terminate, max_environment_steps=120)
+    env = make(cfg, threeway_suite(), agents_per_env=8)
+    inner = env.env._env
+    assert inner.info_magnitudes
+    ocfg = inner.tde_cfg
+    n_off = n_col = n_eps = 0
+    for ep in range(6):
+        env.reset()
+        hs = EnvState(1, 8)
+        hs.load({k: v for k, v in inner.state.host().items() if k in hs.arrays and hs.arrays[k] is not None})
+        steer = (-0.3, 0.3, 0.12, -0.12, 0.05, 0.0)[ep]
+        for t in range(120):
+            action = np.array([0.8, steer if t > 5 else 0.0], dtype=np.float32)
+            obs, reward, terminated, truncated, info = env.step(action)
+            hs["action"][...] = action
+            oracle.env_step(ocfg, inner.world, hs)
+            mag = oracle.ego_infractions(ocfg, inner.world, hs)[0]
+            assert info["offroad"].dtype == torch.float32 and info["offroad"].dim() == 0
+            assert np.float32(info["offroad"]).view(np.uint32) == mag[0].view(np.uint32), (ep, t)
+            assert np.float32(info["collision"]).view(np.uint32) == mag[1].view(np.uint32), (ep, t)
+            assert np.float32(reward) == hs["reward"][0] and terminated == bool(hs["terminated"][0])
+            n_off += mag[0] > 0
+            n_col += mag[1] > 0
+            if terminate and (mag[0] > 0 or mag[1] > 0):
+                assert terminated
+            if terminated or truncated:
+                break
+        n_eps += 1
+    assert n_off > 0 and n_eps == 6
+    if not terminate:
+        assert n_off > 20                      # the ego kept driving off the road: distances of metres, not 0 / 1
+    env.close()
+
+
+def test_road_mesh_hook_runs_the_suite_on_the_callers_mesh(tmp_path):
+    """world_from_waypoint_suite(road_meshes=...): a caller who has the location's road mesh (the reference:
+    find_map_config(location).road_mesh, gym_env.py:312, 184, 260) gets THAT map instead of a synthetic corridor - here the synthetic
+    town's mesh saved to .npy, five scenarios on it sharing one map, HIP == oracle over an episode each"""
+    from torchdriveenv_amd.env import mesh_from_verts_faces, world_from_waypoint_suite
+    from torchdriveenv_amd.synth import Town
+
+    town = Town(n=3, spacing=100.0, ext=30.0)
+    tri = town.mesh()
+    path = tmp_path / "Town_synth.npy"
+    np.save(path, tri.astype(np.float32))
+    # five waypoint routes along the town's first street, shifted along it
+    suites, locs = [], []
+    for k in range(5):
+        x0 = 20.0 + 25.0 * k
+        pts = [town.F(x0 + 14.0 * i, 0.0) for i in range(8)]
+        suites.append([[float(p[0]), float(p[1])] for p in pts])
+        locs.append("Town_synth")
+    data = WaypointSuite(locations=locs, waypoint_suite=suites, car_sequence_suite=[None] * 5, scenarios=[None] * 5)
+    # verts / faces form of the same mesh through the converter
+    verts = tri.reshape(-1, 2)
+    faces = np.arange(len(verts)).reshape(-1, 3)
+    assert np.array_equal(mesh_from_verts_faces(verts, faces), tri)
+    for meshes in ({"Town_synth": str(path)}, lambda loc: tri if loc == "Town_synth" else None):
+        world = world_from_waypoint_suite(data, agents_per_env=8, road_meshes=meshes)
+        assert world.ints["n_maps"] == 1 and (world.arrays["scn"]["map"] == 0).all()        # one map for the location
+        assert world.arrays["maps"]["n_tri"][0] == len(tri)
+    cfg = EnvConfig(seed=2, distance_cutoff=0.25)
+    env = BatchedWaypointEnv(cfg, data, num_envs=40, agents_per_env=8, obs_mode="state", road_meshes={"Town_synth": str(path)},
+                             info_magnitudes=True)
+    assert env.world.ints["n_maps"] == 1
+    hs = EnvState(40, 8)
+    ocfg = _abi.TdeConfig.from_buffer_copy(env.tde_cfg)
+    oracle.env_reset(ocfg, env.world, hs)
+    env.reset()
+    rng = np.random.default_rng(0)
+    n_off = 0
+    for t in range(150):
+        act = np.stack([rng.uniform(-0.2, 1, 40), rng.uniform(-0.3, 0.3, 40)], -1).astype(np.float32)
+        _, rew, term, trunc, info = env.step(torch.from_numpy(act).cuda())
+        hs["action"][...] = act
+        oracle.env_step(ocfg, env.world, hs)
+        assert np.array_equal(rew.cpu().numpy().view(np.uint32), hs["reward"].view(np.uint32)), t
+        n_off += int((info["offroad"] > 0).sum())
+    for k in ("x", "y", "psi", "v", "steps", "episode", "scn", "offroad", "collided"):
+        assert np.array_equal(env.state[k].cpu().numpy(), hs[k]), k
+    assert n_off > 5                           # egos did leave the town's streets: the mesh is the caller's, not a corridor
 
 
 def test_batched_env_device_api_and_vecenv_adapter(small_world):
@@ -173,8 +266,13 @@ def test_terminal_info_survives_in_place_respawn(small_world):
         a = torch.stack([torch.rand(B, generator=g) * 2 - 1, torch.rand(B, generator=g) * 0.6 - 0.3], -1)
         obs, rew, term, trunc, info = env.step(a)
         if term.any():
-            infr = (info["offroad"] > 0) | (info["collision"] > 0) | (info["traffic_light_violation"] > 0)
+            # (info["collision"] is the SUM OF IoUs, as the reference reports it: an overlap thinner than fp32 resolves clips to an
+            #  area of exactly 0 although the mask's strict-SAT predicate - which decides `terminated` - holds; the number of
+            #  overlapping agents, magnitudes[:, 2], is the mask's own predicate)
+            overlaps = env.state["magnitudes"][:, 2]
+            infr = (info["offroad"] > 0) | (overlaps > 0) | (info["traffic_light_violation"] > 0)
             assert torch.equal(infr, term), t                       # terminated <=> an infraction is reported
+            assert ((info["collision"] > 0) <= (overlaps > 0)).all()
             assert (env.state["steps"][term] == 0).all()            # ... although those envs already re-spawned
             seen += int(term.sum())
     assert seen > 10

@@ -14,7 +14,7 @@ torch = pytest.importorskip("torch")
 
 from oracle import oracle  # noqa: E402
 from tests.test_gpu_parity import assert_state_equal, dev  # noqa: E402
-from torchdriveenv_amd import _abi, ops  # noqa: E402
+from torchdriveenv_amd import _abi, _lib, ops  # noqa: E402
 from torchdriveenv_amd.state import EnvState  # noqa: E402
 
 DEV = "cuda:0"
@@ -117,22 +117,26 @@ def test_post_step_equals_magnitudes_then_masked_reset(small_world, A, squared):
 
 
 @pytest.mark.parametrize("obs_mode,frame_stack", [("birdview", 3), ("state", 1)])
-def test_batched_env_info_magnitudes_equals_the_one_launch_step(small_world, obs_mode, frame_stack):
-    """BatchedWaypointEnv(info_magnitudes=True) - step without in-kernel re-spawn, then tde_env_post_step - gives the
-    observations, rewards, flags and episodes of the one-launch step, and info["offroad"] / info["collision"] are the oracle's
-    magnitudes of the state the step left (the reference's info semantics) instead of 0 / 1"""
+def test_batched_env_fused_magnitudes_equal_indicator_env_and_post_step_form(small_world, obs_mode, frame_stack):
+    """BatchedWaypointEnv (default: info_magnitudes=True, tde_state.magnitudes written by the ONE-launch step) gives the
+    observations, rewards, flags and episodes of the indicator env (info_magnitudes=False) and of the round-4 two-launch form
+    (step without re-spawn, then tde_env_post_step), and info["offroad"] / info["collision"] are the oracle's magnitudes of the state
+    the step left (the reference's info semantics, gym_env.py:427-428) instead of 0 / 1"""
     from torchdriveenv_amd.config import EnvConfig
     from torchdriveenv_amd.env import BatchedWaypointEnv
 
     B = 160
     kw = dict(num_envs=B, agents_per_env=16, obs_mode=obs_mode, frame_stack=frame_stack)
-    plain = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, **kw)
-    mag = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, info_magnitudes=True, **kw)
+    plain = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, info_magnitudes=False, **kw)
+    mag = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, **kw)
+    two = BatchedWaypointEnv(EnvConfig(seed=8, distance_cutoff=0.25), small_world, **kw)
+    assert mag.info_magnitudes and plain.state["magnitudes"] is None
     hs = EnvState(B, 16)
     cfg_na = _abi.TdeConfig.from_buffer_copy(plain.tde_cfg)
     cfg_na.flags &= ~_abi.F_AUTORESET
     oracle.env_reset(cfg_na, small_world, hs)
-    assert torch.equal(plain.reset(), mag.reset())
+    o0 = plain.reset()
+    assert torch.equal(o0, mag.reset()) and torch.equal(o0, two.reset())
     rng = np.random.default_rng(2)
     seen = 0
     for t in range(90):
@@ -140,34 +144,110 @@ def test_batched_env_info_magnitudes_equals_the_one_launch_step(small_world, obs
         a = dev(act)
         o1, r1, te1, tr1, i1 = plain.step(a)
         o2, r2, te2, tr2, i2 = mag.step(a)
+        o3, r3, te3, tr3, i3 = two._step_then_post_step(a)
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), t
+        assert torch.equal(o3, o2) and torch.equal(r3, r2) and torch.equal(te3, te2) and torch.equal(tr3, tr2), t
         hs["action"][...] = act
         oracle.env_step(cfg_na, small_world, hs)
         want = oracle.ego_infractions(cfg_na, small_world, hs)
+        assert np.array_equal(hs["magnitudes"].view(np.uint32), want.view(np.uint32))
         assert np.array_equal(i2["offroad"].cpu().numpy().view(np.uint32), want[:, 0].view(np.uint32)), t
         assert np.array_equal(i2["collision"].cpu().numpy().view(np.uint32), want[:, 1].view(np.uint32)), t
+        assert torch.equal(mag.state["magnitudes"], two.state["magnitudes"]), t
         assert torch.equal(i1["offroad"] > 0, i2["offroad"] > 0) and torch.equal(i1["collision"] > 0, i2["collision"] > 0)
         seen += int((want[:, 0] > 0).sum())
         done = (hs["terminated"] | hs["truncated"]).astype(np.uint8)
         if done.any():
             oracle.env_reset(cfg_na, small_world, hs, done)
     for k in ("x", "y", "psi", "v", "steps", "episode", "scn"):
-        assert torch.equal(plain.state[k], mag.state[k]), k
+        assert torch.equal(plain.state[k], mag.state[k]) and torch.equal(two.state[k], mag.state[k]), k
     assert seen > 10 and int(plain.state["episode"].max()) > 1
 
 
+def _step_forms(A):
+    return (("trio", "solo") if A in (8, 16, 32) else ("solo",))
+
+
+@pytest.mark.parametrize("which", ["junctions_8192x16", "town_2048x16", "town_lights_512x16", "wide_64x128", "a32_1024", "a64_256", "a4_512"])
+def test_one_launch_step_magnitudes_equal_step_plus_post_step_and_oracle(which, town):
+    """tde_env_step with tde_state.magnitudes (one launch, every kernel form) == step without TDE_F_AUTORESET + tde_env_post_step
+    (round 4's two launches) == the oracle's step: magnitudes, state, outputs, bit for bit - on BASELINE configs[2]'s batch, the
+    town (large grid), a signalised town, 128 slots per env, and the other group shapes"""
+    from torchdriveenv_amd.synth import synthetic_town, synthetic_world
+
+    lights = False
+    if which == "junctions_8192x16":
+        world, B, A, T = synthetic_world(n_scn=64, A=16, seed=0, n_maps=4), 8192, 16, 12
+    elif which == "town_2048x16":
+        world, B, A, T = town, 2048, 16, 25
+    elif which == "town_lights_512x16":
+        world, B, A, T, lights = synthetic_town(n_scn=64, A=16, seed=3, n_streets=5, spacing=100.0, ext=45.0, n_signals=9), 512, 16, 60, True
+    elif which == "wide_64x128":
+        world, B, A, T = synthetic_town(n_scn=4, A=128, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4), 64, 128, 30
+    elif which == "a32_1024":
+        world, B, A, T = synthetic_world(n_scn=16, A=32, seed=2, n_maps=2), 1024, 32, 40
+    elif which == "a64_256":
+        world, B, A, T = synthetic_world(n_scn=8, A=64, seed=3, n_maps=2), 256, 64, 40
+    else:
+        world, B, A, T = synthetic_world(n_scn=8, A=4, seed=4, n_maps=2), 512, 4, 60
+    flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0)
+    cfg = _abi.default_config(seed=21, flags=flags, max_steps=40, distance_cutoff=0.25)
+    cfg_na = _abi.TdeConfig.from_buffer_copy(cfg)
+    cfg_na.flags &= ~_abi.F_AUTORESET
+    dw = world.to_device(DEV)
+    hs = EnvState(B, A)
+    oracle.env_reset(cfg, world, hs)
+    forms = _step_forms(A)
+    fused = [EnvState(B, A, device=DEV, with_obs=True) for _ in forms]
+    two = EnvState(B, A, device=DEV, with_obs=True, with_magnitudes=False)
+    for d in fused + [two]:
+        d.load(hs.host())
+    mag2 = torch.zeros(B, 4, device=DEV)
+    rng = np.random.default_rng(6)
+    n_off = n_col = n_done = 0
+    try:
+        for t in range(T):
+            act = np.stack([rng.uniform(-0.2, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            oracle.env_step(cfg, world, hs)
+            a = dev(act)
+            for form, d in zip(forms, fused):
+                _lib.kernel_override(step=form)
+                ops.env_step(cfg, dw, d, action=a)
+            _lib.kernel_override()
+            ops.env_step(cfg_na, dw, two, action=a)
+            ops.env_post_step(cfg, dw, two, mag2)
+            want = hs["magnitudes"]
+            for form, d in zip(forms, fused):
+                got = d["magnitudes"].cpu().numpy()
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (which, form, t, np.abs(got - want).max())
+            assert np.array_equal(mag2.cpu().numpy().view(np.uint32), want.view(np.uint32)), (which, t)
+            n_off += int((want[:, 0] > 0).sum()); n_col += int((want[:, 1] > 0).sum())
+            n_done += int(((hs["done_bits"] & 3) != 0).sum())
+        for form, d in zip(forms, fused):
+            assert_state_equal(hs.host(), d.host(), f"{which}: fused step ({form}) vs oracle")
+            for k in ("x", "y", "psi", "v", "steps", "episode", "scn", "obs", "reward"):
+                assert torch.equal(d[k], two[k]), (which, form, k)
+    finally:
+        _lib.kernel_override()
+    assert n_done > 0 and n_off + n_col > 0, (n_done, n_off, n_col)
+    if which in ("junctions_8192x16", "town_2048x16"):
+        assert n_off > 20 and n_col > 5
+
+
 def test_vecenv_with_info_magnitudes_equals_the_plain_vecenv(small_world):
-    """the SB3 path over BatchedWaypointEnv(info_magnitudes=True): WaypointVecEnv clears TDE_F_AUTORESET for its own masked reset,
-    so tde_env_post_step computes magnitudes and re-spawns NOTHING - observations, rewards, dones, terminal observations and
-    episode statistics equal the plain VecEnv's, and the info columns carry the magnitudes"""
+    """the SB3 path over BatchedWaypointEnv (default info_magnitudes=True): WaypointVecEnv clears TDE_F_AUTORESET for its own masked
+    reset, the step kernel writes the magnitudes into the packed output arena (one device-to-host copy for everything) -
+    observations, rewards, dones, terminal observations and episode statistics equal the indicator VecEnv's, and the info columns
+    carry the magnitudes"""
     from torchdriveenv_amd.config import EnvConfig
     from torchdriveenv_amd.env import BatchedWaypointEnv, WaypointVecEnv
 
     B = 96
     cfg = EnvConfig(seed=12, distance_cutoff=0.25, max_environment_steps=40)
     kw = dict(num_envs=B, agents_per_env=16, obs_mode="state")
-    v0 = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, **kw))
-    v1 = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, info_magnitudes=True, **kw))
+    v0 = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, info_magnitudes=False, **kw))
+    v1 = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, **kw))
     assert np.array_equal(v0.reset(), v1.reset())
     rng = np.random.default_rng(3)
     n_done = n_mag = 0

@@ -179,3 +179,57 @@ def test_town_grid_index_equals_brute_force(small_town):
     assert np.array_equal(grid_offroad_numpy(w, 0, px, py, 0.5), want)
     assert np.array_equal(grid_offroad_numpy(w, 0, px, py, 0.5, use_sub=True), want)
     assert 0.1 < want.mean() < 0.9
+
+
+def near_list_d2_numpy(w, map_id, px, py):
+    """what the magnitude kernels do with the near lists (csrc/tde_magnitudes.h: ego_offroad_mag_wave), restated in numpy on the
+    world's tables: the corner's coarse tile -> tile_near word -> the list's records (its length in the first record) -> the minimum
+    of the CPU checker's point-triangle distance over the list.  Returns (d2, code) with code 0 = no list, 1 = all FULL, 2 = listed"""
+    m = w.arrays["maps"][map_id]
+    fx = np.clip((np.float32(px) - m["ox"]) * m["inv_cell"], 0, m["nx"] - 1)
+    fy = np.clip((np.float32(py) - m["oy"]) * m["inv_cell"], 0, m["ny"] - 1)
+    ix, iy = int(fx), int(fy)
+    inside = m["ox"] <= px < m["ox"] + np.float32(m["nx"]) * m["cell"] and m["oy"] <= py < m["oy"] + np.float32(m["ny"]) * m["cell"]
+    tw = int(w.arrays["tile_near"][m["near_base"] + (iy // 4) * (m["nx"] // 4) + ix // 4]) if inside else 0
+    if tw == 0:
+        return None, 0 if inside else 3
+    if tw == 0xFFFFFFFF:
+        return None, 1
+    recs = w.arrays["cell_tri"].reshape(-1, 12)
+    first = m["rec_base"] + tw - 1
+    n = int(recs[first, 9:10].view(np.int32)[0])
+    assert n >= 1
+    tris = recs[first:first + n, :6]
+    return min(oracle.point_mesh_d2(px, py, t[None]) for t in tris), 2
+
+
+def test_near_lists_give_the_brute_force_distance(small_world, small_town):
+    """ABI 10: the minimum of the point-triangle distances over a coarse tile's NEAR LIST equals the CPU checker's minimum over
+    EVERY triangle of the map, bit for bit, for points anywhere in the tile - the magnitude of the offroad infraction
+    (gym_env.py:427) reads two table entries instead of scanning the grid.  Tiles coded 'all FULL' hold only points within the
+    threshold; tiles without a list lie farther than threshold + near_range from the mesh."""
+    from torchdriveenv_amd.world import NEAR_RANGE
+
+    rng = np.random.default_rng(5)
+    for w, n in ((small_world, 2500), (small_town, 1500)):
+        for map_id in range(min(2, w.ints["n_maps"])):
+            m = w.arrays["maps"][map_id]
+            tri = w.arrays["tri"][m["tri_base"]:m["tri_base"] + m["n_tri"]]
+            px, py = _edge_points(tri, n, rng, spread=1.2)
+            codes = np.zeros(4, int)                       # (code 3: outside the grid - the kernels scan)
+            for x, y in zip(px, py):
+                want = oracle.point_mesh_d2(x, y, tri)
+                got, code = near_list_d2_numpy(w, map_id, x, y)
+                codes[code] += 1
+                if code == 2:
+                    assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32), (x, y, got, want)
+                elif code == 1:
+                    assert want <= np.float32(0.5) * np.float32(0.5)
+                elif code == 0:
+                    assert np.sqrt(want) > 0.5 + NEAR_RANGE - 1.0        # (a tile's centre decides: a point of it may be a tile diagonal closer)
+            assert codes[2] > 0.1 * n and codes[1] > 0 and codes[0] > 0, codes
+    # every list's length rides in its first record, and the table ends with 16 spare records
+    recs = small_town.arrays["cell_tri"].reshape(-1, 12)
+    assert (recs[-16:] == 0).all()
+    lens = recs[:, 9].view(np.int32)
+    assert lens.max() < 200 and (lens >= 0).all()

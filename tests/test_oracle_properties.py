@@ -73,9 +73,9 @@ def test_rollout_equals_repeated_steps_and_reward_bounds(small_world):
     for k in ha:
         # (the Monitor-style episode statistics and done_bits belong to the closed-loop step API; a rollout leaves them
         #  alone: tde_abi.h, "tde_env_step only")
-        if k not in ("action", "done_bits") and not k.startswith("ep_"):
+        if k not in ("action", "done_bits", "magnitudes") and not k.startswith("ep_"):
             assert np.array_equal(ha[k].view(np.uint8), hb[k].view(np.uint8)), k
-    assert not ha["ep_return"].any() and hb["ep_final_len"].max() > 0
+    assert not ha["ep_return"].any() and hb["ep_final_len"].max() > 0 and not ha["magnitudes"].any()
     # reward = waypoint_bonus*[reach] + distance_bonus*[moved] - heading_penalty*(1 - cos dpsi)
     assert r.max() <= 101.0 + 1e-6 and r.min() >= -50.0 - 1e-6
     assert ((r > 50) == (r > 99 - 50)).all()
@@ -91,3 +91,26 @@ def test_rollout_equals_repeated_steps_and_reward_bounds(small_world):
     oracle.env_reset(cfg3, small_world, e)
     oracle.env_reset(cfg, small_world, f0)
     assert not np.array_equal(e["x"], f0["x"])
+
+
+def test_step_magnitudes_equal_the_ungated_operator(small_world):
+    """tde_state.magnitudes, which the step fills only for the egos it flagged, equals tde_ego_infractions' brute force on EVERY
+    env: a magnitude is non-zero only under its flag (collision: the mask's own predicate; offroad: a corner beyond the threshold
+    has d^2 > thr^2 and sqrt(d^2) <= thr otherwise) - the gate never changes a value.  Both readings of the threshold."""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    for squared, world in ((0, small_world), (1, synthetic_world(n_scn=8, A=16, seed=0, n_maps=2, threshold=float(np.sqrt(0.5))))):
+        cfg = _abi.default_config(seed=9, flags=_abi.F_ALL & ~_abi.F_AUTORESET, terminated_at_infraction=0, max_steps=10_000,
+                                  offroad_threshold_squared=squared)
+        B, A = 64, 16
+        hs = EnvState(B, A)
+        oracle.env_reset(cfg, world, hs)
+        rng = np.random.default_rng(squared)
+        n_off = n_col = 0
+        for t in range(60):
+            hs["action"][...] = np.stack([rng.uniform(-0.2, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            oracle.env_step(cfg, world, hs)
+            want = oracle.ego_infractions(cfg, world, hs)
+            assert np.array_equal(hs["magnitudes"].view(np.uint32), want.view(np.uint32)), t
+            n_off += int((want[:, 0] > 0).sum()); n_col += int((want[:, 1] > 0).sum())
+        assert n_off > 50 and n_col > 0

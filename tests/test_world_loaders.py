@@ -333,3 +333,58 @@ def test_light_groups_share_the_grid_of_their_mesh():
         sc = dict(map=0, waypoints=[(0, 0), (10, 0)], start_heading=0.0, lights=0)
         tri = np.array([[[0, -5], [20, -5], [20, 5]]], np.float32)
         assemble_world([tri, tri], [sc], 1, light_groups=[dict(map=1, stoplines=[(5, 0, 0, 1, 3, 0)], phases=[(10, [0])])])
+
+
+def test_road_meshes_hook_gives_the_callers_map(tmp_path):
+    """world_from_waypoint_suite(road_meshes=...) (ref gym_env.py:312, 184, 260: find_map_config(location).road_mesh handed to
+    the simulator): scenarios of a location that has a mesh share ONE map built from it - dict of arrays, dict of .npy paths,
+    callable, verts / faces - and a location without one keeps its synthetic corridor; the oracle's offroad flags on the
+    assembled world are those of the caller's triangles (brute force)"""
+    from oracle import oracle
+    from torchdriveenv_amd.env import mesh_from_verts_faces, world_from_waypoint_suite
+    from torchdriveenv_amd.state import EnvState
+    from torchdriveenv_amd.synth import Town
+
+    town = Town(n=3, spacing=100.0, ext=30.0)
+    tri = town.mesh()
+    suites = [[[float(v) for v in town.F(20.0 + 25.0 * k + 14.0 * i, 0.0)] for i in range(8)] for k in range(4)]
+    data = WaypointSuite(locations=["TownA", "TownA", "TownB", "TownA"], waypoint_suite=suites, car_sequence_suite=[None] * 4,
+                         scenarios=[None] * 4)
+    np.save(tmp_path / "a.npy", tri.astype(np.float32))
+    verts, faces = tri.reshape(-1, 2), np.arange(3 * len(tri)).reshape(-1, 3)
+    forms = ({"TownA": tri}, {"TownA": str(tmp_path / "a.npy")}, lambda loc: tri if loc == "TownA" else None,
+             {"TownA": mesh_from_verts_faces(verts, faces)})
+    worlds = [world_from_waypoint_suite(data, agents_per_env=4, road_meshes=f) for f in forms]
+    for w in worlds:
+        assert w.ints["n_maps"] == 2 and list(w.arrays["scn"]["map"]) == [0, 0, 1, 0]      # TownA shared, TownB its corridor
+        assert w.arrays["maps"]["n_tri"][0] == len(tri)
+        assert np.array_equal(w.arrays["tri"][:len(tri)], tri.astype(np.float32).reshape(-1, 6))
+        assert np.array_equal(w.arrays["cell_word"], worlds[0].arrays["cell_word"])
+    with pytest.raises(ValueError):
+        world_from_waypoint_suite(data, agents_per_env=4, road_meshes={"TownA": np.zeros((3, 5))})
+    # an ego driving across the town's block interior is off THIS mesh (a corridor around its own waypoints would hold it)
+    w = worlds[0]
+    cfg = to_tde_config(EnvConfig(seed=1, terminated_at_infraction=False), 1, _abi.F_ALL & ~_abi.F_AUTORESET)
+    hs = EnvState(8, 4)
+    oracle.env_reset(cfg, w, hs)
+    seen = 0
+    for t in range(120):
+        hs["action"][...] = np.array([0.5, 0.25], np.float32)
+        oracle.env_step(cfg, w, hs)
+        x, y, psi = hs["x"][::4], hs["y"][::4], hs["psi"][::4]
+        s, c = np.sin(psi), np.cos(psi)
+        hl, hw = 0.5 * hs["len"][::4], 0.5 * hs["wid"][::4]
+        for e in range(8):
+            m = int(w.arrays["scn"]["map"][hs["scn"][e]])
+            if m != 0:
+                continue
+            far = any(oracle.point_mesh_d2(x[e] + sx * hl[e] * c[e] - sy * hw[e] * s[e], y[e] + sx * hl[e] * s[e] + sy * hw[e] * c[e],
+                                           tri.astype(np.float32)) > 0.25 + 1e-3 for sx in (-1, 1) for sy in (-1, 1))
+            near = all(oracle.point_mesh_d2(x[e] + sx * hl[e] * c[e] - sy * hw[e] * s[e], y[e] + sx * hl[e] * s[e] + sy * hw[e] * c[e],
+                                            tri.astype(np.float32)) < 0.25 - 1e-3 for sx in (-1, 1) for sy in (-1, 1))
+            if far:
+                assert hs["offroad"][4 * e] == 1
+                seen += 1
+            elif near:
+                assert hs["offroad"][4 * e] == 0
+    assert seen > 10

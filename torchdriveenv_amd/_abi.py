@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 9
+TDE_ABI_VERSION = 10
 TDE_MAX_AGENTS = 128
 
 F_NPC = 1 << 0
@@ -17,6 +17,7 @@ F_REWARD = 1 << 3
 F_AUTORESET = 1 << 4
 F_EGO_ONLY_ATTRS = 1 << 5
 F_TRAFFIC_LIGHTS = 1 << 6
+F_NPC_FIRST_STEP = 1 << 7
 F_ALL = F_NPC | F_REPLAY | F_OFFROAD | F_REWARD | F_AUTORESET
 
 CELL_EMPTY, CELL_MIXED, CELL_FULL = 0, 1, 2
@@ -57,7 +58,7 @@ class TdeMap(C.Structure):
         ("nx", C.c_int32), ("ny", C.c_int32), ("cell_base", C.c_int32), ("tri_base", C.c_int32),
         ("n_tri", C.c_int32), ("stop_base", C.c_int32), ("n_stop", C.c_int32), ("phase_base", C.c_int32),
         ("n_phase", C.c_int32), ("cycle_steps", C.c_int32), ("row_shift", C.c_int32), ("cls2_base", C.c_int32),
-        ("rec_base", C.c_int32), ("coarse_base", C.c_int32), ("_pad0", C.c_int32 * 2),
+        ("rec_base", C.c_int32), ("coarse_base", C.c_int32), ("near_base", C.c_int32), ("_pad0", C.c_int32),
     ]
 
 
@@ -68,13 +69,14 @@ class TdeGrid(C.Structure):
         ("n_lists", C.c_int64), ("n_records", C.c_int64),
         ("cell_class", C.POINTER(C.c_uint8)), ("cell_count", C.POINTER(C.c_uint8)),
         ("cell_first", C.POINTER(C.c_uint32)), ("cell_sub", C.POINTER(C.c_uint32)), ("rec_tri", C.POINTER(C.c_int32)),
+        ("tile_near", C.POINTER(C.c_uint32)), ("rec_len", C.POINTER(C.c_int32)), ("n_near_lists", C.c_int64),
     ]
 
 
 MAP_DTYPE = np.dtype([("ox", "f4"), ("oy", "f4"), ("cell", "f4"), ("inv_cell", "f4"), ("nx", "i4"), ("ny", "i4"),
                       ("cell_base", "i4"), ("tri_base", "i4"), ("n_tri", "i4"), ("stop_base", "i4"), ("n_stop", "i4"),
                       ("phase_base", "i4"), ("n_phase", "i4"), ("cycle_steps", "i4"), ("row_shift", "i4"), ("cls2_base", "i4"),
-                      ("rec_base", "i4"), ("coarse_base", "i4"), ("_pad0", "i4", (2,))])
+                      ("rec_base", "i4"), ("coarse_base", "i4"), ("near_base", "i4"), ("_pad0", "i4")])
 STOPLINE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("c", "f4"), ("s", "f4"), ("hl", "f4"), ("hw", "f4"),
                            ("light", "i4"), ("_pad0", "i4")])
 PHASE_DTYPE = np.dtype([("end_step", "i4"), ("red_mask", "u4")])
@@ -86,7 +88,7 @@ SPAWN_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("psi", "f4"), ("v", "f4"), ("
 SCN_DTYPE = np.dtype([("map", "i4"), ("wp_n", "i4"), ("start_heading", "f4"), ("_pad0", "i4")])
 assert SPAWN_DTYPE.itemsize == 64 and SCN_DTYPE.itemsize == 16
 
-WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "cell_cls2", "cell_sub", "cell_coarse", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
+WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "cell_cls2", "cell_sub", "cell_coarse", "tile_near", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
               "stoplines", "phases"]
 WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT", "hints"]
 WORLD_LARGE_GRID = 1 << 0
@@ -102,7 +104,7 @@ STATE_AGENT_U8 = ["present", "collided", "offroad"]
 STATE_ENV_I32 = ["scn", "steps", "target_idx", "reached", "episode"]
 STATE_PTRS = (STATE_AGENT_F32 + STATE_AGENT_I32 + STATE_AGENT_U8 + STATE_ENV_I32 +
               ["action", "reward", "terminated", "truncated", "tl_violation", "info", "info_reached", "done_bits", "obs",
-               "ep_return", "ep_final", "ep_final_len", "slot_cache", "env_cache", "act_cache"])
+               "ep_return", "ep_final", "ep_final_len", "slot_cache", "env_cache", "act_cache", "magnitudes"])
 
 
 class TdeState(C.Structure):
@@ -171,7 +173,7 @@ def default_config(**over):
 
 
 WORLD_DTYPES = {
-    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "cell_cls2": np.uint32, "cell_sub": np.uint32, "cell_coarse": np.uint8, "scn": SCN_DTYPE,
+    "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "cell_cls2": np.uint32, "cell_sub": np.uint32, "cell_coarse": np.uint8, "tile_near": np.uint32, "scn": SCN_DTYPE,
     "wp_xy": np.float64, "spawn": SPAWN_DTYPE, "route_xy": np.float32, "replay_states": np.float32,
     "stoplines": STOPLINE_DTYPE, "phases": PHASE_DTYPE,
 }
@@ -182,7 +184,7 @@ STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n
                 "tl_violation": np.uint8,
                 "info": np.float64, "info_reached": np.int32, "done_bits": np.uint8, "obs": np.float32,
                 "ep_return": np.float64, "ep_final": np.float64, "ep_final_len": np.int32,
-                "slot_cache": np.int32, "env_cache": np.int32, "act_cache": np.int32}          # opaque 32-byte records (tde_slot_cache / tde_env_cache)
+                "slot_cache": np.int32, "env_cache": np.int32, "act_cache": np.int32, "magnitudes": np.float32}          # opaque 32-byte records (tde_slot_cache / tde_env_cache)
 
 
 def state_shapes(B, A):
@@ -191,7 +193,8 @@ def state_shapes(B, A):
     sh.update({"action": (B, 2), "reward": (B,), "terminated": (B,), "truncated": (B,), "tl_violation": (B,),
                "info": (B, 4),
                "info_reached": (B,), "done_bits": (B,), "obs": (B, 8), "ep_return": (B,), "ep_final": (B,),
-               "ep_final_len": (B,), "slot_cache": (B * A, 8), "env_cache": (B, 8), "act_cache": (B * (A + 1), 2)})
+               "ep_final_len": (B,), "slot_cache": (B * A, 8), "env_cache": (B, 8), "act_cache": (B * (A + 1), 2),
+               "magnitudes": (B, 4)})
     return sh
 
 

@@ -55,7 +55,7 @@ def load():
     L.tde_ego_infractions.argtypes = [cfgp, wp, sp, vp, vp]
     L.tde_env_post_step.argtypes = [cfgp, wp, sp, vp, vp]
     L.tde_kernel_override.argtypes = [C.c_int, C.c_int]
-    L.tde_grid_build.argtypes = [vp, i32, f32, f32, f32, i32, C.POINTER(C.POINTER(_abi.TdeGrid))]
+    L.tde_grid_build.argtypes = [vp, i32, f32, f32, f32, f32, i32, C.POINTER(C.POINTER(_abi.TdeGrid))]
     L.tde_grid_free.argtypes = [C.POINTER(_abi.TdeGrid)]
     L.tde_grid_free.restype = None
     for s in SYMBOLS:

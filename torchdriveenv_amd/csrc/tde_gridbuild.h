@@ -21,6 +21,8 @@
 #include <cstring>
 #include <atomic>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <unordered_map>
@@ -66,6 +68,35 @@ struct RowOut {                                 // what one grid row contributes
     std::vector<uint32_t> at;                   // per MIXED cell (in ix order): start in ids
 };
 
+struct TileRow {                                // what one row of coarse tiles contributes to the near lists
+    std::vector<int32_t> ids;                   // concatenated near lists of the row's listed tiles (ascending triangle index)
+    std::vector<uint32_t> at;                   // per listed tile: start in ids (one more entry at the end)
+    std::vector<int32_t> tx;                    // per listed tile: its column
+};
+
+// fn(w) on nt host threads; an exception thrown by a worker (std::bad_alloc from a growing vector: a town mesh allocates
+// hundreds of MB) is carried to the calling thread and rethrown there after every worker has been joined - an exception that
+// leaves a std::thread's function calls std::terminate, which would take the Python process down
+template <typename F> static void run_pool(int nt, F &&fn)
+{
+    std::vector<std::thread> pool;
+    std::exception_ptr err;
+    std::mutex mu;
+    auto body = [&](int w) {
+        try { fn(w); }
+        catch (...) { std::lock_guard<std::mutex> lock(mu); if (!err) err = std::current_exception(); }
+    };
+    try {
+        pool.reserve((size_t)nt);
+        for (int w = 0; w < nt; ++w) pool.emplace_back(body, w);
+    } catch (...) {                             // (thread creation failed part-way: join what runs, then report)
+        for (auto &th : pool) th.join();
+        throw;
+    }
+    for (auto &th : pool) th.join();
+    if (err) std::rethrow_exception(err);
+}
+
 // exact squared Euclidean distance transform (Felzenszwalb & Huttenlocher): f[i] = 0 on the target set, INF elsewhere
 static void edt_1d(const double *f, int n, double *d, int *v, double *z)
 {
@@ -96,18 +127,20 @@ void tde_grid_free(tde_grid *g)
 {
     if (!g) return;
     free(g->cell_class); free(g->cell_count); free(g->cell_first); free(g->cell_sub); free(g->rec_tri);
+    free(g->tile_near); free(g->rec_len);
     free(g);
 }
 
-static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, int32_t n_threads,
-                               tde_grid **out);
+static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, float near_range_f,
+                               int32_t n_threads, tde_grid **out);
 
-int tde_grid_build(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, int32_t n_threads,
-                   tde_grid **out)
+int tde_grid_build(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, float near_range_f,
+                   int32_t n_threads, tde_grid **out)
 {
-    // no C++ exception crosses the C-ABI (host containers and threads are used inside)
+    // no C++ exception crosses the C-ABI (host containers and threads are used inside; a worker thread that throws hands its
+    // exception to the calling thread: run_pool)
     try {
-        return tde_grid_build_impl(tri32, n_tri, threshold_f, cell_f, margin_f, n_threads, out);
+        return tde_grid_build_impl(tri32, n_tri, threshold_f, cell_f, margin_f, near_range_f, n_threads, out);
     } catch (const std::bad_alloc &) {
         return bad("tde_grid_build: out of host memory");
     } catch (const std::exception &e) {
@@ -117,13 +150,14 @@ int tde_grid_build(const float *tri32, int32_t n_tri, float threshold_f, float c
     }
 }
 
-static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, int32_t n_threads,
-                               tde_grid **out)
+static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshold_f, float cell_f, float margin_f, float near_range_f,
+                               int32_t n_threads, tde_grid **out)
 {
     using namespace tde_grid_detail;
     if (!tri32 || !out || n_tri < 1) return bad("tde_grid_build: needs a mesh of at least one triangle");
     if (!(threshold_f > 0.0f) || !(cell_f > 0.0f) || !(margin_f > 0.0f) || !(margin_f < threshold_f))
         return bad("tde_grid_build: needs threshold > margin > 0 and cell > 0");
+    if (!(near_range_f >= 0.0f) || !(near_range_f <= 64.0f)) return bad("tde_grid_build: near_range must be in [0, 64] metres");
     *out = nullptr;
     const double thr = threshold_f, cell = cell_f, margin = margin_f;
     constexpr int LAT = 4;                                   // (LAT + 1)^2 lattice points per cell
@@ -154,7 +188,8 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
     }
     // >= 2 EMPTY cells on every side (the kernels clamp cell coordinates instead of testing bounds); the origin is an
     // integer, exactly representable in fp32 (the kernels subtract it in fp32)
-    const double pad = R + 2.0 * cell;
+    // (with near lists the grid reaches as far as they do: a corner beyond the grid has no tile to look its list up in)
+    const double pad = std::max(R, thr + (double)near_range_f) + 2.0 * cell;
     const double ox = (double)(float)std::floor(lox - pad), oy = (double)(float)std::floor(loy - pad);
     const int64_t nx64 = 8 * (int64_t)std::ceil((hix + pad - ox) / cell / 8.0), ny64 = 8 * (int64_t)std::ceil((hiy + pad - oy) / cell / 8.0);
     if (nx64 < 8 || ny64 < 8 || nx64 > 32768 || ny64 > 32768 || nx64 * ny64 > ((int64_t)1 << 28))
@@ -162,14 +197,18 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
     const int nx = (int)nx64, ny = (int)ny64;
     const size_t ncell = (size_t)nx * ny;
 
-    tde_grid *g = (tde_grid *)calloc(1, sizeof(tde_grid));
+    // (owned until success: an exception or an early return below frees every table)
+    std::unique_ptr<tde_grid, void (*)(tde_grid *)> owner((tde_grid *)calloc(1, sizeof(tde_grid)), tde_grid_free);
+    tde_grid *g = owner.get();
     if (!g) return bad("tde_grid_build: out of memory");
     g->ox = (float)ox; g->oy = (float)oy; g->cell = cell_f; g->nx = nx; g->ny = ny;
     g->cell_class = (uint8_t *)calloc(ncell, 1);
     g->cell_count = (uint8_t *)calloc(ncell, 1);
     g->cell_first = (uint32_t *)calloc(ncell, 4);
     g->cell_sub = (uint32_t *)calloc(ncell, 4);
-    if (!g->cell_class || !g->cell_count || !g->cell_first || !g->cell_sub) { tde_grid_free(g); return bad("tde_grid_build: out of memory"); }
+    const int ntx = nx / TDE_COARSE_CELLS, nty = ny / TDE_COARSE_CELLS;       // (nx, ny are multiples of 8)
+    g->tile_near = (uint32_t *)calloc((size_t)ntx * nty, 4);
+    if (!g->cell_class || !g->cell_count || !g->cell_first || !g->cell_sub || !g->tile_near) return bad("tde_grid_build: out of memory");
 
     // coarse bins of BIN x BIN cells: a triangle is listed in every bin its bounding box, dilated by `band`, overlaps, so the
     // bin of a cell centre holds every triangle within `band` of that centre
@@ -295,16 +334,86 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
     nt = std::max(1, std::min(nt, 64));
     {
         // rows are dealt out in small chunks (a town's roads are not spread evenly over its rows)
-        std::vector<std::thread> pool;
         const int chunk = 16;
         const int nchunks = (ny + chunk - 1) / chunk;
-        for (int w = 0; w < nt; ++w)
-            pool.emplace_back([&, w]() {
-                for (int c = w; c < nchunks; c += nt) work(c * chunk, std::min(ny, (c + 1) * chunk));
-            });
-        for (auto &th : pool) th.join();
+        run_pool(nt, [&](int w) {
+            for (int c = w; c < nchunks; c += nt) work(c * chunk, std::min(ny, (c + 1) * chunk));
+        });
     }
-    if (too_many.load()) { tde_grid_free(g); return bad("tde_grid_build: more than 255 candidate triangles in one grid cell: use a smaller cell"); }
+    if (too_many.load()) return bad("tde_grid_build: more than 255 candidate triangles in one grid cell: use a smaller cell");
+
+    // ---- near lists (ABI 10): per coarse tile of TDE_COARSE_CELLS x TDE_COARSE_CELLS cells the triangles among which the NEAREST
+    // triangle of every point of the tile is found - what the magnitude of the offroad infraction needs (clamp(distance - threshold),
+    // ref gym_env.py:427), where the mask only needs the triangles within the threshold.  For a point p of the tile (centre c,
+    // half diagonal rho of the tile grown by `margin`), its nearest triangle T* has d(T*, p) <= d(Tc, p) <= dnear(c) + rho, so
+    // d(T*, c) <= dnear(c) + 2 rho: the list holds every triangle that close to the centre.  Tiles farther than threshold +
+    // near_range from the mesh get no list (code 0: the kernels scan the grid instead), tiles whose 16 cells are all FULL the
+    // code 0xFFFFFFFF (every point within the threshold: the magnitude's term is 0).
+    std::vector<TileRow> trows((size_t)nty);
+    const double near_d = thr + (double)near_range_f;
+    if (near_range_f > 0.0f) {
+        constexpr int TC = TDE_COARSE_CELLS;
+        const double rho = (0.5 * TC * cell + margin) * std::sqrt(2.0) + 1e-9;
+        const double fband = near_d + 2.0 * rho;
+        // bins of their own (FBIN x FBIN cells): the dilation is several metres where the classification pass needs ~1
+        constexpr int FBIN = 32;
+        const int fnx = (nx + FBIN - 1) / FBIN, fny = (ny + FBIN - 1) / FBIN;
+        const double fsz = FBIN * cell;
+        std::vector<uint32_t> fstart((size_t)fnx * fny + 1, 0u);
+        auto frange = [&](const Tri &t, int &i0, int &i1, int &j0, int &j1) {
+            i0 = std::max(0, (int)std::floor((t.x0 - fband - ox) / fsz)); i1 = std::min(fnx - 1, (int)std::floor((t.x1 + fband - ox) / fsz));
+            j0 = std::max(0, (int)std::floor((t.y0 - fband - oy) / fsz)); j1 = std::min(fny - 1, (int)std::floor((t.y1 + fband - oy) / fsz));
+        };
+        for (const Tri &t : T) {
+            int i0, i1, j0, j1;
+            frange(t, i0, i1, j0, j1);
+            for (int j = j0; j <= j1; ++j)
+                for (int i = i0; i <= i1; ++i) ++fstart[(size_t)j * fnx + i + 1];
+        }
+        for (size_t b = 0; b < (size_t)fnx * fny; ++b) fstart[b + 1] += fstart[b];
+        std::vector<int32_t> fbins(fstart.back());
+        {
+            std::vector<uint32_t> fill(fstart.begin(), fstart.end() - 1);
+            for (int32_t k = 0; k < n_tri; ++k) {             // ascending k: every bin list is sorted by triangle index
+                int i0, i1, j0, j1;
+                frange(T[(size_t)k], i0, i1, j0, j1);
+                for (int j = j0; j <= j1; ++j)
+                    for (int i = i0; i <= i1; ++i) fbins[fill[(size_t)j * fnx + i]++] = k;
+            }
+        }
+        auto near_work = [&](int ty) {
+            TileRow &tr = trows[(size_t)ty];
+            std::vector<std::pair<int32_t, double>> cand;
+            for (int tx = 0; tx < ntx; ++tx) {
+                bool all_full = true;
+                for (int dy = 0; dy < TC && all_full; ++dy)
+                    for (int dx = 0; dx < TC; ++dx)
+                        if (g->cell_class[(size_t)(ty * TC + dy) * nx + tx * TC + dx] != TDE_CELL_FULL) { all_full = false; break; }
+                if (all_full) { g->tile_near[(size_t)ty * ntx + tx] = 0xFFFFFFFFu; continue; }
+                const double pcx = ox + (tx * TC + 0.5 * TC) * cell, pcy = oy + (ty * TC + 0.5 * TC) * cell;
+                const size_t b = (size_t)((ty * TC + TC / 2) / FBIN) * fnx + (size_t)((tx * TC + TC / 2) / FBIN);
+                const uint32_t s0 = fstart[b], s1 = fstart[b + 1];
+                if (s0 == s1) continue;                       // nothing within reach: no list
+                cand.clear();
+                double dnear = 1e300;
+                for (uint32_t s = s0; s < s1; ++s) {
+                    const Tri &t = T[(size_t)fbins[s]];
+                    const double reach = std::min(dnear, near_d) + 2.0 * rho;     // (farther than this it cannot enter the list)
+                    if (pcx < t.x0 - reach || pcx > t.x1 + reach || pcy < t.y0 - reach || pcy > t.y1 + reach) continue;
+                    const double dc = point_tri(t, pcx, pcy, nullptr);
+                    cand.emplace_back(fbins[s], dc);
+                    dnear = std::min(dnear, dc);
+                }
+                if (!(dnear <= near_d)) continue;             // too far from the mesh: no list
+                tr.tx.push_back(tx);
+                tr.at.push_back((uint32_t)tr.ids.size());
+                for (const auto &cd : cand)
+                    if (cd.second <= dnear + 2.0 * rho) tr.ids.push_back(cd.first);
+            }
+            tr.at.push_back((uint32_t)tr.ids.size());
+        };
+        run_pool(nt, [&](int w) { for (int ty = w; ty < nty; ty += nt) near_work(ty); });
+    }
 
     // identical lists share one run of records
     {
@@ -334,12 +443,41 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
                 g->cell_first[ci] = first;
             }
         }
-        if (rec.size() >= ((size_t)1 << 22)) { tde_grid_free(g); return bad("tde_grid_build: more than 2^22 candidate records in one map: use a larger cell"); }
+        if (rec.size() >= ((size_t)1 << 22)) return bad("tde_grid_build: more than 2^22 candidate records in one map: use a larger cell");
         g->n_lists = n_lists;
+        // the near lists follow the cells' candidate lists (a tile's word holds a full 32-bit offset: no 22-bit limit here); a
+        // near list equal to a run that is already there shares it
+        std::vector<std::pair<uint32_t, uint32_t>> starts;    // (first record, length) of every near list
+        int64_t n_near = 0;
+        for (int ty = 0; ty < nty; ++ty) {
+            const TileRow &tr = trows[(size_t)ty];
+            for (size_t q = 0; q < tr.tx.size(); ++q) {
+                const int32_t *ids = tr.ids.data() + tr.at[q];
+                const uint32_t n = tr.at[q + 1] - tr.at[q];
+                uint64_t hsh = 1469598103934665603ull ^ n;
+                for (uint32_t k = 0; k < n; ++k) hsh = (hsh ^ (uint64_t)(uint32_t)ids[k]) * 1099511628211ull;
+                auto &bucket = seen[hsh];
+                uint32_t first = UINT32_MAX;
+                for (const auto &fl : bucket)
+                    if (fl.second == n && !memcmp(rec.data() + fl.first, ids, 4 * (size_t)n)) { first = fl.first; break; }
+                if (first == UINT32_MAX) {
+                    first = (uint32_t)rec.size();
+                    rec.insert(rec.end(), ids, ids + n);
+                    bucket.emplace_back(first, n);
+                }
+                starts.emplace_back(first, n);
+                g->tile_near[(size_t)ty * ntx + tr.tx[q]] = first + 1u;
+                ++n_near;
+            }
+        }
+        if (rec.size() >= ((size_t)1 << 30)) return bad("tde_grid_build: more than 2^30 records in one map: use a smaller near_range");
+        g->n_near_lists = n_near;
         g->n_records = (int64_t)rec.size();
         g->rec_tri = (int32_t *)malloc(std::max<size_t>(1, rec.size()) * 4);
-        if (!g->rec_tri) { tde_grid_free(g); return bad("tde_grid_build: out of memory"); }
+        g->rec_len = (int32_t *)calloc(std::max<size_t>(1, rec.size()), 4);
+        if (!g->rec_tri || !g->rec_len) return bad("tde_grid_build: out of memory");
         memcpy(g->rec_tri, rec.data(), rec.size() * 4);
+        for (const auto &fl : starts) g->rec_len[fl.first] = (int32_t)fl.second;
     }
 
     // clearance of FULL / EMPTY cells: floor(rho / TDE_CLEARANCE_UNIT), rho = distance between the cell's rectangle and the
@@ -350,9 +488,7 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
         std::vector<double> f(ncell);
         {
             auto other = [&](int x, int y) { return g->cell_class[(size_t)y * nx + x] != cls; };
-            std::vector<std::thread> pool;
-            for (int w = 0; w < nt; ++w)
-                pool.emplace_back([&, w]() {
+            run_pool(nt, [&](int w) {
                     for (int y = w; y < ny; y += nt)
                         for (int x = 0; x < nx; ++x) {
                             bool o = false;
@@ -364,12 +500,9 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
                             f[(size_t)y * nx + x] = o ? 0.0 : 1e20;
                         }
                 });
-            for (auto &th : pool) th.join();
         }
         {
-            std::vector<std::thread> pool;
-            for (int w = 0; w < nt; ++w)
-                pool.emplace_back([&, w]() {
+            run_pool(nt, [&](int w) {
                     const int n = std::max(nx, ny);
                     std::vector<double> in((size_t)n), d((size_t)n), z((size_t)n + 1);
                     std::vector<int> v((size_t)n);
@@ -378,12 +511,9 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
                         memcpy(&f[(size_t)y * nx], d.data(), (size_t)nx * 8);
                     }
                 });
-            for (auto &th : pool) th.join();
         }
         {
-            std::vector<std::thread> pool;
-            for (int w = 0; w < nt; ++w)
-                pool.emplace_back([&, w]() {
+            run_pool(nt, [&](int w) {
                     std::vector<double> in((size_t)ny), d((size_t)ny), z((size_t)ny + 1);
                     std::vector<int> v((size_t)ny);
                     for (int x = w; x < nx; x += nt) {
@@ -398,10 +528,9 @@ static int tde_grid_build_impl(const float *tri32, int32_t n_tri, float threshol
                         }
                     }
                 });
-            for (auto &th : pool) th.join();
         }
     }
-    *out = g;
+    *out = owner.release();
     return 0;
 }
 

@@ -13,10 +13,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <type_traits>
 
 #include "../../include/tde_hip.h"
 #include "tde_device.h"
+#include "tde_magnitudes.h"
 #include "tde_raster.h"
 
 namespace tde {
@@ -60,8 +62,56 @@ struct Tiles {
     float4 a[BLOCK];
     float4 b[BLOCK];
     int wide_done[4];           // A > 64 (an env spans two wavefronts): the env's done flag, through LDS instead of a wave ballot
+    float poly[BLOCK / 64][32]; // per wavefront: box_iou_wave's vertex lists (tde_state.magnitudes)
 };
 constexpr float kFar = 1e18f;
+
+// the boxes of an env's slots from its tile rows (ra / rb: slot 0 first), for ego_collision_mag_of: an absent slot is parked at kFar
+struct TileRows {
+    const float4 *ra, *rb;
+    TDE_DEV bool operator()(int j, float &x, float &y, float &c, float &s, float &hl, float &hw) const
+    {
+        const float4 p = ra[j], q = rb[j];
+        x = p.x; y = p.y; c = q.x; s = q.y; hl = q.z; hw = q.w;
+        return p.x != kFar;
+    }
+};
+
+// the map descriptor lane `src` (wave-uniform) holds, on every lane: what the magnitude functions read of it
+TDE_DEV tde_map map_of_lane(const tde_map &m, int src)
+{
+    tde_map r{};
+#define TDE_RL_F(f) r.f = readlane_f(m.f, src)
+#define TDE_RL_I(f) r.f = __builtin_amdgcn_readlane(m.f, src)
+    TDE_RL_F(ox); TDE_RL_F(oy); TDE_RL_F(cell); TDE_RL_F(inv_cell);
+    TDE_RL_I(nx); TDE_RL_I(ny); TDE_RL_I(cell_base); TDE_RL_I(row_shift); TDE_RL_I(rec_base); TDE_RL_I(near_base);
+#undef TDE_RL_F
+#undef TDE_RL_I
+    return r;
+}
+
+// tde_state.magnitudes for the egos of this wavefront that the step flagged (hm / om: ballots of the slots' collision / offroad
+// flags; ego: ballot of the ego lanes), one ego at a time by all 64 lanes: the values of tde_ego_infractions on the state the step
+// left - what get_info reports under "collision" / "offroad" (ref gym_env.py:427-428).  ra / rb: tile rows of the wavefront's
+// lane 0 (lane l's row at ra[l]); `m`: the map descriptor of every lane's env.  Returns this lane's env's four values (ego lanes).
+template <int A>
+TDE_DEV float4 ego_magnitudes_of_wave(const tde_config &cfg, const tde_world &w, const tde_map &m, unsigned long long ego,
+                                      unsigned long long hm, unsigned long long om, const float4 *ra, const float4 *rb, int lane,
+                                      float *poly)
+{
+    float4 mg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (unsigned long long fm = (hm | om) & ego; fm; fm &= fm - 1) {       // (wave-uniform; rarely more than one trip)
+        const int src = __ffsll((long long)fm) - 1;
+        const float4 ea = ra[src], eb4 = rb[src];
+        const EgoBox eb{ea.x, ea.y, eb4.x, eb4.y, eb4.z, eb4.w};
+        float2 cm = make_float2(0.0f, 0.0f);
+        float omag = 0.0f;
+        if ((hm >> src) & 1ull) cm = ego_collision_mag_of(A, lane, eb, TileRows{ra + src, rb + src}, poly);
+        if ((om >> src) & 1ull) omag = ego_offroad_mag_wave(cfg, w, map_of_lane(m, src), eb, lane);
+        if (lane == src) mg = make_float4(omag, cm.x, cm.y, 0.0f);
+    }
+    return mg;
+}
 
 // LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
 TDE_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -881,7 +931,7 @@ TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag,
 template <int A, int BLOCK, bool LIGHTS, bool BIG = false>
 TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold &cold, const tde_state &st,
                           Tiles<BLOCK> &t, int e, int a, bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0,
-                          float &s0, float act_acc, float act_steer)
+                          float &s0, float act_acc, float act_steer, float *mag_out = nullptr)
 {
     using mask_t = typename MaskOf<A>::type;
     const uint32_t F = cfg.flags;
@@ -911,7 +961,8 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
         const float red_gap = (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
         if constexpr (A > 64) npc_action_wide<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
         else npc_action<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
-        if (npc && k > 1) { acc = na; beta = nb; }    // (first step of an episode: the NPCs coast, kFirstStepCoast below)
+        // (first step of an episode: the NPCs coast unless TDE_F_NPC_FIRST_STEP asks for the reference's behaviour, tde_abi.h)
+        if (npc && (k > 1 || (F & TDE_F_NPC_FIRST_STEP))) { acc = na; beta = nb; }
     }
 
     if (live) {
@@ -956,6 +1007,17 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
         tl = tl_violation(w, cx.m, red, ag.x, ag.y, c0, s0, hl, hw);
     }
     out.tl = tl ? 1 : 0;
+
+    // ---- tde_state.magnitudes: the magnitudes of the ego's infractions (get_info's "collision" / "offroad", :427-428), for the
+    // egos this step flagged, before any re-spawn touches the tile.  (A = 128: the ego's wavefront reads the env's 128 rows; its
+    // partner holds no ego lane, skips this and meets it at the barriers below.)
+    if (mag_out) {
+        const unsigned long long ego = __ballot(a == 0 && valid);
+        const int w0 = tid & ~63;                   // this wavefront's first row of the tile
+        const float4 mg = ego_magnitudes_of_wave<A>(cfg, w, cx.m, ego, __ballot(hit), __ballot(off), &t.a[w0], &t.b[w0], tid & 63,
+                                                    t.poly[tid >> 6]);
+        if (a == 0 && valid) reinterpret_cast<float4 *>(mag_out)[e] = mg;
+    }
 
     // ---- reward / termination on the ego lane; the env's other lanes learn "done" from the wave ballot ----------
     if (F & TDE_F_REWARD) {
@@ -1048,7 +1110,7 @@ __global__ __launch_bounds__(kBlock, A > kWave ? WAVES : 1) void env_step_kernel
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     tile_sync<A>();
-    StepOut o = step_lane<A, kBlock, LIGHTS, BIG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
+    StepOut o = step_lane<A, kBlock, LIGHTS, BIG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y, st.magnitudes);
     if (!valid) return;
     store_agent_dynamic(st, g, ag);
     if (o.respawned) store_agent_static(st, g, ag);
@@ -2146,7 +2208,9 @@ TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, c
 // TDE_F_REPLAY or an npc_* constant between two launches gets the actions recomputed in the next launch's prologue instead of
 // replayed.  (Formed in the kernel - twenty dependent scalar instructions, twice - it cost 0.29 us of the 9 us launch:
 // profiles/r04_d_ab_step_act_key.txt.)
-TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(((uint32_t)steps & 0xFFFFFu) | (cfg_hash & 0xFFF00000u)); }
+// (ABI 10: the whole 32-bit hash - the world's tables included - mixed with the step counter by a bijection of it, so distinct step
+//  counters of one configuration never share a word and two configurations collide with probability 2^-32; ABI 9 kept 12 bits)
+TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash ^ ((uint32_t)steps * 0x9E3779B1u)); }
 
 template <int A, bool LIGHTS, bool OBS>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_step_trio_kernel(
@@ -2503,9 +2567,18 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         lds_barrier();                                       // A
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
-        if (!valid) return;
-        st.offroad[g] = (dn && ((dn >> base) & 1ull)) ? 0 : (off ? 1 : 0);
-        if (a == 0 && st.tl_violation) st.tl_violation[e] = tl ? 1 : 0;
+        if (valid) {
+            st.offroad[g] = (dn && ((dn >> base) & 1ull)) ? 0 : (off ? 1 : 0);
+            if (a == 0 && st.tl_violation) st.tl_violation[e] = tl ? 1 : 0;
+        }
+        // tde_state.magnitudes (get_info's "collision" / "offroad", :427-428) for the egos this step flagged: this judge has nothing
+        // left to do while the driver and judge C re-spawn the finished envs, and the rows of the step stay in buffer 0
+        // (ring_post: the rollout kernel's, unused in a one-step launch)
+        if (st.magnitudes) {
+            const float4 mg = ego_magnitudes_of_wave<A>(cfg, w, m, __ballot(a == 0 && valid), sh.hit_mask, om, &sh.a[0][0], &sh.b[0][0],
+                                                        lane, reinterpret_cast<float *>(sh.ring_post));
+            if (a == 0 && valid) reinterpret_cast<float4 *>(st.magnitudes)[e] = mg;
+        }
     }
 }
 
@@ -2813,7 +2886,7 @@ void render_views_kernel(RenderArgs ra, int B)
 
 }  // namespace tde
 
-#include "tde_magnitudes.h"
+#include "tde_magnitudes_kernels.h"
 
 // ------------------------------------------------------------------------------------------------------------------
 // C-ABI
@@ -2853,7 +2926,7 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + tde::kBloc
 
 // which kernel form tde_env_rollout / tde_env_step launch: 0 = by group shape and batch size (the measured choice), else
 // forced (tde_kernel_override: parity tests of every form, A/B runs)
-static int g_force_rollout = 0, g_force_step = 0;
+static std::atomic<int> g_force_rollout{0}, g_force_step{0};
 
 extern "C" {
 
@@ -2967,12 +3040,22 @@ int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state
 // `load_slots`: the agent slots stepping on the device at the same time - the batch's own, or the whole batch's when this is one
 // of the sub-batches tde_env_step_render runs side by side (the choice of kernel form is a matter of load)
 // hash of what the NPC controller depends on besides the state (tde_act_cache; act_key_steps)
-static uint32_t act_cfg_hash(const tde_config &cfg)
+static uint32_t act_cfg_hash(const tde_config &cfg, const tde_world &w)
 {
 #ifdef TDE_ACT_KEY_PLAIN          // (A/B builds: the round-3 key, the step counter alone)
     return 0u;
 #endif
     uint32_t h = cfg.flags & (TDE_F_NPC | TDE_F_REPLAY | TDE_F_TRAFFIC_LIGHTS);
+    // the identity of the tables the controller reads (routes, spawn records, stop lines, light phases, maps, scenarios): a caller
+    // that swaps or rebuilds the world under an unchanged state gets the actions recomputed, not replayed
+    const void *tabs[7] = {w.route_xy, w.spawn, w.stoplines, w.phases, w.maps, w.scn, w.replay_states};
+    for (int i = 0; i < 7; ++i) {
+        const uint64_t a = (uint64_t)(uintptr_t)tabs[i];
+        h = (h ^ (uint32_t)a) * 0x9E3779B1u;
+        h = (h ^ (uint32_t)(a >> 32)) * 0x9E3779B1u;
+    }
+    const int32_t dims[6] = {w.n_routes, w.RW, w.n_replay, w.RT, w.n_scn, w.n_maps};
+    for (int i = 0; i < 6; ++i) h = (h ^ (uint32_t)dims[i]) * 0x9E3779B1u;
     const float c[10] = {cfg.npc_k_steer, cfg.npc_k_speed, cfg.npc_gap_s0, cfg.npc_cone_k, cfg.npc_lane_half, cfg.npc_reach,
                          cfg.npc_max_accel, cfg.npc_max_steer, cfg.npc_cone_range, cfg.dt};
     for (int i = 0; i < 10; ++i) {
@@ -3008,9 +3091,12 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     const bool packable = world->n_routes < id_max && world->n_replay < id_max && world->RW < len_max && world->RT < len_max;
     const bool trio_ok = st->slot_cache && st->env_cache && packable && (st->A == 8 || st->A == 16 || st->A == 32);
     const bool want_trio = force == 3 || (force == 0 && load_slots <= 131072);
-    if (trio_ok && want_trio) {
+    // (TDE_F_NPC_FIRST_STEP: the controller acts on the first step of an episode too - the one-role kernel, which evaluates it on
+    //  every step; the three-role kernel skips it after a re-spawn)
+    const bool first_step_acts = (cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP);
+    if (trio_ok && want_trio && !first_step_acts) {
         const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-        const uint32_t act_hash = act_cfg_hash(*cfg);
+        const uint32_t act_hash = act_cfg_hash(*cfg, *world);
 #define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, act_hash)
 #define TDE_LAUNCH_STEP3_A(AA)                                                                       \
     if (st->obs) { if (lights) TDE_LAUNCH_STEP3(AA, true, true); else TDE_LAUNCH_STEP3(AA, false, true); } \
@@ -3084,7 +3170,7 @@ static tde_state state_slice(const tde_state &s, int64_t e0, int32_t n)
     TDE_ADV(scn, e0); TDE_ADV(steps, e0); TDE_ADV(target_idx, e0); TDE_ADV(reached, e0); TDE_ADV(episode, e0);
     TDE_ADV(action, 2 * e0); TDE_ADV(reward, e0); TDE_ADV(terminated, e0); TDE_ADV(truncated, e0); TDE_ADV(tl_violation, e0);
     TDE_ADV(info, 4 * e0); TDE_ADV(info_reached, e0); TDE_ADV(done_bits, e0); TDE_ADV(obs, 8 * e0); TDE_ADV(ep_return, e0);
-    TDE_ADV(ep_final, e0); TDE_ADV(ep_final_len, e0); TDE_ADV(slot_cache, g0); TDE_ADV(env_cache, e0); TDE_ADV(act_cache, g0 + e0);
+    TDE_ADV(ep_final, e0); TDE_ADV(ep_final_len, e0); TDE_ADV(slot_cache, g0); TDE_ADV(env_cache, e0); TDE_ADV(act_cache, g0 + e0); TDE_ADV(magnitudes, 4 * e0);
 #undef TDE_ADV
     t.B = n;
     return t;
@@ -3138,7 +3224,7 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
         // Two roles (four wavefronts per env) at every batch size - us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs:
         // two roles 6.2 / 8.9 / 18.0 / 34.7, one role 10.6 / 11.4 / 23.3 / 38.9 (profiles/r04_z_wide2_waves.txt).
         // tde_kernel_override(1, 0) forces the one-role kernel.
-        const bool one_role = g_force_rollout == 1;
+        const bool one_role = g_force_rollout == 1 || ((cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP));
         if (one_role) {
             if (l128) tde::env_rollout_kernel<128, true><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
             else tde::env_rollout_kernel<128, false><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
@@ -3161,6 +3247,7 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
     int team = forced ? forced : (st->A == 8 || st->A == 16 || (st->A == 32 && !lights0)) ? 3 : 2;
     if (team == 3 && !trio_shape) team = 2;
+    if ((cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP)) team = 1;   // (the role-split kernels skip the controller after a re-spawn)
     tde_rollout r = *ro;
     if (r.ldb == 0) r.ldb = st->B;
     // The two- and three-role kernels are tuned for ONE residency round of the chip: 8 workgroups (groups of 64 agent slots)

@@ -8,23 +8,26 @@
 //              the IoU of the two boxes - the published form of CollisionMetric.nograd; also the number of such agents.
 //
 // Upstream's values are unpinned here (torchdrivesim absent): the CPU checker defines them (its ego-infractions restatement: brute force over
-// every triangle) and this kernel returns the same bits.  Not on the step path: an env that wants magnitudes steps without
-// TDE_F_AUTORESET and follows the step with tde_env_post_step - magnitudes of the envs the step flagged + the re-spawn of the finished
-// ones in one launch (BatchedWaypointEnv(info_magnitudes=True)); tde_ego_infractions is the operator on an arbitrary state.
+// every triangle) and these functions return the same bits.  Round 5: ON the step path - the one-launch step kernels write
+// tde_state.magnitudes for the egos they flagged, in the tail of the launch (judge O of the three-role kernel, the ego's wavefront
+// of the one-role kernel), before any in-place re-spawn; tde_ego_infractions is the operator on an arbitrary state and
+// tde_env_post_step the round-4 form (step without TDE_F_AUTORESET, then magnitudes + re-spawn in a second launch).
 //
-// One wavefront per env.  The distance of a corner needs the NEAREST triangle, which the grid index only lists for points within
-// the threshold band: a corner in a FULL cell contributes 0; in a MIXED cell whose nearest candidate is within the band radius,
-// that candidate is the nearest triangle; otherwise all 64 lanes scan the cells of a square around the corner for MIXED cells
-// and their candidate lists - the segment from the corner to its nearest mesh point crosses a MIXED cell that lists the
-// triangle it ends on (half a metre before it ends, the distance to the mesh is half a metre: neither FULL nor EMPTY) - growing
-// the square until it covers the best distance found less the band the lists cover.
+// The whole wavefront works on one ego.  The distance of a corner needs the NEAREST triangle, which the cells' candidate lists
+// only hold for points within the threshold band.  ABI 10: every coarse tile (4 x 4 cells) within threshold + near_range of the
+// mesh carries a NEAR LIST (tde_world.tile_near; csrc/tde_gridbuild.h) - the triangles among which the nearest one of any point of
+// the tile is found - so a corner is two dependent look-ups: the tile's word, then the list's records, the four corners side by
+// side on 16 lanes each.  A corner whose tile has no list (farther out than near_range, or outside the grid) falls back to the
+// round-4 scan: all 64 lanes walk the cells of a square around the corner for MIXED cells and their candidate lists - the segment
+// from the corner to its nearest mesh point crosses a MIXED cell that lists the triangle it ends on - growing the square until it
+// covers the best distance found less the band the lists cover.
 #pragma once
 #include "tde_device.h"
 
 namespace tde {
 
 // IoU of two oriented boxes: Sutherland-Hodgman clipping of box 0 by the four edges of box 1 + the shoelace formula, fp32, the
-// CPU checker's expression trees (the published form of CollisionMetric.nograd sums this over the other agents)
+// CPU checker's expression trees (the published form of CollisionMetric.nograd sums this over the other agents).
 TDE_DEV void box_corners_ccw(float x, float y, float c, float s, float hl, float hw, float *px, float *py)
 {
     const float lx = hl * c, ly = hl * s, wx = hw * s, wy = hw * c;
@@ -34,53 +37,60 @@ TDE_DEV void box_corners_ccw(float x, float y, float c, float s, float hl, float
     px[3] = (x + lx) + wx; py[3] = (y + ly) - wy;
 }
 
-// `poly`: 32 floats of LDS, the two vertex lists of the clipping (the overlapping pairs of a wavefront take turns: there is rarely
-// more than one).  As private arrays they are indexed dynamically and live in scratch MEMORY - every access a global-memory round trip
-// on a chain of ~300 of them: 15 us for one pair of boxes, which the whole launch then waits for (profiles/r04_z_magnitudes_cost.txt).
-TDE_DEV float box_iou(float x0, float y0, float c0, float s0, float hl0, float hw0, float x1, float y1, float c1,
-                      float s1, float hl1, float hw1, float *poly)
+TDE_DEV float readlane_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+// (this wavefront's LDS stores are ordered before its later LDS loads: the LDS unit serves a wavefront's instructions in order;
+//  the fence keeps the compiler from moving them across)
+TDE_DEV void wave_lds_fence() { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+
+// The whole wavefront calls it with wave-uniform arguments; `poly` = 32 floats of LDS of this wavefront.  The clip runs ONE
+// POLYGON VERTEX PER LANE (a convex quadrilateral cut by four half planes has at most eight): every stage evaluates the vertex
+// tests side by side, ranks the surviving / inserted vertices with two ballots and writes them to the other vertex list in LDS -
+// four stages of ~40 instructions instead of a chain of ~300 dependent LDS round trips on one lane (round 4: box_iou on the lane of
+// the overlapping slot, 15 us per pair from scratch memory, ~3 us from LDS - and the launch waits for it).  Same operations on the
+// same operands in the same order per vertex, and the shoelace sum runs over the lanes in vertex order: the CPU checker's bits.
+TDE_DEV float box_iou_wave(float x0, float y0, float c0, float s0, float hl0, float hw0, float x1, float y1, float c1, float s1,
+                           float hl1, float hw1, int lane, float *poly)
 {
-#define TDE_AX(i) poly[(i)]
-#define TDE_AY(i) poly[8 + (i)]
-#define TDE_BX(i) poly[16 + (i)]
-#define TDE_BY(i) poly[24 + (i)]
     float px[4], py[4], qx[4], qy[4];
-    int n = 4;
     box_corners_ccw(x0, y0, c0, s0, hl0, hw0, px, py);
     box_corners_ccw(x1, y1, c1, s1, hl1, hw1, qx, qy);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { TDE_AX(i) = px[i]; TDE_AY(i) = py[i]; }
+    float *cur = poly, *nxt = poly + 16;                   // vertex lists: x at [0, 8), y at [8, 16)
+    if (lane < 4) { cur[lane] = TDE_SEL4(lane, px[0], px[1], px[2], px[3]); cur[8 + lane] = TDE_SEL4(lane, py[0], py[1], py[2], py[3]); }
+    wave_lds_fence();
+    int n = 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if (n <= 0) break;
+        if (n <= 0) break;                                     // (wave-uniform: n comes from ballots)
         const float ex = qx[(e + 1) & 3] - qx[e], ey = qy[(e + 1) & 3] - qy[e];
-        int m = 0;
-        for (int i = 0; i < n; ++i) {
-            const int i2 = (i + 1 == n) ? 0 : i + 1;
-            const float axi = TDE_AX(i), ayi = TDE_AY(i), axj = TDE_AX(i2), ayj = TDE_AY(i2);
-            const float sp = ex * (ayi - qy[e]) - ey * (axi - qx[e]);
-            const float sq = ex * (ayj - qy[e]) - ey * (axj - qx[e]);
-            if (sp >= 0.0f && m < 8) { TDE_BX(m) = axi; TDE_BY(m) = ayi; ++m; }
-            if (((sp > 0.0f && sq < 0.0f) || (sp < 0.0f && sq > 0.0f)) && m < 8) {
-                const float t = sp / (sp - sq);
-                TDE_BX(m) = axi + t * (axj - axi);
-                TDE_BY(m) = ayi + t * (ayj - ayi);
-                ++m;
-            }
+        const bool act = lane < n;
+        const int i = act ? lane : 0, i2 = (i + 1 == n) ? 0 : i + 1;
+        const float axi = cur[i], ayi = cur[8 + i], axj = cur[i2], ayj = cur[8 + i2];
+        const float sp = ex * (ayi - qy[e]) - ey * (axi - qx[e]);
+        const float sq = ex * (ayj - qy[e]) - ey * (axj - qx[e]);
+        const bool keep = act && sp >= 0.0f;
+        const bool cross = act && ((sp > 0.0f && sq < 0.0f) || (sp < 0.0f && sq > 0.0f));
+        const unsigned long long km = __ballot(keep), cm = __ballot(cross);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int pos = (int)__popcll(km & below) + (int)__popcll(cm & below);
+        if (keep && pos < 8) { nxt[pos] = axi; nxt[8 + pos] = ayi; }
+        const int pos2 = pos + (keep ? 1 : 0);
+        if (cross && pos2 < 8) {
+            const float t = sp / (sp - sq);
+            nxt[pos2] = axi + t * (axj - axi);
+            nxt[8 + pos2] = ayi + t * (ayj - ayi);
         }
-        n = m;
-        for (int i = 0; i < n; ++i) { TDE_AX(i) = TDE_BX(i); TDE_AY(i) = TDE_BY(i); }
+        const int total = (int)__popcll(km) + (int)__popcll(cm);
+        n = total < 8 ? total : 8;
+        wave_lds_fence();
+        float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (n < 3) return 0.0f;
+    const bool act = lane < n;
+    const int i = act ? lane : 0, i2 = (i + 1 == n) ? 0 : i + 1;
+    const float term = cur[i] * cur[8 + i2] - cur[i2] * cur[8 + i];
     float acc = 0.0f;
-    for (int i = 0; i < n; ++i) {
-        const int i2 = (i + 1 == n) ? 0 : i + 1;
-        acc = acc + (TDE_AX(i) * TDE_AY(i2) - TDE_AX(i2) * TDE_AY(i));
-    }
-#undef TDE_AX
-#undef TDE_AY
-#undef TDE_BX
-#undef TDE_BY
+    for (int k = 0; k < n; ++k) acc = acc + readlane_f(term, k);
+    wave_lds_fence();                                          // (the next pair of this wavefront reuses `poly`)
     const float ai = 0.5f * fabsf(acc);
     const float a0 = (2.0f * hl0) * (2.0f * hw0), a1 = (2.0f * hl1) * (2.0f * hw1);
     return ai / ((a0 + a1) - ai);
@@ -159,158 +169,83 @@ TDE_DEV float point_mesh_d2_wave(const tde_world &w, const tde_map &m, float px,
     return best;
 }
 
-// ---- the two magnitudes in pieces: one wavefront each ---------------------------------------------------------------------------
+// ---- the two magnitudes, by the whole wavefront for ONE ego ---------------------------------------------------------------------
 struct EgoBox { float x, y, c, s, hl, hw; };
-TDE_DEV EgoBox ego_box(const tde_state &st, int64_t g0)
-{
-    EgoBox b;
-    b.x = st.x[g0]; b.y = st.y[g0];
-    sincos_f32(st.psi[g0], b.s, b.c);
-    b.hl = 0.5f * st.len[g0]; b.hw = 0.5f * st.wid[g0];
-    return b;
-}
 
-// collision: (sum of the IoUs with the overlapping agents, in slot order; their number).  iou_of: A floats, poly: 32 floats of
-// LDS of this wavefront
-TDE_DEV float2 ego_collision_mag(const tde_state &st, int64_t g0, const EgoBox &eb, int lane, float *iou_of, float *poly)
+// collision: (sum of the IoUs with the overlapping agents, in slot order; their number).  `row(j, x, y, c, s, hl, hw)` fetches the box
+// of slot j of the ego's env and returns whether the slot is present (global state arrays or the step kernels' LDS tile rows);
+// poly: 32 floats of LDS of this wavefront.  Wave-uniform arguments except `lane`.
+template <typename R>
+TDE_DEV float2 ego_collision_mag_of(int A, int lane, const EgoBox &eb, R &&row, float *poly)
 {
-    const int A = st.A;
+    float cmag = 0.0f;
     int nhit = 0;
     for (int j0 = 0; j0 < A; j0 += 64) {                             // lanes take the other slots, 64 at a time
         const int j = j0 + lane;
         bool hit = false;
-        float v = 0.0f;
-        if (j > 0 && j < A && st.present[g0 + j]) {
-            float sj, cj;
-            sincos_f32(st.psi[g0 + j], sj, cj);
-            const float xj = st.x[g0 + j], yj = st.y[g0 + j], hlj = 0.5f * st.len[g0 + j], hwj = 0.5f * st.wid[g0 + j];
+        float xj = 0.0f, yj = 0.0f, cj = 1.0f, sj = 0.0f, hlj = 0.0f, hwj = 0.0f;
+        if (j > 0 && j < A && row(j, xj, yj, cj, sj, hlj, hwj))
             hit = obb_overlap(eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, xj, yj, cj, sj, hlj, hwj);
-        }
         const unsigned long long hm = __ballot(hit);
-        for (unsigned long long rest = hm; rest; rest &= rest - 1) {    // one overlapping pair at a time through the 32 floats of LDS
-            if (lane == __ffsll((long long)rest) - 1) {
-                float sj, cj;
-                sincos_f32(st.psi[g0 + j], sj, cj);
-                v = box_iou(eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, st.x[g0 + j], st.y[g0 + j], cj, sj, 0.5f * st.len[g0 + j], 0.5f * st.wid[g0 + j], poly);
-            }
+        for (unsigned long long rest = hm; rest; rest &= rest - 1) {    // one overlapping pair at a time, in slot order (rarely > 1)
+            const int src = __ffsll((long long)rest) - 1;
+            const float v = box_iou_wave(eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, readlane_f(xj, src), readlane_f(yj, src),
+                                         readlane_f(cj, src), readlane_f(sj, src), readlane_f(hlj, src), readlane_f(hwj, src), lane, poly);
+            cmag = cmag + v;
         }
-        if (j < A) iou_of[j] = v;
         nhit += (int)__popcll(hm);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wavefront's own LDS stores have landed
-    float cmag = 0.0f;
-    if (nhit) for (int j = 1; j < A; ++j) { const float v = iou_of[j]; if (v != 0.0f) cmag = cmag + v; }
     return make_float2(cmag, (float)nhit);
 }
 
-// offroad: the term of corner c (0..3) of the ego's box - clamp(dist - threshold, 0) - by the whole wavefront
-TDE_DEV float ego_corner_term(const tde_config &cfg, const tde_world &w, const tde_map &m, const EgoBox &eb, int c, int lane)
+// offroad: sum over the four corners (FL, FR, RR, RL - the order of the CPU checker's corner list) of clamp(dist - threshold, 0).
+// Lanes 16 c .. 16 c + 15 take corner c: the tile word, the first 16 records of its near list (the list's length rides in the
+// first record: fetched before it is known, the table ends with 16 spare records), the rest of a longer list, a minimum over the 16
+// lanes; a corner without a near list goes through point_mesh_d2_wave, all 64 lanes, one such corner at a time.
+TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, const tde_map &m, const EgoBox &eb, int lane)
 {
     const float thr = cfg.offroad_threshold, thr2 = thr2_of(cfg);
-    const float band = __builtin_sqrtf(thr2) + 0.04f;            // (the grid's lists cover threshold + 0.05: world.py GRID_MARGIN)
+    const float band = __builtin_sqrtf(thr2) + 0.04f;            // (the cells' lists cover threshold + 0.05: world.py GRID_MARGIN)
     Corners k;
     offroad_issue<false>(w, m, false, eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, k);   // (corner coordinates only)
-    const float px = c == 0 ? k.px0 : c == 1 ? k.px1 : c == 2 ? k.px2 : k.px3;
-    const float py = c == 0 ? k.py0 : c == 1 ? k.py1 : c == 2 ? k.py2 : k.py3;
-    const float d2 = point_mesh_d2_wave(w, m, px, py, band * band, lane);
-    if (d2 < 0.0f) return 0.0f;                                      // inside the mesh
-    const float dist = cfg.offroad_threshold_squared ? d2 : __builtin_sqrtf(d2);
-    return fmaxf(dist - thr, 0.0f);
-}
-
-// out[e] = (offroad magnitude, collision magnitude = sum of IoUs, number of overlapping agents, 0) of env e's ego on the CURRENT
-// state, whatever its flags say; one wavefront per env (every env has work: the operator form, tde_ego_infractions)
-__global__ __launch_bounds__(kBlock) void ego_infractions_kernel(tde_config cfg, tde_world w, tde_state st, float *__restrict__ out)
-{
-    __shared__ float iou_of[kBlock / kWave][TDE_MAX_AGENTS];     // per env: the IoU with every slot, summed in slot order
-    __shared__ float poly[kBlock / kWave][32];                     // per wavefront: box_iou's vertex lists
-    const int lane = (int)(threadIdx.x & 63u);
-    const int e = (int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
-    if (e >= st.B) return;                                           // (wave-uniform)
-    const int64_t g0 = (int64_t)e * st.A;
+    const int c = lane >> 4, r = lane & 15;
+    const float px = TDE_SEL4(c, k.px0, k.px1, k.px2, k.px3), py = TDE_SEL4(c, k.py0, k.py1, k.py2, k.py3);
+    const float fx = __builtin_amdgcn_fmed3f((px - m.ox) * m.inv_cell, 0.0f, (float)(m.nx - 1));
+    const float fy = __builtin_amdgcn_fmed3f((py - m.oy) * m.inv_cell, 0.0f, (float)(m.ny - 1));
+    const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+    const bool inside = px >= m.ox && py >= m.oy && px < m.ox + (float)m.nx * m.cell && py < m.oy + (float)m.ny * m.cell;
+    uint32_t tw = 0u;
+    if (w.tile_near) tw = w.tile_near[(uint32_t)m.near_base + (iy / TDE_COARSE_CELLS) * ((uint32_t)m.nx / TDE_COARSE_CELLS) + ix / TDE_COARSE_CELLS];
+    if (!inside) tw = 0u;                                        // (clamped into a border tile it does not lie in)
+    const bool full = tw == 0xFFFFFFFFu, listed = tw != 0u && !full;
+    float best = 3.0e38f;
+    if (__ballot(listed)) {
+        const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)((uint32_t)m.rec_base + (listed ? tw - 1u : 0u));
+        const float4 t0 = recs[3 * r], t1 = recs[3 * r + 1], t2 = recs[3 * r + 2];
+        const int n = __shfl(__float_as_int(t2.y), lane & 48);      // the list's length, from the lane that holds its first record
+        if (listed && r < n) best = point_tri_d2_words(px, py, t0, t1, t2);
+        for (int q = 16; __ballot(listed && q < n); q += 16)         // (a list of more than 16 triangles: rare)
+            if (listed && q + r < n) best = fminf(best, point_tri_d2_packed(px, py, recs + 3 * (size_t)(q + r)));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o));     // minimum over the corner's 16 lanes
+    }
+    float d2c = full ? -1.0f : best;
+    const unsigned long long scan = __ballot(!full && !listed);
+    for (int cc = 0; cc < 4; ++cc) {
+        if (!((scan >> (16 * cc)) & 1ull)) continue;                 // (wave-uniform)
+        const float sx = readlane_f(px, 16 * cc), sy = readlane_f(py, 16 * cc);
+        const float d2 = point_mesh_d2_wave(w, m, sx, sy, band * band, lane);
+        if (c == cc) d2c = d2;
+    }
+    float term = 0.0f;
+    if (d2c >= 0.0f) {
+        const float dist = cfg.offroad_threshold_squared ? d2c : __builtin_sqrtf(d2c);
+        term = fmaxf(dist - thr, 0.0f);
+    }
     float omag = 0.0f;
-    float2 cm = make_float2(0.0f, 0.0f);
-    if (st.present[g0]) {
-        const EgoBox eb = ego_box(st, g0);
-        cm = ego_collision_mag(st, g0, eb, lane, iou_of[threadIdx.x >> 6], poly[threadIdx.x >> 6]);
-        if (cfg.flags & TDE_F_OFFROAD) {
-            const tde_map m = w.maps[reinterpret_cast<const int4 *>(w.scn)[st.scn[e]].x];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) omag = omag + ego_corner_term(cfg, w, m, eb, c, lane);
-        }
-    }
-    if (lane == 0) reinterpret_cast<float4 *>(out)[e] = make_float4(omag, cm.x, cm.y, 0.0f);
-}
-
-// tde_env_post_step: what follows a step that was launched WITHOUT TDE_F_AUTORESET, in one launch -
-// (a) out[e] = the magnitudes of the ego's infractions on the state that step left, GATED by the flags it stored: a magnitude is
-//     non-zero only under its flag (collision: the same predicate; offroad: a corner beyond the threshold has d^2 > thr^2, and
-//     sqrt(d^2) <= thr for d^2 <= RN(thr * thr) since RN(sqrt(RN(x * x))) = x), so the 98 % of the envs without an infraction
-//     are not looked at;
-// (b) with TDE_F_AUTORESET the re-spawn of the envs it finished (env_reset_kernel's stores for mask = terminated | truncated)
-//     and, when the state carries the compact observation, that of the new episode (state_obs_kernel's expression).
-// One wavefront per env (a workgroup of four wavefronts per env - a corner each - was tried: 32 768 wavefronts to launch for the
-// ~150 that have work, 36 vs 31 us per step of the env; profiles/r04_z_magnitudes_cost.txt).
-template <int A>
-__global__ __launch_bounds__(kBlock) void env_post_step_kernel(tde_config cfg, tde_world w, tde_state st, float *__restrict__ out)
-{
-    __shared__ float iou_of[kBlock / kWave][TDE_MAX_AGENTS];
-    __shared__ float poly[kBlock / kWave][32];
-    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
-    const int e = (int)(blockIdx.x * (kBlock / kWave) + wv);
-    if (e >= st.B) return;                                           // (wave-uniform, like every branch below but the slot guards)
-    const int64_t g0 = (int64_t)e * A;
-    if (out) {
-        float omag = 0.0f;
-        float2 cm = make_float2(0.0f, 0.0f);
-        const bool do_coll = st.present[g0] && st.collided[g0] != 0;
-        const bool do_off = st.present[g0] && (cfg.flags & TDE_F_OFFROAD) && st.offroad[g0] != 0;
-        if (do_coll || do_off) {
-            const EgoBox eb = ego_box(st, g0);
-            if (do_coll) cm = ego_collision_mag(st, g0, eb, lane, iou_of[wv], poly[wv]);
-            if (do_off) {
-                const tde_map m = w.maps[reinterpret_cast<const int4 *>(w.scn)[st.scn[e]].x];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) omag = omag + ego_corner_term(cfg, w, m, eb, c, lane);
-            }
-        }
-        if (lane == 0) reinterpret_cast<float4 *>(out)[e] = make_float4(omag, cm.x, cm.y, 0.0f);
-    }
-    if (!(cfg.flags & TDE_F_AUTORESET) || !(st.terminated[e] | st.truncated[e])) return;
-    Cold cold;
-    fill_cold(cold, cfg, w);
-    const int episode = st.episode[e];
-    for (int a0 = 0; a0 < A; a0 += 64) {
-        const int a = a0 + lane;
-        if (a >= A) continue;
-        Agent ag;
-        EnvRegs er{0, 0, 0, 0, episode};
-        reset_lane<A, false>(cfg, cold, e, a, ag, er);
-        const int64_t g = g0 + a;
-        store_agent_dynamic(st, g, ag);
-        store_agent_static(st, g, ag);
-        st.collided[g] = 0;
-        st.offroad[g] = 0;
-        if (a == 0) {
-            st.scn[e] = er.scn; st.steps[e] = 0; st.target_idx[e] = 1; st.reached[e] = 0; st.episode[e] = er.episode;
-            if (st.ep_return) st.ep_return[e] = 0.0;
-            if (st.obs) {
-                const bool has = 1 < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
-                float fwd = 0.0f, lat = 0.0f;
-                if (has) {
-                    const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + 1];
-                    float s, c;
-                    sincos_f32(ag.psi, s, c);
-                    const float dx = (float)t.x - ag.x, dy = (float)t.y - ag.y;
-                    fwd = dx * c + dy * s;
-                    lat = dy * c - dx * s;
-                }
-                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
-                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
-                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, 0.0f);
-            }
-        }
-    }
+    for (int cc = 0; cc < 4; ++cc) omag = omag + readlane_f(term, 16 * cc);
+    return omag;
 }
 
 }  // namespace tde

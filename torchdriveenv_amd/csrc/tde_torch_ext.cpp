@@ -65,7 +65,7 @@ enum { K_ANY = 0, K_AGENT, K_ENV, K_ENV2, K_ENV4, K_ENV8, K_SLOT8, K_ACT };
 
 #define WF(n, dt) {#n, offsetof(tde_world, n), dt, K_ANY, true}
 const Field kWorldFields[] = {WF(maps, at::kByte), WF(tri, at::kFloat), WF(cell_word, at::kUInt32), WF(cell_tri, at::kFloat),
-                              WF(cell_cls2, at::kUInt32), WF(cell_sub, at::kUInt32), WF(cell_coarse, at::kByte), WF(scn, at::kByte),
+                              WF(cell_cls2, at::kUInt32), WF(cell_sub, at::kUInt32), WF(cell_coarse, at::kByte), WF(tile_near, at::kUInt32), WF(scn, at::kByte),
                               WF(wp_xy, at::kDouble), WF(spawn, at::kByte), WF(route_xy, at::kFloat), WF(replay_states, at::kFloat),
                               WF(stoplines, at::kByte), WF(phases, at::kByte)};
 #undef WF
@@ -80,7 +80,8 @@ const Field kStateFields[] = {
     SF(truncated, at::kByte, K_ENV, true), SF(tl_violation, at::kByte, K_ENV, true), SF(info, at::kDouble, K_ENV4, false),
     SF(info_reached, at::kInt, K_ENV, false), SF(done_bits, at::kByte, K_ENV, false), SF(obs, at::kFloat, K_ENV8, false),
     SF(ep_return, at::kDouble, K_ENV, false), SF(ep_final, at::kDouble, K_ENV, false), SF(ep_final_len, at::kInt, K_ENV, false),
-    SF(slot_cache, at::kInt, K_SLOT8, false), SF(env_cache, at::kInt, K_ENV8, false), SF(act_cache, at::kInt, K_ACT, false)};
+    SF(slot_cache, at::kInt, K_SLOT8, false), SF(env_cache, at::kInt, K_ENV8, false), SF(act_cache, at::kInt, K_ACT, false),
+    SF(magnitudes, at::kFloat, K_ENV4, false)};
 #undef SF
 
 int64_t count_of(int kind, int64_t B, int64_t A)

@@ -69,8 +69,34 @@ def _straight_route(x, y, psi, v):
     return [(x + math.cos(psi) * d, y + math.sin(psi) * d) for d in np.arange(8.0, ahead, 8.0)]
 
 
+def _mesh_of_location(road_meshes, loc):
+    """the caller's drivable mesh for a location as a [n, 3, 2] float array, or None (-> synthetic corridor)"""
+    if road_meshes is None:
+        return None
+    tri = road_meshes(loc) if callable(road_meshes) else road_meshes.get(loc)
+    if tri is None:
+        return None
+    if isinstance(tri, (str, bytes)) or hasattr(tri, "__fspath__"):
+        tri = np.load(tri)                                   # a .npy file of the triangles
+    tri = np.asarray(tri, dtype=np.float64)
+    if tri.ndim == 2 and tri.shape[1] == 6:
+        tri = tri.reshape(-1, 3, 2)
+    if tri.ndim != 3 or tri.shape[1:] != (3, 2) or len(tri) == 0 or not np.isfinite(tri).all():
+        raise ValueError(f"road mesh of location {loc!r} must be a finite [n, 3, 2] (or [n, 6]) array of triangle vertices, "
+                         f"got shape {tri.shape}")
+    return tri
+
+
+def mesh_from_verts_faces(verts, faces):
+    """(V, 2+) vertices and (F, 3) vertex indices - the layout of torchdrivesim's `road_mesh` (ref gym_env.py:184: verts / faces of
+    `map_cfg.road_mesh`) - as the [F, 3, 2] triangle soup `road_meshes` takes"""
+    v = np.asarray(verts, dtype=np.float64).reshape(-1, np.asarray(verts).shape[-1])[:, :2]
+    f = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    return v[f]
+
+
 def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=12.0, threshold=0.5,
-                              background=None, background_radius=250.0, ego_only=False):
+                              background=None, background_radius=250.0, ego_only=False, road_meshes=None):
     """WaypointSuite -> World.  Agent ordering follows the reference: slot 0 ego, then the scenario's agents
     (ref gym_env.py:219-228); `car_sequence_suite[i][k]` replays slot k (ref gym_env.py:275-283).
     The CARLA town meshes the reference takes from torchdrivesim's package data are not available, so each scenario
@@ -83,9 +109,16 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
     near field, which the reference fills through a remote INITIALIZE call (:232-235), stays empty.  Of the kept
     agents the nearest ones (within `background_radius`, so the synthetic corridor mesh stays local) fill the free
     slots after the scenario's own agents.  `ego_only`: the ego alone, no scenario / replay / background agents
-    (ref gym_env.py:192-198)."""
+    (ref gym_env.py:192-198).
+
+    `road_meshes`: the drivable surface per location, as the reference takes it from `find_map_config(location).road_mesh`
+    (ref gym_env.py:312, 184, 260): a dict location -> triangles ([n, 3, 2] or [n, 6] array, or the path of a .npy file holding
+    one; `mesh_from_verts_faces` converts a verts / faces pair), or a callable location -> the same or None.  Scenarios of a
+    location that has a mesh all run on ONE map built from it (one grid index per location); a location without one falls back to
+    the synthetic corridor of its scenario."""
     from . import loaders
     meshes, scenarios = [], []
+    map_of_location = {}
     n = len(data.waypoint_suite)
     for i in range(n):
         wps = [tuple(p) for p in data.waypoint_suite[i]]
@@ -128,14 +161,24 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
                     agents.append(dict(state=(x, y, psi, v), attr=tuple(float(t) for t in bt["agent_attributes"][k][:3]),
                                        vdes=v, route=route, replay=None))
         heading = math.atan2(wps[1][1] - wps[0][1], wps[1][0] - wps[0][0])
-        meshes.append(corridor_mesh(polylines, width=road_width))
+        loc = data.locations[i] if data.locations else None
+        if loc is not None and loc in map_of_location:
+            map_id = map_of_location[loc]
+        else:
+            tri = _mesh_of_location(road_meshes, loc) if loc is not None else None
+            map_id = len(meshes)
+            if tri is not None:
+                map_of_location[loc] = map_id
+                meshes.append(tri)
+            else:
+                meshes.append(corridor_mesh(polylines, width=road_width))
         if len(agents) > agents_per_env - 1:
             # the reference assembles up to ~100 agents per env (gym_env.py:216-237); an env here has agents_per_env slots
             # (a power of two <= TDE_MAX_AGENTS = 64): the scenario's own agents come first, what does not fit is dropped - loudly
             warnings.warn(f"scenario {i}: {len(agents)} non-ego agents but only {agents_per_env - 1} NPC slots "
                           f"(agents_per_env={agents_per_env}): the last {len(agents) - (agents_per_env - 1)} are dropped; "
                           f"raise agents_per_env (a power of two, at most {_abi.TDE_MAX_AGENTS})", stacklevel=2)
-        scn = dict(map=i, waypoints=wps, start_heading=heading, agents=agents[:agents_per_env - 1])
+        scn = dict(map=map_id, waypoints=wps, start_heading=heading, agents=agents[:agents_per_env - 1])
         if ego_attr is not None:
             scn["ego_attr"] = ego_attr
         scenarios.append(scn)
@@ -143,7 +186,9 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
 
 
 class _LazyInfo(dict):
-    """dict of per-env info tensors (ref gym_env.py:419-437) whose values are built when first read"""
+    """dict of per-env info tensors (ref gym_env.py:419-437) whose values are built when first read.  The entries are VIEWS of the
+    env's own output buffers (like reward / terminated / truncated): valid until the next step() overwrites them - clone what
+    must be kept."""
 
     KEYS = ("offroad", "collision", "traffic_light_violation", "is_success")
     EXTRA = ("reached_waypoint_num", "psi_smoothness", "speed_smoothness", "psi_reward", "dist_reward")
@@ -229,13 +274,14 @@ class BatchedWaypointEnv:
 
     def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
                  frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0, binding="ext",
-                 info_magnitudes=False):
+                 info_magnitudes=True, road_meshes=None):
         """binding: "ext" = launches go through the PyTorch-ROCm C++ extension (csrc/tde_torch_ext.cpp), "ctypes" = through
         the ctypes binding of the same C-ABI (ops.py); both call the very same entry points of libtde_hip.so.
-        info_magnitudes: info["offroad"] / info["collision"] hold the MAGNITUDES the reference reports there (ref
-        gym_env.py:427-428: sum over the ego's corners of clamp(distance - threshold, 0); sum of the IoUs with the agents the ego overlaps)
-        instead of 0 / 1 indicators.  They belong to the state BEFORE a finished env is re-spawned, so a step then is three
-        launches - the step without in-kernel re-spawn, tde_ego_infractions, the masked reset - instead of one."""
+        info_magnitudes (default): info["offroad"] / info["collision"] hold the MAGNITUDES the reference reports there (ref
+        gym_env.py:427-428: sum over the ego's corners of clamp(distance - threshold, 0); sum of the IoUs with the agents the ego
+        overlaps), written by the step kernel itself for the egos it flagged, before a finished env is re-spawned
+        (tde_state.magnitudes: still ONE launch per step).  False: 0 / 1 indicators (the kernel then skips the magnitudes).
+        road_meshes: the drivable mesh per location when `data` is a WaypointSuite (world_from_waypoint_suite)."""
         validate(cfg)
         if binding not in ("ext", "ctypes"):
             raise ValueError("binding must be 'ext' or 'ctypes'")                                              # ref gym_env.py:79-80 and the fields this path rejects
@@ -253,7 +299,7 @@ class BatchedWaypointEnv:
         self.world = data if isinstance(data, World) else world_from_waypoint_suite(
             data, agents_per_env,
             threshold=effective_offroad_distance(sim.offroad_threshold, sim.offroad_threshold_squared),
-            background=background if cfg.use_background_traffic else None, ego_only=cfg.ego_only)
+            background=background if cfg.use_background_traffic else None, ego_only=cfg.ego_only, road_meshes=road_meshes)
         check_threshold(self.world, sim.offroad_threshold, sim.offroad_threshold_squared,
                         "EnvConfig.simulator.offroad_threshold")   # a prebuilt World bakes its threshold into the grid
         self.A = self.world.A
@@ -271,8 +317,9 @@ class BatchedWaypointEnv:
         self.tde_cfg.env_base = int(env_base)                        # shard of a larger batch: sharding.ShardedBatchedEnv
         self.dworld = self.world.to_device(self.torch_device)
         # obs_mode "state": tde_env_step writes the compact observation itself (no second launch per step)
+        self.info_magnitudes = bool(info_magnitudes)
         self.state = EnvState(self.num_envs, self.A, device=self.torch_device, with_info=with_info,
-                              with_obs=(obs_mode == "state"))
+                              with_obs=(obs_mode == "state"), with_magnitudes=self.info_magnitudes)
         self.obs_mode, self.frame_stack = obs_mode, max(1, int(frame_stack))
         r = cfg.simulator.renderer
         self._res, self._fov = int(r.res), float(r.fov)
@@ -284,8 +331,7 @@ class BatchedWaypointEnv:
         self.reward_range = (-float("inf"), float("inf"))           # ref gym_env.py:97
         self._vec = None
         self._h = None
-        self.info_magnitudes = bool(info_magnitudes)
-        self._mag = torch.zeros((self.num_envs, 4), dtype=torch.float32, device=self.torch_device) if info_magnitudes else None
+        self._mag = self.state["magnitudes"]                         # float32 [B, 4] written by the step (None: indicators)
         if binding == "ext":
             from . import _ext
             self._h = _ext.env_handle(self.tde_cfg, self.dworld, self.state)
@@ -302,7 +348,9 @@ class BatchedWaypointEnv:
         their frame stack exactly as the last step left it."""
         m = None
         if mask is not None:
-            m = torch.as_tensor(mask, device=self.torch_device).to(torch.uint8).contiguous()
+            # 0 / 1 bytes: the rasteriser reads bits 0-1 of a `fresh` byte (tde_render.fresh), so a mask like done_bits with only
+            # infraction bits set must not re-spawn an env and leave its older stack frames un-blanked
+            m = (torch.as_tensor(mask, device=self.torch_device) != 0).to(torch.uint8).contiguous()
         if m is not None and self.obs_mode == "birdview" and self._obs is not None:
             # the SB3-style auto-reset: the re-spawn and the re-spawned views' first observation in ONE C-ABI call
             if self._stack is not None:
@@ -341,8 +389,6 @@ class BatchedWaypointEnv:
         if not (torch.is_tensor(a) and a.dtype is torch.float32 and a.device == self.torch_device and a.dim() == 2
                 and a.shape[0] == self.num_envs and a.shape[1] == 2 and a.is_contiguous()):
             a = torch.as_tensor(actions, dtype=torch.float32, device=self.torch_device).reshape(self.num_envs, 2).contiguous()
-        if self.info_magnitudes:
-            return self._step_with_magnitudes(a)
         if self._h is not None:
             self._h.step(a, int(self.tde_cfg.flags))
         else:
@@ -359,13 +405,16 @@ class BatchedWaypointEnv:
             obs = self.get_obs(fresh)
         # uint8 0/1 flags seen as bool without a copy; info entries are only computed when they are read
         term, trunc = self._flag_views()
-        return obs, st["reward"], term, trunc, _LazyInfo(st, self.num_envs, self.A)
+        return obs, st["reward"], term, trunc, _LazyInfo(st, self.num_envs, self.A, magnitudes=self._mag)
 
-    def _step_with_magnitudes(self, a):
-        """step without in-kernel re-spawn -> tde_env_post_step (the magnitudes of the infractions the step flagged + the re-spawn of
-        the envs it finished, one launch) -> the observation: the results of the one-launch step, plus info["offroad"] /
-        info["collision"] as the reference reports them (two launches per step, three with the birdview)"""
+    def _step_then_post_step(self, a):
+        """the round-4 form of a step with magnitudes, kept for A/B runs and as a second witness of the fused path
+        (tests/test_gpu_magnitudes.py): step without in-kernel re-spawn -> tde_env_post_step (the magnitudes of the infractions the
+        step flagged + the re-spawn of the envs it finished, one launch) -> the observation.  Same results as step(), one launch
+        more."""
         st = self.state
+        if self._mag is None:
+            raise RuntimeError("needs info_magnitudes=True")
         full = int(self.tde_cfg.flags)
         flags = full & ~_abi.F_AUTORESET
         post = flags | (full & _abi.F_AUTORESET)            # (WaypointVecEnv.step_wait clears the flag: it re-spawns the envs itself)
@@ -433,7 +482,7 @@ class BatchedWaypointEnv:
     def get_info(self):
         """info schema of the reference (ref gym_env.py:419-437), one entry per env; a mapping whose tensors are formed
         on first access (a training loop that never reads `psi_smoothness` does not pay for it)"""
-        return _LazyInfo(self.state, self.num_envs, self.A)
+        return _LazyInfo(self.state, self.num_envs, self.A, magnitudes=self._mag)
 
     def render(self):
         """(B, H, W, 3) uint8 of the current ego views (ref gym_env.py:152-155)"""
@@ -673,7 +722,7 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
         rew = out["reward"].copy()
         bits = out.get("done_bits")
         cols = {"TimeLimit.truncated": trunc & ~term}
-        mag = env._mag.cpu().numpy() if env.info_magnitudes else None   # (the reference's magnitudes: BatchedWaypointEnv(info_magnitudes=True))
+        mag = out.get("magnitudes")                                  # (the reference's magnitudes, part of the same packed copy)
         for k in self.info_keywords:
             if k == "offroad":
                 cols[k] = mag[:, 0].copy() if mag is not None else ((bits >> 2) & 1).astype(np.float32) if bits is not None else None
@@ -759,10 +808,12 @@ class WaypointSuiteEnv(_GymEnvBase):
 
     metadata = {"render_modes": ["video", "rgb_array"], "render_fps": 10}
 
-    def __init__(self, cfg: EnvConfig, data, agents_per_env=8):
+    def __init__(self, cfg: EnvConfig, data, agents_per_env=8, road_meshes=None):
         self.config = cfg
+        # info["offroad"] / info["collision"] carry the MAGNITUDES of compute_offroad() / compute_collision(), as the reference's
+        # get_info reports them (ref gym_env.py:427-428; Monitor logs them, examples/rl_training.py:128)
         self._env = BatchedWaypointEnv(cfg, data, num_envs=1, agents_per_env=agents_per_env, obs_mode="birdview",
-                                       frame_stack=1, auto_reset=False)
+                                       frame_stack=1, auto_reset=False, info_magnitudes=True, road_meshes=road_meshes)
         self.torch_device = self._env.torch_device
         self.render_mode = cfg.render_mode
         self.max_environment_steps = cfg.max_environment_steps
@@ -840,13 +891,14 @@ class SingleAgentWrapper(_GymWrapperBase):
         self.env.close()
 
 
-def make(cfg: EnvConfig, data, agents_per_env=8):
-    """what gym.make('torchdriveenv-v0', args={'cfg': cfg, 'data': data}) returns in the reference (ref __init__.py:10)"""
-    return SingleAgentWrapper(WaypointSuiteEnv(cfg=cfg, data=data, agents_per_env=agents_per_env))
+def make(cfg: EnvConfig, data, agents_per_env=8, road_meshes=None):
+    """what gym.make('torchdriveenv-v0', args={'cfg': cfg, 'data': data}) returns in the reference (ref __init__.py:10);
+    `road_meshes`: see world_from_waypoint_suite"""
+    return SingleAgentWrapper(WaypointSuiteEnv(cfg=cfg, data=data, agents_per_env=agents_per_env, road_meshes=road_meshes))
 
 
 if gym is not None:  # pragma: no cover
     try:
-        gym.register('torchdriveenv-v0', entry_point=lambda args: make(args['cfg'], args['data']))
+        gym.register('torchdriveenv-v0', entry_point=lambda args: make(args['cfg'], args['data'], road_meshes=args.get('road_meshes')))
     except Exception:
         pass

@@ -12,13 +12,14 @@ from . import _abi
 # per-env OUTPUTS of a step: on a device they share one byte arena, so the SB3-shaped numpy path fetches all of them with
 # ONE device-to-host copy into a pinned buffer (EnvState.fetch_outputs) instead of one synchronising .cpu() per array
 OUTPUT_KEYS = ["reward", "terminated", "truncated", "tl_violation", "done_bits", "info", "info_reached", "ep_final",
-               "ep_final_len"]
+               "ep_final_len", "magnitudes"]
 
 
 class EnvState:
     """`arrays[name]` are numpy arrays (host; used with the CPU oracle in tests) or torch tensors (device)."""
 
-    def __init__(self, B, A, device=None, with_info=True, with_obs=False, with_episode=None, with_cache=None):
+    def __init__(self, B, A, device=None, with_info=True, with_obs=False, with_episode=None, with_cache=None,
+                 with_magnitudes=None):
         assert A >= 1 and (A & (A - 1)) == 0 and A <= _abi.TDE_MAX_AGENTS, f"A must be a power of two <= {_abi.TDE_MAX_AGENTS}"
         self.B, self.A, self.device = int(B), int(A), device
         with_episode = with_info if with_episode is None else with_episode
@@ -30,6 +31,9 @@ class EnvState:
             off_keys.add("obs")
         if not with_episode:
             off_keys |= {"ep_return", "ep_final", "ep_final_len"}
+        # the magnitudes of the ego's infractions (tde_state.magnitudes: what the reference's info["offroad" | "collision"] hold)
+        if not (with_info if with_magnitudes is None else with_magnitudes):
+            off_keys.add("magnitudes")
         # the step's lookup caches (tde_state.slot_cache / env_cache): device-side only (the oracle has no use for them)
         if not (with_cache if with_cache is not None else device is not None):
             off_keys |= {"slot_cache", "env_cache", "act_cache"}

@@ -93,7 +93,10 @@ def pitch_cells(a, nx, ny):
 SUB = 4                  # a MIXED cell carries SUB x SUB sub-cell classes (TDE_CELL_SUB)
 
 
-def build_grid_index(tri32, threshold=0.5, cell=0.5, margin=GRID_MARGIN, n_threads=0):
+NEAR_RANGE = 2.0         # metres beyond the threshold the coarse tiles carry a near list for (tde_world.tile_near)
+
+
+def build_grid_index(tri32, threshold=0.5, cell=0.5, margin=GRID_MARGIN, n_threads=0, near_range=NEAR_RANGE):
     """Uniform-grid index over a triangle soup `tri32` [n,3,2] (fp32 vertices, what kernels and oracle see) for the offroad
     test, through `tde_grid_build` (include/tde_hip.h; rounds 1-3 did this in numpy, seconds per 200-triangle junction).
 
@@ -101,6 +104,9 @@ def build_grid_index(tri32, threshold=0.5, cell=0.5, margin=GRID_MARGIN, n_threa
     candidate triangles - plus, for MIXED cells, the candidate list (identical lists share their records) and the classes
     of its SUB x SUB sub-cells, and for FULL / EMPTY cells a clearance.  All conservative by `margin`, so the HIP kernels'
     masks equal the oracle's brute force (tests/test_oracle_math.py::test_grid_index_equals_brute_force).
+    `near_range`: coarse tiles (4 x 4 cells) within threshold + near_range of the mesh also get a NEAR LIST - the triangles among
+    which the nearest triangle of any point of the tile is found - for the MAGNITUDE of the offroad infraction
+    (ref gym_env.py:427); `tile_near` [ny/4 * nx/4] holds 1 + its first record, `rec_len` its length at that record.
     Returns row-major [ny * nx] numpy arrays (copies) and `rec_tri`, the triangle of every record."""
     import ctypes as C
 
@@ -109,8 +115,8 @@ def build_grid_index(tri32, threshold=0.5, cell=0.5, margin=GRID_MARGIN, n_threa
     L = _lib.load()
     tri32 = np.ascontiguousarray(np.asarray(tri32, dtype=np.float32).reshape(-1, 6))
     gp = C.POINTER(_abi.TdeGrid)()
-    _lib.check(L.tde_grid_build(tri32.ctypes.data, len(tri32), float(threshold), float(cell), float(margin), int(n_threads),
-                                C.byref(gp)), "tde_grid_build")
+    _lib.check(L.tde_grid_build(tri32.ctypes.data, len(tri32), float(threshold), float(cell), float(margin), float(near_range),
+                                int(n_threads), C.byref(gp)), "tde_grid_build")
     try:
         g = gp.contents
         n = g.nx * g.ny
@@ -119,7 +125,10 @@ def build_grid_index(tri32, threshold=0.5, cell=0.5, margin=GRID_MARGIN, n_threa
                    cell_count=np.ctypeslib.as_array(g.cell_count, (n,)).copy(),
                    cell_first=np.ctypeslib.as_array(g.cell_first, (n,)).copy(),
                    cell_sub=np.ctypeslib.as_array(g.cell_sub, (n,)).copy(),
-                   rec_tri=np.ctypeslib.as_array(g.rec_tri, (max(1, int(g.n_records)),))[:int(g.n_records)].copy())
+                   rec_tri=np.ctypeslib.as_array(g.rec_tri, (max(1, int(g.n_records)),))[:int(g.n_records)].copy(),
+                   rec_len=np.ctypeslib.as_array(g.rec_len, (max(1, int(g.n_records)),))[:int(g.n_records)].copy(),
+                   tile_near=np.ctypeslib.as_array(g.tile_near, ((g.nx // COARSE) * (g.ny // COARSE),)).copy(),
+                   n_near_lists=int(g.n_near_lists))
     finally:
         L.tde_grid_free(gp)
     return out
@@ -294,7 +303,7 @@ class DeviceWorld:
         self.struct = _abi.fill_world_struct(tensors, ints)
 
 
-def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, light_groups=None):
+def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, light_groups=None, near_range=NEAR_RANGE):
     """meshes: list of [n,3,2] triangle arrays; scenarios: list of dicts with keys
          map (int), waypoints [(x,y)...], start_heading (float),
          agents: list (slots 1..) of dict(state=(x,y,psi,v), attr=(L,W,lr), vdes, route=[(x,y)..] or None,
@@ -327,24 +336,28 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, l
         return len(stop_all) - n_stop, n_stop, len(phase_all) - n_phase, n_phase, cycle
 
     maps = np.zeros(len(meshes) + len(light_groups), dtype=_abi.MAP_DTYPE)
-    tri_all, word_all, rec_all, cls2_all, sub_all, coarse_all = [], [], [], [], [], []
-    tri_base = cell_base = rec_base = cls2_base = coarse_base = 0
+    tri_all, word_all, rec_all, cls2_all, sub_all, coarse_all, near_all = [], [], [], [], [], [], []
+    tri_base = cell_base = rec_base = cls2_base = coarse_base = near_base = 0
     for m, tri in enumerate(meshes):
         tri = np.asarray(tri, dtype=np.float64).reshape(-1, 3, 2)
         # the kernels see fp32 vertices: index the fp32-rounded mesh
         tri32 = tri.astype(np.float32)
-        g = build_grid_index(tri32, threshold, cell)
+        g = build_grid_index(tri32, threshold, cell, near_range=near_range)
         stop_base, n_stop, phase_base, n_phase, cycle = add_lights(lights[m])
         maps[m] = (g["ox"], g["oy"], g["cell"], np.float32(1.0) / np.float32(g["cell"]), g["nx"], g["ny"], cell_base,
                    tri_base, len(tri), stop_base, n_stop, phase_base, n_phase, cycle,
-                   row_shift_of(g["nx"]), cls2_base, rec_base, coarse_base, (0, 0))
+                   row_shift_of(g["nx"]), cls2_base, rec_base, coarse_base, near_base, 0)
         # cell word = class | count << 2 | first record << 10: the count of a MIXED cell is the length of its candidate list
         # (records from the map's rec_base + first on), that of a FULL / EMPTY cell its clearance (TDE_CLEARANCE_UNITs, rounded
         # down): every point within that distance of ANY point of the cell lies in a cell of the same class - the rasteriser
         # classifies a whole block of pixels with one look-up
         word_all.append(pitch_cells(g["cell_class"].astype(np.uint32) | (g["cell_count"].astype(np.uint32) << 2) |
                                     (g["cell_first"] << 10), g["nx"], g["ny"]))
-        rec_all.append(pack_triangles(tri32)[g["rec_tri"]])   # per-list copies: one dependent load less in the kernel
+        recs = pack_triangles(tri32)[g["rec_tri"]]           # per-list copies: one dependent load less in the kernel
+        recs[:, 9] = g["rec_len"].astype(np.int32).view(np.float32)   # (the length of a near list rides in its first record)
+        rec_all.append(recs)
+        near_all.append(g["tile_near"])
+        near_base += len(g["tile_near"])
         sub_all.append(sub_tiles(g["cell_sub"], g["nx"], g["ny"]))   # sub-cell classes of the MIXED cells, 8 x 4 cells per line
         c2, ntile = class_tiles(g["cell_class"], g["nx"], g["ny"])
         cls2_all.append(c2)
@@ -407,10 +420,11 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, l
     replay_states = np.zeros((max(1, len(replays)), RT, 4), np.float32)
     for i, r in enumerate(replays):
         replay_states[i, :len(r)] = r
-    rec_cat = np.concatenate(rec_all, 0) if rec_base else np.zeros((1, 12), np.float32)
+    # (16 zero records at the end: the magnitude kernels fetch the first 16 records of a near list before they know its length)
+    rec_cat = np.concatenate(rec_all + [np.zeros((16, 12), np.float32)], 0)
     arrays = dict(maps=maps, tri=np.concatenate(tri_all, 0), cell_word=np.concatenate(word_all), cell_tri=rec_cat,
                   cell_cls2=np.concatenate(cls2_all), cell_sub=np.concatenate(sub_all), cell_coarse=np.concatenate(coarse_all),
-                  scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states,
+                  tile_near=np.concatenate(near_all), scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states,
                   stoplines=np.asarray(stop_all, dtype=_abi.STOPLINE_DTYPE) if stop_all
                   else np.zeros(1, _abi.STOPLINE_DTYPE),
                   phases=np.asarray(phase_all, dtype=_abi.PHASE_DTYPE) if phase_all else np.zeros(1, _abi.PHASE_DTYPE))
