@@ -94,23 +94,29 @@ TDE_DEV tde_map map_of_lane(const tde_map &m, int src)
 // flags; ego: ballot of the ego lanes), one ego at a time by all 64 lanes: the values of tde_ego_infractions on the state the step
 // left - what get_info reports under "collision" / "offroad" (ref gym_env.py:427-428).  ra / rb: tile rows of the wavefront's
 // lane 0 (lane l's row at ra[l]); `m`: the map descriptor of every lane's env.  Returns this lane's env's four values (ego lanes).
-template <int A>
-TDE_DEV float4 ego_magnitudes_of_wave(const tde_config &cfg, const tde_world &w, const tde_map &m, unsigned long long ego,
-                                      unsigned long long hm, unsigned long long om, const float4 *ra, const float4 *rb, int lane,
-                                      float *poly)
+// `map_of(src)`: the (wave-uniform) map descriptor of the env whose ego sits on lane src; `out_e`: this lane's env's entry of
+// tde_state.magnitudes (ego lanes; nullptr on the others).  Every ego lane stores zeros first and the lane of a flagged ego its
+// values when they are known (same lane, same address, program order): nothing is carried in registers through the section.
+template <int A, bool LEAN = false, typename M>
+TDE_DEV void ego_magnitudes_of_wave(const tde_config &cfg, const tde_world &w, M &&map_of, unsigned long long ego,
+                                    unsigned long long hm, unsigned long long om, const float4 *ra, const float4 *rb, int lane,
+                                    float *poly, float4 *out_e)
 {
-    float4 mg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (out_e) *out_e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (unsigned long long fm = (hm | om) & ego; fm; fm &= fm - 1) {       // (wave-uniform; rarely more than one trip)
         const int src = __ffsll((long long)fm) - 1;
         const float4 ea = ra[src], eb4 = rb[src];
-        const EgoBox eb{ea.x, ea.y, eb4.x, eb4.y, eb4.z, eb4.w};
-        float2 cm = make_float2(0.0f, 0.0f);
-        float omag = 0.0f;
-        if ((hm >> src) & 1ull) cm = ego_collision_mag_of(A, lane, eb, TileRows{ra + src, rb + src}, poly);
-        if ((om >> src) & 1ull) omag = ego_offroad_mag_wave(cfg, w, map_of_lane(m, src), eb, lane);
-        if (lane == src) mg = make_float4(omag, cm.x, cm.y, 0.0f);
+        // (wave-uniform values in scalar registers: the section runs under the three-role kernel's 80-VGPR budget)
+        const EgoBox eb{readlane_f(ea.x, 0), readlane_f(ea.y, 0), readlane_f(eb4.x, 0), readlane_f(eb4.y, 0), readlane_f(eb4.z, 0), readlane_f(eb4.w, 0)};
+        if ((hm >> src) & 1ull) {
+            const float2 cm = ego_collision_mag_of(A, lane, eb, TileRows{ra + src, rb + src}, poly);
+            if (lane == src) { reinterpret_cast<float *>(out_e)[1] = cm.x; reinterpret_cast<float *>(out_e)[2] = cm.y; }
+        }
+        if ((om >> src) & 1ull) {
+            const float omag = ego_offroad_mag_wave<LEAN>(cfg, w, map_of(src), eb, lane);
+            if (lane == src) reinterpret_cast<float *>(out_e)[0] = omag;
+        }
     }
-    return mg;
 }
 
 // LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
@@ -928,7 +934,10 @@ TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag,
 // Called by all BLOCK lanes of the workgroup, converged (contains barriers and wave ballots).
 // LIGHTS: compiled with the traffic-light code (stop-line violation of the ego, NPCs stopping at red lines); the
 // kernels without it serve configs that have no lights at zero cost.
-template <int A, int BLOCK, bool LIGHTS, bool BIG = false>
+#ifndef TDE_SOLO_MAG_LEAN
+#define TDE_SOLO_MAG_LEAN 1         // the one-role kernel's magnitudes section with the low-register scan too (A/B)
+#endif
+template <int A, int BLOCK, bool LIGHTS, bool BIG = false, bool MAG = false>
 TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold &cold, const tde_state &st,
                           Tiles<BLOCK> &t, int e, int a, bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0,
                           float &s0, float act_acc, float act_steer, float *mag_out = nullptr)
@@ -1011,12 +1020,12 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     // ---- tde_state.magnitudes: the magnitudes of the ego's infractions (get_info's "collision" / "offroad", :427-428), for the
     // egos this step flagged, before any re-spawn touches the tile.  (A = 128: the ego's wavefront reads the env's 128 rows; its
     // partner holds no ego lane, skips this and meets it at the barriers below.)
-    if (mag_out) {
+    if constexpr (MAG) {
         const unsigned long long ego = __ballot(a == 0 && valid);
         const int w0 = tid & ~63;                   // this wavefront's first row of the tile
-        const float4 mg = ego_magnitudes_of_wave<A>(cfg, w, cx.m, ego, __ballot(hit), __ballot(off), &t.a[w0], &t.b[w0], tid & 63,
-                                                    t.poly[tid >> 6]);
-        if (a == 0 && valid) reinterpret_cast<float4 *>(mag_out)[e] = mg;
+        ego_magnitudes_of_wave<A, TDE_SOLO_MAG_LEAN != 0>(cfg, w, [&](int src) { return map_of_lane(cx.m, src); }, ego, __ballot(hit), __ballot(off),
+                                  &t.a[w0], &t.b[w0], tid & 63, t.poly[tid >> 6],
+                                  (a == 0 && valid) ? reinterpret_cast<float4 *>(mag_out) + e : nullptr);
     }
 
     // ---- reward / termination on the ego lane; the env's other lanes learn "done" from the wave ballot ----------
@@ -1081,7 +1090,8 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
 // round, 4 (128 VGPRs, 16 spilled) above 1536 envs, where a fourth resident wavefront is worth more than the spills cost
 // (us per step at 256 / 1024 / 2048 / 4096 envs of ~122 agents: 15.7 / 18.2 / 33.1 / 51.2 against 16.7 / 20.3 / 28.3 / 48.5,
 //  profiles/r04_z_wide_waves.txt)
-template <int A, bool LIGHTS, bool OBS, bool BIG = false, int WAVES = TDE_WIDE_WAVES>
+// MAG: also writes tde_state.magnitudes (a template flag for the same reason: 84 -> 128 VGPRs with the code in it)
+template <int A, bool LIGHTS, bool OBS, bool BIG = false, int WAVES = TDE_WIDE_WAVES, bool MAG = false>
 __global__ __launch_bounds__(kBlock, A > kWave ? WAVES : 1) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
                                                           const float *__restrict__ action, float *reward_k,
                                                           uint8_t *done_k)
@@ -1110,7 +1120,7 @@ __global__ __launch_bounds__(kBlock, A > kWave ? WAVES : 1) void env_step_kernel
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     tile_sync<A>();
-    StepOut o = step_lane<A, kBlock, LIGHTS, BIG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y, st.magnitudes);
+    StepOut o = step_lane<A, kBlock, LIGHTS, BIG, MAG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y, st.magnitudes);
     if (!valid) return;
     store_agent_dynamic(st, g, ag);
     if (o.respawned) store_agent_static(st, g, ag);
@@ -1272,7 +1282,28 @@ struct DuoShared {
     // formed by judge O ahead of barrier B together with the stop-line cache
     int4 lights[8];
     float4 ego_next[8][2];               // ... and the ego's start (pose, attributes) computed from them by judge C (ego_spawn)
+    // one-step three-role kernel with tde_state.magnitudes: what the magnitude functions read of every env's map descriptor
+    // (ox, oy, cell, inv_cell | nx, ny, cell_base, row_shift | rec_base, near_base, -, -), parked by judge O ahead of barrier B
+    int4 mapw[8][3];
 };
+
+TDE_DEV void map_to_lds(int4 *dst, const tde_map &m)
+{
+    dst[0] = make_int4(__float_as_int(m.ox), __float_as_int(m.oy), __float_as_int(m.cell), __float_as_int(m.inv_cell));
+    dst[1] = make_int4(m.nx, m.ny, m.cell_base, m.row_shift);
+    dst[2] = make_int4(m.rec_base, m.near_base, 0, 0);
+}
+TDE_DEV tde_map map_from_lds(const int4 *src)
+{
+    const int4 a = src[0], b = src[1], c = src[2];
+    tde_map r{};
+    // (wave-uniform: scalar registers - the section runs under the three-role kernel's 80-VGPR budget)
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+    r.ox = __int_as_float(RFL(a.x)); r.oy = __int_as_float(RFL(a.y)); r.cell = __int_as_float(RFL(a.z)); r.inv_cell = __int_as_float(RFL(a.w));
+    r.nx = RFL(b.x); r.ny = RFL(b.y); r.cell_base = RFL(b.z); r.row_shift = RFL(b.w); r.rec_base = RFL(c.x); r.near_base = RFL(c.y);
+#undef RFL
+    return r;
+}
 constexpr int kStopCache = TDE_STOP_CACHE;
 
 // the lanes of an env fetch its first min(n_stop, kStopCache) lines, one each per trip (the driver calls it at start and after re-spawns)
@@ -2212,7 +2243,9 @@ TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, c
 //  counters of one configuration never share a word and two configurations collide with probability 2^-32; ABI 9 kept 12 bits)
 TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash ^ ((uint32_t)steps * 0x9E3779B1u)); }
 
-template <int A, bool LIGHTS, bool OBS>
+// MAG: also writes tde_state.magnitudes (judge O, behind barrier A); a template flag because the code, taken or not, costs the
+// plain kernel its registers: 73 -> 80 VGPRs + 40 spilled, and a launch with a private segment takes 1.3 us longer to dispatch
+template <int A, bool LIGHTS, bool OBS, bool MAG = false>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_step_trio_kernel(
     tde_config cfg, tde_world w, tde_state st, uint32_t act_hash)
 {
@@ -2225,11 +2258,13 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
     }
     const uint32_t F = cfg.flags;
-    const int64_t g = (int64_t)blockIdx.x * kWave + lane;
-    const int e = (int)(g / A), a = (int)(g % A);
+    // (32-bit slot index: B * A slots of ~60 bytes of state each cannot exceed 2^32, and an int64 index costs every role two
+    //  registers for the whole launch - the kernel has none to spare with the magnitudes section in it)
+    const uint32_t g = blockIdx.x * (uint32_t)kWave + (uint32_t)lane;
+    const int e = (int)(g / (uint32_t)A), a = (int)(g % (uint32_t)A);
     const int B = st.B;
     const bool valid = e < B;
-    const int64_t gs = valid ? g : 0;
+    const uint32_t gs = valid ? g : 0u;
     const int es = valid ? e : 0;
     const int base = lane - a;
     // Every role first ISSUES the loads of its state (none of them needs the cold block), then meets the others at the
@@ -2544,6 +2579,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             m = cold.maps[map];
         }
         const float thr2 = thr2_of(cfg);
+        if constexpr (MAG) { if (a == 0) map_to_lds(sh.mapw[lane / A], m); }
         uint32_t red_k = 0u;
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) {
             // in the wait for barrier B: the env's stop lines into LDS, the red masks of this step and of the next one
@@ -2574,10 +2610,18 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         // tde_state.magnitudes (get_info's "collision" / "offroad", :427-428) for the egos this step flagged: this judge has nothing
         // left to do while the driver and judge C re-spawn the finished envs, and the rows of the step stay in buffer 0
         // (ring_post: the rollout kernel's, unused in a one-step launch)
-        if (st.magnitudes) {
-            const float4 mg = ego_magnitudes_of_wave<A>(cfg, w, m, __ballot(a == 0 && valid), sh.hit_mask, om, &sh.a[0][0], &sh.b[0][0],
-                                                        lane, reinterpret_cast<float *>(sh.ring_post));
-            if (a == 0 && valid) reinterpret_cast<float4 *>(st.magnitudes)[e] = mg;
+        if constexpr (MAG) {
+            // (the map descriptors wait in LDS: kept in registers across the offroad test they cost the kernel its spill-free fit;
+            //  the lane's indices are formed AGAIN, from the hardware lane counter, so that nothing of the kernel's prologue has to
+            //  stay live through this section - the compiler otherwise parks those values in scratch memory for the whole launch,
+            //  and a launch with a private segment takes 1.3 us longer to dispatch)
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int64_t g2 = (int64_t)blockIdx.x * kWave + ln;
+            const int e2 = (int)(g2 / A);
+            const bool ego2 = (g2 % A) == 0 && e2 < st.B;
+            ego_magnitudes_of_wave<A, true>(cfg, w, [&](int src) { return map_from_lds(sh.mapw[src / A]); }, __ballot(ego2), sh.hit_mask, om,
+                                            &sh.a[0][0], &sh.b[0][0], ln, reinterpret_cast<float *>(sh.ring_post),
+                                            ego2 ? reinterpret_cast<float4 *>(st.magnitudes) + e2 : nullptr);
         }
     }
 }
@@ -2888,6 +2932,11 @@ void render_views_kernel(RenderArgs ra, int B)
 
 #include "tde_magnitudes_kernels.h"
 
+// Register / spill figures of a few kernels in seconds instead of the 80 s of the whole translation unit:
+// -DTDE_KERNEL_PROBE -I<dir of a tde_probe.inc holding explicit instantiations> --offload-device-only (scripts/probe_kernel.sh)
+#ifdef TDE_KERNEL_PROBE
+#include "tde_probe.inc"
+#else
 // ------------------------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------------------------
@@ -3097,7 +3146,11 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     if (trio_ok && want_trio && !first_step_acts) {
         const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
         const uint32_t act_hash = act_cfg_hash(*cfg, *world);
-#define TDE_LAUNCH_STEP3(AA, L, O) tde::env_step_trio_kernel<AA, L, O><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, act_hash)
+#define TDE_LAUNCH_STEP3(AA, L, O)                                                                                                   \
+    do {                                                                                                                           \
+        if (st->magnitudes) tde::env_step_trio_kernel<AA, L, O, true><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, act_hash); \
+        else tde::env_step_trio_kernel<AA, L, O, false><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, act_hash);               \
+    } while (0)
 #define TDE_LAUNCH_STEP3_A(AA)                                                                       \
     if (st->obs) { if (lights) TDE_LAUNCH_STEP3(AA, true, true); else TDE_LAUNCH_STEP3(AA, false, true); } \
     else { if (lights) TDE_LAUNCH_STEP3(AA, true, false); else TDE_LAUNCH_STEP3(AA, false, false); }
@@ -3109,7 +3162,11 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     }
     const unsigned nb = blocks_for((int64_t)st->B * st->A);
     if ((world->hints & TDE_WORLD_LARGE_GRID) && (st->A == 32 || st->A == 64)) {      // (up to 16 slots per env the class map is read anyway)
-#define TDE_LAUNCH_STEP_BIG(AA, L, O) tde::env_step_kernel<AA, L, O, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits)
+#define TDE_LAUNCH_STEP_BIG(AA, L, O)                                                                                                                                   \
+    do {                                                                                                                                                              \
+        if (st->magnitudes) tde::env_step_kernel<AA, L, O, true, TDE_WIDE_WAVES, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits); \
+        else tde::env_step_kernel<AA, L, O, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits);            \
+    } while (0)
 #define TDE_LAUNCH_STEP_BIG_A(AA)                                                                              \
     if (st->obs) { if (lights) TDE_LAUNCH_STEP_BIG(AA, true, true); else TDE_LAUNCH_STEP_BIG(AA, false, true); } \
     else { if (lights) TDE_LAUNCH_STEP_BIG(AA, true, false); else TDE_LAUNCH_STEP_BIG(AA, false, false); }
@@ -3120,16 +3177,27 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
         return eb == hipSuccess ? 0 : fail("tde_env_step", eb);
     }
     if (st->A == 128 && st->B > 6 * cu_count()) {            // (128 slots, more than a residency round of the 3-per-SIMD form: 4 per SIMD)
-#define TDE_LAUNCH_STEP_W4(L, O) tde::env_step_kernel<128, L, O, false, 4><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits)
+#define TDE_LAUNCH_STEP_W4(L, O)                                                                                                                                  \
+    do {                                                                                                                                                          \
+        if (st->magnitudes) tde::env_step_kernel<128, L, O, false, 4, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits); \
+        else tde::env_step_kernel<128, L, O, false, 4><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits);      \
+    } while (0)
         if (st->obs) { if (lights) TDE_LAUNCH_STEP_W4(true, true); else TDE_LAUNCH_STEP_W4(false, true); }
         else { if (lights) TDE_LAUNCH_STEP_W4(true, false); else TDE_LAUNCH_STEP_W4(false, false); }
 #undef TDE_LAUNCH_STEP_W4
         hipError_t e4 = hipGetLastError();
         return e4 == hipSuccess ? 0 : fail("tde_env_step", e4);
     }
-#define TDE_LAUNCH_STEP(L, O)                                                                                          \
-    TDE_DISPATCH_A128(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                 \
-                              *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits))
+#define TDE_LAUNCH_STEP(L, O)                                                                                                                  \
+    do {                                                                                                                                       \
+        if (st->magnitudes) {                                                                                                                  \
+            TDE_DISPATCH_A128(st->A, tde::env_step_kernel<kA, L, O, false, TDE_WIDE_WAVES, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>( \
+                                      *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits));                                        \
+        } else {                                                                                                                               \
+            TDE_DISPATCH_A128(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                              \
+                                      *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits));                                        \
+        }                                                                                                                                      \
+    } while (0)
     if (st->obs) {
         if (lights) { TDE_LAUNCH_STEP(true, true); } else { TDE_LAUNCH_STEP(false, true); }
     } else {
@@ -3413,3 +3481,4 @@ int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void 
 
 // host-side table build (no kernels): tde_grid_build / tde_grid_free
 #include "tde_gridbuild.h"
+#endif  // TDE_KERNEL_PROBE

@@ -169,6 +169,48 @@ TDE_DEV float point_mesh_d2_wave(const tde_world &w, const tde_map &m, float px,
     return best;
 }
 
+// The same value with a fraction of the registers, for the fall-back INSIDE the three-role step kernel: point_mesh_d2_wave takes
+// ~90 VGPRs and the kernel has 80 - 43 spilled registers and a private segment for EVERY launch (+1.3 us to dispatch), for a
+// path that only a corner beyond the near lists takes.  The 64 lanes are an 8 x 8 block of cells; the square of side 2 hw cells
+// around the corner's cell is walked block by block, one record per trip, and grown (scanned again from scratch: this path is
+// rare and its cost is the cell words of a corner that is metres off the road anyway) until it is known to hold a cell that lists
+// the nearest triangle - the covering argument of point_mesh_d2_wave.  A minimum of the same values: the same bits.
+TDE_DEV float point_mesh_d2_scan_lean(const tde_world &w, const tde_map &m, float px, float py, float bandw, int lane)
+{
+    const float fx = __builtin_amdgcn_fmed3f((px - m.ox) * m.inv_cell, 0.0f, (float)(m.nx - 1));
+    const float fy = __builtin_amdgcn_fmed3f((py - m.oy) * m.inv_cell, 0.0f, (float)(m.ny - 1));
+    const int ix = (int)fx, iy = (int)fy;
+    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(uint32_t)m.rec_base;
+    // the corner's own cell: an EMPTY cell's clearance says how far the first square has to reach at least
+    const uint32_t wd = w.cell_word[(uint32_t)m.cell_base + (((uint32_t)iy << m.row_shift) + (uint32_t)ix)];
+    const float clear = (wd & 3u) == TDE_CELL_EMPTY ? (float)((wd >> 2) & 255u) * TDE_CLEARANCE_UNIT : 0.0f;
+    int hw = (((int)((clear + 0.5f) * m.inv_cell) + 2) + 3) & ~3;                  // a multiple of 4: the square is whole 8 x 8 blocks
+    const int lx = lane & 7, ly = lane >> 3;
+    float best = 3.0e38f;
+    for (;;) {
+        float b = 3.0e38f;
+        for (int by = iy - hw; by < iy + hw; by += 8)
+            for (int bx = ix - hw; bx < ix + hw; bx += 8) {
+                const int cx = bx + lx, cy = by + ly;
+                uint32_t cw = 0u;
+                if (cx >= 0 && cx < m.nx && cy >= 0 && cy < m.ny) cw = w.cell_word[(uint32_t)m.cell_base + (((uint32_t)cy << m.row_shift) + (uint32_t)cx)];
+                if ((cw & 3u) != TDE_CELL_MIXED) continue;
+                const int n = (int)((cw >> 2) & 255u);
+                for (int k = 0; k < n; ++k) b = fminf(b, point_tri_d2_packed(px, py, recs + 3 * (size_t)((cw >> 10) + (uint32_t)k)));
+            }
+        best = fminf(best, wave_min(b));
+        if (ix - hw <= 0 && iy - hw <= 0 && ix + hw >= m.nx && iy + hw >= m.ny) break;   // every cell of the map was looked at
+        if (best < 3.0e38f) {
+            const float need = __builtin_sqrtf(best) - bandw + (m.cell + 0.05f);
+            if (((float)hw - 1.0f) * m.cell >= need) break;
+            hw = (((int)(need * m.inv_cell) + 2) + 3) & ~3;
+        } else {
+            hw = 2 * hw + 4;
+        }
+    }
+    return best;
+}
+
 // ---- the two magnitudes, by the whole wavefront for ONE ego ---------------------------------------------------------------------
 struct EgoBox { float x, y, c, s, hl, hw; };
 
@@ -202,6 +244,7 @@ TDE_DEV float2 ego_collision_mag_of(int A, int lane, const EgoBox &eb, R &&row, 
 // Lanes 16 c .. 16 c + 15 take corner c: the tile word, the first 16 records of its near list (the list's length rides in the
 // first record: fetched before it is known, the table ends with 16 spare records), the rest of a longer list, a minimum over the 16
 // lanes; a corner without a near list goes through point_mesh_d2_wave, all 64 lanes, one such corner at a time.
+template <bool LEAN = false>
 TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, const tde_map &m, const EgoBox &eb, int lane)
 {
     const float thr = cfg.offroad_threshold, thr2 = thr2_of(cfg);
@@ -231,10 +274,15 @@ TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, co
     }
     float d2c = full ? -1.0f : best;
     const unsigned long long scan = __ballot(!full && !listed);
+#pragma unroll 1
     for (int cc = 0; cc < 4; ++cc) {
         if (!((scan >> (16 * cc)) & 1ull)) continue;                 // (wave-uniform)
         const float sx = readlane_f(px, 16 * cc), sy = readlane_f(py, 16 * cc);
-        const float d2 = point_mesh_d2_wave(w, m, sx, sy, band * band, lane);
+#ifndef TDE_X_NOSCAN
+        const float d2 = LEAN ? point_mesh_d2_scan_lean(w, m, sx, sy, band, lane) : point_mesh_d2_wave(w, m, sx, sy, band * band, lane);
+#else
+        const float d2 = sx + sy;
+#endif
         if (c == cc) d2c = d2;
     }
     float term = 0.0f;
