@@ -170,10 +170,10 @@ def secondary(dev, region_s=0.3):
             worlds[(A, town)] = (w, w.to_device(dev))
         return worlds[(A, town)]
 
-    def run(name, config, B, A, stepwise, flags, render=False, n_streams=1, with_info=False, town=False, **cfg_over):
+    def run(name, config, B, A, stepwise, flags, render=False, n_streams=1, with_info=False, town=False, magnitudes=None, **cfg_over):
         w, dw = world_of(A, town)
         cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=flags, **cfg_over)
-        st = EnvState(B, A, device=dev, with_info=with_info, with_obs=with_info)
+        st = EnvState(B, A, device=dev, with_info=with_info, with_obs=with_info, with_magnitudes=magnitudes)
         ops.env_reset(cfg, dw, st)
         g = torch.Generator(device="cpu").manual_seed(0)
         actions = torch.stack([torch.rand(CH, B, generator=g) * 2 - 1, torch.rand(CH, B, generator=g) * 0.6 - 0.3], -1)
@@ -241,8 +241,12 @@ def secondary(dev, region_s=0.3):
         ("closed_loop", dict(name="configs[2] shape, closed loop: one tde_env_step launch per timestep through the extension",
                              config=3, B=8192, A=16, stepwise=True, flags=F)),
         ("closed_loop_full_outputs", dict(name="the same with everything BatchedWaypointEnv.step asks of the kernel: float64 info terms, done bits, Monitor "
-                                               "episode statistics and the compact observation written by the step itself",
-                                          config=3, B=8192, A=16, stepwise=True, flags=F, with_info=True)),
+                                               "episode statistics, the compact observation AND the magnitudes of the ego's infractions (the reference's "
+                                               "info['offroad' | 'collision'], gym_env.py:427-428), all written by the one step launch",
+                                          config=3, B=8192, A=16, stepwise=True, flags=F, with_info=True, magnitudes=True)),
+        ("closed_loop_full_outputs_indicators", dict(name="the same with 0 / 1 infraction indicators instead of the magnitudes (BatchedWaypointEnv(info_magnitudes=False): "
+                                                          "round 4's closed_loop_full_outputs)",
+                                                     config=3, B=8192, A=16, stepwise=True, flags=F, with_info=True, magnitudes=False)),
         ("config2", dict(name="configs[1]: 1024 envs x 8 agents, kinematics + collision only, 250 steps per launch",
                          config=2, B=1024, A=8, stepwise=False, flags=0)),
         ("lights", dict(name="configs[2] + traffic-light / stop-line term (TDE_F_TRAFFIC_LIGHTS), rollout",

@@ -108,14 +108,18 @@ TDE_DEV void ego_magnitudes_of_wave(const tde_config &cfg, const tde_world &w, M
         const float4 ea = ra[src], eb4 = rb[src];
         // (wave-uniform values in scalar registers: the section runs under the three-role kernel's 80-VGPR budget)
         const EgoBox eb{readlane_f(ea.x, 0), readlane_f(ea.y, 0), readlane_f(eb4.x, 0), readlane_f(eb4.y, 0), readlane_f(eb4.z, 0), readlane_f(eb4.w, 0)};
+#ifndef TDE_X_NOCOLL                  // (timing experiments: WRONG results)
         if ((hm >> src) & 1ull) {
             const float2 cm = ego_collision_mag_of(A, lane, eb, TileRows{ra + src, rb + src}, poly);
             if (lane == src) { reinterpret_cast<float *>(out_e)[1] = cm.x; reinterpret_cast<float *>(out_e)[2] = cm.y; }
         }
+#endif
+#ifndef TDE_X_NOOFF
         if ((om >> src) & 1ull) {
             const float omag = ego_offroad_mag_wave<LEAN>(cfg, w, map_of(src), eb, lane);
             if (lane == src) reinterpret_cast<float *>(out_e)[0] = omag;
         }
+#endif
     }
 }
 
@@ -2566,10 +2570,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     } else {
         // ===================== judge O: offroad, stop lines =====================
         __builtin_amdgcn_s_setprio(TDE_SPRIO_O);
-        const int scn = st.scn[es];
-        const int k = st.steps[es] + 1;
+        const int eso = es;
+        const int scn = st.scn[eso];
+        const int k = st.steps[eso] + 1;
         int4 e0 = make_int4(0, 0, 0, 0);
-        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) e0 = reinterpret_cast<const int4 *>(st.env_cache + es)[0];
+        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) e0 = reinterpret_cast<const int4 *>(st.env_cache + eso)[0];
         float lpsi = 0.0f;                                   // the ego's heading before the step (:373), for its psi term
         if (a == 0 && valid && (F & TDE_F_REWARD)) lpsi = st.psi[g];
         lds_barrier();                                       // cold is published
@@ -2593,13 +2598,67 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
         const bool live = rc.z != 0.0f;
         bool off = false, tl = false;
-        if (F & TDE_F_OFFROAD) off = box_offroad<true, TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
+        // MAG: the ego lanes fetch the near-list words of their four corners (tde_world.tile_near) beside the offroad test - the
+        // first half of the chain tile word -> records that the offroad MAGNITUDE of a flagged ego walks (each a round trip to
+        // HBM / the fabric for these rarely touched lines); they are consumed behind barrier A
+        Corners kc{};
+        uint32_t tw0 = 0u, tw1 = 0u, tw2 = 0u, tw3 = 0u;
+        if (F & TDE_F_OFFROAD) {
+            if constexpr (MAG) {
+                offroad_issue<TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, kc);
+                if (a == 0 && live) {
+                    tw0 = near_tile_word(w, m, kc.px0, kc.py0); tw1 = near_tile_word(w, m, kc.px1, kc.py1);
+                    tw2 = near_tile_word(w, m, kc.px2, kc.py2); tw3 = near_tile_word(w, m, kc.px3, kc.py3);
+                }
+                off = offroad_resolve<true, TDE_STEP_CLS2 != 0>(w, kc, thr2, m.rec_base);
+            } else {
+                off = box_offroad<true, TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
+            }
+        }
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
             tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + m.stop_base, lane / A}, m.n_stop, red_k, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
         const unsigned long long om = __ballot(off), tm = __ballot(tl);
         if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
         // the ego's psi term for judge C (get_reward :403; ring_pre is the rollout kernel's, unused in a one-step launch)
         if (a == 0 && valid && (F & TDE_F_REWARD)) reinterpret_cast<double *>(sh.ring_pre)[lane] = reward_psi_term(cold, lpsi, rc.x);
+        // MAG: the records of the first flagged ego's near lists are requested here, AHEAD of barrier A (no wait: the loads
+        // are in flight while this wavefront sits at the barrier and forms the done masks)
+        // (the ego lanes' corner points and tile words go to LDS - ring_post, the rollout kernel's and unused in a one-step launch:
+        //  floats [32, 32 + 8 * 12) behind box_iou_wave's 32 - so that nothing but the first ego's twelve record registers stays
+        //  live across the barrier: the section runs under this kernel's 80-VGPR budget)
+        float *nearw = reinterpret_cast<float *>(sh.ring_post) + 32;
+        if constexpr (MAG) {
+            if (a == 0) {
+                float4 *d = reinterpret_cast<float4 *>(nearw + 12 * (lane / A));
+                d[0] = make_float4(kc.px0, kc.px1, kc.px2, kc.px3);
+                d[1] = make_float4(kc.py0, kc.py1, kc.py2, kc.py3);
+                d[2] = make_float4(__uint_as_float(tw0), __uint_as_float(tw1), __uint_as_float(tw2), __uint_as_float(tw3));
+            }
+            wave_lds_fence();
+        }
+        auto corners_of = [&](int src, NearFetch &nf, bool fetch) {   // lanes 16 c .. 16 c + 15 take corner c of the ego on lane src
+            const float *sp = nearw + 12 * (src / A) + (lane >> 4);
+            nf.px = sp[0]; nf.py = sp[4]; nf.tw = __float_as_uint(sp[8]);
+            nf.t0 = nf.t1 = nf.t2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (fetch && __ballot(near_listed(nf.tw))) near_issue(w, __builtin_amdgcn_readfirstlane(sh.mapw[src / A][2].x), lane, nf);
+        };
+        // the near-list records of the first two flagged egos are TOUCHED here, ahead of barrier A: one dword per lane, sixteen
+        // lanes per corner - every 128-byte line of a list's first 16 records holds the start of one - so that the real fetch behind
+        // the barrier finds them in the L2 (held in registers across the barrier, twelve per lane and ego, they cost the kernel its
+        // spill-free fit)
+        float touch0 = 0.0f, touch1 = 0.0f;
+        unsigned long long fo = 0ull;
+        if constexpr (MAG) {
+            fo = om & __ballot(a == 0 && valid);
+            auto touch = [&](int src) {
+                const uint32_t tw = __float_as_uint(nearw[12 * (src / A) + 8 + (lane >> 4)]);
+                const uint32_t rb0 = (uint32_t)__builtin_amdgcn_readfirstlane(sh.mapw[src / A][2].x);
+                const float *recs = w.cell_tri + 12 * (size_t)(rb0 + (near_listed(tw) ? tw - 1u : 0u));
+                return near_listed(tw) ? recs[12 * (lane & 15)] : 0.0f;
+            };
+            if (fo) touch0 = touch(__ffsll((long long)fo) - 1);
+            if (fo & (fo - 1)) touch1 = touch(__ffsll((long long)(fo & (fo - 1))) - 1);
+        }
         lds_barrier();                                       // A
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
@@ -2608,20 +2667,34 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             if (a == 0 && st.tl_violation) st.tl_violation[e] = tl ? 1 : 0;
         }
         // tde_state.magnitudes (get_info's "collision" / "offroad", :427-428) for the egos this step flagged: this judge has nothing
-        // left to do while the driver and judge C re-spawn the finished envs, and the rows of the step stay in buffer 0
-        // (ring_post: the rollout kernel's, unused in a one-step launch)
+        // left to do while the driver and judge C re-spawn the finished envs, and the rows of the step stay in buffer 0.  Every ego
+        // lane stores zeros first and the lane of a flagged ego its values when they are known (same lane, same address, program
+        // order).
         if constexpr (MAG) {
-            // (the map descriptors wait in LDS: kept in registers across the offroad test they cost the kernel its spill-free fit;
-            //  the lane's indices are formed AGAIN, from the hardware lane counter, so that nothing of the kernel's prologue has to
-            //  stay live through this section - the compiler otherwise parks those values in scratch memory for the whole launch,
-            //  and a launch with a private segment takes 1.3 us longer to dispatch)
-            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            const int64_t g2 = (int64_t)blockIdx.x * kWave + ln;
-            const int e2 = (int)(g2 / A);
-            const bool ego2 = (g2 % A) == 0 && e2 < st.B;
-            ego_magnitudes_of_wave<A, true>(cfg, w, [&](int src) { return map_from_lds(sh.mapw[src / A]); }, __ballot(ego2), sh.hit_mask, om,
-                                            &sh.a[0][0], &sh.b[0][0], ln, reinterpret_cast<float *>(sh.ring_post),
-                                            ego2 ? reinterpret_cast<float4 *>(st.magnitudes) + e2 : nullptr);
+            const bool ego = a == 0 && valid;
+            float *out_e = ego ? st.magnitudes + 4 * (int64_t)e : nullptr;
+            if (ego) *reinterpret_cast<float4 *>(out_e) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // (collision first: it runs out of LDS while the touched lines of the offroad part arrive)
+#ifndef TDE_X_NOCOLL
+            const unsigned long long hm = sh.hit_mask;
+            for (unsigned long long fc = hm & __ballot(ego); fc; fc &= fc - 1) {     // collision (rarely more than one trip)
+                const int src = __ffsll((long long)fc) - 1;
+                const float4 ea = sh.a[0][src], eb4 = sh.b[0][src];
+                const EgoBox eb{readlane_f(ea.x, 0), readlane_f(ea.y, 0), readlane_f(eb4.x, 0), readlane_f(eb4.y, 0), readlane_f(eb4.z, 0), readlane_f(eb4.w, 0)};
+                const float2 cm = ego_collision_mag_of(A, lane, eb, TileRows{&sh.a[0][src], &sh.b[0][src]}, reinterpret_cast<float *>(sh.ring_post));
+                if (lane == src) { out_e[1] = cm.x; out_e[2] = cm.y; }
+            }
+#endif
+            asm volatile("" :: "v"(touch0), "v"(touch1));            // (the touches complete here at the latest)
+#ifndef TDE_X_NOOFF                   // (timing experiments: WRONG results)
+            for (unsigned long long f = fo; f; f &= f - 1) {          // offroad
+                const int src = __ffsll((long long)f) - 1;
+                NearFetch nf;
+                corners_of(src, nf, true);
+                const float omag = near_finish<true>(cfg, w, map_from_lds(sh.mapw[src / A]), nf, lane);
+                if (lane == src) out_e[0] = omag;
+            }
+#endif
         }
     }
 }

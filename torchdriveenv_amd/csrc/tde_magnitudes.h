@@ -37,6 +37,10 @@ TDE_DEV void box_corners_ccw(float x, float y, float c, float s, float hl, float
     px[3] = (x + lx) + wx; py[3] = (y + ly) - wy;
 }
 
+template <int N> TDE_DEV float row_ror_f(float v)       // lane l of every 16-lane row receives the value of lane (l - N) mod 16 of its row
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
+}
 TDE_DEV float readlane_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 // (this wavefront's LDS stores are ordered before its later LDS loads: the LDS unit serves a wavefront's instructions in order;
 //  the fence keeps the compiler from moving them across)
@@ -244,33 +248,63 @@ TDE_DEV float2 ego_collision_mag_of(int A, int lane, const EgoBox &eb, R &&row, 
 // Lanes 16 c .. 16 c + 15 take corner c: the tile word, the first 16 records of its near list (the list's length rides in the
 // first record: fetched before it is known, the table ends with 16 spare records), the rest of a longer list, a minimum over the 16
 // lanes; a corner without a near list goes through point_mesh_d2_wave, all 64 lanes, one such corner at a time.
-template <bool LEAN = false>
-TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, const tde_map &m, const EgoBox &eb, int lane)
+// The pieces, so that a caller with time to fill (the three-role step kernel: the ego lanes fetch their corners' tile words beside
+// the offroad test, the record loads of a flagged ego are issued ahead of the barrier behind which the magnitudes are due) can
+// start them early: each piece of the chain tile word -> records is a round trip to HBM / the fabric for these rarely touched lines.
+// the tile_near word of the coarse tile a point lies in (0: no list - also for a point outside the grid, which the clamp would put
+// into a border tile it does not lie in)
+TDE_DEV uint32_t near_tile_word(const tde_world &w, const tde_map &m, float px, float py)
 {
-    const float thr = cfg.offroad_threshold, thr2 = thr2_of(cfg);
-    const float band = __builtin_sqrtf(thr2) + 0.04f;            // (the cells' lists cover threshold + 0.05: world.py GRID_MARGIN)
-    Corners k;
-    offroad_issue<false>(w, m, false, eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, k);   // (corner coordinates only)
-    const int c = lane >> 4, r = lane & 15;
-    const float px = TDE_SEL4(c, k.px0, k.px1, k.px2, k.px3), py = TDE_SEL4(c, k.py0, k.py1, k.py2, k.py3);
     const float fx = __builtin_amdgcn_fmed3f((px - m.ox) * m.inv_cell, 0.0f, (float)(m.nx - 1));
     const float fy = __builtin_amdgcn_fmed3f((py - m.oy) * m.inv_cell, 0.0f, (float)(m.ny - 1));
     const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
     const bool inside = px >= m.ox && py >= m.oy && px < m.ox + (float)m.nx * m.cell && py < m.oy + (float)m.ny * m.cell;
     uint32_t tw = 0u;
-    if (w.tile_near) tw = w.tile_near[(uint32_t)m.near_base + (iy / TDE_COARSE_CELLS) * ((uint32_t)m.nx / TDE_COARSE_CELLS) + ix / TDE_COARSE_CELLS];
-    if (!inside) tw = 0u;                                        // (clamped into a border tile it does not lie in)
-    const bool full = tw == 0xFFFFFFFFu, listed = tw != 0u && !full;
+    if (w.tile_near && inside) tw = w.tile_near[(uint32_t)m.near_base + (iy / TDE_COARSE_CELLS) * ((uint32_t)m.nx / TDE_COARSE_CELLS) + ix / TDE_COARSE_CELLS];
+    return tw;
+}
+
+// one ego's four corners in flight: lanes 16 c .. 16 c + 15 hold corner c's point, its tile word and record r = lane & 15 of its list
+struct NearFetch {
+    float px, py;
+    uint32_t tw;
+    float4 t0, t1, t2;
+};
+TDE_DEV bool near_full(uint32_t tw) { return tw == 0xFFFFFFFFu; }
+TDE_DEV bool near_listed(uint32_t tw) { return tw != 0u && tw != 0xFFFFFFFFu; }
+
+// fetch record r of the corner's near list (before its length is known: the table ends with 16 spare records)
+TDE_DEV void near_issue(const tde_world &w, int rec_base, int lane, NearFetch &nf)
+{
+    const int r = lane & 15;
+    const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)((uint32_t)rec_base + (near_listed(nf.tw) ? nf.tw - 1u : 0u));
+    nf.t0 = recs[3 * r]; nf.t1 = recs[3 * r + 1]; nf.t2 = recs[3 * r + 2];
+}
+
+// the magnitude from the fetched records: the rest of a list longer than 16, the minimum over the corner's 16 lanes, the scan for a
+// corner without a list, clamp(dist - threshold, 0), the sum over the corners in the CPU checker's order
+template <bool LEAN = false>
+TDE_DEV float near_finish(const tde_config &cfg, const tde_world &w, const tde_map &m, const NearFetch &nf, int lane)
+{
+    const float thr = cfg.offroad_threshold, thr2 = thr2_of(cfg);
+    const float band = __builtin_sqrtf(thr2) + 0.04f;            // (the cells' lists cover threshold + 0.05: world.py GRID_MARGIN)
+    const int c = lane >> 4, r = lane & 15;
+    const float px = nf.px, py = nf.py;
+    const bool full = near_full(nf.tw), listed = near_listed(nf.tw);
     float best = 3.0e38f;
     if (__ballot(listed)) {
-        const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)((uint32_t)m.rec_base + (listed ? tw - 1u : 0u));
-        const float4 t0 = recs[3 * r], t1 = recs[3 * r + 1], t2 = recs[3 * r + 2];
-        const int n = __shfl(__float_as_int(t2.y), lane & 48);      // the list's length, from the lane that holds its first record
-        if (listed && r < n) best = point_tri_d2_words(px, py, t0, t1, t2);
-        for (int q = 16; __ballot(listed && q < n); q += 16)         // (a list of more than 16 triangles: rare)
-            if (listed && q + r < n) best = fminf(best, point_tri_d2_packed(px, py, recs + 3 * (size_t)(q + r)));
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o));     // minimum over the corner's 16 lanes
+        // the list's length, from the lane that holds its first record (four v_readlane + selects: a ds_bpermute is an LDS round trip)
+        const int n = TDE_SEL4(c, __builtin_amdgcn_readlane(__float_as_int(nf.t2.y), 0), __builtin_amdgcn_readlane(__float_as_int(nf.t2.y), 16),
+                               __builtin_amdgcn_readlane(__float_as_int(nf.t2.y), 32), __builtin_amdgcn_readlane(__float_as_int(nf.t2.y), 48));
+        if (listed && r < n) best = point_tri_d2_words(px, py, nf.t0, nf.t1, nf.t2);
+        if (__ballot(listed && 16 < n)) {                            // (a list of more than 16 triangles: rare)
+            const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)((uint32_t)m.rec_base + (listed ? nf.tw - 1u : 0u));
+            for (int q = 16; __ballot(listed && q < n); q += 16)
+                if (listed && q + r < n) best = fminf(best, point_tri_d2_packed(px, py, recs + 3 * (size_t)(q + r)));
+        }
+        // minimum over the corner's 16 lanes = one DPP row: rotations by 8, 4, 2, 1 (a minimum of the same values)
+        best = fminf(best, row_ror_f<8>(best)); best = fminf(best, row_ror_f<4>(best));
+        best = fminf(best, row_ror_f<2>(best)); best = fminf(best, row_ror_f<1>(best));
     }
     float d2c = full ? -1.0f : best;
     const unsigned long long scan = __ballot(!full && !listed);
@@ -278,11 +312,7 @@ TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, co
     for (int cc = 0; cc < 4; ++cc) {
         if (!((scan >> (16 * cc)) & 1ull)) continue;                 // (wave-uniform)
         const float sx = readlane_f(px, 16 * cc), sy = readlane_f(py, 16 * cc);
-#ifndef TDE_X_NOSCAN
         const float d2 = LEAN ? point_mesh_d2_scan_lean(w, m, sx, sy, band, lane) : point_mesh_d2_wave(w, m, sx, sy, band * band, lane);
-#else
-        const float d2 = sx + sy;
-#endif
         if (c == cc) d2c = d2;
     }
     float term = 0.0f;
@@ -294,6 +324,20 @@ TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, co
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) omag = omag + readlane_f(term, 16 * cc);
     return omag;
+}
+
+template <bool LEAN = false>
+TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, const tde_map &m, const EgoBox &eb, int lane)
+{
+    Corners k;
+    offroad_issue<false>(w, m, false, eb.x, eb.y, eb.c, eb.s, eb.hl, eb.hw, k);   // (corner coordinates only)
+    const int c = lane >> 4;
+    NearFetch nf;
+    nf.px = TDE_SEL4(c, k.px0, k.px1, k.px2, k.px3); nf.py = TDE_SEL4(c, k.py0, k.py1, k.py2, k.py3);
+    nf.tw = near_tile_word(w, m, nf.px, nf.py);
+    nf.t0 = nf.t1 = nf.t2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (__ballot(near_listed(nf.tw))) near_issue(w, m.rec_base, lane, nf);
+    return near_finish<LEAN>(cfg, w, m, nf, lane);
 }
 
 }  // namespace tde
