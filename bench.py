@@ -342,16 +342,60 @@ def python_boundary(B=8192, A=16):
     return out
 
 
+FIXED_MOD = 1 << 48                  # check sums are exact integers below 2^53: they travel as float64 through all_gather
+
+
+def fixed_check(cfg, dw, B, A, actions, dev):
+    """fresh state, reset, ONE rollout over the CH action rows: (sum of the reward bit patterns, sum of the done bytes, sum of the
+    final x bit patterns), each modulo 2^48 - exact and independent of the order of summation, so a shard's values can be compared
+    with the same sums over its columns of the unsharded batch"""
+    import torch
+
+    from torchdriveenv_amd import ops
+    from torchdriveenv_amd.state import EnvState
+
+    st = EnvState(B, A, device=dev, with_info=False)
+    ops.env_reset(cfg, dw, st)
+    reward, done = ops.env_rollout(cfg, dw, st, actions)
+    torch.cuda.synchronize()
+    return fixed_sums(reward, done, st["x"])
+
+
+def fixed_sums(reward, done, x):
+    import torch
+
+    bits = lambda t: int(t.contiguous().view(torch.int32).to(torch.int64).sum().item()) % FIXED_MOD   # noqa: E731
+    return [bits(reward), int(done.to(torch.int64).sum().item()) % FIXED_MOD, bits(x)]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def spawn_ranks(n):
+def bench_world(kind, A):
+    """the benchmark's static tables, built ONCE per machine (world.cached_world: the first caller builds and saves them, the other
+    ranks load the file) - N ranks that each build the grid index of a town side by side on the same host cores spend seconds
+    there before their first launch.  Returns (world, "built" | "loaded", seconds)."""
+    from torchdriveenv_amd.synth import synthetic_town, synthetic_world
+    from torchdriveenv_amd.world import cached_world
+
+    t0 = time.perf_counter()
+    if kind == "town":
+        w, how = cached_world(f"bench-town-A{A}", lambda: synthetic_town(n_scn=256, A=A, seed=0))
+    else:
+        w, how = cached_world(f"bench-junctions-A{A}", lambda: synthetic_world(n_scn=64, A=A, seed=0, n_maps=4))
+    return w, how, time.perf_counter() - t0
+
+
+def spawn_ranks(n, world_kind=None, A=None):
     """`python bench.py --gpus N` without a launcher: start one fresh child process per rank.  This process has not
-    touched the GPU (no HIP call, no torch import), so the children are ordinary new processes; rank 0's JSON line
-    passes through on stdout."""
+    touched the GPU (no HIP call: the grid-index build it does for the ranks - bench_world - is host code), so the
+    children are ordinary new processes; rank 0's JSON line passes through on stdout."""
+    if world_kind is not None:
+        _, how, dt = bench_world(world_kind, A)        # the ranks find the file: none of them builds
+        print(f"[bench] parent: world tables {how} in {dt:.2f} s", file=sys.stderr, flush=True)
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
     for r in range(n):
@@ -417,6 +461,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still create the process group (world size 1) and run the barrier, the MAX reduce and "
                          "the host gather through it - how the RCCL path (--backend nccl) is exercised on a one-GPU box")
+    ap.add_argument("--check-fixed", action="store_true",
+                    help="after the timed region (not timed): a fresh reset of this rank's shard and ONE 250-step rollout from its "
+                         "action rows, reported as exact integer check sums per rank under check[].fixed - a function of (seed, global "
+                         "env index, actions) alone, so the N shards can be held against the unsharded batch (tests/test_gpu_sharded_bench.py)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
                     help="rollout: up to 250 steps per C-ABI call (default); step: one C-ABI call per step from Python")
     ap.add_argument("--binding", default="ext", choices=["ext", "ctypes"],
@@ -435,9 +483,10 @@ def main():
                     help="force a form of the one-step kernel (A/B runs; default: the library's choice by batch size)")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size == 1 and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus))               # before anything touches the GPU
+        sys.exit(spawn_ranks(args.gpus, args.world, CONFIGS[args.config]["agents"]))   # before anything touches the GPU
     if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
 
@@ -483,10 +532,7 @@ def main():
     C = CONFIGS[args.config]
     B, A = (args.envs or C["envs"]), C["agents"]
     n = world_size
-    if args.world == "town":
-        world = synthetic_town(n_scn=256, A=A, seed=0)
-    else:
-        world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)      # same tables on every GPU (replicated)
+    world, world_how, world_s = bench_world(args.world, A)            # same tables on every GPU (replicated); built once per machine
     flags = 0 if args.config == 2 else _abi.F_ALL
     base_cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=flags)   # shipped reward constants
     cfg, nb = shard_config(base_cfg, rank, n, B * n)                  # env_base = rank * B: shard of the global batch
@@ -559,6 +605,7 @@ def main():
 
     # ---- un-timed: the CLI's warm-up, at least one full-length launch, at least MIN_WARM_S of launches --------------
     t0 = time.perf_counter()
+    startup_s = t0 - t_start                        # process start (after argument parsing) -> first launch: imports, world, uploads
     run(max(args.warmup, CH))
     torch.cuda.synchronize()
     warm_steps = max(args.warmup, CH)
@@ -603,24 +650,33 @@ def main():
     dev_ms = marks[0].elapsed_time(ev_end)
     if streams:
         ops.fork_streams(streams, dev)
+    built = 1.0 if world_how == "built" else 0.0
     if dist is not None:
-        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([wall, dev_ms, startup_s, world_s, built], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(tt[0]), float(tt[1])
+        wall, dev_ms, startup_s, world_s = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
+        ts = torch.tensor([built], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        built = float(ts[0])
 
     # sanity of what was just computed (not timed): finite rewards, episodes progressing
     chk = dict(reward_sum=float((st["reward"] if stepwise else reward).double().sum()),
                done_frac=float(((st["terminated"] | st["truncated"]) if stepwise else (done > 0)).float().mean()),
                episodes=int(st["episode"].max()))
     assert np.isfinite(chk["reward_sum"])
+    fixed = [0.0, 0.0, 0.0]
+    if args.check_fixed:
+        fixed = fixed_check(cfg, dw, B, A, actions, dev)
+        chk["fixed"] = dict(reward_bits=int(fixed[0]), done_sum=int(fixed[1]), x_bits=int(fixed[2]))
     if dist is not None:
         # the "host gather" of per-shard results: a few numbers per rank through all_gather (no pickling, so it works
         # the same over RCCL and gloo), assembled on the host
-        mine = torch.tensor([chk["reward_sum"], chk["done_frac"], float(chk["episodes"]), float(cfg.env_base)],
+        mine = torch.tensor([chk["reward_sum"], chk["done_frac"], float(chk["episodes"]), float(cfg.env_base)] + [float(v) for v in fixed],
                             dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         parts = [torch.empty_like(mine) for _ in range(world_size)]
         dist.all_gather(parts, mine)
-        chk = [dict(rank=i, env_base=int(p[3]), reward_sum=float(p[0]), done_frac=float(p[1]), episodes=int(p[2]))
+        chk = [dict(rank=i, env_base=int(p[3]), reward_sum=float(p[0]), done_frac=float(p[1]), episodes=int(p[2]),
+                    **({"fixed": dict(reward_bits=int(p[4]), done_sum=int(p[5]), x_bits=int(p[6]))} if args.check_fixed else {}))
                for i, p in enumerate(parts)]
     if rank == 0:
         bpes = bytes_per_env_step(args.config, A)
@@ -714,6 +770,9 @@ def main():
                                    "us_per_step is taken from the first event to an event recorded after all sub-batch "
                                    "streams were joined")},
             "check": chk,
+            # rank start-up (MAX over ranks): process start -> first launch, and the part of it spent on the world tables; the
+            # tables are built once per machine (by the parent of `--gpus N`, else by the first rank to ask) and loaded by the rest
+            "startup": {"to_first_launch_s": startup_s, "world_tables_s": world_s, "ranks_that_built_the_world": int(built)},
         }
         if n == 1 and args.config == 3 and not stepwise and not args.no_secondary and not args.force_dist:
             out["secondary"] = secondary(dev)

@@ -171,8 +171,11 @@ def patch_step3(s):
             "        }\n        tde_mark(&stl, 16);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 17);\n        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_O2);\n")
     k = sub(k, "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n",
             "        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }\n        tde_mark(&stl, 18);\n")
-    k = sub(k, "reward_psi_term(cold, lpsi, rc.x);\n        lds_barrier();                                       // A\n",
-            "reward_psi_term(cold, lpsi, rc.x);\n        tde_mark(&stl, 20);\n        lds_barrier();                                       // A\n        tde_mark(&stl, 19);\n        tde_flush(16, 21);\n")
+    # (round 5: the magnitudes section - slot 21 = from barrier A to its end; slot 20 now includes the pre-A touches)
+    k = sub(k, "        lds_barrier();                                       // A\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        if (valid) {\n            st.offroad[g]",
+            "        tde_mark(&stl, 20);\n        lds_barrier();                                       // A\n        tde_mark(&stl, 19);\n        unsigned long long term_m, trunc_m;\n        const unsigned long long dn = done_of(k, term_m, trunc_m);\n        if (valid) {\n            st.offroad[g]")
+    k = sub(k, "                if (lane == src) out_e[0] = omag;\n            }\n#endif\n        }\n    }\n}\n",
+            "                if (lane == src) out_e[0] = omag;\n            }\n#endif\n        }\n        tde_mark(&stl, 21);\n        tde_flush(16, 22);\n    }\n}\n")
     k = sub(k, "        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);", "        tde_flush(8, 13);\n        if (!valid) return;\n        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);")
     return s[:a] + k + s[b:]
 

@@ -38,12 +38,19 @@ def host_gather(obj, dst=0):
 # ------------------------------------------------------------------------------------------------------------------
 def _shard_worker(rank, n_shards, device, cfg, world, total, kw, conn, shm):
     """one shard: its own process, its own GPU context, its own BatchedWaypointEnv with env_base = first global env"""
+    import time
+
     import numpy as np
     import torch
 
     from .env import BatchedWaypointEnv
 
     try:
+        t0 = time.perf_counter()
+        if isinstance(world, str):                        # the tables the parent saved once (World.save): a read of the page cache
+            from .world import World
+            world = World.load(world)
+        t_world = time.perf_counter() - t0
         torch.cuda.set_device(device)
         lo, hi = shard_range(rank, n_shards, total)
         env = BatchedWaypointEnv(cfg, world, num_envs=hi - lo, device=f"cuda:{device}", env_base=lo, **kw)
@@ -55,7 +62,7 @@ def _shard_worker(rank, n_shards, device, cfg, world, total, kw, conn, shm):
         pinned = page_lock(mine)
         venv = env.as_vec_env(copy_obs=False, obs_buffers=[mine])
         rew_all, done_all = shm["reward"].numpy(), shm["done"].numpy()
-        conn.send(("ready", lo, hi, pinned))
+        conn.send(("ready", lo, hi, pinned, t_world, time.perf_counter() - t0))
         while True:
             cmd, arg = conn.recv()
             if cmd == "reset":
@@ -131,20 +138,51 @@ class ShardedBatchedEnv:
                      "reward": torch.zeros(self.num_envs, dtype=torch.float32).share_memory_(),
                      "done": torch.zeros(self.num_envs, dtype=torch.bool).share_memory_(),
                      "action": torch.zeros((self.num_envs, 2), dtype=torch.float32).share_memory_()}
+        # The static tables reach the workers through ONE file the parent writes (World.save) instead of a pickle per worker: a
+        # town's tables are ~170 MB, and a World that every shard assembles for itself costs seconds of grid-index build per
+        # process on the same host cores before the first launch
+        import os
+        import tempfile
+        import time
+
+        from .world import World
+        t0 = time.perf_counter()
+        world_arg, tmp = world, None
+        if isinstance(world, World):
+            shm_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            fd, tmp = tempfile.mkstemp(prefix="tde_world_", suffix=".npz", dir=shm_dir)
+            os.close(fd)
+            world.save(tmp)
+            world_arg = tmp
+        t_save = time.perf_counter() - t0
         ctx = mp.get_context("spawn")
         self._conns, self._procs, self.ranges = [], [], []
-        for rank in range(self.n_shards):
-            parent, child = ctx.Pipe()
-            p = ctx.Process(target=_shard_worker, args=(rank, self.n_shards, self.devices[rank], cfg, world,
-                                                        self.num_envs, env_kw, child, self._shm), daemon=True)
-            p.start()
-            self._conns.append(parent)
-            self._procs.append(p)
-        self.pinned = []
-        for c in self._conns:
-            tag, lo, hi, pinned = self._recv(c)
-            self.ranges.append((lo, hi))
-            self.pinned.append(bool(pinned))
+        try:
+            for rank in range(self.n_shards):
+                parent, child = ctx.Pipe()
+                p = ctx.Process(target=_shard_worker, args=(rank, self.n_shards, self.devices[rank], cfg, world_arg,
+                                                            self.num_envs, env_kw, child, self._shm), daemon=True)
+                p.start()
+                self._conns.append(parent)
+                self._procs.append(p)
+            self.pinned = []
+            loads, readies = [], []
+            for c in self._conns:
+                tag, lo, hi, pinned, t_world, t_ready = self._recv(c)
+                self.ranges.append((lo, hi))
+                self.pinned.append(bool(pinned))
+                loads.append(t_world)
+                readies.append(t_ready)
+        finally:
+            if tmp is not None:
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
+        # start-up, seconds: the parent's one save, the slowest worker's load of it, the slowest worker from its first line to "ready"
+        self.startup = {"world_save_s": t_save, "world_load_s_max": max(loads), "worker_ready_s_max": max(readies),
+                        "total_s": time.perf_counter() - t0}
+        self.last_step_timing = None
         self._np = np
 
     @staticmethod
@@ -176,15 +214,25 @@ class ShardedBatchedEnv:
     def step(self, actions):
         from .env import LazyInfos
 
+        import time
+
         np = self._np
+        t0 = time.perf_counter()
         self._shm["action"].numpy()[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 2)
         parts = self._all("step")
+        t1 = time.perf_counter()
         cols = {k: np.concatenate([p[0][k] for p in parts]) for k in parts[0][0]}
         terminal = {}
         for p in parts:
             terminal.update(p[1])
-        return (self._obs(), self._shm["reward"].numpy().copy(), self._shm["done"].numpy().copy(),
-                LazyInfos(self.num_envs, cols, terminal))
+        out = (self._obs(), self._shm["reward"].numpy().copy(), self._shm["done"].numpy().copy(),
+               LazyInfos(self.num_envs, cols, terminal))
+        t2 = time.perf_counter()
+        # step_s: until every shard has stepped and written its slices of the shared buffers (the observations' device-to-host
+        # copies land there directly); gather_s: what the parent then does on the host - info columns, reward / done copies and,
+        # with copy_obs, the copy of the gathered observations
+        self.last_step_timing = {"step_s": t1 - t0, "gather_s": t2 - t1, "obs_bytes": int(self._shm["obs"].numel() * self._shm["obs"].element_size())}
+        return out
 
     def gather_state(self):
         """every shard's state arrays concatenated in global env order (tests / checkpoints)"""

@@ -280,6 +280,45 @@ class World:
         return cls(arrays, ints, None if thr < 0 else thr)
 
 
+def cached_world(key, builder, cache_dir=None):
+    """`builder()` -> World, built ONCE per machine for a given `key` and shared through a file: the first caller (a file lock
+    decides) builds and saves it (World.save), everybody else - the other ranks of a multi-GPU job, whose grid-index builds would
+    otherwise run side by side on the same host cores before the first launch - loads the tables (World.load: a read of the page
+    cache).  The key is extended by the ABI version and the modification times of the library and of the Python that assembles
+    worlds, so a rebuilt package never meets a stale file.  Returns (world, "built" | "loaded")."""
+    import fcntl
+    import hashlib
+    import os
+    import tempfile
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    stamp = [str(_abi.TDE_ABI_VERSION)]
+    for f in ("libtde_hip.so", "world.py", "synth.py", "_abi.py"):
+        try:
+            stamp.append(str(os.stat(os.path.join(here, f)).st_mtime_ns))
+        except OSError:
+            stamp.append("-")
+    h = hashlib.sha1(("|".join([str(key)] + stamp)).encode()).hexdigest()[:20]
+    d = cache_dir or os.environ.get("TDE_WORLD_CACHE") or os.path.join(tempfile.gettempdir(), f"tde_worlds_{os.getuid()}")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, f"world_{h}.npz")
+    with open(path + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(path):
+                try:
+                    return World.load(path), "loaded"
+                except Exception:
+                    os.unlink(path)                         # (a torn or foreign file: rebuild)
+            w = builder()
+            tmp = path + f".tmp{os.getpid()}"
+            w.save(tmp)
+            os.replace(tmp, path)
+            return w, "built"
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def effective_offroad_distance(threshold, squared=False):
     """the distance a box corner may be from the mesh: `threshold`, or sqrt(threshold) when the threshold is applied to
     the SQUARED distance (tde_config.offroad_threshold_squared)"""
