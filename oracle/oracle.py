@@ -56,8 +56,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        # TDE_ORACLE_LIB: a sanitizer build of the same source (`make -C oracle san`; tests/test_sanitizers.py)
+        path = os.environ.get("TDE_ORACLE_LIB")
+        if not path:
+            build()
+            path = _LIB_PATH
+        L = C.CDLL(path)
         f32p = C.POINTER(C.c_float)
         L.tde_oracle_sincosf.argtypes = [C.c_float, f32p, f32p]
         L.tde_oracle_sincosf.restype = None

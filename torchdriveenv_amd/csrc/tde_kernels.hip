@@ -3028,8 +3028,10 @@ static int bad(const char *msg)
 }
 
 static bool pow2_le64(int A) { return A >= 1 && A <= TDE_MAX_AGENTS && (A & (A - 1)) == 0; }
-// (up to 64 slots an env lives inside one wavefront and every kernel form applies; 128 = TDE_MAX_AGENTS: the one-role kernels'
-//  generic forms only - TDE_DISPATCH_A128 - and a rollout is a sequence of one-step launches)
+// (up to 64 slots an env lives inside one wavefront and every kernel form applies; 128 = TDE_MAX_AGENTS: an env spans two
+//  wavefronts - tde_env_step runs the one-role kernel's generic form (TDE_DISPATCH_A128), tde_env_rollout the persistent
+//  env_rollout_wide_kernel (two roles, four wavefronts per env) at every batch size, the one-role persistent kernel only under
+//  tde_kernel_override(1, 0); forced forms 2 and 3 do not exist at 128 slots and leave the choice as it is)
 
 #define TDE_DISPATCH_A(A, ...)                                  \
     switch (A) {                                                \

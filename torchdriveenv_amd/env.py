@@ -174,7 +174,7 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
                 meshes.append(corridor_mesh(polylines, width=road_width))
         if len(agents) > agents_per_env - 1:
             # the reference assembles up to ~100 agents per env (gym_env.py:216-237); an env here has agents_per_env slots
-            # (a power of two <= TDE_MAX_AGENTS = 64): the scenario's own agents come first, what does not fit is dropped - loudly
+            # (a power of two <= TDE_MAX_AGENTS = 128): the scenario's own agents come first, what does not fit is dropped - loudly
             warnings.warn(f"scenario {i}: {len(agents)} non-ego agents but only {agents_per_env - 1} NPC slots "
                           f"(agents_per_env={agents_per_env}): the last {len(agents) - (agents_per_env - 1)} are dropped; "
                           f"raise agents_per_env (a power of two, at most {_abi.TDE_MAX_AGENTS})", stacklevel=2)

@@ -93,6 +93,36 @@ def pitch_cells(a, nx, ny):
 SUB = 4                  # a MIXED cell carries SUB x SUB sub-cell classes (TDE_CELL_SUB)
 
 
+_GRID_LIB = None
+
+
+def _grid_lib():
+    """the library that holds tde_grid_build / tde_grid_free: libtde_hip.so - or, under TDE_GRID_LIB, a host-compiler build of
+    the same source (csrc/tde_gridbuild.h through oracle/grid_host.cpp) with AddressSanitizer / UBSan in it
+    (`make -C oracle san`; tests/test_sanitizers.py).  The tables do not depend on which one built them."""
+    global _GRID_LIB
+    import ctypes as C
+    import os
+
+    from . import _lib
+
+    path = os.environ.get("TDE_GRID_LIB")
+    if not path:
+        return _lib.load()
+    if _GRID_LIB is None:
+        L = C.CDLL(path)
+        if L.tde_abi_version() != _abi.TDE_ABI_VERSION:
+            raise _lib.TdeError(f"{path}: ABI {L.tde_abi_version()}, expected {_abi.TDE_ABI_VERSION}")
+        L.tde_last_error.restype = C.c_char_p
+        L.tde_grid_build.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                     C.POINTER(C.POINTER(_abi.TdeGrid))]
+        L.tde_grid_build.restype = C.c_int
+        L.tde_grid_free.argtypes = [C.POINTER(_abi.TdeGrid)]
+        L.tde_grid_free.restype = None
+        _GRID_LIB = L
+    return _GRID_LIB
+
+
 NEAR_RANGE = 2.0         # metres beyond the threshold the coarse tiles carry a near list for (tde_world.tile_near)
 
 
@@ -112,11 +142,13 @@ def build_grid_index(tri32, threshold=0.5, cell=0.5, margin=GRID_MARGIN, n_threa
 
     from . import _lib
 
-    L = _lib.load()
+    L = _grid_lib()
     tri32 = np.ascontiguousarray(np.asarray(tri32, dtype=np.float32).reshape(-1, 6))
     gp = C.POINTER(_abi.TdeGrid)()
-    _lib.check(L.tde_grid_build(tri32.ctypes.data, len(tri32), float(threshold), float(cell), float(margin), float(near_range),
-                                int(n_threads), C.byref(gp)), "tde_grid_build")
+    rc = L.tde_grid_build(tri32.ctypes.data, len(tri32), float(threshold), float(cell), float(margin), float(near_range),
+                          int(n_threads), C.byref(gp))
+    if rc != 0:
+        raise _lib.TdeError("tde_grid_build: " + (L.tde_last_error().decode() or f"error {rc}"))
     try:
         g = gp.contents
         n = g.nx * g.ny
