@@ -551,9 +551,7 @@ def main():
     done = torch.empty((CH, B), dtype=torch.uint8, device=dev)
     img = ops.render_ego(cfg, dw, st) if args.config == 5 else None
     handle = None
-    if stepwise and args.binding == "ext":
-        import ctypes
-
+    if args.binding == "ext":                       # every launch of the timed region goes through the PyTorch-ROCm extension
         from torchdriveenv_amd import _ext
         handle = _ext.env_handle(cfg, dw, st)
     cfg_flags = int(cfg.flags)
@@ -570,7 +568,10 @@ def main():
     def launch(k, row):
         """k consecutive timesteps (k <= CH); `row` = first row of the action buffer to use"""
         if not stepwise:
-            ops.env_rollout(cfg, dw, st, actions[:k], reward[:k], done[:k])
+            if handle is not None:
+                handle.rollout(actions[:k], reward[:k], done[:k], cfg_flags)
+            else:
+                ops.env_rollout(cfg, dw, st, actions[:k], reward[:k], done[:k])
             return
         if streams:                                 # config 5 as sub-batches on their own streams: one call per timestep
             for i in range(k):
@@ -691,11 +692,13 @@ def main():
         elif stepwise:
             trio = st["slot_cache"] is not None and A in (8, 16, 32) and (
                 args.step_kernel == "trio" or (args.step_kernel is None and B * A <= 131072))
-            kernel = f"tde::env_step_trio_kernel<{A}, false, false>" if trio else f"tde::env_step_kernel<{A}, false, false>"
+            kernel = f"tde::env_step_trio_kernel<{A}, false, false, false>" if trio else f"tde::env_step_kernel<{A}, false, false>"
         else:
             team = {"solo": "", "duo": "_duo", "trio": "_trio"}.get(
                 args.rollout_kernel, "_trio" if A in (8, 16, 32) else "_duo")
-            kernel = f"tde::env_rollout{team}_kernel<{A}, false>"
+            # template arguments: <A, LIGHTS, BIG> for the two- / three-role kernels (BIG = large-grid world), <A, LIGHTS> for the one-role one
+            big = "true" if args.world == "town" else "false"
+            kernel = f"tde::env_rollout{team}_kernel<{A}, false>" if team == "" else f"tde::env_rollout{team}_kernel<{A}, false, {big}>"
         # per-step-equivalent durations of the timed launches (a launch of k steps: its duration / k * spl)
         per = sorted(d / k * spl for d, k in zip(dur_us, lens)) if not stepwise else sorted(d / k for d, k in zip(dur_us, lens))
         kern_us = sum(dur_us) / max(1, sum(lens)) * spl               # average duration per launch of `spl` steps
@@ -745,7 +748,7 @@ def main():
                                    (" [town map: 1 km^2, 5.7e4 triangles, 256 scenarios]" if args.world == "town" else ""),
                        "world": args.world,
                        "envs_per_gpu": B, "agents_per_env": A, "global_envs": B * n, "mode": args.mode,
-                       "binding": (args.binding if stepwise else "ctypes"),
+                       "binding": args.binding,
                        "streams": max(1, n_streams), "steps_per_call": spl, "timed_steps": total, "untimed_warmup_steps": warm_steps + CH,
                        "sharding": f"{n} contiguous shard(s) of one global batch (env_base = rank * {B}), "
                                    "no data-path collective",

@@ -1834,10 +1834,27 @@ template <int N> TDE_DEV void dummy_valu(float seed)
 #define TDE_PRIO_C 0
 #define TDE_PRIO_O 1
 #endif
+// TDE_ROLLOUT_CONST_ARGS (A/B builds only: one set of arguments per process, no two rollouts in flight): the four argument structs
+// in a __constant__ block instead of ~650 bytes of kernel arguments - the experiment of VERDICT r4 item 6 (do the SGPR spills and the
+// LDS copy of the cold arguments go away?); profiles/r05_c_ab_rollout_const_args.txt
+#ifndef TDE_ROLLOUT_CONST_ARGS
+#define TDE_ROLLOUT_CONST_ARGS 0
+#endif
+struct RolloutArgs { tde_config cfg; tde_world w; tde_state st; tde_rollout ro; };
+#if TDE_ROLLOUT_CONST_ARGS
+__constant__ RolloutArgs g_rollout_args;
+#endif
 template <int A, bool LIGHTS, bool BIG>
-__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_rollout_trio_kernel(tde_config cfg, tde_world w, tde_state st,
-                                                                    tde_rollout ro)
+__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_rollout_trio_kernel(
+#if TDE_ROLLOUT_CONST_ARGS
+    int unused_)
 {
+    const tde_config &cfg = g_rollout_args.cfg; const tde_world &w = g_rollout_args.w; const tde_state &st = g_rollout_args.st;
+    const tde_rollout &ro = g_rollout_args.ro;
+#else
+    tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
+{
+#endif
     __shared__ DuoShared sh;
     __shared__ Cold cold;
     const int lane = threadIdx.x & (kWave - 1);
@@ -3326,7 +3343,16 @@ static int rollout_launch(const tde_config *cfg, const tde_world *world, const t
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     const bool big = (world->hints & TDE_WORLD_LARGE_GRID) != 0;      // corner classes from the 2-bit class map (tde_abi.h)
     if (team == 3) {
+#if TDE_ROLLOUT_CONST_ARGS
+        {
+            tde::RolloutArgs ra{*cfg, *world, *st, *ro};
+            hipError_t ec = hipMemcpyToSymbolAsync(HIP_SYMBOL(tde::g_rollout_args), &ra, sizeof(ra), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+            if (ec != hipSuccess) return fail("tde_env_rollout (argument block)", ec);
+        }
+#define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(0)
+#else
 #define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
+#endif
 #define TDE_LAUNCH_TRIO(AA)                                                                          \
     if (lights) { if (big) TDE_LAUNCH_TRIO2(AA, true, true); else TDE_LAUNCH_TRIO2(AA, true, false); } \
     else { if (big) TDE_LAUNCH_TRIO2(AA, false, true); else TDE_LAUNCH_TRIO2(AA, false, false); }
