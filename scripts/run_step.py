@@ -16,7 +16,8 @@ world = synthetic_town(n_scn=256, A=A, seed=0) if TOWN else synthetic_world(n_sc
 dw = world.to_device(dev)
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
 _lib.kernel_override(step=kern if kern in ("solo", "trio") else None)
-st = EnvState(B, A, device=dev, with_info=False)
+FULL = os.environ.get("TDE_STEP_OUTPUTS", "")             # "" bare, "full" = info / done bits / episode stats / obs, "mag" = + magnitudes
+st = EnvState(B, A, device=dev, with_info=bool(FULL), with_obs=bool(FULL), with_magnitudes=(FULL == "mag"))
 ops.env_reset(cfg, dw, st)
 g = torch.Generator().manual_seed(0)
 acts = torch.stack([torch.rand(250, B, generator=g) * 2 - 1, torch.rand(250, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)
@@ -24,4 +25,4 @@ ops.env_rollout(cfg, dw, st, acts)                      # a steady-state mix of 
 for i in range(n):
     ops.env_step(cfg, dw, st, action=acts[i % 250])
 torch.cuda.synchronize()
-print("ok", n, "steps", kern)
+print("ok", n, "steps", kern, FULL)

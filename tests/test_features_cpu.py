@@ -268,3 +268,25 @@ def test_lazy_terminal_mapping_builds_entries_on_demand():
     assert infos[2]["episode"]["l"] == 7 and "terminal_observation" not in infos[3] and infos[2] is infos[2]
     no_stats = LazyTerminal(idx, obs, None, None, 0.0)
     assert "episode" not in no_stats[2]
+
+
+def test_single_agent_wrapper_transforms_mirror_the_reference():
+    """SingleAgentWrapper.transform_out / transform_in (ref gym_env.py:463-481): tensors lose / gain the two leading singleton
+    dimensions (and go to the CPU on the way out), dicts are mapped entry by entry, numpy arrays go through torch, anything else
+    passes through - on a stand-in env (no GPU involved)"""
+    import numpy as np
+    import torch
+
+    from torchdriveenv_amd.env import SingleAgentWrapper
+
+    class Env:
+        torch_device = torch.device("cpu")
+
+    w = SingleAgentWrapper(Env())
+    t = torch.arange(6.0).reshape(1, 1, 2, 3)
+    out = w.transform_out({"a": t, "b": np.zeros((1, 1, 4), np.uint8), "c": 3.5, "d": {"e": torch.ones(1, 1)}})
+    assert out["a"].shape == (2, 3) and out["b"].shape == (4,) and out["b"].dtype == np.uint8 and out["c"] == 3.5
+    assert out["d"]["e"].dim() == 0 and out["d"]["e"].device.type == "cpu"
+    back = w.transform_in({"a": out["a"], "c": 3.5})
+    assert back["a"].shape == (1, 1, 2, 3) and torch.equal(back["a"], t) and back["c"] == 3.5
+    assert w.torch_device == torch.device("cpu")           # attribute access falls through to the wrapped env

@@ -384,3 +384,43 @@ def test_configs3_partitioning_at_full_size_on_one_gpu():
     hr, hd = oracle.env_rollout(cfg, world, hs, np.ascontiguousarray(actions[:, lo:lo + SUB].numpy()))
     assert np.array_equal(hr.view(np.uint32), fr[:, lo:lo + SUB].view(np.uint32)) and np.array_equal(hd, fd[:, lo:lo + SUB])
     assert (fd & 1).sum() > 0 and fep.max() >= 2
+
+
+@pytest.mark.parametrize("A,world_kw", [(16, dict(n_scn=8, A=16, seed=0, n_maps=2)), (8, dict(n_scn=8, A=8, seed=1, n_maps=2))])
+def test_npc_first_step_flag_step_and_rollout_match_the_oracle(A, world_kw):
+    """TDE_F_NPC_FIRST_STEP (the NPC controller acts on the first step of an episode too, as the reference's NPCs do,
+    gym_env.py:285-294): tde_env_step and tde_env_rollout route to their one-role kernels, which evaluate the controller on
+    every step - bit for bit the oracle under the same flag through re-spawns, and NOT the default rule's trajectories"""
+    from tests.test_gpu_parity import assert_state_equal, dev
+
+    world = synthetic_world(**world_kw)
+    dw = world.to_device(DEV)
+    B, K = 192, 90
+    flags = _abi.F_ALL | _abi.F_NPC_FIRST_STEP
+    cfg = _abi.default_config(seed=14, flags=flags, max_steps=30, distance_cutoff=0.25)
+    rng = np.random.default_rng(1)
+    acts = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+    # closed loop
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    for t in range(K):
+        hs["action"][...] = acts[t]
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds, action=dev(acts[t]))
+    assert_state_equal(hs.host(), ds.host(), "first-step flag, closed loop")
+    assert int(hs["episode"].max()) > 2
+    # rollout
+    hr, dr = EnvState(B, A), EnvState(B, A, device=DEV)
+    oracle.env_reset(cfg, world, hr)
+    ops.env_reset(cfg, dw, dr)
+    rew_o, done_o = oracle.env_rollout(cfg, world, hr, acts)
+    rew_d, done_d = ops.env_rollout(cfg, dw, dr, dev(acts))
+    assert np.array_equal(rew_d.cpu().numpy().view(np.uint32), rew_o.view(np.uint32)) and np.array_equal(done_d.cpu().numpy(), done_o)
+    assert_state_equal(hr.host(), dr.host(), "first-step flag, rollout")
+    # the default rule gives other trajectories (the flag is not a no-op)
+    cfg0 = _abi.default_config(seed=14, flags=_abi.F_ALL, max_steps=30, distance_cutoff=0.25)
+    d0 = EnvState(B, A, device=DEV)
+    ops.env_reset(cfg0, dw, d0)
+    ops.env_rollout(cfg0, dw, d0, dev(acts))
+    assert not torch.equal(d0["x"], dr["x"])

@@ -114,3 +114,45 @@ def test_step_magnitudes_equal_the_ungated_operator(small_world):
             assert np.array_equal(hs["magnitudes"].view(np.uint32), want.view(np.uint32)), t
             n_off += int((want[:, 0] > 0).sum()); n_col += int((want[:, 1] > 0).sum())
         assert n_off > 50 and n_col > 0
+
+
+def test_first_step_npc_rule_known_answers_and_the_opt_out(small_world):
+    """DESIGN R14 / tde_abi.h TDE_F_NPC_FIRST_STEP.  Default: on the FIRST step of an episode the NPCs coast with the zero action
+    (known answer, independent of any controller: v' = v bit for bit, x' = x + v cos(psi) dt, psi unchanged up to its wrap) and act from step two on.
+    With the flag the controller acts on step one too, as the reference's NPCs do (gym_env.py:285-294: IAIWrapper drives them
+    from the first simulator.step) - checked against the batched-tensor restatement of the controller (oracle/torch_step.py:
+    torch ops, another code path than the C loops) to 1e-5, and it DIFFERS from coasting for the NPCs that have a route."""
+    from oracle.torch_step import TorchWorld, torch_env_step
+
+    B, A = 48, 16
+    tw = TorchWorld(small_world)
+    for flag in (0, _abi.F_NPC_FIRST_STEP):
+        cfg = _abi.default_config(seed=6, flags=(_abi.F_ALL & ~_abi.F_AUTORESET) | flag)
+        hs, ht = EnvState(B, A), EnvState(B, A)
+        oracle.env_reset(cfg, small_world, hs)
+        ht.load(hs.host())
+        pre = hs.host()
+        act = np.zeros((B, 2), np.float32)
+        hs["action"][...] = act; ht["action"][...] = act
+        oracle.env_step(cfg, small_world, hs)
+        torch_env_step(cfg, small_world, tw, ht)
+        npc = (np.arange(B * A) % A != 0) & (pre["present"] != 0)
+        routed = npc & (small_world.arrays["spawn"].reshape(-1, A)["route"][pre["scn"]].reshape(-1) >= 0)
+        replayed = npc & (small_world.arrays["spawn"].reshape(-1, A)["replay"][pre["scn"]].reshape(-1) >= 0)
+        free = npc & ~replayed
+        for k in ("x", "y", "psi", "v"):
+            assert np.abs(hs[k] - ht[k]).max() <= 1e-5 * max(1.0, np.abs(pre[k]).max()), (flag, k)
+        if not flag:
+            assert np.array_equal(hs["v"][free].view(np.uint32), pre["v"][free].view(np.uint32))          # coasting: v' = v
+            dpsi = np.abs(hs["psi"][free] - pre["psi"][free])                                              # (the wrap (pi + psi) % 2 pi - pi
+            assert np.minimum(dpsi, 2 * np.pi - dpsi).max() < 1e-6                                          #  re-rounds the heading)
+            dt = np.float32(0.1)
+            s, c = oracle.sincosf(pre["psi"])
+            assert np.array_equal((pre["x"] + (pre["v"] * c) * dt)[free].view(np.uint32), hs["x"][free].view(np.uint32))
+            coast_v = hs["v"].copy()
+        else:
+            moved = routed & ~replayed
+            assert moved.sum() > 100 and (hs["v"][moved] != coast_v[moved]).mean() > 0.5                    # the controller acted
+        # from step two on the two rules agree on WHAT runs (the controller), not on the state it runs from
+        oracle.env_step(cfg, small_world, hs)
+        assert (hs["v"][free] != pre["v"][free]).mean() > 0.3

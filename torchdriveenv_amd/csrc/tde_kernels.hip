@@ -2623,7 +2623,9 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (F & TDE_F_OFFROAD) {
             if constexpr (MAG) {
                 offroad_issue<TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, kc);
-                if (a == 0 && live) {
+                // (only for an ego with a corner outside the FULL cells - one that CAN be off the road: the others' words would be
+                //  four more loads per env that this wavefront has to wait for ahead of barrier A, and every workgroup has egos)
+                if (a == 0 && live && min(min(kc.w0 & 3u, kc.w1 & 3u), min(kc.w2 & 3u, kc.w3 & 3u)) != TDE_CELL_FULL) {
                     tw0 = near_tile_word(w, m, kc.px0, kc.py0); tw1 = near_tile_word(w, m, kc.px1, kc.py1);
                     tw2 = near_tile_word(w, m, kc.px2, kc.py2); tw3 = near_tile_word(w, m, kc.px3, kc.py3);
                 }

@@ -884,6 +884,13 @@ class SingleAgentWrapper(_GymWrapperBase):
             return self.transform_out(torch.tensor(x)).cpu().numpy()
         return x
 
+    def transform_in(self, x):                                      # ref gym_env.py:474-481 (unused upstream too: kept for the surface)
+        if torch.is_tensor(x):
+            return x.unsqueeze(0).unsqueeze(0)
+        if isinstance(x, dict):
+            return {k: self.transform_in(v) for k, v in x.items()}
+        return x
+
     def render(self, *args, **kwargs):
         return self.env.render(*args, **kwargs)
 
