@@ -267,3 +267,45 @@ def test_vecenv_with_info_magnitudes_equals_the_plain_vecenv(small_world):
     for k in ("x", "y", "psi", "episode", "scn", "steps"):
         assert torch.equal(v0.env.state[k], v1.env.state[k]), k
     assert n_done > 30 and n_mag > 3
+
+
+@pytest.mark.parametrize("near_range", [0.0, 0.25])
+def test_magnitudes_through_the_grid_scans_when_no_near_list_reaches(near_range):
+    """a world WITHOUT near lists (near_range = 0), and one whose lists end a quarter metre beyond the threshold: every / most
+    flagged corners then take the fall-back scans of the grid - the low-register one inside the three-role step kernel, the
+    two-records-per-trip one in the one-role kernel and in tde_ego_infractions - and the values are still the oracle's brute force,
+    bit for bit, for egos that wander metres off the road (terminated_at_infraction = 0)"""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=8, A=16, seed=0, n_maps=2, near_range=near_range)
+    tn = world.arrays["tile_near"]
+    listed = int(((tn != 0) & (tn != 0xFFFFFFFF)).sum())
+    assert (listed == 0) if near_range == 0.0 else (listed > 0)
+    cfg = _abi.default_config(seed=31, flags=_abi.F_ALL & ~_abi.F_AUTORESET, terminated_at_infraction=0, max_steps=10_000)
+    B, A = 256, 16
+    dw = world.to_device(DEV)
+    hs = EnvState(B, A)
+    oracle.env_reset(cfg, world, hs)
+    forms = ("trio", "solo")
+    ds = [EnvState(B, A, device=DEV) for _ in forms]
+    for d in ds:
+        d.load(hs.host())
+    rng = np.random.default_rng(8)
+    n_off = far = 0
+    try:
+        for t in range(45):
+            act = np.stack([rng.uniform(-0.2, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            oracle.env_step(cfg, world, hs)
+            want = hs["magnitudes"]
+            for form, d in zip(forms, ds):
+                _lib.kernel_override(step=form)
+                ops.env_step(cfg, dw, d, action=dev(act))
+                got = d["magnitudes"].cpu().numpy()
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (form, t, np.abs(got - want).max())
+            _lib.kernel_override()
+            assert np.array_equal(ops.ego_infractions(cfg, dw, ds[0]).cpu().numpy().view(np.uint32), want.view(np.uint32)), t
+            n_off += int((want[:, 0] > 0).sum()); far += int((want[:, 0] > 8.0).sum())
+    finally:
+        _lib.kernel_override()
+    assert n_off > 500 and far > 50            # corners metres beyond any list: the scans grew their squares

@@ -187,7 +187,12 @@ TDE_DEV float point_mesh_d2_scan_lean(const tde_world &w, const tde_map &m, floa
     const float4 *recs = reinterpret_cast<const float4 *>(w.cell_tri) + 3 * (size_t)(uint32_t)m.rec_base;
     // the corner's own cell: an EMPTY cell's clearance says how far the first square has to reach at least
     const uint32_t wd = w.cell_word[(uint32_t)m.cell_base + (((uint32_t)iy << m.row_shift) + (uint32_t)ix)];
-    const float clear = (wd & 3u) == TDE_CELL_EMPTY ? (float)((wd >> 2) & 255u) * TDE_CLEARANCE_UNIT : 0.0f;
+    // (a point outside the grid was clamped into a border cell: EMPTY, and the scan is about distances, not cells)
+    const bool inside = px >= m.ox && py >= m.oy && px < m.ox + (float)m.nx * m.cell && py < m.oy + (float)m.ny * m.cell;
+    // a corner in a FULL cell lies within the threshold: its term is 0 and the squares below - which find the nearest triangle
+    // through the MIXED cells between the corner and the mesh - are not for it (a world without near lists sends it here)
+    if ((wd & 3u) == TDE_CELL_FULL && inside) return -1.0f;
+    const float clear = ((wd & 3u) == TDE_CELL_EMPTY && inside) ? (float)((wd >> 2) & 255u) * TDE_CLEARANCE_UNIT : 0.0f;
     int hw = (((int)((clear + 0.5f) * m.inv_cell) + 2) + 3) & ~3;                  // a multiple of 4: the square is whole 8 x 8 blocks
     const int lx = lane & 7, ly = lane >> 3;
     float best = 3.0e38f;

@@ -153,8 +153,9 @@ def _junction_scenario(J, m, rng, A, n_parked, min_gap=10.0):
     return dict(map=m, waypoints=wps, start_heading=heading, agents=agents, ego_attr=_attrs(rng))
 
 
-def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.25, threshold=0.5, lights=True):
-    """World with `n_scn` scenarios of A-1 NPCs each on `n_maps` junction maps.  Deterministic in `seed`."""
+def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.25, threshold=0.5, lights=True, near_range=None):
+    """World with `n_scn` scenarios of A-1 NPCs each on `n_maps` junction maps.  Deterministic in `seed`.
+    near_range: how far beyond the threshold the grid index carries near lists (world.NEAR_RANGE by default; 0: none)."""
     rng = np.random.default_rng(seed)
     juncs = []
     for m in range(n_maps):
@@ -166,8 +167,10 @@ def synthetic_world(n_scn=64, A=16, seed=0, n_maps=4, n_parked=1, cell=0.25, thr
         juncs.append(Junction(ang, [rng.uniform(110.0, 140.0) for _ in ang]))
     meshes = [j.mesh() for j in juncs]
     scenarios = [_junction_scenario(juncs[si % n_maps], si % n_maps, rng, A, n_parked) for si in range(n_scn)]
+    from .world import NEAR_RANGE
     return assemble_world(meshes, scenarios, A, threshold=threshold, cell=cell,
-                          lights=[j.lights() for j in juncs] if lights else None)
+                          lights=[j.lights() for j in juncs] if lights else None,
+                          near_range=NEAR_RANGE if near_range is None else near_range)
 
 
 # ------------------------------------------------------------------------------------------------
