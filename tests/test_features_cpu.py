@@ -256,7 +256,9 @@ def test_lazy_terminal_mapping_builds_entries_on_demand():
 
     idx = np.array([2, 5])
     obs = np.arange(6, dtype=np.float32).reshape(2, 3)
-    t = LazyTerminal(idx, obs, np.array([1.23456789, -2.0]), np.array([7, 9]), 0.5)
+    ep_r, ep_l = np.zeros(8), np.zeros(8, np.int32)                  # per-ENV arrays (the step's ep_final / ep_final_len outputs)
+    ep_r[[2, 5]], ep_l[[2, 5]] = [1.23456789, -2.0], [7, 9]
+    t = LazyTerminal(idx, lambda n: obs[n], ep_r, ep_l, 0.5)
     assert len(t) == 2 and 5 in t and 3 not in t and t.get(3) is None and sorted(t.keys()) == [2, 5]
     e = t[5]
     assert np.array_equal(e["terminal_observation"], obs[1]) and e["episode"] == {"r": -2.0, "l": 9, "t": 0.5}
@@ -266,7 +268,7 @@ def test_lazy_terminal_mapping_builds_entries_on_demand():
         t[4]
     infos = LazyInfos(8, {"offroad": np.zeros(8, np.float32)}, t)
     assert infos[2]["episode"]["l"] == 7 and "terminal_observation" not in infos[3] and infos[2] is infos[2]
-    no_stats = LazyTerminal(idx, obs, None, None, 0.0)
+    no_stats = LazyTerminal(idx, lambda n: obs[n], None, None, 0.0)
     assert "episode" not in no_stats[2]
 
 

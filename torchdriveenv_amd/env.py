@@ -596,29 +596,33 @@ class LazyInfos:
 class LazyTerminal:
     """env -> the extra info entries of the envs that finished at a step (`terminal_observation`, Monitor's `episode`), as a
     read-only mapping that builds an entry when it is asked for: at 8192 envs some env finishes at every step, and a dict per
-    finished env per step was a Python loop on the step's critical path."""
+    finished env per step was a Python loop on the step's critical path.  `idx`: the finished envs, ascending; `obs_of(n)`: the
+    terminal observation of the n-th of them; ep_r / ep_l: per-ENV arrays (or None)."""
 
-    def __init__(self, idx, term_obs, ep_r, ep_l, t):
-        self._pos = {int(i): n for n, i in enumerate(idx)}
-        self._obs, self._r, self._l, self._t = term_obs, ep_r, ep_l, t
+    def __init__(self, idx, obs_of, ep_r, ep_l, t):
+        self._idx, self._obs_of, self._r, self._l, self._t = idx, obs_of, ep_r, ep_l, t
+
+    def _n(self, i):
+        n = int(np.searchsorted(self._idx, i))
+        return n if n < len(self._idx) and self._idx[n] == i else None
 
     def get(self, i, default=None):
-        n = self._pos.get(i)
+        n = self._n(i)
         if n is None:
             return default
-        ex = {"terminal_observation": self._obs[n]}
+        ex = {"terminal_observation": self._obs_of(n)}
         if self._r is not None:                                  # Monitor: round(sum(rewards), 6), len(rewards), elapsed
-            ex["episode"] = {"r": round(float(self._r[n]), 6), "l": int(self._l[n]), "t": self._t}
+            ex["episode"] = {"r": round(float(self._r[i]), 6), "l": int(self._l[i]), "t": self._t}
         return ex
 
     def __contains__(self, i):
-        return i in self._pos
+        return self._n(i) is not None
 
     def __len__(self):
-        return len(self._pos)
+        return len(self._idx)
 
     def __iter__(self):
-        return iter(self._pos)
+        return (int(i) for i in self._idx)
 
     def __getitem__(self, i):
         ex = self.get(i)
@@ -627,10 +631,10 @@ class LazyTerminal:
         return ex
 
     def keys(self):
-        return self._pos.keys()
+        return [int(i) for i in self._idx]
 
     def items(self):
-        return ((i, self.get(i)) for i in self._pos)
+        return ((int(i), self.get(int(i))) for i in self._idx)
 
 
 class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
@@ -641,8 +645,10 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
     the same methods on a plain class (tests/test_features_cpu.py walks the abstract interface).
 
     Per step: one fused step launch, one observation launch, ONE packed device-to-host copy of all per-env outputs and
-    one of the observation, one stream synchronisation; `infos` is a LazyInfos.  copy_obs=False hands out views of a
-    ring of three pinned buffers (an observation stays valid for the two following steps) instead of fresh arrays."""
+    one of the observation, one stream synchronisation; `infos` is a LazyInfos.  copy_obs=False hands out views of
+    rings of three pinned buffers (observations, rewards, info columns and terminal observations stay valid for the two following
+    steps) instead of fresh arrays.  With the compact observation (obs_mode="state") a step is ONE stream synchronisation, the
+    re-spawn of the finished envs included; the birdview needs a second one for the re-spawned envs' first frames."""
 
     def __init__(self, env, copy_obs=True, info_keywords=("offroad", "collision", "traffic_light_violation", "is_success",
                                                            "reached_waypoint_num", "psi_smoothness", "speed_smoothness",
@@ -676,6 +682,8 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
         else:
             self._obs_ring = [torch.empty(shape, dtype=odt, pin_memory=True) for _ in range(1 if copy_obs else 3)]
         self._turn = 0
+        self._act_pin = self._act_np = self._act_dev = None
+        self._obs2_ring = None
 
     # ---- helpers
     def _obs_to_host(self, obs, rows=None):
@@ -701,62 +709,94 @@ class WaypointVecEnv(_SB3VecEnv if _SB3VecEnv is not None else object):
         if self._pending is None:
             raise RuntimeError("step_wait() without step_async()")
         env = self.env
+        st = env.state
         acts, self._pending = self._pending, None
         auto = env.auto_reset
+        # the actions cross the bus from a pinned staging buffer, asynchronously (a pageable source makes the copy synchronous)
+        if self._act_pin is None:
+            self._act_pin = torch.empty((self.num_envs, 2), dtype=torch.float32, pin_memory=True)
+            self._act_np = self._act_pin.numpy()
+            self._act_dev = torch.empty((self.num_envs, 2), dtype=torch.float32, device=env.torch_device)
+        self._act_np[...] = acts.reshape(self.num_envs, 2)
+        self._act_dev.copy_(self._act_pin, non_blocking=True)
         # terminal_observation needs the pre-reset frame: run the step without in-kernel reset, then re-spawn the
         # finished envs with the masked reset kernel
         env.tde_cfg.flags &= ~_abi.F_AUTORESET
         try:
-            obs, _, _, _, _ = env.step(acts)
+            obs, _, _, _, _ = env.step(self._act_dev)
         finally:
             if auto:
                 env.tde_cfg.flags |= _abi.F_AUTORESET
-        buf = self._obs_to_host(obs)
-        out = env.state.fetch_outputs()                              # ONE copy of every per-env output + the stream sync
+        one_sync = auto and env.obs_mode == "state" and env._h is not None
+        pre = None
+        if one_sync:
+            # compact observation: the observation the step left goes to an internal ring (the finished envs' terminal
+            # observations), then the re-spawn of the finished envs (tde_env_post_step: one launch, it rewrites exactly their
+            # observation rows) and the copy of the 32-byte rows into the caller-visible ring are queued behind it - ONE
+            # synchronisation per step, no mask upload, no gather of the finished rows (round 4: two synchronisations per step)
+            if self._obs2_ring is None:
+                self._obs2_ring = [torch.empty(self._obs_ring[0].shape, dtype=self._obs_ring[0].dtype, pin_memory=True) for _ in range(3)]
+            pre = self._obs2_ring[self._turn % 3]
+            pre.copy_(obs, non_blocking=True)
+            st.copy_outputs_async(ring=3)                            # ONE copy of every per-env output, queued (no synchronisation yet)
+            env._h.post_step(None, int(env.tde_cfg.flags))
+            buf = self._obs_to_host(st["obs"])
+        else:
+            buf = self._obs_to_host(obs)
+            st.copy_outputs_async(ring=3)
+        torch.cuda.current_stream(env.torch_device).synchronize()
+        out = st.outputs_views()
         self._turn += 1
         obs_np = buf.numpy()
-        if self.copy_obs:
-            obs_np = obs_np.copy()
-        term, trunc = out["terminated"].astype(bool), out["truncated"].astype(bool)
+        pre_np = pre.numpy() if one_sync else obs_np                 # the observation the step left (terminal for the finished envs)
+        term, trunc = out["terminated"].view(np.bool_), out["truncated"].view(np.bool_)      # (0 / 1 bytes seen as bool: no copy)
         done = term | trunc
-        rew = out["reward"].copy()
         bits = out.get("done_bits")
         cols = {"TimeLimit.truncated": trunc & ~term}
         mag = out.get("magnitudes")                                  # (the reference's magnitudes, part of the same packed copy)
         for k in self.info_keywords:
             if k == "offroad":
-                cols[k] = mag[:, 0].copy() if mag is not None else ((bits >> 2) & 1).astype(np.float32) if bits is not None else None
+                cols[k] = mag[:, 0] if mag is not None else ((bits >> 2) & 1).astype(np.float32) if bits is not None else None
             elif k == "collision":
-                cols[k] = mag[:, 1].copy() if mag is not None else ((bits >> 3) & 1).astype(np.float32) if bits is not None else None
+                cols[k] = mag[:, 1] if mag is not None else ((bits >> 3) & 1).astype(np.float32) if bits is not None else None
             elif k == "traffic_light_violation":
                 cols[k] = out["tl_violation"].astype(np.float32)
             elif k == "is_success":
-                cols[k] = trunc.copy()
+                cols[k] = trunc
             elif k == "reached_waypoint_num":
-                cols[k] = out["info_reached"].copy()
+                cols[k] = out["info_reached"]
             else:
-                cols[k] = out["info"][:, LazyInfos.INFO_COLS.index(k)].copy()
+                cols[k] = out["info"][:, LazyInfos.INFO_COLS.index(k)]
         cols = {k: v for k, v in cols.items() if v is not None}
+        rew = out["reward"]
+        if self.copy_obs:                                            # fresh arrays: nothing handed out aliases a staging buffer
+            cols = {k: v.copy() for k, v in cols.items()}
+            rew = rew.copy()
         terminal = {}
-        if done.any():
-            idx = np.nonzero(done)[0]
-            ep_r = out["ep_final"][idx].copy() if "ep_final" in out else None
-            ep_l = out["ep_final_len"][idx].copy() if "ep_final_len" in out else None
+        idx = np.flatnonzero(done)
+        if len(idx):
+            ep_r, ep_l = out.get("ep_final"), out.get("ep_final_len")
             t = round(time.time() - self._t_start, 6)
-            term_obs = obs_np[idx].copy()
-            if auto:
+            if one_sync and not self.copy_obs:
+                obs_of = lambda n: pre_np[idx[n]]                    # noqa: E731  (a view of the internal ring: valid for the next two steps)
+            else:
+                term_rows = pre_np[idx]                              # (fancy index: a copy, taken before the rows are overwritten below)
+                obs_of = lambda n: term_rows[n]                      # noqa: E731
+            if auto and not one_sync:
                 # Only the re-spawned envs are reset and re-rendered; only their first observations cross the bus.  The reset
                 # mask is formed ON the device from the step's own outputs (no upload), the gathered rows land in a pinned
-                # staging buffer with an asynchronous copy, and the stream is synchronised once (round 3: a mask upload, a
-                # synchronous .cpu() and a dict per finished env at every step).
-                st = env.state
+                # staging buffer with an asynchronous copy, and the stream is synchronised a second time
                 new = env.reset(mask=st["terminated"] | st["truncated"])
                 sel = new.index_select(0, torch.from_numpy(idx).to(env.torch_device, non_blocking=True))
                 pin = self._sel_staging(len(idx), sel)
                 pin.copy_(sel, non_blocking=True)
                 torch.cuda.current_stream(env.torch_device).synchronize()
                 obs_np[idx] = pin.numpy()
-            terminal = LazyTerminal(idx, term_obs, ep_r, ep_l, t)
+            if self.copy_obs and ep_r is not None:
+                ep_r, ep_l = ep_r.copy(), ep_l.copy()
+            terminal = LazyTerminal(idx, obs_of, ep_r, ep_l, t)
+        if self.copy_obs:
+            obs_np = obs_np.copy()
         return obs_np, rew, done, LazyInfos(self.num_envs, cols, terminal)
 
     def _sel_staging(self, n, like):

@@ -72,13 +72,31 @@ class EnvState:
         stream synchronisation).  The views alias the staging buffer: they are overwritten by the next fetch."""
         import torch
 
-        if self._pinned is None:
-            self._pinned = torch.empty(self._arena.shape, dtype=torch.uint8, pin_memory=True)
-            self._host = self._pinned.numpy()
-        self._pinned.copy_(self._arena, non_blocking=True)
+        self.copy_outputs_async(ring=1)
         torch.cuda.current_stream(self._arena.device).synchronize()
-        shapes = _abi.state_shapes(self.B, self.A)
-        return {n: self._host[o:o + nb].view(_abi.STATE_DTYPES[n]).reshape(shapes[n]) for n, (o, nb) in self._slots.items()}
+        return self.outputs_views()
+
+    def copy_outputs_async(self, ring=1):
+        """queue the ONE device-to-host copy of the output arena on the current stream, into the next of `ring` pinned staging
+        buffers, WITHOUT synchronising: the caller queues what else the step needs (the re-spawn of the finished envs, the
+        observation copies) behind it and synchronises once; outputs_views() then gives the numpy views.  With ring > 1 the views of
+        a fetch stay valid until ring - 1 further fetches have been made."""
+        import torch
+
+        if self._pinned is None or len(self._pinned) != ring:
+            self._pinned = [torch.empty(self._arena.shape, dtype=torch.uint8, pin_memory=True) for _ in range(ring)]
+            self._hosts = [p.numpy() for p in self._pinned]
+            self._turn = 0
+            shapes = _abi.state_shapes(self.B, self.A)
+            # (the views are formed once per staging buffer: a dict comprehension of numpy views per step was 6 us of the step)
+            self._views = [{n: h[o:o + nb].view(_abi.STATE_DTYPES[n]).reshape(shapes[n]) for n, (o, nb) in self._slots.items()}
+                           for h in self._hosts]
+        self._turn = (self._turn + 1) % ring
+        self._pinned[self._turn].copy_(self._arena, non_blocking=True)
+
+    def outputs_views(self):
+        """numpy views of the staging buffer the last copy_outputs_async filled (after the caller's synchronisation)"""
+        return self._views[self._turn]
 
     def __getitem__(self, k):
         return self.arrays[k]
