@@ -349,14 +349,22 @@ TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, co
 // The ego's start (set_start_pos, ref gym_env.py:351-367) from the episode's random words: a point on the first waypoint segment,
 // a speed in [0, 10), the scenario's start heading + normal(0, 0.1) (:359-361: Box-Muller on the shared log / sincos
 // specifications); with TDE_F_EGO_ONLY_ATTRS also its attributes (:192-198).  pose = (x, y, psi, v), attr = (len, wid, lr, -).
-TDE_DEV void ego_spawn(const tde_config &cfg, const Cold &w, int scn, const uint4 &r0, const uint4 &r1, float4 &pose, float4 &attr)
+// (wp1_out / scn_out: the scenario's entry and its second waypoint - the first TARGET of the new episode, target_idx = 1 - which
+//  this function reads anyway: the one-step three-role kernel parks them in LDS so that the re-spawn path, the tail every launch
+//  waits for, starts with the ego's reward context in hand instead of behind two dependent look-ups)
+TDE_DEV void ego_spawn(const tde_config &cfg, const Cold &w, int scn, const uint4 &r0, const uint4 &r1, float4 &pose, float4 &attr,
+                       double2 *wp1_out = nullptr, int4 *scn_out = nullptr)
 {
     const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
+    const double2 w0 = reinterpret_cast<const double2 *>(wp)[0], w1 = reinterpret_cast<const double2 *>(wp)[1];
+    const int4 se = reinterpret_cast<const int4 *>(w.scn)[scn];               // map, wp_n, start_heading, pad
+    if (wp1_out) *wp1_out = w1;
+    if (scn_out) *scn_out = se;
     const double f = u01(r0.y);
-    const double sx = wp[0] + f * (wp[2] - wp[0]);
-    const double sy = wp[1] + f * (wp[3] - wp[1]);
+    const double sx = w0.x + f * (w1.x - w0.x);
+    const double sy = w0.y + f * (w1.y - w0.y);
     const double speed = u01(r0.z) * 10.0;
-    const double psi0 = (double)reinterpret_cast<const float *>(w.scn + scn)[2] + (double)normal_f32(r1.z, r1.w) * 0.1;
+    const double psi0 = (double)__int_as_float(se.z) + (double)normal_f32(r1.z, r1.w) * 0.1;
     pose = make_float4((float)sx, (float)sy, (float)psi0, (float)speed);
     attr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (cfg.flags & TDE_F_EGO_ONLY_ATTRS)
@@ -1286,6 +1294,8 @@ struct DuoShared {
     // formed by judge O ahead of barrier B together with the stop-line cache
     int4 lights[8];
     float4 ego_next[8][2];               // ... and the ego's start (pose, attributes) computed from them by judge C (ego_spawn)
+    double2 ego_next_tgt[8];             // ... the new episode's first target (the scenario's second waypoint) ...
+    int4 ego_next_scn[8];                // ... and its scenario entry (map, wp_n, start heading, -): the reward context of the re-spawn
     // one-step three-role kernel with tde_state.magnitudes: what the magnitude functions read of every env's map descriptor
     // (ox, oy, cell, inv_cell | nx, ny, cell_base, row_shift | rec_base, near_base, -, -), parked by judge O ahead of barrier B
     int4 mapw[8][3];
@@ -2499,8 +2509,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         if (respawns && a == 0 && valid) {
             const uint4 d0 = sh.draw[lane / A][0], d1 = sh.draw[lane / A][1];
             float4 pose, attr;
-            ego_spawn(cfg, cold, (int)(((uint64_t)d0.x * (uint64_t)cold.n_scn) >> 32), d0, d1, pose, attr);
+            double2 wp1;
+            int4 sce;
+            ego_spawn(cfg, cold, (int)(((uint64_t)d0.x * (uint64_t)cold.n_scn) >> 32), d0, d1, pose, attr, &wp1, &sce);
             sh.ego_next[lane / A][0] = pose; sh.ego_next[lane / A][1] = attr;
+            sh.ego_next_tgt[lane / A] = wp1; sh.ego_next_scn[lane / A] = sce;
         }
         lds_barrier();                                       // A: off / tl masks and the ego's psi term are in
         if (a == 0 && valid && (F & TDE_F_REWARD)) {
@@ -2519,12 +2532,20 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         float oc = rb.x, os = rb.y;
         const int k_done = k;
         const int reached_out = er.reached;
+        int new_map = -1;                                    // the new episode's map id when it came with the parked scenario entry
         if (respawned) {
             reset_lane<A, true, (A >= 8)>(cfg, cold, e, a, ag, er, sh.draw[lane / A][0], sh.draw[lane / A][1],
                                           (A >= 8) ? sh.ego_next[lane / A] : nullptr);
             if (a == 0 && (F & TDE_F_REWARD)) {
-                cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
-                load_ego_target(cold, er, cx);
+                if constexpr (A >= 8) {                      // (parked ahead of barrier A: no look-up on the launch's tail)
+                    const int4 sce = sh.ego_next_scn[lane / A];
+                    const double2 t1 = sh.ego_next_tgt[lane / A];
+                    cx.n_wp = sce.y; new_map = sce.x;
+                    cx.wtx = t1.x; cx.wty = t1.y;            // (target_idx = 1; read only when 1 < n_wp)
+                } else {
+                    cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
+                    load_ego_target(cold, er, cx);
+                }
                 if (OBS) sincos_f32(ag.psi, os, oc);
             }
         }
@@ -2559,7 +2580,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             if (F & TDE_F_REWARD) {
                 if (respawned || er.target_idx != ti0 || !ecache_ok) {
                     int4 *ec4 = reinterpret_cast<int4 *>(st.env_cache + e);
-                    ec4[0] = make_int4(er.scn, er.target_idx, cx.n_wp | TDE_CACHE_VALID, reinterpret_cast<const int4 *>(cold.scn)[er.scn].x);
+                    ec4[0] = make_int4(er.scn, er.target_idx, cx.n_wp | TDE_CACHE_VALID, new_map >= 0 ? new_map : reinterpret_cast<const int4 *>(cold.scn)[er.scn].x);
                     reinterpret_cast<double2 *>(st.env_cache + e)[1] = make_double2(cx.wtx, cx.wty);
                 }
             }
