@@ -394,8 +394,10 @@ def spawn_ranks(n, world_kind=None, A=None):
     touched the GPU (no HIP call: the grid-index build it does for the ranks - bench_world - is host code), so the
     children are ordinary new processes; rank 0's JSON line passes through on stdout."""
     if world_kind is not None:
-        _, how, dt = bench_world(world_kind, A)        # the ranks find the file: none of them builds
-        print(f"[bench] parent: world tables {how} in {dt:.2f} s", file=sys.stderr, flush=True)
+        # in a child of its own: THIS process then still has not loaded the HIP runtime (nor torch) when it starts the ranks
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; _, how, dt = bench.bench_world({world_kind!r}, {int(A)}); "
+                "print(f'[bench] parent: world tables {how} in {dt:.2f} s', file=sys.stderr, flush=True)")
+        subprocess.run([sys.executable, "-c", code], check=False)     # (a failure only means that the first rank builds them)
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
     for r in range(n):

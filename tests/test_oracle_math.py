@@ -233,3 +233,44 @@ def test_near_lists_give_the_brute_force_distance(small_world, small_town):
     assert (recs[-16:] == 0).all()
     lens = recs[:, 9].view(np.int32)
     assert lens.max() < 200 and (lens >= 0).all()
+
+
+def test_near_lists_on_random_triangle_soups():
+    """the near lists' guarantee does not lean on road-like meshes: random triangle soups (overlapping, slivers, a degenerate
+    triangle, isolated islands), random points - wherever a tile carries a list, the minimum over the list is the brute-force
+    distance bit for bit; an all-FULL tile only holds points within the threshold; a tile without a list is far from every
+    triangle"""
+    from torchdriveenv_amd.world import build_grid_index
+
+    rng = np.random.default_rng(42)
+    for trial in range(6):
+        n = int(rng.integers(8, 60))
+        c = rng.uniform(-20, 20, (n, 1, 2))
+        tri = (c + rng.normal(0, rng.uniform(0.3, 4.0, (n, 1, 1)), (n, 3, 2))).astype(np.float32)
+        tri[0, 2] = tri[0, 1]                                  # a degenerate triangle (two equal vertices)
+        tri[1] = np.array([[0, 0], [6, 0.001], [12, 0]], np.float32) + rng.uniform(-5, 5, 2).astype(np.float32)   # a sliver
+        near_range = float(rng.choice([0.5, 2.0, 4.0]))
+        g = build_grid_index(tri, threshold=0.5, cell=float(rng.choice([0.25, 0.5])), near_range=near_range, n_threads=2)
+        flat = tri.reshape(-1, 6)
+        ntx = g["nx"] // 4
+        pts = np.concatenate([rng.uniform(-26, 26, (250, 2)), (c[rng.integers(n, size=250), 0] + rng.normal(0, 2.5, (250, 2)))]).astype(np.float32)
+        seen = np.zeros(3, int)
+        for x, y in pts:
+            ix, iy = int((x - g["ox"]) / g["cell"]), int((y - g["oy"]) / g["cell"])
+            if not (0 <= ix < g["nx"] and 0 <= iy < g["ny"]):
+                continue
+            tw = int(g["tile_near"][(iy // 4) * ntx + ix // 4])
+            want = oracle.point_mesh_d2(x, y, flat)
+            if tw == 0:
+                seen[0] += 1
+                assert np.sqrt(want) > 0.5 + near_range - 2.0 * g["cell"] * 4
+            elif tw == 0xFFFFFFFF:
+                seen[1] += 1
+                assert want <= np.float32(0.25)
+            else:
+                seen[2] += 1
+                first, ln = tw - 1, int(g["rec_len"][tw - 1])
+                ids = g["rec_tri"][first:first + ln]
+                got = min(oracle.point_mesh_d2(x, y, flat[k:k + 1]) for k in ids)
+                assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32), (trial, x, y, got, want)
+        assert seen[2] > 50, seen
