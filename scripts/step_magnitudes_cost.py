@@ -17,6 +17,8 @@ def world_of(which):
         return synthetic_town(n_scn=256, A=16, seed=0), 8192, 16
     if which == "wide":
         return synthetic_town(n_scn=32, A=128, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4), 1024, 128
+    if which == "big":                         # configs[3]'s whole batch on one GPU: the one-role kernel (above 131 072 agent slots)
+        return synthetic_world(n_scn=64, A=16, seed=0, n_maps=4), 65536, 16
     if which == "a32":
         return synthetic_world(n_scn=64, A=32, seed=0, n_maps=4), 8192, 32
     return synthetic_world(n_scn=64, A=16, seed=0, n_maps=4), 8192, 16

@@ -283,6 +283,7 @@ TDE_DEV void store_agent_static(const tde_state &st, int64_t g, const Agent &a)
 // registers across the steps of a rollout instead of being re-fetched through a dependent-load chain every step.
 struct Ctx {
     tde_map m;                 // map of the env's scenario
+    int map_id;                // ... and its index in tde_world.maps (one-step kernel with magnitudes: the descriptor is fetched again there)
     float tgx, tgy;            // NPC: current route waypoint
     float tgx2, tgy2;          // (three-role step only) the one after it, from / for the slot cache
     int route_n, replay_len;   // NPC: length of its route / replay row (0 if none)
@@ -325,6 +326,7 @@ TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, co
     // controller's result (vd = min(v_des, sqrt(amax*(gap - s0)))).  The 1 % + 0.1 m margin dwarfs fp32 rounding.
     cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
     const int4 sc = reinterpret_cast<const int4 *>(w.scn)[er.scn];          // map, wp_n, start_heading, pad
+    cx.map_id = sc.x;
     if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) cx.m = w.maps[sc.x];
     ag.route = -1; ag.replay = -1;
     if (a > 0) {
@@ -1029,17 +1031,6 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
     }
     out.tl = tl ? 1 : 0;
 
-    // ---- tde_state.magnitudes: the magnitudes of the ego's infractions (get_info's "collision" / "offroad", :427-428), for the
-    // egos this step flagged, before any re-spawn touches the tile.  (A = 128: the ego's wavefront reads the env's 128 rows; its
-    // partner holds no ego lane, skips this and meets it at the barriers below.)
-    if constexpr (MAG) {
-        const unsigned long long ego = __ballot(a == 0 && valid);
-        const int w0 = tid & ~63;                   // this wavefront's first row of the tile
-        ego_magnitudes_of_wave<A, TDE_SOLO_MAG_LEAN != 0>(cfg, w, [&](int src) { return map_of_lane(cx.m, src); }, ego, __ballot(hit), __ballot(off),
-                                  &t.a[w0], &t.b[w0], tid & 63, t.poly[tid >> 6],
-                                  (a == 0 && valid) ? reinterpret_cast<float4 *>(mag_out) + e : nullptr);
-    }
-
     // ---- reward / termination on the ego lane; the env's other lanes learn "done" from the wave ballot ----------
     if (F & TDE_F_REWARD) {
         int done = 0;
@@ -1079,8 +1070,10 @@ TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold 
                     out.respawned = true;
                     live = ag.present;
                     sincos_f32(ag.psi, s0, c0);
-                    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);   // only this lane reads its slot until
-                }                                                            // the next step's first barrier...
+                    // (only this lane reads its slot until the next step's first barrier...  MAG - the one-step kernel with
+                    //  tde_state.magnitudes - has no next step, and its magnitudes section reads the rows of THIS step at the end)
+                    if constexpr (!MAG) write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
+                }
             }
         }
     }
@@ -1132,60 +1125,75 @@ __global__ __launch_bounds__(kBlock, A > kWave ? WAVES : 1) void env_step_kernel
     sincos_f32(ag.psi, s0, c0);
     write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
     tile_sync<A>();
+    const int map0 = cx.map_id;                     // (MAG: the map of the episode that is being stepped; a re-spawn replaces cx)
     StepOut o = step_lane<A, kBlock, LIGHTS, BIG, MAG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y, st.magnitudes);
-    if (!valid) return;
-    store_agent_dynamic(st, g, ag);
-    if (o.respawned) store_agent_static(st, g, ag);
-    // flags of a re-spawned agent are cleared, as tde_reset_env does
-    st.collided[g] = o.respawned ? 0 : o.collided;
-    st.offroad[g] = o.respawned ? 0 : o.offroad;
-    if (a == 0) {
-        st.steps[e] = er.steps;
-        st.target_idx[e] = er.target_idx;
-        st.reached[e] = er.reached;
-        st.reward[e] = o.reward;
-        st.terminated[e] = o.terminated;
-        st.truncated[e] = o.truncated;
-        if (st.tl_violation) st.tl_violation[e] = o.tl;
-        if (o.respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
-        if (reward_k) reward_k[e] = o.reward;
-        if (done_k)
-            done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
-        if (st.ep_return) {
-            // Monitor-style episode statistics (examples/rl_training.py:123-128): float64 sum of the episode's rewards
-            double ret = st.ep_return[e] + (double)o.reward;
-            if (o.terminated | o.truncated) {
-                if (st.ep_final) st.ep_final[e] = ret;
-                if (st.ep_final_len) st.ep_final_len[e] = o.k;
-                if (o.respawned) ret = 0.0;
+    const unsigned long long hit_m = MAG ? __ballot(o.collided != 0) : 0ull, off_m = MAG ? __ballot(o.offroad != 0) : 0ull;
+    if (valid) {
+        store_agent_dynamic(st, g, ag);
+        if (o.respawned) store_agent_static(st, g, ag);
+        // flags of a re-spawned agent are cleared, as tde_reset_env does
+        st.collided[g] = o.respawned ? 0 : o.collided;
+        st.offroad[g] = o.respawned ? 0 : o.offroad;
+        if (a == 0) {
+            st.steps[e] = er.steps;
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = o.reward;
+            st.terminated[e] = o.terminated;
+            st.truncated[e] = o.truncated;
+            if (st.tl_violation) st.tl_violation[e] = o.tl;
+            if (o.respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
+            if (reward_k) reward_k[e] = o.reward;
+            if (done_k)
+                done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
+            if (st.ep_return) {
+                // Monitor-style episode statistics (examples/rl_training.py:123-128): float64 sum of the episode's rewards
+                double ret = st.ep_return[e] + (double)o.reward;
+                if (o.terminated | o.truncated) {
+                    if (st.ep_final) st.ep_final[e] = ret;
+                    if (st.ep_final_len) st.ep_final_len[e] = o.k;
+                    if (o.respawned) ret = 0.0;
+                }
+                st.ep_return[e] = ret;
             }
-            st.ep_return[e] = ret;
+            if (OBS && st.obs) {
+                // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it.  The cached
+                // ego target is current unless the reward path is off or the episode just ended without a re-spawn.
+                const bool ended = (o.terminated | o.truncated) && !o.respawned;
+                // (the target from cx as VALUES behind an empty asm: left to itself the compiler turns "cx.wtx or the table entry" into
+                //  ONE load through a select of ADDRESSES, which pins cx in scratch memory - 24 B of private segment, and a one-step
+                //  launch with a private segment costs 1.3 us more to dispatch, profiles/r03_g_step_outputs_cost.txt)
+                bool has = er.target_idx < cx.n_wp;
+                double tx = cx.wtx, ty = cx.wty;
+                asm volatile("" : "+v"(tx), "+v"(ty));            // (values, not loads from cx: nothing to merge with the load below)
+                if (!(cfg.flags & TDE_F_REWARD) || ended) {
+                    has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
+                    const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
+                    tx = t2.x; ty = t2.y;
+                }
+                float fwd = 0.0f, lat = 0.0f;
+                if (has) {
+                    const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
+                    fwd = dx * c0 + dy * s0;
+                    lat = dy * c0 - dx * s0;
+                }
+                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
+                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
+                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
+            }
         }
-        if (OBS && st.obs) {
-            // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it.  The cached
-            // ego target is current unless the reward path is off or the episode just ended without a re-spawn.
-            const bool ended = (o.terminated | o.truncated) && !o.respawned;
-            // (the target from cx as VALUES behind an empty asm: left to itself the compiler turns "cx.wtx or the table entry" into
-            //  ONE load through a select of ADDRESSES, which pins cx in scratch memory - 24 B of private segment, and a one-step
-            //  launch with a private segment costs 1.3 us more to dispatch, profiles/r03_g_step_outputs_cost.txt)
-            bool has = er.target_idx < cx.n_wp;
-            double tx = cx.wtx, ty = cx.wty;
-            asm volatile("" : "+v"(tx), "+v"(ty));            // (values, not loads from cx: nothing to merge with the load below)
-            if (!(cfg.flags & TDE_F_REWARD) || ended) {
-                has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
-                const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
-                tx = t2.x; ty = t2.y;
-            }
-            float fwd = 0.0f, lat = 0.0f;
-            if (has) {
-                const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
-                fwd = dx * c0 + dy * s0;
-                lat = dy * c0 - dx * s0;
-            }
-            float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
-            ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
-            ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
-        }
+    }
+    if constexpr (MAG) {
+        // tde_state.magnitudes (get_info's "collision" / "offroad", ref gym_env.py:427-428) for the egos this step flagged: the whole
+        // wavefront works on one ego at a time, from the rows of THIS step (a re-spawn does not rewrite them in this kernel) and
+        // the map descriptor fetched again through the scalar path.  Placed BEHIND the stores, where nothing of the step is live
+        // any more: inside step_lane the section raised the kernel from 84 to 114 VGPRs (4 instead of 6 wavefronts per SIMD:
+        // +15 % per step at 65 536 envs x 16, where this kernel runs)
+        const unsigned long long ego = __ballot(a == 0 && valid);
+        const int w0 = (int)(threadIdx.x & ~63u);
+        ego_magnitudes_of_wave<A, TDE_SOLO_MAG_LEAN != 0>(cfg, w, [&](int src) { return cold.maps[__builtin_amdgcn_readlane(map0, src)]; }, ego,
+                                                           hit_m, off_m, &t.a[w0], &t.b[w0], (int)(threadIdx.x & 63u), t.poly[threadIdx.x >> 6],
+                                                           (a == 0 && valid) ? reinterpret_cast<float4 *>(st.magnitudes) + e : nullptr);
     }
 }
 
