@@ -108,13 +108,13 @@ TDE_DEV void ego_magnitudes_of_wave(const tde_config &cfg, const tde_world &w, M
         const float4 ea = ra[src], eb4 = rb[src];
         // (wave-uniform values in scalar registers: the section runs under the three-role kernel's 80-VGPR budget)
         const EgoBox eb{readlane_f(ea.x, 0), readlane_f(ea.y, 0), readlane_f(eb4.x, 0), readlane_f(eb4.y, 0), readlane_f(eb4.z, 0), readlane_f(eb4.w, 0)};
-#ifndef TDE_X_NOCOLL                  // (timing experiments: WRONG results)
+#ifndef TDE_EXP_NO_COLL_MAG                  // (timing experiments: WRONG results)
         if ((hm >> src) & 1ull) {
             const float2 cm = ego_collision_mag_of(A, lane, eb, TileRows{ra + src, rb + src}, poly);
             if (lane == src) { reinterpret_cast<float *>(out_e)[1] = cm.x; reinterpret_cast<float *>(out_e)[2] = cm.y; }
         }
 #endif
-#ifndef TDE_X_NOOFF
+#ifndef TDE_EXP_NO_OFF_MAG
         if ((om >> src) & 1ull) {
             const float omag = ego_offroad_mag_wave<LEAN>(cfg, w, map_of(src), eb, lane);
             if (lane == src) reinterpret_cast<float *>(out_e)[0] = omag;
@@ -2723,7 +2723,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             float *out_e = ego ? st.magnitudes + 4 * (int64_t)e : nullptr;
             if (ego) *reinterpret_cast<float4 *>(out_e) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             // (collision first: it runs out of LDS while the touched lines of the offroad part arrive)
-#ifndef TDE_X_NOCOLL
+#ifndef TDE_EXP_NO_COLL_MAG
             const unsigned long long hm = sh.hit_mask;
             for (unsigned long long fc = hm & __ballot(ego); fc; fc &= fc - 1) {     // collision (rarely more than one trip)
                 const int src = __ffsll((long long)fc) - 1;
@@ -2734,7 +2734,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             }
 #endif
             asm volatile("" :: "v"(touch0), "v"(touch1));            // (the touches complete here at the latest)
-#ifndef TDE_X_NOOFF                   // (timing experiments: WRONG results)
+#ifndef TDE_EXP_NO_OFF_MAG                   // (timing experiments: WRONG results)
             for (unsigned long long f = fo; f; f &= f - 1) {          // offroad
                 const int src = __ffsll((long long)f) - 1;
                 NearFetch nf;
