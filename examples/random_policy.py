@@ -35,8 +35,9 @@ def main():
         obs, reward, terminated, truncated, info = env.step(action)
         ret += reward
         done = (terminated | truncated).float()          # statistics stay on the device: no host sync in the loop
-        stats += torch.stack([done.sum(), (ret * done).sum(), (info["offroad"] * done).sum(),
-                              (info["collision"] * done).sum()])
+        # (info["offroad"] / info["collision"] are MAGNITUDES, as in the reference, gym_env.py:427-428: > 0 counts the endings)
+        stats += torch.stack([done.sum(), (ret * done).sum(), ((info["offroad"] > 0).float() * done).sum(),
+                              ((info["collision"] > 0).float() * done).sum()])
         ret *= 1.0 - done
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
