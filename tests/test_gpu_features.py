@@ -780,3 +780,44 @@ def test_world_beyond_the_packed_cache_entry_takes_the_one_role_kernel(small_wor
     assert not bool((ds["slot_cache"][:, 1] & (1 << 30)).any())
     ops.env_step(cfg, dw, ds)                              # the same state under the real counts: three roles, entries appear
     assert bool((ds["slot_cache"][:, 1] & (1 << 30)).any())
+
+
+@pytest.mark.parametrize("copy_obs", [True, False])
+def test_vecenv_one_synchronisation_path_equals_the_two_synchronisation_path(small_world, copy_obs):
+    """WaypointVecEnv with the compact observation: through the extension a step is ONE stream synchronisation (the finished envs
+    re-spawned by tde_env_post_step behind the output copy, every observation row copied twice); through the ctypes binding it is
+    the round-4 sequence (masked reset, gather of the finished rows, a second synchronisation).  Same observations, rewards,
+    dones, info columns, terminal observations and episode statistics, step by step - with fresh arrays and with ring views"""
+    from torchdriveenv_amd.config import EnvConfig
+    from torchdriveenv_amd.env import BatchedWaypointEnv, WaypointVecEnv
+
+    B = 128
+    cfg = EnvConfig(seed=21, distance_cutoff=0.25, max_environment_steps=30)
+    kw = dict(num_envs=B, agents_per_env=16, obs_mode="state")
+    one = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, binding="ext", **kw), copy_obs=copy_obs)
+    two = WaypointVecEnv(BatchedWaypointEnv(cfg, small_world, binding="ctypes", **kw), copy_obs=copy_obs)
+    assert np.array_equal(one.reset(), two.reset())
+    rng = np.random.default_rng(5)
+    n_done = 0
+    keep = []                                                   # (ring views must survive the next two steps)
+    for t in range(80):
+        acts = np.stack([rng.uniform(-0.5, 1, B), rng.uniform(-0.3, 0.3, B)], -1)
+        o1, r1, d1, i1 = one.step(acts)
+        o2, r2, d2, i2 = two.step(acts)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2), t
+        for k in i1.columns:
+            assert np.array_equal(i1.column(k), i2.column(k)), (t, k)
+        for i in np.nonzero(d1)[0]:
+            a, b = i1[int(i)], i2[int(i)]
+            assert np.array_equal(a["terminal_observation"], b["terminal_observation"]), (t, i)
+            assert a["episode"]["r"] == b["episode"]["r"] and a["episode"]["l"] == b["episode"]["l"]
+            assert a["TimeLimit.truncated"] == b["TimeLimit.truncated"]
+            n_done += 1
+        if not copy_obs:
+            keep.append((o1, o1.copy(), r1, r1.copy()))
+            if len(keep) > 2:
+                v, c, rv, rc = keep.pop(0)
+                assert np.array_equal(v, c) and np.array_equal(rv, rc), t        # still intact two steps later
+    for k in ("x", "y", "psi", "episode", "scn", "steps"):
+        assert torch.equal(one.env.state[k], two.env.state[k]), k
+    assert n_done > 40

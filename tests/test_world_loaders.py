@@ -388,3 +388,34 @@ def test_road_meshes_hook_gives_the_callers_map(tmp_path):
             elif near:
                 assert hs["offroad"][4 * e] == 0
     assert seen > 10
+
+
+def _cached_world_worker(cache_dir, q):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from torchdriveenv_amd.synth import synthetic_world
+    from torchdriveenv_amd.world import cached_world
+
+    w, how = cached_world("race-test", lambda: synthetic_world(n_scn=2, A=4, seed=3, n_maps=1), cache_dir)
+    q.put((how, int(w.arrays["cell_word"].sum() % 1000003), w.ints["n_scn"]))
+
+
+@pytest.mark.timeout(300)
+def test_cached_world_is_built_once_by_racing_processes(tmp_path):
+    """world.cached_world: N processes that ask for the same tables at once (the ranks of a multi-GPU job) - exactly one builds and
+    saves them, the others wait for the file and load identical tables"""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cached_world_worker, args=(str(tmp_path), q)) for _ in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == ["built", "loaded", "loaded"]
+    assert len({r[1:] for r in res}) == 1
