@@ -168,15 +168,20 @@ def _step_forms(A):
     return (("trio", "solo") if A in (8, 16, 32) else ("solo",))
 
 
-@pytest.mark.parametrize("which", ["junctions_8192x16", "town_2048x16", "town_lights_512x16", "wide_64x128", "a32_1024", "a64_256", "a4_512"])
+@pytest.mark.parametrize("which", ["junctions_8192x16", "town_2048x16", "town_lights_512x16", "wide_64x128", "a32_1024", "a64_256", "a4_512",
+                                   "squared_threshold_512x16", "a8_lights_512"])
 def test_one_launch_step_magnitudes_equal_step_plus_post_step_and_oracle(which, town):
     """tde_env_step with tde_state.magnitudes (one launch, every kernel form) == step without TDE_F_AUTORESET + tde_env_post_step
     (round 4's two launches) == the oracle's step: magnitudes, state, outputs, bit for bit - on BASELINE configs[2]'s batch, the
     town (large grid), a signalised town, 128 slots per env, and the other group shapes"""
     from torchdriveenv_amd.synth import synthetic_town, synthetic_world
 
-    lights = False
-    if which == "junctions_8192x16":
+    lights, squared = False, 0
+    if which == "squared_threshold_512x16":     # (the other reading of the threshold: distances are SQUARED distances, tde_abi.h)
+        world, B, A, T, squared = synthetic_world(n_scn=8, A=16, seed=0, n_maps=2, threshold=float(np.sqrt(0.5))), 512, 16, 60, 1
+    elif which == "a8_lights_512":
+        world, B, A, T, lights = synthetic_world(n_scn=8, A=8, seed=1, n_maps=2), 512, 8, 60, True
+    elif which == "junctions_8192x16":
         world, B, A, T = synthetic_world(n_scn=64, A=16, seed=0, n_maps=4), 8192, 16, 12
     elif which == "town_2048x16":
         world, B, A, T = town, 2048, 16, 25
@@ -191,7 +196,7 @@ def test_one_launch_step_magnitudes_equal_step_plus_post_step_and_oracle(which, 
     else:
         world, B, A, T = synthetic_world(n_scn=8, A=4, seed=4, n_maps=2), 512, 4, 60
     flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0)
-    cfg = _abi.default_config(seed=21, flags=flags, max_steps=40, distance_cutoff=0.25)
+    cfg = _abi.default_config(seed=21, flags=flags, max_steps=40, distance_cutoff=0.25, offroad_threshold_squared=squared)
     cfg_na = _abi.TdeConfig.from_buffer_copy(cfg)
     cfg_na.flags &= ~_abi.F_AUTORESET
     dw = world.to_device(DEV)
