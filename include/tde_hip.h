@@ -136,8 +136,10 @@ TDE_API int tde_state_obs(const tde_world *world, const tde_state *state, float 
  * the ego's of the IoU of the two boxes (CollisionMetric.nograd's published form, gym_env.py:48).  Evaluated on the state as it
  * is: call it after a step WITHOUT TDE_F_AUTORESET and before tde_env_reset re-spawns the finished envs.  Cost: a corner within a
  * few metres of the mesh is a handful of table look-ups; the nearest triangle of a corner r metres away is found by scanning the
- * grid cells of a square of side ~ 2r around it - microseconds up to ~ 10 m, a millisecond at 100 m (an ego that keeps driving off
- * the map under terminated_at_infraction = 0). */
+ * grid cells of a square of side ~ 2r around it - microseconds up to ~ 10 m - and, once that square would hold more cells than
+ * (eight times) the map has triangles, by the definition itself: the minimum over all the map's triangles (tde_world.tri), 64 per
+ * trip - tens of microseconds for an ego that keeps driving hundreds of metres off a junction map under
+ * terminated_at_infraction = 0 (a millisecond by the scan alone).  The same holds for tde_state.magnitudes of tde_env_step. */
 TDE_API int tde_ego_infractions(const tde_config *cfg, const tde_world *world, const tde_state *state, float *out, void *stream);
 
 /* What follows a step that was launched WITHOUT TDE_F_AUTORESET, in one launch (one wavefront per env):

@@ -314,3 +314,45 @@ def test_magnitudes_through_the_grid_scans_when_no_near_list_reaches(near_range)
     finally:
         _lib.kernel_override()
     assert n_off > 500 and far > 50            # corners metres beyond any list: the scans grew their squares
+
+
+@pytest.mark.parametrize("A", [16, 32, 64])
+def test_magnitudes_far_off_a_small_map_take_the_triangle_walk(A):
+    """egos tens to hundreds of metres off a map of a few hundred triangles (terminated_at_infraction = 0 lets them drive on): the
+    square a grid scan would have to walk holds more cells than the map has triangles, and the scans switch to the oracle's own
+    definition - the minimum over ALL triangles from the raw vertices (tde_world.tri).  Same bits in every kernel form and in
+    tde_ego_infractions, outside the grid too."""
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=8, A=A, seed=1, n_maps=2)
+    cfg = _abi.default_config(seed=5, flags=_abi.F_ALL & ~_abi.F_AUTORESET, terminated_at_infraction=0, max_steps=10_000)
+    B = 128
+    dw = world.to_device(DEV)
+    hs = EnvState(B, A)
+    oracle.env_reset(cfg, world, hs)
+    rng = np.random.default_rng(3)
+    # the egos are put at 10 .. 600 m from their spawn points, in any direction (half of them beyond the grid's padding)
+    r = np.exp(rng.uniform(np.log(10.0), np.log(600.0), B)).astype(np.float32)
+    th = rng.uniform(0, 2 * np.pi, B)
+    x, y = hs["x"].reshape(B, A), hs["y"].reshape(B, A)
+    x[:, 0] += (r * np.cos(th)).astype(np.float32); y[:, 0] += (r * np.sin(th)).astype(np.float32)
+    forms = _step_forms(A)
+    ds = [EnvState(B, A, device=DEV) for _ in forms]
+    for d in ds:
+        d.load(hs.host())
+    try:
+        for t in range(6):
+            act = np.stack([rng.uniform(0, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            oracle.env_step(cfg, world, hs)
+            want = hs["magnitudes"]
+            for form, d in zip(forms, ds):
+                _lib.kernel_override(step=form)
+                ops.env_step(cfg, dw, d, action=dev(act))
+                got = d["magnitudes"].cpu().numpy()
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (form, t, np.abs(got - want).max())
+            _lib.kernel_override()
+            assert np.array_equal(ops.ego_infractions(cfg, dw, ds[0]).cpu().numpy().view(np.uint32), want.view(np.uint32)), t
+    finally:
+        _lib.kernel_override()
+    assert (want[:, 0] > 4 * 8.0).sum() > B // 2 and want[:, 0].max() > 1000.0       # (four corners, each hundreds of metres out)

@@ -85,6 +85,7 @@ TDE_DEV tde_map map_of_lane(const tde_map &m, int src)
 #define TDE_RL_I(f) r.f = __builtin_amdgcn_readlane(m.f, src)
     TDE_RL_F(ox); TDE_RL_F(oy); TDE_RL_F(cell); TDE_RL_F(inv_cell);
     TDE_RL_I(nx); TDE_RL_I(ny); TDE_RL_I(cell_base); TDE_RL_I(row_shift); TDE_RL_I(rec_base); TDE_RL_I(near_base);
+    TDE_RL_I(tri_base); TDE_RL_I(n_tri);
 #undef TDE_RL_F
 #undef TDE_RL_I
     return r;
@@ -1305,7 +1306,7 @@ struct DuoShared {
     double2 ego_next_tgt[8];             // ... the new episode's first target (the scenario's second waypoint) ...
     int4 ego_next_scn[8];                // ... and its scenario entry (map, wp_n, start heading, -): the reward context of the re-spawn
     // one-step three-role kernel with tde_state.magnitudes: what the magnitude functions read of every env's map descriptor
-    // (ox, oy, cell, inv_cell | nx, ny, cell_base, row_shift | rec_base, near_base, -, -), parked by judge O ahead of barrier B
+    // (ox, oy, cell, inv_cell | nx, ny, cell_base, row_shift | rec_base, near_base, tri_base, n_tri), parked by judge O ahead of barrier B
     int4 mapw[8][3];
 };
 
@@ -1313,7 +1314,7 @@ TDE_DEV void map_to_lds(int4 *dst, const tde_map &m)
 {
     dst[0] = make_int4(__float_as_int(m.ox), __float_as_int(m.oy), __float_as_int(m.cell), __float_as_int(m.inv_cell));
     dst[1] = make_int4(m.nx, m.ny, m.cell_base, m.row_shift);
-    dst[2] = make_int4(m.rec_base, m.near_base, 0, 0);
+    dst[2] = make_int4(m.rec_base, m.near_base, m.tri_base, m.n_tri);
 }
 TDE_DEV tde_map map_from_lds(const int4 *src)
 {
@@ -1323,6 +1324,7 @@ TDE_DEV tde_map map_from_lds(const int4 *src)
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
     r.ox = __int_as_float(RFL(a.x)); r.oy = __int_as_float(RFL(a.y)); r.cell = __int_as_float(RFL(a.z)); r.inv_cell = __int_as_float(RFL(a.w));
     r.nx = RFL(b.x); r.ny = RFL(b.y); r.cell_base = RFL(b.z); r.row_shift = RFL(b.w); r.rec_base = RFL(c.x); r.near_base = RFL(c.y);
+    // (tri_base, n_tri - words .z / .w of the third: only the far-field fall-back of the scan reads them, from LDS, if it runs at all)
 #undef RFL
     return r;
 }
@@ -2284,8 +2286,18 @@ TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash 
 
 // MAG: also writes tde_state.magnitudes (judge O, behind barrier A); a template flag because the code, taken or not, costs the
 // plain kernel its registers: 73 -> 80 VGPRs + 40 spilled, and a launch with a private segment takes 1.3 us longer to dispatch
+#ifndef TDE_TRIO_STEP_WPE
+#define TDE_TRIO_STEP_WPE 6          // (A/B: wavefronts per SIMD the one-step three-role kernel is compiled for)
+#endif
+// 32 slots per env, or the magnitudes section beside the stop-line test: 80 VGPRs hold those variants only with 2 - 23 spilled
+// registers, i.e. a private segment for every launch; compiled for five wavefronts per SIMD (102 VGPRs) they have none and run as
+// fast (8192 x 32: 14.75 / 15.63 / 17.41 us bare / full / with magnitudes, against 14.74 / 15.65 / 17.44 with the spills).  One
+// more reason: a build of the 32-slot variant whose spill slots moved (the far-field fall-back of the scans added to the section)
+// produced WRONG, run-to-run different states on the device - stale scratch read somewhere - and no variant of this kernel should
+// depend on where the register allocator puts things: none of them has a private segment now.
+constexpr int trio_step_wpe(int A, bool LIGHTS, bool MAG) { return ((A == 32 || (MAG && LIGHTS)) && TDE_TRIO_STEP_WPE == 6) ? 5 : TDE_TRIO_STEP_WPE; }
 template <int A, bool LIGHTS, bool OBS, bool MAG = false>
-__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_step_trio_kernel(
+__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_step_wpe(A, LIGHTS, MAG), trio_step_wpe(A, LIGHTS, MAG)))) void env_step_trio_kernel(
     tde_config cfg, tde_world w, tde_state st, uint32_t act_hash)
 {
     __shared__ DuoShared sh;
@@ -2739,7 +2751,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 const int src = __ffsll((long long)f) - 1;
                 NearFetch nf;
                 corners_of(src, nf, true);
-                const float omag = near_finish<true>(cfg, w, map_from_lds(sh.mapw[src / A]), nf, lane);
+                const float omag = near_finish<true>(cfg, w, map_from_lds(sh.mapw[src / A]), nf, lane, [&]() {
+                    const int4 c = sh.mapw[src / A][2];
+                    return make_int2(__builtin_amdgcn_readfirstlane(c.z), __builtin_amdgcn_readfirstlane(c.w));
+                });
                 if (lane == src) out_e[0] = omag;
             }
 #endif

@@ -107,6 +107,42 @@ TDE_DEV float wave_min(float v)
     return v;
 }
 
+// point -> triangle from the RAW vertices (tde_world.tri: what the CPU checker's brute force reads), the edge reciprocals formed here
+// with IEEE divisions - the values the packed records carry (world.py: pack_triangles; 0 for a degenerate edge)
+TDE_DEV float point_tri_d2_raw(float px, float py, const float *__restrict__ t)
+{
+    const float ax = t[0], ay = t[1], bx = t[2], by = t[3], cx = t[4], cy = t[5];
+    const float e0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+    const float e1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
+    const float e2 = (ax - cx) * (py - cy) - (ay - cy) * (px - cx);
+    if ((e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) || (e0 <= 0.0f && e1 <= 0.0f && e2 <= 0.0f)) return 0.0f;
+    auto inv = [](float ux, float uy) { const float l2 = ux * ux + uy * uy; return l2 > 0.0f ? 1.0f / l2 : 0.0f; };
+    float d = seg_d2_inv(px, py, ax, ay, bx, by, inv(bx - ax, by - ay));
+    d = fminf(d, seg_d2_inv(px, py, bx, by, cx, cy, inv(cx - bx, cy - by)));
+    d = fminf(d, seg_d2_inv(px, py, cx, cy, ax, ay, inv(ax - cx, ay - cy)));
+    return d;
+}
+
+// the CPU checker's own definition, 64 triangles per trip: what the grid scans below switch to when the square they would have to
+// walk holds more cells than (eight times) the map has triangles - a corner tens of metres off a small map (a junction, the corridor
+// of a WaypointSuite scenario) is then a dozen trips instead of a thousand.  A minimum of the same values: the same bits.
+TDE_DEV float point_mesh_d2_brute_wave(const tde_world &w, int tri_base, int n_tri, float px, float py, int lane)
+{
+    const float *T = w.tri + 6 * (size_t)(uint32_t)tri_base;
+    float best = 3.0e38f;
+    for (int k = lane; k < n_tri; k += 64) best = fminf(best, point_tri_d2_raw(px, py, T + 6 * (size_t)k));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o));
+    return best;
+}
+TDE_DEV bool scan_prefers_brute(int n_tri, int hw) { return (long long)(2 * hw) * (2 * hw) > 8ll * (long long)n_tri; }
+// (tri_base, n_tri) of the map from its descriptor: what the scans take by default; the three-role step kernel, which keeps the
+// descriptor's other words in scalar registers, hands in a functor that reads the two from LDS when - if ever - they are needed
+struct TriSpanOfMap {
+    const tde_map &m;
+    TDE_DEV int2 operator()() const { return make_int2(m.tri_base, m.n_tri); }
+};
+
 // squared distance of the wave-uniform point (px, py) to the mesh of map m, exactly min over ALL its triangles of
 // point_tri_d2 (the CPU checker's brute-force minimum); -1 when the point lies in a FULL cell (within the threshold: the
 // caller's clamp is 0 and the exact value is not needed).  Every lane of the wavefront calls it.
@@ -137,6 +173,7 @@ TDE_DEV float point_mesh_d2_wave(const tde_world &w, const tde_map &m, float px,
     float cover = ((cls == TDE_CELL_EMPTY && inside) ? (float)((wd >> 2) & 255u) * TDE_CLEARANCE_UNIT : 0.0f) + 0.5f;
     for (;;) {
         const int hw = (int)(cover * m.inv_cell) + 2;
+        if (w.tri && scan_prefers_brute(m.n_tri, hw)) return fminf(best, point_mesh_d2_brute_wave(w, m.tri_base, m.n_tri, px, py, lane));
         const int x0 = max(ix - hw, 0), x1 = min(ix + hw, m.nx - 1), y0 = max(iy - hw, 0), y1 = min(iy + hw, m.ny - 1);
         const int nxs = x1 - x0 + 1, ncell = nxs * (y1 - y0 + 1);
         float b = 3.0e38f;
@@ -179,7 +216,8 @@ TDE_DEV float point_mesh_d2_wave(const tde_world &w, const tde_map &m, float px,
 // around the corner's cell is walked block by block, one record per trip, and grown (scanned again from scratch: this path is
 // rare and its cost is the cell words of a corner that is metres off the road anyway) until it is known to hold a cell that lists
 // the nearest triangle - the covering argument of point_mesh_d2_wave.  A minimum of the same values: the same bits.
-TDE_DEV float point_mesh_d2_scan_lean(const tde_world &w, const tde_map &m, float px, float py, float bandw, int lane)
+template <typename SPAN>
+TDE_DEV float point_mesh_d2_scan_lean(const tde_world &w, const tde_map &m, float px, float py, float bandw, int lane, SPAN &&tri_span)
 {
     const float fx = __builtin_amdgcn_fmed3f((px - m.ox) * m.inv_cell, 0.0f, (float)(m.nx - 1));
     const float fy = __builtin_amdgcn_fmed3f((py - m.oy) * m.inv_cell, 0.0f, (float)(m.ny - 1));
@@ -197,6 +235,10 @@ TDE_DEV float point_mesh_d2_scan_lean(const tde_world &w, const tde_map &m, floa
     const int lx = lane & 7, ly = lane >> 3;
     float best = 3.0e38f;
     for (;;) {
+        if (w.tri && hw >= 32) {                                     // (a square of 64 x 64 cells or more: rare, and only then is the span read)
+            const int2 ts = tri_span();
+            if (scan_prefers_brute(ts.y, hw)) return fminf(best, point_mesh_d2_brute_wave(w, ts.x, ts.y, px, py, lane));
+        }
         float b = 3.0e38f;
         for (int by = iy - hw; by < iy + hw; by += 8)
             for (int bx = ix - hw; bx < ix + hw; bx += 8) {
@@ -288,8 +330,8 @@ TDE_DEV void near_issue(const tde_world &w, int rec_base, int lane, NearFetch &n
 
 // the magnitude from the fetched records: the rest of a list longer than 16, the minimum over the corner's 16 lanes, the scan for a
 // corner without a list, clamp(dist - threshold, 0), the sum over the corners in the CPU checker's order
-template <bool LEAN = false>
-TDE_DEV float near_finish(const tde_config &cfg, const tde_world &w, const tde_map &m, const NearFetch &nf, int lane)
+template <bool LEAN = false, typename SPAN>
+TDE_DEV float near_finish(const tde_config &cfg, const tde_world &w, const tde_map &m, const NearFetch &nf, int lane, SPAN &&tri_span)
 {
     const float thr = cfg.offroad_threshold, thr2 = thr2_of(cfg);
     const float band = __builtin_sqrtf(thr2) + 0.04f;            // (the cells' lists cover threshold + 0.05: world.py GRID_MARGIN)
@@ -317,7 +359,9 @@ TDE_DEV float near_finish(const tde_config &cfg, const tde_world &w, const tde_m
     for (int cc = 0; cc < 4; ++cc) {
         if (!((scan >> (16 * cc)) & 1ull)) continue;                 // (wave-uniform)
         const float sx = readlane_f(px, 16 * cc), sy = readlane_f(py, 16 * cc);
-        const float d2 = LEAN ? point_mesh_d2_scan_lean(w, m, sx, sy, band, lane) : point_mesh_d2_wave(w, m, sx, sy, band * band, lane);
+        float d2;
+        if constexpr (LEAN) d2 = point_mesh_d2_scan_lean(w, m, sx, sy, band, lane, tri_span);
+        else d2 = point_mesh_d2_wave(w, m, sx, sy, band * band, lane);
         if (c == cc) d2c = d2;
     }
     float term = 0.0f;
@@ -342,7 +386,13 @@ TDE_DEV float ego_offroad_mag_wave(const tde_config &cfg, const tde_world &w, co
     nf.tw = near_tile_word(w, m, nf.px, nf.py);
     nf.t0 = nf.t1 = nf.t2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (__ballot(near_listed(nf.tw))) near_issue(w, m.rec_base, lane, nf);
-    return near_finish<LEAN>(cfg, w, m, nf, lane);
+    return near_finish<LEAN>(cfg, w, m, nf, lane, TriSpanOfMap{m});
+}
+
+template <bool LEAN = false>
+TDE_DEV float near_finish(const tde_config &cfg, const tde_world &w, const tde_map &m, const NearFetch &nf, int lane)
+{
+    return near_finish<LEAN>(cfg, w, m, nf, lane, TriSpanOfMap{m});
 }
 
 }  // namespace tde

@@ -96,7 +96,7 @@ def mesh_from_verts_faces(verts, faces):
 
 
 def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=12.0, threshold=0.5,
-                              background=None, background_radius=250.0, ego_only=False, road_meshes=None):
+                              background=None, background_radius=250.0, ego_only=False, road_meshes=None, near_range=None):
     """WaypointSuite -> World.  Agent ordering follows the reference: slot 0 ego, then the scenario's agents
     (ref gym_env.py:219-228); `car_sequence_suite[i][k]` replays slot k (ref gym_env.py:275-283).
     The CARLA town meshes the reference takes from torchdrivesim's package data are not available, so each scenario
@@ -115,7 +115,13 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
     (ref gym_env.py:312, 184, 260): a dict location -> triangles ([n, 3, 2] or [n, 6] array, or the path of a .npy file holding
     one; `mesh_from_verts_faces` converts a verts / faces pair), or a callable location -> the same or None.  Scenarios of a
     location that has a mesh all run on ONE map built from it (one grid index per location); a location without one falls back to
-    the synthetic corridor of its scenario."""
+    the synthetic corridor of its scenario.
+
+    `near_range` (metres; default world.NEAR_RANGE = 2): how far beyond the offroad threshold the grid index carries NEAR LISTS, from
+    which the MAGNITUDE of the offroad infraction (info["offroad"], ref gym_env.py:427) is two table look-ups; a corner farther out
+    is still exact but found by scanning the grid, and beyond the reach where that square would hold more cells than the map has
+    triangles by a walk over all the map's triangles (tens of microseconds per such ego and step).  Raise it (it costs table memory:
+    a few records per square metre of the band) for `terminated_at_infraction=False` runs whose egos keep driving off the road."""
     from . import loaders
     meshes, scenarios = [], []
     map_of_location = {}
@@ -182,7 +188,9 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
         if ego_attr is not None:
             scn["ego_attr"] = ego_attr
         scenarios.append(scn)
-    return assemble_world(meshes, scenarios, agents_per_env, threshold=threshold)
+    from .world import NEAR_RANGE
+    return assemble_world(meshes, scenarios, agents_per_env, threshold=threshold,
+                          near_range=NEAR_RANGE if near_range is None else float(near_range))
 
 
 class _LazyInfo(dict):
@@ -274,14 +282,17 @@ class BatchedWaypointEnv:
 
     def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
                  frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0, binding="ext",
-                 info_magnitudes=True, road_meshes=None):
+                 info_magnitudes=True, road_meshes=None, near_range=None):
         """binding: "ext" = launches go through the PyTorch-ROCm C++ extension (csrc/tde_torch_ext.cpp), "ctypes" = through
         the ctypes binding of the same C-ABI (ops.py); both call the very same entry points of libtde_hip.so.
         info_magnitudes (default): info["offroad"] / info["collision"] hold the MAGNITUDES the reference reports there (ref
         gym_env.py:427-428: sum over the ego's corners of clamp(distance - threshold, 0); sum of the IoUs with the agents the ego
         overlaps), written by the step kernel itself for the egos it flagged, before a finished env is re-spawned
         (tde_state.magnitudes: still ONE launch per step).  False: 0 / 1 indicators (the kernel then skips the magnitudes).
-        road_meshes: the drivable mesh per location when `data` is a WaypointSuite (world_from_waypoint_suite)."""
+        road_meshes / near_range: the drivable mesh per location and the reach of the grid index's near lists when `data` is a
+        WaypointSuite (world_from_waypoint_suite).  With `terminated_at_infraction=False` an ego may drive far off the road, where
+        the exact offroad magnitude is found by a scan of the grid or a walk over the map's triangles (tens of microseconds per such
+        ego and step; `near_range` moves that point outwards, info_magnitudes=False skips the work)."""
         validate(cfg)
         if binding not in ("ext", "ctypes"):
             raise ValueError("binding must be 'ext' or 'ctypes'")                                              # ref gym_env.py:79-80 and the fields this path rejects
@@ -299,7 +310,8 @@ class BatchedWaypointEnv:
         self.world = data if isinstance(data, World) else world_from_waypoint_suite(
             data, agents_per_env,
             threshold=effective_offroad_distance(sim.offroad_threshold, sim.offroad_threshold_squared),
-            background=background if cfg.use_background_traffic else None, ego_only=cfg.ego_only, road_meshes=road_meshes)
+            background=background if cfg.use_background_traffic else None, ego_only=cfg.ego_only, road_meshes=road_meshes,
+            near_range=near_range)
         check_threshold(self.world, sim.offroad_threshold, sim.offroad_threshold_squared,
                         "EnvConfig.simulator.offroad_threshold")   # a prebuilt World bakes its threshold into the grid
         self.A = self.world.A
@@ -862,6 +874,7 @@ class WaypointSuiteEnv(_GymEnvBase):
         self.reward_range = (-float("inf"), float("inf"))
         self.collision_threshold = 0.0
         self.offroad_threshold = 0.0
+        self._obs_pin = None
 
     @property
     def environment_steps(self):
@@ -880,11 +893,27 @@ class WaypointSuiteEnv(_GymEnvBase):
         return obs.cpu().numpy().reshape(1, 1, 3, 64, 64).astype(np.uint8), {}
 
     def step(self, action):                                         # ref gym_env.py:369-389
-        obs, rew, term, trunc, info = self._env.step(torch.as_tensor(action).reshape(1, 2))
-        info = {k: (v.reshape(1, 1) if k in ("offroad", "collision", "traffic_light_violation") else
-                    (bool(v[0]) if v.dtype == torch.bool else v[0].item())) for k, v in info.items()}
-        return (obs.cpu().numpy().reshape(1, 1, 3, 64, 64).astype(np.uint8), float(rew[0]), bool(term[0]),
-                bool(trunc[0]), info)
+        """one timestep.  Everything the reference's step returns crosses the bus in TWO asynchronous copies - the observation
+        and the packed per-env outputs - behind ONE stream synchronisation (a `.item()` / `.cpu()` per returned value was a dozen
+        synchronisations per step); the (1, 1) info tensors are therefore host tensors (the reference's live on `torch_device`;
+        SingleAgentWrapper moves them to the CPU either way, gym_env.py:463-472)."""
+        env = self._env
+        st = env.state
+        obs, _, _, _, _ = env.step(torch.as_tensor(action, dtype=torch.float32).reshape(1, 2))
+        if self._obs_pin is None:
+            self._obs_pin = torch.empty((1, 3, 64, 64), dtype=torch.uint8, pin_memory=True)
+        self._obs_pin.copy_(obs, non_blocking=True)
+        out = st.fetch_outputs()                                     # (the one synchronisation: the observation copy is ahead of it)
+        mag = out["magnitudes"][0]
+        t11 = lambda v: torch.tensor([[v]], dtype=torch.float32)    # noqa: E731
+        trunc = bool(out["truncated"][0])
+        info = {"offroad": t11(mag[0]), "collision": t11(mag[1]), "traffic_light_violation": t11(float(out["tl_violation"][0])),
+                "is_success": trunc}
+        if "info" in out:
+            inf = out["info"][0]
+            info.update(reached_waypoint_num=int(out["info_reached"][0]), psi_smoothness=float(inf[0]), speed_smoothness=float(inf[1]),
+                        psi_reward=float(inf[2]), dist_reward=float(inf[3]))
+        return (self._obs_pin.numpy().reshape(1, 1, 3, 64, 64).copy(), float(out["reward"][0]), bool(out["terminated"][0]), trunc, info)
 
     def render(self):                                               # ref gym_env.py:152-157
         if self.render_mode == "rgb_array":
