@@ -2643,7 +2643,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
             m = cold.maps[map];
         }
         const float thr2 = thr2_of(cfg);
-        if constexpr (MAG) { if (a == 0) map_to_lds(sh.mapw[lane / A], m); }
+#ifndef TDE_EXP_MAG_FRAME
+#define TDE_EXP_MAG_FRAME 0          // timing experiments (WRONG results): 1 no zero store, 2 no tile words, 4 no parking, 8 no touches, 16 no map words
+#endif
+        if constexpr (MAG) { if (a == 0 && !(TDE_EXP_MAG_FRAME & 16)) map_to_lds(sh.mapw[lane / A], m); }
         uint32_t red_k = 0u;
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) {
             // in the wait for barrier B: the env's stop lines into LDS, the red masks of this step and of the next one
@@ -2667,7 +2670,9 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
                 offroad_issue<TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, kc);
                 // (only for an ego with a corner outside the FULL cells - one that CAN be off the road: the others' words would be
                 //  four more loads per env that this wavefront has to wait for ahead of barrier A, and every workgroup has egos)
-                if (a == 0 && live && min(min(kc.w0 & 3u, kc.w1 & 3u), min(kc.w2 & 3u, kc.w3 & 3u)) != TDE_CELL_FULL) {
+                // (tried, profiles/r05_magnitudes_floor.md: EVERY ego's words, issued beside the class look-ups: +0.16 us; the words kept
+                //  in registers across barrier A and parked behind it, no touches: +-0)
+                if (!(TDE_EXP_MAG_FRAME & 2) && a == 0 && live && min(min(kc.w0 & 3u, kc.w1 & 3u), min(kc.w2 & 3u, kc.w3 & 3u)) != TDE_CELL_FULL) {
                     tw0 = near_tile_word(w, m, kc.px0, kc.py0); tw1 = near_tile_word(w, m, kc.px1, kc.py1);
                     tw2 = near_tile_word(w, m, kc.px2, kc.py2); tw3 = near_tile_word(w, m, kc.px3, kc.py3);
                 }
@@ -2689,7 +2694,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         //  live across the barrier: the section runs under this kernel's 80-VGPR budget)
         float *nearw = reinterpret_cast<float *>(sh.ring_post) + 32;
         if constexpr (MAG) {
-            if (a == 0) {
+            if (a == 0 && !(TDE_EXP_MAG_FRAME & 4)) {
                 float4 *d = reinterpret_cast<float4 *>(nearw + 12 * (lane / A));
                 d[0] = make_float4(kc.px0, kc.px1, kc.px2, kc.px3);
                 d[1] = make_float4(kc.py0, kc.py1, kc.py2, kc.py3);
@@ -2717,8 +2722,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
                 const float *recs = w.cell_tri + 12 * (size_t)(rb0 + (near_listed(tw) ? tw - 1u : 0u));
                 return near_listed(tw) ? recs[12 * (lane & 15)] : 0.0f;
             };
-            if (fo) touch0 = touch(__ffsll((long long)fo) - 1);
-            if (fo & (fo - 1)) touch1 = touch(__ffsll((long long)(fo & (fo - 1))) - 1);
+            if (fo && !(TDE_EXP_MAG_FRAME & 8)) touch0 = touch(__ffsll((long long)fo) - 1);
+            if ((fo & (fo - 1)) && !(TDE_EXP_MAG_FRAME & 8)) touch1 = touch(__ffsll((long long)(fo & (fo - 1))) - 1);
         }
         lds_barrier();                                       // A
         unsigned long long term_m, trunc_m;
@@ -2734,7 +2739,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         if constexpr (MAG) {
             const bool ego = a == 0 && valid;
             float *out_e = ego ? st.magnitudes + 4 * (int64_t)e : nullptr;
-            if (ego) *reinterpret_cast<float4 *>(out_e) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (ego && !(TDE_EXP_MAG_FRAME & 1)) *reinterpret_cast<float4 *>(out_e) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             // (collision first: it runs out of LDS while the touched lines of the offroad part arrive)
 #ifndef TDE_EXP_NO_COLL_MAG
             const unsigned long long hm = sh.hit_mask;
