@@ -2292,11 +2292,14 @@ TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash 
 // 32 slots per env: 80 VGPRs hold those variants only with 8 - 23 spilled registers, i.e. a private segment for every launch;
 // compiled for five wavefronts per SIMD (102 VGPRs) they have none and run as fast (8192 x 32: 14.75 / 15.63 / 17.41 us bare / full /
 // with magnitudes, against 14.74 / 15.65 / 17.44 with the spills).  One more reason: a build of the 32-slot variant whose spill slots
-// had moved (the far-field fall-back of the scans added to the section) produced WRONG, run-to-run different states on the device -
-// stale scratch read somewhere - and this variant no longer depends on where the register allocator puts things.  (The variants
+// had moved (the far-field fall-back of the scans added to the section) produced WRONG, run-to-run different states on the device
+// (profiles/r05_a32_respawn_anomaly.md) - and this variant no longer depends on where the register allocator puts things.  (The variants
 // with the magnitudes section beside the stop-line test, 2 - 3 spilled registers at 8 / 16 slots, stay at six: at five they lose a
 // third - the lights' closed loop with magnitudes 12.5 -> 16.0 us.)
-constexpr int trio_step_wpe(int A, bool LIGHTS, bool MAG) { return (A == 32 && TDE_TRIO_STEP_WPE == 6) ? 5 : TDE_TRIO_STEP_WPE; }
+#ifndef TDE_TRIO32_STEP_WPE
+#define TDE_TRIO32_STEP_WPE 5
+#endif
+constexpr int trio_step_wpe(int A, bool LIGHTS, bool MAG) { return A == 32 ? TDE_TRIO32_STEP_WPE : TDE_TRIO_STEP_WPE; }
 template <int A, bool LIGHTS, bool OBS, bool MAG = false>
 __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_step_wpe(A, LIGHTS, MAG), trio_step_wpe(A, LIGHTS, MAG)))) void env_step_trio_kernel(
     tde_config cfg, tde_world w, tde_state st, uint32_t act_hash)
