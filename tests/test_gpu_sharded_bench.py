@@ -42,7 +42,7 @@ def test_bench_eight_ranks_on_one_gpu_equal_the_unsharded_batch(tmp_path):
     assert [c["env_base"] for c in out["check"]] == [r * B for r in range(N)]
     # the world tables: built once by the parent, loaded by every rank
     assert "world tables built" in p.stderr and out["startup"]["ranks_that_built_the_world"] == 0
-    assert out["startup"]["world_tables_s"] < 1.5, out["startup"]
+    assert out["startup"]["world_tables_s"] < 5.0, out["startup"]           # (typically 0.03 s: a load; the bound only guards against a build)
     # the unsharded batch: 65 536 envs in this process, the action columns of shard r drawn as rank r draws them (seed = r)
     os.environ["TDE_WORLD_CACHE"] = str(tmp_path / "worlds")
     world, how, _ = bench.bench_world("junctions", A)
@@ -78,7 +78,7 @@ def test_sharded_env_eight_workers_birdview_equals_unsharded(small_world):
     sh = ShardedBatchedEnv(cfg, small_world, total_envs=total, n_shards=8, devices=[0] * 8, copy_obs=False, **kw)
     try:
         assert sh.n_shards == 8 and [hi - lo for lo, hi in sh.ranges] == [1024] * 8
-        assert sh.startup["world_load_s_max"] < 1.0, sh.startup          # workers load the tables the parent saved once
+        assert sh.startup["world_load_s_max"] < 5.0, sh.startup          # workers load the tables the parent saved once (typically 0.05 s)
         ref = BatchedWaypointEnv(cfg, small_world, num_envs=total, **kw).as_vec_env()
         o0, o1 = sh.reset(), ref.reset()
         assert np.array_equal(o0, o1)
