@@ -2291,11 +2291,11 @@ TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash 
 #endif
 // 32 slots per env: 80 VGPRs hold those variants only with 8 - 23 spilled registers, i.e. a private segment for every launch;
 // compiled for five wavefronts per SIMD (102 VGPRs) they have none and run as fast (8192 x 32: 14.75 / 15.63 / 17.41 us bare / full /
-// with magnitudes, against 14.74 / 15.65 / 17.44 with the spills).  One more reason: a build of the 32-slot variant whose spill slots
-// had moved (the far-field fall-back of the scans added to the section) produced WRONG, run-to-run different states on the device
-// (profiles/r05_a32_respawn_anomaly.md) - and this variant no longer depends on where the register allocator puts things.  (The variants
-// with the magnitudes section beside the stop-line test, 2 - 3 spilled registers at 8 / 16 slots, stay at six: at five they lose a
-// third - the lights' closed loop with magnitudes 12.5 -> 16.0 us.)
+// with magnitudes, against 14.74 / 15.65 / 17.44 with the spills).  (The variants with the magnitudes section beside the stop-line
+// test, 2 - 3 spilled registers at 8 / 16 slots, stay at six: at five they lose a third - the lights' closed loop with magnitudes
+// 12.5 -> 16.0 us.)  NOTE for whoever edits this kernel: MI355X computes a 64-bit shift wrong when its amount sits in the wavefront's
+// LAST allocated VGPR (here: `(dn >> base) & 1` with base in v79 of 80 - profiles/r05_a32_respawn_anomaly.md); the allocator decides
+// that, not the source, so build.py audits the linked code object (isa_audit.py) and refuses a library with the pattern.
 #ifndef TDE_TRIO32_STEP_WPE
 #define TDE_TRIO32_STEP_WPE 5
 #endif
