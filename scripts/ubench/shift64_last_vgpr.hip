@@ -12,8 +12,8 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(2); } } while (0)
 
 // NV = the kernel's VGPR budget (a multiple of 8).  The clobber list forces the allocation up to v(NV-1); nothing else may exceed it.
-#define SHIFT_KERNEL(NV, LASTREG, CTRLREG)                                                                                          \
-    __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(NV))) void k_shift_##NV(const uint64_t *m, const int *amt,        \
+#define SHIFT_KERNEL_OP(NAME, OP, CEXPR, NV, LASTREG, CTRLREG)                                                                                          \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(NV))) void NAME(const uint64_t *m, const int *amt,        \
                                                                                            uint64_t *r_last, uint64_t *r_ctrl,     \
                                                                                            uint64_t *r_c, int rounds)                \
     {                                                                                                                              \
@@ -23,19 +23,41 @@
         uint64_t x = 0, y = 0;                                                                                                     \
         for (int r = 0; r < rounds; ++r) {                                                                                         \
             uint64_t t0, t1;                                                                                                       \
-            asm volatile("v_mov_b32 " LASTREG ", %1\n\tv_lshrrev_b64 %0, " LASTREG ", %2" : "=&v"(t0) : "v"(a), "v"(mv) : LASTREG);   \
-            asm volatile("v_mov_b32 " CTRLREG ", %1\n\tv_lshrrev_b64 %0, " CTRLREG ", %2" : "=&v"(t1) : "v"(a), "v"(mv) : CTRLREG);   \
+            asm volatile("v_mov_b32 " LASTREG ", %1\n\t" OP " %0, " LASTREG ", %2" : "=&v"(t0) : "v"(a), "v"(mv) : LASTREG);   \
+            asm volatile("v_mov_b32 " CTRLREG ", %1\n\t" OP " %0, " CTRLREG ", %2" : "=&v"(t1) : "v"(a), "v"(mv) : CTRLREG);   \
             x |= t0 ^ (uint64_t)r * 0;                                                                                             \
             y |= t1;                                                                                                               \
         }                                                                                                                          \
         r_last[i] = x;                                                                                                             \
         r_ctrl[i] = y;                                                                                                             \
-        r_c[i] = mv >> a;                                                                                                          \
+        r_c[i] = CEXPR;                                                                                                            \
     }
 
+#define SHIFT_KERNEL(NV, LASTREG, CTRLREG) SHIFT_KERNEL_OP(k_shift_##NV, "v_lshrrev_b64", mv >> a, NV, LASTREG, CTRLREG)
 SHIFT_KERNEL(8, "v7", "v6")
 SHIFT_KERNEL(16, "v15", "v14")
 SHIFT_KERNEL(80, "v79", "v78")
+SHIFT_KERNEL_OP(k_shl_16, "v_lshlrev_b64", mv << a, 16, "v15", "v14")
+SHIFT_KERNEL_OP(k_sar_16, "v_ashrrev_i64", (uint64_t)((int64_t)mv >> a), 16, "v15", "v14")
+// the 32-bit shift, for comparison (no erratum expected): the low dword only
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(16))) void k_shr32_16(const uint64_t *m, const int *amt, uint64_t *r_last,
+                                                                                      uint64_t *r_ctrl, uint64_t *r_c, int rounds)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t mv = (uint32_t)m[i];
+    const int a = amt[i];
+    uint32_t x = 0, y = 0;
+    for (int r = 0; r < rounds; ++r) {
+        uint32_t t0, t1;
+        asm volatile("v_mov_b32 v15, %1\n\tv_lshrrev_b32 %0, v15, %2" : "=&v"(t0) : "v"(a), "v"(mv) : "v15");
+        asm volatile("v_mov_b32 v14, %1\n\tv_lshrrev_b32 %0, v14, %2" : "=&v"(t1) : "v"(a), "v"(mv) : "v14");
+        x |= t0;
+        y |= t1;
+    }
+    r_last[i] = x;
+    r_ctrl[i] = y;
+    r_c[i] = mv >> (a & 31);
+}
 
 // the neighbours: wavefronts with a different allocation whose registers hold all-ones patterns for a while
 __global__ __launch_bounds__(64) void k_noise(uint32_t *out, int spin)
@@ -49,7 +71,7 @@ __global__ __launch_bounds__(64) void k_noise(uint32_t *out, int spin)
     out[blockIdx.x * 64 + threadIdx.x] = acc;
 }
 
-template <typename K> static int run(const char *name, K kernel, int nblk)
+template <typename K> static int run(const char *name, K kernel, int nblk, bool mask32 = false)
 {
     const int n = nblk * 64;
     uint64_t *m, *r0, *r1, *rc;
@@ -70,11 +92,12 @@ template <typename K> static int run(const char *name, K kernel, int nblk)
         hipLaunchKernelGGL(kernel, dim3(nblk), dim3(64), 0, s0, m, amt, r0, r1, rc, 50);
         CHECK(hipDeviceSynchronize());
         for (int i = 0; i < n; ++i) {
-            const uint64_t want = m[i] >> amt[i];
-            if (rc[i] != want) { printf("compiler shift wrong?!\n"); return 2; }
-            bad_last += r0[i] != want;
-            bad_ctrl += r1[i] != want;
-            if (r0[i] != want && bad_last <= 3)
+            uint64_t want = rc[i];                       // (the same operation as the compiler emits it)
+            if (mask32) want &= 0xFFFFFFFFull;
+            const uint64_t g0 = mask32 ? (r0[i] & 0xFFFFFFFFull) : r0[i], g1 = mask32 ? (r1[i] & 0xFFFFFFFFull) : r1[i];
+            bad_last += g0 != want;
+            bad_ctrl += g1 != want;
+            if (g0 != want && bad_last <= 3)
                 printf("  %s: lane %d amt %d m %016llx: got %016llx want %016llx\n", name, i, amt[i], (unsigned long long)m[i], (unsigned long long)r0[i], (unsigned long long)want);
         }
         total += n;
@@ -89,6 +112,10 @@ int main()
     rc |= run("8 VGPRs", k_shift_8, 8192);
     rc |= run("16 VGPRs", k_shift_16, 8192);
     rc |= run("80 VGPRs", k_shift_80, 8192);
+    rc |= run("shl64/16", k_shl_16, 8192);
+    rc |= run("sar64/16", k_sar_16, 8192);
+    const int r32 = run("shr32/16", k_shr32_16, 8192, true);
+    printf("32-bit shift with its amount in the last VGPR: %s\n", r32 ? "WRONG too" : "fine");
     printf(rc ? "ERRATUM REPRODUCED\n" : "not reproduced by this test\n");
     return 0;
 }
