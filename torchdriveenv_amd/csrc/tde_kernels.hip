@@ -2344,6 +2344,9 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         const float2 act = reinterpret_cast<const float2 *>(st.action)[es];
         const int4 *sc4 = reinterpret_cast<const int4 *>(st.slot_cache + gs);
         const int4 sc0 = sc4[0], sc1 = sc4[1];
+#ifdef TDE_EXP_EXTRA_LOAD            // timing experiment: 16 more bytes per slot in the prologue burst (is it bandwidth-bound?)
+        const int4 extra_ld = reinterpret_cast<const int4 *>(w.cell_word)[gs];
+#endif
         // the stored action of this slot and the key of its env's entries (tde_act_cache: A + 1 entries per env)
         float2 ac = make_float2(0.0f, 0.0f);
         int2 akey = make_int2(-1, 0);                                        // episode, steps
@@ -2356,6 +2359,9 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         Ctx cx;
         bool rebuilt;
         load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, ag, er, cx, false, rebuilt);     // (no map: the lights are judge O's)
+#ifdef TDE_EXP_EXTRA_LOAD
+        asm volatile("" :: "v"(extra_ld.x), "v"(extra_ld.y), "v"(extra_ld.z), "v"(extra_ld.w));
+#endif
         const bool need_tg2 = !rebuilt && valid && (sc0.y & kSlotTg2Later) != 0;   // (left by the re-spawn of the previous launch)
         float c0, s0;
         const bool live = valid && ag.present;
