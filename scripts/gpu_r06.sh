@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-6 GPU pass: gpurun -- bash scripts/gpu_r06.sh <tag> [tests] [ab:<libA>:<libB>...] [ubench]
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+exec < /dev/null
+TAG=${1:-r06}; shift
+O=gpurun_out/$TAG; mkdir -p $O
+for what in "$@"; do
+  case "$what" in
+    ubench) ./scripts/ubench/shift64_last_vgpr > $O/shift64_last_vgpr.txt 2>&1; tail -12 $O/shift64_last_vgpr.txt;;
+    tests) ( time timeout 1800 python -m pytest tests -m gpu -q -x ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt;;
+    ab:*) LIBS=$(echo "${what#ab:}" | tr ':' ' ')
+      python scripts/ab_rollout.py $LIBS > $O/ab_rollout.txt 2>&1; grep -v amdgpu.ids $O/ab_rollout.txt | tail -4
+      python scripts/ab_rollout.py --lights $LIBS > $O/ab_rollout_lights.txt 2>&1; grep -v amdgpu.ids $O/ab_rollout_lights.txt | tail -4
+      python scripts/ab_step.py $LIBS > $O/ab_step.txt 2>&1; grep -v amdgpu.ids $O/ab_step.txt | tail -4
+      python scripts/ab_step.py --lights --outputs $LIBS > $O/ab_step_lights.txt 2>&1; grep -v amdgpu.ids $O/ab_step_lights.txt | tail -4;;
+    bench) python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json;;
+    *) echo "unknown phase $what";;
+  esac
+done

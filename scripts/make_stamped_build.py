@@ -1,6 +1,6 @@
 """Builds ab/libS.so: the library with s_memtime stamps / counters patched into ONE kernel, plus the debug entry point
 `tde_debug_stamps` that scripts/phase_stamps.py, render_stamps.py and trip_counts.py read.  The instrumentation is
-applied to a copy of csrc/tde_kernels.hip by text substitution (asserted), so the shipped kernels stay clean.
+applied to a copy of csrc/tde_kernels.h (built as the single-unit form of the library) by text substitution (asserted), so the shipped kernels stay clean.
 
     python scripts/make_stamped_build.py duo|trio|step3|trips      # then  TDE_HIP_LIB=$PWD/ab/libS.so python scripts/...
 
@@ -15,7 +15,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "torchdriveenv_amd", "csrc", "tde_kernels.hip")
+SRC = os.path.join(ROOT, "torchdriveenv_amd", "csrc", "tde_kernels.h")    # (the device code of every unit of the library)
 sys.path.insert(0, ROOT)
 from torchdriveenv_amd.build import FLAGS  # noqa: E402
 
@@ -201,7 +201,11 @@ def patched_source(mode):
     tests/test_boundary.py::test_stamp_patches_apply_to_the_current_source)"""
     s = open(SRC).read()
     s = sub(s, ANCHOR, PRELUDE + ANCHOR)
-    return PATCHES[mode](s) + EPILOGUE
+    # the patched device code first (it defines the header's include guard, so the units' own #include of tde_kernels.h is a
+    # no-op), then every unit of the library as csrc/tde_kernels.hip lists them, then the debug entry point
+    units = [ln for ln in open(SRC[:-2] + ".hip").read().splitlines() if ln.startswith('#include "tde_') and ln.endswith('.hip"')]
+    assert len(units) >= 5, "csrc/tde_kernels.hip no longer lists the library's units"
+    return "#define TDE_TU_API 1\n" + PATCHES[mode](s) + "\n".join(units) + "\n" + EPILOGUE
 
 
 def main():

@@ -59,6 +59,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(16))) void k_shr
     r_c[i] = mv >> (a & 31);
 }
 
+// Scope of the erratum (round 6): the same 64-bit shift with the amount NOT in a VGPR - a scalar register (a wave-uniform amount)
+// and an inline literal - while the 64-bit VALUE sits in the wavefront's last register pair v[14:15] of 16, and the value in the last
+// pair with the amount in a low VGPR.  Expected: fine (the hazard LLVM names for gfx11 is about the register AFTER the amount).
+#define SHIFT_KERNEL_SCOPE(NAME, AMT_OPERAND, AMT_CONSTRAINT, AMT_EXPR, CEXPR)                                                      \
+    __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(16))) void NAME(const uint64_t *m, const int *amt, uint64_t *r_last,   \
+                                                                                    uint64_t *r_ctrl, uint64_t *r_c, int rounds)            \
+    {                                                                                                                              \
+        const int i = blockIdx.x * 64 + threadIdx.x;                                                                               \
+        const uint64_t mv = m[i];                                                                                                  \
+        const int a = AMT_EXPR;                                                                                                    \
+        uint64_t x = 0, y = 0;                                                                                                     \
+        for (int r = 0; r < rounds; ++r) {                                                                                         \
+            uint64_t t0, t1;                                                                                                       \
+            asm volatile("v_mov_b32 v14, %2\n\tv_mov_b32 v15, %3\n\tv_lshrrev_b64 %0, " AMT_OPERAND ", v[14:15]"                     \
+                         : "=&v"(t0) : AMT_CONSTRAINT(a), "v"((uint32_t)mv), "v"((uint32_t)(mv >> 32)) : "v14", "v15");            \
+            asm volatile("v_mov_b32 v12, %2\n\tv_mov_b32 v13, %3\n\tv_lshrrev_b64 %0, " AMT_OPERAND ", v[12:13]"                     \
+                         : "=&v"(t1) : AMT_CONSTRAINT(a), "v"((uint32_t)mv), "v"((uint32_t)(mv >> 32)) : "v12", "v13");            \
+            x |= t0;                                                                                                               \
+            y |= t1;                                                                                                               \
+        }                                                                                                                          \
+        r_last[i] = x;                                                                                                             \
+        r_ctrl[i] = y;                                                                                                             \
+        r_c[i] = CEXPR;                                                                                                            \
+    }
+SHIFT_KERNEL_SCOPE(k_shr_sgpr_16, "%1", "s", __builtin_amdgcn_readfirstlane(amt[blockIdx.x * 64]) & 63, mv >> a)
+SHIFT_KERNEL_SCOPE(k_shr_lit_16, "20", "s", 20, mv >> 20)
+SHIFT_KERNEL_SCOPE(k_shr_lowv_16, "%1", "v", amt[i], mv >> a)
+
 // the neighbours: wavefronts with a different allocation whose registers hold all-ones patterns for a while
 __global__ __launch_bounds__(64) void k_noise(uint32_t *out, int spin)
 {
@@ -114,6 +142,10 @@ int main()
     rc |= run("80 VGPRs", k_shift_80, 8192);
     rc |= run("shl64/16", k_shl_16, 8192);
     rc |= run("sar64/16", k_sar_16, 8192);
+    // (not part of the verdict: the amount is not in the last VGPR in these three)
+    const int rs = run("sgpr amt", k_shr_sgpr_16, 8192), rl = run("literal", k_shr_lit_16, 8192), rv = run("value last", k_shr_lowv_16, 8192);
+    printf("amount in an SGPR / an inline literal / a low VGPR, the VALUE in the last register pair: %s / %s / %s\n", rs ? "WRONG" : "fine",
+           rl ? "WRONG" : "fine", rv ? "WRONG" : "fine");
     const int r32 = run("shr32/16", k_shr32_16, 8192, true);
     printf("32-bit shift with its amount in the last VGPR: %s\n", r32 ? "WRONG too" : "fine");
     printf(rc ? "ERRATUM REPRODUCED\n" : "not reproduced by this test\n");

@@ -23,6 +23,42 @@ constexpr float kPio2A = 1.5703125f;                // Cody-Waite split of pi/2 
 constexpr float kPio2B = 4.837512969970703125e-4f;
 constexpr float kPio2C = 7.54978995489188216e-8f;
 
+// ---- 64-bit lane masks without 64-bit shifts by a VGPR amount ---------------------------------------------------------
+// MI355X computes v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64 wrong when the shift AMOUNT sits in the wavefront's last allocated
+// VGPR (profiles/r05_a32_respawn_anomaly.md; scripts/ubench/shift64_last_vgpr.hip reproduces it) - and which register holds an
+// amount is the allocator's choice.  So no kernel shifts a 64-bit value by a per-lane amount: a lane's bit of a wave mask is taken
+// from the 32-bit HALF that holds it with one 32-bit shift, masks are assembled from two 32-bit words, and a lane's rank in a
+// mask comes from v_mbcnt.  (Shifts by a wave-uniform amount are scalar instructions; 32-bit shifts are not affected.)
+// torchdriveenv_amd/isa_audit.py fails the build if a 64-bit shift by a VGPR amount appears anywhere in the library.
+TDE_DEV uint32_t mask_lo(unsigned long long m) { return (uint32_t)m; }
+TDE_DEV uint32_t mask_hi(unsigned long long m) { return (uint32_t)(m >> 32); }
+// "is bit 5 of i set" as a value the optimiser cannot see through: left transparent, `(i & 32) ? hi : lo` is recognised as
+// trunc(m >> (i & 32)) and comes back as the very v_lshrrev_b64 by a VGPR amount this is here to avoid
+TDE_DEV bool upper_half(int i)
+{
+    int up = i & 32;
+    asm("" : "+v"(up));
+    return up != 0;
+}
+// bit i (0 .. 63) of m
+TDE_DEV uint32_t mask_bit(unsigned long long m, int i) { return ((upper_half(i) ? mask_hi(m) : mask_lo(m)) >> (i & 31)) & 1u; }
+TDE_DEV uint32_t mask_bit(uint32_t m, int i) { return (m >> i) & 1u; }
+// the bits of m from bit s (0 .. 63) up that lie in the same 32-bit half, at bit 0: what (uint32_t)(m >> s) gives when the field
+// read does not straddle bit 32 (an env's lanes: a power of two <= 32, aligned)
+TDE_DEV uint32_t mask_field(unsigned long long m, int s) { return (upper_half(s) ? mask_hi(m) : mask_lo(m)) >> (s & 31); }
+// 1 << i (0 .. 63) as a 64-bit mask
+TDE_DEV unsigned long long one_bit64(int i)
+{
+    const uint32_t b = 1u << (i & 31);
+    const bool up = upper_half(i);
+    return ((unsigned long long)(up ? b : 0u) << 32) | (up ? 0u : b);
+}
+// number of set bits of m below this lane's own bit (v_mbcnt_lo / _hi): popcount(m & ((1 << lane) - 1))
+TDE_DEV int lane_prefix(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi(mask_hi(m), __builtin_amdgcn_mbcnt_lo(mask_lo(m), 0u));
+}
+
 // sin and cos of an fp32 angle.  ONE specification shared with the CPU checker: Cody-Waite reduction
 // by pi/2 and degree-7/8 minimax polynomials, every multiply-add an explicit fused multiply-add (fmaf: one rounding, the
 // same on CPU and GPU), so CPU and GPU agree bit for bit (<= 2 ulp vs libm).  Half the instructions of the unfused form.

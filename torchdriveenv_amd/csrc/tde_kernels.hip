@@ -1,3646 +1,19 @@
-// tde_kernels.hip — hand-written CDNA4 (gfx950) kernels of the batched driving-env step path and the C-ABI that
-// exposes them (include/tde_hip.h).  No torch types anywhere: plain device pointers, sizes and a hipStream_t.
-//
-// Mapping (DESIGN.md "Kernels"): one lane per agent slot, env-major, so an env of A (power of two <= 64) slots is a
-// contiguous lane group inside ONE wavefront.  The persistent rollout kernels run K timesteps per launch with the agent
-// state in registers, every group of 64 slots (64/A envs) served by one, two or three wavefronts that split the step by
-// role (env_rollout_kernel / _duo_ / _trio_, chosen by group shape); the one-step kernel uses 256-thread workgroups.
-// Per-env agent tiles are staged in LDS for the all-pairs sweeps (one tile per step serves the collision sweep of that
-// step and the NPC controller of the next); env termination is gathered with wave ballots; the drivable-mesh grid
-// index and the scenario tables are read-only and stay in L2 / Infinity Cache.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <atomic>
-#include <type_traits>
-
-#include "../../include/tde_hip.h"
-#include "tde_device.h"
-#include "tde_magnitudes.h"
-#include "tde_raster.h"
-
-namespace tde {
-
-constexpr int kBlock = 256;
-constexpr int kWave = 64;
-
-// 16-byte streaming store as ONE global_store_dwordx4 ... nt.  (__builtin_nontemporal_store on the members of HIP's uint4
-// struct gives four dword stores whose lanes interleave at 16-byte stride: four times the store instructions, each
-// writing a quarter of every cache line it touches.)
-TDE_DEV void store_nt16(void *dst, const uint4 &v)
-{
-    u32x4_t t;
-    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(dst));
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// per-lane registers
-// ------------------------------------------------------------------------------------------------------------------
-struct Agent {
-    float x, y, psi, v, len, wid, lr, vdes;
-    float inv_lr;               // 1.0f / lr (bicycle)
-    int route, route_wp, replay;
-    bool present;
-};
-
-struct EnvRegs {   // replicated on every lane of the env
-    int scn, steps, target_idx, reached, episode;
-};
-
-// LDS tile, one slot per lane of the workgroup, two 16-B records per agent so that a sweep reads them with
-// ds_read_b128 (all lanes of an env read the same address: broadcast, no bank conflict):
-//     a = (x, y, reach, lane_half + hw + 0.01)     b = (cos psi, sin psi, hl, hw)
-//     (hl, hw = half length / width; reach = (hl + hw) * kReach bounds the circumradius)
-// The tile always holds the CURRENT state of every slot: it is written once per step, after the integration, and
-// serves that step's collision sweep and the next step's NPC controller (whose "pre-step" state it is).
-// An absent slot is parked at x = y = kFar, which fails every cheap sweep test by itself (no present flag to read).
-template <int BLOCK>
-struct Tiles {
-    float4 a[BLOCK];
-    float4 b[BLOCK];
-    int wide_done[4];           // A > 64 (an env spans two wavefronts): the env's done flag, through LDS instead of a wave ballot
-    float poly[BLOCK / 64][32]; // per wavefront: box_iou_wave's vertex lists (tde_state.magnitudes)
-};
-constexpr float kFar = 1e18f;
-
-// the boxes of an env's slots from its tile rows (ra / rb: slot 0 first), for ego_collision_mag_of: an absent slot is parked at kFar
-struct TileRows {
-    const float4 *ra, *rb;
-    TDE_DEV bool operator()(int j, float &x, float &y, float &c, float &s, float &hl, float &hw) const
-    {
-        const float4 p = ra[j], q = rb[j];
-        x = p.x; y = p.y; c = q.x; s = q.y; hl = q.z; hw = q.w;
-        return p.x != kFar;
-    }
-};
-
-// the map descriptor lane `src` (wave-uniform) holds, on every lane: what the magnitude functions read of it
-TDE_DEV tde_map map_of_lane(const tde_map &m, int src)
-{
-    tde_map r{};
-#define TDE_RL_F(f) r.f = readlane_f(m.f, src)
-#define TDE_RL_I(f) r.f = __builtin_amdgcn_readlane(m.f, src)
-    TDE_RL_F(ox); TDE_RL_F(oy); TDE_RL_F(cell); TDE_RL_F(inv_cell);
-    TDE_RL_I(nx); TDE_RL_I(ny); TDE_RL_I(cell_base); TDE_RL_I(row_shift); TDE_RL_I(rec_base); TDE_RL_I(near_base);
-    TDE_RL_I(tri_base); TDE_RL_I(n_tri);
-#undef TDE_RL_F
-#undef TDE_RL_I
-    return r;
-}
-
-// tde_state.magnitudes for the egos of this wavefront that the step flagged (hm / om: ballots of the slots' collision / offroad
-// flags; ego: ballot of the ego lanes), one ego at a time by all 64 lanes: the values of tde_ego_infractions on the state the step
-// left - what get_info reports under "collision" / "offroad" (ref gym_env.py:427-428).  ra / rb: tile rows of the wavefront's
-// lane 0 (lane l's row at ra[l]); `m`: the map descriptor of every lane's env.  Returns this lane's env's four values (ego lanes).
-// `map_of(src)`: the (wave-uniform) map descriptor of the env whose ego sits on lane src; `out_e`: this lane's env's entry of
-// tde_state.magnitudes (ego lanes; nullptr on the others).  Every ego lane stores zeros first and the lane of a flagged ego its
-// values when they are known (same lane, same address, program order): nothing is carried in registers through the section.
-template <int A, bool LEAN = false, typename M>
-TDE_DEV void ego_magnitudes_of_wave(const tde_config &cfg, const tde_world &w, M &&map_of, unsigned long long ego,
-                                    unsigned long long hm, unsigned long long om, const float4 *ra, const float4 *rb, int lane,
-                                    float *poly, float4 *out_e)
-{
-    if (out_e) *out_e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (unsigned long long fm = (hm | om) & ego; fm; fm &= fm - 1) {       // (wave-uniform; rarely more than one trip)
-        const int src = __ffsll((long long)fm) - 1;
-        const float4 ea = ra[src], eb4 = rb[src];
-        // (wave-uniform values in scalar registers: the section runs under the three-role kernel's 80-VGPR budget)
-        const EgoBox eb{readlane_f(ea.x, 0), readlane_f(ea.y, 0), readlane_f(eb4.x, 0), readlane_f(eb4.y, 0), readlane_f(eb4.z, 0), readlane_f(eb4.w, 0)};
-#ifndef TDE_EXP_NO_COLL_MAG                  // (timing experiments: WRONG results)
-        if ((hm >> src) & 1ull) {
-            const float2 cm = ego_collision_mag_of(A, lane, eb, TileRows{ra + src, rb + src}, poly);
-            if (lane == src) { reinterpret_cast<float *>(out_e)[1] = cm.x; reinterpret_cast<float *>(out_e)[2] = cm.y; }
-        }
-#endif
-#ifndef TDE_EXP_NO_OFF_MAG
-        if ((om >> src) & 1ull) {
-            const float omag = ego_offroad_mag_wave<LEAN>(cfg, w, map_of(src), eb, lane);
-            if (lane == src) reinterpret_cast<float *>(out_e)[0] = omag;
-        }
-#endif
-    }
-}
-
-// LDS-only workgroup barrier: unlike __syncthreads() it does not wait for global loads / stores in flight
-TDE_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// Between a phase that writes tile rows and one that reads them in the ONE-role kernels.  Up to 64 slots per env the rows of
-// an env are written and read by ONE wavefront, whose LDS instructions execute in order: nothing to wait for - the four
-// wavefronts of a 256-thread workgroup are independent chains, and a __syncthreads() (s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier)
-// made each of them wait for the slowest at every phase AND for its own grid-index loads that were meant to stay in flight
-// across the collision sweep.  128 slots per env: the env's two wavefronts meet at an LDS-only barrier.
-#ifndef TDE_TILE_SYNC_WG
-#define TDE_TILE_SYNC_WG 0          // 1: the old __syncthreads() (A/B)
-#endif
-template <int A> TDE_DEV void tile_sync()
-{
-    if constexpr (TDE_TILE_SYNC_WG) __syncthreads();
-    else if constexpr (A > kWave) lds_barrier();
-    else { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
-}
-
-template <int A> struct MaskOf { using type = uint32_t; };
-template <> struct MaskOf<64> { using type = unsigned long long; };
-template <> struct MaskOf<128> { using type = unsigned long long; };   // (A = 128 never builds a mask: the *_wide forms)
-TDE_DEV int lowest_bit(uint32_t m) { return __ffs((int)m) - 1; }
-TDE_DEV int lowest_bit(unsigned long long m) { return __ffsll((long long)m) - 1; }
-
-// All-pairs sweeps read the A tile rows of the lane's env and reduce each row to ONE candidate bit.  What shapes them
-// (scripts/ubench/valu_latency.hip: a lone wavefront issues a dependent VALU instruction every ~10 cycles, independent
-// ones every ~5, and a v_cmp -> v_cndmask pair through VCC costs ~24):
-//   * rows are processed in blocks of kSweepBlock, STAGE by stage across the block (every stage is kSweepBlock or
-//     2 x kSweepBlock independent instructions), the stages pinned in that order (pin() below);
-//   * the block's tile rows are fetched one block ahead, right after the last stage that reads the previous ones;
-//   * the row's verdict is formed as a float whose SIGN bit says "candidate" and shifted into the mask with one
-//     v_alignbit_b32 (mask = mask << 1 | sign): no compare, no select, no VCC.
-// Bit order: row r of the env lands in bit A-1-r (row_of_bit / bit_of_row below).
-constexpr int kSweepBlock = 2;
-// Stage pins.  sched_barrier only constrains the machine scheduler, and instruction selection is free to place pure
-// arithmetic on either side of it; an empty asm that takes the stage's values as read-write operands is a real data
-// dependency: everything that produces them is issued before it, everything that consumes them after it.  The
-// "memory" form keeps the LDS reads of the next block on their side of the pin (it does not wait for them).
-template <int C> TDE_DEV void pin(float (&a)[C])
-{
-#pragma unroll
-    for (int j = 0; j < C; ++j) asm volatile("" : "+v"(a[j]));
-}
-template <int C> TDE_DEV void pin(float (&a)[C], float (&b)[C])
-{
-#pragma unroll
-    for (int j = 0; j < C; ++j) asm volatile("" : "+v"(a[j]), "+v"(b[j]));
-}
-TDE_DEV void pin_memory() { asm volatile("" ::: "memory"); }
-template <int A> TDE_DEV int row_of_bit(int b) { return A - 1 - b; }
-template <int A> TDE_DEV typename MaskOf<A>::type bit_of_row(int r) { return (typename MaskOf<A>::type)1 << (A - 1 - r); }
-TDE_DEV uint32_t push_sign(uint32_t mask, float verdict)
-{
-    return __builtin_amdgcn_alignbit(mask, __float_as_uint(verdict), 31);   // ({mask, verdict} >> 31): mask << 1 | sign
-}
-// `stage(rows, verdicts, prefetch)`: computes the C verdict floats of a block from its C tile rows
-// (C = min(A, kSweepBlock)) and calls `prefetch()` at the point where the rows have been consumed.  Two register sets
-// alternate, so a block's rows are requested a whole block (about 20 instructions) before they are used: with one set
-// the 2 x ds_read_b128 were waited for a handful of instructions after their issue (~60 exposed cycles per block).
-template <int A, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks(const float4 *rows, S &&stage)
-{
-    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
-    constexpr int NB = A / C;
-    uint32_t word = 0, hi = 0;
-#ifndef TDE_SWEEP_AHEAD
-#define TDE_SWEEP_AHEAD 1
-#endif
-    // 1: one register set, the next block fetched in place; 2: two sets, a block's rows requested a whole block ahead
-    // (hides the LDS latency but costs 8 more VGPRs: under the 80-VGPR cap of the three-role kernel the spills it
-    // causes cost more than it saves, same-box A/B 3.76 vs 3.69 us per step)
-    constexpr int AHEAD = TDE_SWEEP_AHEAD;
-    float4 r0[C], r1[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) r0[j] = rows[j];
-    if (NB > 1 && AHEAD == 2) {
-#pragma unroll
-        for (int j = 0; j < C; ++j) r1[j] = rows[C + j];
-    }
-    auto block = [&](int b, float4 (&r)[C]) {
-        float v[C];
-        stage(r, v, [&]() {                        // the rows are consumed: block b + AHEAD lands in the same registers
-            if (b + AHEAD < NB) {
-#pragma unroll
-                for (int j = 0; j < C; ++j) r[j] = rows[(b + AHEAD) * C + j];
-            }
-        });
-#pragma unroll
-        for (int j = 0; j < C; ++j) word = push_sign(word, v[j]);
-        if (A == 64 && (b + 1) * C == 32) { hi = word; word = 0; }
-    };
-#pragma unroll
-    for (int b = 0; b < NB; b += 2) {
-        block(b, r0);
-        if (b + 1 < NB) { if (AHEAD == 2) block(b + 1, r1); else block(b + 1, r0); }
-    }
-    if constexpr (A == 64) return ((unsigned long long)hi << 32) | word;
-    else return word;
-}
-
-// The same sweep with every row fetched as two 8-byte halves (.xy / .zw) that are consumed - and therefore re-fetched for
-// the next block - at different stages: `stage(xy, zw, verdicts, prefetch_xy, prefetch_zw)`.  The halves of the two rows
-// of a block travel in one ds_read2_b64 each, so the number of LDS instructions is that of the 16-byte form.
-template <int A, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks_halves(const float4 *rows, S &&stage)
-{
-    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
-    constexpr int NB = A / C;
-    uint32_t word = 0, hi = 0;
-    const float2 *h = reinterpret_cast<const float2 *>(rows);
-    float2 xy[C], zw[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) { xy[j] = h[2 * j]; zw[j] = h[2 * j + 1]; }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        float v[C];
-        stage(xy, zw, v,
-              [&]() {
-                  if (b + 1 < NB) {
-#pragma unroll
-                      for (int j = 0; j < C; ++j) xy[j] = h[2 * ((b + 1) * C + j)];
-                  }
-              },
-              [&]() {
-                  if (b + 1 < NB) {
-#pragma unroll
-                      for (int j = 0; j < C; ++j) zw[j] = h[2 * ((b + 1) * C + j) + 1];
-                  }
-              });
-#pragma unroll
-        for (int j = 0; j < C; ++j) word = push_sign(word, v[j]);
-        if (A == 64 && (b + 1) * C == 32) { hi = word; word = 0; }
-    }
-    if constexpr (A == 64) return ((unsigned long long)hi << 32) | word;
-    else return word;
-}
-
-TDE_DEV void load_agent(const tde_state &st, int64_t g, Agent &a)
-{
-    a.x = st.x[g]; a.y = st.y[g]; a.psi = st.psi[g]; a.v = st.v[g];
-    a.len = st.len[g]; a.wid = st.wid[g]; a.lr = st.lr[g]; a.vdes = st.vdes[g];
-    a.inv_lr = 1.0f / a.lr;
-    a.route_wp = st.route_wp[g];
-    a.route = -1; a.replay = -1;        // filled from the spawn record by load_ctx
-    a.present = st.present[g] != 0;
-}
-
-TDE_DEV void store_agent_dynamic(const tde_state &st, int64_t g, const Agent &a)
-{
-    st.x[g] = a.x; st.y[g] = a.y; st.psi[g] = a.psi; st.v[g] = a.v;
-    st.route_wp[g] = a.route_wp;
-}
-
-TDE_DEV void store_agent_static(const tde_state &st, int64_t g, const Agent &a)
-{
-    st.len[g] = a.len; st.wid[g] = a.wid; st.lr[g] = a.lr; st.vdes[g] = a.vdes;
-    st.present[g] = a.present ? 1 : 0;
-}
-
-// Table entries that only change on rare events (route waypoint switch, ego waypoint advance, reset) are kept in
-// registers across the steps of a rollout instead of being re-fetched through a dependent-load chain every step.
-struct Ctx {
-    tde_map m;                 // map of the env's scenario
-    int map_id;                // ... and its index in tde_world.maps (one-step kernel with magnitudes: the descriptor is fetched again there)
-    float tgx, tgy;            // NPC: current route waypoint
-    float tgx2, tgy2;          // (three-role step only) the one after it, from / for the slot cache
-    int route_n, replay_len;   // NPC: length of its route / replay row (0 if none)
-    float g_far;               // NPC: gap beyond which a leader cannot cap the speed (see npc_action)
-    double wtx, wty;           // ego: current target waypoint
-    int n_wp;                  // ego: number of waypoints of the scenario
-};
-
-TDE_DEV void load_route_target(const Cold &w, const Agent &ag, Ctx &cx)
-{
-    if (ag.route >= 0 && ag.route_wp < cx.route_n) {
-        const float2 tg = reinterpret_cast<const float2 *>(w.route_xy)[(int64_t)ag.route * w.RW + ag.route_wp];
-        cx.tgx = tg.x; cx.tgy = tg.y;
-    }
-}
-
-TDE_DEV void load_ego_target(const Cold &w, const EnvRegs &er, Ctx &cx)
-{
-    if (er.target_idx < cx.n_wp) {
-        const double2 tg = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + er.target_idx];
-        cx.wtx = tg.x; cx.wty = tg.y;
-    }
-}
-
-// the ego's reward context (number of waypoints, current target) on EVERY lane of the env (batched reward, judge C)
-TDE_DEV void load_ego_ctx(const Cold &w, const EnvRegs &er, Ctx &cx)
-{
-    cx.n_wp = reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
-    cx.wtx = cx.wty = 0.0;
-    load_ego_target(w, er, cx);
-}
-
-// sp4 = the slot's spawn record as four 16-B words (tde_spawn), or nullptr to fetch it here
-template <int A>
-TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, const EnvRegs &er, Ctx &cx)
-{
-    const uint32_t F = cfg.flags;
-    cx.tgx = cx.tgy = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0;
-    // A leader whose gap is beyond the distance at which the braking-distance speed exceeds v_des cannot change the
-    // controller's result (vd = min(v_des, sqrt(amax*(gap - s0)))).  The 1 % + 0.1 m margin dwarfs fp32 rounding.
-    cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
-    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[er.scn];          // map, wp_n, start_heading, pad
-    cx.map_id = sc.x;
-    if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) cx.m = w.maps[sc.x];
-    ag.route = -1; ag.replay = -1;
-    if (a > 0) {
-        if (F & (TDE_F_NPC | TDE_F_REPLAY)) {
-            const int4 *rec = reinterpret_cast<const int4 *>(w.spawn + ((int64_t)er.scn * A + a));
-            const int4 r2 = rec[2];                                              // route, route_wp, route_n, replay
-            if (F & TDE_F_NPC) { ag.route = r2.x; cx.route_n = r2.z; load_route_target(w, ag, cx); }
-            if (F & TDE_F_REPLAY) { ag.replay = r2.w; cx.replay_len = rec[3].x; }
-        }
-    } else if (F & TDE_F_REWARD) {
-        cx.n_wp = sc.y;
-        load_ego_target(w, er, cx);
-    }
-}
-
-// WaypointSuiteEnv.reset + set_start_pos + build_simulator's initial tensors for one env (ref gym_env.py:319-367,
-// 192-198, 241-247); every lane of the env runs it for its own slot.  Mirrors tde_reset_env of the oracle.
-// SPREAD (every caller: the lanes of an env enter together - the condition is per env): with A >= 8 the ego needs two
-// Philox blocks (counter words 0, 1) and every other lane block 0; lane a of the env computes block a - ONE evaluation -
-// and the words travel by wavefront shuffles (ds_bpermute): block 0 to every lane of the env, block 1 to its ego.  Same
-// counters, same words, same arithmetic behind them.
-// The ego's start (set_start_pos, ref gym_env.py:351-367) from the episode's random words: a point on the first waypoint segment,
-// a speed in [0, 10), the scenario's start heading + normal(0, 0.1) (:359-361: Box-Muller on the shared log / sincos
-// specifications); with TDE_F_EGO_ONLY_ATTRS also its attributes (:192-198).  pose = (x, y, psi, v), attr = (len, wid, lr, -).
-// (wp1_out / scn_out: the scenario's entry and its second waypoint - the first TARGET of the new episode, target_idx = 1 - which
-//  this function reads anyway: the one-step three-role kernel parks them in LDS so that the re-spawn path, the tail every launch
-//  waits for, starts with the ego's reward context in hand instead of behind two dependent look-ups)
-TDE_DEV void ego_spawn(const tde_config &cfg, const Cold &w, int scn, const uint4 &r0, const uint4 &r1, float4 &pose, float4 &attr,
-                       double2 *wp1_out = nullptr, int4 *scn_out = nullptr)
-{
-    const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
-    const double2 w0 = reinterpret_cast<const double2 *>(wp)[0], w1 = reinterpret_cast<const double2 *>(wp)[1];
-    const int4 se = reinterpret_cast<const int4 *>(w.scn)[scn];               // map, wp_n, start_heading, pad
-    if (wp1_out) *wp1_out = w1;
-    if (scn_out) *scn_out = se;
-    const double f = u01(r0.y);
-    const double sx = w0.x + f * (w1.x - w0.x);
-    const double sy = w0.y + f * (w1.y - w0.y);
-    const double speed = u01(r0.z) * 10.0;
-    const double psi0 = (double)__int_as_float(se.z) + (double)normal_f32(r1.z, r1.w) * 0.1;
-    pose = make_float4((float)sx, (float)sy, (float)psi0, (float)speed);
-    attr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (cfg.flags & TDE_F_EGO_ONLY_ATTRS)
-        attr = make_float4((float)(u01(r0.w) * (5.5 - 4.8) + 4.8), (float)(u01(r1.x) * (2.2 - 1.8) + 1.8),
-                           (float)(u01(r1.y) * (0.97 - 0.82) + 0.82), 0.0f);
-}
-
-// (DRAWN: the env's Philox blocks 0 and 1 for this episode were drawn by the caller - the one-step three-role kernel draws them
-//  ahead of the barrier behind which it learns whether the env finished, off the launch's tail)
-template <int A, bool SPREAD = true, bool DRAWN = false>
-TDE_DEV void reset_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er,
-                        uint4 d0 = make_uint4(0, 0, 0, 0), uint4 d1 = make_uint4(0, 0, 0, 0), const float4 *pre_ego = nullptr)
-{
-    uint32_t ep = (uint32_t)er.episode;
-    const uint32_t ge = w.env_base + (uint32_t)e;       // global env index keys the stream
-    const uint64_t seed = w.seed;
-    constexpr bool spread = (SPREAD && A >= 8 && A <= 64) || DRAWN;       // (A > 64: an env spans two wavefronts - no shuffles)
-    uint4 r0, r1s = make_uint4(0, 0, 0, 0);
-    if constexpr (DRAWN) {
-        r0 = d0; r1s = d1;
-    } else if constexpr (spread) {
-        const uint4 mine = philox(seed, ge, ep, (uint32_t)a, 0x7DEu);
-        const int first = (int)(threadIdx.x & 63) - a;   // the env's first lane in the wavefront
-        auto block = [&](int k) {
-            return make_uint4((uint32_t)__shfl((int)mine.x, first + k), (uint32_t)__shfl((int)mine.y, first + k),
-                              (uint32_t)__shfl((int)mine.z, first + k), (uint32_t)__shfl((int)mine.w, first + k));
-        };
-        r0 = block(0); r1s = block(1);
-    } else {
-        r0 = philox(seed, ge, ep, 0u, 0x7DEu);
-    }
-    int scn = (int)(((uint64_t)r0.x * (uint64_t)w.n_scn) >> 32);
-    er.scn = scn;
-    er.steps = 0;
-    er.target_idx = 1;
-    er.reached = 0;
-    er.episode = (int)(ep + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(w.spawn + ((int64_t)scn * A + a));
-    const float4 ss = rec[0], sa = rec[1];
-    const int4 si = reinterpret_cast<const int4 *>(rec)[2], sj = reinterpret_cast<const int4 *>(rec)[3];
-    ag.x = ss.x; ag.y = ss.y; ag.psi = ss.z; ag.v = ss.w;
-    ag.len = sa.x; ag.wid = sa.y; ag.lr = sa.z; ag.vdes = sa.w;
-    ag.route = si.x; ag.route_wp = si.y; ag.replay = si.w;
-    ag.present = sj.y != 0;
-    if (a == 0) {
-        uint4 r1 = r1s;
-        if constexpr (!spread) r1 = philox(seed, ge, ep, 1u, 0x7DEu);
-        float4 pose, attr;
-        if (pre_ego) { pose = pre_ego[0]; attr = pre_ego[1]; }
-        else ego_spawn(cfg, w, scn, r0, r1, pose, attr);
-        ag.x = pose.x; ag.y = pose.y; ag.psi = pose.z; ag.v = pose.w;
-        ag.present = true; ag.route = -1; ag.replay = -1; ag.vdes = 0.0f;
-        if (cfg.flags & TDE_F_EGO_ONLY_ATTRS) { ag.len = attr.x; ag.wid = attr.y; ag.lr = attr.z; }
-    }
-    ag.inv_lr = 1.0f / ag.lr;
-}
-
-// reset_lane + the slot's table entries (what load_ctx gives) for the one-step kernels' re-spawn path, which is the tail every
-// launch waits for: the spawn record carries the first route target (tde_spawn.tgx0 / tgy0) and the route / replay lengths, so
-// the only loads behind the scenario draw are the record itself, the scenario entry and - for the ego - its first waypoint
-// target: ONE round of independent loads instead of the chain record -> route table.  `want_map`: also the map descriptor.
-template <int A, bool DRAWN = false>
-TDE_DEV void respawn_lane(const tde_config &cfg, const Cold &w, int e, int a, Agent &ag, EnvRegs &er, Ctx &cx, bool want_map,
-                          uint4 d0 = make_uint4(0, 0, 0, 0), uint4 d1 = make_uint4(0, 0, 0, 0), const float4 *pre_ego = nullptr)
-{
-    reset_lane<A, true, DRAWN>(cfg, w, e, a, ag, er, d0, d1, pre_ego);
-    const uint32_t F = cfg.flags;
-    cx.tgx = cx.tgy = cx.tgx2 = cx.tgy2 = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0;
-    cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
-    const int4 sc = reinterpret_cast<const int4 *>(w.scn)[er.scn];          // map, wp_n, start_heading, pad
-    if (want_map && (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS))) cx.m = w.maps[sc.x];
-    const int route = ag.route, replay = ag.replay;
-    ag.route = -1; ag.replay = -1;
-    if (a > 0) {
-        const int4 *rec = reinterpret_cast<const int4 *>(w.spawn + ((int64_t)er.scn * A + a));   // (the lines reset_lane just read)
-        const int4 r2 = rec[2], r3 = rec[3];                                 // route, route_wp, route_n, replay | replay_len, present, tgx0, tgy0
-        if (F & TDE_F_NPC) { ag.route = route; cx.route_n = r2.z; cx.tgx = __int_as_float(r3.z); cx.tgy = __int_as_float(r3.w); }
-        if (F & TDE_F_REPLAY) { ag.replay = replay; cx.replay_len = r3.x; }
-    } else if (F & TDE_F_REWARD) {
-        cx.n_wp = sc.y;
-        load_ego_target(w, er, cx);
-    }
-}
-
-// heuristic NPC controller (R14 slot), mirrors tde_npc_action of the oracle; reads the tile (= pre-step state).
-// Two phases: a branch-free sweep over the A slots with the cheap tests that almost every slot fails (ahead of me?
-// close enough to cap my speed? inside the widest corridor?) builds a candidate bit mask; the exact lane / yield-cone
-// tests then run only for the set bits, every lane walking its own list (the wavefront iterates
-// max-over-lanes(popcount) times, usually 0-2).  Skipped slots cannot change the result, so the action keeps every
-// bit of the oracle's full sweep.
-// ra / rb: the a / b tile rows of the lane's env (slot 0 first).
-// npc_gap: the leader gap over the A rows at ra / rb.  `i` = the lane's own slot RELATIVE to ra (outside [0, A) when the rows are
-// the other half of a 128-slot env: it is then only the "not taken" stand-in row and the j < i operand), `own_bit` = its bit in the
-// candidate mask (0 when it is not among these rows).
-template <int A>
-TDE_DEV float npc_gap(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, typename MaskOf<A>::type own_bit, const Agent &ag,
-                      float cp, float sp, bool has_target, float g_far)
-{
-    using mask_t = typename MaskOf<A>::type;
-    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
-    mask_t cand = 0;
-    const float hl_i = 0.5f * ag.len;
-    if (has_target) {
-        // Conservative forms of the exact tests below: a slot that passes there passes here.  The prefilter only has to
-        // be a superset, so it is free to round differently: the forward / lateral offsets are bilinear forms evaluated
-        // with fused multiply-adds (|error| < 1e-3 m for |coordinates| < 1e4 m) and every condition is relaxed by 1 cm,
-        // folded into the constants so that each is a plain sign test:
-        //   ahead            f' = fj + 0.01                                   > 0
-        //   gap < g_far      n  = reach_j - f' + (g_far + hl_i + 0.05 + 0.02) > 0      (reach_j >= hl_j)
-        //   widest corridor  w  = max(cone_k, 0) * f' + (halfw_j + 0.01) - |lj| > 0    (tile row a.w = halfw_j + 0.01)
-        // verdict = max3(-f', -n, -w): negative (sign bit set) <=> all three hold.
-        const float nP = 0.01f - (ag.x * cp + ag.y * sp), nQ = -(ag.y * cp - ag.x * sp);
-        const float L = (g_far + hl_i) + 0.07f;
-        const float kc = fmaxf(cfg.npc_cone_k, 0.0f);
-        // (the rows as two 8-byte halves fetched at different stages: 3.63 vs 3.67 us; with 16-byte reads like the
-        //  collision sweep 3.25 vs 3.19, profiles/r02_d_ab_diet_steps.txt H1 / Q2)
-        cand = sweep_blocks_halves<A>(ra, [&](float2 (&xy)[C], float2 (&zw)[C], float (&v)[C], auto &&prefetch_xy, auto &&prefetch_zw) {
-            float f[C], l[C], n[C], w[C];
-#pragma unroll
-            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(xy[j].y, sp, nP); l[j] = __builtin_fmaf(-xy[j].x, sp, nQ); }
-            pin(f, l);
-#pragma unroll
-            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(xy[j].x, cp, f[j]); l[j] = __builtin_fmaf(xy[j].y, cp, l[j]); }
-            pin(f, l);
-            pin_memory();
-            prefetch_xy();                                     // the positions are consumed: fetch the next block's
-            pin_memory();
-#pragma unroll
-            for (int j = 0; j < C; ++j) { n[j] = zw[j].x - f[j]; w[j] = __builtin_fmaf(kc, f[j], zw[j].y); }
-            pin(n, w);
-            pin_memory();
-            prefetch_zw();
-            pin_memory();
-#pragma unroll
-            for (int j = 0; j < C; ++j) { n[j] = n[j] + L; w[j] = w[j] - fabsf(l[j]); }
-            pin(n, w);
-#pragma unroll
-            for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
-            pin(v);
-        });
-        cand &= ~own_bit;
-    }
-    float gap = 1e30f;
-    // exact tests of the candidates; every lane walks its own list, so the wavefront makes max-over-lanes(count) trips
-    // (3.8 on average for 0.9 candidates per lane: the busiest lane of 64 follows a platoon).  TWO candidates per trip:
-    // two independent chains per lane - a lone wavefront issues independent instructions twice as fast as dependent
-    // ones - and ceil(count / 2) trips (2.2).  A lane with fewer candidates tests its own row instead, which cannot be
-    // taken (fj = 0).
-    while (__ballot(cand != 0)) {
-        const mask_t c1 = cand & (cand - 1);
-        int j[2];
-        j[0] = cand ? row_of_bit<A>(lowest_bit(cand)) : i;
-        j[1] = c1 ? row_of_bit<A>(lowest_bit(c1)) : i;
-        cand = c1 & (c1 - 1);
-        // the two tests stage by stage (pins as in the sweeps: left alone, the scheduler runs them one after the other)
-        float4 pj[2], qj[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { pj[u] = ra[j[u]]; qj[u] = rb[j[u]]; }
-        float ex[2], ey[2], fj[2], lj[2], hd[2], halfw[2], t0[2], t1[2], g[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { ex[u] = pj[u].x - ag.x; ey[u] = pj[u].y - ag.y; }
-        pin(ex, ey);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { fj[u] = ex[u] * cp; t0[u] = ey[u] * sp; lj[u] = ey[u] * cp; t1[u] = ex[u] * sp; }
-        pin(fj, t0);
-        pin(lj, t1);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            fj[u] = fj[u] + t0[u]; lj[u] = lj[u] - t1[u];
-            hd[u] = cp * qj[u].x; t0[u] = sp * qj[u].y;
-            halfw[u] = cfg.npc_lane_half + qj[u].w;        // = npc_lane_half + 0.5f * wid_j (qj.w = hw_j = 0.5f * wid_j)
-            g[u] = hl_i + qj[u].z;                         // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit
-        }
-        pin(fj, lj);
-        pin(hd, t0);
-        pin(halfw, g);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { hd[u] = hd[u] + t0[u]; t1[u] = cfg.npc_cone_k * fj[u]; g[u] = fj[u] - g[u]; }
-        pin(hd, t1);
-        pin(g);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) t1[u] = halfw[u] + t1[u];
-        pin(t1);
-        // the predicates as SIGN BITS of correctly rounded differences (a < b <=> sign(a - b); exact, gradual underflow),
-        // combined with bitwise and / or and blended in with v_bfi: a v_cmp -> s_and -> v_cndmask chain through SGPR
-        // pairs costs a lone wavefront ~24 cycles per link, six compares per candidate
-        int tk[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float al = fabsf(lj[u]);
-            const int inlane = __float_as_int(al - halfw[u]);                  // al < halfw
-            const int c1 = __float_as_int(al - t1[u]);                         // al < halfw + cone_k * fj
-            const int c2 = __float_as_int(fj[u] - cfg.npc_cone_range);         // fj < cone_range
-            const int c3 = __float_as_int(-0.5f - hd[u]);                      // hd > -0.5
-            const int c4 = j[u] - i;                                           // j < i
-            const int ahead = __float_as_int(0.0f - fj[u]);                    // fj > 0 (0 - fj: +0 for fj = +-0)
-            tk[u] = (((c1 & c2) & (c3 & c4)) | inlane) & ahead;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t m = (uint32_t)(tk[u] >> 31);                        // all ones: taken
-            g[u] = __uint_as_float((m & __float_as_uint(g[u])) | (~m & __float_as_uint(1e30f)));
-        }
-        gap = fminf(gap, fminf(g[0], g[1]));
-    }
-    return gap;
-}
-
-// the controller's action from the leader gap
-TDE_DEV void npc_act_of_gap(const tde_config &cfg, const Agent &ag, float cp, float sp, bool has_target, float tgx, float tgy, float gap,
-                            float red_gap, float &acc, float &beta)
-{
-    const float amax = cfg.npc_max_accel, smax = cfg.npc_max_steer;
-    if (!has_target) {
-        acc = clampf(cfg.npc_k_speed * (0.0f - ag.v), -amax, amax);
-        beta = 0.0f;
-        return;
-    }
-    const float dx = tgx - ag.x, dy = tgy - ag.y;
-    const float fwd = dx * cp + dy * sp;
-    const float lat = dy * cp - dx * sp;
-    const float dist = sqrt_cr_f32(dx * dx + dy * dy);
-    const float sin_err = lat / fmaxf(dist, 1e-3f);
-    beta = (fwd < 0.0f) ? copysignf(smax, lat) : clampf(cfg.npc_k_steer * sin_err, -smax, smax);
-    gap = fminf(gap, red_gap);
-    const float vd = fminf(ag.vdes, sqrt_cr_f32(amax * fmaxf(gap - cfg.npc_gap_s0, 0.0f)));
-    acc = clampf(cfg.npc_k_speed * (vd - ag.v), -amax, amax);
-}
-
-template <int A>
-TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp,
-                        float sp, bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc,
-                        float &beta)
-{
-    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far);
-    npc_act_of_gap(cfg, ag, cp, sp, has_target, tgx, tgy, gap, red_gap, acc, beta);
-}
-
-// R9 for one slot against the A slots of its env (rows ra / rb).  Overlapping convex boxes have centres closer than the
-// sum of their circumradii; hl+hw >= circumradius, so a pair beyond (ri+rj)^2 * 1.001 cannot pass the SAT test, in exact
-// or in fp32 arithmetic (the 1.001 is folded into the radii, kReach).  Phase 1 marks the pairs inside that radius
-// (branch-free, free to fuse its multiply-adds), phase 2 runs the 4-axis SAT test on the marked ones only.
-// Called by all lanes of the wavefront, converged.
-// collide_part: against the A rows at ra / rb; `own_bit` = the lane's own slot's bit in the candidate mask (0: not among these rows)
-template <int A>
-TDE_DEV bool collide_part(const float4 *ra, const float4 *rb, typename MaskOf<A>::type own_bit, bool live, float x, float y, float c, float s,
-                          float hl, float hw, float ri)
-{
-    using mask_t = typename MaskOf<A>::type;
-    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
-    mask_t cand = 0;
-    if (live) {
-        // verdict = d^2 - (ri + rj)^2: negative <=> inside the sum of the (padded) circumradii
-        cand = sweep_blocks<A>(ra, [&](float4 (&r)[C], float (&v)[C], auto &&prefetch) {
-            float dx[C], dy[C], rr[C];
-#pragma unroll
-            for (int j = 0; j < C; ++j) { dx[j] = r[j].x - x; dy[j] = r[j].y - y; rr[j] = ri + r[j].z; }
-            // the fourth component is not needed, but a 12-byte ds_read_b96 occupies the LDS array for 8 cycles per
-            // wavefront and a 16-byte ds_read_b128 for 4: keep the row a full 16-byte read
-#pragma unroll
-            for (int j = 0; j < C; ++j) asm volatile("" :: "v"(r[j].w));
-            pin(dx, dy);
-            pin(rr);
-            pin_memory();
-            prefetch();
-            pin_memory();
-#pragma unroll
-            for (int j = 0; j < C; ++j) dy[j] = dy[j] * dy[j];
-            pin(dy);
-#pragma unroll
-            for (int j = 0; j < C; ++j) dx[j] = __builtin_fmaf(dx[j], dx[j], dy[j]);
-            pin(dx);
-#pragma unroll
-            for (int j = 0; j < C; ++j) v[j] = __builtin_fmaf(-rr[j], rr[j], dx[j]);
-            pin(v);
-        });
-        cand &= ~own_bit;
-    }
-    bool hit = false;
-    while (__ballot(cand != 0)) {
-        if (cand) {
-            const int j = row_of_bit<A>(lowest_bit(cand));
-            cand &= cand - 1;
-            const float4 pj = ra[j], qj = rb[j];
-            hit = hit | obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
-        }
-    }
-    return hit;
-}
-
-template <int A>
-TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
-                          float hl, float hw, float ri)
-{
-    return collide_part<A>(ra, rb, bit_of_row<A>(a), live, x, y, c, s, hl, hw, ri);
-}
-
-// ---- more than 64 slots per env (A = 128: the reference assembles up to ~100 agents, gym_env.py:216-237) -------------------
-// An env then spans two wavefronts of a workgroup and its rows are swept as TWO HALVES of 64 with the forms above (a 64-bit
-// candidate mask per half, the exact tests on the set bits): the lane's own slot is a bit of one of the halves, the leader gap
-// is the minimum over both (a minimum of the same values in another order: same bits), the collision flag their OR.
-// (round 4's first form walked every row with the exact tests: 43 us per step at ~ 120 agents per env against the masks' 11,
-//  profiles/r04_y_wide_times.txt)
-template <int A>
-TDE_DEV void npc_action_wide(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp, float sp,
-                             bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc, float &beta)
-{
-    static_assert(A == 128, "two halves of 64 rows");
-    const unsigned long long own = 1ull << (63 - (i & 63));
-    const float g0 = npc_gap<64>(cfg, ra, rb, i, i < 64 ? own : 0ull, ag, cp, sp, has_target, g_far);
-    const float g1 = npc_gap<64>(cfg, ra + 64, rb + 64, i - 64, i < 64 ? 0ull : own, ag, cp, sp, has_target, g_far);
-    npc_act_of_gap(cfg, ag, cp, sp, has_target, tgx, tgy, fminf(g0, g1), red_gap, acc, beta);
-}
-
-template <int A>
-TDE_DEV bool collide_rows_wide(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s, float hl,
-                               float hw, float ri)
-{
-    static_assert(A == 128, "two halves of 64 rows");
-    const unsigned long long own = 1ull << (63 - (a & 63));
-    const bool h0 = collide_part<64>(ra, rb, a < 64 ? own : 0ull, live, x, y, c, s, hl, hw, ri);
-    const bool h1 = collide_part<64>(ra + 64, rb + 64, a < 64 ? 0ull : own, live, x, y, c, s, hl, hw, ri);
-    return h0 | h1;
-}
-
-// The same for 16 slots per env when the wavefront's lane l holds slot l % 16 of its env, i.e. an env is one 16-lane DPP
-// row (three-role kernels).  The circumradius test of a pair is symmetric - both lanes would compute the same bits - so
-// each lane tests only the eight slots AHEAD of it in the row (offsets 1..8, slot index mod 16) and hands the verdict to
-// the partner: the neighbour's (x, y, reach) arrive through the DPP row-rotate operand of the subtract / add itself
-// (v_sub_f32_dpp ... row_ror), the partner's copy of the verdict through one v_mov_b32_dpp.  8 x 6 + 15 x 1 + 7 VALU
-// instead of 16 x 7, and no LDS read (16 ds_read_b128 = 64 LDS-array cycles per wavefront and step).
-// Candidate mask: bit 15 - o for offsets o = 1..8, bit o - 9 for o = 9..15 (the order the verdicts become available).
-// The exact tests read the candidate's rows from LDS as before.  All 64 lanes must be active.
-#ifndef TDE_COLLIDE_DPP
-#define TDE_COLLIDE_DPP 1
-#endif
-template <int N> TDE_DEV float dpp_row_ror(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
-}
-TDE_DEV bool collide_rows_dpp16(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s,
-                                float hl, float hw, float ri)
-{
-    uint32_t fwd = 0, bwd = 0;
-    auto offset = [&](auto dtag) {
-        constexpr int D = decltype(dtag)::value;
-        // lane l receives the registers of lane l + D of its row: rotate right by 16 - D
-        const float dx = dpp_row_ror<16 - D>(x) - x, dy = dpp_row_ror<16 - D>(y) - y, rr = dpp_row_ror<16 - D>(ri) + ri;
-        const float dy2 = dy * dy;
-        const float d2 = __builtin_fmaf(dx, dx, dy2);
-        const float v = __builtin_fmaf(-rr, rr, d2);       // negative <=> inside the sum of the (padded) circumradii
-        fwd = push_sign(fwd, v);
-        if constexpr (D < 8) bwd = push_sign(bwd, dpp_row_ror<D>(v));   // the verdict of the pair (l - D, l), for lane l
-    };
-    offset(std::integral_constant<int, 1>{}); offset(std::integral_constant<int, 2>{});
-    offset(std::integral_constant<int, 3>{}); offset(std::integral_constant<int, 4>{});
-    offset(std::integral_constant<int, 5>{}); offset(std::integral_constant<int, 6>{});
-    offset(std::integral_constant<int, 7>{}); offset(std::integral_constant<int, 8>{});
-    // fwd: offset D at bit 8 - D; bwd: offset 16 - D at bit 7 - D
-    uint32_t cand = live ? ((fwd << 7) | bwd) : 0u;
-    bool hit = false;
-    while (__ballot(cand != 0)) {
-        if (cand) {
-            const int b = lowest_bit(cand);
-            cand &= cand - 1;
-            const int o = b < 7 ? 9 + b : 15 - b;
-            const int j = (a + o) & 15;
-            const float4 pj = ra[j], qj = rb[j];
-            hit = hit | obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w);
-        }
-    }
-    return hit;
-}
-
-// hl + hw bounds the circumradius; kReach^2 >= 1.001 keeps the circle test a superset of the SAT test in fp32
-constexpr float kReach = 1.0005f;
-
-struct StepOut {
-    float reward;
-    uint8_t terminated, truncated, collided, offroad, tl;
-    bool respawned;
-    int k;                      // environment_steps of this step (before any re-spawn zeroes the counter)
-};
-
-// lights of map m that are red at env step k (the cycle restarts with the episode)
-TDE_DEV uint32_t red_mask(const tde_world &w, const tde_map &m, int k)
-{
-    if (m.cycle_steps <= 0) return 0u;
-    const int t = k % m.cycle_steps;
-    uint32_t red = 0;
-    for (int p = 0; p < m.n_phase; ++p) {
-        const tde_light_phase ph = w.phases[m.phase_base + p];
-        if (t < ph.end_step) { red = ph.red_mask; break; }
-    }
-    return red;
-}
-
-// red(k) and red(k + 1) with the phase table fetched as ONE round of independent loads (four entries per round): the one-step
-// kernels have no step loop to keep a window across, and red_mask's early-exit loop is a chain of dependent L2 round trips
-TDE_DEV void red_mask_pair(const tde_world &w, const tde_map &m, int k, uint32_t &r0, uint32_t &r1)
-{
-    r0 = r1 = 0u;
-    if (m.cycle_steps <= 0) return;
-    const int t0 = k % m.cycle_steps;
-    const int t1 = (t0 + 1 == m.cycle_steps) ? 0 : t0 + 1;
-    bool f0 = false, f1 = false;
-    for (int p = 0; p < m.n_phase; p += 4) {
-        tde_light_phase ph[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ph[u] = w.phases[m.phase_base + (p + u < m.n_phase ? p + u : m.n_phase - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (p + u < m.n_phase) {
-                if (!f0 && t0 < ph[u].end_step) { r0 = ph[u].red_mask; f0 = true; }
-                if (!f1 && t1 < ph[u].end_step) { r1 = ph[u].red_mask; f1 = true; }
-            }
-        }
-    }
-}
-
-// The red mask only changes at phase boundaries: the persistent kernels keep it with the window of env steps [lo, hi)
-// it holds for (red is a function of the map and the env step; a re-spawn may change the map: invalidate()).
-struct RedCache {
-    uint32_t red;
-    int lo, hi;
-    TDE_DEV void invalidate() { lo = hi = 0; }
-};
-
-TDE_DEV uint32_t red_mask_cached(const tde_world &w, const tde_map &m, int k, RedCache &rc)
-{
-    if (k >= rc.lo && k < rc.hi) return rc.red;
-    rc.red = 0u; rc.lo = k; rc.hi = k + 1;
-    if (m.cycle_steps <= 0) { rc.lo = 0; rc.hi = 0x7fffffff; return 0u; }
-    const int t = k % m.cycle_steps;
-    int begin = 0;
-    for (int p = 0; p < m.n_phase; ++p) {
-        const tde_light_phase ph = w.phases[m.phase_base + p];
-        if (t < ph.end_step) { rc.red = ph.red_mask; rc.lo = k - (t - begin); rc.hi = k + (ph.end_step - t); break; }
-        begin = ph.end_step;
-    }
-    return rc.red;
-}
-
-#ifndef TDE_RED_GAP_WIDE
-#define TDE_RED_GAP_WIDE 1          // 0: the stop-line loops a line at a time (A/B)
-#endif
-// compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
-// is red.  Mirrors tde_tl_violation of the oracle.
-// `line(i, a, b)` fetches stop line i of the map: (x, y, cos, sin) and (hl, hw, light, -)
-template <typename L>
-TDE_DEV bool tl_violation_of(const L &line, int n_stop, uint32_t red, float x, float y, float c, float s, float hl, float hw)
-{
-    bool v = false;
-#if TDE_RED_GAP_WIDE
-    if (red) {
-        // four lines per trip like red_line_gap_of: the reach tests side by side, the four-axis test for the lines in reach (rare)
-        for (int k0 = 0; k0 < n_stop; k0 += 4) {
-            float4 a[4], b[4];
-            if (k0 < L::kCached) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
-            }
-            bool near[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float dx = a[u].x - x, dy = a[u].y - y, rr = ((hl + hw) + (b[u].x + b[u].y)) * kReach;
-                near[u] = (k0 + u < n_stop) && ((red >> __float_as_int(b[u].z)) & 1u) && dx * dx + dy * dy < rr * rr;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (near[u]) v = v || obb_overlap(x, y, c, s, hl, hw, a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y);
-        }
-    }
-    return v;
-#endif
-    if (red) {
-        for (int i = 0; i < n_stop; ++i) {
-            float4 a, b;
-            line(i, a, b);
-            if ((red >> __float_as_int(b.z)) & 1u) {
-                // circumradius reject first, as in collide_rows (overlapping boxes have centres closer than the sum of their
-                // padded circumradii, in exact and in fp32 arithmetic): the ego is rarely within reach of a stop line, and
-                // the four-axis test is 40 instructions that the contended judge wavefront then never issues
-                const float dx = a.x - x, dy = a.y - y, rr = ((hl + hw) + (b.x + b.y)) * kReach;
-                if (dx * dx + dy * dy < rr * rr) v = v || obb_overlap(x, y, c, s, hl, hw, a.x, a.y, a.z, a.w, b.x, b.y);
-            }
-        }
-    }
-    return v;
-}
-
-struct GlobalLines {
-    static constexpr int kCached = 0;
-    const tde_stopline *base;
-    TDE_DEV void operator()(int i, float4 &a, float4 &b) const
-    {
-        a = reinterpret_cast<const float4 *>(base + i)[0];
-        b = reinterpret_cast<const float4 *>(base + i)[1];
-    }
-    TDE_DEV void global(int i, float4 &a, float4 &b) const { (*this)(i, a, b); }
-    TDE_DEV void cached(int i, float4 &a, float4 &b) const { (*this)(i, a, b); }
-};
-
-TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, uint32_t red, float x, float y, float c, float s,
-                          float hl, float hw)
-{
-    return tl_violation_of(GlobalLines{w.stoplines + m.stop_base}, m.n_stop, red, x, y, c, s, hl, hw);
-}
-
-// gap to a red stop line ahead in the own lane (same travel direction), treated as a standing leader by the NPC
-// controller.  Mirrors the stop-line loop of the oracle's tde_npc_action.
-template <typename L>
-TDE_DEV float red_line_gap_of(const tde_config &cfg, const L &line, int n_stop, uint32_t red, const Agent &ag, float cp,
-                              float sp)
-{
-    float gap = 1e30f;
-#if TDE_RED_GAP_WIDE
-    // four lines per trip, all fetched first, the four tests side by side and branch-free (a minimum over the same values in
-    // another order: same bits): on the driver's chain a line at a time was four dependent LDS round trips with a branch each
-    for (int k0 = 0; k0 < n_stop; k0 += 4) {
-        float4 a[4], b[4];
-        // (a trip lies wholly inside or wholly outside the LDS cache - its size is a multiple of four: one address space per
-        //  trip.  Left to choose per line, the compiler forms a select of an LDS and a global ADDRESS and the backend rejects it)
-        if (k0 < L::kCached) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float ex = a[u].x - ag.x, ey = a[u].y - ag.y;
-            const float fj = ex * cp + ey * sp;
-            const float lj = ey * cp - ex * sp;
-            const float hd = cp * a[u].z + sp * a[u].w;
-            const float g = fj - 0.5f * ag.len;
-            const bool on = (k0 + u < n_stop) && ((red >> __float_as_int(b[u].z)) & 1u) && g > 0.0f && fabsf(lj) < b[u].y && hd > 0.5f;
-            gap = on ? fminf(gap, g + cfg.npc_gap_s0 - 1.0f) : gap;
-        }
-    }
-#else
-    for (int k = 0; k < n_stop; ++k) {
-        float4 a, b;
-        line(k, a, b);
-        if (!((red >> __float_as_int(b.z)) & 1u)) continue;
-        const float ex = a.x - ag.x, ey = a.y - ag.y;
-        const float fj = ex * cp + ey * sp;
-        const float lj = ey * cp - ex * sp;
-        const float hd = cp * a.z + sp * a.w;
-        const float g = fj - 0.5f * ag.len;
-        if (g > 0.0f && fabsf(lj) < b.y && hd > 0.5f) gap = fminf(gap, g + cfg.npc_gap_s0 - 1.0f);
-    }
-#endif
-    return gap;
-}
-
-TDE_DEV float red_line_gap(const tde_config &cfg, const tde_world &w, const tde_map &m, uint32_t red, const Agent &ag,
-                           float cp, float sp)
-{
-    return red_line_gap_of(cfg, GlobalLines{w.stoplines + m.stop_base}, m.n_stop, red, ag, cp, sp);
-}
-
-TDE_DEV void write_tile_slot(float4 &ta, float4 &tb, bool live, const Agent &ag, float c, float s, float lane_half)
-{
-    const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
-    // a: what the branch-free sweeps read (position, reach = padded hl + hw, lane half width + 1 cm of prefilter slack);
-    // b: the rest of what the exact tests need (heading, half extents)
-    ta = live ? make_float4(ag.x, ag.y, (hl + hw) * kReach, (lane_half + hw) + 0.01f) : make_float4(kFar, kFar, 0.0f, 0.0f);
-    tb = make_float4(c, s, hl, hw);
-}
-
-// One timestep for this lane's agent slot.  WaypointSuiteEnv.step over GymEnv.step, ref gym_env.py:369-389,115-120.
-// On entry the tile holds the current state of every slot and (c0, s0) = (cos psi, sin psi) of this slot; both are
-// kept up to date on exit.  `act_acc/act_steer` are the ego action of this lane's env (used by slot 0).
-// Called by all BLOCK lanes of the workgroup, converged (contains barriers and wave ballots).
-// LIGHTS: compiled with the traffic-light code (stop-line violation of the ego, NPCs stopping at red lines); the
-// kernels without it serve configs that have no lights at zero cost.
-#ifndef TDE_SOLO_MAG_LEAN
-#define TDE_SOLO_MAG_LEAN 1         // the one-role kernel's magnitudes section with the low-register scan too (A/B)
-#endif
-template <int A, int BLOCK, bool LIGHTS, bool BIG = false, bool MAG = false>
-TDE_DEV StepOut step_lane(const tde_config &cfg, const tde_world &w, const Cold &cold, const tde_state &st,
-                          Tiles<BLOCK> &t, int e, int a, bool valid, Agent &ag, EnvRegs &er, Ctx &cx, float &c0,
-                          float &s0, float act_acc, float act_steer, float *mag_out = nullptr)
-{
-    using mask_t = typename MaskOf<A>::type;
-    const uint32_t F = cfg.flags;
-    const int tid = threadIdx.x;
-    const int base = tid - a;                       // first lane of this env inside the workgroup
-    bool live = valid && ag.present;
-    const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-    StepOut out{0.0f, 0, 0, 0, 0, 0, false, 0};
-
-    er.steps += 1;                                  // :116
-    const int k = er.steps;
-    out.k = k;
-
-    // replayed agents take their recorded state at time k (:275-283); issue the read ahead of the sweeps
-    const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
-    float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-
-    // ---- actions: ego from outside, NPC slots from the controller (reads the tile = pre-step state) ---------------
-    const float lx = ag.x, ly = ag.y, lpsi = ag.psi, lv = ag.v;   // :371-375 last_x, last_y, last_psi, last_speed
-    const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-    float acc = 0.0f, beta = 0.0f;
-    if (a == 0) { acc = act_acc; beta = act_steer; }
-    const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask(w, cx.m, k) : 0u;
-    if (F & TDE_F_NPC) {
-        float na, nb;
-        const float red_gap = (LIGHTS && red && has_target) ? red_line_gap(cfg, w, cx.m, red, ag, c0, s0) : 1e30f;
-        if constexpr (A > 64) npc_action_wide<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
-        else npc_action<A>(cfg, &t.a[base], &t.b[base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
-        // (first step of an episode: the NPCs coast unless TDE_F_NPC_FIRST_STEP asks for the reference's behaviour, tde_abi.h)
-        if (npc && (k > 1 || (F & TDE_F_NPC_FIRST_STEP))) { acc = na; beta = nb; }
-    }
-
-    if (live) {
-        bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);          // :117
-        if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
-    }
-    bool switched = false;
-    if (has_target) {
-        const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
-        if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { ag.route_wp += 1; switched = true; }
-    }
-
-    // ---- post-step tile: collision sweep now, NPC controller next step -----------------------------------------
-    sincos_f32(ag.psi, s0, c0);
-    const float hl = 0.5f * ag.len, hw = 0.5f * ag.wid;
-    const float ri = (hl + hw) * kReach;
-    // One-step launches of up to 16 slots per env read the corners' classes from the 2-bit class map (tde_device.h: 17.0 -> 12.1 MB
-    // of HBM / fabric traffic per step at 8192 x 16, same time); at 32 slots per env the extra round trip of the MIXED corners
-    // costs 0.55 us of the launch's tail (15.85 -> 16.43 us, profiles/r03_f_step_cls2_ab.txt) and the cell words stay.
-    // (BIG - a large grid, tde_world.hints: the cell words of a town are 66 MB per km^2 and the class map wins at any A)
-    constexpr bool kStepCls2 = (BLOCK == kBlock) && TDE_STEP_CLS2 && (A <= 16 || BIG);
-    Corners corners;                                // cell words of the four corners: loads stay in flight during
-    if (F & TDE_F_OFFROAD)                          // the collision sweep
-        offroad_issue<kStepCls2>(w, cx.m, live, ag.x, ag.y, c0, s0, hl, hw, corners);
-    tile_sync<A>();                                 // every lane is done reading the pre-step tile
-    write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
-    tile_sync<A>();
-    bool hit;
-    if constexpr (A > 64) hit = collide_rows_wide<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
-    else hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, ag.x, ag.y, c0, s0, hl, hw, ri);
-    // the next route waypoint is fetched while the offroad test runs
-    if (switched) load_route_target(cold, ag, cx);
-
-    bool off = false;
-    // (one-step launches end with their slowest wavefront: two candidate records per trip there, tde_device.h)
-    if (F & TDE_F_OFFROAD) off = offroad_resolve<BLOCK == kBlock, kStepCls2>(w, corners, thr2_of(cfg), cx.m.rec_base);
-    out.collided = hit ? 1 : 0;
-    out.offroad = off ? 1 : 0;
-
-    bool tl = false;
-    if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid) {
-        tl = tl_violation(w, cx.m, red, ag.x, ag.y, c0, s0, hl, hw);
-    }
-    out.tl = tl ? 1 : 0;
-
-    // ---- reward / termination on the ego lane; the env's other lanes learn "done" from the wave ballot ----------
-    if (F & TDE_F_REWARD) {
-        int done = 0;
-        if (a == 0 && valid) {
-            const int ti0 = er.target_idx;
-            RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, ag.x, ag.y, ag.psi, ag.v, off, hit,
-                                      tl, k, er.target_idx, er.reached, st.info != nullptr);
-            out.reward = r.reward;
-            out.terminated = r.terminated;
-            out.truncated = r.truncated;
-            if (st.info) {
-                double *inf = st.info + 4 * (int64_t)e;
-                inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
-            }
-            if (st.info_reached) st.info_reached[e] = er.reached;
-            done = (r.terminated | r.truncated) ? 1 : 0;
-            // (a finished env reloads it when it re-spawns; without TDE_F_AUTORESET there is no re-spawn to do so)
-            if (er.target_idx != ti0 && (!done || !(F & TDE_F_AUTORESET))) load_ego_target(cold, er, cx);
-        }
-        if (F & TDE_F_AUTORESET) {
-            // wave ballot of the ego lanes' termination flags: the reset path is skipped by wavefronts in which no
-            // env finished; otherwise each lane looks up the bit of its env's ego lane
-            unsigned long long any;
-            bool mine;
-            if constexpr (A > 64) {                 // the env spans two wavefronts: its flag travels through LDS
-                if (a == 0) t.wide_done[tid / A] = done;
-                lds_barrier();
-                mine = t.wide_done[tid / A] != 0;
-                any = mine ? 1ull : 0ull;
-            } else {
-                any = __ballot(done);
-                mine = ((any >> ((tid & 63) - a)) & 1ull) != 0;
-            }
-            if (any) {
-                if (mine && valid) {
-                    respawn_lane<A>(cfg, cold, e, a, ag, er, cx, true);
-                    out.respawned = true;
-                    live = ag.present;
-                    sincos_f32(ag.psi, s0, c0);
-                    // (only this lane reads its slot until the next step's first barrier...  MAG - the one-step kernel with
-                    //  tde_state.magnitudes - has no next step, and its magnitudes section reads the rows of THIS step at the end)
-                    if constexpr (!MAG) write_tile_slot(t.a[tid], t.b[tid], live, ag, c0, s0, cfg.npc_lane_half);
-                }
-            }
-        }
-    }
-    tile_sync<A>();                                 // ...so the tile is consistent for the next step's controller
-    return out;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// kernels
-// ------------------------------------------------------------------------------------------------------------------
-// (A = 128: wavefronts per SIMD the one-role kernels are compiled for - registers per lane 512 / that)
-#ifndef TDE_WIDE_WAVES
-#define TDE_WIDE_WAVES 3
-#endif
-// one launch = one timestep of every env
-// OBS: also writes the compact observation (tde_state.obs); a template flag because the code, taken or not, costs the
-// plain kernel 0.9 us per launch (it keeps the ego target and the heading's sin/cos alive to the end)
-// WAVES (A = 128 only): the wavefronts per SIMD the kernel is compiled for - 3 (133 VGPRs, no spills) for batches of one residency
-// round, 4 (128 VGPRs, 16 spilled) above 1536 envs, where a fourth resident wavefront is worth more than the spills cost
-// (us per step at 256 / 1024 / 2048 / 4096 envs of ~122 agents: 15.7 / 18.2 / 33.1 / 51.2 against 16.7 / 20.3 / 28.3 / 48.5,
-//  profiles/r04_z_wide_waves.txt)
-// MAG: also writes tde_state.magnitudes (a template flag for the same reason: 84 -> 128 VGPRs with the code in it)
-template <int A, bool LIGHTS, bool OBS, bool BIG = false, int WAVES = TDE_WIDE_WAVES, bool MAG = false>
-__global__ __launch_bounds__(kBlock, A > kWave ? WAVES : 1) void env_step_kernel(tde_config cfg, tde_world w, tde_state st,
-                                                          const float *__restrict__ action, float *reward_k,
-                                                          uint8_t *done_k)
-{
-    __shared__ Tiles<kBlock> t;
-    __shared__ Cold cold;
-    if (threadIdx.x == 0) fill_cold(cold, cfg, w);
-    __syncthreads();
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int e = (int)(g / A), a = (int)(g % A);
-    const bool valid = e < st.B;
-    const int64_t gs = valid ? g : 0;
-    const int es = valid ? e : 0;
-    Agent ag;
-    load_agent(st, gs, ag);
-    if (!valid) ag.present = false;
-    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
-    Ctx cx;
-    // (the one-role kernel does not use the lookup caches even when they are there: read in its prologue and kept like the
-    //  three-role kernel keeps them they made it SLOWER - 8192 x 16: 10.4 -> 11.0 us, configs[4] on three streams 42.4 -> 44.3 -
-    //  for 6 MB more traffic per step: its wavefronts have the whole serial step ahead of them, the table chain is not what
-    //  they wait for.  profiles/r03_f_solo_with_caches.txt)
-    load_ctx<A>(cfg, cold, a, ag, er, cx);
-    const float2 act = reinterpret_cast<const float2 *>(action)[es];
-    float c0, s0;
-    sincos_f32(ag.psi, s0, c0);
-    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
-    tile_sync<A>();
-    const int map0 = cx.map_id;                     // (MAG: the map of the episode that is being stepped; a re-spawn replaces cx)
-    StepOut o = step_lane<A, kBlock, LIGHTS, BIG, MAG>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y, st.magnitudes);
-    const unsigned long long hit_m = MAG ? __ballot(o.collided != 0) : 0ull, off_m = MAG ? __ballot(o.offroad != 0) : 0ull;
-    if (valid) {
-        store_agent_dynamic(st, g, ag);
-        if (o.respawned) store_agent_static(st, g, ag);
-        // flags of a re-spawned agent are cleared, as tde_reset_env does
-        st.collided[g] = o.respawned ? 0 : o.collided;
-        st.offroad[g] = o.respawned ? 0 : o.offroad;
-        if (a == 0) {
-            st.steps[e] = er.steps;
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            st.reward[e] = o.reward;
-            st.terminated[e] = o.terminated;
-            st.truncated[e] = o.truncated;
-            if (st.tl_violation) st.tl_violation[e] = o.tl;
-            if (o.respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
-            if (reward_k) reward_k[e] = o.reward;
-            if (done_k)
-                done_k[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
-            if (st.ep_return) {
-                // Monitor-style episode statistics (examples/rl_training.py:123-128): float64 sum of the episode's rewards
-                double ret = st.ep_return[e] + (double)o.reward;
-                if (o.terminated | o.truncated) {
-                    if (st.ep_final) st.ep_final[e] = ret;
-                    if (st.ep_final_len) st.ep_final_len[e] = o.k;
-                    if (o.respawned) ret = 0.0;
-                }
-                st.ep_return[e] = ret;
-            }
-            if (OBS && st.obs) {
-                // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it.  The cached
-                // ego target is current unless the reward path is off or the episode just ended without a re-spawn.
-                const bool ended = (o.terminated | o.truncated) && !o.respawned;
-                // (the target from cx as VALUES behind an empty asm: left to itself the compiler turns "cx.wtx or the table entry" into
-                //  ONE load through a select of ADDRESSES, which pins cx in scratch memory - 24 B of private segment, and a one-step
-                //  launch with a private segment costs 1.3 us more to dispatch, profiles/r03_g_step_outputs_cost.txt)
-                bool has = er.target_idx < cx.n_wp;
-                double tx = cx.wtx, ty = cx.wty;
-                asm volatile("" : "+v"(tx), "+v"(ty));            // (values, not loads from cx: nothing to merge with the load below)
-                if (!(cfg.flags & TDE_F_REWARD) || ended) {
-                    has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
-                    const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
-                    tx = t2.x; ty = t2.y;
-                }
-                float fwd = 0.0f, lat = 0.0f;
-                if (has) {
-                    const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
-                    fwd = dx * c0 + dy * s0;
-                    lat = dy * c0 - dx * s0;
-                }
-                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
-                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
-                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
-            }
-        }
-    }
-    if constexpr (MAG) {
-        // tde_state.magnitudes (get_info's "collision" / "offroad", ref gym_env.py:427-428) for the egos this step flagged: the whole
-        // wavefront works on one ego at a time, from the rows of THIS step (a re-spawn does not rewrite them in this kernel) and
-        // the map descriptor fetched again through the scalar path.  Placed BEHIND the stores, where nothing of the step is live
-        // any more: inside step_lane the section raised the kernel from 84 to 114 VGPRs (4 instead of 6 wavefronts per SIMD:
-        // +15 % per step at 65 536 envs x 16, where this kernel runs)
-        const unsigned long long ego = __ballot(a == 0 && valid);
-        const int w0 = (int)(threadIdx.x & ~63u);
-        ego_magnitudes_of_wave<A, TDE_SOLO_MAG_LEAN != 0>(cfg, w, [&](int src) { return cold.maps[__builtin_amdgcn_readlane(map0, src)]; }, ego,
-                                                           hit_m, off_m, &t.a[w0], &t.b[w0], (int)(threadIdx.x & 63u), t.poly[threadIdx.x >> 6],
-                                                           (a == 0 && valid) ? reinterpret_cast<float4 *>(st.magnitudes) + e : nullptr);
-    }
-}
-
-// one launch = K timesteps of every env.  A wavefront is a workgroup (64 lanes = 64/A envs): state and the cached
-// table entries (Ctx) live in registers across the K steps, the only per-step global traffic is the ego action
-// (prefetched one step ahead), the per-step reward/done outputs and the grid-index reads; wavefronts never wait for
-// each other, so a wave that takes the rare reset / mesh-boundary path does not stall the batch.
-// (A = 128: the workgroup is the env's two wavefronts)
-template <int A, bool LIGHTS>
-__global__ __launch_bounds__(A > kWave ? A : kWave, A > kWave ? TDE_WIDE_WAVES : 1) void env_rollout_kernel(tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
-{
-    constexpr int kGroup = A > kWave ? A : kWave;
-    __shared__ Tiles<kGroup> t;
-    __shared__ Cold cold;
-    if (threadIdx.x == 0) fill_cold(cold, cfg, w);
-    __syncthreads();
-    const int64_t g = (int64_t)blockIdx.x * kGroup + threadIdx.x;
-    const int e = (int)(g / A), a = (int)(g % A);
-    const int B = st.B;
-    const int LB = ro.ldb;                                  // row pitch of the [K][..] action / reward / done buffers
-    const bool valid = e < B;
-    const int64_t gs = valid ? g : 0;
-    const int es = valid ? e : 0;
-    Agent ag;
-    load_agent(st, gs, ag);
-    if (!valid) ag.present = false;
-    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
-    Ctx cx;
-    load_ctx<A>(cfg, cold, a, ag, er, cx);
-    const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
-    float2 act = acts[es];
-    float c0, s0;
-    sincos_f32(ag.psi, s0, c0);
-    write_tile_slot(t.a[threadIdx.x], t.b[threadIdx.x], valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
-    tile_sync<A>();
-    StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
-    for (int k = 0; k < ro.K; ++k) {
-        const int kn = (k + 1 < ro.K) ? k + 1 : k;
-        const float2 act_next = acts[(int64_t)kn * LB + es];      // in flight during this step
-        o = step_lane<A, kGroup, LIGHTS>(cfg, w, cold, st, t, es, a, valid, ag, er, cx, c0, s0, act.x, act.y);
-        if (valid && a == 0) {
-            if (ro.reward) ro.reward[(int64_t)k * LB + e] = o.reward;
-            if (ro.done)
-                ro.done[(int64_t)k * LB + e] =
-                    (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
-        }
-        act = act_next;
-    }
-    if (!valid) return;
-    store_agent_dynamic(st, g, ag);
-    store_agent_static(st, g, ag);
-    st.collided[g] = o.respawned ? 0 : o.collided;
-    st.offroad[g] = o.respawned ? 0 : o.offroad;
-    if (a == 0) {
-        st.scn[e] = er.scn; st.episode[e] = er.episode;
-        st.steps[e] = er.steps;
-        st.target_idx[e] = er.target_idx;
-        st.reached[e] = er.reached;
-        st.reward[e] = o.reward;
-        st.terminated[e] = o.terminated;
-        st.truncated[e] = o.truncated;
-        if (st.tl_violation) st.tl_violation[e] = o.tl;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Two-role persistent rollout.  A lone wavefront cannot issue faster than its dependent-instruction latency allows
-// (~10 cycles per dependent fp32 VALU op against ~2 cycles of issue, scripts/ubench/valu_latency.hip), and the headline
-// batch only fills two wavefronts per SIMD, so the single-role kernel above leaves half of the issue slots empty.
-// Here every group of 64 agent slots is served by TWO wavefronts of one workgroup that split the step by role:
-//   drive : NPC controller + bicycle integration + replay + route switching (R4, R5, R14) -> the next tile; the ego
-//           lane's reward arithmetic and waypoint advance (R2, R6, R7, R12), which only need the pose before and after
-//   judge : collision, offroad, stop-line violation, terminated / truncated, the done byte (R8-R11)
-// The judge works on step i while the driver already computes step i+1 from the same tile, speculating that no env of
-// its wavefront finished; when one did (about 7 % of wave-steps) the driver re-spawns those lanes and recomputes.
-// Tiles are double-buffered by step parity; per step two LDS-only barriers:
-//   A: judge has published done(i-1) and is finished with both tile buffers
-//   B: driver has committed the rows of step i (and any re-spawned rows of step i-1)
-// Same arithmetic in the same order per agent as step_lane, so results stay bit-identical to the oracle.
-// ------------------------------------------------------------------------------------------------------------------
-#ifndef TDE_STOP_CACHE
-#define TDE_STOP_CACHE 24
-#endif
-struct DuoShared {
-    float4 a[2][kWave], b[2][kWave];
-    float4 c[2][kWave];                  // (psi, v, live, -): what the judge's ego lane and liveness test need
-    unsigned long long done;             // ballot of the ego lanes whose env finished at the last judged step
-    // three-role kernels: per-slot ballots of the judges of the previous step, and next to them the two config words the
-    // done test needs, so that done_of() is ONE LDS round trip (two 16-byte reads) instead of three dependent ones
-    alignas(16) unsigned long long hit_mask;
-    unsigned long long off_mask, tl_mask;
-    int32_t max_steps_w, term_at_infraction_w;
-    // the first kStopCache stop lines of every env's map (A >= 8, i.e. at most 8 envs per group): the per-step stop-line
-    // loops read LDS instead of walking the global table with one exposed L2 round trip per line
-    float4 stop[8][TDE_STOP_CACHE][2];
-    // three-role kernel: the ego actions of the next two steps, relayed by judge O (slot = step & 1, indexed by the ego's
-    // lane): the driver's loop then issues no global load of its own, so nothing in it ever waits on vmcnt
-    float2 act[2][kWave];
-    // three-role rollout kernel, judge C: the ego poses (x, y, psi, v) before / after the last up to A steps of every env
-    // of the group, slot (env's first lane + step) - the reward arithmetic runs on a whole window at once (see there)
-    float4 ring_pre[kWave], ring_post[kWave];
-    // one-step three-role kernel: Philox blocks 0 and 1 of every env's NEXT episode (what a re-spawn at this step would draw),
-    // written by the driver's lanes 0 and 1 of the env ahead of barrier A
-    uint4 draw[8][2];
-    // one-step three-role kernel with lights: (red mask of this step, of the next step, stop_base, n_stop) of every env's map,
-    // formed by judge O ahead of barrier B together with the stop-line cache
-    int4 lights[8];
-    float4 ego_next[8][2];               // ... and the ego's start (pose, attributes) computed from them by judge C (ego_spawn)
-    double2 ego_next_tgt[8];             // ... the new episode's first target (the scenario's second waypoint) ...
-    int4 ego_next_scn[8];                // ... and its scenario entry (map, wp_n, start heading, -): the reward context of the re-spawn
-    // one-step three-role kernel with tde_state.magnitudes: what the magnitude functions read of every env's map descriptor
-    // (ox, oy, cell, inv_cell | nx, ny, cell_base, row_shift | rec_base, near_base, tri_base, n_tri), parked by judge O ahead of barrier B
-    int4 mapw[8][3];
-};
-
-TDE_DEV void map_to_lds(int4 *dst, const tde_map &m)
-{
-    dst[0] = make_int4(__float_as_int(m.ox), __float_as_int(m.oy), __float_as_int(m.cell), __float_as_int(m.inv_cell));
-    dst[1] = make_int4(m.nx, m.ny, m.cell_base, m.row_shift);
-    dst[2] = make_int4(m.rec_base, m.near_base, m.tri_base, m.n_tri);
-}
-TDE_DEV tde_map map_from_lds(const int4 *src)
-{
-    const int4 a = src[0], b = src[1], c = src[2];
-    tde_map r{};
-    // (wave-uniform: scalar registers - the section runs under the three-role kernel's 80-VGPR budget)
-#define RFL(x) __builtin_amdgcn_readfirstlane(x)
-    r.ox = __int_as_float(RFL(a.x)); r.oy = __int_as_float(RFL(a.y)); r.cell = __int_as_float(RFL(a.z)); r.inv_cell = __int_as_float(RFL(a.w));
-    r.nx = RFL(b.x); r.ny = RFL(b.y); r.cell_base = RFL(b.z); r.row_shift = RFL(b.w); r.rec_base = RFL(c.x); r.near_base = RFL(c.y);
-    // (tri_base, n_tri - words .z / .w of the third: only the far-field fall-back of the scan reads them, from LDS, if it runs at all)
-#undef RFL
-    return r;
-}
-constexpr int kStopCache = TDE_STOP_CACHE;
-
-// the lanes of an env fetch its first min(n_stop, kStopCache) lines, one each per trip (the driver calls it at start and after re-spawns)
-template <int A>
-TDE_DEV void fill_stop_cache(DuoShared &sh, const tde_world &w, const tde_map &m, int lane, int a)
-{
-    if constexpr (A >= 8) {
-        for (int i = a; i < kStopCache && i < m.n_stop; i += A) {
-            const float4 *src = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i));
-            sh.stop[lane / A][i][0] = src[0];
-            sh.stop[lane / A][i][1] = src[1];
-        }
-    }
-}
-
-template <int A>
-struct CachedLines {
-    const DuoShared &sh;
-    const tde_stopline *base;
-    int envw;
-    TDE_DEV void operator()(int i, float4 &a, float4 &b) const
-    {
-        if (A >= 8 && i < kStopCache) { a = sh.stop[envw][i][0]; b = sh.stop[envw][i][1]; }
-        else { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
-    }
-    static constexpr int kCached = A >= 8 ? kStopCache : 0;
-    static_assert(kStopCache % 4 == 0, "red_line_gap_of walks the lines four at a time");
-    TDE_DEV void cached(int i, float4 &a, float4 &b) const { a = sh.stop[envw][i][0]; b = sh.stop[envw][i][1]; }
-    TDE_DEV void global(int i, float4 &a, float4 &b) const { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
-};
-
-
-TDE_DEV void write_rows(DuoShared &sh, int buf, int lane, bool live, const Agent &ag, float c, float s, float lane_half)
-{
-    write_tile_slot(sh.a[buf][lane], sh.b[buf][lane], live, ag, c, s, lane_half);
-    sh.c[buf][lane] = make_float4(ag.psi, ag.v, live ? 1.0f : 0.0f, 0.0f);
-}
-
-// BIG (tde_world.hints & TDE_WORLD_LARGE_GRID): the judges take the corner classes from the 2-bit class map
-template <int A, bool LIGHTS, bool BIG>
-__global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_rollout_duo_kernel(tde_config cfg, tde_world w, tde_state st,
-                                                                    tde_rollout ro)
-{
-    __shared__ DuoShared sh;
-    __shared__ Cold cold;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = drive, 1 = judge
-    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull; }
-    const uint32_t F = cfg.flags;
-    const int64_t g = (int64_t)blockIdx.x * kWave + lane;
-    const int e = (int)(g / A), a = (int)(g % A);
-    const int B = st.B;
-    const int LB = ro.ldb;                                  // row pitch of the [K][..] action / reward / done buffers
-    const bool valid = e < B;
-    const int64_t gs = valid ? g : 0;
-    const int es = valid ? e : 0;
-    const int base = lane - a;
-    __syncthreads();                                         // cold is filled
-    // every role loads its own copy of the per-lane state inside its branch: with nothing live across the role switch
-    // the register allocator treats the roles separately (the shared prologue cost tens of scratch spills)
-#define TDE_ROLE_PROLOGUE                                                                                 \
-    Agent ag;                                                                                             \
-    load_agent(st, gs, ag);                                                                               \
-    if (!valid) ag.present = false;                                                                       \
-    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};              \
-    Ctx cx;                                                                                               \
-    load_ctx<A>(cfg, cold, a, ag, er, cx);
-
-    if (role == 0) {
-        // ================================ drive ================================
-        TDE_ROLE_PROLOGUE
-        RedCache redc; redc.invalidate();
-        __builtin_amdgcn_s_setprio(3);           // the driver is the serial chain of the simulation; the judge fills in
-        float c0, s0;
-        sincos_f32(ag.psi, s0, c0);
-        write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
-        lds_barrier();                                       // rows of the launch state are in buffer 1
-        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
-        float2 act = acts[es];
-        RewardOut rw{};
-        for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1, q = p ^ 1;
-            const int kn = (i + 1 < ro.K) ? i + 1 : i;
-            const float2 act_next = acts[(int64_t)kn * LB + es];
-            float nx, ny, npsi, nv, nc, ns;
-            float na = 0.0f, nb = 0.0f;
-            int nwp, k, n_target = er.target_idx, n_reached = er.reached;
-            bool switched, live;
-            for (int pass = 0;; ++pass) {
-                // one step from the rows in buffer q, nothing committed yet (step_lane up to the tile write)
-                k = er.steps + 1;                                                            // :116
-                live = valid && ag.present;
-                const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-                const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
-                float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-                const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-                float acc = 0.0f, beta = 0.0f;
-                if (a == 0) { acc = act.x; beta = act.y; }
-                if (F & TDE_F_NPC) {
-                    // The controller runs in the first pass only.  A second pass means that an env of this wavefront finished
-                    // and its lanes were re-spawned: they are at the first step of their episode, where the NPCs coast (zero
-                    // action: the controller reads the scene of the previous step, which a fresh episode does not have), and
-                    // the other envs' actions are those of the first pass - nothing to recompute (rounds 1-3 repeated the
-                    // whole sweep here, on 7 % of the wave-steps).
-                    if (pass == 0) {
-                        const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
-                        const float red_gap =
-                            (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-                        npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
-                                      cx.g_far, red_gap, na, nb);
-                    }
-                    if (npc && k > 1) { acc = na; beta = nb; }
-                }
-                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
-                if (live) {
-                    bicycle(nx, ny, npsi, nv, ag.inv_lr, acc, beta, cfg.dt);                      // :117
-                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
-                }
-                switched = false;
-                nwp = ag.route_wp;
-                if (has_target) {
-                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;
-                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
-                }
-                sincos_f32(npsi, ns, nc);
-                // The ego lane's reward arithmetic and waypoint bookkeeping (:391-411, :378-383) live here: they need the
-                // pose before and after the step, which this wavefront holds, and not the infraction flags (only
-                // `terminated` does, which the judge settles); this wavefront would otherwise idle at barrier A.
-                if ((F & TDE_F_REWARD) && a == 0 && valid) {
-                    n_target = er.target_idx; n_reached = er.reached;
-                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, ag.x, ag.y, ag.psi, ag.v, nx, ny, npsi, nv, false,
-                                     false, false, k, n_target, n_reached, st.info != nullptr);
-                }
-                if (pass) break;
-                lds_barrier();                               // A: done(i-1) is published
-                const unsigned long long dn = sh.done;
-                if (!dn) break;
-                // an env of this wavefront finished at step i-1: re-spawn its lanes (as step_lane does in place),
-                // put their rows into buffer q and recompute the step
-                if (((dn >> base) & 1ull) && valid) {
-                    reset_lane<A>(cfg, cold, e, a, ag, er);
-                    load_ctx<A>(cfg, cold, a, ag, er, cx);
-                    redc.invalidate();
-                    sincos_f32(ag.psi, s0, c0);
-                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges' pre-step rows of the new episode)
-                    if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
-                }
-            }
-            ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
-            c0 = nc; s0 = ns;
-            er.steps = k;
-            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);
-            lds_barrier();                                   // B: rows of step i are in buffer p
-            if (switched) load_route_target(cold, ag, cx);
-            if (a == 0 && valid) {
-                if (F & TDE_F_REWARD) {
-                    const bool advanced = n_target != er.target_idx;
-                    er.target_idx = n_target; er.reached = n_reached;
-                    if (st.info) {
-                        double *inf = st.info + 4 * (int64_t)e;
-                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
-                    }
-                    if (st.info_reached) st.info_reached[e] = er.reached;
-                    if (advanced) load_ego_target(cold, er, cx);   // (a finished env reloads it when it re-spawns)
-                }
-                if (ro.reward) ro.reward[(int64_t)i * LB + e] = rw.reward;
-            }
-            act = act_next;
-        }
-        lds_barrier();                                       // A of the step after the last: done(K-1)
-        const unsigned long long dn = sh.done;
-        if (((dn >> base) & 1ull) && valid) reset_lane<A>(cfg, cold, e, a, ag, er);
-        if (!valid) return;
-        store_agent_dynamic(st, g, ag);
-        store_agent_static(st, g, ag);
-        if (a == 0) {
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            st.reward[e] = rw.reward;
-        }
-    } else {
-        // ================================ judge ================================
-        TDE_ROLE_PROLOGUE
-        RedCache redc; redc.invalidate();
-        StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
-        const float thr2 = thr2_of(cfg);
-        lds_barrier();
-        for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1;
-            lds_barrier();                                   // A
-            lds_barrier();                                   // B: rows of step i are in buffer p
-            er.steps += 1;
-            const int k = er.steps;
-            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
-            const bool live = rc.z != 0.0f;
-            const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
-            Corners corners;
-            if (F & TDE_F_OFFROAD) offroad_issue<BIG || TDE_ROLLOUT_CLS2>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
-            const bool hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, live, x, y, c0, s0, hl, hw, ra.z);
-            bool off = false;
-            if (F & TDE_F_OFFROAD) off = offroad_resolve<false, BIG || TDE_ROLLOUT_CLS2>(w, corners, thr2, cx.m.rec_base);
-            bool tl = false;
-            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-                tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
-            o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
-            unsigned long long any = 0ull;
-            if (F & TDE_F_REWARD) {                          // R8 / R11: the flags settle here (reward: the driver)
-                int done = 0;
-                if (a == 0 && valid) {
-                    o.terminated = (uint8_t)(cold.terminated_at_infraction && (off || hit || tl));
-                    o.truncated = (uint8_t)(k >= cold.max_steps);
-                    done = (o.terminated | o.truncated) ? 1 : 0;
-                }
-                if (F & TDE_F_AUTORESET) any = __ballot(done);
-            }
-            if (lane == 0) sh.done = any;
-            if (valid && a == 0 && ro.done)
-                ro.done[(int64_t)i * LB + e] =
-                    (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
-            if (any && ((any >> base) & 1ull) && valid) {
-                reset_lane<A>(cfg, cold, e, a, ag, er);
-                load_ctx<A>(cfg, cold, a, ag, er, cx);
-                    redc.invalidate();
-                o.respawned = true;
-            }
-        }
-        lds_barrier();                                       // lets the driver read done(K-1)
-        if (!valid) return;
-        st.collided[g] = o.respawned ? 0 : o.collided;
-        st.offroad[g] = o.respawned ? 0 : o.offroad;
-        if (a == 0) {
-            st.scn[e] = er.scn; st.episode[e] = er.episode;
-            st.steps[e] = er.steps;
-            st.terminated[e] = o.terminated;
-            st.truncated[e] = o.truncated;
-            if (st.tl_violation) st.tl_violation[e] = o.tl;
-        }
-    }
-}
-
-#undef TDE_ROLE_PROLOGUE
-
-// ------------------------------------------------------------------------------------------------------------------
-// The two-role rollout for 128 agent slots per env (the reference's ~100-agent scenes): ONE env per workgroup of four
-// wavefronts - drive (slots 0-63), drive (64-127), judge (0-63), judge (64-127).  The one-role kernel runs both 128-row
-// sweeps of a slot one behind the other in a single wavefront (3130 VALU per wave-step, 11 us per step with two wavefronts per
-// SIMD: a latency chain); here the controller's sweep and the collision sweep of a step run side by side as in the
-// narrower kernels, with the same two barriers per step.  What differs from env_rollout_duo_kernel: a lane's slot is
-// (wavefront & 1) * 64 + lane, the sweeps are the *_wide forms (two 64-row halves), and the env's done flag is one word
-// written by the judge's ego lane instead of a ballot (read by every wavefront behind the next barrier A, where the
-// judges also do their own re-spawn bookkeeping).  Same per-agent arithmetic in the same order: same bits.
-// ------------------------------------------------------------------------------------------------------------------
-struct WideShared {
-    float4 a[2][128], b[2][128], c[2][128];
-    int done;                            // the env finished at the last judged step (and auto-reset is on)
-    float4 stop[kStopCache][2];          // the first kStopCache stop lines of the env's map
-};
-struct WideLines {
-    const WideShared &sh;
-    const tde_stopline *base;
-    static constexpr int kCached = kStopCache;
-    TDE_DEV void cached(int i, float4 &a, float4 &b) const { a = sh.stop[i][0]; b = sh.stop[i][1]; }
-    TDE_DEV void global(int i, float4 &a, float4 &b) const { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
-    TDE_DEV void operator()(int i, float4 &a, float4 &b) const { if (i < kStopCache) cached(i, a, b); else global(i, a, b); }
-};
-TDE_DEV void fill_stop_cache_wide(WideShared &sh, const tde_world &w, const tde_map &m, int a)
-{
-    for (int i = a; i < kStopCache && i < m.n_stop; i += 128) {
-        const float4 *src = reinterpret_cast<const float4 *>(w.stoplines + (m.stop_base + i));
-        sh.stop[i][0] = src[0];
-        sh.stop[i][1] = src[1];
-    }
-}
-TDE_DEV void write_rows_wide(WideShared &sh, int buf, int a, bool live, const Agent &ag, float c, float s, float lane_half)
-{
-    write_tile_slot(sh.a[buf][a], sh.b[buf][a], live, ag, c, s, lane_half);
-    sh.c[buf][a] = make_float4(ag.psi, ag.v, live ? 1.0f : 0.0f, 0.0f);
-}
-
-#ifndef TDE_WIDE2_WAVES
-#define TDE_WIDE2_WAVES 4
-#endif
-template <bool LIGHTS>
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(tde_config cfg, tde_world w, tde_state st,
-                                                                     tde_rollout ro)
-{
-    constexpr int A = 128;
-    __shared__ WideShared sh;
-    __shared__ Cold cold;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int role = wv >> 1;                               // 0 = drive, 1 = judge
-    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
-    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0; }
-    const uint32_t F = cfg.flags;
-    const int e = (int)blockIdx.x;                          // (the grid is B workgroups: every env is valid)
-    const int64_t g = (int64_t)e * A + a;
-    const int LB = ro.ldb;
-    __syncthreads();                                         // cold is filled
-    // (every role loads its own copy of the per-lane state inside its branch: nothing live across the role switch)
-#define TDE_WIDE_PROLOGUE                                                                                 \
-    Agent ag;                                                                                             \
-    load_agent(st, g, ag);                                                                                \
-    EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};                   \
-    Ctx cx;                                                                                               \
-    load_ctx<A>(cfg, cold, a, ag, er, cx);                                                                \
-    RedCache redc; redc.invalidate();
-    if (role == 0) {
-        // ================================ drive ================================
-        TDE_WIDE_PROLOGUE
-        __builtin_amdgcn_s_setprio(3);
-        float c0, s0;
-        sincos_f32(ag.psi, s0, c0);
-        write_rows_wide(sh, 1, a, ag.present, ag, c0, s0, cfg.npc_lane_half);
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache_wide(sh, w, cx.m, a);
-        lds_barrier();                                       // rows of the launch state are in buffer 1
-        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
-        float2 act = acts[e];
-        for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1, q = p ^ 1;
-            const int kn = (i + 1 < ro.K) ? i + 1 : i;
-            const float2 act_next = acts[(int64_t)kn * LB + e];
-            float nx, ny, npsi, nv, nc, ns;
-            float na = 0.0f, nb = 0.0f;
-            int nwp, k;
-            bool switched, live;
-            for (int pass = 0;; ++pass) {
-                k = er.steps + 1;                                                            // :116
-                live = ag.present;
-                const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-                const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
-                float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-                const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-                float acc = 0.0f, beta = 0.0f;
-                if (a == 0) { acc = act.x; beta = act.y; }
-                if (F & TDE_F_NPC) {
-                    if (pass == 0) {                         // (a second pass = a re-spawn: first step, the NPCs coast)
-                        const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
-                        const float red_gap =
-                            (LIGHTS && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-                        npc_action_wide<A>(cfg, &sh.a[q][0], &sh.b[q][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
-                    }
-                    if (npc && k > 1) { acc = na; beta = nb; }
-                }
-                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
-                if (live) {
-                    bicycle(nx, ny, npsi, nv, ag.inv_lr, acc, beta, cfg.dt);                      // :117
-                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
-                }
-                switched = false;
-                nwp = ag.route_wp;
-                if (has_target) {
-                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;
-                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
-                }
-                sincos_f32(npsi, ns, nc);
-                if (pass) break;
-                lds_barrier();                               // A: done(i-1) is published
-                if (!sh.done) break;
-                // the env finished at step i-1: re-spawn (as step_lane does in place), rows into buffer q, recompute the step
-                reset_lane<A>(cfg, cold, e, a, ag, er);
-                load_ctx<A>(cfg, cold, a, ag, er, cx);
-                redc.invalidate();
-                sincos_f32(ag.psi, s0, c0);
-                write_rows_wide(sh, q, a, ag.present, ag, c0, s0, cfg.npc_lane_half);
-                if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache_wide(sh, w, cx.m, a);
-            }
-            ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
-            c0 = nc; s0 = ns;
-            er.steps = k;
-            write_rows_wide(sh, p, a, live, ag, c0, s0, cfg.npc_lane_half);
-            lds_barrier();                                   // B: rows of step i are in buffer p
-            if (switched) load_route_target(cold, ag, cx);
-            act = act_next;
-        }
-        lds_barrier();                                       // A of the step after the last: done(K-1)
-        if (sh.done) reset_lane<A>(cfg, cold, e, a, ag, er);
-        store_agent_dynamic(st, g, ag);
-        store_agent_static(st, g, ag);
-    } else {
-        // ================================ judge ================================
-        TDE_WIDE_PROLOGUE
-        StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
-        const float thr2 = thr2_of(cfg);
-        RewardOut rw{};
-        lds_barrier();
-        for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1, q = p ^ 1;
-            lds_barrier();                                   // A: done(i-1) is in sh.done (written behind barrier B of step i-1)
-            if (i > 0 && sh.done) {                          // this role's bookkeeping of the new episode
-                reset_lane<A>(cfg, cold, e, a, ag, er);
-                load_ctx<A>(cfg, cold, a, ag, er, cx);
-                redc.invalidate();
-            }
-            lds_barrier();                                   // B: rows of step i are in buffer p
-            er.steps += 1;
-            const int k = er.steps;
-            const float4 ra = sh.a[p][a], rb = sh.b[p][a], rc = sh.c[p][a];
-            const bool live = rc.z != 0.0f;
-            const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
-            Corners corners;
-            if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
-            const bool hit = collide_rows_wide<A>(&sh.a[p][0], &sh.b[p][0], a, live, x, y, c0, s0, hl, hw, ra.z);
-            bool off = false;
-            if (F & TDE_F_OFFROAD) off = offroad_resolve<false, false>(w, corners, thr2, cx.m.rec_base);
-            bool tl = false;
-            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0)
-                tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
-            o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
-            if (a == 0) {
-                int done = 0;
-                if (F & TDE_F_REWARD) {
-                    // The ego's reward arithmetic and waypoint bookkeeping (:391-411, :378-383) from its rows before (buffer q: the
-                    // previous step's, or the new episode's spawn rows after a re-spawn) and after the step - here, not on the
-                    // driver as in env_rollout_duo_kernel: the driver is the wavefront short of registers (its spills are on its path)
-                    const float4 pa = sh.a[q][0], pc = sh.c[q][0];
-                    int n_target = er.target_idx, n_reached = er.reached;
-                    rw = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, pa.x, pa.y, pc.x, pc.y, x, y, rc.x, rc.y, false, false, false, k,
-                                     n_target, n_reached, st.info != nullptr);
-                    const bool advanced = n_target != er.target_idx;
-                    er.target_idx = n_target; er.reached = n_reached;
-                    if (st.info) {
-                        double *inf = st.info + 4 * (int64_t)e;
-                        inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
-                    }
-                    if (st.info_reached) st.info_reached[e] = er.reached;
-                    if (advanced) load_ego_target(cold, er, cx);   // (a finished env reloads it when it re-spawns)
-                    // R8 / R11: the flags
-                    o.terminated = (uint8_t)(cold.terminated_at_infraction && (off || hit || tl));
-                    o.truncated = (uint8_t)(k >= cold.max_steps);
-                    done = (o.terminated | o.truncated) ? 1 : 0;
-                }
-                sh.done = ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? done : 0;
-                if (ro.reward) ro.reward[(int64_t)i * LB + e] = rw.reward;
-                if (ro.done)
-                    ro.done[(int64_t)i * LB + e] =
-                        (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
-            }
-        }
-        lds_barrier();                                       // done(K-1) is in sh.done
-        const bool respawned = sh.done != 0;
-        if (respawned) reset_lane<A>(cfg, cold, e, a, ag, er);
-        st.collided[g] = respawned ? 0 : o.collided;
-        st.offroad[g] = respawned ? 0 : o.offroad;
-        if (a == 0) {
-            st.scn[e] = er.scn; st.episode[e] = er.episode;
-            st.steps[e] = er.steps;
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            st.reward[e] = rw.reward;
-            st.terminated[e] = o.terminated;
-            st.truncated[e] = o.truncated;
-            if (st.tl_violation) st.tl_violation[e] = o.tl;
-        }
-    }
-}
-#undef TDE_WIDE_PROLOGUE
-
-// ------------------------------------------------------------------------------------------------------------------
-// Three roles per group: the same loop with the judge split in two wavefronts, six wavefronts per SIMD (80 VGPRs each):
-//   drive   : as above, without the reward arithmetic
-//   judge C : collision of all slots; the ego lane's reward arithmetic, waypoint advance, outputs
-//   judge O : offroad of all slots, stop-line violation of the ego
-// The judges publish per-slot ballots (hit / off / tl); at barrier A every wavefront that needs done(i-1) forms it
-// from those masks by itself (R8: terminated = infraction of the ego; R11: truncated = step count), so the judges never
-// wait for each other.  What depends on the other judge's mask (the done byte, terminated, C's own re-spawn
-// bookkeeping) is settled by C after the next barrier A.
-// ------------------------------------------------------------------------------------------------------------------
-// sensitivity probe of tuning builds only (scripts/build_variant.sh -DTDE_DEBUG -DTDE_DUMMY_D=100 ...): N extra dependent /
-// independent VALU instructions per step in one role, results discarded - which role's instructions cost how much
-#ifdef TDE_DEBUG
-#ifndef TDE_DUMMY_D
-#define TDE_DUMMY_D 0
-#endif
-#ifndef TDE_DUMMY_C
-#define TDE_DUMMY_C 0
-#endif
-#ifndef TDE_DUMMY_O
-#define TDE_DUMMY_O 0
-#endif
-#ifndef TDE_DUMMY_ILP
-#define TDE_DUMMY_ILP 1
-#endif
-template <int N> TDE_DEV void dummy_valu(float seed)
-{
-    if constexpr (N > 0) {
-        float v[TDE_DUMMY_ILP];
-#pragma unroll
-        for (int u = 0; u < TDE_DUMMY_ILP; ++u) v[u] = seed + (float)u;
-#pragma unroll
-        for (int n = 0; n < N / TDE_DUMMY_ILP; ++n) {
-#pragma unroll
-            for (int u = 0; u < TDE_DUMMY_ILP; ++u) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[u]));
-        }
-#pragma unroll
-        for (int u = 0; u < TDE_DUMMY_ILP; ++u) asm volatile("" :: "v"(v[u]));
-    }
-}
-#define TDE_PROBE(N, seed) dummy_valu<N>(seed)
-#else
-#define TDE_PROBE(N, seed) ((void)0)
-#endif
-// issue priorities of the three roles.  Round 1: driver > judge C > judge O (2, 1, 0).  After round 2's diet of judge C
-// (windowed reward, DPP collision prefilter) judge O's chain - four dependent cell-word loads per slot - is the longer one
-// of the two: (2, 0, 1) 2.93 us per step against (2, 1, 0) 3.00, (3, 0, 2) 2.93, (2, 0, 2) 2.99, (1, 0, 1) 2.99
-// (profiles/r02_d_ab_diet_steps.txt, tail)
-#ifndef TDE_STEP_PRIO_SWITCH    // one-step three-role kernel: priorities follow the critical path (driver -> judges -> driver)
-#define TDE_STEP_PRIO_SWITCH 1
-#endif
-#ifndef TDE_STEP_PRIO_D2        // ... behind barrier B: driver (next step's controller), judge C, judge O
-#define TDE_STEP_PRIO_D2 0
-#define TDE_STEP_PRIO_C2 3
-#define TDE_STEP_PRIO_O2 2
-#endif
-#ifndef TDE_SPRIO_C             // the one-step three-role kernel's judges (its driver: 2)
-#define TDE_SPRIO_C 0
-#define TDE_SPRIO_O 1
-#endif
-#ifndef TDE_PRIO_D
-#define TDE_PRIO_D 2
-#define TDE_PRIO_C 0
-#define TDE_PRIO_O 1
-#endif
-// TDE_ROLLOUT_CONST_ARGS (A/B builds only: one set of arguments per process, no two rollouts in flight): the four argument structs
-// in a __constant__ block instead of ~650 bytes of kernel arguments - the experiment of VERDICT r4 item 6 (do the SGPR spills and the
-// LDS copy of the cold arguments go away?); profiles/r05_c_ab_rollout_const_args.txt
-#ifndef TDE_ROLLOUT_CONST_ARGS
-#define TDE_ROLLOUT_CONST_ARGS 0
-#endif
-struct RolloutArgs { tde_config cfg; tde_world w; tde_state st; tde_rollout ro; };
-#if TDE_ROLLOUT_CONST_ARGS
-__constant__ RolloutArgs g_rollout_args;
-#endif
-template <int A, bool LIGHTS, bool BIG>
-__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6))) void env_rollout_trio_kernel(
-#if TDE_ROLLOUT_CONST_ARGS
-    int unused_)
-{
-    const tde_config &cfg = g_rollout_args.cfg; const tde_world &w = g_rollout_args.w; const tde_state &st = g_rollout_args.st;
-    const tde_rollout &ro = g_rollout_args.ro;
-#else
-    tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
-{
-#endif
-    __shared__ DuoShared sh;
-    __shared__ Cold cold;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = drive, 1 = judge
-    if (threadIdx.x == 0) {
-        fill_cold(cold, cfg, w); sh.done = 0ull; sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull;
-        sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
-    }
-    const uint32_t F = cfg.flags;
-    const int64_t g = (int64_t)blockIdx.x * kWave + lane;
-    const int e = (int)(g / A), a = (int)(g % A);
-    const int B = st.B;
-    const int LB = ro.ldb;                                  // row pitch of the [K][..] action / reward / done buffers
-    const bool valid = e < B;
-    const int64_t gs = valid ? g : 0;
-    const int es = valid ? e : 0;
-    const int base = lane - a;
-    __syncthreads();                                         // cold is filled
-    // every role loads its own copy of the per-lane state inside its branch: nothing is live across the role switch
-#define TDE_ROLE_PROLOGUE                                                                                 \
-    Agent ag;                                                                                             \
-    load_agent(st, gs, ag);                                                                               \
-    if (!valid) ag.present = false;                                                                       \
-    EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};              \
-    Ctx cx;                                                                                               \
-    load_ctx<A>(cfg, cold, a, ag, er, cx);
-
-    // done(i-1) of every ego lane from the judges' masks of that step (k = its environment_steps): R8 / R11
-    uint4 m0, m1;                                            // the masks done_of last read (judge C's done byte)
-    auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
-        const unsigned long long ego = __ballot(a == 0 && valid);
-        m0 = *reinterpret_cast<const uint4 *>(&sh.hit_mask);                      // hit, off
-        m1 = *reinterpret_cast<const uint4 *>(&sh.tl_mask);                       // tl, max_steps, term_at_infraction
-        const unsigned long long infr = (((unsigned long long)(m0.y | m0.w | m1.y)) << 32) | (m0.x | m0.z | m1.x);
-        term_m = ((F & TDE_F_REWARD) && m1.w) ? (infr & ego) : 0ull;
-        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= (int)m1.z) : 0ull;
-        return ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? (term_m | trunc_m) : 0ull;
-    };
-    if (role == 0) {
-        // ================================ drive ================================
-        TDE_ROLE_PROLOGUE
-        RedCache redc; redc.invalidate();
-        // issue priority in the order of the roles' chains (TDE_PRIO_* above); round 1, same-box A/B: (3,0,0) 4.00 us,
-        // (3,2,0) 3.84, (2,1,0) 3.81, none 4.4-4.8
-        __builtin_amdgcn_s_setprio(TDE_PRIO_D);
-        float c0, s0;
-        sincos_f32(ag.psi, s0, c0);
-        write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
-        lds_barrier();                                       // rows of the launch state are in buffer 1; actions 0, 1 relayed
-        for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1, q = p ^ 1;
-            const float2 act = sh.act[p][base];              // ego action of step i (judge O fetched it two steps ago)
-            float nx, ny, npsi, nv, nc, ns;
-            float na = 0.0f, nb = 0.0f;
-            int nwp, k;
-            bool switched, live;
-            for (int pass = 0;; ++pass) {
-                // one step from the rows in buffer q, nothing committed yet (step_lane up to the tile write)
-                k = er.steps + 1;                                                            // :116
-                live = valid && ag.present;
-                const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-                const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
-                float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-                const bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-                float acc = 0.0f, beta = 0.0f;
-                if (a == 0) { acc = act.x; beta = act.y; }
-                if (F & TDE_F_NPC) {
-                    // The controller runs in the first pass only.  A second pass means that an env of this wavefront finished
-                    // and its lanes were re-spawned: they are at the first step of their episode, where the NPCs coast (zero
-                    // action: the controller reads the scene of the previous step, which a fresh episode does not have), and
-                    // the other envs' actions are those of the first pass - nothing to recompute (rounds 1-3 repeated the
-                    // whole sweep here, on 7 % of the wave-steps).
-                    if (pass == 0) {
-                        const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
-                        const float red_gap =
-                            (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-                        npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
-                                      cx.g_far, red_gap, na, nb);
-                    }
-                    if (npc && k > 1) { acc = na; beta = nb; }
-                }
-                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
-                if (live) {
-                    bicycle(nx, ny, npsi, nv, ag.inv_lr, acc, beta, cfg.dt);                      // :117
-                    if (replayed) { nx = rep.x; ny = rep.y; npsi = rep.z; nv = rep.w; }
-                }
-                switched = false;
-                nwp = ag.route_wp;
-                if (has_target) {
-                    const float dx = cx.tgx - nx, dy = cx.tgy - ny;
-                    if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { nwp += 1; switched = true; }
-                }
-                sincos_f32(npsi, ns, nc);
-                TDE_PROBE(TDE_DUMMY_D, nx);
-                if (pass) break;
-                lds_barrier();                               // A: the judges' masks of step i-1 are published
-                unsigned long long term_m, trunc_m;
-                const unsigned long long dn = i > 0 ? done_of(er.steps, term_m, trunc_m) : 0ull;
-                if (lane == 0) sh.done = dn;                 // judge O takes it from here (behind barrier B)
-                if (!dn) break;
-                // an env of this wavefront finished at step i-1: re-spawn its lanes (as step_lane does in place),
-                // put their rows into buffer q and recompute the step
-                if (((dn >> base) & 1ull) && valid) {
-                    reset_lane<A>(cfg, cold, e, a, ag, er);
-                    load_ctx<A>(cfg, cold, a, ag, er, cx);
-                    redc.invalidate();
-                    sincos_f32(ag.psi, s0, c0);
-                    write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges' pre-step rows of the new episode)
-                    if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
-                }
-            }
-            ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
-            c0 = nc; s0 = ns;
-            er.steps = k;
-            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);
-            lds_barrier();                                   // B: rows of step i are in buffer p
-            if (switched) load_route_target(cold, ag, cx);
-        }
-        lds_barrier();                                       // A of the step after the last: masks of step K-1
-        {
-            unsigned long long term_m, trunc_m;
-            const unsigned long long dn = done_of(er.steps, term_m, trunc_m);
-            if (lane == 0) sh.done = dn;
-            lds_barrier();                                   // the judges read it for their final flag stores
-            if (((dn >> base) & 1ull) && valid) reset_lane<A>(cfg, cold, e, a, ag, er);
-        }
-        if (!valid) return;
-        store_agent_dynamic(st, g, ag);
-        store_agent_static(st, g, ag);
-    } else if (role == 1) {
-        // ===================== judge C: collision, reward, outputs, waypoint advance =====================
-        __builtin_amdgcn_s_setprio(TDE_PRIO_C);
-        TDE_ROLE_PROLOGUE
-        RedCache redc; redc.invalidate();
-        bool hit = false;
-        uint8_t last_term = 0, last_trunc = 0;
-        // Reward (R6 / R7 / R12), batched.  Only the ego lane of an env has a reward to compute - one lane in A - and the
-        // arithmetic (float64 cosine, the reach and cut-off tests) cost this wavefront ~110 instructions per step for 64 / A
-        // useful lanes.  Instead the ego lane only RECORDS its pose before / after each step in an LDS ring, and the
-        // arithmetic runs when the ring holds A steps (or an env of the wavefront finished, or the launch ends), one lane
-        // per (env, step): lane `a` of an env evaluates the env's pending step `a`.  What couples the steps - the
-        // waypoint target advances when a step reaches it - is resolved by passes: every pending step is tested against
-        // the current target, the FIRST reaching step of an env (ballot + ffs) closes the steps up to it, the target
-        // advances, and the steps behind it are tested again (a second pass is common, a third needs two waypoints
-        // within a window).  Per-step results are identical to the step-by-step evaluation: same operands, same
-        // operations (reward_motion_terms / reward_reach / reward_sum are what reward_core is made of).
-        int npend = 0, ipend0 = 0;                           // pending steps [ipend0, ipend0 + npend) (wavefront-uniform)
-        const bool batch = (F & TDE_F_REWARD) != 0;
-        if (batch) load_ego_ctx(cold, er, cx);
-        auto flush = [&](bool final) {
-            const int n = npend;
-            if (n == 0) return;
-            const bool act = valid && a < n;
-            const float4 r0 = sh.ring_pre[lane], r1 = sh.ring_post[lane];
-            const RewardBounds rbn = reward_bounds(cold);
-            double dist_r = 0.0, psi_r = 0.0;
-            if (act) reward_motion_terms(cold, rbn, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, dist_r, psi_r);
-            int from = 0;                                    // first pending step of this env that is not closed yet
-            for (;;) {
-                bool reach = false;
-                if (act && a >= from && er.target_idx < cx.n_wp) reach = reward_reach(cold, rbn, r1.x, r1.y, cx.wtx, cx.wty);
-                const unsigned long long rm = __ballot(reach);
-                const uint32_t envbits = (uint32_t)(rm >> base) & (A >= 32 ? 0xffffffffu : ((1u << (A & 31)) - 1u));
-                const int s1 = envbits ? __ffs((int)envbits) - 1 : A;      // first reaching step of this env (A: none)
-                if (act && a >= from && a <= s1) {
-                    const float rwd = reward_sum(cold, a == s1, dist_r, psi_r);
-                    if (ro.reward) ro.reward[(int64_t)(ipend0 + a) * LB + e] = rwd;
-                    if (final && a == n - 1) {               // the launch's last step: the per-env outputs
-                        st.reward[e] = rwd;
-                        if (st.info) {
-                            double *inf = st.info + 4 * (int64_t)e;
-                            inf[0] = (double)fabsf((r0.z - r1.z) / 0.1f); inf[1] = (double)fabsf((r0.w - r1.w) / 0.1f);
-                            inf[2] = psi_r; inf[3] = dist_r;
-                        }
-                    }
-                }
-                bool more = false;
-                if (s1 < A) {
-                    er.target_idx += 1; er.reached += 1;
-                    load_ego_target(cold, er, cx);
-                    from = s1 + 1;
-                    more = valid && from < n;
-                } else {
-                    from = n;
-                }
-                if (!__ballot(more)) break;
-            }
-            if (final && a == 0 && valid && st.info_reached) st.info_reached[e] = er.reached;
-            ipend0 += n; npend = 0;
-        };
-        // what needs the other judge's masks (terminated, the done byte, this wavefront's own re-spawn bookkeeping) is
-        // settled after the next barrier A
-        auto settle = [&](int i) {           // i = the step whose masks are complete now
-            unsigned long long term_m, trunc_m;
-            const unsigned long long dn = done_of(er.steps, term_m, trunc_m);
-            if (a == 0 && valid) {
-                last_term = (uint8_t)((term_m >> lane) & 1ull); last_trunc = (uint8_t)((trunc_m >> lane) & 1ull);
-                if (ro.done) {
-                    // this lane's bit of the masks done_of just read: the half that holds it, one 32-bit shift each
-                    const bool up = lane >= 32;
-                    const uint32_t sft = (uint32_t)lane & 31u;
-                    const uint32_t hb = ((up ? m0.y : m0.x) >> sft) & 1u, ob = ((up ? m0.w : m0.z) >> sft) & 1u,
-                                   tb = ((up ? m1.y : m1.x) >> sft) & 1u;
-                    ro.done[(int64_t)i * LB + e] = (uint8_t)(last_term | (last_trunc << 1) | (ob << 2) | (hb << 3) | (tb << 4));
-                }
-            }
-            return dn;
-        };
-        lds_barrier();
-        for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1, q = p ^ 1;
-            lds_barrier();                                   // A: masks of step i-1 are complete
-            if (i > 0) {
-                const unsigned long long dn = settle(i - 1);
-                if (dn && batch) flush(false);               // the finished episode's steps, before its env re-spawns
-                if (dn && ((dn >> base) & 1ull) && valid) {
-                    reset_lane<A>(cfg, cold, e, a, ag, er);
-                    load_ctx<A>(cfg, cold, a, ag, er, cx);
-                    if (batch) load_ego_ctx(cold, er, cx);
-                    redc.invalidate();
-                }
-            }
-            lds_barrier();                                   // B: rows of step i are in buffer p
-            er.steps += 1;
-            const int k = er.steps;
-            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
-            if constexpr (A == 16 && TDE_COLLIDE_DPP)
-                hit = collide_rows_dpp16(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
-            else
-                hit = collide_rows<A>(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
-            const unsigned long long m = __ballot(hit);
-            if (lane == 0) sh.hit_mask = m;
-            TDE_PROBE(TDE_DUMMY_C, ra.x);
-            if (batch) {
-                if (a == 0 && valid) {
-                    const float4 pa = sh.a[q][lane], pc = sh.c[q][lane];      // state before the step (:371-375)
-                    sh.ring_pre[lane + npend] = make_float4(pa.x, pa.y, pc.x, pc.y);
-                    sh.ring_post[lane + npend] = make_float4(ra.x, ra.y, rc.x, rc.y);
-                }
-                npend += 1;
-                if (npend == A && i + 1 < ro.K) flush(false);        // (the launch's last step is closed by the final flush)
-            } else if (a == 0 && valid && ro.reward) {
-                ro.reward[(int64_t)i * LB + e] = 0.0f;
-            }
-        }
-        lds_barrier();                                       // A'
-        settle(ro.K - 1);
-        if (batch) flush(true);
-        lds_barrier();                                       // done(K-1) is in sh.done
-        const bool respawned = ((sh.done >> base) & 1ull) != 0;
-        if (respawned && valid) reset_lane<A>(cfg, cold, e, a, ag, er);
-        if (!valid) return;
-        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);
-        if (a == 0) {
-            st.scn[e] = er.scn; st.episode[e] = er.episode;
-            st.steps[e] = er.steps;
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            if (!batch) st.reward[e] = 0.0f;
-            st.terminated[e] = last_term;
-            st.truncated[e] = last_trunc;
-        }
-    } else {
-        // ===================== judge O: offroad, stop lines =====================
-        __builtin_amdgcn_s_setprio(TDE_PRIO_O);
-        TDE_ROLE_PROLOGUE
-        RedCache redc; redc.invalidate();
-        const float thr2 = thr2_of(cfg);
-        bool off = false, tl = false;
-        // action relay: this wavefront (lowest priority, off the simulation's serial chain) fetches the ego actions two
-        // steps ahead and parks them in LDS for the driver
-        const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
-        const bool ego = a == 0 && valid;
-        if (ego) {
-            sh.act[0][lane] = acts[e];
-            sh.act[1][lane] = acts[(int64_t)(ro.K > 1 ? 1 : 0) * LB + e];
-        }
-        lds_barrier();
-        for (int i = 0; i < ro.K; ++i) {
-            const int p = i & 1;
-            float2 act2 = make_float2(0.0f, 0.0f);
-            if (ego) act2 = acts[(int64_t)(i + 2 < ro.K ? i + 2 : ro.K - 1) * LB + e];   // in flight during this step
-            lds_barrier();                                   // A: masks of step i-1 are complete
-            lds_barrier();                                   // B: rows of step i are in buffer p
-            if (i > 0) {
-                // done(i-1) as the driver formed it between the two barriers (one 8-byte read instead of the three masks
-                // and the ballots of done_of): this role only needs it for its own re-spawn bookkeeping
-                const unsigned long long dn = sh.done;
-                if (dn && ((dn >> base) & 1ull) && valid) {
-                    reset_lane<A>(cfg, cold, e, a, ag, er);
-                    load_ctx<A>(cfg, cold, a, ag, er, cx);
-                    redc.invalidate();
-                }
-            }
-            er.steps += 1;
-            const int k = er.steps;
-            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
-            const bool live = rc.z != 0.0f;
-            off = false;
-            if (F & TDE_F_OFFROAD) off = box_offroad<false, BIG || TDE_ROLLOUT_CLS2>(w, cx.m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
-            tl = false;
-            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-                tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
-            TDE_PROBE(TDE_DUMMY_O, ra.x);
-            const unsigned long long om = __ballot(off), tm = __ballot(tl);
-            if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
-            if (ego) sh.act[p][lane] = act2;                 // step i+2 -> slot i & 1 (step i's action is consumed: B passed)
-        }
-        lds_barrier();                                       // A'
-        lds_barrier();                                       // done(K-1) is in sh.done
-        if (!valid) return;
-        st.offroad[g] = ((sh.done >> base) & 1ull) ? 0 : (off ? 1 : 0);
-        if (a == 0 && st.tl_violation) st.tl_violation[e] = tl ? 1 : 0;
-    }
-}
-#undef TDE_ROLE_PROLOGUE
-
-// ------------------------------------------------------------------------------------------------------------------
-// Closed-loop step, three roles (tde_env_step when the lookup caches are present): ONE timestep per launch, the
-// consumer's loop (SB3 calls step once per policy action, ref gym_env.py:453-461).  env_step_kernel above runs the whole
-// step as one serial chain per wavefront behind a prologue of three dependent table look-ups; here
-//   * the per-slot / per-env table entries come from the self-validating caches next to the state (tde_slot_cache /
-//     tde_env_cache): the prologue is ONE round of independent loads (a stale or empty entry falls back to the chain and
-//     is rewritten),
-//   * the step is split over the three wavefronts of the rollout kernel: drive (controller, bicycle, replay, route
-//     switch -> rows), judge C (collision, the ego's reward, outputs, episode statistics, the compact observation) and
-//     judge O (offroad, stop lines); the judges' prologues and the driver's chain overlap, and the judges run in parallel.
-// Same per-agent arithmetic in the same order as step_lane: results equal the oracle's bit for bit.
-// Barriers: B = rows of the step are committed, A = the judges' masks are published (every role forms done from them).
-// ------------------------------------------------------------------------------------------------------------------
-// The driver's table entries (route target and the one after it, route / replay ids and lengths; the map when
-// `want_map`) from the slot's cache entry (s0, s1, s2: its three 16-byte words, fetched by the caller ahead of the
-// workgroup's first barrier), or - when the entry is missing or keyed for another state - through the table chain.
-TDE_DEV void load_next_target(const Cold &w, const Agent &ag, int route_n, float &x2, float &y2)
-{
-    x2 = y2 = 0.0f;
-    if (ag.route >= 0 && ag.route_wp + 1 < route_n) {
-        const float2 tg = reinterpret_cast<const float2 *>(w.route_xy)[(int64_t)ag.route * w.RW + ag.route_wp + 1];
-        x2 = tg.x; y2 = tg.y;
-    }
-}
-
-constexpr uint32_t kSlotKeyFlags = TDE_F_NPC | TDE_F_REPLAY;   // part of a slot entry's key (store_slot_cache)
-// key bit: the entry's second target (tgx2, tgy2) has not been fetched yet - a re-spawn leaves that dependent look-up
-// (spawn record -> route table) to the next launch's driver, which has idle time behind barrier B; not part of the comparison
-constexpr int kSlotTg2Later = 1 << 29;
-
-// key word of a slot entry (tde_slot_cache.key)
-TDE_DEV int slot_key(const Agent &ag, uint32_t F)
-{
-    return (ag.route_wp & 0xFFFF) | (int)((F & kSlotKeyFlags) << 16) | TDE_CACHE_VALID;
-}
-
-template <int A>
-TDE_DEV void load_ctx_cached(const tde_config &cfg, const Cold &cold, const tde_state &st, int64_t g, int a, bool valid,
-                             const int4 &s0, const int4 &s1, Agent &ag, const EnvRegs &er, Ctx &cx,
-                             bool want_map, bool &rebuilt)
-{
-    const uint32_t F = cfg.flags;
-    const bool hit = !valid || (s0.x == er.scn && (s0.y & ~kSlotTg2Later) == slot_key(ag, F));
-    rebuilt = !hit;
-    cx.wtx = cx.wty = 0.0; cx.n_wp = 0;                   // (the ego's target is judge C's business)
-    cx.tgx2 = cx.tgy2 = 0.0f;
-    if (__ballot(!hit)) {                                 // some lane of this wavefront needs the table chain
-        if (!hit) {
-            load_ctx<A>(cfg, cold, a, ag, er, cx);        // (also fetches the map when offroad / lights are on)
-            load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);
-        }
-    }
-    if (hit) {
-        cx.tgx = __int_as_float(s0.z); cx.tgy = __int_as_float(s0.w);
-        constexpr uint32_t idm = (1u << TDE_CACHE_ID_BITS) - 1u;
-        ag.route = (int)((uint32_t)s1.x & idm) - 1; cx.route_n = (int)((uint32_t)s1.x >> TDE_CACHE_ID_BITS);
-        ag.replay = (int)((uint32_t)s1.y & idm) - 1; cx.replay_len = (int)((uint32_t)s1.y >> TDE_CACHE_ID_BITS);
-        cx.tgx2 = __int_as_float(s1.z); cx.tgy2 = __int_as_float(s1.w);
-        cx.g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;
-        if (want_map && (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS))) {
-            const int4 e0 = reinterpret_cast<const int4 *>(st.env_cache + (g / A))[0];     // scn, target_idx, n_wp, map
-            const int map = ((e0.z & TDE_CACHE_VALID) && e0.x == er.scn) ? e0.w : reinterpret_cast<const int4 *>(cold.scn)[er.scn].x;
-            cx.m = cold.maps[map];
-        }
-    }
-}
-
-// (the route / replay ids of an entry are those load_ctx found under the NPC / REPLAY flags of the launch that wrote it: the
-//  two flag bits are part of the key, so a caller that switches them between launches gets a rebuilt entry, not a stale one)
-TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, const EnvRegs &er, const Ctx &cx, uint32_t F,
-                              bool tg2_later = false)
-{
-    static_assert(sizeof(tde_slot_cache) == 32, "two 16-byte words per slot");
-    int4 *sc4 = reinterpret_cast<int4 *>(st.slot_cache + g);
-    sc4[0] = make_int4(er.scn, slot_key(ag, F) | (tg2_later ? kSlotTg2Later : 0), __float_as_int(cx.tgx), __float_as_int(cx.tgy));
-    sc4[1] = make_int4((int)((uint32_t)(ag.route + 1) | ((uint32_t)cx.route_n << TDE_CACHE_ID_BITS)),
-                       (int)((uint32_t)(ag.replay + 1) | ((uint32_t)cx.replay_len << TDE_CACHE_ID_BITS)),
-                       __float_as_int(cx.tgx2), __float_as_int(cx.tgy2));
-}
-
-// What a stored NPC action depends on besides the state it was computed from: the feature flags the controller sees and its
-// constants.  12 bits of a hash of them (formed on the host by env_step_launch: act_cfg_hash) ride in the key entry of the
-// action cache above the step counter (tde_act_cache), so a caller that changes TDE_F_TRAFFIC_LIGHTS / TDE_F_NPC /
-// TDE_F_REPLAY or an npc_* constant between two launches gets the actions recomputed in the next launch's prologue instead of
-// replayed.  (Formed in the kernel - twenty dependent scalar instructions, twice - it cost 0.29 us of the 9 us launch:
-// profiles/r04_d_ab_step_act_key.txt.)
-// (ABI 10: the whole 32-bit hash - the world's tables included - mixed with the step counter by a bijection of it, so distinct step
-//  counters of one configuration never share a word and two configurations collide with probability 2^-32; ABI 9 kept 12 bits)
-TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash ^ ((uint32_t)steps * 0x9E3779B1u)); }
-
-// MAG: also writes tde_state.magnitudes (judge O, behind barrier A); a template flag because the code, taken or not, costs the
-// plain kernel its registers: 73 -> 80 VGPRs + 40 spilled, and a launch with a private segment takes 1.3 us longer to dispatch
-#ifndef TDE_TRIO_STEP_WPE
-#define TDE_TRIO_STEP_WPE 6          // (A/B: wavefronts per SIMD the one-step three-role kernel is compiled for)
-#endif
-// 32 slots per env: 80 VGPRs hold those variants only with 8 - 23 spilled registers, i.e. a private segment for every launch;
-// compiled for five wavefronts per SIMD (102 VGPRs) they have none and run as fast (8192 x 32: 14.75 / 15.63 / 17.41 us bare / full /
-// with magnitudes, against 14.74 / 15.65 / 17.44 with the spills).  (The variants with the magnitudes section beside the stop-line
-// test, 2 - 3 spilled registers at 8 / 16 slots, stay at six: at five they lose a third - the lights' closed loop with magnitudes
-// 12.5 -> 16.0 us.)  NOTE for whoever edits this kernel: MI355X computes a 64-bit shift wrong when its amount sits in the wavefront's
-// LAST allocated VGPR (here: `(dn >> base) & 1` with base in v79 of 80 - profiles/r05_a32_respawn_anomaly.md); the allocator decides
-// that, not the source, so build.py audits the linked code object (isa_audit.py) and refuses a library with the pattern.
-#ifndef TDE_TRIO32_STEP_WPE
-#define TDE_TRIO32_STEP_WPE 5
-#endif
-constexpr int trio_step_wpe(int A, bool LIGHTS, bool MAG) { return A == 32 ? TDE_TRIO32_STEP_WPE : TDE_TRIO_STEP_WPE; }
-template <int A, bool LIGHTS, bool OBS, bool MAG = false>
-__global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_step_wpe(A, LIGHTS, MAG), trio_step_wpe(A, LIGHTS, MAG)))) void env_step_trio_kernel(
-    tde_config cfg, tde_world w, tde_state st, uint32_t act_hash)
-{
-    __shared__ DuoShared sh;
-    __shared__ Cold cold;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x == 0) {
-        fill_cold(cold, cfg, w); sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull;
-        sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
-    }
-    const uint32_t F = cfg.flags;
-    // (32-bit slot index: B * A slots of ~60 bytes of state each cannot exceed 2^32, and an int64 index costs every role two
-    //  registers for the whole launch - the kernel has none to spare with the magnitudes section in it)
-    const uint32_t g = blockIdx.x * (uint32_t)kWave + (uint32_t)lane;
-    const int e = (int)(g / (uint32_t)A), a = (int)(g % (uint32_t)A);
-    const int B = st.B;
-    const bool valid = e < B;
-    const uint32_t gs = valid ? g : 0u;
-    const int es = valid ? e : 0;
-    const int base = lane - a;
-    // Every role first ISSUES the loads of its state (none of them needs the cold block), then meets the others at the
-    // LDS-only barrier that publishes `cold`: the loads stay in flight across it (a __syncthreads would wait for them).
-    // done of every ego lane from the judges' masks (k = environment_steps of this step): R8 / R11
-    auto done_of = [&](int k, unsigned long long &term_m, unsigned long long &trunc_m) {
-        const unsigned long long ego = __ballot(a == 0 && valid);
-        const uint4 m0 = *reinterpret_cast<const uint4 *>(&sh.hit_mask);          // hit, off
-        const uint4 m1 = *reinterpret_cast<const uint4 *>(&sh.tl_mask);           // tl, max_steps, term_at_infraction
-        const unsigned long long infr = (((unsigned long long)(m0.y | m0.w | m1.y)) << 32) | (m0.x | m0.z | m1.x);
-        term_m = ((F & TDE_F_REWARD) && m1.w) ? (infr & ego) : 0ull;
-        trunc_m = (F & TDE_F_REWARD) ? __ballot(a == 0 && valid && k >= (int)m1.z) : 0ull;
-        return ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? (term_m | trunc_m) : 0ull;
-    };
-    if (role == 0) {
-        // ================================ drive ================================
-        __builtin_amdgcn_s_setprio(2);
-        Agent ag;
-        load_agent(st, gs, ag);
-        if (!valid) ag.present = false;
-        EnvRegs er{st.scn[es], st.steps[es], 0, 0, st.episode[es]};
-        const float2 act = reinterpret_cast<const float2 *>(st.action)[es];
-        const int4 *sc4 = reinterpret_cast<const int4 *>(st.slot_cache + gs);
-        const int4 sc0 = sc4[0], sc1 = sc4[1];
-#ifdef TDE_EXP_EXTRA_LOAD            // timing experiment: 16 more bytes per slot in the prologue burst (is it bandwidth-bound?)
-        const int4 extra_ld = reinterpret_cast<const int4 *>(w.cell_word)[gs];
-#endif
-        // the stored action of this slot and the key of its env's entries (tde_act_cache: A + 1 entries per env)
-        float2 ac = make_float2(0.0f, 0.0f);
-        int2 akey = make_int2(-1, 0);                                        // episode, steps
-        if (st.act_cache) {
-            const float2 *ap = reinterpret_cast<const float2 *>(st.act_cache) + (int64_t)es * (A + 1);
-            ac = ap[a];
-            akey = reinterpret_cast<const int2 *>(ap)[A];
-        }
-        lds_barrier();                                                       // cold is published
-        Ctx cx;
-        bool rebuilt;
-        load_ctx_cached<A>(cfg, cold, st, gs, a, valid, sc0, sc1, ag, er, cx, false, rebuilt);     // (no map: the lights are judge O's)
-#ifdef TDE_EXP_EXTRA_LOAD
-        asm volatile("" :: "v"(extra_ld.x), "v"(extra_ld.y), "v"(extra_ld.z), "v"(extra_ld.w));
-#endif
-        const bool need_tg2 = !rebuilt && valid && (sc0.y & kSlotTg2Later) != 0;   // (left by the re-spawn of the previous launch)
-        float c0, s0;
-        const bool live = valid && ag.present;
-        const int k = er.steps + 1;                                          // :116
-        const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-        const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
-        float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-        bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-        float acc = 0.0f, beta = 0.0f;
-        if (a == 0) { acc = act.x; beta = act.y; }
-        // the controller's action for this step: stored by the previous launch (key = the state's episode / step counters)
-        // or, when some slot of this wavefront has none, computed here from the pre-step rows.
-        // Lights: the red masks of this and the next step, the stop lines in LDS and where the rest of them lie come from judge O
-        // (sh.lights, sh.stop: written while it waits for barrier B - the driver's own path to B carries neither the phase table's
-        // nor the stop lines' loads); `early`: ahead of B the driver fetches what it needs itself (the rare recompute).
-        auto controller = [&](int buf, bool early, float &na, float &nb) {
-            float red_gap = 1e30f;
-            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) {
-                if (early) {
-                    const tde_map m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
-                    const uint32_t red = red_mask(w, m, k);
-                    if (red && has_target) red_gap = red_line_gap(cfg, w, m, red, ag, c0, s0);
-                } else {
-                    const int4 lw = sh.lights[lane / A];
-                    if (lw.y && has_target)
-                        red_gap = red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + lw.z, lane / A}, lw.w, (uint32_t)lw.y, ag, c0, s0);
-                }
-            }
-            npc_action<A>(cfg, &sh.a[buf][base], &sh.b[buf][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far,
-                          red_gap, na, nb);
-        };
-        if (F & TDE_F_NPC) {
-            // (k == 1, the first step of an episode: the NPCs coast - nothing to look up or compute)
-            const bool stored = !npc || k == 1 || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
-            if (__ballot(!stored)) {
-                sincos_f32(ag.psi, s0, c0);
-                write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's own rows are in LDS
-                float na, nb;
-                controller(1, true, na, nb);
-                if (npc) { acc = na; beta = nb; }
-            } else if (npc) {
-                acc = ac.x; beta = ac.y;
-            }
-            if (npc && k == 1) acc = beta = 0.0f;
-        }
-        if (live) {
-            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117
-            if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
-        }
-        bool switched = false;
-        if (has_target) {
-            const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
-            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) {
-                ag.route_wp += 1; switched = true;
-                cx.tgx = cx.tgx2; cx.tgy = cx.tgy2;                          // the look-ahead entry: no table read on the chain
-            }
-        }
-        sincos_f32(ag.psi, s0, c0);
-        er.steps = k;
-        write_rows(sh, 0, lane, live, ag, c0, s0, cfg.npc_lane_half);
-        lds_barrier();                                       // B: rows of this step are in buffer 0
-        // behind B the critical path is the judges' (stamps: C 4.8 k, O 4.1 k cycles against 3.2 k for the controller below):
-        // the driver steps back until their masks are in
-        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_D2);
-        if (switched && need_tg2) load_route_target(cold, ag, cx);               // (the look-ahead entry was not there yet: rare)
-        if (switched || need_tg2) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);   // (only stored: the entry after the current one)
-        // the controller of the NEXT step runs here, beside the judges of this one: it needs the state after this step
-        // only.  Speculative like the rollout kernels' driver: an env that turns out to have finished is re-spawned below
-        // and the wavefront repeats it on the new rows.
-        float na2 = 0.0f, nb2 = 0.0f;
-        has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-        if ((F & TDE_F_NPC) && st.act_cache) controller(0, false, na2, nb2);
-        constexpr bool kDrawAhead = A >= 8;                  // (judge C has drawn the next episode's random words: sh.draw)
-        lds_barrier();                                       // A: the judges' masks are published
-        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(3);                 // the launch's tail: re-spawn and stores
-        unsigned long long term_m, trunc_m;
-        const unsigned long long dn = done_of(k, term_m, trunc_m);
-        bool respawned = false;
-        if (dn) {
-#ifdef TDE_EXP_NO_D_RESPAWN           // timing experiment (WRONG results)
-            if (false) {
-#else
-            if (((dn >> base) & 1ull) && valid) {
-#endif
-                respawn_lane<A, kDrawAhead>(cfg, cold, e, a, ag, er, cx, false, sh.draw[lane / A][0], sh.draw[lane / A][1],
-                                            kDrawAhead ? sh.ego_next[lane / A] : nullptr);
-                respawned = true;                                             // (its second route target: left to the next launch)
-            }
-            // The re-spawn path is the tail every launch waits for (1.9 % of the envs finish per step, 7 % of the wavefronts
-            // hold one): the next step's controller is NOT recomputed here for the re-spawned envs - their action-cache
-            // entries are stored invalid and the next launch computes them in its prologue (env_step_trio_kernel, `stored`);
-            // the other envs of the wavefront keep the actions computed above, whose inputs did not change.
-        }
-        if (!valid) return;
-        store_agent_dynamic(st, g, ag);
-        if (respawned) store_agent_static(st, g, ag);
-        if (respawned || switched || rebuilt || need_tg2) store_slot_cache(st, g, ag, er, cx, cfg.flags, respawned);
-        if (st.act_cache) {
-            float2 *ap = reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1);
-            ap[a] = make_float2(na2, nb2);
-            if (a == 0)     // (re-spawn is per env: the ego lane's flag is the env's)
-                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));
-        }
-    } else if (role == 1) {
-        // ===================== judge C: collision, reward, outputs =====================
-        __builtin_amdgcn_s_setprio(TDE_SPRIO_C);
-        EnvRegs er{st.scn[es], st.steps[es], st.target_idx[es], st.reached[es], st.episode[es]};
-        // the ego's pose before the step (:371-375), read before the driver commits the new one at the end of the launch
-        float lx = 0.0f, ly = 0.0f, lpsi = 0.0f, lv = 0.0f;
-        Ctx cx;
-        cx.n_wp = 0; cx.wtx = cx.wty = 0.0;
-        bool ecache_ok = false;
-        int4 e0 = make_int4(0, 0, 0, 0);
-        double2 etg = make_double2(0.0, 0.0);
-        double ep_ret = 0.0;
-        if (a == 0 && valid) {
-            lx = st.x[g]; ly = st.y[g]; lpsi = st.psi[g]; lv = st.v[g];
-            e0 = reinterpret_cast<const int4 *>(st.env_cache + e)[0];
-            etg = reinterpret_cast<const double2 *>(st.env_cache + e)[1];
-            if (st.ep_return) ep_ret = st.ep_return[e];
-        }
-        lds_barrier();                                       // cold is published
-        if (a == 0 && valid && (F & TDE_F_REWARD)) {
-            ecache_ok = (e0.z & TDE_CACHE_VALID) && e0.x == er.scn && e0.y == er.target_idx;
-            if (ecache_ok) {
-                cx.n_wp = e0.z & ~TDE_CACHE_VALID; cx.wtx = etg.x; cx.wty = etg.y;
-            } else {
-                cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
-                load_ego_target(cold, er, cx);
-            }
-        }
-        // What a re-spawn of this env would draw - the NEXT episode's Philox blocks 0 and 1, lanes 0 and 1 of the env, one
-        // evaluation each - goes to LDS here, in this judge's idle time ahead of barrier B: driver and judge C start their
-        // re-spawn paths (the tail every launch waits for) with the scenario index in hand instead of behind ten Philox rounds.
-        // (A judge that has seen the ego's infraction touching the spawn record ahead of barrier A - a software prefetch of
-        // what the re-spawn will load - made the launch 0.23 us LONGER: profiles/r04_j_ab_step_prefetch.txt.)
-        constexpr bool kDrawAhead = A >= 8;
-        const bool respawns = kDrawAhead && (F & TDE_F_AUTORESET) && (F & TDE_F_REWARD);
-        if (respawns && a < 2)
-            sh.draw[lane / A][a] = philox(cold.seed, cold.env_base + (uint32_t)es, (uint32_t)er.episode, (uint32_t)a, 0x7DEu);
-        lds_barrier();                                       // B
-        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_C2);    // the longest chain behind B
-        er.steps += 1;
-        const int k = er.steps;
-        const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
-        bool hit;
-        if constexpr (A == 16 && TDE_COLLIDE_DPP)
-            hit = collide_rows_dpp16(&sh.a[0][base], &sh.b[0][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
-        else
-            hit = collide_rows<A>(&sh.a[0][base], &sh.b[0][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
-        const unsigned long long hm = __ballot(hit);
-        if (lane == 0) sh.hit_mask = hm;
-        // The ego's reward (R6 / R7 / R12).  Its float64 cosine (psi_reward, :403) is judge O's (it is the shorter of the two
-        // judges: stamps 5.1 k against 2.9 k cycles behind barrier B, profiles/r04_d_step_stamps.txt) and arrives through LDS at
-        // barrier A; the sum of :409-411 is formed here in the reference's order.
-        RewardOut rw{};
-        const int ti0 = er.target_idx;
-        bool reach = false;
-        if (a == 0 && valid && (F & TDE_F_REWARD)) {
-            const RewardBounds rb = reward_bounds(cold);
-            rw.dist_r = reward_dist_term(cold, rb, lx, ly, ra.x, ra.y);
-            reach = ti0 < cx.n_wp && reward_reach(cold, rb, ra.x, ra.y, cx.wtx, cx.wty);
-            if (reach) { er.reached += 1; er.target_idx = ti0 + 1; }
-            if (st.info) {
-                rw.psi_smooth = (double)fabsf((lpsi - rc.x) / 0.1f);
-                rw.speed_smooth = (double)fabsf((lv - rc.y) / 0.1f);
-            }
-            if (er.target_idx != ti0) load_ego_target(cold, er, cx);
-        }
-        // The ego's start in the episode a re-spawn would open (its look-ups behind the scenario draw, the Gaussian heading
-        // noise: ~1.2 k cycles on ONE lane) is formed here, every step, in this judge's idle time ahead of barrier A - what is
-        // left on the re-spawn path, the tail every launch waits for, is the spawn records and the stores.
-        if (respawns && a == 0 && valid) {
-            const uint4 d0 = sh.draw[lane / A][0], d1 = sh.draw[lane / A][1];
-            float4 pose, attr;
-            double2 wp1;
-            int4 sce;
-            ego_spawn(cfg, cold, (int)(((uint64_t)d0.x * (uint64_t)cold.n_scn) >> 32), d0, d1, pose, attr, &wp1, &sce);
-            sh.ego_next[lane / A][0] = pose; sh.ego_next[lane / A][1] = attr;
-            sh.ego_next_tgt[lane / A] = wp1; sh.ego_next_scn[lane / A] = sce;
-        }
-        lds_barrier();                                       // A: off / tl masks and the ego's psi term are in
-        if (a == 0 && valid && (F & TDE_F_REWARD)) {
-            rw.psi_r = reinterpret_cast<const double *>(sh.ring_pre)[lane];
-            rw.reward = reward_sum(cold, reach, rw.dist_r, rw.psi_r);
-        }
-        unsigned long long term_m, trunc_m;
-        const unsigned long long dn = done_of(k, term_m, trunc_m);
-#ifdef TDE_EXP_NO_C_RESPAWN           // timing experiment (WRONG results)
-        const bool respawned = false;
-#else
-        const bool respawned = dn && ((dn >> base) & 1ull) && valid;
-#endif
-        Agent ag;                                            // only filled (and used) when the env re-spawns
-        ag.x = ra.x; ag.y = ra.y; ag.psi = rc.x; ag.v = rc.y;
-        float oc = rb.x, os = rb.y;
-        const int k_done = k;
-        const int reached_out = er.reached;
-        int new_map = -1;                                    // the new episode's map id when it came with the parked scenario entry
-        if (respawned) {
-            reset_lane<A, true, (A >= 8)>(cfg, cold, e, a, ag, er, sh.draw[lane / A][0], sh.draw[lane / A][1],
-                                          (A >= 8) ? sh.ego_next[lane / A] : nullptr);
-            if (a == 0 && (F & TDE_F_REWARD)) {
-                if constexpr (A >= 8) {                      // (parked ahead of barrier A: no look-up on the launch's tail)
-                    const int4 sce = sh.ego_next_scn[lane / A];
-                    const double2 t1 = sh.ego_next_tgt[lane / A];
-                    cx.n_wp = sce.y; new_map = sce.x;
-                    cx.wtx = t1.x; cx.wty = t1.y;            // (target_idx = 1; read only when 1 < n_wp)
-                } else {
-                    cx.n_wp = reinterpret_cast<const int4 *>(cold.scn)[er.scn].y;
-                    load_ego_target(cold, er, cx);
-                }
-                if (OBS) sincos_f32(ag.psi, os, oc);
-            }
-        }
-        if (!valid) return;
-        st.collided[g] = respawned ? 0 : (hit ? 1 : 0);
-        if (a == 0) {
-            const uint8_t term = (uint8_t)((term_m >> lane) & 1ull), trunc = (uint8_t)((trunc_m >> lane) & 1ull);
-            const uint8_t off0 = (uint8_t)((sh.off_mask >> lane) & 1ull), hit0 = (uint8_t)((sh.hit_mask >> lane) & 1ull),
-                          tl0 = (uint8_t)((sh.tl_mask >> lane) & 1ull);
-            st.steps[e] = er.steps;
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            st.reward[e] = rw.reward;
-            st.terminated[e] = term;
-            st.truncated[e] = trunc;
-            if (respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
-            if ((F & TDE_F_REWARD) && st.info) {
-                double *inf = st.info + 4 * (int64_t)e;
-                inf[0] = rw.psi_smooth; inf[1] = rw.speed_smooth; inf[2] = rw.psi_r; inf[3] = rw.dist_r;
-            }
-            if ((F & TDE_F_REWARD) && st.info_reached) st.info_reached[e] = reached_out;
-            if (st.done_bits) st.done_bits[e] = (uint8_t)(term | (trunc << 1) | (off0 << 2) | (hit0 << 3) | (tl0 << 4));
-            if (st.ep_return) {
-                double ret = ep_ret + (double)rw.reward;
-                if (term | trunc) {
-                    if (st.ep_final) st.ep_final[e] = ret;
-                    if (st.ep_final_len) st.ep_final_len[e] = k_done;
-                    if (respawned) ret = 0.0;
-                }
-                st.ep_return[e] = ret;
-            }
-            if (F & TDE_F_REWARD) {
-                if (respawned || er.target_idx != ti0 || !ecache_ok) {
-                    int4 *ec4 = reinterpret_cast<int4 *>(st.env_cache + e);
-                    ec4[0] = make_int4(er.scn, er.target_idx, cx.n_wp | TDE_CACHE_VALID, new_map >= 0 ? new_map : reinterpret_cast<const int4 *>(cold.scn)[er.scn].x);
-                    reinterpret_cast<double2 *>(st.env_cache + e)[1] = make_double2(cx.wtx, cx.wty);
-                }
-            }
-            if (OBS && st.obs) {
-                const bool ended = (term | trunc) && !respawned;
-                bool has = er.target_idx < cx.n_wp;          // (one-armed, values pinned: see env_step_kernel)
-                double tx = cx.wtx, ty = cx.wty;
-                asm volatile("" : "+v"(tx), "+v"(ty));
-                if (!(F & TDE_F_REWARD) || ended) {
-                    has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
-                    const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
-                    tx = t2.x; ty = t2.y;
-                }
-                float fwd = 0.0f, lat = 0.0f;
-                if (has) {
-                    const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
-                    fwd = dx * oc + dy * os;
-                    lat = dy * oc - dx * os;
-                }
-                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
-                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
-                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
-            }
-        }
-    } else {
-        // ===================== judge O: offroad, stop lines =====================
-        __builtin_amdgcn_s_setprio(TDE_SPRIO_O);
-        const int eso = es;
-        const int scn = st.scn[eso];
-        const int k = st.steps[eso] + 1;
-        int4 e0 = make_int4(0, 0, 0, 0);
-        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) e0 = reinterpret_cast<const int4 *>(st.env_cache + eso)[0];
-        float lpsi = 0.0f;                                   // the ego's heading before the step (:373), for its psi term
-        if (a == 0 && valid && (F & TDE_F_REWARD)) lpsi = st.psi[g];
-        lds_barrier();                                       // cold is published
-        tde_map m{};
-        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) {
-            const int map = ((e0.z & TDE_CACHE_VALID) && e0.x == scn) ? e0.w : reinterpret_cast<const int4 *>(cold.scn)[scn].x;
-            m = cold.maps[map];
-        }
-        const float thr2 = thr2_of(cfg);
-#ifndef TDE_EXP_MAG_FRAME
-#define TDE_EXP_MAG_FRAME 0          // timing experiments (WRONG results): 1 no zero store, 2 no tile words, 4 no parking, 8 no touches, 16 no map words
-#endif
-        if constexpr (MAG) { if (a == 0 && !(TDE_EXP_MAG_FRAME & 16)) map_to_lds(sh.mapw[lane / A], m); }
-        uint32_t red_k = 0u;
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) {
-            // in the wait for barrier B: the env's stop lines into LDS, the red masks of this step and of the next one
-            fill_stop_cache<A>(sh, w, m, lane, a);
-            uint32_t red_n;
-            red_mask_pair(w, m, k, red_k, red_n);
-            if (a == 0) sh.lights[lane / A] = make_int4((int)red_k, (int)red_n, m.stop_base, m.n_stop);
-        }
-        lds_barrier();                                       // B
-        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_O2);
-        const float4 ra = sh.a[0][lane], rb = sh.b[0][lane], rc = sh.c[0][lane];
-        const bool live = rc.z != 0.0f;
-        bool off = false, tl = false;
-        // MAG: the ego lanes fetch the near-list words of their four corners (tde_world.tile_near) beside the offroad test - the
-        // first half of the chain tile word -> records that the offroad MAGNITUDE of a flagged ego walks (each a round trip to
-        // HBM / the fabric for these rarely touched lines); they are consumed behind barrier A
-        Corners kc{};
-        uint32_t tw0 = 0u, tw1 = 0u, tw2 = 0u, tw3 = 0u;
-        if (F & TDE_F_OFFROAD) {
-            if constexpr (MAG) {
-                offroad_issue<TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, kc);
-                // (only for an ego with a corner outside the FULL cells - one that CAN be off the road: the others' words would be
-                //  four more loads per env that this wavefront has to wait for ahead of barrier A, and every workgroup has egos)
-                // (tried, profiles/r05_magnitudes_floor.md: EVERY ego's words, issued beside the class look-ups: +0.16 us; the words kept
-                //  in registers across barrier A and parked behind it, no touches: +-0)
-                if (!(TDE_EXP_MAG_FRAME & 2) && a == 0 && live && min(min(kc.w0 & 3u, kc.w1 & 3u), min(kc.w2 & 3u, kc.w3 & 3u)) != TDE_CELL_FULL) {
-                    tw0 = near_tile_word(w, m, kc.px0, kc.py0); tw1 = near_tile_word(w, m, kc.px1, kc.py1);
-                    tw2 = near_tile_word(w, m, kc.px2, kc.py2); tw3 = near_tile_word(w, m, kc.px3, kc.py3);
-                }
-                off = offroad_resolve<true, TDE_STEP_CLS2 != 0>(w, kc, thr2, m.rec_base);
-            } else {
-                off = box_offroad<true, TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
-            }
-        }
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-            tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + m.stop_base, lane / A}, m.n_stop, red_k, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
-        const unsigned long long om = __ballot(off), tm = __ballot(tl);
-        if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
-        // the ego's psi term for judge C (get_reward :403; ring_pre is the rollout kernel's, unused in a one-step launch)
-        if (a == 0 && valid && (F & TDE_F_REWARD)) reinterpret_cast<double *>(sh.ring_pre)[lane] = reward_psi_term(cold, lpsi, rc.x);
-        // MAG: the records of the first flagged ego's near lists are requested here, AHEAD of barrier A (no wait: the loads
-        // are in flight while this wavefront sits at the barrier and forms the done masks)
-        // (the ego lanes' corner points and tile words go to LDS - ring_post, the rollout kernel's and unused in a one-step launch:
-        //  floats [32, 32 + 8 * 12) behind box_iou_wave's 32 - so that nothing but the first ego's twelve record registers stays
-        //  live across the barrier: the section runs under this kernel's 80-VGPR budget)
-        float *nearw = reinterpret_cast<float *>(sh.ring_post) + 32;
-        if constexpr (MAG) {
-            if (a == 0 && !(TDE_EXP_MAG_FRAME & 4)) {
-                float4 *d = reinterpret_cast<float4 *>(nearw + 12 * (lane / A));
-                d[0] = make_float4(kc.px0, kc.px1, kc.px2, kc.px3);
-                d[1] = make_float4(kc.py0, kc.py1, kc.py2, kc.py3);
-                d[2] = make_float4(__uint_as_float(tw0), __uint_as_float(tw1), __uint_as_float(tw2), __uint_as_float(tw3));
-            }
-            wave_lds_fence();
-        }
-        auto corners_of = [&](int src, NearFetch &nf, bool fetch) {   // lanes 16 c .. 16 c + 15 take corner c of the ego on lane src
-            const float *sp = nearw + 12 * (src / A) + (lane >> 4);
-            nf.px = sp[0]; nf.py = sp[4]; nf.tw = __float_as_uint(sp[8]);
-            nf.t0 = nf.t1 = nf.t2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (fetch && __ballot(near_listed(nf.tw))) near_issue(w, __builtin_amdgcn_readfirstlane(sh.mapw[src / A][2].x), lane, nf);
-        };
-        // the near-list records of the first two flagged egos are TOUCHED here, ahead of barrier A: one dword per lane, sixteen
-        // lanes per corner - every 128-byte line of a list's first 16 records holds the start of one - so that the real fetch behind
-        // the barrier finds them in the L2 (held in registers across the barrier, twelve per lane and ego, they cost the kernel its
-        // spill-free fit)
-        float touch0 = 0.0f, touch1 = 0.0f;
-        unsigned long long fo = 0ull;
-        if constexpr (MAG) {
-            fo = om & __ballot(a == 0 && valid);
-            auto touch = [&](int src) {
-                const uint32_t tw = __float_as_uint(nearw[12 * (src / A) + 8 + (lane >> 4)]);
-                const uint32_t rb0 = (uint32_t)__builtin_amdgcn_readfirstlane(sh.mapw[src / A][2].x);
-                const float *recs = w.cell_tri + 12 * (size_t)(rb0 + (near_listed(tw) ? tw - 1u : 0u));
-                return near_listed(tw) ? recs[12 * (lane & 15)] : 0.0f;
-            };
-            if (fo && !(TDE_EXP_MAG_FRAME & 8)) touch0 = touch(__ffsll((long long)fo) - 1);
-            if ((fo & (fo - 1)) && !(TDE_EXP_MAG_FRAME & 8)) touch1 = touch(__ffsll((long long)(fo & (fo - 1))) - 1);
-        }
-        lds_barrier();                                       // A
-        unsigned long long term_m, trunc_m;
-        const unsigned long long dn = done_of(k, term_m, trunc_m);
-        if (valid) {
-            st.offroad[g] = (dn && ((dn >> base) & 1ull)) ? 0 : (off ? 1 : 0);
-            if (a == 0 && st.tl_violation) st.tl_violation[e] = tl ? 1 : 0;
-        }
-        // tde_state.magnitudes (get_info's "collision" / "offroad", :427-428) for the egos this step flagged: this judge has nothing
-        // left to do while the driver and judge C re-spawn the finished envs, and the rows of the step stay in buffer 0.  Every ego
-        // lane stores zeros first and the lane of a flagged ego its values when they are known (same lane, same address, program
-        // order).
-        if constexpr (MAG) {
-            const bool ego = a == 0 && valid;
-            float *out_e = ego ? st.magnitudes + 4 * (int64_t)e : nullptr;
-            if (ego && !(TDE_EXP_MAG_FRAME & 1)) *reinterpret_cast<float4 *>(out_e) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            // (collision first: it runs out of LDS while the touched lines of the offroad part arrive)
-#ifndef TDE_EXP_NO_COLL_MAG
-            const unsigned long long hm = sh.hit_mask;
-            for (unsigned long long fc = hm & __ballot(ego); fc; fc &= fc - 1) {     // collision (rarely more than one trip)
-                const int src = __ffsll((long long)fc) - 1;
-                const float4 ea = sh.a[0][src], eb4 = sh.b[0][src];
-                const EgoBox eb{readlane_f(ea.x, 0), readlane_f(ea.y, 0), readlane_f(eb4.x, 0), readlane_f(eb4.y, 0), readlane_f(eb4.z, 0), readlane_f(eb4.w, 0)};
-                const float2 cm = ego_collision_mag_of(A, lane, eb, TileRows{&sh.a[0][src], &sh.b[0][src]}, reinterpret_cast<float *>(sh.ring_post));
-                if (lane == src) { out_e[1] = cm.x; out_e[2] = cm.y; }
-            }
-#endif
-            asm volatile("" :: "v"(touch0), "v"(touch1));            // (the touches complete here at the latest)
-#ifndef TDE_EXP_NO_OFF_MAG                   // (timing experiments: WRONG results)
-            for (unsigned long long f = fo; f; f &= f - 1) {          // offroad
-                const int src = __ffsll((long long)f) - 1;
-                NearFetch nf;
-                corners_of(src, nf, true);
-                const float omag = near_finish<true>(cfg, w, map_from_lds(sh.mapw[src / A]), nf, lane, [&]() {
-                    const int4 c = sh.mapw[src / A][2];
-                    return make_int2(__builtin_amdgcn_readfirstlane(c.z), __builtin_amdgcn_readfirstlane(c.w));
-                });
-                if (lane == src) out_e[0] = omag;
-            }
-#endif
-        }
-    }
-}
-
-template <int A>
-__global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_world w, tde_state st,
-                                                           const uint8_t *__restrict__ mask)
-{
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int e = (int)(g / A), a = (int)(g % A);
-    if (e >= st.B) return;
-    if (mask && !mask[e]) return;
-    Agent ag;
-    EnvRegs er{0, 0, 0, 0, st.episode[e]};
-    Cold cold;
-    fill_cold(cold, cfg, w);
-    reset_lane<A>(cfg, cold, e, a, ag, er);
-    store_agent_dynamic(st, g, ag);
-    store_agent_static(st, g, ag);
-    st.collided[g] = 0;
-    st.offroad[g] = 0;
-    if (a == 0) {
-        st.scn[e] = er.scn; st.steps[e] = 0; st.target_idx[e] = 1; st.reached[e] = 0; st.episode[e] = er.episode;
-        if (st.ep_return) st.ep_return[e] = 0.0;
-    }
-}
-
-// --- operator-level kernels (SimulatorInterface methods) ------------------------------------------------
-__global__ __launch_bounds__(kBlock) void kinematics_kernel(int64_t n, float *x, float *y, float *psi, float *v,
-                                                            const float *__restrict__ lr,
-                                                            const uint8_t *__restrict__ present,
-                                                            const float *__restrict__ action, float dt)
-{
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    if (present && !present[i]) return;
-    float2 act = reinterpret_cast<const float2 *>(action)[i];
-    float X = x[i], Y = y[i], P = psi[i], V = v[i];
-    bicycle(X, Y, P, V, 1.0f / lr[i], act.x, act.y, dt);
-    x[i] = X; y[i] = Y; psi[i] = P; v[i] = V;
-}
-
-// kinematics (optional) + all-pairs collision; BASELINE config 2 when KIN
-template <int A, bool KIN>
-__global__ __launch_bounds__(kBlock) void collide_kernel(int B, float *x, float *y, float *psi, float *v,
-                                                         const float *__restrict__ lr, const float *__restrict__ len,
-                                                         const float *__restrict__ wid,
-                                                         const uint8_t *__restrict__ present,
-                                                         const float *__restrict__ action, float dt,
-                                                         uint8_t *__restrict__ out)
-{
-    __shared__ Tiles<kBlock> t;
-    const int tid = threadIdx.x;
-    const int64_t g = (int64_t)blockIdx.x * kBlock + tid;
-    const int a = (int)(g % A);
-    const bool valid = (g / A) < B;
-    const int64_t gs = valid ? g : 0;
-    float X = x[gs], Y = y[gs], P = psi[gs];
-    const bool live = valid && present[gs] != 0;
-    if (KIN && live) {
-        float V = v[gs];
-        float2 act = reinterpret_cast<const float2 *>(action)[gs];
-        bicycle(X, Y, P, V, 1.0f / lr[gs], act.x, act.y, dt);
-        x[g] = X; y[g] = Y; psi[g] = P; v[g] = V;
-    }
-    float s1, c1;
-    sincos_f32(P, s1, c1);
-    const float hl = 0.5f * len[gs], hw = 0.5f * wid[gs];
-    const float ri = (hl + hw) * kReach;
-    t.a[tid] = live ? make_float4(X, Y, ri, 0.0f) : make_float4(kFar, kFar, 0.0f, 0.0f);
-    t.b[tid] = make_float4(c1, s1, hl, hw);
-    tile_sync<A>();
-    const int base = tid - a;
-    bool hit;
-    if constexpr (A > 64) hit = collide_rows_wide<A>(&t.a[base], &t.b[base], a, live, X, Y, c1, s1, hl, hw, ri);
-    else hit = collide_rows<A>(&t.a[base], &t.b[base], a, live, X, Y, c1, s1, hl, hw, ri);
-    if (valid) out[g] = hit ? 1 : 0;
-}
-
-__global__ __launch_bounds__(kBlock) void offroad_kernel(int B, int A, const float *__restrict__ x,
-                                                         const float *__restrict__ y, const float *__restrict__ psi,
-                                                         const float *__restrict__ len, const float *__restrict__ wid,
-                                                         const uint8_t *__restrict__ present, tde_world w,
-                                                         const int32_t *__restrict__ map_of_env, float thr,
-                                                         uint8_t *__restrict__ out)
-{
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = g < (int64_t)B * A;
-    const int64_t gs = valid ? g : 0;
-    const bool live = valid && present[gs] != 0;
-    float s1, c1;
-    sincos_f32(psi[gs], s1, c1);
-    const tde_map m = w.maps[map_of_env[gs / A]];
-    const bool off = box_offroad(w, m, live, x[gs], y[gs], c1, s1, 0.5f * len[gs], 0.5f * wid[gs], thr * thr);
-    if (valid) out[g] = off ? 1 : 0;
-}
-
-__global__ __launch_bounds__(kBlock) void reward_kernel(
-    tde_config cfg, int n, const float *__restrict__ pre_x, const float *__restrict__ pre_y,
-    const float *__restrict__ pre_psi, const float *__restrict__ pre_v, const float *__restrict__ x,
-    const float *__restrict__ y, const float *__restrict__ psi, const float *__restrict__ v,
-    const uint8_t *__restrict__ offroad, const uint8_t *__restrict__ collided, const uint8_t *__restrict__ tl,
-    const double *__restrict__ wp_xy, const int32_t *__restrict__ wp_n, int NW, const int32_t *__restrict__ scn,
-    int32_t *steps, int32_t *target_idx, int32_t *reached, float *reward, uint8_t *terminated, uint8_t *truncated,
-    double *info, int32_t *info_reached)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    int k = steps[i] + 1;
-    steps[i] = k;
-    int ti = target_idx[i], rc = reached[i];
-    const int s = scn[i];
-    const int nw = wp_n[s];
-    double wtx = 0.0, wty = 0.0;
-    if (ti < nw) { wtx = wp_xy[((int64_t)s * NW + ti) * 2]; wty = wp_xy[((int64_t)s * NW + ti) * 2 + 1]; }
-    RewardOut r = reward_core(cfg, nw, wtx, wty, pre_x[i], pre_y[i], pre_psi[i], pre_v[i], x[i], y[i], psi[i], v[i],
-                              offroad[i] != 0, collided[i] != 0, tl ? tl[i] != 0 : false, k, ti, rc);
-    target_idx[i] = ti;
-    reached[i] = rc;
-    reward[i] = r.reward;
-    terminated[i] = r.terminated;
-    truncated[i] = r.truncated;
-    if (info) {
-        double *inf = info + 4 * (int64_t)i;
-        inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
-    }
-    if (info_reached) info_reached[i] = rc;
-}
-
-// compact observation of the ego (obs_mode "state" of the host mirror): one lane per env
-__global__ __launch_bounds__(kBlock) void state_obs_kernel(tde_world w, tde_state st, float *__restrict__ out)
-{
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= st.B) return;
-    const int64_t g = (int64_t)e * st.A;
-    const float x = st.x[g], y = st.y[g], psi = st.psi[g], v = st.v[g];
-    const int scn = st.scn[e], ti = st.target_idx[e];
-    const int n_wp = reinterpret_cast<const int4 *>(w.scn)[scn].y;
-    const bool has = ti < n_wp;
-    float fwd = 0.0f, lat = 0.0f;
-    if (has) {
-        const double2 t = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)scn * w.NW + ti];
-        float s, c;
-        sincos_f32(psi, s, c);
-        const float dx = (float)t.x - x, dy = (float)t.y - y;
-        fwd = dx * c + dy * s;
-        lat = dy * c - dx * s;
-    }
-    float4 *o = reinterpret_cast<float4 *>(out) + 2 * (int64_t)e;
-    o[0] = make_float4(x, y, psi, v);
-    o[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)st.steps[e]);
-}
-
-
-// Frame stack (VecFrameStack(n_stack, channels_order="first"), ref examples/rl_training.py:160): the older frames of
-// every view move down by one frame, in place, before the new frame is rasterised.  A launch of its own: as a pure
-// streaming copy it runs at cache / HBM bandwidth, whereas inside the rasteriser's workgroups the same bytes cost two
-// exposed round trips per view (212 -> ~110 us per 8192 views at n_stack 3).  One workgroup per view and chunk: read
-// the chunk, barrier, write it (dst trails src by one frame, so later chunks read above everything written so far).
-__global__ __launch_bounds__(kBlock) void frame_shift_kernel(uint8_t *__restrict__ stack, int plane, int ns)
-{
-    uint8_t *out = stack + (int64_t)blockIdx.x * 3 * ns * plane;
-    const int tid = threadIdx.x;
-    const int nvec = 3 * (ns - 1) * plane / 16;
-    const uint4 *src = reinterpret_cast<const uint4 *>(out + 3 * plane);
-    uint4 *dst = reinterpret_cast<uint4 *>(out);
-    for (int i0 = 0; i0 < nvec; i0 += kBlock * 8) {
-        uint4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * kBlock + tid; if (i < nvec) v[u] = src[i]; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * kBlock + tid;
-            if (i < nvec) {
-                store_nt16(&dst[i], v[u]);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// R13: ego-centred birdview raster (get_obs -> render_egocentric, ref gym_env.py:122-124; layers: tde_abi.h), stand-alone
-// form: one wavefront per view (tde_raster.h: raster_view), agent poses read from the state arrays.
-// ------------------------------------------------------------------------------------------------------------------
-// Kernel arguments of the rasteriser: only what it reads (tde_config + tde_world + tde_state + tde_render by value are
-// about 120 SGPRs of arguments).
-struct RenderArgs {
-    const tde_map *maps;
-    const uint32_t *cell_word;
-    const float *cell_tri;
-    const tde_scenario *scn_tab;
-    const double *wp_xy;
-    const tde_stopline *stoplines;
-    const tde_light_phase *phases;
-    const float *x, *y, *psi, *len, *wid;
-    const uint8_t *present;
-    const int32_t *scn, *steps, *target_idx;
-    tde_render rd;
-    float thr2;
-    uint32_t flags;
-    int32_t NW, A;
-    const uint32_t *cell_cls2, *cell_sub;
-    const uint8_t *cell_coarse;
-    int32_t K8, K4;                     // raster_block_clearance(8 / 4, res)
-};
-
-// agent poses from the state arrays (slot j of the view's env)
-struct StateAgents {
-    const float *x, *y, *psi, *len, *wid;
-    const uint8_t *present;
-    int64_t g0;
-    struct Raw { float x, y, psi, len, wid; uint8_t present; };
-    TDE_DEV Raw fetch(int j) const
-    {
-        const int64_t g = g0 + j;
-        return Raw{x[g], y[g], psi[g], len[g], wid[g], present[g]};
-    }
-    TDE_DEV bool unpack(const Raw &r, float &ox, float &oy, float &oc, float &os, float &hl, float &hw) const
-    {
-        ox = r.x; oy = r.y;
-        sincos_f32(r.psi, os, oc);
-        hl = 0.5f * r.len; hw = 0.5f * r.wid;
-        return r.present != 0;
-    }
-};
-
-// Eight views (wavefronts) per SIMD: at most 64 VGPRs, 80 SGPRs and 5 KB of LDS per view, so that 8192 views are ONE
-// residency round of the chip (32 per CU).  A view is bound by the latency of its chain of dependent memory round trips, so
-// the more views in flight the better: 7 per SIMD 47.6 us, 6 per SIMD 48.3, 8 per SIMD 44.4; two views per wavefront, one
-// after the other, 79 us (profiles/r03_b_render_views_per_wave.txt)
-#ifndef TDE_RENDER_WAVES
-#define TDE_RENDER_WAVES 8
-#endif
-#ifndef TDE_RENDER_SGPRS
-#define TDE_RENDER_SGPRS 80
-#endif
-// TDE_RENDER_VPW views per workgroup, one wavefront each (they share nothing: no barrier): fewer, larger workgroups for the
-// dispatcher to place
-#ifndef TDE_RENDER_VPW
-#define TDE_RENDER_VPW 4
-#endif
-constexpr int kViewsPerGroup = TDE_RENDER_VPW;
-template <int SIZE>   // 64: 64 x 64 images (the reference's observation; every stride a constant); 0: rd.H x rd.W
-__global__ __launch_bounds__(kWave * kViewsPerGroup) __attribute__((amdgpu_waves_per_eu(TDE_RENDER_WAVES, TDE_RENDER_WAVES), amdgpu_num_sgpr(TDE_RENDER_SGPRS)))
-void render_views_kernel(RenderArgs ra, int B)
-{
-    __shared__ RasterScratch Sall[kViewsPerGroup];
-#if TDE_RASTER_SKIP & 64          // tuning probe: the launch alone (what 8192 wavefronts with this footprint cost to place)
-    if (ra.rd.H != 12345) { if (threadIdx.x == 9999) Sall[0].plane[0] = 1; return; }
-#endif
-    const tde_render &rd = ra.rd;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    RasterScratch &S = Sall[wv];
-#ifndef TDE_RENDER_VPWAVE
-#define TDE_RENDER_VPWAVE 1
-#endif
-  for (int rep = 0; rep < TDE_RENDER_VPWAVE; ++rep) {
-    const int e = (blockIdx.x * kViewsPerGroup + wv) * TDE_RENDER_VPWAVE + rep;
-    if (e >= B) return;
-    if (rd.only && !rd.only[e]) continue;          // masked call: this view keeps its pixels and its ring
-    const int ns = rd.n_stack > 1 ? rd.n_stack : 1;
-    const int plane = rd.H * rd.W;
-    const int64_t g0 = (int64_t)e * ra.A;
-    const int scn = ra.scn[e];
-    const int4 sc = reinterpret_cast<const int4 *>(ra.scn_tab)[scn];            // map, wp_n, start_heading, pad
-    RasterJob J;
-    J.cell_word = ra.cell_word; J.cell_tri = ra.cell_tri; J.cell_cls2 = ra.cell_cls2; J.cell_sub = ra.cell_sub;
-    J.cell_coarse = ra.cell_coarse;
-    J.m = ra.maps[sc.x];
-    J.stoplines = ra.stoplines + J.m.stop_base;
-    J.wp = ra.wp_xy + (int64_t)scn * ra.NW * 2;
-    J.lights = (ra.flags & TDE_F_TRAFFIC_LIGHTS) != 0 && J.m.n_stop > 0;
-    J.red = 0u;
-    if (J.lights) {
-        // the light state at the env's current step (oracle: tde_red_mask)
-        tde_world w{};
-        w.phases = ra.phases;
-        J.red = red_mask(w, J.m, ra.steps[e]);
-    }
-    J.n_wp = sc.y; J.ti = ra.target_idx[e]; J.A = ra.A;
-    J.ex = ra.x[g0]; J.ey = ra.y[g0];
-    sincos_f32(ra.psi[g0], J.se, J.ce);
-    J.H = rd.H; J.W = rd.W; J.ns = ns; J.phase = rd.phase; J.flags = rd.flags;
-    J.res = rd.fov / (float)rd.W; J.inv_res = 1.0f / J.res; J.thr2 = ra.thr2;
-    J.K8 = ra.K8; J.K4 = ra.K4;
-    J.out = rd.out + (int64_t)e * 3 * ns * plane;
-    J.ring = rd.layers ? rd.layers + (int64_t)e * ns * plane : nullptr;
-    J.fresh = rd.fresh && (rd.fresh[e] & 3);       // the episode of this view just (re)started: older frames are blank
-#if TDE_RASTER_SKIP & 128         // tuning probe: the view's own duration (s_memtime ticks) over its first 16 output bytes
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    int dbg[3] = {0, 0, 0};
-    raster_view<SIZE>(S, J, StateAgents{ra.x, ra.y, ra.psi, ra.len, ra.wid, ra.present, g0}, dbg);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == 0) {
-        reinterpret_cast<unsigned long long *>(J.out)[0] = t1 - t0;
-        reinterpret_cast<int *>(J.out)[2] = dbg[0]; reinterpret_cast<int *>(J.out)[3] = dbg[1]; reinterpret_cast<int *>(J.out)[4] = dbg[2];
-    }
-#else
-    raster_view<SIZE>(S, J, StateAgents{ra.x, ra.y, ra.psi, ra.len, ra.wid, ra.present, g0});
-#endif
-  }
-}
-
-}  // namespace tde
-
-#include "tde_magnitudes_kernels.h"
-
-// Register / spill figures of a few kernels in seconds instead of the 80 s of the whole translation unit:
+// tde_kernels.hip — libtde_hip.so as ONE translation unit: every unit of the library included here.  build.py compiles the units
+// side by side instead (about a third of the wall time on 8 cores); this form serves the A/B and resource-probe scripts
+// (scripts/build_variant.sh, scripts/kernel_resources.sh, scripts/probe_kernel.sh), which pass one source file to hipcc.
+#define TDE_TU_API 1
+#include "tde_kernels.h"
+
+// Register / spill figures of a few kernels in seconds instead of the minutes of the whole library:
 // -DTDE_KERNEL_PROBE -I<dir of a tde_probe.inc holding explicit instantiations> --offload-device-only (scripts/probe_kernel.sh)
 #ifdef TDE_KERNEL_PROBE
 #include "tde_probe.inc"
 #else
-// ------------------------------------------------------------------------------------------------------------------
-// C-ABI
-// ------------------------------------------------------------------------------------------------------------------
-static thread_local char g_err[256] = "";
-
-static int fail(const char *what, hipError_t e)
-{
-    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
-    return (int)e;
-}
-
-static int bad(const char *msg)
-{
-    snprintf(g_err, sizeof(g_err), "%s", msg);
-    return (int)hipErrorInvalidValue;
-}
-
-static bool pow2_le64(int A) { return A >= 1 && A <= TDE_MAX_AGENTS && (A & (A - 1)) == 0; }
-// (up to 64 slots an env lives inside one wavefront and every kernel form applies; 128 = TDE_MAX_AGENTS: an env spans two
-//  wavefronts - tde_env_step runs the one-role kernel's generic form (TDE_DISPATCH_A128), tde_env_rollout the persistent
-//  env_rollout_wide_kernel (two roles, four wavefronts per env) at every batch size, the one-role persistent kernel only under
-//  tde_kernel_override(1, 0); forced forms 2 and 3 do not exist at 128 slots and leave the choice as it is)
-
-#define TDE_DISPATCH_A(A, ...)                                  \
-    switch (A) {                                                \
-        case 1: { constexpr int kA = 1; __VA_ARGS__; } break;   \
-        case 2: { constexpr int kA = 2; __VA_ARGS__; } break;   \
-        case 4: { constexpr int kA = 4; __VA_ARGS__; } break;   \
-        case 8: { constexpr int kA = 8; __VA_ARGS__; } break;   \
-        case 16: { constexpr int kA = 16; __VA_ARGS__; } break; \
-        case 32: { constexpr int kA = 32; __VA_ARGS__; } break; \
-        case 64: { constexpr int kA = 64; __VA_ARGS__; } break; \
-    }
-#define TDE_DISPATCH_A128(A, ...)                               \
-    if ((A) == 128) { constexpr int kA = 128; __VA_ARGS__; } else TDE_DISPATCH_A(A, __VA_ARGS__)
-
-static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + tde::kBlock - 1) / tde::kBlock); }
-
-// which kernel form tde_env_rollout / tde_env_step launch: 0 = by group shape and batch size (the measured choice), else
-// forced (tde_kernel_override: parity tests of every form, A/B runs)
-static std::atomic<int> g_force_rollout{0}, g_force_step{0};
-
-extern "C" {
-
-int tde_abi_version(void) { return TDE_ABI_VERSION; }
-
-int tde_kernel_override(int rollout_team, int step_team)
-{
-    if (rollout_team < 0 || rollout_team > 3 || !(step_team == 0 || step_team == 1 || step_team == 3))
-        return bad("tde_kernel_override: rollout_team in {0, 1, 2, 3}, step_team in {0, 1, 3}");
-    g_force_rollout = rollout_team;
-    g_force_step = step_team;
-    return 0;
-}
-
-const char *tde_last_error(void) { return g_err; }
-
-int tde_kinematics_step(int64_t n, float *x, float *y, float *psi, float *v, const float *lr, const uint8_t *present,
-                        const float *action, float dt, void *stream)
-{
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(tde::kinematics_kernel, dim3(blocks_for(n)), dim3(tde::kBlock), 0, (hipStream_t)stream, n, x, y,
-                       psi, v, lr, present, action, dt);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_kinematics_step", e);
-}
-
-int tde_compute_collision(int32_t B, int32_t A, const float *x, const float *y, const float *psi, const float *len,
-                          const float *wid, const uint8_t *present, uint8_t *out, void *stream)
-{
-    if (!pow2_le64(A)) return bad("tde_compute_collision: A must be a power of two in [1,128]");
-    if (B <= 0) return 0;
-    const unsigned nb = blocks_for((int64_t)B * A);
-    TDE_DISPATCH_A128(A, tde::collide_kernel<kA, false><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
-                          B, const_cast<float *>(x), const_cast<float *>(y), const_cast<float *>(psi), (float *)nullptr,
-                          (const float *)nullptr, len, wid, present, (const float *)nullptr, 0.0f, out));
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_compute_collision", e);
-}
-
-int tde_kin_collide_step(int32_t B, int32_t A, float *x, float *y, float *psi, float *v, const float *lr,
-                         const float *len, const float *wid, const uint8_t *present, const float *action, float dt,
-                         uint8_t *collided, void *stream)
-{
-    if (!pow2_le64(A)) return bad("tde_kin_collide_step: A must be a power of two in [1,128]");
-    if (B <= 0) return 0;
-    const unsigned nb = blocks_for((int64_t)B * A);
-    TDE_DISPATCH_A128(A, tde::collide_kernel<kA, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(
-                          B, x, y, psi, v, lr, len, wid, present, action, dt, collided));
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_kin_collide_step", e);
-}
-
-int tde_compute_offroad(int32_t B, int32_t A, const float *x, const float *y, const float *psi, const float *len,
-                        const float *wid, const uint8_t *present, const tde_world *world, const int32_t *map_of_env,
-                        float threshold, uint8_t *out, void *stream)
-{
-    if (!world) return bad("tde_compute_offroad: world is NULL");
-    if (B <= 0) return 0;
-    hipLaunchKernelGGL(tde::offroad_kernel, dim3(blocks_for((int64_t)B * A)), dim3(tde::kBlock), 0, (hipStream_t)stream,
-                       B, A, x, y, psi, len, wid, present, *world, map_of_env, threshold, out);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_compute_offroad", e);
-}
-
-int tde_waypoint_reward(const tde_config *cfg, int32_t n, const float *pre_x, const float *pre_y, const float *pre_psi,
-                        const float *pre_v, const float *x, const float *y, const float *psi, const float *v,
-                        const uint8_t *offroad, const uint8_t *collided, const uint8_t *tl_violation,
-                        const double *wp_xy, const int32_t *wp_n, int32_t NW, const int32_t *scn, int32_t *steps,
-                        int32_t *target_idx, int32_t *reached, float *reward, uint8_t *terminated, uint8_t *truncated,
-                        double *info, int32_t *info_reached, void *stream)
-{
-    if (!cfg) return bad("tde_waypoint_reward: cfg is NULL");
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(tde::reward_kernel, dim3(blocks_for(n)), dim3(tde::kBlock), 0, (hipStream_t)stream, *cfg, n,
-                       pre_x, pre_y, pre_psi, pre_v, x, y, psi, v, offroad, collided, tl_violation, wp_xy, wp_n, NW, scn,
-                       steps, target_idx, reached, reward, terminated, truncated, info, info_reached);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_waypoint_reward", e);
-}
-
-static int check_env_args(const char *fn, const tde_config *cfg, const tde_world *w, const tde_state *st)
-{
-    if (!cfg || !w || !st) { snprintf(g_err, sizeof(g_err), "%s: NULL argument", fn); return (int)hipErrorInvalidValue; }
-    if (!pow2_le64(st->A)) { snprintf(g_err, sizeof(g_err), "%s: A must be a power of two in [1,128]", fn); return (int)hipErrorInvalidValue; }
-    if (w->A != st->A) { snprintf(g_err, sizeof(g_err), "%s: world.A (%d) != state.A (%d)", fn, w->A, st->A); return (int)hipErrorInvalidValue; }
-    // sqrt_cr_f32 (the controller's braking-distance speed) is exact for arguments that are zero or in the normal fp32
-    // range: amax times a length difference of metres is, for any sensible amax
-    if ((cfg->flags & TDE_F_NPC) && !(cfg->npc_max_steer >= 0.0f)) {          // clampf(v, -smax, smax) needs lo <= hi
-        snprintf(g_err, sizeof(g_err), "%s: config.npc_max_steer must be >= 0 (got %g)", fn, (double)cfg->npc_max_steer);
-        return (int)hipErrorInvalidValue;
-    }
-    if ((cfg->flags & TDE_F_NPC) && !(cfg->npc_max_accel >= 1e-3f && cfg->npc_max_accel <= 1e3f)) {
-        snprintf(g_err, sizeof(g_err), "%s: config.npc_max_accel must be in [1e-3, 1e3] m/s^2 (got %g)", fn, (double)cfg->npc_max_accel);
-        return (int)hipErrorInvalidValue;
-    }
-    return 0;
-}
-
-int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state *st, const uint8_t *mask,
-                  void *stream)
-{
-    int rc = check_env_args("tde_env_reset", cfg, world, st);
-    if (rc) return rc;
-    if (st->B <= 0) return 0;
-    const unsigned nb = blocks_for((int64_t)st->B * st->A);
-    TDE_DISPATCH_A128(st->A, tde::env_reset_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, mask));
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_env_reset", e);
-}
-
-// `load_slots`: the agent slots stepping on the device at the same time - the batch's own, or the whole batch's when this is one
-// of the sub-batches tde_env_step_render runs side by side (the choice of kernel form is a matter of load)
-// hash of what the NPC controller depends on besides the state (tde_act_cache; act_key_steps)
-static uint32_t act_cfg_hash(const tde_config &cfg, const tde_world &w)
-{
-#ifdef TDE_ACT_KEY_PLAIN          // (A/B builds: the round-3 key, the step counter alone)
-    return 0u;
+#include "tde_api.hip"
+#include "tde_step_trio.hip"
+#include "tde_step_solo.hip"
+#include "tde_step_solo_mag.hip"
+#include "tde_rollout_trio.hip"
+#include "tde_rollout_duo.hip"
+#include "tde_rollout_solo.hip"
 #endif
-    uint32_t h = cfg.flags & (TDE_F_NPC | TDE_F_REPLAY | TDE_F_TRAFFIC_LIGHTS);
-    // the identity of the tables the controller reads (routes, spawn records, stop lines, light phases, maps, scenarios): a caller
-    // that swaps or rebuilds the world under an unchanged state gets the actions recomputed, not replayed
-    const void *tabs[7] = {w.route_xy, w.spawn, w.stoplines, w.phases, w.maps, w.scn, w.replay_states};
-    for (int i = 0; i < 7; ++i) {
-        const uint64_t a = (uint64_t)(uintptr_t)tabs[i];
-        h = (h ^ (uint32_t)a) * 0x9E3779B1u;
-        h = (h ^ (uint32_t)(a >> 32)) * 0x9E3779B1u;
-    }
-    const int32_t dims[6] = {w.n_routes, w.RW, w.n_replay, w.RT, w.n_scn, w.n_maps};
-    for (int i = 0; i < 6; ++i) h = (h ^ (uint32_t)dims[i]) * 0x9E3779B1u;
-    const float c[10] = {cfg.npc_k_steer, cfg.npc_k_speed, cfg.npc_gap_s0, cfg.npc_cone_k, cfg.npc_lane_half, cfg.npc_reach,
-                         cfg.npc_max_accel, cfg.npc_max_steer, cfg.npc_cone_range, cfg.dt};
-    for (int i = 0; i < 10; ++i) {
-        uint32_t b;
-        memcpy(&b, &c[i], 4);
-        h = (h ^ b) * 0x9E3779B1u;
-    }
-    return h;
-}
-
-static int cu_count();
-static int env_step_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream, int64_t load_slots)
-{
-    int rc = check_env_args("tde_env_step", cfg, world, st);
-    if (rc) return rc;
-    if (st->B <= 0) return 0;
-    if (!st->action) return bad("tde_env_step: state.action is NULL");
-    if ((cfg->flags & TDE_F_OFFROAD) && TDE_STEP_CLS2 && !world->cell_cls2) return bad("tde_env_step: world.cell_cls2 is NULL (ABI 7 class map)");
-    const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-    // With the lookup caches present (and a group shape the three-role kernels are built for) the step runs as three
-    // wavefronts per 64 agent slots; tde_kernel_override forces one form (A/B runs).
-    // Which one wins is a matter of load (bench.py --mode step --step-kernel solo|trio, us per step at 16 agents per env,
-    // profiles/r03_d_step_matrix.txt):
-    //   envs     2048   4096   8192   16384   32768
-    //   3 roles  7.26   7.91   9.45   16.58   27.34
-    //   1 role   9.19   9.37  10.76   14.56   24.25
-    // (round 2: 3 roles 12.3 at 8192 envs - its re-spawn path, the tail every launch waits for, recomputed the next step's
-    //  controller and walked the record -> route table chain: +3.4 us with TDE_F_AUTORESET; now +1).  Three roles up to
-    // 131 072 agent slots, one role above (configs[4]: 8192 x 32).  tde_kernel_override(0, 1 | 3) forces one.
-    const int force = g_force_step;
-    // (slot entries pack route / replay ids into 20 bits and their lengths into 12: tde_abi.h)
-    const int32_t id_max = (1 << TDE_CACHE_ID_BITS) - 1, len_max = 1 << (32 - TDE_CACHE_ID_BITS);
-    const bool packable = world->n_routes < id_max && world->n_replay < id_max && world->RW < len_max && world->RT < len_max;
-    const bool trio_ok = st->slot_cache && st->env_cache && packable && (st->A == 8 || st->A == 16 || st->A == 32);
-    const bool want_trio = force == 3 || (force == 0 && load_slots <= 131072);
-    // (TDE_F_NPC_FIRST_STEP: the controller acts on the first step of an episode too - the one-role kernel, which evaluates it on
-    //  every step; the three-role kernel skips it after a re-spawn)
-    const bool first_step_acts = (cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP);
-    if (trio_ok && want_trio && !first_step_acts) {
-        const unsigned ng = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-        const uint32_t act_hash = act_cfg_hash(*cfg, *world);
-#define TDE_LAUNCH_STEP3(AA, L, O)                                                                                                   \
-    do {                                                                                                                           \
-        if (st->magnitudes) tde::env_step_trio_kernel<AA, L, O, true><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, act_hash); \
-        else tde::env_step_trio_kernel<AA, L, O, false><<<ng, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, act_hash);               \
-    } while (0)
-#define TDE_LAUNCH_STEP3_A(AA)                                                                       \
-    if (st->obs) { if (lights) TDE_LAUNCH_STEP3(AA, true, true); else TDE_LAUNCH_STEP3(AA, false, true); } \
-    else { if (lights) TDE_LAUNCH_STEP3(AA, true, false); else TDE_LAUNCH_STEP3(AA, false, false); }
-        if (st->A == 8) { TDE_LAUNCH_STEP3_A(8) } else if (st->A == 16) { TDE_LAUNCH_STEP3_A(16) } else { TDE_LAUNCH_STEP3_A(32) }
-#undef TDE_LAUNCH_STEP3_A
-#undef TDE_LAUNCH_STEP3
-        hipError_t e3 = hipGetLastError();
-        return e3 == hipSuccess ? 0 : fail("tde_env_step", e3);
-    }
-    const unsigned nb = blocks_for((int64_t)st->B * st->A);
-    if ((world->hints & TDE_WORLD_LARGE_GRID) && (st->A == 32 || st->A == 64)) {      // (up to 16 slots per env the class map is read anyway)
-#define TDE_LAUNCH_STEP_BIG(AA, L, O)                                                                                                                                   \
-    do {                                                                                                                                                              \
-        if (st->magnitudes) tde::env_step_kernel<AA, L, O, true, TDE_WIDE_WAVES, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits); \
-        else tde::env_step_kernel<AA, L, O, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits);            \
-    } while (0)
-#define TDE_LAUNCH_STEP_BIG_A(AA)                                                                              \
-    if (st->obs) { if (lights) TDE_LAUNCH_STEP_BIG(AA, true, true); else TDE_LAUNCH_STEP_BIG(AA, false, true); } \
-    else { if (lights) TDE_LAUNCH_STEP_BIG(AA, true, false); else TDE_LAUNCH_STEP_BIG(AA, false, false); }
-        if (st->A == 32) { TDE_LAUNCH_STEP_BIG_A(32) } else { TDE_LAUNCH_STEP_BIG_A(64) }
-#undef TDE_LAUNCH_STEP_BIG_A
-#undef TDE_LAUNCH_STEP_BIG
-        hipError_t eb = hipGetLastError();
-        return eb == hipSuccess ? 0 : fail("tde_env_step", eb);
-    }
-    if (st->A == 128 && st->B > 6 * cu_count()) {            // (128 slots, more than a residency round of the 3-per-SIMD form: 4 per SIMD)
-#define TDE_LAUNCH_STEP_W4(L, O)                                                                                                                                  \
-    do {                                                                                                                                                          \
-        if (st->magnitudes) tde::env_step_kernel<128, L, O, false, 4, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits); \
-        else tde::env_step_kernel<128, L, O, false, 4><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, st->action, (float *)nullptr, st->done_bits);      \
-    } while (0)
-        if (st->obs) { if (lights) TDE_LAUNCH_STEP_W4(true, true); else TDE_LAUNCH_STEP_W4(false, true); }
-        else { if (lights) TDE_LAUNCH_STEP_W4(true, false); else TDE_LAUNCH_STEP_W4(false, false); }
-#undef TDE_LAUNCH_STEP_W4
-        hipError_t e4 = hipGetLastError();
-        return e4 == hipSuccess ? 0 : fail("tde_env_step", e4);
-    }
-#define TDE_LAUNCH_STEP(L, O)                                                                                                                  \
-    do {                                                                                                                                       \
-        if (st->magnitudes) {                                                                                                                  \
-            TDE_DISPATCH_A128(st->A, tde::env_step_kernel<kA, L, O, false, TDE_WIDE_WAVES, true><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>( \
-                                      *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits));                                        \
-        } else {                                                                                                                               \
-            TDE_DISPATCH_A128(st->A, tde::env_step_kernel<kA, L, O><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(                              \
-                                      *cfg, *world, *st, st->action, (float *)nullptr, st->done_bits));                                        \
-        }                                                                                                                                      \
-    } while (0)
-    if (st->obs) {
-        if (lights) { TDE_LAUNCH_STEP(true, true); } else { TDE_LAUNCH_STEP(false, true); }
-    } else {
-        if (lights) { TDE_LAUNCH_STEP(true, false); } else { TDE_LAUNCH_STEP(false, false); }
-    }
-#undef TDE_LAUNCH_STEP
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_env_step", e);
-}
-
-int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream)
-{
-    return env_step_launch(cfg, world, st, stream, st ? (int64_t)st->B * st->A : 0);
-}
-
-// number of CUs of the current device (cached per device)
-static int cu_count()
-{
-    static thread_local int cached_dev = -1, cached = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (dev != cached_dev) {
-        int n = 0;
-        cached = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-        cached_dev = dev;
-    }
-    return cached;
-}
-
-// env arrays advanced by e0 envs, agent arrays by e0 * A slots: the shard [e0, e0 + n) of a batch as a tde_state of its own
-static tde_state state_slice(const tde_state &s, int64_t e0, int32_t n)
-{
-    tde_state t = s;
-    const int64_t g0 = e0 * s.A;
-#define TDE_ADV(p, k) if (t.p) t.p += (k)
-    TDE_ADV(x, g0); TDE_ADV(y, g0); TDE_ADV(psi, g0); TDE_ADV(v, g0); TDE_ADV(len, g0); TDE_ADV(wid, g0); TDE_ADV(lr, g0);
-    TDE_ADV(vdes, g0); TDE_ADV(route_wp, g0); TDE_ADV(present, g0); TDE_ADV(collided, g0); TDE_ADV(offroad, g0);
-    TDE_ADV(scn, e0); TDE_ADV(steps, e0); TDE_ADV(target_idx, e0); TDE_ADV(reached, e0); TDE_ADV(episode, e0);
-    TDE_ADV(action, 2 * e0); TDE_ADV(reward, e0); TDE_ADV(terminated, e0); TDE_ADV(truncated, e0); TDE_ADV(tl_violation, e0);
-    TDE_ADV(info, 4 * e0); TDE_ADV(info_reached, e0); TDE_ADV(done_bits, e0); TDE_ADV(obs, 8 * e0); TDE_ADV(ep_return, e0);
-    TDE_ADV(ep_final, e0); TDE_ADV(ep_final_len, e0); TDE_ADV(slot_cache, g0); TDE_ADV(env_cache, e0); TDE_ADV(act_cache, g0 + e0); TDE_ADV(magnitudes, 4 * e0);
-#undef TDE_ADV
-    t.B = n;
-    return t;
-}
-
-static int rollout_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, int team,
-                          void *stream)
-{
-    const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
-    const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-    const bool big = (world->hints & TDE_WORLD_LARGE_GRID) != 0;      // corner classes from the 2-bit class map (tde_abi.h)
-    if (team == 3) {
-#if TDE_ROLLOUT_CONST_ARGS
-        {
-            tde::RolloutArgs ra{*cfg, *world, *st, *ro};
-            hipError_t ec = hipMemcpyToSymbolAsync(HIP_SYMBOL(tde::g_rollout_args), &ra, sizeof(ra), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
-            if (ec != hipSuccess) return fail("tde_env_rollout (argument block)", ec);
-        }
-#define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(0)
-#else
-#define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
-#endif
-#define TDE_LAUNCH_TRIO(AA)                                                                          \
-    if (lights) { if (big) TDE_LAUNCH_TRIO2(AA, true, true); else TDE_LAUNCH_TRIO2(AA, true, false); } \
-    else { if (big) TDE_LAUNCH_TRIO2(AA, false, true); else TDE_LAUNCH_TRIO2(AA, false, false); }
-        if (st->A == 8) { TDE_LAUNCH_TRIO(8) } else if (st->A == 16) { TDE_LAUNCH_TRIO(16) } else { TDE_LAUNCH_TRIO(32) }
-#undef TDE_LAUNCH_TRIO
-#undef TDE_LAUNCH_TRIO2
-    } else if (team == 1) {
-        if (lights) {
-            TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, true><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
-        } else {
-            TDE_DISPATCH_A(st->A, tde::env_rollout_kernel<kA, false><<<nb, tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro));
-        }
-    } else {
-#define TDE_LAUNCH_DUO(L, G) TDE_DISPATCH_A(st->A, tde::env_rollout_duo_kernel<kA, L, G><<<nb, 2 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro))
-        if (lights) { if (big) { TDE_LAUNCH_DUO(true, true); } else { TDE_LAUNCH_DUO(true, false); } }
-        else { if (big) { TDE_LAUNCH_DUO(false, true); } else { TDE_LAUNCH_DUO(false, false); } }
-#undef TDE_LAUNCH_DUO
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
-}
-
-int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro,
-                    void *stream)
-{
-    int rc = check_env_args("tde_env_rollout", cfg, world, st);
-    if (rc) return rc;
-    if (!ro) return bad("tde_env_rollout: rollout is NULL");
-    if (st->B <= 0 || ro->K <= 0) return 0;
-    if (!ro->actions) return bad("tde_env_rollout: rollout.actions is NULL");
-    if (ro->ldb != 0 && ro->ldb < st->B) return bad("tde_env_rollout: rollout.ldb must be 0 (= B) or >= B");
-    if (st->A > 64) {
-        // 128 slots per env: the one-role persistent kernel with the env's two wavefronts as its workgroup (the role-split kernels
-        // keep an env inside one wavefront)
-        tde_rollout r128 = *ro;
-        if (r128.ldb == 0) r128.ldb = st->B;
-        const bool l128 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-        // Two roles (four wavefronts per env) at every batch size - us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs:
-        // two roles 6.2 / 8.9 / 18.0 / 34.7, one role 10.6 / 11.4 / 23.3 / 38.9 (profiles/r04_z_wide2_waves.txt).
-        // tde_kernel_override(1, 0) forces the one-role kernel.
-        const bool one_role = g_force_rollout == 1 || ((cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP));
-        if (one_role) {
-            if (l128) tde::env_rollout_kernel<128, true><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
-            else tde::env_rollout_kernel<128, false><<<(unsigned)st->B, 128, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
-        } else {                                              // two roles, four wavefronts per env
-            if (l128) tde::env_rollout_wide_kernel<true><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
-            else tde::env_rollout_wide_kernel<false><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, r128);
-        }
-        hipError_t e = hipGetLastError();
-        return e == hipSuccess ? 0 : fail("tde_env_rollout", e);
-    }
-    // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
-    // forces one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median
-    // us per step (scripts/ab_rollout.py duo:... trio:..., profiles/r02_e_rollout_matrix.txt): three roles win at 8 and 16
-    // agents per env, without traffic lights (3.17 vs 3.50, 3.06 vs 3.54) and with them (5.32 vs 5.55, 4.55 vs 5.01), and
-    // at 32 without lights (3.70 vs 4.11); at 32 WITH lights the 32-row sweeps plus the stop-line loops spill under the
-    // 80-VGPR cap and the two-role kernel (128 VGPRs, four wavefronts per SIMD) is faster (5.18 vs 7.66); at 64 the two
-    // are equal (5.03) and two roles run.
-    const int forced = g_force_rollout;
-    const bool lights0 = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
-    const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
-    int team = forced ? forced : (st->A == 8 || st->A == 16 || (st->A == 32 && !lights0)) ? 3 : 2;
-    if (team == 3 && !trio_shape) team = 2;
-    if ((cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP)) team = 1;   // (the role-split kernels skip the controller after a re-spawn)
-    tde_rollout r = *ro;
-    if (r.ldb == 0) r.ldb = st->B;
-    // The two- and three-role kernels are tuned for ONE residency round of the chip: 8 workgroups (groups of 64 agent slots)
-    // per CU - 8192 envs x 16 agents on 256 CUs.  A larger batch as one grid runs its later rounds badly (16 384 envs:
-    // 1784 us per 250-step launch against 2 x 737; profiles/r03_c_scale_envs.txt), so it is cut into consecutive launches
-    // of one round each on the same stream: envs are independent, every launch runs at the tuned shape, and the last,
-    // partial one is simply a smaller batch.  (A batch of less than 1.5 rounds stays one launch: its few extra workgroups
-    // slip in as the first ones finish.)
-    const int64_t groups = ((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave;
-    const int64_t round = 8 * (int64_t)cu_count();
-    if (team == 1 || 2 * groups < 3 * round) return rollout_launch(cfg, world, st, &r, team, stream);
-    const int64_t envs_per_round = round * (tde::kWave / st->A);
-    for (int64_t e0 = 0; e0 < st->B; e0 += envs_per_round) {
-        const int32_t n = (int32_t)((st->B - e0 < envs_per_round) ? st->B - e0 : envs_per_round);
-        tde_config c = *cfg;
-        c.env_base = cfg->env_base + (uint32_t)e0;                           // the reset RNG is keyed by the global env index
-        const tde_state s = state_slice(*st, e0, n);
-        tde_rollout rr = r;
-        rr.actions = r.actions + 2 * e0;
-        if (rr.reward) rr.reward += e0;
-        if (rr.done) rr.done += e0;
-        rc = rollout_launch(&c, world, &s, &rr, team, stream);
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-// the argument checks of a render request, without launching anything (tde_render_ego; tde_env_step_render runs them before
-// its first launch, so that a bad request leaves the state of every sub-batch untouched)
-static int check_render_args(const char *who, const tde_world *world, const tde_render *rd)
-{
-    char msg[200];
-    auto say = [&](const char *what) { snprintf(msg, sizeof(msg), "%s: %s", who, what); return bad(msg); };
-    if (!rd || !rd->out) return say("render/out is NULL");
-    // (the layer plane in LDS holds the image rounded up to multiples of 8 in both directions)
-    if (rd->H <= 0 || rd->W <= 0 || (rd->W % 4) != 0 || (rd->H % 4) != 0 || (rd->H * rd->W) % 16 != 0 ||
-        ((rd->H + 7) & ~7) * ((rd->W + 7) & ~7) > tde::kRasterMaxPix || rd->H > 256 || rd->W > 256)
-        return say("H and W must be positive multiples of 4 (at most 256) whose product, each rounded up to a multiple of 8, is <= 4096");
-    if (rd->phase < 0) return say("phase must be >= 0 (keep it reduced modulo n_stack)");
-    if (!(rd->fov > 0.0f)) return say("fov must be positive");
-    if (!world->cell_cls2 || !world->cell_sub || !world->cell_word || !world->cell_tri || !world->cell_coarse) return say("the world has no grid index tables");
-    return 0;
-}
-
-int tde_render_ego(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_render *rd,
-                   void *stream)
-{
-    int rc = check_env_args("tde_render_ego", cfg, world, st);
-    if (rc) return rc;
-    rc = check_render_args("tde_render_ego", world, rd);
-    if (rc) return rc;
-    if (st->B <= 0) return 0;
-    if (rd->n_stack > 1 && !rd->layers && !rd->only)       // (a masked call re-renders the newest frame in place)
-        tde::frame_shift_kernel<<<st->B, tde::kBlock, 0, (hipStream_t)stream>>>(rd->out, rd->H * rd->W, rd->n_stack);
-    tde::RenderArgs ra;
-    ra.maps = world->maps; ra.cell_word = world->cell_word; ra.cell_tri = world->cell_tri; ra.scn_tab = world->scn;
-    ra.wp_xy = world->wp_xy; ra.stoplines = world->stoplines; ra.phases = world->phases;
-    ra.x = st->x; ra.y = st->y; ra.psi = st->psi; ra.len = st->len; ra.wid = st->wid; ra.present = st->present;
-    ra.scn = st->scn; ra.steps = st->steps; ra.target_idx = st->target_idx;
-    ra.rd = *rd;
-    ra.thr2 = cfg->offroad_threshold_squared ? cfg->offroad_threshold : cfg->offroad_threshold * cfg->offroad_threshold;
-    ra.flags = cfg->flags; ra.NW = world->NW; ra.A = st->A;
-    const float res = rd->fov / (float)rd->W;
-    ra.K8 = tde::raster_block_clearance(8, res); ra.K4 = tde::raster_block_clearance(4, res);
-    ra.cell_cls2 = world->cell_cls2; ra.cell_sub = world->cell_sub; ra.cell_coarse = world->cell_coarse;
-    const int vpg = tde::kViewsPerGroup * TDE_RENDER_VPWAVE;
-    const unsigned ng = (unsigned)((st->B + vpg - 1) / vpg);
-    if (rd->H == 64 && rd->W == 64) tde::render_views_kernel<64><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
-    else tde::render_views_kernel<0><<<ng, tde::kWave * tde::kViewsPerGroup, 0, (hipStream_t)stream>>>(ra, st->B);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_render_ego", e);
-}
-
-int tde_env_reset_render(const tde_config *cfg, const tde_world *world, const tde_state *st, const uint8_t *mask,
-                         const tde_render *rd, void *stream)
-{
-    int rc = check_env_args("tde_env_reset_render", cfg, world, st);
-    if (rc) return rc;
-    if (!mask) return bad("tde_env_reset_render: mask is NULL (a full reset renders with tde_render_ego)");
-    rc = check_render_args("tde_env_reset_render", world, rd);   // (before the reset: a bad request re-spawns nothing)
-    if (rc) return rc;
-    rc = tde_env_reset(cfg, world, st, mask, stream);
-    if (rc) return rc;
-    tde_render r = *rd;
-    r.fresh = mask;                                              // the re-spawned views' older frames restart blank,
-    r.only = mask;                                               // only their newest frame is rendered again, in place
-    return tde_render_ego(cfg, world, st, &r, stream);
-}
-
-int tde_env_step_render(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_render *rd,
-                        void *const *streams, int32_t n_streams)
-{
-    int rc = check_env_args("tde_env_step_render", cfg, world, st);
-    if (rc) return rc;
-    if (!streams || n_streams < 1 || n_streams > 16) return bad("tde_env_step_render: streams is NULL or n_streams not in [1, 16]");
-    if (rd) {                                              // before the first launch: a failing call advances no sub-batch
-        rc = check_render_args("tde_env_step_render", world, rd);
-        if (rc) return rc;
-    }
-    if (st->B <= 0) return 0;
-    // equal shares rounded up to whole groups of 64 envs (any A: slices start on wavefront and workgroup boundaries)
-    const int64_t share = ((((int64_t)st->B + n_streams - 1) / n_streams) + 63) & ~(int64_t)63;
-    int i = 0;
-    for (int64_t e0 = 0; e0 < st->B; e0 += share, ++i) {
-        const int32_t n = (int32_t)((st->B - e0 < share) ? st->B - e0 : share);
-        tde_config c = *cfg;
-        c.env_base = cfg->env_base + (uint32_t)e0;                           // the reset RNG is keyed by the global env index
-        const tde_state s = state_slice(*st, e0, n);
-        // (the sub-batches run side by side: configs[4] in two halves, us per timestep: one-role steps 46.0, three-role 49.1,
-        //  profiles/r03_f_config5_streams_matrix.txt - the kernel form follows the whole batch's load)
-        rc = env_step_launch(&c, world, &s, streams[i], (int64_t)st->B * st->A);
-        if (rc) return rc;
-        if (rd) {
-            tde_render r = *rd;
-            const int64_t ns = rd->n_stack > 1 ? rd->n_stack : 1, plane = (int64_t)rd->H * rd->W;
-            if (r.out) r.out += e0 * 3 * ns * plane;
-            if (r.layers) r.layers += e0 * ns * plane;
-            if (r.fresh) r.fresh += e0;
-            if (r.only) r.only += e0;
-            rc = tde_render_ego(&c, world, &s, &r, streams[i]);
-            if (rc) return rc;
-        }
-    }
-    return 0;
-}
-
-int tde_ego_infractions(const tde_config *cfg, const tde_world *world, const tde_state *st, float *out, void *stream)
-{
-    int rc = check_env_args("tde_ego_infractions", cfg, world, st);
-    if (rc) return rc;
-    if (!out) return bad("tde_ego_infractions: out is NULL");
-    if (st->B <= 0) return 0;
-    const unsigned nb = (unsigned)((st->B + (tde::kBlock / tde::kWave) - 1) / (tde::kBlock / tde::kWave));
-    tde::ego_infractions_kernel<<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, out);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_ego_infractions", e);
-}
-
-int tde_env_post_step(const tde_config *cfg, const tde_world *world, const tde_state *st, float *magnitudes, void *stream)
-{
-    int rc = check_env_args("tde_env_post_step", cfg, world, st);
-    if (rc) return rc;
-    if (st->B <= 0) return 0;
-    if (!st->terminated || !st->truncated || !st->collided || !st->offroad) return bad("tde_env_post_step: the state lacks the step's flag arrays");
-    const unsigned nb = (unsigned)((st->B + (tde::kBlock / tde::kWave) - 1) / (tde::kBlock / tde::kWave));
-    TDE_DISPATCH_A128(st->A, tde::env_post_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, magnitudes));
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_env_post_step", e);
-}
-
-int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void *stream)
-{
-    if (!world || !st || !out) return bad("tde_state_obs: world/state/out is NULL");
-    if (st->B <= 0) return 0;
-    if (!st->x || !st->y || !st->psi || !st->v || !st->scn || !st->target_idx || !st->steps || !world->scn || !world->wp_xy)
-        return bad("tde_state_obs: a required state / world pointer is NULL");
-    tde::state_obs_kernel<<<blocks_for(st->B), tde::kBlock, 0, (hipStream_t)stream>>>(*world, *st, out);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("tde_state_obs", e);
-}
-
-}  // extern "C"
-
-// host-side table build (no kernels): tde_grid_build / tde_grid_free
-#include "tde_gridbuild.h"
-#endif  // TDE_KERNEL_PROBE

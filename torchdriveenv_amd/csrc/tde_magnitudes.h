@@ -74,8 +74,7 @@ TDE_DEV float box_iou_wave(float x0, float y0, float c0, float s0, float hl0, fl
         const bool keep = act && sp >= 0.0f;
         const bool cross = act && ((sp > 0.0f && sq < 0.0f) || (sp < 0.0f && sq > 0.0f));
         const unsigned long long km = __ballot(keep), cm = __ballot(cross);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int pos = (int)__popcll(km & below) + (int)__popcll(cm & below);
+        const int pos = lane_prefix(km) + lane_prefix(cm);       // (survivors / crossings on the lanes below this one: v_mbcnt)
         if (keep && pos < 8) { nxt[pos] = axi; nxt[8 + pos] = ayi; }
         const int pos2 = pos + (keep ? 1 : 0);
         if (cross && pos2 < 8) {

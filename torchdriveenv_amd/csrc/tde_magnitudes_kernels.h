@@ -31,6 +31,7 @@ struct StateRows {
 
 // out[e] = (offroad magnitude, collision magnitude = sum of IoUs, number of overlapping agents, 0) of env e's ego on the CURRENT
 // state, whatever its flags say; one wavefront per env (every env has work: the operator form, tde_ego_infractions)
+#ifdef TDE_TU_API      // (a non-template kernel: compiled by the one unit that launches it)
 __global__ __launch_bounds__(kBlock) void ego_infractions_kernel(tde_config cfg, tde_world w, tde_state st, float *__restrict__ out)
 {
     __shared__ float poly[kBlock / kWave][32];                     // per wavefront: box_iou_wave's vertex lists
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(kBlock) void ego_infractions_kernel(tde_config cfg,
     }
     if (lane == 0) reinterpret_cast<float4 *>(out)[e] = make_float4(omag, cm.x, cm.y, 0.0f);
 }
+#endif
 
 // tde_env_post_step: what follows a step that was launched WITHOUT TDE_F_AUTORESET, in one launch -
 // (a) out[e] = the magnitudes of the ego's infractions on the state that step left, GATED by the flags it stored: a magnitude is

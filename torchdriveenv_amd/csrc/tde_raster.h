@@ -106,10 +106,7 @@ inline int raster_block_clearance(int n, float res, float unit = TDE_RASTER_COAR
 // plane is written as bytes, 16-, 32- and 64-bit words and read back as 16-byte vectors).
 TDE_DEV void wave_phase() { asm volatile("" ::: "memory"); }
 
-TDE_DEV int lane_prefix(unsigned long long m)
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
+// (lane_prefix: tde_device.h)
 
 // per-view pixel maps
 struct RasterView {
