@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TDE_ABI_VERSION 10
+#define TDE_ABI_VERSION 11
 #define TDE_MAX_AGENTS 128
 
 /* feature bits of tde_config.flags */
@@ -43,13 +43,15 @@ extern "C" {
 #define TDE_F_AUTORESET  (1u << 4)  /* envs that finished this step are re-spawned in place (VecEnv semantics) */
 #define TDE_F_EGO_ONLY_ATTRS (1u << 5) /* cfg.ego_only: random ego attrs at reset (gym_env.py:192-198) */
 #define TDE_F_TRAFFIC_LIGHTS (1u << 6) /* red-light stop-line violation, third term of is_terminated (gym_env.py:415) */
-#define TDE_F_NPC_FIRST_STEP (1u << 7) /* the NPC controller also acts on the FIRST step of an episode, as the reference's NPCs do
-                                          (gym_env.py:285-294: IAIWrapper predicts from step one).  Default (bit clear): the NPCs coast
-                                          through step one with the zero action - the controller reads the scene of the previous
-                                          step, which a fresh episode does not have - and the role-split kernels rely on that to
-                                          skip the controller after a re-spawn; with the bit set tde_env_step / tde_env_rollout run
-                                          their one-role kernels, which evaluate the controller on every step */
-#define TDE_F_ALL (TDE_F_NPC | TDE_F_REPLAY | TDE_F_OFFROAD | TDE_F_REWARD | TDE_F_AUTORESET)
+#define TDE_F_NPC_FIRST_STEP (1u << 7) /* the NPC controller acts from the FIRST step of an episode, as the reference's NPCs do
+                                          (gym_env.py:285-294: IAIWrapper predicts from step one) - part of TDE_F_ALL and what the
+                                          host mirror sets by default (SimulatorConfig.npc_first_step).  Every kernel form honours
+                                          it: the role-split rollout kernels run the controller a second time on the spawn rows of
+                                          an env they re-spawned, the three-role step kernel computes a re-spawned env's first
+                                          actions in the next launch's prologue.  Bit clear = the round-4 / 5 rule, kept as the
+                                          opt-out: the NPCs coast through step one with the zero action (nothing to compute after
+                                          a re-spawn: ~0.1 us per rollout step, ~0.5 us per closed-loop launch cheaper) */
+#define TDE_F_ALL (TDE_F_NPC | TDE_F_REPLAY | TDE_F_OFFROAD | TDE_F_REWARD | TDE_F_AUTORESET | TDE_F_NPC_FIRST_STEP)
 
 /* cell classes of the offroad grid index (HIP side only; the oracle is brute force over triangles) */
 #define TDE_CELL_MAX_TRIS 255u
@@ -157,9 +159,22 @@ typedef struct tde_spawn {
 typedef struct tde_scenario {
     int32_t map;                /* map id */
     int32_t wp_n;               /* number of ego waypoints */
-    float start_heading;        /* stand-in for find_lanelet_directions at the start point (gym_env.py:359) */
+    float start_heading;        /* the start heading when the world carries no heading table (tde_world.NH == 0): the direction of
+                                   the first waypoint segment, a stand-in for find_lanelet_directions (gym_env.py:359) */
     int32_t _pad0;
 } tde_scenario;
+
+/* (ABI 11) One entry of the first-step gap cache, tde_world.first_gap: what the NPC controller of slot a finds on the FIRST step of
+ * an episode of scenario s apart from the ego - min(leader gap over the scenario's other NPCs, gap to a red stop line) at the spawn
+ * state, which depends on the scenario's tables and the controller's constants only, not on the episode.  `key` = the launch's
+ * controller hash | 1 (what tde_act_cache's key carries: config.flags & (NPC | REPLAY | TRAFFIC_LIGHTS), the npc_* constants, the
+ * identity of the world's tables); an entry with another key (zero-initialised memory) is recomputed and rewritten by the lane
+ * that meets it, as ONE 8-byte store.  With a valid entry the first step of a re-spawned env costs the role-split kernels one
+ * exact test against the ego's row instead of the controller's sweep over the env's slots; same minimum, same bits. */
+typedef struct tde_first_gap {
+    float gap;
+    uint32_t key;
+} tde_first_gap;
 
 /* Static world tables, replicated per GPU.  All pointers live in the address space of the
  * library they are handed to (device for libtde_hip, host for libtde_oracle). */
@@ -208,10 +223,18 @@ typedef struct tde_world {
     const float *replay_states; /* [P][RT][4] */
     const tde_stopline *stoplines;   /* [n_stop_total] */
     const tde_light_phase *phases;   /* [n_phase_total] */
+    const float *start_psi;     /* (ABI 11) [S][NH] the ego's start heading along the first waypoint segment of every scenario: entry j
+                                   = the lane direction at the point p0 + (j + 0.5) / NH * (p1 - p0), what the reference takes from
+                                   find_lanelet_directions(lanelet_map, x, y) at the sampled start point (gym_env.py:359-361); an
+                                   episode that starts at fraction f of the segment reads entry floor(f * NH).  Unused (may be a
+                                   one-element dummy) when NH == 0: tde_scenario.start_heading then */
+    tde_first_gap *first_gap;   /* (ABI 11) [S][A] the first-step gap cache (see tde_first_gap): the ONE table of the world the
+                                   kernels WRITE - scratch that belongs to the world's device copy, zero-initialised by its owner;
+                                   NULL: no cache (every first step runs the controller's sweep).  The CPU checker ignores it */
     int32_t n_maps, n_scn, NW, A;
     int32_t n_routes, RW, n_replay, RT;
     int32_t hints;              /* (ABI 9) TDE_WORLD_*: properties of the tables that select a kernel form (never results) */
-    int32_t _pad0;
+    int32_t NH;                 /* (ABI 11) entries per scenario of start_psi; 0: none */
 } tde_world;
 /* tde_world.hints: some map's grid is large (more than 2^21 cells, ~360 m x 360 m at 0.25 m cells): the persistent rollout kernels
  * and the 32- / 64-slot one-step kernel then take the corner classes from the 2-bit class map (cell_cls2, 1/16 of cell_word's

@@ -153,6 +153,17 @@ TDE_API int tde_ego_infractions(const tde_config *cfg, const tde_world *world, c
  * reset() a VecEnv issues for finished envs (gym_env.py:319-349; examples/rl_training.py:159-160). */
 TDE_API int tde_env_post_step(const tde_config *config, const tde_world *world, const tde_state *state, float *magnitudes, void *stream);
 
+/* (ABI 11) Fills the world's first-step gap cache (tde_world.first_gap, see tde_first_gap in tde_abi.h) for `config`: per (scenario, NPC
+ * slot) what the NPC controller finds on the FIRST step of an episode apart from the ego - min(leader gap over the scenario's other
+ * NPCs at their spawn poses, gap to a stop line that is red at step one) - keyed by the controller hash of (config, world).  With it
+ * the role-split kernels give a re-spawned env its first NPC actions (TDE_F_NPC_FIRST_STEP; the reference's NPCs are driven from the
+ * first simulator.step: IAIWrapper, gym_env.py:285-294) from one exact test against the ego's row instead of the controller's sweep;
+ * without it (or with entries of another configuration) they run the whole controller: same results either way.
+ * tde_env_step / tde_env_rollout call this themselves, on their stream, the first time they meet a (world, configuration) pair (a
+ * small per-process memo of the pairs already served): a caller only needs it to choose WHEN the launch happens (e.g. outside a
+ * stream capture).  One launch of n_scn * A lanes; up to 64 agent slots per env (the 128-slot kernels do not use the cache: no-op). */
+TDE_API int tde_first_gaps(const tde_config *config, const tde_world *world, void *stream);
+
 /* ---- host side: static tables ------------------------------------------------------------------------------------ */
 
 /* Offroad grid index of ONE drivable mesh - what the simulator prepares once per map from the road mesh it is constructed

@@ -383,7 +383,12 @@ static void tde_reset_env(const tde_config *cfg, const tde_world *w, tde_state *
     double speed = tde_u01(r0[2]) * 10.0;
     /* start_orientation = lanelet direction + normal(0, 0.1)  :359-361 (round 3: a true Gaussian, Box-Muller on the shared
      * fp32 log / sincos specifications; rounds 1-2 used Irwin-Hall(12) - 6, whose tails end at +-0.6 rad) */
-    double psi0 = (double)w->scn[scn].start_heading + (double)tde_normal(r1[2], r1[3]) * 0.1;
+    /* the lane direction at the start point: find_lanelet_directions(lanelet_map, x, y)[0] (:359) = the world's heading table along
+     * the first waypoint segment read at the drawn fraction (tde_world.start_psi, NH entries per scenario), or - without one - the
+     * scenario's start_heading (the direction of that segment) */
+    float lane_psi = w->scn[scn].start_heading;
+    if (w->NH > 0) lane_psi = w->start_psi[(int64_t)scn * w->NH + (int32_t)(f * (double)w->NH)];
+    double psi0 = (double)lane_psi + (double)tde_normal(r1[2], r1[3]) * 0.1;
 
     st->scn[e] = scn;
     st->steps[e] = 0;          /* :339 */

@@ -33,6 +33,7 @@ ap.add_argument("--town", action="store_true", help="the 1 km x 1 km town map (s
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawns")
 ap.add_argument("--truncate-only", type=int, default=0, metavar="N",
                 help="no termination at infractions, truncation after N steps: every env re-spawns every N steps")
+ap.add_argument("--coast", action="store_true", help="clear TDE_F_NPC_FIRST_STEP: the NPCs coast through an episode's first step (the rule of rounds 4 / 5)")
 args = ap.parse_args()
 
 B, A, K = args.envs, args.agents, args.steps
@@ -49,7 +50,7 @@ actions = torch.stack([torch.rand(K, B, generator=g) * 2 - 1, torch.rand(K, B, g
 actions = actions.float().contiguous().to(dev)
 reward = torch.empty((K, B), device=dev)
 done = torch.empty((K, B), dtype=torch.uint8, device=dev)
-flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0)
+flags = (_abi.F_ALL & ~(_abi.F_NPC_FIRST_STEP if args.coast else 0)) | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0)
 cfg = _abi.default_config(seed=1, distance_cutoff=0.25, flags=flags)
 if args.endless:
     cfg.terminated_at_infraction = 0

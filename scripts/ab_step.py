@@ -30,12 +30,13 @@ ap.add_argument("--lights", action="store_true", help="with TDE_F_TRAFFIC_LIGHTS
 ap.add_argument("--kernel", default=None, choices=["solo", "trio"])
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawn tail")
 ap.add_argument("--outputs", action="store_true", help="with info / done bits / episode statistics / compact observation")
+ap.add_argument("--coast", action="store_true", help="clear TDE_F_NPC_FIRST_STEP: the NPCs coast through an episode's first step (the rule of rounds 4 / 5)")
 args = ap.parse_args()
 B, A, K = args.envs, args.agents, args.steps
 dev = torch.device("cuda:0")
 world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell, n_signals=args.signals, signal_reach=args.signal_reach) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell)
 dw = world.to_device(dev)
-cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=_abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0))
+cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=(_abi.F_ALL & ~(_abi.F_NPC_FIRST_STEP if args.coast else 0)) | (_abi.F_TRAFFIC_LIGHTS if args.lights else 0))
 if args.endless:
     cfg.terminated_at_infraction = 0
     cfg.max_steps = 1 << 30

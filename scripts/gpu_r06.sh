@@ -13,6 +13,16 @@ for what in "$@"; do
       python scripts/ab_rollout.py --lights $LIBS > $O/ab_rollout_lights.txt 2>&1; grep -v amdgpu.ids $O/ab_rollout_lights.txt | tail -4
       python scripts/ab_step.py $LIBS > $O/ab_step.txt 2>&1; grep -v amdgpu.ids $O/ab_step.txt | tail -4
       python scripts/ab_step.py --lights --outputs $LIBS > $O/ab_step_lights.txt 2>&1; grep -v amdgpu.ids $O/ab_step_lights.txt | tail -4;;
+    abcoast:*) LIBS=$(echo "${what#abcoast:}" | tr ':' ' ')
+      for opt in "" "--coast" "--lights" "--lights --coast"; do
+        echo "== rollout $opt" >> $O/ab_first_step.txt; python scripts/ab_rollout.py $opt $LIBS 2>&1 | grep -v amdgpu.ids | tail -3 >> $O/ab_first_step.txt
+        echo "== step $opt" >> $O/ab_first_step.txt; python scripts/ab_step.py $opt $LIBS 2>&1 | grep -v amdgpu.ids | tail -3 >> $O/ab_first_step.txt
+      done; cat $O/ab_first_step.txt;;
+    t:*) ( time timeout 1200 python -m pytest tests -m gpu -q -x -k "${what#t:}" ) > $O/pytest_k.txt 2>&1; tail -15 $O/pytest_k.txt;;
+    abstep:*) LIBS=$(echo "${what#abstep:}" | tr ':' ' ')
+      for opt in "--coast" ""; do
+        echo "== step $opt" >> $O/ab_step_bisect.txt; python scripts/ab_step.py $opt $LIBS 2>&1 | grep -v amdgpu.ids | tail -5 >> $O/ab_step_bisect.txt
+      done; cat $O/ab_step_bisect.txt;;
     bench) python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json;;
     *) echo "unknown phase $what";;
   esac

@@ -98,8 +98,8 @@ def patch_trio(s):
     # npc_action gets an optional stamp cursor
     s = sub(s, "float g_far, float red_gap, float &acc,\n                        float &beta)\n{\n    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far);\n",
             "float g_far, float red_gap, float &acc,\n                        float &beta, unsigned long long *stl = nullptr)\n{\n    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far, stl);\n    tde_mark(stl, 2);\n")
-    s = sub(s, "                      float cp, float sp, bool has_target, float g_far)\n{\n    using mask_t = typename MaskOf<A>::type;",
-            "                      float cp, float sp, bool has_target, float g_far, unsigned long long *stl = nullptr)\n{\n    using mask_t = typename MaskOf<A>::type;")
+    s = sub(s, "                      float cp, float sp, bool has_target, float g_far)\n{\n    using mask_t = typename MaskOf<A>::type;\n    constexpr int C = A < kSweepBlock ? A : kSweepBlock;\n    mask_t cand = 0;\n    const float hl_i = 0.5f * ag.len;\n    if (has_target) {",
+            "                      float cp, float sp, bool has_target, float g_far, unsigned long long *stl = nullptr)\n{\n    using mask_t = typename MaskOf<A>::type;\n    constexpr int C = A < kSweepBlock ? A : kSweepBlock;\n    mask_t cand = 0;\n    const float hl_i = 0.5f * ag.len;\n    if (has_target) {")
     s = sub(s, "        cand &= ~own_bit;\n    }\n    float gap = 1e30f;\n",
             "        cand &= ~own_bit;\n    }\n    tde_mark(stl, 1);\n    float gap = 1e30f;\n")
     a, b = kernel_span(s, "env_rollout_trio_kernel")
@@ -109,10 +109,11 @@ def patch_trio(s):
     # ---- driver
     k = sub(k, "        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];",
             "        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];")
-    k = sub(k, "                if (F & TDE_F_NPC) {\n                    // The controller runs in the first pass only.",
-            "                tde_mark(&stl, 0);\n                if (F & TDE_F_NPC) {\n                    // The controller runs in the first pass only.")
-    k = sub(k, "                                      cx.g_far, red_gap, na, nb);\n                    }\n                    if (npc && k > 1) { acc = na; beta = nb; }\n                }\n                nx = ag.x;",
-            "                                      cx.g_far, red_gap, na, nb, &stl);\n                    }\n                    if (npc && k > 1) { acc = na; beta = nb; }\n                }\n                tde_mark(&stl, 3);\n                nx = ag.x;")
+    k = sub(k, "                if (F & TDE_F_NPC) {\n                    // A second pass means that an env of this wavefront finished and its lanes were re-spawned: they are at the",
+            "                tde_mark(&stl, 0);\n                if (F & TDE_F_NPC) {\n                    // A second pass means that an env of this wavefront finished and its lanes were re-spawned: they are at the")
+    k = sub(k, "                                      cx.g_far, red_gap, na, nb);\n                    }\n                    if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }",
+            "                                      cx.g_far, red_gap, na, nb, &stl);\n                    }\n                    if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }")
+    k = sub(k, "                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;\n", "                tde_mark(&stl, 3);\n                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;\n")
     k = sub(k, "                switched = false;\n                nwp = ag.route_wp;", "                tde_mark(&stl, 4);\n                switched = false;\n                nwp = ag.route_wp;")
     k = sub(k, "                sincos_f32(npsi, ns, nc);\n                TDE_PROBE(TDE_DUMMY_D, nx);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n",
             "                sincos_f32(npsi, ns, nc);\n                tde_mark(&stl, 5);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n                tde_mark(&stl, 6);\n")

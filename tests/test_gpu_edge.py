@@ -386,40 +386,114 @@ def test_configs3_partitioning_at_full_size_on_one_gpu():
     assert (fd & 1).sum() > 0 and fep.max() >= 2
 
 
-@pytest.mark.parametrize("A,world_kw", [(16, dict(n_scn=8, A=16, seed=0, n_maps=2)), (8, dict(n_scn=8, A=8, seed=1, n_maps=2))])
-def test_npc_first_step_flag_step_and_rollout_match_the_oracle(A, world_kw):
-    """TDE_F_NPC_FIRST_STEP (the NPC controller acts on the first step of an episode too, as the reference's NPCs do,
-    gym_env.py:285-294): tde_env_step and tde_env_rollout route to their one-role kernels, which evaluate the controller on
-    every step - bit for bit the oracle under the same flag through re-spawns, and NOT the default rule's trajectories"""
+@pytest.mark.parametrize("A,lights", [(16, True), (8, False), (32, True)])
+def test_first_step_gap_cache_filled_and_missing_give_the_oracles_results(A, lights):
+    """tde_world.first_gap (ABI 11): with the cache filled (tde_first_gaps; tde_env_step / tde_env_rollout fill it on first use) a
+    re-spawned env's first NPC actions come from min(cached gap, exact test against the ego) - with its entries missing (zeroed behind
+    the library's back, or never filled: another configuration's keys) from the whole controller.  Both equal the oracle bit for bit,
+    in the three-role step kernel and the two- / three-role rollout kernels; the table itself: a keyed entry per NPC slot, 1e30 for a
+    slot without a route."""
+    from tests.test_gpu_parity import assert_state_equal, dev
+
+    world = synthetic_world(n_scn=8, A=A, seed=5, n_maps=2)
+    dw = world.to_device(DEV)
+    B, K = 128, 70
+    cfg = _abi.default_config(seed=21, flags=_abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0), max_steps=25, distance_cutoff=0.25)
+    rng = np.random.default_rng(2)
+    acts = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+    hs = EnvState(B, A)
+    oracle.env_reset(cfg, world, hs)
+    for t in range(K):
+        hs["action"][...] = acts[t]
+        oracle.env_step(cfg, world, hs)
+    hr = EnvState(B, A)
+    oracle.env_reset(cfg, world, hr)
+    rew_o, done_o = oracle.env_rollout(cfg, world, hr, acts)
+    assert int(hs["episode"].max()) > 2
+    fg = dw.tensors["first_gap"]
+    assert int(fg.to(torch.int64).sum()) == 0                              # uploaded empty
+    ops.first_gaps(cfg, dw)
+    tab = fg.cpu().numpy().reshape(world.n_scn, A, 2)
+    assert (tab[:, 1:, 1] == tab[0, 1, 1]).all() and tab[0, 1, 1] & 1 and (tab[:, 0] == 0).all()      # one key, odd; the ego's slot unused
+    gaps = tab[..., 0].copy().view(np.float32)
+    routed = (world.arrays["spawn"].reshape(world.n_scn, A)["route"] >= 0) & (world.arrays["spawn"].reshape(world.n_scn, A)["present"] != 0)
+    assert (gaps[:, 1:][~routed[:, 1:]] == np.float32(1e30)).all() and (gaps[:, 1:][routed[:, 1:]] < np.float32(1e30)).any()
+    filled = fg.clone()
+    try:
+        for what in ("filled", "missing", "foreign keys"):
+            if what == "missing":
+                fg.zero_()                                       # (the library's memo says "filled": it does not fill again)
+            elif what == "foreign keys":
+                fg.copy_(filled.view(torch.int32).bitwise_xor(torch.tensor([0, 0x10], dtype=torch.int32, device=DEV)).view(torch.uint32))   # entries of "another configuration"
+            _lib.kernel_override()
+            ds = EnvState(B, A, device=DEV)
+            ops.env_reset(cfg, dw, ds)
+            for t in range(K):
+                ops.env_step(cfg, dw, ds, action=dev(acts[t]))
+            assert_state_equal(hs.host(), ds.host(), f"closed loop, first-step gap cache {what}")
+            for form in ("duo", "trio"):
+                _lib.kernel_override(rollout=form)
+                dr = EnvState(B, A, device=DEV)
+                ops.env_reset(cfg, dw, dr)
+                rew_d, done_d = ops.env_rollout(cfg, dw, dr, dev(acts))
+                assert np.array_equal(rew_d.cpu().numpy().view(np.uint32), rew_o.view(np.uint32)) and np.array_equal(done_d.cpu().numpy(), done_o), (what, form)
+                assert_state_equal(hr.host(), dr.host(), f"rollout {form}, first-step gap cache {what}")
+            if what != "filled":
+                assert not torch.equal(fg, filled)               # nothing re-filled it behind the test's back
+    finally:
+        _lib.kernel_override()
+
+
+@pytest.mark.parametrize("rule", ["acts", "coasts"])
+@pytest.mark.parametrize("A,world_kw,lights", [(16, dict(n_scn=8, A=16, seed=0, n_maps=2), False), (8, dict(n_scn=8, A=8, seed=1, n_maps=2), True),
+                                               (32, dict(n_scn=6, A=32, seed=2, n_maps=2), False), (4, dict(n_scn=6, A=4, seed=3, n_maps=2), False)])
+def test_npc_first_step_flag_step_and_rollout_match_the_oracle(A, world_kw, lights, rule):
+    """TDE_F_NPC_FIRST_STEP - the default since round 6: the NPC controller acts from the first step of an episode, as the reference's
+    NPCs do (gym_env.py:285-294) - and its opt-out (the NPCs coast through step one), in EVERY kernel form: the three-role step kernel
+    (a re-spawned env's first actions computed in the next launch's prologue) and the one-role one, the one- / two- / three-role
+    rollout kernels (the role-split drivers run the controller again on the spawn rows of an env they re-spawned).  Bit for bit the
+    oracle under the same flag through many re-spawns; and the two rules give different trajectories (the flag is not a no-op)."""
     from tests.test_gpu_parity import assert_state_equal, dev
 
     world = synthetic_world(**world_kw)
     dw = world.to_device(DEV)
     B, K = 192, 90
-    flags = _abi.F_ALL | _abi.F_NPC_FIRST_STEP
+    base = (_abi.F_ALL & ~_abi.F_NPC_FIRST_STEP) | (_abi.F_TRAFFIC_LIGHTS if lights else 0)
+    flags = base | (_abi.F_NPC_FIRST_STEP if rule == "acts" else 0)
     cfg = _abi.default_config(seed=14, flags=flags, max_steps=30, distance_cutoff=0.25)
     rng = np.random.default_rng(1)
     acts = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
-    # closed loop
-    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    hs = EnvState(B, A)
     oracle.env_reset(cfg, world, hs)
-    ops.env_reset(cfg, dw, ds)
     for t in range(K):
         hs["action"][...] = acts[t]
         oracle.env_step(cfg, world, hs)
-        ops.env_step(cfg, dw, ds, action=dev(acts[t]))
-    assert_state_equal(hs.host(), ds.host(), "first-step flag, closed loop")
     assert int(hs["episode"].max()) > 2
-    # rollout
-    hr, dr = EnvState(B, A), EnvState(B, A, device=DEV)
+    hr = EnvState(B, A)
     oracle.env_reset(cfg, world, hr)
-    ops.env_reset(cfg, dw, dr)
     rew_o, done_o = oracle.env_rollout(cfg, world, hr, acts)
-    rew_d, done_d = ops.env_rollout(cfg, dw, dr, dev(acts))
-    assert np.array_equal(rew_d.cpu().numpy().view(np.uint32), rew_o.view(np.uint32)) and np.array_equal(done_d.cpu().numpy(), done_o)
-    assert_state_equal(hr.host(), dr.host(), "first-step flag, rollout")
-    # the default rule gives other trajectories (the flag is not a no-op)
-    cfg0 = _abi.default_config(seed=14, flags=_abi.F_ALL, max_steps=30, distance_cutoff=0.25)
+    try:
+        # closed loop: the library's own choice (three roles at 8 / 16 / 32 slots with the caches) and the one-role kernel
+        for form in (None, "solo"):
+            _lib.kernel_override(step=form)
+            ds = EnvState(B, A, device=DEV)
+            ops.env_reset(cfg, dw, ds)
+            for t in range(K):
+                ops.env_step(cfg, dw, ds, action=dev(acts[t]))
+            assert_state_equal(hs.host(), ds.host(), f"first-step rule {rule}, closed loop, step form {form}")
+        _lib.kernel_override()
+        # rollout: every form that exists at this slot count
+        for form in (None, "solo", "duo") + (("trio",) if A in (8, 16, 32) else ()):
+            _lib.kernel_override(rollout=form)
+            dr = EnvState(B, A, device=DEV)
+            ops.env_reset(cfg, dw, dr)
+            rew_d, done_d = ops.env_rollout(cfg, dw, dr, dev(acts))
+            assert np.array_equal(rew_d.cpu().numpy().view(np.uint32), rew_o.view(np.uint32)) and np.array_equal(done_d.cpu().numpy(), done_o), (rule, form)
+            assert_state_equal(hr.host(), dr.host(), f"first-step rule {rule}, rollout form {form}")
+    finally:
+        _lib.kernel_override()
+    # the other rule gives other trajectories (the flag is not a no-op)
+    cfg0 = _abi.default_config(seed=14, flags=flags ^ _abi.F_NPC_FIRST_STEP, max_steps=30, distance_cutoff=0.25)
     d0 = EnvState(B, A, device=DEV)
     ops.env_reset(cfg0, dw, d0)
     ops.env_rollout(cfg0, dw, d0, dev(acts))

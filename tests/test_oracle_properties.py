@@ -117,17 +117,19 @@ def test_step_magnitudes_equal_the_ungated_operator(small_world):
 
 
 def test_first_step_npc_rule_known_answers_and_the_opt_out(small_world):
-    """DESIGN R14 / tde_abi.h TDE_F_NPC_FIRST_STEP.  Default: on the FIRST step of an episode the NPCs coast with the zero action
-    (known answer, independent of any controller: v' = v bit for bit, x' = x + v cos(psi) dt, psi unchanged up to its wrap) and act from step two on.
-    With the flag the controller acts on step one too, as the reference's NPCs do (gym_env.py:285-294: IAIWrapper drives them
-    from the first simulator.step) - checked against the batched-tensor restatement of the controller (oracle/torch_step.py:
-    torch ops, another code path than the C loops) to 1e-5, and it DIFFERS from coasting for the NPCs that have a route."""
+    """DESIGN R14 / tde_abi.h TDE_F_NPC_FIRST_STEP.  Without the flag (the opt-out): on the FIRST step of an episode the NPCs coast
+    with the zero action (known answer, independent of any controller: v' = v bit for bit, x' = x + v cos(psi) dt, psi unchanged up
+    to its wrap) and act from step two on.  With the flag (part of TDE_F_ALL since round 6: the default) the controller acts on step
+    one too, as the reference's NPCs do (gym_env.py:285-294: IAIWrapper drives them from the first simulator.step) - checked against
+    the batched-tensor restatement of the controller (oracle/torch_step.py: torch ops, another code path than the C loops) to 1e-5,
+    and it DIFFERS from coasting for the NPCs that have a route."""
+    assert _abi.F_ALL & _abi.F_NPC_FIRST_STEP                         # the default is the reference's timing
     from oracle.torch_step import TorchWorld, torch_env_step
 
     B, A = 48, 16
     tw = TorchWorld(small_world)
     for flag in (0, _abi.F_NPC_FIRST_STEP):
-        cfg = _abi.default_config(seed=6, flags=(_abi.F_ALL & ~_abi.F_AUTORESET) | flag)
+        cfg = _abi.default_config(seed=6, flags=(_abi.F_ALL & ~_abi.F_AUTORESET & ~_abi.F_NPC_FIRST_STEP) | flag)
         hs, ht = EnvState(B, A), EnvState(B, A)
         oracle.env_reset(cfg, small_world, hs)
         ht.load(hs.host())

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-TDE_ABI_VERSION = 10
+TDE_ABI_VERSION = 11
 TDE_MAX_AGENTS = 128
 
 F_NPC = 1 << 0
@@ -18,7 +18,7 @@ F_AUTORESET = 1 << 4
 F_EGO_ONLY_ATTRS = 1 << 5
 F_TRAFFIC_LIGHTS = 1 << 6
 F_NPC_FIRST_STEP = 1 << 7
-F_ALL = F_NPC | F_REPLAY | F_OFFROAD | F_REWARD | F_AUTORESET
+F_ALL = F_NPC | F_REPLAY | F_OFFROAD | F_REWARD | F_AUTORESET | F_NPC_FIRST_STEP    # (TDE_F_ALL: the reference's NPC timing)
 
 CELL_EMPTY, CELL_MIXED, CELL_FULL = 0, 1, 2
 
@@ -89,13 +89,13 @@ SCN_DTYPE = np.dtype([("map", "i4"), ("wp_n", "i4"), ("start_heading", "f4"), ("
 assert SPAWN_DTYPE.itemsize == 64 and SCN_DTYPE.itemsize == 16
 
 WORLD_PTRS = ["maps", "tri", "cell_word", "cell_tri", "cell_cls2", "cell_sub", "cell_coarse", "tile_near", "scn", "wp_xy", "spawn", "route_xy", "replay_states",
-              "stoplines", "phases"]
-WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT", "hints"]
+              "stoplines", "phases", "start_psi", "first_gap"]
+WORLD_INTS = ["n_maps", "n_scn", "NW", "A", "n_routes", "RW", "n_replay", "RT", "hints", "NH"]
 WORLD_LARGE_GRID = 1 << 0
 
 
 class TdeWorld(C.Structure):
-    _fields_ = [(n, _p) for n in WORLD_PTRS] + [(n, C.c_int32) for n in WORLD_INTS] + [("_pad0", C.c_int32)]
+    _fields_ = [(n, _p) for n in WORLD_PTRS] + [(n, C.c_int32) for n in WORLD_INTS]
 
 
 STATE_AGENT_F32 = ["x", "y", "psi", "v", "len", "wid", "lr", "vdes"]
@@ -175,7 +175,8 @@ def default_config(**over):
 WORLD_DTYPES = {
     "maps": MAP_DTYPE, "tri": np.float32, "cell_word": np.uint32, "cell_tri": np.float32, "cell_cls2": np.uint32, "cell_sub": np.uint32, "cell_coarse": np.uint8, "tile_near": np.uint32, "scn": SCN_DTYPE,
     "wp_xy": np.float64, "spawn": SPAWN_DTYPE, "route_xy": np.float32, "replay_states": np.float32,
-    "stoplines": STOPLINE_DTYPE, "phases": PHASE_DTYPE,
+    "stoplines": STOPLINE_DTYPE, "phases": PHASE_DTYPE, "start_psi": np.float32,
+    "first_gap": np.uint32,        # tde_first_gap [S][A] as pairs of words (gap bits, key): scratch the kernels fill, zeros at upload
 }
 
 STATE_DTYPES = {**{n: np.float32 for n in STATE_AGENT_F32}, **{n: np.int32 for n in STATE_AGENT_I32},

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("TDE_HIP_LIB") or os.path.join(_PKG, "libtde_hip.so") 
 # every symbol include/tde_hip.h declares
 SYMBOLS = ["tde_abi_version", "tde_last_error", "tde_kernel_override", "tde_kinematics_step", "tde_compute_collision",
            "tde_compute_offroad", "tde_kin_collide_step", "tde_waypoint_reward", "tde_env_reset", "tde_env_step",
-           "tde_env_rollout", "tde_render_ego", "tde_env_reset_render", "tde_env_step_render", "tde_state_obs", "tde_ego_infractions", "tde_env_post_step", "tde_grid_build", "tde_grid_free"]
+           "tde_env_rollout", "tde_render_ego", "tde_env_reset_render", "tde_env_step_render", "tde_state_obs", "tde_ego_infractions", "tde_env_post_step", "tde_first_gaps", "tde_grid_build", "tde_grid_free"]
 
 _lib = None
 
@@ -54,6 +54,7 @@ def load():
     L.tde_state_obs.argtypes = [wp, sp, vp, vp]
     L.tde_ego_infractions.argtypes = [cfgp, wp, sp, vp, vp]
     L.tde_env_post_step.argtypes = [cfgp, wp, sp, vp, vp]
+    L.tde_first_gaps.argtypes = [cfgp, wp, vp]
     L.tde_kernel_override.argtypes = [C.c_int, C.c_int]
     L.tde_grid_build.argtypes = [vp, i32, f32, f32, f32, f32, i32, C.POINTER(C.POINTER(_abi.TdeGrid))]
     L.tde_grid_free.argtypes = [C.POINTER(_abi.TdeGrid)]

@@ -64,7 +64,10 @@ def link(objs, out, verbose=False):
     subprocess.run(cmd, check=True)
 
 
-def build(force=False, verbose=False, extra=()):
+def build(force=False, verbose=False, extra=(), out=None):
+    """`extra`: more compiler flags (-D switches of an A/B variant); `out`: where to put the library (default: in-tree, where
+    _lib.load() finds it; a variant for scripts/ab_*.py goes elsewhere, e.g. ab/libX.so)"""
+    OUT = out or globals()["OUT"]
     stale = not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(p) for p in DEPS)
     if force or stale:
         from . import isa_audit
@@ -88,4 +91,9 @@ def build(force=False, verbose=False, extra=()):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    # python -m torchdriveenv_amd.build [OUT.so] [-DNAME=VAL ...]: the in-tree library, or a variant of it
+    args = sys.argv[1:]
+    outs = [a for a in args if not a.startswith("-")]
+    print(build(force=True, verbose=not outs, extra=[a for a in args if a.startswith("-")], out=os.path.abspath(outs[0]) if outs else None))

@@ -33,6 +33,10 @@ class SimulatorConfig:
     npc_reach: float = 3.0
     npc_max_accel: float = 3.0
     npc_max_steer: float = 0.3
+    # the NPC controller acts from the FIRST step of an episode, as the reference's NPCs do (ref gym_env.py:285-294: IAIWrapper
+    # predicts from step one) -> TDE_F_NPC_FIRST_STEP.  False: the NPCs coast through step one (the rule of rounds 4 / 5, slightly
+    # cheaper: a re-spawn then leaves nothing to recompute)
+    npc_first_step: bool = True
 
 
 @dataclass

@@ -138,31 +138,35 @@ int tde_env_reset(const tde_config *cfg, const tde_world *world, const tde_state
 
 // `load_slots`: the agent slots stepping on the device at the same time - the batch's own, or the whole batch's when this is one
 // of the sub-batches tde_env_step_render runs side by side (the choice of kernel form is a matter of load)
-// hash of what the NPC controller depends on besides the state (tde_act_cache; act_key_steps)
-static uint32_t act_cfg_hash(const tde_config &cfg, const tde_world &w)
+// The (world, configuration) pairs whose first-step gap cache this process has filled: tde_env_step / tde_env_rollout fill it on
+// first use.  A stale entry (the table's memory re-used by another world at the same address with the same tables) only costs
+// speed: the kernels check every entry's key and fall back to the whole controller.
+static std::atomic<uint64_t> g_fg_memo[16];
+static std::atomic<unsigned> g_fg_next{0};
+static uint64_t fg_memo_word(const tde_world &w, uint32_t hash)
 {
-#ifdef TDE_ACT_KEY_PLAIN          // (A/B builds: the round-3 key, the step counter alone)
-    return 0u;
-#endif
-    uint32_t h = cfg.flags & (TDE_F_NPC | TDE_F_REPLAY | TDE_F_TRAFFIC_LIGHTS);
-    // the identity of the tables the controller reads (routes, spawn records, stop lines, light phases, maps, scenarios): a caller
-    // that swaps or rebuilds the world under an unchanged state gets the actions recomputed, not replayed
-    const void *tabs[7] = {w.route_xy, w.spawn, w.stoplines, w.phases, w.maps, w.scn, w.replay_states};
-    for (int i = 0; i < 7; ++i) {
-        const uint64_t a = (uint64_t)(uintptr_t)tabs[i];
-        h = (h ^ (uint32_t)a) * 0x9E3779B1u;
-        h = (h ^ (uint32_t)(a >> 32)) * 0x9E3779B1u;
-    }
-    const int32_t dims[6] = {w.n_routes, w.RW, w.n_replay, w.RT, w.n_scn, w.n_maps};
-    for (int i = 0; i < 6; ++i) h = (h ^ (uint32_t)dims[i]) * 0x9E3779B1u;
-    const float c[10] = {cfg.npc_k_steer, cfg.npc_k_speed, cfg.npc_gap_s0, cfg.npc_cone_k, cfg.npc_lane_half, cfg.npc_reach,
-                         cfg.npc_max_accel, cfg.npc_max_steer, cfg.npc_cone_range, cfg.dt};
-    for (int i = 0; i < 10; ++i) {
-        uint32_t b;
-        memcpy(&b, &c[i], 4);
-        h = (h ^ b) * 0x9E3779B1u;
-    }
-    return h;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint64_t x = (uint64_t)(uintptr_t)w.first_gap * 0x9E3779B97F4A7C15ull;
+    x ^= ((uint64_t)hash << 8) ^ (uint64_t)(dev & 0xff);
+    return x | 1ull;
+}
+
+static int first_gaps_launch(const tde_config *cfg, const tde_world *world, void *stream, bool use_memo)
+{
+    if (!world->first_gap || world->A > tde::kWave || world->n_scn <= 0) return 0;
+    if (!(cfg->flags & TDE_F_NPC) || !(cfg->flags & TDE_F_NPC_FIRST_STEP)) return 0;
+    const uint32_t hash = tde_host::act_cfg_hash(*cfg, *world);
+    const uint64_t word = fg_memo_word(*world, hash);
+    if (use_memo)
+        for (auto &m : g_fg_memo)
+            if (m.load(std::memory_order_relaxed) == word) return 0;
+    const unsigned nb = blocks_for((int64_t)world->n_scn * world->A);
+    TDE_DISPATCH_A(world->A, tde::first_gap_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, hash | 1u));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("tde_first_gaps", e);
+    g_fg_memo[g_fg_next.fetch_add(1, std::memory_order_relaxed) % 16].store(word, std::memory_order_relaxed);
+    return 0;
 }
 
 static int env_step_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream, int64_t load_slots)
@@ -189,10 +193,11 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     const bool packable = world->n_routes < id_max && world->n_replay < id_max && world->RW < len_max && world->RT < len_max;
     const bool trio_ok = st->slot_cache && st->env_cache && packable && (st->A == 8 || st->A == 16 || st->A == 32);
     const bool want_trio = force == 3 || (force == 0 && load_slots <= 131072);
-    // (TDE_F_NPC_FIRST_STEP: the controller acts on the first step of an episode too - the one-role kernel, which evaluates it on
-    //  every step; the three-role kernel skips it after a re-spawn)
-    const bool first_step_acts = (cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP);
-    if (trio_ok && want_trio && !first_step_acts) return tde_host::launch_step_trio(cfg, world, st, act_cfg_hash(*cfg, *world), stream);
+    if (trio_ok && want_trio) {
+        rc = first_gaps_launch(cfg, world, stream, true);                    // (first use of this world with this configuration)
+        if (rc) return rc;
+    }
+    if (trio_ok && want_trio) return tde_host::launch_step_trio(cfg, world, st, tde_host::act_cfg_hash(*cfg, *world), stream);
     // the one-role kernel (its forms - the class map on large grids, four wavefronts per SIMD for big 128-slot batches - are chosen
     // by the launcher); with / without tde_state.magnitudes are two translation units
     return st->magnitudes ? tde_host::launch_step_solo_mag(cfg, world, st, stream) : tde_host::launch_step_solo(cfg, world, st, stream);
@@ -223,6 +228,10 @@ static tde_state state_slice(const tde_state &s, int64_t e0, int32_t n)
 static int rollout_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, int team,
                           void *stream)
 {
+    if (team != 1) {                                                         // (the role-split kernels read the first-step gap cache)
+        const int rc = first_gaps_launch(cfg, world, stream, true);
+        if (rc) return rc;
+    }
     if (team == 3) return tde_host::launch_rollout_trio(cfg, world, st, ro, stream);
     if (team == 1) return tde_host::launch_rollout_solo(cfg, world, st, ro, stream);
     return tde_host::launch_rollout_duo(cfg, world, st, ro, stream);
@@ -245,7 +254,7 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
         // Two roles (four wavefronts per env) at every batch size - us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs:
         // two roles 6.2 / 8.9 / 18.0 / 34.7, one role 10.6 / 11.4 / 23.3 / 38.9 (profiles/r04_z_wide2_waves.txt).
         // tde_kernel_override(1, 0) forces the one-role kernel.
-        const bool one_role = g_force_rollout == 1 || ((cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP));
+        const bool one_role = g_force_rollout == 1;
         return one_role ? tde_host::launch_rollout_solo(cfg, world, st, &r128, stream) : tde_host::launch_rollout_wide(cfg, world, st, &r128, stream);
     }
     // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
@@ -260,7 +269,6 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
     const bool trio_shape = st->A == 8 || st->A == 16 || st->A == 32;
     int team = forced ? forced : (st->A == 8 || st->A == 16 || (st->A == 32 && !lights0)) ? 3 : 2;
     if (team == 3 && !trio_shape) team = 2;
-    if ((cfg->flags & TDE_F_NPC) && (cfg->flags & TDE_F_NPC_FIRST_STEP)) team = 1;   // (the role-split kernels skip the controller after a re-spawn)
     tde_rollout r = *ro;
     if (r.ldb == 0) r.ldb = st->B;
     // The two- and three-role kernels are tuned for ONE residency round of the chip: 8 workgroups (groups of 64 agent slots)
@@ -409,6 +417,13 @@ int tde_env_post_step(const tde_config *cfg, const tde_world *world, const tde_s
     TDE_DISPATCH_A128(st->A, tde::env_post_step_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, *st, magnitudes));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("tde_env_post_step", e);
+}
+
+int tde_first_gaps(const tde_config *cfg, const tde_world *world, void *stream)
+{
+    if (!cfg || !world) return bad("tde_first_gaps: NULL argument");
+    if (!pow2_le64(world->A)) return bad("tde_first_gaps: world.A must be a power of two in [1,128]");
+    return first_gaps_launch(cfg, world, stream, false);
 }
 
 int tde_state_obs(const tde_world *world, const tde_state *st, float *out, void *stream)

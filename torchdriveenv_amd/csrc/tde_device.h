@@ -498,8 +498,9 @@ struct Cold {
     const double *wp_xy;
     const tde_map *maps;
     const float *route_xy;
+    const float *start_psi;              // the heading table along the first waypoint segments (tde_world.start_psi), NH per scenario
     uint32_t env_base;
-    int n_scn, NW, RW, max_steps, terminated_at_infraction;
+    int n_scn, NW, RW, max_steps, terminated_at_infraction, NH;
 };
 
 TDE_DEV void fill_cold(Cold &c, const tde_config &cfg, const tde_world &w)
@@ -510,6 +511,7 @@ TDE_DEV void fill_cold(Cold &c, const tde_config &cfg, const tde_world &w)
     c.cut_sliver = sliver_of(cfg.distance_cutoff); c.reach_sliver = sliver_of(cfg.reach_radius);
     cut2f_bounds(cfg.distance_cutoff, c.cut2f_lo, c.cut2f_hi);
     c.spawn = w.spawn; c.scn = w.scn; c.wp_xy = w.wp_xy; c.maps = w.maps; c.route_xy = w.route_xy;
+    c.start_psi = w.start_psi; c.NH = w.NH;
     c.env_base = cfg.env_base; c.n_scn = w.n_scn; c.NW = w.NW; c.RW = w.RW;
     c.max_steps = cfg.max_steps; c.terminated_at_infraction = cfg.terminated_at_infraction;
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/tde_hip.h"
 
@@ -44,6 +45,33 @@ inline int cu_count()
         cached_dev = dev;
     }
     return cached;
+}
+
+// hash of what the NPC controller depends on besides the state (tde_act_cache; act_key_steps)
+inline uint32_t act_cfg_hash(const tde_config &cfg, const tde_world &w)
+{
+#ifdef TDE_ACT_KEY_PLAIN          // (A/B builds: the round-3 key, the step counter alone)
+    return 0u;
+#endif
+    uint32_t h = cfg.flags & (TDE_F_NPC | TDE_F_REPLAY | TDE_F_TRAFFIC_LIGHTS);
+    // the identity of the tables the controller reads (routes, spawn records, stop lines, light phases, maps, scenarios): a caller
+    // that swaps or rebuilds the world under an unchanged state gets the actions recomputed, not replayed
+    const void *tabs[7] = {w.route_xy, w.spawn, w.stoplines, w.phases, w.maps, w.scn, w.replay_states};
+    for (int i = 0; i < 7; ++i) {
+        const uint64_t a = (uint64_t)(uintptr_t)tabs[i];
+        h = (h ^ (uint32_t)a) * 0x9E3779B1u;
+        h = (h ^ (uint32_t)(a >> 32)) * 0x9E3779B1u;
+    }
+    const int32_t dims[6] = {w.n_routes, w.RW, w.n_replay, w.RT, w.n_scn, w.n_maps};
+    for (int i = 0; i < 6; ++i) h = (h ^ (uint32_t)dims[i]) * 0x9E3779B1u;
+    const float c[10] = {cfg.npc_k_steer, cfg.npc_k_speed, cfg.npc_gap_s0, cfg.npc_cone_k, cfg.npc_lane_half, cfg.npc_reach,
+                         cfg.npc_max_accel, cfg.npc_max_steer, cfg.npc_cone_range, cfg.dt};
+    for (int i = 0; i < 10; ++i) {
+        uint32_t b;
+        memcpy(&b, &c[i], 4);
+        h = (h ^ b) * 0x9E3779B1u;
+    }
+    return h;
 }
 
 // ---- one launcher per kernel family; each is defined by the unit that instantiates the family (build.py compiles them side by

@@ -375,7 +375,11 @@ TDE_DEV void ego_spawn(const tde_config &cfg, const Cold &w, int scn, const uint
     const double sx = w0.x + f * (w1.x - w0.x);
     const double sy = w0.y + f * (w1.y - w0.y);
     const double speed = u01(r0.z) * 10.0;
-    const double psi0 = (double)__int_as_float(se.z) + (double)normal_f32(r1.z, r1.w) * 0.1;
+    // the lane direction at the start point (find_lanelet_directions, :359): the world's heading table along the first waypoint
+    // segment at the drawn fraction, or - without one - the scenario's start heading
+    float lane_psi = __int_as_float(se.z);
+    if (w.NH > 0) lane_psi = w.start_psi[(int64_t)scn * w.NH + (int)(f * (double)w.NH)];
+    const double psi0 = (double)lane_psi + (double)normal_f32(r1.z, r1.w) * 0.1;
     pose = make_float4((float)sx, (float)sy, (float)psi0, (float)speed);
     attr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (cfg.flags & TDE_F_EGO_ONLY_ATTRS)
@@ -470,6 +474,133 @@ TDE_DEV void respawn_lane(const tde_config &cfg, const Cold &w, int e, int a, Ag
 // npc_gap: the leader gap over the A rows at ra / rb.  `i` = the lane's own slot RELATIVE to ra (outside [0, A) when the rows are
 // the other half of a 128-slot env: it is then only the "not taken" stand-in row and the j < i operand), `own_bit` = its bit in the
 // candidate mask (0 when it is not among these rows).
+// npc_candidates: the branch-free sweep - the candidate mask over the A rows at ra (bit order: bit_of_row)
+template <int A>
+TDE_DEV typename MaskOf<A>::type npc_candidates(const tde_config &cfg, const float4 *ra, const Agent &ag, float cp, float sp, float g_far)
+{
+    using mask_t = typename MaskOf<A>::type;
+    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
+    mask_t cand = 0;
+    const float hl_i = 0.5f * ag.len;
+    {
+        // Conservative forms of the exact tests below: a slot that passes there passes here.  The prefilter only has to
+        // be a superset, so it is free to round differently: the forward / lateral offsets are bilinear forms evaluated
+        // with fused multiply-adds (|error| < 1e-3 m for |coordinates| < 1e4 m) and every condition is relaxed by 1 cm,
+        // folded into the constants so that each is a plain sign test:
+        //   ahead            f' = fj + 0.01                                   > 0
+        //   gap < g_far      n  = reach_j - f' + (g_far + hl_i + 0.05 + 0.02) > 0      (reach_j >= hl_j)
+        //   widest corridor  w  = max(cone_k, 0) * f' + (halfw_j + 0.01) - |lj| > 0    (tile row a.w = halfw_j + 0.01)
+        // verdict = max3(-f', -n, -w): negative (sign bit set) <=> all three hold.
+        const float nP = 0.01f - (ag.x * cp + ag.y * sp), nQ = -(ag.y * cp - ag.x * sp);
+        const float L = (g_far + hl_i) + 0.07f;
+        const float kc = fmaxf(cfg.npc_cone_k, 0.0f);
+        // (the rows as two 8-byte halves fetched at different stages: 3.63 vs 3.67 us; with 16-byte reads like the
+        //  collision sweep 3.25 vs 3.19, profiles/r02_d_ab_diet_steps.txt H1 / Q2)
+        cand = sweep_blocks_halves<A>(ra, [&](float2 (&xy)[C], float2 (&zw)[C], float (&v)[C], auto &&prefetch_xy, auto &&prefetch_zw) {
+            float f[C], l[C], n[C], w[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(xy[j].y, sp, nP); l[j] = __builtin_fmaf(-xy[j].x, sp, nQ); }
+            pin(f, l);
+#pragma unroll
+            for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(xy[j].x, cp, f[j]); l[j] = __builtin_fmaf(xy[j].y, cp, l[j]); }
+            pin(f, l);
+            pin_memory();
+            prefetch_xy();                                     // the positions are consumed: fetch the next block's
+            pin_memory();
+#pragma unroll
+            for (int j = 0; j < C; ++j) { n[j] = zw[j].x - f[j]; w[j] = __builtin_fmaf(kc, f[j], zw[j].y); }
+            pin(n, w);
+            pin_memory();
+            prefetch_zw();
+            pin_memory();
+#pragma unroll
+            for (int j = 0; j < C; ++j) { n[j] = n[j] + L; w[j] = w[j] - fabsf(l[j]); }
+            pin(n, w);
+#pragma unroll
+            for (int j = 0; j < C; ++j) v[j] = fmaxf(fmaxf(-f[j], -n[j]), -w[j]);
+            pin(v);
+        });
+    }
+    return cand;
+}
+
+// npc_gap_exact: the exact lane / yield-cone tests of the rows in `cand` -> the leader gap (1e30: none).  The prefilter above is a
+// superset filter, so the exact tests ARE the specification: a row outside the candidates cannot be taken, and the minimum over any
+// split of the candidates is the minimum over all of them (same values, same bits).  Called by all lanes of the wavefront.
+template <int A>
+TDE_DEV float npc_gap_exact(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, typename MaskOf<A>::type cand, const Agent &ag,
+                            float cp, float sp)
+{
+    using mask_t = typename MaskOf<A>::type;
+    const float hl_i = 0.5f * ag.len;
+    float gap = 1e30f;
+    // exact tests of the candidates; every lane walks its own list, so the wavefront makes max-over-lanes(count) trips
+    // (3.8 on average for 0.9 candidates per lane: the busiest lane of 64 follows a platoon).  TWO candidates per trip:
+    // two independent chains per lane - a lone wavefront issues independent instructions twice as fast as dependent
+    // ones - and ceil(count / 2) trips (2.2).  A lane with fewer candidates tests its own row instead, which cannot be
+    // taken (fj = 0).
+    while (__ballot(cand != 0)) {
+        const mask_t c1 = cand & (cand - 1);
+        int j[2];
+        j[0] = cand ? row_of_bit<A>(lowest_bit(cand)) : i;
+        j[1] = c1 ? row_of_bit<A>(lowest_bit(c1)) : i;
+        cand = c1 & (c1 - 1);
+        // the two tests stage by stage (pins as in the sweeps: left alone, the scheduler runs them one after the other)
+        float4 pj[2], qj[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { pj[u] = ra[j[u]]; qj[u] = rb[j[u]]; }
+        float ex[2], ey[2], fj[2], lj[2], hd[2], halfw[2], t0[2], t1[2], g[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { ex[u] = pj[u].x - ag.x; ey[u] = pj[u].y - ag.y; }
+        pin(ex, ey);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { fj[u] = ex[u] * cp; t0[u] = ey[u] * sp; lj[u] = ey[u] * cp; t1[u] = ex[u] * sp; }
+        pin(fj, t0);
+        pin(lj, t1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            fj[u] = fj[u] + t0[u]; lj[u] = lj[u] - t1[u];
+            hd[u] = cp * qj[u].x; t0[u] = sp * qj[u].y;
+            halfw[u] = cfg.npc_lane_half + qj[u].w;        // = npc_lane_half + 0.5f * wid_j (qj.w = hw_j = 0.5f * wid_j)
+            g[u] = hl_i + qj[u].z;                         // 0.5f*(len_i + len_j) == 0.5f*len_i + 0.5f*len_j bit for bit
+        }
+        pin(fj, lj);
+        pin(hd, t0);
+        pin(halfw, g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { hd[u] = hd[u] + t0[u]; t1[u] = cfg.npc_cone_k * fj[u]; g[u] = fj[u] - g[u]; }
+        pin(hd, t1);
+        pin(g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) t1[u] = halfw[u] + t1[u];
+        pin(t1);
+        // the predicates as SIGN BITS of correctly rounded differences (a < b <=> sign(a - b); exact, gradual underflow),
+        // combined with bitwise and / or and blended in with v_bfi: a v_cmp -> s_and -> v_cndmask chain through SGPR
+        // pairs costs a lone wavefront ~24 cycles per link, six compares per candidate
+        int tk[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float al = fabsf(lj[u]);
+            const int inlane = __float_as_int(al - halfw[u]);                  // al < halfw
+            const int c1 = __float_as_int(al - t1[u]);                         // al < halfw + cone_k * fj
+            const int c2 = __float_as_int(fj[u] - cfg.npc_cone_range);         // fj < cone_range
+            const int c3 = __float_as_int(-0.5f - hd[u]);                      // hd > -0.5
+            const int c4 = j[u] - i;                                           // j < i
+            const int ahead = __float_as_int(0.0f - fj[u]);                    // fj > 0 (0 - fj: +0 for fj = +-0)
+            tk[u] = (((c1 & c2) & (c3 & c4)) | inlane) & ahead;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t m = (uint32_t)(tk[u] >> 31);                        // all ones: taken
+            g[u] = __uint_as_float((m & __float_as_uint(g[u])) | (~m & __float_as_uint(1e30f)));
+        }
+        gap = fminf(gap, fminf(g[0], g[1]));
+    }
+    return gap;
+}
+
+// (the hot path's form: sweep and exact tests in ONE function - split in two calls the same code costs the three-role kernels
+//  registers: 13 -> 18 spilled VGPRs in the rollout kernel, +0.5 us per closed-loop launch)
 template <int A>
 TDE_DEV float npc_gap(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, typename MaskOf<A>::type own_bit, const Agent &ag,
                       float cp, float sp, bool has_target, float g_far)
@@ -612,6 +743,36 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
 {
     const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far);
     npc_act_of_gap(cfg, ag, cp, sp, has_target, tgx, tgy, gap, red_gap, acc, beta);
+}
+
+// ---- the controller on the FIRST step of an episode (TDE_F_NPC_FIRST_STEP) in the role-split kernels -------------------------------
+// On step one the pre-step scene of an env is its scenario's spawn records - the same every episode - plus the ego at its drawn start.
+// What an NPC's controller finds there apart from the ego, G1 = min(leader gap over the scenario's other NPCs, gap to a red stop line
+// at step one), depends on the scenario's tables and the controller's constants only: tde_first_gaps (first_gap_kernel below) computes
+// it once per (scenario, slot) into the world's first-step gap cache (tde_world.first_gap, keyed by the controller hash).  With valid
+// entries a re-spawned env's first action is min(G1, exact test against the ego's row) -> npc_act_of_gap: one trip of the exact loop
+// instead of the sweep over the env's rows and the stop-line loop (a minimum over the same values in another order: the same bits as
+// npc_action); with an entry missing (tde_first_gaps not called for this configuration) the kernels run the whole controller.
+#ifndef TDE_FIRST_GAP
+#define TDE_FIRST_GAP 1             // 0: the kernels ignore the first-step gap cache (A/B; same results)
+#endif
+TDE_DEV uint32_t first_gap_key(uint32_t act_hash) { return act_hash | 1u; }     // (never 0: zero-initialised entries are invalid)
+
+// The first-step action (na, nb) of the lanes with `fresh_npc` (NPC slots of an env at k == 1) from their cache entries `ent`; the
+// other lanes keep theirs.  Returns false - nothing computed - when a lane that needs an entry has none (wave-uniform).
+// Called by all lanes of the wavefront, converged.
+template <int A>
+TDE_DEV bool npc_first_step(const tde_config &cfg, uint2 ent, uint32_t key, const float4 *ra, const float4 *rb, int a, const Agent &ag, float cp,
+                            float sp, bool fresh_npc, bool has_target, float tgx, float tgy, float &na, float &nb)
+{
+    using mask_t = typename MaskOf<A>::type;
+    const bool use = fresh_npc && has_target;                 // the lanes whose action depends on a gap
+    if (!TDE_FIRST_GAP || __ballot(use && ent.y != key)) return false;
+    const float g_ego = npc_gap_exact<A>(cfg, ra, rb, a, use ? bit_of_row<A>(0) : (mask_t)0, ag, cp, sp);
+    float xa, xb;
+    npc_act_of_gap(cfg, ag, cp, sp, has_target, tgx, tgy, fminf(__uint_as_float(ent.x), g_ego), 1e30f, xa, xb);
+    if (fresh_npc) { na = xa; nb = xb; }
+    return true;
 }
 
 // R9 for one slot against the A slots of its env (rows ra / rb).  Overlapping convex boxes have centres closer than the
@@ -1377,7 +1538,7 @@ TDE_DEV void write_rows(DuoShared &sh, int buf, int lane, bool live, const Agent
 // BIG (tde_world.hints & TDE_WORLD_LARGE_GRID): the judges take the corner classes from the 2-bit class map
 template <int A, bool LIGHTS, bool BIG>
 __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_rollout_duo_kernel(tde_config cfg, tde_world w, tde_state st,
-                                                                    tde_rollout ro)
+                                                                    tde_rollout ro, uint32_t act_hash)
 {
     __shared__ DuoShared sh;
     __shared__ Cold cold;
@@ -1385,6 +1546,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = drive, 1 = judge
     if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull; }
     const uint32_t F = cfg.flags;
+    const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;   // the NPC controller acts on an episode's first step too
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
     const int B = st.B;
@@ -1425,6 +1587,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             float na = 0.0f, nb = 0.0f;
             int nwp, k, n_target = er.target_idx, n_reached = er.reached;
             bool switched, live;
+            bool again = false;                              // the second pass runs the controller too (wave-uniform; see the re-spawn)
             for (int pass = 0;; ++pass) {
                 // one step from the rows in buffer q, nothing committed yet (step_lane up to the tile write)
                 k = er.steps + 1;                                                            // :116
@@ -1437,19 +1600,20 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 float acc = 0.0f, beta = 0.0f;
                 if (a == 0) { acc = act.x; beta = act.y; }
                 if (F & TDE_F_NPC) {
-                    // The controller runs in the first pass only.  A second pass means that an env of this wavefront finished
-                    // and its lanes were re-spawned: they are at the first step of their episode, where the NPCs coast (zero
-                    // action: the controller reads the scene of the previous step, which a fresh episode does not have), and
-                    // the other envs' actions are those of the first pass - nothing to recompute (rounds 1-3 repeated the
-                    // whole sweep here, on 7 % of the wave-steps).
-                    if (pass == 0) {
+                    // A second pass means that an env of this wavefront finished and its lanes were re-spawned: they are at the
+                    // first step of their episode.  Without TDE_F_NPC_FIRST_STEP the re-spawned NPCs coast through it (zero
+                    // action) and there is nothing to recompute; with it (the default: the reference's NPCs act from step one,
+                    // gym_env.py:285-294) their first actions came out of the re-spawn block below - or, when the world's first-step
+                    // gap cache had no entry for them (`again`), the controller runs a second time here, on the new episode's spawn
+                    // rows in buffer q: the other envs' rows and state are unchanged, so their lanes get the first pass's values again.
+                    if (pass == 0 || again) {
                         const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
                         const float red_gap =
                             (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
                         npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
                                       cx.g_far, red_gap, na, nb);
                     }
-                    if (npc && k > 1) { acc = na; beta = nb; }
+                    if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }
                 }
                 nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
                 if (live) {
@@ -1477,13 +1641,26 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 if (!dn) break;
                 // an env of this wavefront finished at step i-1: re-spawn its lanes (as step_lane does in place),
                 // put their rows into buffer q and recompute the step
-                if (mask_bit(dn, base) && valid) {
+                const bool fresh = mask_bit(dn, base) && valid;
+                uint2 fg_ent = make_uint2(0u, 0u);           // the lane's entry of the world's first-step gap cache
+                if (fresh) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
+                    if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap)    // (in flight across the table look-ups of load_ctx)
+                        fg_ent = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     redc.invalidate();
                     sincos_f32(ag.psi, s0, c0);
                     write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges' pre-step rows of the new episode)
                     if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
+                }
+                if (first_acts && (F & TDE_F_NPC)) {
+                    // TDE_F_NPC_FIRST_STEP: the re-spawned lanes' first actions, from the world's first-step gap cache and ONE exact
+                    // test against the ego's new row (the second pass applies them; the other lanes keep the first pass's) - or, an
+                    // entry missing, by the controller itself in the second pass
+                    const bool f_npc = fresh && a > 0 && ag.present;
+                    const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                    again = !npc_first_step<A>(cfg, fg_ent, first_gap_key(act_hash), &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, f_npc, f_target,
+                                               cx.tgx, cx.tgy, na, nb);
                 }
             }
             ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
@@ -1633,6 +1810,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
     const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
     if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0; }
     const uint32_t F = cfg.flags;
+    const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;   // the NPC controller acts on an episode's first step too
     const int e = (int)blockIdx.x;                          // (the grid is B workgroups: every env is valid)
     const int64_t g = (int64_t)e * A + a;
     const int LB = ro.ldb;
@@ -1675,13 +1853,13 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
                 float acc = 0.0f, beta = 0.0f;
                 if (a == 0) { acc = act.x; beta = act.y; }
                 if (F & TDE_F_NPC) {
-                    if (pass == 0) {                         // (a second pass = a re-spawn: first step, the NPCs coast)
+                    if (pass == 0 || first_acts) {           // (a second pass = a re-spawn: the new episode's first step)
                         const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
                         const float red_gap =
                             (LIGHTS && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
                         npc_action_wide<A>(cfg, &sh.a[q][0], &sh.b[q][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
                     }
-                    if (npc && k > 1) { acc = na; beta = nb; }
+                    if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }
                 }
                 nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
                 if (live) {
@@ -1705,6 +1883,9 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
                 sincos_f32(ag.psi, s0, c0);
                 write_rows_wide(sh, q, a, ag.present, ag, c0, s0, cfg.npc_lane_half);
                 if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache_wide(sh, w, cx.m, a);
+                // the second pass's controller reads the spawn rows of BOTH halves of the env: the two driver wavefronts meet (the
+                // judges come to the same barrier from their own bookkeeping of the re-spawn: sh.done is the same word for all four)
+                if (first_acts) lds_barrier();
             }
             ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
             c0 = nc; s0 = ns;
@@ -1732,6 +1913,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
                 reset_lane<A>(cfg, cold, e, a, ag, er);
                 load_ctx<A>(cfg, cold, a, ag, er, cx);
                 redc.invalidate();
+                if (first_acts) lds_barrier();               // (the drivers' barrier between the spawn rows and their second pass)
             }
             lds_barrier();                                   // B: rows of step i are in buffer p
             er.steps += 1;
@@ -1868,7 +2050,7 @@ template <int N> TDE_DEV void dummy_valu(float seed)
 #ifndef TDE_ROLLOUT_CONST_ARGS
 #define TDE_ROLLOUT_CONST_ARGS 0
 #endif
-struct RolloutArgs { tde_config cfg; tde_world w; tde_state st; tde_rollout ro; };
+struct RolloutArgs { tde_config cfg; tde_world w; tde_state st; tde_rollout ro; uint32_t act_hash; };
 #if TDE_ROLLOUT_CONST_ARGS
 __constant__ RolloutArgs g_rollout_args;
 #endif
@@ -1879,8 +2061,9 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
 {
     const tde_config &cfg = g_rollout_args.cfg; const tde_world &w = g_rollout_args.w; const tde_state &st = g_rollout_args.st;
     const tde_rollout &ro = g_rollout_args.ro;
+    const uint32_t act_hash = g_rollout_args.act_hash;
 #else
-    tde_config cfg, tde_world w, tde_state st, tde_rollout ro)
+    tde_config cfg, tde_world w, tde_state st, tde_rollout ro, uint32_t act_hash)
 {
 #endif
     __shared__ DuoShared sh;
@@ -1892,6 +2075,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
     }
     const uint32_t F = cfg.flags;
+    const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;   // the NPC controller acts on an episode's first step too
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
     const int B = st.B;
@@ -1940,6 +2124,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             float na = 0.0f, nb = 0.0f;
             int nwp, k;
             bool switched, live;
+            bool again = false;                              // the second pass runs the controller too (wave-uniform; see the re-spawn)
             for (int pass = 0;; ++pass) {
                 // one step from the rows in buffer q, nothing committed yet (step_lane up to the tile write)
                 k = er.steps + 1;                                                            // :116
@@ -1952,19 +2137,20 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 float acc = 0.0f, beta = 0.0f;
                 if (a == 0) { acc = act.x; beta = act.y; }
                 if (F & TDE_F_NPC) {
-                    // The controller runs in the first pass only.  A second pass means that an env of this wavefront finished
-                    // and its lanes were re-spawned: they are at the first step of their episode, where the NPCs coast (zero
-                    // action: the controller reads the scene of the previous step, which a fresh episode does not have), and
-                    // the other envs' actions are those of the first pass - nothing to recompute (rounds 1-3 repeated the
-                    // whole sweep here, on 7 % of the wave-steps).
-                    if (pass == 0) {
+                    // A second pass means that an env of this wavefront finished and its lanes were re-spawned: they are at the
+                    // first step of their episode.  Without TDE_F_NPC_FIRST_STEP the re-spawned NPCs coast through it (zero
+                    // action) and there is nothing to recompute; with it (the default: the reference's NPCs act from step one,
+                    // gym_env.py:285-294) their first actions came out of the re-spawn block below - or, when the world's first-step
+                    // gap cache had no entry for them (`again`), the controller runs a second time here, on the new episode's spawn
+                    // rows in buffer q: the other envs' rows and state are unchanged, so their lanes get the first pass's values again.
+                    if (pass == 0 || again) {
                         const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
                         const float red_gap =
                             (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
                         npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
                                       cx.g_far, red_gap, na, nb);
                     }
-                    if (npc && k > 1) { acc = na; beta = nb; }
+                    if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }
                 }
                 nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;
                 if (live) {
@@ -1987,13 +2173,26 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 if (!dn) break;
                 // an env of this wavefront finished at step i-1: re-spawn its lanes (as step_lane does in place),
                 // put their rows into buffer q and recompute the step
-                if (mask_bit(dn, base) && valid) {
+                const bool fresh = mask_bit(dn, base) && valid;
+                uint2 fg_ent = make_uint2(0u, 0u);           // the lane's entry of the world's first-step gap cache
+                if (fresh) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
+                    if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap)    // (in flight across the table look-ups of load_ctx)
+                        fg_ent = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     redc.invalidate();
                     sincos_f32(ag.psi, s0, c0);
                     write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges' pre-step rows of the new episode)
                     if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
+                }
+                if (first_acts && (F & TDE_F_NPC)) {
+                    // TDE_F_NPC_FIRST_STEP: the re-spawned lanes' first actions, from the world's first-step gap cache and ONE exact
+                    // test against the ego's new row (the second pass applies them; the other lanes keep the first pass's) - or, an
+                    // entry missing, by the controller itself in the second pass
+                    const bool f_npc = fresh && a > 0 && ag.present;
+                    const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                    again = !npc_first_step<A>(cfg, fg_ent, first_gap_key(act_hash), &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, f_npc, f_target,
+                                               cx.tgx, cx.tgy, na, nb);
                 }
             }
             ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
@@ -2320,6 +2519,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
     }
     const uint32_t F = cfg.flags;
+    const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;   // the NPC controller acts on an episode's first step too
     // (32-bit slot index: B * A slots of ~60 bytes of state each cannot exceed 2^32, and an int64 index costs every role two
     //  registers for the whole launch - the kernel has none to spare with the magnitudes section in it)
     const uint32_t g = blockIdx.x * (uint32_t)kWave + (uint32_t)lane;
@@ -2385,7 +2585,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         // Lights: the red masks of this and the next step, the stop lines in LDS and where the rest of them lie come from judge O
         // (sh.lights, sh.stop: written while it waits for barrier B - the driver's own path to B carries neither the phase table's
         // nor the stop lines' loads); `early`: ahead of B the driver fetches what it needs itself (the rare recompute).
-        auto controller = [&](int buf, bool early, float &na, float &nb) {
+        auto red_gap_of = [&](bool early) {
             float red_gap = 1e30f;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) {
                 if (early) {
@@ -2398,12 +2598,18 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
                         red_gap = red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + lw.z, lane / A}, lw.w, (uint32_t)lw.y, ag, c0, s0);
                 }
             }
+            return red_gap;
+        };
+        auto controller = [&](int buf, bool early, float &na, float &nb) {
+            const float red_gap = red_gap_of(early);
             npc_action<A>(cfg, &sh.a[buf][base], &sh.b[buf][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far,
                           red_gap, na, nb);
         };
         if (F & TDE_F_NPC) {
-            // (k == 1, the first step of an episode: the NPCs coast - nothing to look up or compute)
-            const bool stored = !npc || k == 1 || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
+            // (k == 1, the first step of an episode: without TDE_F_NPC_FIRST_STEP the NPCs coast - nothing to look up or compute;
+            //  with it the launch that re-spawned the env stored its first actions like any others - from the world's first-step gap
+            //  cache, see the re-spawn below - or, without entries for its scenario, stored the key invalid: computed here)
+            const bool stored = !npc || (k == 1 && !first_acts) || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
             if (__ballot(!stored)) {
                 sincos_f32(ag.psi, s0, c0);
                 write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
@@ -2414,7 +2620,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
             } else if (npc) {
                 acc = ac.x; beta = ac.y;
             }
-            if (npc && k == 1) acc = beta = 0.0f;
+            if (npc && k == 1 && !first_acts) acc = beta = 0.0f;
         }
         if (live) {
             bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117
@@ -2449,20 +2655,42 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
         bool respawned = false;
+        bool first_ok = false;                               // the re-spawned envs' first actions are in (na2, nb2) (wave-uniform)
+        uint2 fge = make_uint2(0u, 0u);
         if (dn) {
 #ifdef TDE_EXP_NO_D_RESPAWN           // timing experiment (WRONG results)
             if (false) {
 #else
             if (mask_bit(dn, base) && valid) {
 #endif
+                // (TDE_F_NPC_FIRST_STEP: the slot's entry of the world's first-step gap cache for the NEW scenario - known from the
+                //  parked draw - is requested ahead of the spawn record's loads)
+                if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap && st.act_cache && kDrawAhead)
+                    fge = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)(int)(((uint64_t)sh.draw[lane / A][0].x * (uint64_t)cold.n_scn) >> 32) * A + a));
                 respawn_lane<A, kDrawAhead>(cfg, cold, e, a, ag, er, cx, false, sh.draw[lane / A][0], sh.draw[lane / A][1],
                                             kDrawAhead ? sh.ego_next[lane / A] : nullptr);
                 respawned = true;                                             // (its second route target: left to the next launch)
             }
+            if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && w.first_gap && st.act_cache && kDrawAhead) {
+                // TDE_F_NPC_FIRST_STEP: the new episode's first NPC actions, here, so that the next launch finds them stored like any
+                // others: min(cached G1, ONE exact test against the ego's drawn start) -> npc_act_of_gap on the spawn state the
+                // lane has just loaded (rows of the re-spawned slots in buffer 1, free behind barrier B).  An entry missing
+                // (tde_first_gaps not run for this configuration): the key is stored invalid and the next launch's prologue runs
+                // the controller.
+                const bool f_npc = respawned && a > 0 && ag.present;
+                const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                float fs = 0.0f, fc = 1.0f;
+                if (respawned) sincos_f32(ag.psi, fs, fc);
+                write_rows(sh, 1, lane, respawned && ag.present, ag, fc, fs, cfg.npc_lane_half);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (this wavefront's own rows)
+                first_ok = npc_first_step<A>(cfg, fge, first_gap_key(act_hash), &sh.a[1][base], &sh.b[1][base], a, ag, fc, fs, f_npc, f_target,
+                                             cx.tgx, cx.tgy, na2, nb2);
+            }
             // The re-spawn path is the tail every launch waits for (1.9 % of the envs finish per step, 7 % of the wavefronts
-            // hold one): the next step's controller is NOT recomputed here for the re-spawned envs - their action-cache
-            // entries are stored invalid and the next launch computes them in its prologue (env_step_trio_kernel, `stored`);
-            // the other envs of the wavefront keep the actions computed above, whose inputs did not change.
+            // hold one): the controller's SWEEP is never repeated here for the re-spawned envs - without the gap cache (or the
+            // flag) their action-cache entries are stored invalid and the next launch computes them in its prologue
+            // (env_step_trio_kernel, `stored`); the other envs of the wavefront keep the actions computed above, whose inputs
+            // did not change.
         }
         if (!valid) return;
         store_agent_dynamic(st, g, ag);
@@ -2472,7 +2700,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
             float2 *ap = reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1);
             ap[a] = make_float2(na2, nb2);
             if (a == 0)     // (re-spawn is per env: the ego lane's flag is the env's)
-                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));
+                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && (!respawned || first_ok)) ? er.episode : -1, act_key_steps(act_hash, er.steps));
         }
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================
@@ -2805,6 +3033,45 @@ __global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_w
         st.scn[e] = er.scn; st.steps[e] = 0; st.target_idx[e] = 1; st.reached[e] = 0; st.episode[e] = er.episode;
         if (st.ep_return) st.ep_return[e] = 0.0;
     }
+}
+
+// tde_first_gaps: the world's first-step gap cache (tde_world.first_gap; npc_first_step above) for one configuration.  One lane per
+// (scenario, slot) in the step kernels' mapping: the scenario's spawn rows go to the LDS tile with the EGO PARKED (absent: its pose is
+// the episode's), every routed NPC runs the controller's own leader-gap sweep over them - the same rows, the same lane state, hence the
+// same gap values as the kernels' sweep at the first step of any episode of that scenario, without the ego's - and takes the minimum
+// with its gap to a stop line that is red at step one.
+template <int A>
+__global__ __launch_bounds__(kBlock) void first_gap_kernel(tde_config cfg, tde_world w, uint32_t key)
+{
+    static_assert(A <= kWave, "a scenario's slots inside one wavefront");
+    __shared__ Tiles<kBlock> t;
+    const uint32_t F = cfg.flags;
+    const int tid = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + tid;
+    const int scn = (int)(g / A), a = (int)(g % A);
+    const bool valid = scn < w.n_scn;
+    const float4 *rec = reinterpret_cast<const float4 *>(w.spawn + (valid ? g : 0));
+    const float4 ss = rec[0], sa = rec[1];
+    const int4 si = reinterpret_cast<const int4 *>(rec)[2], sj = reinterpret_cast<const int4 *>(rec)[3];
+    Agent ag{};
+    ag.x = ss.x; ag.y = ss.y; ag.psi = ss.z; ag.v = ss.w;
+    ag.len = sa.x; ag.wid = sa.y; ag.lr = sa.z; ag.vdes = sa.w;
+    ag.route = (F & TDE_F_NPC) ? si.x : -1; ag.route_wp = si.y;
+    ag.present = valid && sj.y != 0 && a > 0;                   // (slot 0 is the ego: parked)
+    float c0, s0;
+    sincos_f32(ag.psi, s0, c0);
+    write_tile_slot(t.a[tid], t.b[tid], ag.present, ag, c0, s0, cfg.npc_lane_half);
+    tile_sync<A>();
+    const bool has_target = (F & TDE_F_NPC) && ag.present && ag.route >= 0 && ag.route_wp < si.z;
+    const float g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;        // (load_ctx)
+    const int base = tid - a;
+    float gap = npc_gap<A>(cfg, &t.a[base], &t.b[base], a, bit_of_row<A>(a), ag, c0, s0, has_target, g_far);
+    if ((F & TDE_F_TRAFFIC_LIGHTS) && has_target) {
+        const tde_map m = w.maps[reinterpret_cast<const int4 *>(w.scn)[scn].x];
+        const uint32_t red = red_mask(w, m, 1);
+        if (red) gap = fminf(gap, red_line_gap(cfg, w, m, red, ag, c0, s0));
+    }
+    if (valid && a > 0) *reinterpret_cast<uint2 *>(w.first_gap + g) = make_uint2(__float_as_uint(gap), key);
 }
 
 // --- operator-level kernels (SimulatorInterface methods) ------------------------------------------------

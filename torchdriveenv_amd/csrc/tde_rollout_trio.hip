@@ -10,15 +10,17 @@ int launch_rollout_trio(const tde_config *cfg, const tde_world *world, const tde
     const unsigned nb = (unsigned)(((int64_t)st->B * st->A + tde::kWave - 1) / tde::kWave);
     const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
     const bool big = (world->hints & TDE_WORLD_LARGE_GRID) != 0;      // corner classes from the 2-bit class map (tde_abi.h)
+    const uint32_t act_hash = act_cfg_hash(*cfg, *world);             // keys the world's first-step gap cache (tde_first_gap)
+    (void)act_hash;
 #if TDE_ROLLOUT_CONST_ARGS
     {
-        tde::RolloutArgs ra{*cfg, *world, *st, *ro};
+        tde::RolloutArgs ra{*cfg, *world, *st, *ro, act_cfg_hash(*cfg, *world)};
         hipError_t ec = hipMemcpyToSymbolAsync(HIP_SYMBOL(tde::g_rollout_args), &ra, sizeof(ra), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
         if (ec != hipSuccess) return fail("tde_env_rollout (argument block)", ec);
     }
 #define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(0)
 #else
-#define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
+#define TDE_LAUNCH_TRIO2(AA, L, G) tde::env_rollout_trio_kernel<AA, L, G><<<nb, 3 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro, act_hash)
 #endif
 #define TDE_LAUNCH_TRIO(AA)                                                                          \
     if (lights) { if (big) TDE_LAUNCH_TRIO2(AA, true, true); else TDE_LAUNCH_TRIO2(AA, true, false); } \

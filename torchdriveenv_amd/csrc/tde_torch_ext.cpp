@@ -67,7 +67,7 @@ enum { K_ANY = 0, K_AGENT, K_ENV, K_ENV2, K_ENV4, K_ENV8, K_SLOT8, K_ACT };
 const Field kWorldFields[] = {WF(maps, at::kByte), WF(tri, at::kFloat), WF(cell_word, at::kUInt32), WF(cell_tri, at::kFloat),
                               WF(cell_cls2, at::kUInt32), WF(cell_sub, at::kUInt32), WF(cell_coarse, at::kByte), WF(tile_near, at::kUInt32), WF(scn, at::kByte),
                               WF(wp_xy, at::kDouble), WF(spawn, at::kByte), WF(route_xy, at::kFloat), WF(replay_states, at::kFloat),
-                              WF(stoplines, at::kByte), WF(phases, at::kByte)};
+                              WF(stoplines, at::kByte), WF(phases, at::kByte), WF(start_psi, at::kFloat), WF(first_gap, at::kUInt32)};
 #undef WF
 #define SF(n, dt, k, req) {#n, offsetof(tde_state, n), dt, k, req}
 const Field kStateFields[] = {
@@ -135,7 +135,7 @@ class World {
         };
         w.n_maps = geti("n_maps"); w.n_scn = geti("n_scn"); w.NW = geti("NW"); w.A = geti("A");
         w.n_routes = geti("n_routes"); w.RW = geti("RW"); w.n_replay = geti("n_replay"); w.RT = geti("RT");
-        w.hints = geti("hints");
+        w.hints = geti("hints"); w.NH = geti("NH");
         // the tables whose sizes the struct's integers imply
         auto bytes_of = [&](const char *k) { const at::Tensor t = py::cast<at::Tensor>(tensors[k]); return (int64_t)t.numel() * (int64_t)t.element_size(); };
         TORCH_CHECK(w.n_maps >= 1 && w.n_scn >= 1 && w.NW >= 2 && w.A >= 1, "world sizes out of range");
@@ -145,6 +145,8 @@ class World {
         TORCH_CHECK(bytes_of("wp_xy") == (int64_t)w.n_scn * w.NW * 16, "world.wp_xy: expected [n_scn][NW][2] float64");
         TORCH_CHECK(bytes_of("route_xy") >= (int64_t)w.n_routes * w.RW * 8, "world.route_xy: smaller than [n_routes][RW][2] float32");
         TORCH_CHECK(bytes_of("replay_states") >= (int64_t)w.n_replay * w.RT * 16, "world.replay_states: smaller than [n_replay][RT][4] float32");
+        TORCH_CHECK(w.NH >= 0 && bytes_of("start_psi") >= (int64_t)w.n_scn * w.NH * 4, "world.start_psi: smaller than [n_scn][NH] float32");
+        TORCH_CHECK(bytes_of("first_gap") == (int64_t)w.n_scn * w.A * (int64_t)sizeof(tde_first_gap), "world.first_gap: expected n_scn * A * sizeof(tde_first_gap) bytes");
     }
     tde_world w;
     at::Device dev;

@@ -325,6 +325,8 @@ class BatchedWaypointEnv:
             flags |= _abi.F_EGO_ONLY_ATTRS
         if self.world.has_lights:
             flags |= _abi.F_TRAFFIC_LIGHTS
+        if cfg.simulator.npc_first_step:                             # ref gym_env.py:285-294: the NPCs act from step one
+            flags |= _abi.F_NPC_FIRST_STEP
         self.tde_cfg = to_tde_config(cfg, seed, flags)
         self.tde_cfg.env_base = int(env_base)                        # shard of a larger batch: sharding.ShardedBatchedEnv
         self.dworld = self.world.to_device(self.torch_device)

@@ -136,6 +136,14 @@ def env_reset(cfg, dworld, state, mask=None):
                                _lib.current_stream(state.device)), "tde_env_reset")
 
 
+def first_gaps(cfg, dworld):
+    """tde_first_gaps: fill the device world's first-step gap cache for `cfg` now (tde_env_step / tde_env_rollout do it themselves
+    on first use: only needed to choose when the launch happens)"""
+    L = _lib.load()
+    dev = next(iter(dworld.tensors.values())).device
+    _lib.check(_call(dev, L.tde_first_gaps, C.byref(cfg), C.byref(dworld.struct), _lib.current_stream(dev)), "tde_first_gaps")
+
+
 def env_step(cfg, dworld, state, action=None):
     """one timestep of every env.  `action` (float32 [B,2] on the device) is read in place if given, else
     state["action"] is used."""

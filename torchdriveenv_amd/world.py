@@ -377,6 +377,10 @@ class DeviceWorld:
 def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, light_groups=None, near_range=NEAR_RANGE):
     """meshes: list of [n,3,2] triangle arrays; scenarios: list of dicts with keys
          map (int), waypoints [(x,y)...], start_heading (float),
+         start_headings (optional): the lane direction at NH points along the first waypoint segment, entry j at
+           p0 + (j + 0.5) / NH * (p1 - p0) - the heading field the reference samples with find_lanelet_directions at the drawn
+           start point (ref gym_env.py:359-361); every scenario that gives one must give the same NH, the others get their
+           start_heading repeated.  An episode that starts at fraction f of the segment reads entry floor(f * NH)
          agents: list (slots 1..) of dict(state=(x,y,psi,v), attr=(L,W,lr), vdes, route=[(x,y)..] or None,
                                          replay=[(x,y,psi,v)...] or None)
          ego_attr (L,W,lr)
@@ -450,6 +454,10 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, l
     NW = max(2, max(len(s["waypoints"]) for s in scenarios))
     wp_xy = np.zeros((S, NW, 2), np.float64)
     scn = np.zeros(S, _abi.SCN_DTYPE)
+    nhs = {len(sc["start_headings"]) for sc in scenarios if sc.get("start_headings") is not None}
+    assert len(nhs) <= 1 and 0 not in nhs, f"scenarios disagree on the number of start-heading samples: {sorted(nhs)}"
+    NH = nhs.pop() if nhs else 0
+    start_psi = np.zeros((S, max(NH, 1)), np.float32)
     spawn = np.zeros((S, A), _abi.SPAWN_DTYPE)
     spawn["len"], spawn["wid"], spawn["lr"] = 1.0, 1.0, 1.0
     spawn["route"], spawn["replay"] = -1, -1
@@ -463,6 +471,7 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, l
             assert light_groups[s["lights"]]["map"] == s["map"], f"scenario {si}: its light group belongs to another mesh"
             m_of = len(meshes) + s["lights"]
         scn[si] = (m_of, len(w), s["start_heading"], 0)
+        start_psi[si] = s["start_heading"] if s.get("start_headings") is None else np.asarray(s["start_headings"], np.float64)
         ego = spawn[si, 0]
         ego["present"] = 1
         ego["len"], ego["wid"], ego["lr"] = s.get("ego_attr", (5.0, 2.0, 1.9))
@@ -498,8 +507,11 @@ def assemble_world(meshes, scenarios, A, threshold=0.5, cell=0.5, lights=None, l
                   tile_near=np.concatenate(near_all), scn=scn, wp_xy=wp_xy, spawn=spawn, route_xy=route_xy, replay_states=replay_states,
                   stoplines=np.asarray(stop_all, dtype=_abi.STOPLINE_DTYPE) if stop_all
                   else np.zeros(1, _abi.STOPLINE_DTYPE),
-                  phases=np.asarray(phase_all, dtype=_abi.PHASE_DTYPE) if phase_all else np.zeros(1, _abi.PHASE_DTYPE))
+                  phases=np.asarray(phase_all, dtype=_abi.PHASE_DTYPE) if phase_all else np.zeros(1, _abi.PHASE_DTYPE),
+                  start_psi=start_psi,
+                  # the first-step gap cache (tde_first_gap [S][A]): scratch of the device copy, all entries invalid
+                  first_gap=np.zeros((S * A, 2), np.uint32))
     large = bool((maps["nx"].astype(np.int64) * maps["ny"]).max() > LARGE_GRID_CELLS)
     ints = dict(n_maps=len(maps), n_scn=S, NW=NW, A=A, n_routes=len(routes), RW=RW, n_replay=len(replays), RT=RT,
-                hints=_abi.WORLD_LARGE_GRID if large else 0)
+                hints=_abi.WORLD_LARGE_GRID if large else 0, NH=NH)
     return World(arrays, ints, threshold)
