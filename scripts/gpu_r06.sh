@@ -23,6 +23,12 @@ for what in "$@"; do
       for opt in "--coast" ""; do
         echo "== step $opt" >> $O/ab_step_bisect.txt; python scripts/ab_step.py $opt $LIBS 2>&1 | grep -v amdgpu.ids | tail -5 >> $O/ab_step_bisect.txt
       done; cat $O/ab_step_bisect.txt;;
+    prof:*) LIBS=$(echo "${what#prof:}" | tr ':' ' ')
+      for L in $LIBS; do for C in 1 0; do
+        T=$(basename $L .so)_coast$C
+        TDE_HIP_LIB=$PWD/$L TDE_COAST=$C rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o st -- python3 scripts/run_step.py 2000 > $O/prof_$T.log 2>&1
+        echo "== $T"; grep -h "env_step_trio\|first_gap" $O/prof_$T/*/st_kernel_stats.csv 2>/dev/null | cut -c1-200 || find $O/prof_$T -name "*stats*" | head
+      done; done; find $O -name "*.csv" -size +2M -delete;;
     bench) python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json;;
     *) echo "unknown phase $what";;
   esac

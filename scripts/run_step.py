@@ -15,6 +15,8 @@ dev = torch.device("cuda:0")
 world = synthetic_town(n_scn=256, A=A, seed=0) if TOWN else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
+if os.environ.get("TDE_COAST") == "1":                  # the opt-out of TDE_F_NPC_FIRST_STEP: the NPCs coast through an episode's first step
+    cfg.flags &= ~_abi.F_NPC_FIRST_STEP
 _lib.kernel_override(step=kern if kern in ("solo", "trio") else None)
 FULL = os.environ.get("TDE_STEP_OUTPUTS", "")             # "" bare, "full" = info / done bits / episode stats / obs, "mag" = + magnitudes
 st = EnvState(B, A, device=dev, with_info=bool(FULL), with_obs=bool(FULL), with_magnitudes=(FULL == "mag"))

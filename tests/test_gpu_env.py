@@ -386,3 +386,111 @@ def test_step_is_capturable_in_a_hip_graph(small_world, obs_mode, frame_stack):
     for k in ("x", "y", "psi", "v", "steps", "episode", "scn", "target_idx"):
         assert torch.equal(eager.state[k], graphed.state[k]), k
     assert int(eager.state["episode"].max()) >= 2            # re-spawns happened inside the replays
+
+
+def _validation_lights_and_headings(val):
+    """per location of the validation suite: stop lines across every scenario's route at its second and fourth waypoint (two lights,
+    alternating red), and a lane-direction field that bends with the position"""
+    import math
+
+    lights = {}
+    for loc, wps in zip(val.locations, val.waypoint_suite):
+        d = lights.setdefault(loc, dict(stoplines=[], phases=[(25, [0]), (10, []), (25, [1]), (10, [])]))
+        for n, light in ((1, 0), (3, 1)):
+            if n < len(wps):
+                p, q = wps[n - 1], wps[n]
+                d["stoplines"].append((q[0], q[1], math.atan2(q[1] - p[1], q[0] - p[0]), 2.0, 9.0, light))
+
+    def field(loc, x, y):
+        i = val.locations.index(loc)
+        p, q = val.waypoint_suite[i][0], val.waypoint_suite[i][1]
+        return math.atan2(q[1] - p[1], q[0] - p[0]) + 0.004 * (x - p[0]) - 0.003 * (y - p[1])
+    return lights, field
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
+def test_validation_worlds_with_traffic_lights_and_start_headings_hip_vs_oracle(case, tmp_path):
+    """The reference's five validation cases with what its map config adds to every env (ref gym_env.py:181-189, 290-291, 359-361, 415,
+    429): stop lines + a light cycle (`traffic_lights=`) and a lane-direction field for the start heading (`start_headings=`), through
+    world_from_waypoint_suite -> the HIP step with TDE_F_TRAFFIC_LIGHTS against the oracle on the same world: every state array and
+    output bit for bit over 200 steps of 64 envs with re-spawns (start headings read from the table every time), red-line violations
+    terminating episodes, the NPCs stopping at red lines, the birdview with the painted lines pixel for pixel."""
+    from tests.golden_util import write_validation_suite_yaml
+    from torchdriveenv_amd import ops
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+    from torchdriveenv_amd.loaders import load_waypoint_suite_data
+
+    val = load_waypoint_suite_data(write_validation_suite_yaml(str(tmp_path / "validation_cases.yml")))
+    lights, field = _validation_lights_and_headings(val)
+    one = WaypointSuite(locations=val.locations[case:case + 1], waypoint_suite=val.waypoint_suite[case:case + 1],
+                        scenarios=val.scenarios[case:case + 1], car_sequence_suite=val.car_sequence_suite[case:case + 1])
+    world = world_from_waypoint_suite(one, agents_per_env=8, traffic_lights=lights, start_headings=field)
+    assert world.has_lights and world.ints["NH"] == 16 and world.arrays["maps"]["n_stop"].max() >= 1
+    B, A, DEV = 64, 8, "cuda:0"
+    cfg = _abi.default_config(seed=15 + case, distance_cutoff=0.25, max_steps=60, flags=_abi.F_ALL | _abi.F_TRAFFIC_LIGHTS)
+    dw = world.to_device(DEV)
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    assert np.array_equal(hs["psi"].view(np.uint32), ds["psi"].cpu().numpy().view(np.uint32))
+    assert len(np.unique(hs["psi"][::A])) > B // 2                                  # table entry + noise
+    rng = np.random.default_rng(case)
+    n_tl = 0
+    for t in range(200):
+        act = np.stack([rng.uniform(0.0, 1.0, B), rng.normal(0.0, 0.04, B).clip(-0.3, 0.3)], -1).astype(np.float32)
+        hs["action"][...] = act
+        ds["action"].copy_(torch.from_numpy(act).to(DEV))
+        oracle.env_step(cfg, world, hs)
+        ops.env_step(cfg, dw, ds)
+        n_tl += int(hs["tl_violation"].sum())
+        if t % 40 == 39 or t == 199:
+            h, d = hs.host(), ds.host()
+            for k in h:
+                if k != "action":
+                    assert np.array_equal(h[k].view(np.uint8), d[k].view(np.uint8)), (case, t, k)
+    assert hs["episode"].max() >= 3 and n_tl > 0                                    # re-spawns and red-line violations happened
+    want = oracle.render_ego(cfg, world, hs)
+    got = ops.render_ego(cfg, dw, ds).cpu().numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_make_with_traffic_lights_terminates_at_a_red_line_and_reports_the_violation(tmp_path):
+    """The reference-shaped surface: make(cfg, data, road_meshes=, traffic_lights=, start_headings=) (what gym.make('torchdriveenv-v0')
+    returns, ref __init__.py:10) on validation case 0 with its map's stop lines: an ego driven straight ahead crosses the first line
+    while its light is red -> terminated, info['traffic_light_violation'] > 0 (ref gym_env.py:415, 429), at the very step the oracle
+    says, with the oracle's rewards; with the light green over that stretch the same drive passes the line."""
+    from tests.golden_util import write_validation_suite_yaml
+    from torchdriveenv_amd.env import corridor_mesh, make, world_from_waypoint_suite
+    from torchdriveenv_amd.loaders import load_waypoint_suite_data
+
+    val = load_waypoint_suite_data(write_validation_suite_yaml(str(tmp_path / "validation_cases.yml")))
+    lights, field = _validation_lights_and_headings(val)
+    one = WaypointSuite(locations=val.locations[:1], waypoint_suite=val.waypoint_suite[:1], scenarios=val.scenarios[:1],
+                        car_sequence_suite=val.car_sequence_suite[:1])
+    mesh = {val.locations[0]: corridor_mesh([one.waypoint_suite[0]], width=14.0)}
+    ecfg = EnvConfig(seed=11, distance_cutoff=0.25, use_background_traffic=False, device="cuda:0")
+    kw = dict(agents_per_env=8, road_meshes=mesh, start_headings=field)
+    results = {}
+    for name, spec in (("red", lights), ("green", {k: dict(v, phases=[(200, [])]) for k, v in lights.items()})):
+        env = make(ecfg, one, traffic_lights=spec, **kw)
+        inner = env.env._env
+        assert inner.world.has_lights and (inner.tde_cfg.flags & _abi.F_TRAFFIC_LIGHTS) and (inner.tde_cfg.flags & _abi.F_NPC_FIRST_STEP)
+        world = world_from_waypoint_suite(one, agents_per_env=8, traffic_lights=spec, road_meshes=mesh, start_headings=field)
+        hs = EnvState(1, 8, with_magnitudes=True)
+        oracle.env_reset(inner.tde_cfg, world, hs)
+        obs, _ = env.reset()
+        assert obs.shape == (3, 64, 64) and np.float32(inner.state["psi"][0].item()) == hs["psi"][0]
+        saw = []
+        for t in range(80):
+            a = np.asarray([1.0, 0.0], np.float32)
+            hs["action"][...] = a[None]
+            oracle.env_step(inner.tde_cfg, world, hs)
+            obs, r, term, trunc, info = env.step(a)
+            assert np.float32(r) == hs["reward"][0] and term == bool(hs["terminated"][0]) and float(info["traffic_light_violation"]) == float(hs["tl_violation"][0])
+            saw.append(float(info["traffic_light_violation"]))
+            if term or trunc:
+                break
+        results[name] = (t, term, saw[-1])
+    t_red, term_red, tl_red = results["red"]
+    assert term_red and tl_red > 0 and t_red < 79                                   # stopped by the red line
+    assert results["green"][2] == 0.0 and results["green"][0] > t_red              # the same drive passes it on green

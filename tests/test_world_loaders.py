@@ -419,3 +419,122 @@ def test_cached_world_is_built_once_by_racing_processes(tmp_path):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == ["built", "loaded", "loaded"]
     assert len({r[1:] for r in res}) == 1
+
+
+def _line_across(p, q, length=2.0, width=9.0, light=0):
+    """a stop line centred at q across the travel direction p -> q: (x, y, psi, length, width, light)"""
+    return (q[0], q[1], math.atan2(q[1] - p[1], q[0] - p[0]), length, width, light)
+
+
+def test_traffic_lights_hook_groups_renumbers_and_shares(tmp_path):
+    """world_from_waypoint_suite(traffic_lights=...) (ref gym_env.py:181-189: stop lines + light controller of the map config):
+    a small location becomes ONE light group per map, a location with more than 32 lights is cut into per-scenario neighbourhoods
+    of at most 32 lights re-numbered from 0, identical neighbourhoods share a descriptor, red masks follow the re-numbering, and
+    traffic_lights_from_controller builds the description from stop-line objects + a controller's state sequence"""
+    from torchdriveenv_amd.env import MAX_GROUP_LIGHTS, traffic_lights_from_controller, world_from_waypoint_suite
+
+    # "Big": 40 lights on a 2 km street, one stop line each, every second one red in phase 0, the others in phase 1
+    big_lines = [(50.0 * i, 0.0, 0.0, 2.0, 9.0, i) for i in range(40)]
+    big = dict(stoplines=big_lines, phases=[(20, list(range(0, 40, 2))), (30, list(range(1, 40, 2)))])
+    small = traffic_lights_from_controller(
+        stoplines=[dict(actor_id=7, agent_type="traffic_light", x=30.0, y=100.0, orientation=0.0, length=2.0, width=9.0),
+                   dict(actor_id=9, agent_type="traffic_light", x=60.0, y=100.0, orientation=0.0, length=2.0, width=9.0),
+                   dict(actor_id=11, agent_type="stop_sign", x=90.0, y=100.0, orientation=0.0, length=2.0, width=9.0)],
+        light_states=[{7: "red", 9: "green"}, {7: "green", 9: "yellow"}, {7: "green", 9: "red"}], durations=[3.0, 0.5, 2.04])
+    assert small["actor_ids"] == [7, 9] and len(small["stoplines"]) == 2 and small["phases"] == [(30, [0]), (5, []), (20, [1])]
+    wps = lambda x0, y0: [[x0 + 14.0 * k, y0] for k in range(6)]                     # noqa: E731
+    data = WaypointSuite(locations=["Big", "Big", "Big", "Small", "Small", "None"],
+                         waypoint_suite=[wps(0, 0), wps(5, 0), wps(1500, 0), wps(0, 100), wps(10, 100), wps(0, 300)],
+                         car_sequence_suite=[None] * 6, scenarios=[None] * 6)
+    lights = {"Big": big, "Small": small}
+    world = world_from_waypoint_suite(data, agents_per_env=4, traffic_lights=lights, light_radius=400.0)
+    maps, scn = world.arrays["maps"], world.arrays["scn"]
+    n_mesh = 6                                                                        # no road_meshes: a corridor mesh per scenario
+    assert world.has_lights and world.ints["n_maps"] == n_mesh + 5                    # 3 Big neighbourhoods (on 3 meshes) + 2 Small
+    assert scn["map"][5] == 5                                                         # "None": no lights, its own mesh descriptor
+    for si in range(5):
+        d = maps[scn["map"][si]]
+        assert scn["map"][si] >= n_mesh and d["cycle_steps"] == (50 if si < 3 else 55) and d["cell_base"] == maps[si]["cell_base"]
+    st = world.arrays["stoplines"]
+    for si, x0 in ((0, 0.0), (1, 5.0), (2, 1500.0)):
+        d = maps[scn["map"][si]]
+        mine = st[d["stop_base"]:d["stop_base"] + d["n_stop"]]
+        assert 1 <= d["n_stop"] <= MAX_GROUP_LIGHTS and mine["light"].max() == d["n_stop"] - 1 and mine["light"].min() == 0
+        assert (np.abs(mine["x"] - (x0 + 35.0)).max() <= 400.0 + 35.0 + 1e-3)          # within reach of the scenario's waypoints
+        ph = world.arrays["phases"][d["phase_base"]:d["phase_base"] + d["n_phase"]]
+        assert list(ph["end_step"]) == [20, 50]
+        # the re-numbered masks: local light n is global light round(x / 50) - red in phase 0 iff that is even
+        glob = np.round(mine["x"] / 50.0).astype(int)
+        want0 = sum(1 << int(n) for n, g in zip(mine["light"], glob) if g % 2 == 0)
+        assert ph["red_mask"][0] == want0 and ph["red_mask"][1] == ((1 << int(d["n_stop"])) - 1) ^ want0
+    small_d = [maps[scn["map"][si]] for si in (3, 4)]
+    assert all(d["n_stop"] == 2 and d["n_phase"] == 3 for d in small_d)
+    # a per-location mesh: the two Small scenarios then share ONE mesh and ONE light group
+    mesh = {"Small": np.asarray([[[-20, 90], [120, 90], [120, 110]], [[-20, 90], [120, 110], [-20, 110]]], np.float64)}
+    w2 = world_from_waypoint_suite(WaypointSuite(locations=["Small", "Small"], waypoint_suite=[wps(0, 100), wps(10, 100)],
+                                                 car_sequence_suite=[None, None], scenarios=[None, None]),
+                                   agents_per_env=4, traffic_lights=lambda loc: lights.get(loc), road_meshes=mesh)
+    assert w2.ints["n_maps"] == 2 and list(w2.arrays["scn"]["map"]) == [1, 1] and w2.arrays["maps"]["n_stop"][1] == 2
+    with pytest.raises(ValueError):
+        world_from_waypoint_suite(data, agents_per_env=4, traffic_lights={"Big": dict(stoplines=[(0, 0, 0, 2, 9, 0)], phases=[])})
+
+
+def _normal_f32(ra, rb):
+    """numpy restatement of the reset's Gaussian (oracle tde_normal / device normal_f32): Box-Muller in fp32 on the shared log / sincos"""
+    from oracle import oracle
+
+    f = np.float32
+    u1 = (f(ra >> 8) + f(0.5)) * f(1.0 / 16777216.0)
+    u2 = f(rb >> 8) * f(1.0 / 16777216.0)
+    s, c = oracle.sincosf(np.asarray([f(6.28318530717958647692) * u2], np.float32))
+    lg = f(oracle.lib().tde_oracle_logf(float(u1)))
+    return f(np.sqrt(f(-2.0) * lg)) * f(c[0])
+
+
+def test_start_headings_hook_fills_the_table_and_the_reset_reads_it():
+    """world_from_waypoint_suite(start_headings=...) (ref gym_env.py:357-361: start_orientation = find_lanelet_directions(lanelet_map,
+    x, y)[0] at the drawn start point + normal(0, 0.1)): the field is sampled at NH points along every scenario's first segment; an
+    episode that starts at fraction f reads entry floor(f * NH).  The oracle's reset against a numpy restatement of the draw."""
+    import ctypes as C
+
+    from oracle import oracle
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+    from torchdriveenv_amd.state import EnvState
+
+    oracle.lib().tde_oracle_logf.restype = C.c_float
+    oracle.lib().tde_oracle_logf.argtypes = [C.c_float]
+    field = lambda loc, x, y: (0.3 if loc == "A" else -1.1) + 0.01 * x - 0.02 * y          # noqa: E731
+    data = WaypointSuite(locations=["A", "B", "A"], waypoint_suite=[[[0, 0], [14, 3], [28, 3]], [[5, 5], [5, 19], [5, 33]], [[-3, 2], [9, -6], [20, -6]]],
+                         car_sequence_suite=[None] * 3, scenarios=[None] * 3)
+    NH = 8
+    world = world_from_waypoint_suite(data, agents_per_env=2, start_headings=field, heading_samples=NH)
+    assert world.ints["NH"] == NH and world.arrays["start_psi"].shape == (3, NH)
+    for si, loc in enumerate(data.locations):
+        p0, p1 = np.asarray(data.waypoint_suite[si][0], float), np.asarray(data.waypoint_suite[si][1], float)
+        want = [field(loc, *(p0 + (j + 0.5) / NH * (p1 - p0))) for j in range(NH)]
+        assert np.array_equal(world.arrays["start_psi"][si], np.asarray(want, np.float32))
+    # the dict form, with one location left to its segment direction
+    w2 = world_from_waypoint_suite(data, agents_per_env=2, start_headings={"A": lambda x, y: 0.25}, heading_samples=4)
+    seg_b = math.atan2(19 - 5, 0.0)
+    assert np.array_equal(w2.arrays["start_psi"], np.asarray([[0.25] * 4, [seg_b] * 4, [0.25] * 4], np.float32))
+    assert world_from_waypoint_suite(data, agents_per_env=2).ints["NH"] == 0
+    # reset: every env's start pose from the table
+    cfg = _abi.default_config(seed=77)
+    B = 256
+    hs = EnvState(B, 2)
+    oracle.env_reset(cfg, world, hs)
+    oracle.env_reset(cfg, world, hs)                              # (second episode: the counters move)
+    seen = set()
+    for e in range(B):
+        r0 = oracle.philox(77, e, 1, 0, 0x7DE)
+        r1 = oracle.philox(77, e, 1, 1, 0x7DE)
+        scn = (int(r0[0]) * 3) >> 32
+        assert scn == hs["scn"][e]
+        f = (int(r0[1]) >> 8) / 16777216.0
+        idx = int(f * NH)
+        seen.add((scn, idx))
+        wp = np.asarray(data.waypoint_suite[scn], np.float64)
+        assert hs["x"][2 * e] == np.float32(wp[0, 0] + f * (wp[1, 0] - wp[0, 0])) and hs["y"][2 * e] == np.float32(wp[0, 1] + f * (wp[1, 1] - wp[0, 1]))
+        want = np.float32(float(world.arrays["start_psi"][scn, idx]) + float(_normal_f32(int(r1[2]), int(r1[3]))) * 0.1)
+        assert hs["psi"][2 * e] == want, (e, scn, idx)
+    assert len(seen) > 15                                          # the table's entries were really exercised

@@ -756,6 +756,7 @@ TDE_DEV void npc_action(const tde_config &cfg, const float4 *ra, const float4 *r
 #ifndef TDE_FIRST_GAP
 #define TDE_FIRST_GAP 1             // 0: the kernels ignore the first-step gap cache (A/B; same results)
 #endif
+constexpr uint32_t kGapForm = 0x5bd1e995u;      // act-cache key domain of "first-step gaps forwarded by the re-spawning launch" (step kernel)
 TDE_DEV uint32_t first_gap_key(uint32_t act_hash) { return act_hash | 1u; }     // (never 0: zero-initialised entries are invalid)
 
 // The first-step action (na, nb) of the lanes with `fresh_npc` (NPC slots of an env at k == 1) from their cache entries `ent`; the
@@ -1546,6 +1547,10 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = drive, 1 = judge
     if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0ull; }
     const uint32_t F = cfg.flags;
+    // The first-step gap cache pays where the controller's second pass walks stop lines (interleaved A/B at 8192 x 16, us per step,
+    // cache / whole controller: with lights 3.92 / 4.13; without 2.935 / 2.905 - there the cheap path's code costs the loop more than
+    // the re-spawned envs' second sweep does: profiles/r06_first_step_matrix.txt)
+    constexpr bool kGapCache = TDE_FIRST_GAP != 0 && LIGHTS;
     const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;   // the NPC controller acts on an episode's first step too
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
@@ -1645,7 +1650,7 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 uint2 fg_ent = make_uint2(0u, 0u);           // the lane's entry of the world's first-step gap cache
                 if (fresh) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
-                    if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap)    // (in flight across the table look-ups of load_ctx)
+                    if (kGapCache && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap)    // (in flight across the table look-ups of load_ctx)
                         fg_ent = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     redc.invalidate();
@@ -1657,10 +1662,13 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                     // TDE_F_NPC_FIRST_STEP: the re-spawned lanes' first actions, from the world's first-step gap cache and ONE exact
                     // test against the ego's new row (the second pass applies them; the other lanes keep the first pass's) - or, an
                     // entry missing, by the controller itself in the second pass
-                    const bool f_npc = fresh && a > 0 && ag.present;
-                    const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-                    again = !npc_first_step<A>(cfg, fg_ent, first_gap_key(act_hash), &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, f_npc, f_target,
-                                               cx.tgx, cx.tgy, na, nb);
+                    again = true;
+                    if constexpr (kGapCache) {
+                        const bool f_npc = fresh && a > 0 && ag.present;
+                        const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                        again = !npc_first_step<A>(cfg, fg_ent, first_gap_key(act_hash), &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, f_npc, f_target,
+                                                   cx.tgx, cx.tgy, na, nb);
+                    }
                 }
             }
             ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
@@ -2075,6 +2083,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
     }
     const uint32_t F = cfg.flags;
+    // The first-step gap cache pays where the controller's second pass walks stop lines (interleaved A/B at 8192 x 16, us per step,
+    // cache / whole controller: with lights 3.92 / 4.13; without 2.935 / 2.905 - there the cheap path's code costs the loop more than
+    // the re-spawned envs' second sweep does: profiles/r06_first_step_matrix.txt)
+    constexpr bool kGapCache = TDE_FIRST_GAP != 0 && LIGHTS;
     const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;   // the NPC controller acts on an episode's first step too
     const int64_t g = (int64_t)blockIdx.x * kWave + lane;
     const int e = (int)(g / A), a = (int)(g % A);
@@ -2177,7 +2189,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 uint2 fg_ent = make_uint2(0u, 0u);           // the lane's entry of the world's first-step gap cache
                 if (fresh) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
-                    if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap)    // (in flight across the table look-ups of load_ctx)
+                    if (kGapCache && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap)    // (in flight across the table look-ups of load_ctx)
                         fg_ent = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     redc.invalidate();
@@ -2189,10 +2201,13 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     // TDE_F_NPC_FIRST_STEP: the re-spawned lanes' first actions, from the world's first-step gap cache and ONE exact
                     // test against the ego's new row (the second pass applies them; the other lanes keep the first pass's) - or, an
                     // entry missing, by the controller itself in the second pass
-                    const bool f_npc = fresh && a > 0 && ag.present;
-                    const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-                    again = !npc_first_step<A>(cfg, fg_ent, first_gap_key(act_hash), &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, f_npc, f_target,
-                                               cx.tgx, cx.tgy, na, nb);
+                    again = true;
+                    if constexpr (kGapCache) {
+                        const bool f_npc = fresh && a > 0 && ag.present;
+                        const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+                        again = !npc_first_step<A>(cfg, fg_ent, first_gap_key(act_hash), &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, f_npc, f_target,
+                                                   cx.tgx, cx.tgy, na, nb);
+                    }
                 }
             }
             ag.x = nx; ag.y = ny; ag.psi = npsi; ag.v = nv; ag.route_wp = nwp;
@@ -2607,15 +2622,24 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         };
         if (F & TDE_F_NPC) {
             // (k == 1, the first step of an episode: without TDE_F_NPC_FIRST_STEP the NPCs coast - nothing to look up or compute;
-            //  with it the launch that re-spawned the env stored its first actions like any others - from the world's first-step gap
-            //  cache, see the re-spawn below - or, without entries for its scenario, stored the key invalid: computed here)
+            //  with it the launch that re-spawned the env stored the key invalid - or forwarded gaps, below: computed here)
             const bool stored = !npc || (k == 1 && !first_acts) || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
+            // first step with TDE_F_NPC_FIRST_STEP: the launch that re-spawned the env forwarded its slots' entries of the world's
+            // first-step gap cache in place of actions (key domain kGapForm; npc_first_step)
+            const bool gap_ok = TDE_FIRST_GAP && first_acts && k == 1 && akey.x == er.episode && akey.y == act_key_steps(act_hash ^ kGapForm, er.steps) &&
+                                (!has_target || __float_as_uint(ac.y) == first_gap_key(act_hash));
             if (__ballot(!stored)) {
                 sincos_f32(ag.psi, s0, c0);
                 write_rows(sh, 1, lane, live, ag, c0, s0, cfg.npc_lane_half);    // pre-step rows: what the controller reads
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wavefront's own rows are in LDS
-                float na, nb;
-                controller(1, true, na, nb);
+                float na = ac.x, nb = ac.y;
+                if (__ballot(!stored && !gap_ok)) {
+                    controller(1, true, na, nb);                                 // (every lane of the wavefront: same values as stored ones)
+                } else {
+                    // only first steps with forwarded gaps are missing: min(G1, the exact test against the ego's row) -> the action
+                    npc_first_step<A>(cfg, make_uint2(__float_as_uint(ac.x), __float_as_uint(ac.y)), first_gap_key(act_hash), &sh.a[1][base],
+                                      &sh.b[1][base], a, ag, c0, s0, !stored, has_target, cx.tgx, cx.tgy, na, nb);
+                }
                 if (npc) { acc = na; beta = nb; }
             } else if (npc) {
                 acc = ac.x; beta = ac.y;
@@ -2655,36 +2679,21 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         unsigned long long term_m, trunc_m;
         const unsigned long long dn = done_of(k, term_m, trunc_m);
         bool respawned = false;
-        bool first_ok = false;                               // the re-spawned envs' first actions are in (na2, nb2) (wave-uniform)
-        uint2 fge = make_uint2(0u, 0u);
         if (dn) {
 #ifdef TDE_EXP_NO_D_RESPAWN           // timing experiment (WRONG results)
             if (false) {
 #else
             if (mask_bit(dn, base) && valid) {
 #endif
-                // (TDE_F_NPC_FIRST_STEP: the slot's entry of the world's first-step gap cache for the NEW scenario - known from the
-                //  parked draw - is requested ahead of the spawn record's loads)
-                if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap && st.act_cache && kDrawAhead)
-                    fge = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)(int)(((uint64_t)sh.draw[lane / A][0].x * (uint64_t)cold.n_scn) >> 32) * A + a));
                 respawn_lane<A, kDrawAhead>(cfg, cold, e, a, ag, er, cx, false, sh.draw[lane / A][0], sh.draw[lane / A][1],
                                             kDrawAhead ? sh.ego_next[lane / A] : nullptr);
                 respawned = true;                                             // (its second route target: left to the next launch)
-            }
-            if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && w.first_gap && st.act_cache && kDrawAhead) {
-                // TDE_F_NPC_FIRST_STEP: the new episode's first NPC actions, here, so that the next launch finds them stored like any
-                // others: min(cached G1, ONE exact test against the ego's drawn start) -> npc_act_of_gap on the spawn state the
-                // lane has just loaded (rows of the re-spawned slots in buffer 1, free behind barrier B).  An entry missing
-                // (tde_first_gaps not run for this configuration): the key is stored invalid and the next launch's prologue runs
-                // the controller.
-                const bool f_npc = respawned && a > 0 && ag.present;
-                const bool f_target = f_npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-                float fs = 0.0f, fc = 1.0f;
-                if (respawned) sincos_f32(ag.psi, fs, fc);
-                write_rows(sh, 1, lane, respawned && ag.present, ag, fc, fs, cfg.npc_lane_half);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (this wavefront's own rows)
-                first_ok = npc_first_step<A>(cfg, fge, first_gap_key(act_hash), &sh.a[1][base], &sh.b[1][base], a, ag, fc, fs, f_npc, f_target,
-                                             cx.tgx, cx.tgy, na2, nb2);
+                // TDE_F_NPC_FIRST_STEP: the new episode's first actions are the next launch's (its prologue holds the ego's start);
+                // what it needs of the scenario - this slot's entry of the world's first-step gap cache - travels in the action slot
+                if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap && st.act_cache) {
+                    const uint2 fe = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
+                    na2 = __uint_as_float(fe.x); nb2 = __uint_as_float(fe.y);
+                }
             }
             // The re-spawn path is the tail every launch waits for (1.9 % of the envs finish per step, 7 % of the wavefronts
             // hold one): the controller's SWEEP is never repeated here for the re-spawned envs - without the gap cache (or the
@@ -2699,8 +2708,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
         if (st.act_cache) {
             float2 *ap = reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1);
             ap[a] = make_float2(na2, nb2);
-            if (a == 0)     // (re-spawn is per env: the ego lane's flag is the env's)
-                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && (!respawned || first_ok)) ? er.episode : -1, act_key_steps(act_hash, er.steps));
+            if (a == 0) {   // (re-spawn is per env: the ego lane's flag is the env's)
+                const bool fwd = TDE_FIRST_GAP && respawned && first_acts && (F & TDE_F_NPC) && w.first_gap;     // the slots hold forwarded gaps
+                reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && (!respawned || fwd)) ? er.episode : -1,
+                                                            act_key_steps(fwd ? act_hash ^ kGapForm : act_hash, er.steps));
+            }
         }
     } else if (role == 1) {
         // ===================== judge C: collision, reward, outputs =====================

@@ -95,8 +95,121 @@ def mesh_from_verts_faces(verts, faces):
     return v[f]
 
 
+def traffic_lights_from_controller(stoplines, light_states, durations, dt=0.1):
+    """The per-location traffic-light description `traffic_lights=` takes, from the pieces the reference's map config holds
+    (ref gym_env.py:181-189: `map_cfg.stoplines` with agent_type 'traffic_light' and `map_cfg.traffic_light_controller`):
+
+      stoplines     iterable of stop lines: objects / dicts with actor_id, x, y, orientation (or psi), length, width
+                    (an `agent_type` other than 'traffic_light' - stop / yield signs - is skipped, as at gym_env.py:183)
+      light_states  the controller's cycle: one mapping actor_id -> 'red' | 'yellow' | 'green' (anything but 'red' lets traffic
+                    pass: compute_traffic_lights_violations only counts red lights) per phase
+      durations     seconds each phase lasts (rounded to whole steps of `dt`, at least one)
+
+    -> dict(stoplines=[(x, y, psi, length, width, light)], phases=[(n_steps, [red lights])], actor_ids=[...]) with `light` the
+    index of the line's actor in actor_ids."""
+    def get(o, *names, default=None):
+        for n in names:
+            v = o.get(n) if isinstance(o, dict) else getattr(o, n, None)
+            if v is not None:
+                return v
+        return default
+
+    ids, lines = [], []
+    for sl in stoplines:
+        if get(sl, "agent_type", default="traffic_light") != "traffic_light":
+            continue
+        aid = get(sl, "actor_id")
+        if aid not in ids:
+            ids.append(aid)
+        lines.append((float(get(sl, "x")), float(get(sl, "y")), float(get(sl, "orientation", "psi", default=0.0)),
+                      float(get(sl, "length", default=1.0)), float(get(sl, "width", default=3.5)), ids.index(aid)))
+    assert len(light_states) == len(durations) and len(durations) >= 1, "one duration per phase of the light cycle"
+    phases = []
+    for states, sec in zip(light_states, durations):
+        red = sorted(ids.index(a) for a, st in states.items() if a in ids and str(st).lower() == "red")
+        phases.append((max(1, int(round(float(sec) / dt))), red))
+    return dict(stoplines=lines, phases=phases, actor_ids=ids)
+
+
+def _lights_of_location(traffic_lights, loc):
+    """the caller's traffic lights of a location as dict(stoplines=[(x, y, psi, length, width, light)], phases=[(n_steps, [red])])
+    with validated shapes, or None"""
+    if traffic_lights is None or loc is None:
+        return None
+    spec = traffic_lights(loc) if callable(traffic_lights) else traffic_lights.get(loc)
+    if spec is None or not spec.get("stoplines"):
+        return None
+    lines = [tuple(float(t) for t in sl[:5]) + (int(sl[5]),) for sl in spec["stoplines"]]
+    phases = [(int(n), sorted(int(i) for i in red)) for n, red in spec["phases"]]
+    if not phases or min(n for n, _ in phases) < 1 or min(sl[5] for sl in lines) < 0 or not np.isfinite(np.asarray([sl[:5] for sl in lines])).all():
+        raise ValueError(f"traffic lights of location {loc!r}: stop lines are (x, y, psi, length, width, light >= 0), phases (n_steps >= 1, "
+                         f"[red lights]) and there is at least one phase")
+    return dict(stoplines=lines, phases=phases)
+
+
+MAX_GROUP_LIGHTS = 32        # a light is a bit of a 32-bit mask (tde_light_phase.red_mask)
+
+
+def _light_group(spec, polylines, radius):
+    """The stop lines of `spec` a scenario sees: all of them when the location is small (at most 32 lights), else those within
+    `radius` metres of the scenario's polylines - at most 32 distinct lights, the nearest ones (a light is a bit of a 32-bit mask
+    and the kernels walk every stop line of a scenario's map descriptor) - with the lights re-numbered 0 .. n-1 inside the group.
+    -> (sorted tuple of the kept stop-line indices, dict(stoplines, phases)) or (None, None) when nothing is in reach."""
+    lines = spec["stoplines"]
+    lights = sorted({sl[5] for sl in lines})
+    keep = list(range(len(lines)))
+    if len(lights) > MAX_GROUP_LIGHTS:
+        pts = np.concatenate([np.asarray(pl, np.float64).reshape(-1, 2) for pl in polylines], 0)
+        ctr = np.asarray([sl[:2] for sl in lines], np.float64)
+        d = np.sqrt(((ctr[:, None, :] - pts[None, :, :]) ** 2).sum(-1)).min(1)
+        near = [i for i in range(len(lines)) if d[i] <= radius]
+        by_light = {}
+        for i in near:
+            by_light[lines[i][5]] = min(by_light.get(lines[i][5], np.inf), d[i])
+        if len(by_light) > MAX_GROUP_LIGHTS:
+            order = sorted(by_light, key=lambda g: (by_light[g], g))
+            warnings.warn(f"{len(by_light)} traffic lights within {radius:g} m of a scenario: the nearest {MAX_GROUP_LIGHTS} are kept "
+                          f"(lower light_radius to choose differently)", stacklevel=3)
+            by_light = {g: by_light[g] for g in order[:MAX_GROUP_LIGHTS]}
+        keep = [i for i in near if lines[i][5] in by_light]
+        lights = sorted(by_light)
+    if not keep:
+        return None, None
+    local = {g: n for n, g in enumerate(lights)}
+    grp = dict(stoplines=[lines[i][:5] + (local[lines[i][5]],) for i in keep],
+               phases=[(n, [local[g] for g in red if g in local]) for n, red in spec["phases"]])
+    return tuple(keep), grp
+
+
+def _heading_table(start_headings, loc, p0, p1, n):
+    """the lane direction at n points along the first waypoint segment p0 -> p1 (entry j at fraction (j + 0.5) / n), from the
+    caller's heading field: what the reference reads with find_lanelet_directions(lanelet_map, x, y)[0] at the sampled start point
+    (ref gym_env.py:359-361).  None when the caller gives no field for the location."""
+    if start_headings is None or loc is None:
+        return None
+    f = start_headings
+    if isinstance(f, dict):
+        f = f.get(loc)
+        if f is None:
+            return None
+        field = f if callable(f) else (lambda x, y, c=float(f): c)
+    else:
+        field = lambda x, y: start_headings(loc, x, y)       # noqa: E731
+    out = []
+    for j in range(n):
+        t = (j + 0.5) / n
+        psi = field(p0[0] + t * (p1[0] - p0[0]), p0[1] + t * (p1[1] - p0[1]))
+        if psi is None:
+            return None
+        out.append(float(np.asarray(psi, dtype=np.float64).reshape(-1)[0]))    # (find_lanelet_directions returns a list: its first entry)
+    if not np.isfinite(out).all():
+        raise ValueError(f"start_headings of location {loc!r} returned a non-finite heading")
+    return out
+
+
 def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=12.0, threshold=0.5,
-                              background=None, background_radius=250.0, ego_only=False, road_meshes=None, near_range=None):
+                              background=None, background_radius=250.0, ego_only=False, road_meshes=None, near_range=None,
+                              traffic_lights=None, light_radius=150.0, start_headings=None, heading_samples=16):
     """WaypointSuite -> World.  Agent ordering follows the reference: slot 0 ego, then the scenario's agents
     (ref gym_env.py:219-228); `car_sequence_suite[i][k]` replays slot k (ref gym_env.py:275-283).
     The CARLA town meshes the reference takes from torchdrivesim's package data are not available, so each scenario
@@ -117,6 +230,23 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
     location that has a mesh all run on ONE map built from it (one grid index per location); a location without one falls back to
     the synthetic corridor of its scenario.
 
+    `traffic_lights`: the stop lines and light cycle per location, as the reference takes them from the map config
+    (`map_cfg.stoplines` / `map_cfg.traffic_light_controller`, ref gym_env.py:181-189; fed to the NPCs :290-291, to is_terminated
+    :415 and get_info :429): a dict location -> dict(stoplines=[(x, y, psi, length, width, light)], phases=[(n_steps, [red
+    lights])]) or a callable location -> the same or None (`traffic_lights_from_controller` builds one from stop-line objects and
+    a controller's state sequence).  The cycle restarts with every episode.  A location with more than 32 lights is cut into
+    per-scenario neighbourhoods (the lines within `light_radius` metres of the scenario's waypoints, agents and replay paths; a
+    light is a bit of a 32-bit mask): each distinct set becomes a light group - a map descriptor of its own that shares the
+    location's mesh (assemble_world).  A world with lights steps with TDE_F_TRAFFIC_LIGHTS (BatchedWaypointEnv sets it): the ego's
+    stop-line violation terminates the episode and shows in info["traffic_light_violation"], the NPCs stop at red lines, the
+    birdview paints the lines.
+
+    `start_headings`: the lane direction at the ego's start - what the reference reads with find_lanelet_directions(lanelet_map,
+    x, y)[0] at the point it drew on the first waypoint segment (ref gym_env.py:357-361) - as a callable (location, x, y) -> psi
+    or a dict location -> callable (x, y) -> psi (or a constant).  Sampled at `heading_samples` points along every scenario's
+    first segment into the world's heading table (tde_world.start_psi); the episode's start heading is the entry of its drawn
+    fraction + normal(0, 0.1).  Without it: the direction of the first segment.
+
     `near_range` (metres; default world.NEAR_RANGE = 2): how far beyond the offroad threshold the grid index carries NEAR LISTS, from
     which the MAGNITUDE of the offroad infraction (info["offroad"], ref gym_env.py:427) is two table look-ups; a corner farther out
     is still exact but found by scanning the grid, and beyond the reach where that square would hold more cells than the map has
@@ -125,6 +255,7 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
     from . import loaders
     meshes, scenarios = [], []
     map_of_location = {}
+    light_groups, group_of = [], {}                  # (map id, kept stop lines) -> index into light_groups
     n = len(data.waypoint_suite)
     for i in range(n):
         wps = [tuple(p) for p in data.waypoint_suite[i]]
@@ -187,9 +318,23 @@ def world_from_waypoint_suite(data: WaypointSuite, agents_per_env=8, road_width=
         scn = dict(map=map_id, waypoints=wps, start_heading=heading, agents=agents[:agents_per_env - 1])
         if ego_attr is not None:
             scn["ego_attr"] = ego_attr
+        spec = _lights_of_location(traffic_lights, loc)
+        if spec is not None:
+            key, grp = _light_group(spec, polylines, float(light_radius))
+            if key is not None:
+                if (map_id, loc, key) not in group_of:
+                    group_of[(map_id, loc, key)] = len(light_groups)
+                    light_groups.append(dict(map=map_id, **grp))
+                scn["lights"] = group_of[(map_id, loc, key)]
+        table = _heading_table(start_headings, loc, wps[0], wps[1], int(heading_samples))
+        if table is not None:
+            scn["start_headings"] = table
         scenarios.append(scn)
+    if any("start_headings" in sc for sc in scenarios):      # one table size per world: the others repeat their segment's direction
+        for sc in scenarios:
+            sc.setdefault("start_headings", [sc["start_heading"]] * int(heading_samples))
     from .world import NEAR_RANGE
-    return assemble_world(meshes, scenarios, agents_per_env, threshold=threshold,
+    return assemble_world(meshes, scenarios, agents_per_env, threshold=threshold, light_groups=light_groups,
                           near_range=NEAR_RANGE if near_range is None else float(near_range))
 
 
@@ -282,13 +427,16 @@ class BatchedWaypointEnv:
 
     def __init__(self, cfg: EnvConfig, data, num_envs, agents_per_env=16, device=None, obs_mode="birdview",
                  frame_stack=1, auto_reset=True, with_info=True, background=None, env_base=0, binding="ext",
-                 info_magnitudes=True, road_meshes=None, near_range=None):
+                 info_magnitudes=True, road_meshes=None, near_range=None, traffic_lights=None, start_headings=None, light_radius=150.0,
+                 heading_samples=16):
         """binding: "ext" = launches go through the PyTorch-ROCm C++ extension (csrc/tde_torch_ext.cpp), "ctypes" = through
         the ctypes binding of the same C-ABI (ops.py); both call the very same entry points of libtde_hip.so.
         info_magnitudes (default): info["offroad"] / info["collision"] hold the MAGNITUDES the reference reports there (ref
         gym_env.py:427-428: sum over the ego's corners of clamp(distance - threshold, 0); sum of the IoUs with the agents the ego
         overlaps), written by the step kernel itself for the egos it flagged, before a finished env is re-spawned
         (tde_state.magnitudes: still ONE launch per step).  False: 0 / 1 indicators (the kernel then skips the magnitudes).
+        traffic_lights / start_headings (light_radius, heading_samples): the stop lines + light cycle and the lane-direction field per
+        location, as the reference takes them from the map config (ref gym_env.py:181-189, 359-361): world_from_waypoint_suite.
         road_meshes / near_range: the drivable mesh per location and the reach of the grid index's near lists when `data` is a
         WaypointSuite (world_from_waypoint_suite).  With `terminated_at_infraction=False` an ego may drive far off the road, where
         the exact offroad magnitude is found by a scan of the grid or a walk over the map's triangles (tens of microseconds per such
@@ -311,7 +459,8 @@ class BatchedWaypointEnv:
             data, agents_per_env,
             threshold=effective_offroad_distance(sim.offroad_threshold, sim.offroad_threshold_squared),
             background=background if cfg.use_background_traffic else None, ego_only=cfg.ego_only, road_meshes=road_meshes,
-            near_range=near_range)
+            near_range=near_range, traffic_lights=traffic_lights, light_radius=light_radius, start_headings=start_headings,
+            heading_samples=heading_samples)
         check_threshold(self.world, sim.offroad_threshold, sim.offroad_threshold_squared,
                         "EnvConfig.simulator.offroad_threshold")   # a prebuilt World bakes its threshold into the grid
         self.A = self.world.A
@@ -349,6 +498,8 @@ class BatchedWaypointEnv:
         if binding == "ext":
             from . import _ext
             self._h = _ext.env_handle(self.tde_cfg, self.dworld, self.state)
+        # the world's first-step gap cache for this configuration, now - not inside the first step() (which may be under a stream capture)
+        ops.first_gaps(self.tde_cfg, self.dworld)
 
     @property
     def auto_reset(self):
@@ -862,12 +1013,13 @@ class WaypointSuiteEnv(_GymEnvBase):
 
     metadata = {"render_modes": ["video", "rgb_array"], "render_fps": 10}
 
-    def __init__(self, cfg: EnvConfig, data, agents_per_env=8, road_meshes=None):
+    def __init__(self, cfg: EnvConfig, data, agents_per_env=8, road_meshes=None, traffic_lights=None, start_headings=None):
         self.config = cfg
         # info["offroad"] / info["collision"] carry the MAGNITUDES of compute_offroad() / compute_collision(), as the reference's
         # get_info reports them (ref gym_env.py:427-428; Monitor logs them, examples/rl_training.py:128)
         self._env = BatchedWaypointEnv(cfg, data, num_envs=1, agents_per_env=agents_per_env, obs_mode="birdview",
-                                       frame_stack=1, auto_reset=False, info_magnitudes=True, road_meshes=road_meshes)
+                                       frame_stack=1, auto_reset=False, info_magnitudes=True, road_meshes=road_meshes,
+                                       traffic_lights=traffic_lights, start_headings=start_headings)
         self.torch_device = self._env.torch_device
         self.render_mode = cfg.render_mode
         self.max_environment_steps = cfg.max_environment_steps
@@ -969,14 +1121,19 @@ class SingleAgentWrapper(_GymWrapperBase):
         self.env.close()
 
 
-def make(cfg: EnvConfig, data, agents_per_env=8, road_meshes=None):
-    """what gym.make('torchdriveenv-v0', args={'cfg': cfg, 'data': data}) returns in the reference (ref __init__.py:10);
-    `road_meshes`: see world_from_waypoint_suite"""
-    return SingleAgentWrapper(WaypointSuiteEnv(cfg=cfg, data=data, agents_per_env=agents_per_env, road_meshes=road_meshes))
+def make(cfg: EnvConfig, data, agents_per_env=8, road_meshes=None, traffic_lights=None, start_headings=None):
+    """what gym.make('torchdriveenv-v0', args={'cfg': cfg, 'data': data}) returns in the reference (ref __init__.py:10).
+    `road_meshes`, `traffic_lights`, `start_headings`: what the reference takes from torchdrivesim's map config of the location
+    (`find_map_config`: road mesh ref gym_env.py:184, stop lines + light controller :181-189, lanelet directions :359) - see
+    world_from_waypoint_suite"""
+    return SingleAgentWrapper(WaypointSuiteEnv(cfg=cfg, data=data, agents_per_env=agents_per_env, road_meshes=road_meshes,
+                                               traffic_lights=traffic_lights, start_headings=start_headings))
 
 
 if gym is not None:  # pragma: no cover
     try:
-        gym.register('torchdriveenv-v0', entry_point=lambda args: make(args['cfg'], args['data'], road_meshes=args.get('road_meshes')))
+        gym.register('torchdriveenv-v0', entry_point=lambda args: make(args['cfg'], args['data'], road_meshes=args.get('road_meshes'),
+                                                                       traffic_lights=args.get('traffic_lights'),
+                                                                       start_headings=args.get('start_headings')))
     except Exception:
         pass
