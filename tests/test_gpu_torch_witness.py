@@ -4,6 +4,8 @@ oracle/torch_step.py - the step restated as B x A fp32 tensor ops with the real 
 brute-force pass over every triangle - and the other side is tde_env_step on the GPU (not the C oracle: rounds 1-4 held HIP
 against the C oracle on the GPU and the C oracle against torch on the CPU only).  Teacher-forced: both sides start every step
 from the SAME state, the device's."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,9 +23,17 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("form", ["trio", "solo"])
 def test_hip_step_tracks_a_pytorch_fp32_step(small_world, form):
-    """64 envs x 16 agents, 120 teacher-forced steps: kinematic state within 1e-5 x the coordinate scale, collision / offroad masks
-    equal away from their decision bands (> 99.9 % of the slots), rewards within 2e-3 (libm-class vs the kernel's polynomial
-    sine / cosine; the reward's float64 terms amplify a 1-ulp heading difference by heading_penalty)"""
+    """64 envs x 16 agents, 120 teacher-forced steps of tde_env_step against the PyTorch fp32 step, held to what the comparison
+    OBSERVES (round 5's bounds - 1e-5 x the batch's largest coordinate, rewards 2e-3, masks 99.9 % - would have stayed green through a
+    100 x worse sine):
+      * kinematic state: PER ELEMENT |d| <= 1e-5 * max(1, |ref|) (observed: 8e-6 absolute on coordinates of tens of metres, 7e-7
+        relative: the kernel's polynomial sine / cosine is within 2 ulp of libm's),
+      * rewards within 1e-4 (observed 1.4e-6: the float64 heading term amplifies a 1-ulp heading difference by heading_penalty),
+      * collision / offroad masks EQUAL on every slot whose decision is farther than witness_util.BAND = 1e-4 m from its threshold
+        (SAT slack, corner distance to the mesh vs the threshold); the slots inside the band are counted, not excused wholesale.
+    The observed maxima go to gpurun_out/r06_witness_<form>.json (profiles/ keeps a copy)."""
+    from tests.witness_util import BAND, Observed, collision_margin, offroad_margin
+
     cfg = _abi.default_config(seed=4, distance_cutoff=0.25)
     B, A = 64, 16
     _lib.kernel_override(step=form)
@@ -32,8 +42,9 @@ def test_hip_step_tracks_a_pytorch_fp32_step(small_world, form):
         ds, hs = EnvState(B, A, device=DEV), EnvState(B, A)
         ops.env_reset(cfg, dw, ds)
         tw = TorchWorld(small_world)
+        scn_map = small_world.arrays["scn"]["map"].astype(np.int64)
         rng = np.random.default_rng(0)
-        agree = {"collided": [], "offroad": [], "done": []}
+        obs = Observed()
         n_coll = n_off = 0
         for t in range(120):
             keep = ds.host()
@@ -44,30 +55,43 @@ def test_hip_step_tracks_a_pytorch_fp32_step(small_world, form):
             torch_env_step(cfg, small_world, tw, hs, oracle_reset=oracle.env_reset)
             d = ds.host()
             done = ((d["done_bits"] & 3) != 0)                  # the step's flags before the in-kernel re-spawn cleared them
-            live = np.repeat(~done, A)                          # finished envs were re-spawned: compare the others' state
+            live = np.repeat(~done, A) & (hs["present"] != 0)   # finished envs were re-spawned: compare the others' state
             for k in ("x", "y", "psi", "v"):
-                err = np.abs(d[k] - hs[k])[live]
+                got, ref = d[k][live].astype(np.float64), hs[k][live].astype(np.float64)
+                err = np.abs(got - ref)
                 if k == "psi":
-                    err = np.minimum(err, 2 * np.pi - err)      # the wrap point itself may land on either side
-                assert err.max() <= 1e-5 * max(1.0, np.abs(keep[k]).max()), (t, k, err.max())
+                    wrapped = err > np.pi                       # the wrap point itself may land on either side
+                    got = np.where(wrapped, got - np.sign(got - ref) * 2 * np.pi, got)
+                    err = np.abs(got - ref)
+                assert (err <= 1e-5 * np.maximum(1.0, np.abs(ref))).all(), (t, k, float(err.max()))
+                obs.state(got, ref)
             assert (d["route_wp"] != hs["route_wp"])[live].mean() < 1e-3
-            assert np.allclose(d["reward"], hs["reward"], atol=2e-3), (t, np.abs(d["reward"] - hs["reward"]).max())
-            agree["collided"].append((d["collided"] == hs["collided"])[live].mean())
-            agree["offroad"].append((d["offroad"] == hs["offroad"])[live].mean())
-            agree["done"].append((done == (hs["terminated"] | hs["truncated"]).astype(bool)).mean())
-            # the ego's flags of finished envs live in done_bits (bit 2 offroad, bit 3 collided)
+            assert np.allclose(d["reward"], hs["reward"], rtol=0, atol=1e-4), (t, np.abs(d["reward"] - hs["reward"]).max())
+            obs.reward(d["reward"], hs["reward"])
+            # masks: the torch side's post-step state (= the device's within 1e-5) gives every slot's decision margin
+            obs.rec["slot_steps"] += int(live.sum())
+            bad_c = obs.mask("collided", d["collided"], hs["collided"], collision_margin(hs, B, A), live)
+            bad_o = obs.mask("offroad", d["offroad"], hs["offroad"], offroad_margin(hs, B, A, tw, scn_map, cfg.offroad_threshold), live)
+            assert bad_c == 0 and bad_o == 0, (t, bad_c, bad_o)
+            # a finished env's flags: done must agree unless its ego sits inside a band (then the episode ends on one side only)
+            t_done = (hs["terminated"] | hs["truncated"]).astype(bool)
+            ego_band = (np.minimum(collision_margin(hs, B, A), offroad_margin(hs, B, A, tw, scn_map, cfg.offroad_threshold)).reshape(B, A)[:, 0] <= BAND)
+            assert (done == t_done)[~ego_band].all(), t
             ego_off, ego_col = (d["done_bits"] >> 2) & 1, (d["done_bits"] >> 3) & 1
-            assert (ego_off == hs["offroad"].reshape(B, A)[:, 0])[~done].all() and (ego_col == hs["collided"].reshape(B, A)[:, 0])[~done].all()
+            assert (ego_off == hs["offroad"].reshape(B, A)[:, 0])[~done & ~ego_band].all() and (ego_col == hs["collided"].reshape(B, A)[:, 0])[~done & ~ego_band].all()
             n_coll += int(hs["collided"].sum()); n_off += int(hs["offroad"].sum())
-        assert min(np.mean(v) for v in agree.values()) > 0.999, {k: float(np.mean(v)) for k, v in agree.items()}
         assert int(ds["episode"].max()) > 1 and n_coll > 20 and n_off > 20
+        assert obs.rec["collided_in_band"] + obs.rec["offroad_in_band"] < 0.001 * obs.rec["slot_steps"]     # the band is not where the agents live
+        obs.write(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"r06_witness_{form}.json"),
+                  what=f"tde_env_step ({form}) vs oracle/torch_step.py, 64 envs x 16 agents x 120 teacher-forced steps", n_collided=n_coll, n_offroad=n_off)
     finally:
         _lib.kernel_override()
 
 
 def test_hip_kinematics_within_1e5_of_torch_fp32():
     """KinematicBicycle.step alone, 50 000 agents: tde_kinematics_step on the GPU against the literal torch-op restatement
-    (torch.sin / torch.cos / %), teacher-forced single steps - the fp32 state tolerance of the north star, 1e-5 x scale"""
+    (torch.sin / torch.cos / %), teacher-forced single steps - the fp32 state tolerance of the north star, per element:
+    |d| <= 1e-5 * max(1, |ref|)"""
     from tests.test_oracle_vs_torch import torch_bicycle
 
     g = torch.Generator().manual_seed(0)
@@ -83,6 +107,6 @@ def test_hip_kinematics_within_1e5_of_torch_fp32():
         got = torch.stack(cols, -1).cpu().numpy()
         diff = np.abs(got - want.numpy())
         diff[:, 2] = np.minimum(diff[:, 2], 2 * np.pi - diff[:, 2])
-        assert diff.max() <= 1e-5 * max(1.0, float(want.abs().max())), diff.max()
+        assert (diff <= 1e-5 * np.maximum(1.0, np.abs(want.numpy()))).all(), diff.max()          # per element
         assert diff[:, 3].max() == 0.0                           # v' = v + a * dt has no transcendental: bit-exact
         st = want
