@@ -247,12 +247,18 @@ def secondary(dev, region_s=0.3):
         ("closed_loop_full_outputs_indicators", dict(name="the same with 0 / 1 infraction indicators instead of the magnitudes (BatchedWaypointEnv(info_magnitudes=False): "
                                                           "round 4's closed_loop_full_outputs)",
                                                      config=3, B=8192, A=16, stepwise=True, flags=F, with_info=True, magnitudes=False)),
+        ("coast_rule", dict(name="configs[2] with TDE_F_NPC_FIRST_STEP cleared (the opt-out: NPCs coast through an episode's first step - the rule "
+                                 "rounds 4 / 5 were measured under), rollout", config=3, B=8192, A=16, stepwise=False, flags=F & ~_abi.F_NPC_FIRST_STEP)),
+        ("coast_rule_closed_loop", dict(name="the same in closed loop", config=3, B=8192, A=16, stepwise=True, flags=F & ~_abi.F_NPC_FIRST_STEP)),
         ("config2", dict(name="configs[1]: 1024 envs x 8 agents, kinematics + collision only, 250 steps per launch",
                          config=2, B=1024, A=8, stepwise=False, flags=0)),
         ("lights", dict(name="configs[2] + traffic-light / stop-line term (TDE_F_TRAFFIC_LIGHTS), rollout",
                         config=3, B=8192, A=16, stepwise=False, flags=F | _abi.F_TRAFFIC_LIGHTS)),
         ("lights_closed_loop", dict(name="the same in closed loop: what BatchedWaypointEnv.step launches on maps that carry traffic lights",
                                     config=3, B=8192, A=16, stepwise=True, flags=F | _abi.F_TRAFFIC_LIGHTS)),
+        ("lights_closed_loop_full_outputs", dict(name="the reference's operating point in closed loop: traffic lights + NPCs acting from step one + every output of "
+                                                      "BatchedWaypointEnv.step (info terms, done bits, episode statistics, observation, infraction magnitudes)",
+                                                 config=3, B=8192, A=16, stepwise=True, flags=F | _abi.F_TRAFFIC_LIGHTS, with_info=True, magnitudes=True)),
         ("agents_128", dict(name="1024 envs x 128 agent slots (~122 present per env: the reference's ~100-agent scenes), rollout",
                             config=3, B=1024, A=128, stepwise=False, flags=F, town="crowded")),
         ("agents_128_closed_loop", dict(name="the same in closed loop: one tde_env_step launch per timestep",
@@ -781,6 +787,26 @@ def main():
         }
         if n == 1 and args.config == 3 and not stepwise and not args.no_secondary and not args.force_dist:
             out["secondary"] = secondary(dev)
+            # the other operating points, compact, INSIDE `roofline` (what the driver's record keeps): us per timestep and the
+            # algorithmic-bytes fraction of the 8 TB/s peak, same definition as roofline.frac.  All with the default flags (NPCs
+            # acting from an episode's first step) unless named otherwise; `secondary` holds the full entries.
+            sec = out["secondary"]
+
+            def pt(key):
+                e = sec.get(key) or {}
+                return ({"us": round(e["us_per_step"], 3), "frac": round(e["roofline"]["frac"], 4)} if "us_per_step" in e else {"error": e.get("error", "missing")})
+            out["roofline"]["points"] = {
+                "headline": {"us": round(kern_us / spl, 3), "frac": round(achieved / HBM_PEAK_GBPS, 4)},
+                "coast_rule": pt("coast_rule"), "coast_rule_closed_loop": pt("coast_rule_closed_loop"),
+                "closed_loop": pt("closed_loop"), "closed_loop_full": pt("closed_loop_full_outputs"),
+                "config5": pt("config5"), "config5_one_stream": pt("config5_one_stream"), "town": pt("town"),
+                "town_closed_loop": pt("town_closed_loop"), "town_config5": pt("town_config5"),
+                "lights": pt("lights"),                                   # rollout, lights + first step
+                "reference_semantics": pt("lights_closed_loop"),          # closed loop, lights + first step: the reference's step()
+                "reference_semantics_full": pt("lights_closed_loop_full_outputs"),
+                "agents_128": pt("agents_128"), "agents_128_closed_loop": pt("agents_128_closed_loop"),
+                "note": "us per timestep / algorithmic bytes over the 8 TB/s peak; default flags = TDE_F_ALL (NPCs act from step one); "
+                        "reference_semantics = traffic lights + first step, closed loop"}
             try:
                 out["secondary"]["python_boundary"] = python_boundary()
             except Exception as exc:                                   # pragma: no cover

@@ -174,3 +174,19 @@ def test_grid_build_argument_errors_and_shared_lists():
     assert (g["rec_len"][first] > 0).all() and (first + g["rec_len"][first] <= len(g["rec_tri"])).all()
     none = build_grid_index(strip_mesh([(0.0, 0.0), (60.0, 0.0)], 7.0, 5.0).astype(np.float32), 0.5, 0.25, near_range=0.0)
     assert ((none["tile_near"] == 0) | (none["tile_near"] == 0)).all() and none["n_near_lists"] == 0
+
+
+def test_experiment_switches_do_not_compile_into_a_product_build(tmp_path):
+    """TDE_EXP_* (timing experiments that skip work: WRONG results) are fenced: a translation unit of the library with one of them set
+    only compiles with -DTDE_EXPERIMENT_BUILD (csrc/tde_kernels.h); build.py passes neither"""
+    import subprocess
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "torchdriveenv_amd", "csrc", "tde_rollout_solo.hip")
+    base = [hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--offload-device-only", "-x", "hip", src]
+    bad = subprocess.run(base + ["-DTDE_EXP_NO_D_RESPAWN"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "TDE_EXPERIMENT_BUILD" in bad.stderr
+    from torchdriveenv_amd import build as b
+    assert not any("TDE_EXP" in f for f in b.CFLAGS + b.LDFLAGS)

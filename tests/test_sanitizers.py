@@ -1,8 +1,8 @@
-"""Host code under sanitizers (CPU suite).  `make -C oracle san` builds, with gcc / g++:
-  * the oracle (oracle/tde_oracle.c) and the HOST grid builder (csrc/tde_gridbuild.h through oracle/grid_host.cpp - in the product
-    it is compiled inside the one .hip translation unit, where no host sanitizer reaches it) as shared libraries with
-    AddressSanitizer + UndefinedBehaviorSanitizer;
-  * the grid builder's multi-threaded passes as a stand-alone driver under ThreadSanitizer (and under ASan + UBSan).
+"""Host code under sanitizers (CPU suite), built with gcc / g++:
+  * `make -C oracle san`: the oracle (oracle/tde_oracle.c) as a shared library with AddressSanitizer + UndefinedBehaviorSanitizer;
+  * `make -C torchdriveenv_amd/csrc san`: the library's HOST grid builder (csrc/tde_gridbuild.h through csrc/tde_grid_host.cpp - in
+    libtde_hip.so it is compiled by hipcc inside tde_api.hip, where no host sanitizer reaches it) as a shared library with ASan +
+    UBSan, and its multi-threaded passes as a stand-alone driver under ThreadSanitizer (and under ASan + UBSan).
 The oracle / grid / loader tests then run in a child process with the ASan runtime preloaded and TDE_ORACLE_LIB / TDE_GRID_LIB
 pointing at the sanitized libraries: they must pass with no sanitizer report."""
 import os
@@ -12,14 +12,16 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SAN = os.path.join(ROOT, "oracle", "_san")
+SAN = os.path.join(ROOT, "torchdriveenv_amd", "_san")          # the library's host code
+ORACLE_SAN = os.path.join(ROOT, "oracle", "_san")              # the checker
 
 
 @pytest.fixture(scope="module")
 def san_build():
-    p = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "san"], capture_output=True, text=True)
-    if p.returncode != 0:
-        pytest.fail("make -C oracle san failed:\n" + p.stderr[-2000:])
+    for d in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "torchdriveenv_amd", "csrc")):
+        p = subprocess.run(["make", "-C", d, "san"], capture_output=True, text=True)
+        if p.returncode != 0:
+            pytest.fail(f"make -C {d} san failed:\n" + p.stderr[-2000:])
     return SAN
 
 
@@ -44,7 +46,7 @@ def test_oracle_and_grid_tests_pass_on_the_sanitized_libraries(san_build):
     asan_rt = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
     if not os.path.isabs(asan_rt) or not os.path.exists(asan_rt):
         pytest.skip("no ASan runtime next to gcc")
-    env = dict(os.environ, LD_PRELOAD=asan_rt, TDE_ORACLE_LIB=os.path.join(san_build, "libtde_oracle_asan.so"),
+    env = dict(os.environ, LD_PRELOAD=asan_rt, TDE_ORACLE_LIB=os.path.join(ORACLE_SAN, "libtde_oracle_asan.so"),
                TDE_GRID_LIB=os.path.join(san_build, "libtde_grid_asan.so"),
                # (leaks: CPython and torch keep memory until exit by design; alloc_dealloc_mismatch: torch's operator new vs free)
                ASAN_OPTIONS="detect_leaks=0:alloc_dealloc_mismatch=0:halt_on_error=1:abort_on_error=0",

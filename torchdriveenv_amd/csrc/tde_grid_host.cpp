@@ -1,14 +1,15 @@
-// grid_host.cpp — the HOST grid builder (torchdriveenv_amd/csrc/tde_gridbuild.h: tde_grid_build / tde_grid_free of include/tde_hip.h)
-// as a translation unit of its own for the host compiler, so that it can be built and run under AddressSanitizer /
-// UndefinedBehaviorSanitizer / ThreadSanitizer (`make -C oracle san`): in the product it is compiled inside the one .hip
-// translation unit of libtde_hip.so, where no host sanitizer reaches it.  TEST INFRASTRUCTURE: same source, same entry points,
-// plus tde_last_error for the message.  With -DTDE_GRID_DRIVER it is a stand-alone program (no Python: ThreadSanitizer and a
-// Python process with torch in it do not get along) that builds the index of a synthetic road network on 1, 3 and 8 threads and
-// checks that the tables do not depend on the thread count.
+// tde_grid_host.cpp — the library's HOST grid builder (tde_gridbuild.h: tde_grid_build / tde_grid_free of include/tde_hip.h) as a
+// translation unit of its own for the HOST compiler, so that this product code can be built and run under AddressSanitizer /
+// UndefinedBehaviorSanitizer / ThreadSanitizer (`make -C torchdriveenv_amd/csrc san` -> torchdriveenv_amd/_san/): in libtde_hip.so it
+// is compiled by hipcc inside tde_api.hip, where no host sanitizer reaches it.  Same source, same entry points, plus tde_last_error
+// for the message; world.py loads such a build instead of libtde_hip.so when TDE_GRID_LIB names it (tests/test_sanitizers.py).
+// With -DTDE_GRID_DRIVER it is a stand-alone program (no Python: ThreadSanitizer and a Python process with torch in it do not get
+// along) that builds the index of a synthetic road network on 1, 3 and 8 threads and checks that the tables do not depend on the
+// thread count.
 #include <cstdio>
 #include <cstring>
 
-#include "../include/tde_hip.h"
+#include "../../include/tde_hip.h"
 
 static thread_local char g_err[256] = "";
 static int bad(const char *msg)
@@ -19,7 +20,7 @@ static int bad(const char *msg)
 extern "C" __attribute__((visibility("default"))) const char *tde_last_error(void) { return g_err; }
 extern "C" __attribute__((visibility("default"))) int tde_abi_version(void) { return TDE_ABI_VERSION; }
 
-#include "../torchdriveenv_amd/csrc/tde_gridbuild.h"
+#include "tde_gridbuild.h"
 
 #ifdef TDE_GRID_DRIVER
 #include <cmath>

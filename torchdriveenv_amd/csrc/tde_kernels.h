@@ -25,6 +25,17 @@
 #include "tde_magnitudes.h"
 #include "tde_raster.h"
 
+// ---- experiment switches ---------------------------------------------------------------------------------------------------------------
+// TDE_EXP_*: builds for TIMING experiments that skip part of the work and therefore compute WRONG results (what a section costs:
+// profiles/r05_magnitudes_floor.md, r04_k_ab_step_no_respawn.txt).  They only compile with -DTDE_EXPERIMENT_BUILD, which no product build
+// sets (build.py never passes it; scripts/build_variant.sh passes whatever it is given): a stray -DTDE_EXP_... in a product build is an
+// error, not a silently wrong library.  (Switches that keep the results - TDE_FIRST_GAP, TDE_COLLIDE_DPP, TDE_STEP_CLS2, the issue
+// priorities ... - are A/B switches and need no fence.)
+#if (defined(TDE_EXP_NO_COLL_MAG) || defined(TDE_EXP_NO_OFF_MAG) || defined(TDE_EXP_EXTRA_LOAD) || defined(TDE_EXP_NO_D_RESPAWN) || \
+     defined(TDE_EXP_NO_C_RESPAWN) || (defined(TDE_EXP_MAG_FRAME) && TDE_EXP_MAG_FRAME != 0)) && !defined(TDE_EXPERIMENT_BUILD)
+#error "TDE_EXP_* switches build a library that computes WRONG results (timing experiments): add -DTDE_EXPERIMENT_BUILD to say you mean it"
+#endif
+
 namespace tde {
 
 constexpr int kBlock = 256;

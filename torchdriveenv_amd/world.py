@@ -98,8 +98,9 @@ _GRID_LIB = None
 
 def _grid_lib():
     """the library that holds tde_grid_build / tde_grid_free: libtde_hip.so - or, under TDE_GRID_LIB, a host-compiler build of
-    the same source (csrc/tde_gridbuild.h through oracle/grid_host.cpp) with AddressSanitizer / UBSan in it
-    (`make -C oracle san`; tests/test_sanitizers.py).  The tables do not depend on which one built them."""
+    the same source (csrc/tde_gridbuild.h through csrc/tde_grid_host.cpp) with AddressSanitizer / UBSan in it
+    (`make -C torchdriveenv_amd/csrc san` -> torchdriveenv_amd/_san/; tests/test_sanitizers.py).  The tables do not depend on which
+    one built them."""
     global _GRID_LIB
     import ctypes as C
     import os
