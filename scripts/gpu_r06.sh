@@ -29,6 +29,13 @@ for what in "$@"; do
         TDE_HIP_LIB=$PWD/$L TDE_COAST=$C rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o st -- python3 scripts/run_step.py 2000 > $O/prof_$T.log 2>&1
         echo "== $T"; grep -h "env_step_trio\|first_gap" $O/prof_$T/*/st_kernel_stats.csv 2>/dev/null | cut -c1-200 || find $O/prof_$T -name "*stats*" | head
       done; done; find $O -name "*.csv" -size +2M -delete;;
+    ablights:*) LIBS=$(echo "${what#ablights:}" | tr ':' ' ')
+      python scripts/ab_rollout.py --lights $LIBS 2>&1 | grep -v amdgpu.ids | tail -5 > $O/ab_lights.txt
+      python scripts/ab_step.py --lights $LIBS 2>&1 | grep -v amdgpu.ids | tail -5 >> $O/ab_lights.txt
+      python scripts/ab_rollout.py --lights --town --signals 64 $LIBS 2>&1 | grep -v amdgpu.ids | tail -5 >> $O/ab_lights.txt
+      cat $O/ab_lights.txt;;
+    wide) python scripts/wide_times.py > $O/wide_times.txt 2>&1; grep -v amdgpu $O/wide_times.txt;;
+    wideforms) python scripts/wide_step_forms.py > $O/wide_step_forms.txt 2>&1; grep -v amdgpu $O/wide_step_forms.txt;;
     bench) python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json;;
     *) echo "unknown phase $what";;
   esac

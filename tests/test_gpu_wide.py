@@ -88,6 +88,42 @@ def test_env_step_rollout_and_birdview_128_slots(crowded_town, lights):
         _lib.kernel_override()
 
 
+@pytest.mark.parametrize("lights", [False, True])
+@pytest.mark.parametrize("form", [None, "solo"])
+def test_both_step_forms_at_128_slots_with_every_output(crowded_town, lights, form):
+    """tde_env_step at 128 agent slots: the two-role kernel (round 6: drive / judge wavefronts for each half of the env's slots, the next
+    step's controller beside the judges, actions through tde_act_cache) and the one-role kernel (tde_kernel_override(0, 1); also what a
+    state without the action cache gets), with info terms, done bits, episode statistics, the compact observation and the infraction
+    magnitudes: 60 steps with re-spawns == the oracle, every array bit for bit; a state edit behind the cache's back (load) is survived"""
+    from torchdriveenv_amd import _lib
+    from torchdriveenv_amd.synth import synthetic_world
+
+    world = synthetic_world(n_scn=4, A=128, seed=9, n_maps=2) if lights else crowded_town
+    cfg = _abi.default_config(seed=43, distance_cutoff=0.25, flags=_abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0), max_steps=25)
+    B, A = 24, 128
+    hs = EnvState(B, A, with_magnitudes=True)                         # (the oracle does not form the compact observation: state_obs below)
+    ds = EnvState(B, A, device=DEV, with_obs=True, with_magnitudes=True)
+    dw = world.to_device(DEV)
+    oracle.env_reset(cfg, world, hs)
+    ops.env_reset(cfg, dw, ds)
+    rng = np.random.default_rng(11)
+    _lib.kernel_override(step=form)
+    try:
+        for t in range(60):
+            act = np.stack([rng.uniform(-0.3, 1, B), rng.uniform(-0.25, 0.25, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            oracle.env_step(cfg, world, hs)
+            ops.env_step(cfg, dw, ds, action=dev(act))
+            if t % 7 == 0 or t > 56:
+                assert_state_equal(hs.host(), ds.host(), f"step {t}, 128 slots, form {form}, lights={lights}")
+                assert torch.equal(ds["obs"], ops.state_obs(dw, ds))
+            if t == 30:                                           # the caches do not survive a reload: recomputed, same results
+                ds.load(ds.host())
+        assert int(hs["episode"].max()) >= 3 and float(hs["magnitudes"][:, :2].max()) >= 0.0
+    finally:
+        _lib.kernel_override()
+
+
 def test_batched_env_with_128_slots(crowded_town):
     """the host mirror end to end: BatchedWaypointEnv(agents_per_env = 128), birdview observation, 30 steps == the oracle"""
     from torchdriveenv_amd.config import EnvConfig

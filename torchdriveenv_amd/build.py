@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 # the units, longest first (the pool starts them in this order)
 UNITS = ["tde_step_solo_mag.hip", "tde_step_solo.hip", "tde_step_trio.hip", "tde_rollout_duo.hip", "tde_rollout_trio.hip",
-         "tde_rollout_solo.hip", "tde_api.hip"]
+         "tde_rollout_solo.hip", "tde_step_wide.hip", "tde_api.hip"]
 SRC = [os.path.join(_CSRC, u) for u in UNITS]
 HEADERS = ["tde_kernels.h", "tde_host.h", "tde_device.h", "tde_raster.h", "tde_gridbuild.h", "tde_magnitudes.h", "tde_magnitudes_kernels.h"]
 DEPS = SRC + [os.path.join(_CSRC, h) for h in HEADERS] + [os.path.join(_PKG, "..", "include", "tde_abi.h"),

@@ -995,6 +995,10 @@ TDE_DEV uint32_t red_mask_cached(const tde_world &w, const tde_map &m, int k, Re
 #ifndef TDE_RED_GAP_WIDE
 #define TDE_RED_GAP_WIDE 1          // 0: the stop-line loops a line at a time (A/B)
 #endif
+#ifndef TDE_RED_GAP_LINES
+#define TDE_RED_GAP_LINES 4         // stop lines fetched and tested side by side per trip of the wide loops (2 x 4 registers each)
+#endif
+constexpr int kLinesPerTrip = TDE_RED_GAP_LINES;
 // compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
 // is red.  Mirrors tde_tl_violation of the oracle.
 // `line(i, a, b)` fetches stop line i of the map: (x, y, cos, sin) and (hl, hw, light, -)
@@ -1005,23 +1009,23 @@ TDE_DEV bool tl_violation_of(const L &line, int n_stop, uint32_t red, float x, f
 #if TDE_RED_GAP_WIDE
     if (red) {
         // four lines per trip like red_line_gap_of: the reach tests side by side, the four-axis test for the lines in reach (rare)
-        for (int k0 = 0; k0 < n_stop; k0 += 4) {
-            float4 a[4], b[4];
+        for (int k0 = 0; k0 < n_stop; k0 += kLinesPerTrip) {
+            float4 a[kLinesPerTrip], b[kLinesPerTrip];
             if (k0 < L::kCached) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+                for (int u = 0; u < kLinesPerTrip; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+                for (int u = 0; u < kLinesPerTrip; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
             }
-            bool near[4];
+            bool near[kLinesPerTrip];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kLinesPerTrip; ++u) {
                 const float dx = a[u].x - x, dy = a[u].y - y, rr = ((hl + hw) + (b[u].x + b[u].y)) * kReach;
                 near[u] = (k0 + u < n_stop) && ((red >> __float_as_int(b[u].z)) & 1u) && dx * dx + dy * dy < rr * rr;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < kLinesPerTrip; ++u)
                 if (near[u]) v = v || obb_overlap(x, y, c, s, hl, hw, a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y);
         }
     }
@@ -1071,19 +1075,19 @@ TDE_DEV float red_line_gap_of(const tde_config &cfg, const L &line, int n_stop, 
 #if TDE_RED_GAP_WIDE
     // four lines per trip, all fetched first, the four tests side by side and branch-free (a minimum over the same values in
     // another order: same bits): on the driver's chain a line at a time was four dependent LDS round trips with a branch each
-    for (int k0 = 0; k0 < n_stop; k0 += 4) {
-        float4 a[4], b[4];
+    for (int k0 = 0; k0 < n_stop; k0 += kLinesPerTrip) {
+        float4 a[kLinesPerTrip], b[kLinesPerTrip];
         // (a trip lies wholly inside or wholly outside the LDS cache - its size is a multiple of four: one address space per
         //  trip.  Left to choose per line, the compiler forms a select of an LDS and a global ADDRESS and the backend rejects it)
         if (k0 < L::kCached) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+            for (int u = 0; u < kLinesPerTrip; ++u) line.cached(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
+            for (int u = 0; u < kLinesPerTrip; ++u) line.global(k0 + u < n_stop ? k0 + u : n_stop - 1, a[u], b[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kLinesPerTrip; ++u) {
             const float ex = a[u].x - ag.x, ey = a[u].y - ag.y;
             const float fj = ex * cp + ey * sp;
             const float lj = ey * cp - ex * sp;
@@ -1535,7 +1539,7 @@ struct CachedLines {
         else { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
     }
     static constexpr int kCached = A >= 8 ? kStopCache : 0;
-    static_assert(kStopCache % 4 == 0, "red_line_gap_of walks the lines four at a time");
+    static_assert(kStopCache % kLinesPerTrip == 0, "red_line_gap_of walks the lines kLinesPerTrip at a time: a trip lies inside or outside the LDS cache");
     TDE_DEV void cached(int i, float4 &a, float4 &b) const { a = sh.stop[envw][i][0]; b = sh.stop[envw][i][1]; }
     TDE_DEV void global(int i, float4 &a, float4 &b) const { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
 };
@@ -1997,6 +2001,229 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
     }
 }
 #undef TDE_WIDE_PROLOGUE
+
+// ------------------------------------------------------------------------------------------------------------------
+// Closed-loop step for 128 agent slots per env, two roles (tde_env_step with the action cache; round 6).  The one-role kernel runs
+// the whole step as ONE chain per wavefront: controller sweep over the env's 128 rows -> bicycle -> collision sweep over 128 rows ->
+// offroad -> reward (17.8 us per step at 1024 envs of ~122 agents, two wavefronts per SIMD).  Here, as in env_step_trio_kernel, the
+// controller's actions for THIS step were computed by the previous launch (tde_act_cache) and the next step's are computed by the
+// drive wavefronts BESIDE the judges' sweeps:
+//   drive (slots 0-63), drive (64-127): stored action -> bicycle -> replay -> route switch -> rows; then the next step's controller
+//   judge (0-63), judge (64-127)      : collision, offroad, stop lines; the ego lane: reward, termination, outputs, statistics
+// One env per workgroup of four wavefronts (4 per SIMD, 128 VGPRs: the 128-row sweeps fit without the squeeze of the 80-VGPR forms).
+// Barriers (LDS-only): E = do the drivers hold stored actions (else E2 + the controller on the pre-step rows, in the prologue: the first
+// launch, a re-spawned env's first step, a state edited from outside), B = the rows of the step are committed, A = the env's done
+// flag is published.  Same per-agent arithmetic in the same order as step_lane: the oracle's bits.
+// ------------------------------------------------------------------------------------------------------------------
+TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps);       // (the action cache's key word: defined with env_step_trio_kernel below)
+
+struct WideStepShared : WideShared {
+    int early[2];                        // a drive wavefront has a slot without a stored action
+    float poly[32];                      // MAG: box_iou_wave's vertex lists
+};
+
+template <bool LIGHTS, bool OBS, bool MAG>
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_step_wide_kernel(tde_config cfg, tde_world w, tde_state st,
+                                                                                                           uint32_t act_hash)
+{
+    constexpr int A = 128;
+    __shared__ WideStepShared sh;
+    __shared__ Cold cold;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = wv >> 1;                               // 0 = drive, 1 = judge
+    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
+    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }
+    const uint32_t F = cfg.flags;
+    const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;
+    const bool lights = LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS);
+    const int e = (int)blockIdx.x;                          // (the grid is B workgroups: every env is valid)
+    const int64_t g = (int64_t)e * A + a;
+    __syncthreads();                                         // cold is filled
+    if (role == 0) {
+        // ================================ drive ================================
+        __builtin_amdgcn_s_setprio(2);
+        Agent ag;
+        load_agent(st, g, ag);
+        EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
+        const float2 act = reinterpret_cast<const float2 *>(st.action)[e];
+        float2 ac = make_float2(0.0f, 0.0f);
+        int2 akey = make_int2(-1, 0);                        // episode, steps (tde_act_cache: A + 1 entries per env)
+        float2 *ap = st.act_cache ? reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1) : nullptr;
+        if (ap) { ac = ap[a]; akey = reinterpret_cast<const int2 *>(ap)[A]; }
+        Ctx cx;
+        load_ctx<A>(cfg, cold, a, ag, er, cx);
+        const bool live = ag.present;
+        const int k = er.steps + 1;                          // :116
+        const bool npc = (F & TDE_F_NPC) && a > 0 && live;
+        const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
+        float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
+        bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+        float acc = 0.0f, beta = 0.0f;
+        if (a == 0) { acc = act.x; beta = act.y; }
+        float c0, s0;
+        auto controller = [&](int buf, int kk, float &na, float &nb) {
+            const uint32_t red = lights ? red_mask(w, cx.m, kk) : 0u;
+            const float red_gap = (lights && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+            npc_action_wide<A>(cfg, &sh.a[buf][0], &sh.b[buf][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+        };
+        if (lights) fill_stop_cache_wide(sh, w, cx.m, a);
+        if (F & TDE_F_NPC) {
+            const bool stored = !npc || (k == 1 && !first_acts) || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
+            if (__ballot(!stored) && lane == 0) sh.early[wv] = 1;
+        }
+        lds_barrier();                                       // E: does a drive wavefront lack stored actions?
+        if (sh.early[0] | sh.early[1]) {
+            sincos_f32(ag.psi, s0, c0);
+            write_rows_wide(sh, 1, a, live, ag, c0, s0, cfg.npc_lane_half);      // pre-step rows: what the controller reads
+            lds_barrier();                                   // E2: both halves' rows (and the stop lines) are in
+            float na, nb;
+            controller(1, k, na, nb);
+            if (npc) { acc = na; beta = nb; }
+        } else if (npc) {
+            acc = ac.x; beta = ac.y;
+        }
+        if (npc && k == 1 && !first_acts) acc = beta = 0.0f;
+        if (live) {
+            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117
+            if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
+        }
+        bool switched = false;
+        if (has_target) {
+            const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
+            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { ag.route_wp += 1; switched = true; }
+        }
+        sincos_f32(ag.psi, s0, c0);
+        er.steps = k;
+        write_rows_wide(sh, 0, a, live, ag, c0, s0, cfg.npc_lane_half);
+        lds_barrier();                                       // B: rows of this step are in buffer 0
+        __builtin_amdgcn_s_setprio(0);                       // behind B the judges' sweeps are the critical path
+        if (switched) load_route_target(cold, ag, cx);
+        // the controller of the NEXT step, beside the judges of this one (speculative: a re-spawn below discards it)
+        float na2 = 0.0f, nb2 = 0.0f;
+        has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+        if ((F & TDE_F_NPC) && ap) controller(0, k + 1, na2, nb2);
+        lds_barrier();                                       // A: the env's done flag is published
+        __builtin_amdgcn_s_setprio(3);
+        const bool respawned = sh.done != 0;
+        if (respawned) reset_lane<A>(cfg, cold, e, a, ag, er);
+        store_agent_dynamic(st, g, ag);
+        if (respawned) store_agent_static(st, g, ag);
+        if (ap) {
+            ap[a] = make_float2(na2, nb2);
+            // (a re-spawned env's first actions are the next launch's: its key is stored invalid - the prologue above computes them)
+            if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));
+        }
+    } else {
+        // ================================ judge ================================
+        __builtin_amdgcn_s_setprio(1);
+        Agent ag;
+        load_agent(st, g, ag);                               // (the pose BEFORE the step: :371-375 for the ego lane)
+        EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
+        double ep_ret = 0.0;
+        if (a == 0 && st.ep_return) ep_ret = st.ep_return[e];
+        Ctx cx;
+        load_ctx<A>(cfg, cold, a, ag, er, cx);
+        const float lx = ag.x, ly = ag.y, lpsi = ag.psi, lv = ag.v;
+        const float thr2 = thr2_of(cfg);
+        lds_barrier();                                       // E
+        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2
+        lds_barrier();                                       // B: rows of this step are in buffer 0
+        __builtin_amdgcn_s_setprio(2);
+        er.steps += 1;
+        const int k = er.steps;
+        const float4 ra = sh.a[0][a], rb = sh.b[0][a], rc = sh.c[0][a];
+        const bool live = rc.z != 0.0f;
+        const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
+        Corners corners;
+        if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+        const bool hit = collide_rows_wide<A>(&sh.a[0][0], &sh.b[0][0], a, live, x, y, c0, s0, hl, hw, ra.z);
+        bool off = false;
+        if (F & TDE_F_OFFROAD) off = offroad_resolve<true, false>(w, corners, thr2, cx.m.rec_base);
+        bool tl = false;
+        if (lights && a == 0) tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
+        StepOut o{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
+        const int ti0 = er.target_idx;
+        if (a == 0) {
+            int done = 0;
+            if (F & TDE_F_REWARD) {
+                RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, x, y, rc.x, rc.y, off, hit, tl, k, er.target_idx, er.reached,
+                                          st.info != nullptr);
+                o.reward = r.reward; o.terminated = r.terminated; o.truncated = r.truncated;
+                if (st.info) {
+                    double *inf = st.info + 4 * (int64_t)e;
+                    inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
+                }
+                if (st.info_reached) st.info_reached[e] = er.reached;
+                done = (r.terminated | r.truncated) ? 1 : 0;
+            }
+            sh.done = ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? done : 0;
+        }
+        const unsigned long long hit_m = MAG ? __ballot(hit) : 0ull, off_m = MAG ? __ballot(off) : 0ull;
+        lds_barrier();                                       // A
+        const bool respawned = sh.done != 0;
+        st.collided[g] = respawned ? 0 : o.collided;
+        st.offroad[g] = respawned ? 0 : o.offroad;
+        const tde_map map0 = cx.m;                           // (MAG: the map of the episode that was stepped; a re-spawn replaces cx)
+        if (a == 0) {
+            ag.x = x; ag.y = y; ag.psi = rc.x; ag.v = rc.y;  // the ego after the step (the compact observation)
+            float oc = c0, os = s0;
+            if (respawned) {
+                respawn_lane<A>(cfg, cold, e, a, ag, er, cx, false);             // (per-lane draws at 128 slots: no cross-lane traffic)
+                if (OBS) sincos_f32(ag.psi, os, oc);
+            } else if ((F & TDE_F_REWARD) && er.target_idx != ti0) {
+                load_ego_target(cold, er, cx);
+            }
+            st.steps[e] = er.steps;
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = o.reward;
+            st.terminated[e] = o.terminated;
+            st.truncated[e] = o.truncated;
+            if (st.tl_violation) st.tl_violation[e] = o.tl;
+            if (respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
+            if (st.done_bits) st.done_bits[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
+            if (st.ep_return) {
+                double ret = ep_ret + (double)o.reward;
+                if (o.terminated | o.truncated) {
+                    if (st.ep_final) st.ep_final[e] = ret;
+                    if (st.ep_final_len) st.ep_final_len[e] = k;
+                    if (respawned) ret = 0.0;
+                }
+                st.ep_return[e] = ret;
+            }
+            if (OBS && st.obs) {
+                // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it
+                const bool ended = (o.terminated | o.truncated) && !respawned;
+                bool has = er.target_idx < cx.n_wp;
+                double tx = cx.wtx, ty = cx.wty;
+                asm volatile("" : "+v"(tx), "+v"(ty));
+                if (!(F & TDE_F_REWARD) || ended) {
+                    has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
+                    const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
+                    tx = t2.x; ty = t2.y;
+                }
+                float fwd = 0.0f, lat = 0.0f;
+                if (has) {
+                    const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
+                    fwd = dx * oc + dy * os;
+                    lat = dy * oc - dx * os;
+                }
+                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
+                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
+                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
+            }
+        }
+        if constexpr (MAG) {
+            // tde_state.magnitudes for a flagged ego (get_info's "collision" / "offroad", :427-428), by the ego's wavefront from the
+            // rows of THIS step (a re-spawn does not rewrite them) - behind the stores, as in the one-role kernel
+            if ((wv & 1) == 0)
+                ego_magnitudes_of_wave<A, true>(cfg, w, [&](int) { return map0; }, __ballot(a == 0), hit_m, off_m, &sh.a[0][0], &sh.b[0][0], lane, sh.poly,
+                                                a == 0 ? reinterpret_cast<float4 *>(st.magnitudes) + e : nullptr);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Three roles per group: the same loop with the judge split in two wavefronts, six wavefronts per SIMD (80 VGPRs each):
