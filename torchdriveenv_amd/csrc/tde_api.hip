@@ -193,12 +193,13 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     const bool packable = world->n_routes < id_max && world->n_replay < id_max && world->RW < len_max && world->RT < len_max;
     const bool trio_ok = st->slot_cache && st->env_cache && packable && (st->A == 8 || st->A == 16 || st->A == 32);
     const bool want_trio = force == 3 || (force == 0 && load_slots <= 131072);
-    // 128 agent slots per env: two roles (four wavefronts per env) when the action cache is there and the batch fits ONE residency round
-    // of that form (4 workgroups per CU) - the next step's controller then runs beside the judges' sweeps.  us per step, ~122 agents
+    // 128 agent slots per env: two roles (four wavefronts per env) when the action cache is there and the batch is at most HALF a residency
+    // round of that form (2 workgroups per CU: 512 envs) - the next step's controller then runs beside the judges' sweeps.  us per step, ~122 agents
     // per env, one role / two roles (profiles/r06_p_wide_step_forms.txt): 1 env 13.4 / 8.9 (the reference's own operating point),
-    // 64 envs 15.5 / 13.1, 256 16.1 / 14.4, 1024 19.1 / 18.8 (the sweeps' VALU work fills the chip either way), 2048 29.1 / 31.9.
+    // 64 envs 15.5 / 13.1, 256 16.1 / 14.4, 512 16.4 / 15.5, 1024 19.1 / 18.8 through ctypes but 17.8 / 18.5 through the extension (the sweeps' VALU
+    // work fills the chip either way), 2048 29.1 / 31.9.
     // tde_kernel_override(0, 1) forces the one-role kernel.
-    if (st->A == 128 && st->act_cache && force != 1 && st->B <= 4 * cu_count())
+    if (st->A == 128 && st->act_cache && force != 1 && st->B <= 2 * cu_count())
         return tde_host::launch_step_wide(cfg, world, st, tde_host::act_cfg_hash(*cfg, *world), stream);
     if (trio_ok && want_trio) {
         rc = first_gaps_launch(cfg, world, stream, true);                    // (first use of this world with this configuration)

@@ -374,9 +374,12 @@ TDE_DEV void load_ctx(const tde_config &cfg, const Cold &w, int a, Agent &ag, co
 // (wp1_out / scn_out: the scenario's entry and its second waypoint - the first TARGET of the new episode, target_idx = 1 - which
 //  this function reads anyway: the one-step three-role kernel parks them in LDS so that the re-spawn path, the tail every launch
 //  waits for, starts with the ego's reward context in hand instead of behind two dependent look-ups)
+// (heading_tab / NH: the world's heading table from the KERNEL ARGUMENTS - scalar registers - for the caller that runs this every step
+//  on a critical stretch, judge C of the one-step three-role kernel; by default from the cold block in LDS)
 TDE_DEV void ego_spawn(const tde_config &cfg, const Cold &w, int scn, const uint4 &r0, const uint4 &r1, float4 &pose, float4 &attr,
-                       double2 *wp1_out = nullptr, int4 *scn_out = nullptr)
+                       double2 *wp1_out = nullptr, int4 *scn_out = nullptr, const float *heading_tab = nullptr, int NH = -1)
 {
+    if (NH < 0) { NH = w.NH; heading_tab = w.start_psi; }
     const double *wp = w.wp_xy + (int64_t)scn * w.NW * 2;
     const double2 w0 = reinterpret_cast<const double2 *>(wp)[0], w1 = reinterpret_cast<const double2 *>(wp)[1];
     const int4 se = reinterpret_cast<const int4 *>(w.scn)[scn];               // map, wp_n, start_heading, pad
@@ -389,7 +392,7 @@ TDE_DEV void ego_spawn(const tde_config &cfg, const Cold &w, int scn, const uint
     // the lane direction at the start point (find_lanelet_directions, :359): the world's heading table along the first waypoint
     // segment at the drawn fraction, or - without one - the scenario's start heading
     float lane_psi = __int_as_float(se.z);
-    if (w.NH > 0) lane_psi = w.start_psi[(int64_t)scn * w.NH + (int)(f * (double)w.NH)];
+    if (NH > 0) lane_psi = heading_tab[(int64_t)scn * NH + (int)(f * (double)NH)];
     const double psi0 = (double)lane_psi + (double)normal_f32(r1.z, r1.w) * 0.1;
     pose = make_float4((float)sx, (float)sy, (float)psi0, (float)speed);
     attr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -2923,15 +2926,18 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
 #else
             if (mask_bit(dn, base) && valid) {
 #endif
+                // TDE_F_NPC_FIRST_STEP: the new episode's first actions are the next launch's (its prologue holds the ego's start);
+                // what it needs of the scenario - this slot's entry of the world's first-step gap cache - travels in the action slot.
+                // Requested AHEAD of the spawn record's loads (the new scenario is known from the parked draw): behind them it was a
+                // second memory round trip on the tail every launch waits for
+                uint2 fe = make_uint2(0u, 0u);
+                const bool fwd_lane = TDE_FIRST_GAP && kDrawAhead && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap && st.act_cache;
+                if (fwd_lane)
+                    fe = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)(int)(((uint64_t)sh.draw[lane / A][0].x * (uint64_t)cold.n_scn) >> 32) * A + a));
                 respawn_lane<A, kDrawAhead>(cfg, cold, e, a, ag, er, cx, false, sh.draw[lane / A][0], sh.draw[lane / A][1],
                                             kDrawAhead ? sh.ego_next[lane / A] : nullptr);
                 respawned = true;                                             // (its second route target: left to the next launch)
-                // TDE_F_NPC_FIRST_STEP: the new episode's first actions are the next launch's (its prologue holds the ego's start);
-                // what it needs of the scenario - this slot's entry of the world's first-step gap cache - travels in the action slot
-                if (TDE_FIRST_GAP && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap && st.act_cache) {
-                    const uint2 fe = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
-                    na2 = __uint_as_float(fe.x); nb2 = __uint_as_float(fe.y);
-                }
+                if (fwd_lane) { na2 = __uint_as_float(fe.x); nb2 = __uint_as_float(fe.y); }
             }
             // The re-spawn path is the tail every launch waits for (1.9 % of the envs finish per step, 7 % of the wavefronts
             // hold one): the controller's SWEEP is never repeated here for the re-spawned envs - without the gap cache (or the
@@ -2947,7 +2953,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
             float2 *ap = reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1);
             ap[a] = make_float2(na2, nb2);
             if (a == 0) {   // (re-spawn is per env: the ego lane's flag is the env's)
-                const bool fwd = TDE_FIRST_GAP && respawned && first_acts && (F & TDE_F_NPC) && w.first_gap;     // the slots hold forwarded gaps
+                const bool fwd = TDE_FIRST_GAP && kDrawAhead && respawned && first_acts && (F & TDE_F_NPC) && w.first_gap;     // the slots hold forwarded gaps
                 reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && (!respawned || fwd)) ? er.episode : -1,
                                                             act_key_steps(fwd ? act_hash ^ kGapForm : act_hash, er.steps));
             }
@@ -3026,7 +3032,7 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
             float4 pose, attr;
             double2 wp1;
             int4 sce;
-            ego_spawn(cfg, cold, (int)(((uint64_t)d0.x * (uint64_t)cold.n_scn) >> 32), d0, d1, pose, attr, &wp1, &sce);
+            ego_spawn(cfg, cold, (int)(((uint64_t)d0.x * (uint64_t)cold.n_scn) >> 32), d0, d1, pose, attr, &wp1, &sce, w.start_psi, w.NH);
             sh.ego_next[lane / A][0] = pose; sh.ego_next[lane / A][1] = attr;
             sh.ego_next_tgt[lane / A] = wp1; sh.ego_next_scn[lane / A] = sce;
         }
