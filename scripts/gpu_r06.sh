@@ -36,6 +36,12 @@ for what in "$@"; do
       cat $O/ab_lights.txt;;
     wide) python scripts/wide_times.py > $O/wide_times.txt 2>&1; grep -v amdgpu $O/wide_times.txt;;
     wideforms) python scripts/wide_step_forms.py > $O/wide_step_forms.txt 2>&1; grep -v amdgpu $O/wide_step_forms.txt;;
+    stamps) for L in ab/libS_nofg.so ab/libS_fg.so; do for opt in "--coast" ""; do echo "== $L $opt" >> $O/step_stamps.txt; TDE_HIP_LIB=$PWD/$L python scripts/step_stamps.py $opt 2>&1 | grep -v amdgpu >> $O/step_stamps.txt; done; done; cat $O/step_stamps.txt;;
+    abprio:*) LIBS=$(echo "${what#abprio:}" | tr ':' ' ')
+      for opt in "" "--outputs" "--lights"; do echo "== step $opt" >> $O/ab_step_prio.txt; python scripts/ab_step.py $opt $LIBS 2>&1 | grep -v amdgpu.ids | tail -7 >> $O/ab_step_prio.txt; done; cat $O/ab_step_prio.txt;;
+    robust) ( time TDE_FUZZ_CASES=120 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -n 8 ) > $O/fuzz360.txt 2>&1; tail -3 $O/fuzz360.txt
+      timeout 900 python scripts/soak.py > $O/soak.txt 2>&1; grep -v amdgpu $O/soak.txt | tail -8
+      timeout 900 python scripts/stress_step_forms.py 60 > $O/stress_step_forms.txt 2>&1; grep -v amdgpu $O/stress_step_forms.txt | tail -6;;
     bench) python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json;;
     *) echo "unknown phase $what";;
   esac

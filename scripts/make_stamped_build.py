@@ -210,14 +210,18 @@ def patched_source(mode):
 
 
 def main():
+    """python scripts/make_stamped_build.py MODE [OUT.so] [-DNAME=VAL ...]"""
     mode = sys.argv[1] if len(sys.argv) > 1 else "duo"
+    rest = sys.argv[2:]
+    extra = [a for a in rest if a.startswith("-")]
+    outs = [a for a in rest if not a.startswith("-")]
     s = patched_source(mode)
     os.makedirs(os.path.join(ROOT, "ab"), exist_ok=True)
-    tmp = os.path.join(ROOT, "ab", f"tde_kernels_{mode}_stamped.hip")
+    out = os.path.abspath(outs[0]) if outs else os.path.join(ROOT, "ab", "libS.so")
+    tmp = os.path.join(ROOT, "ab", f"tde_kernels_{mode}_stamped_{os.path.basename(out)[:-3]}.hip")
     open(tmp, "w").write(s)
-    out = os.path.join(ROOT, "ab", "libS.so")
-    cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "torchdriveenv_amd", "csrc"),
-                                              "-I" + os.path.join(ROOT, "include"), "-o", out, tmp]
+    cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-I" + os.path.join(ROOT, "torchdriveenv_amd", "csrc"),
+                                                      "-I" + os.path.join(ROOT, "include"), "-o", out, tmp]
     subprocess.run(cmd, check=True)
     print(out)
 

@@ -18,19 +18,23 @@ world = synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
 dw = world.to_device(dev)
 LIGHTS = "--lights" in sys.argv
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25, flags=_abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if LIGHTS else 0))
+if "--coast" in sys.argv:                                 # the opt-out of TDE_F_NPC_FIRST_STEP
+    cfg.flags &= ~_abi.F_NPC_FIRST_STEP
 _lib.kernel_override(step="trio")
 st = EnvState(B, A, device=dev, with_info=False)
 ops.env_reset(cfg, dw, st)
-act = torch.zeros(B, 2, device=dev)
-for _ in range(50):
-    ops.env_step(cfg, dw, st, action=act)
+g = torch.Generator().manual_seed(0)
+acts = torch.stack([torch.rand(250, B, generator=g) * 2 - 1, torch.rand(250, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)
+ops.env_rollout(cfg, dw, st, acts)                        # a steady-state mix of episode ages
+for i in range(50):
+    ops.env_step(cfg, dw, st, action=acts[i])
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 24)()
 lib.tde_debug_stamps(out, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(N):
-    ops.env_step(cfg, dw, st, action=act)
+for i in range(N):
+    ops.env_step(cfg, dw, st, action=acts[i % 250])
 e1.record()
 torch.cuda.synchronize()
 lib.tde_debug_stamps(out, 0)

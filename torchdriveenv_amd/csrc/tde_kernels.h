@@ -1484,6 +1484,10 @@ struct DuoShared {
     // three-role rollout kernel, judge C: the ego poses (x, y, psi, v) before / after the last up to A steps of every env
     // of the group, slot (env's first lane + step) - the reward arithmetic runs on a whole window at once (see there)
     float4 ring_pre[kWave], ring_post[kWave];
+    // three-role rollout kernel with traffic lights: every slot's gap to a red stop line for the driver's NEXT step, computed by judge C
+    // from the rows the driver's controller reads (slot = step & 1), and the step they were published for (-1: none yet)
+    float red_gap[2][kWave];
+    int red_seq;
     // one-step three-role kernel: Philox blocks 0 and 1 of every env's NEXT episode (what a re-spawn at this step would draw),
     // written by the driver's lanes 0 and 1 of the env ahead of barrier A
     uint4 draw[8][2];
@@ -2322,8 +2326,14 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     if (threadIdx.x == 0) {
         fill_cold(cold, cfg, w); sh.done = 0ull; sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull;
         sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
+        sh.red_seq = -1;
     }
     const uint32_t F = cfg.flags;
+    // Traffic lights (LIGHTS): the NPCs' gaps to red stop lines are JUDGE C's work - first thing behind barrier B, from the rows the
+    // driver's controller is reading at that moment, handed over through LDS (sh.red_gap / sh.red_seq; the driver needs them only at
+    // the end of its sweep).  In the driver the map's light fields, the red-mask window and the four-lines-per-trip loop (32
+    // registers) had the hot loop spill 40 VGPRs with ~17 scratch loads per step on its chain; judge C has the registers.
+    const bool lights = LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS);
     // The first-step gap cache pays where the controller's second pass walks stop lines (interleaved A/B at 8192 x 16, us per step,
     // cache / whole controller: with lights 3.92 / 4.13; without 2.935 / 2.905 - there the cheap path's code costs the loop more than
     // the re-spawned envs' second sweep does: profiles/r06_first_step_matrix.txt)
@@ -2361,14 +2371,12 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
     if (role == 0) {
         // ================================ drive ================================
         TDE_ROLE_PROLOGUE
-        RedCache redc; redc.invalidate();
         // issue priority in the order of the roles' chains (TDE_PRIO_* above); round 1, same-box A/B: (3,0,0) 4.00 us,
         // (3,2,0) 3.84, (2,1,0) 3.81, none 4.4-4.8
         __builtin_amdgcn_s_setprio(TDE_PRIO_D);
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
         write_rows(sh, 1, lane, valid && ag.present, ag, c0, s0, cfg.npc_lane_half);
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
         lds_barrier();                                       // rows of the launch state are in buffer 1; actions 0, 1 relayed
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1, q = p ^ 1;
@@ -2397,11 +2405,21 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     // gap cache had no entry for them (`again`), the controller runs a second time here, on the new episode's spawn
                     // rows in buffer q: the other envs' rows and state are unchanged, so their lanes get the first pass's values again.
                     if (pass == 0 || again) {
-                        const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
-                        const float red_gap =
-                            (LIGHTS && red && has_target) ? red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-                        npc_action<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
-                                      cx.g_far, red_gap, na, nb);
+                        const float gap = npc_gap<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, bit_of_row<A>(a), ag, c0, s0, has_target, cx.g_far);
+                        float red_gap = 1e30f;
+                        if (lights) {
+                            if (pass == 0) {
+                                // judge C's gaps for this step (published long before the sweep above ends: the wait is a formality)
+                                while (*reinterpret_cast<volatile int *>(&sh.red_seq) != i) __builtin_amdgcn_s_sleep(1);
+                                red_gap = *reinterpret_cast<volatile float *>(&sh.red_gap[p][lane]);
+                            } else if (has_target) {
+                                // (the second pass of a re-spawn without cached first-step gaps: rare - from the tables, by this wavefront)
+                                const tde_map m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
+                                const uint32_t red = red_mask(w, m, k);
+                                if (red) red_gap = red_line_gap(cfg, w, m, red, ag, c0, s0);
+                            }
+                        }
+                        npc_act_of_gap(cfg, ag, c0, s0, has_target, cx.tgx, cx.tgy, gap, has_target ? red_gap : 1e30f, na, nb);
                     }
                     if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }
                 }
@@ -2433,10 +2451,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     if (kGapCache && first_acts && (F & TDE_F_NPC) && a > 0 && w.first_gap)    // (in flight across the table look-ups of load_ctx)
                         fg_ent = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
-                    redc.invalidate();
                     sincos_f32(ag.psi, s0, c0);
                     write_rows(sh, q, lane, ag.present, ag, c0, s0, cfg.npc_lane_half);   // (the judges' pre-step rows of the new episode)
-                    if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache<A>(sh, w, cx.m, lane, a);
                 }
                 if (first_acts && (F & TDE_F_NPC)) {
                     // TDE_F_NPC_FIRST_STEP: the re-spawned lanes' first actions, from the world's first-step gap cache and ONE exact
@@ -2548,7 +2564,26 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             }
             return dn;
         };
-        lds_barrier();
+        // the NPCs' gaps to red stop lines for the driver's step `step` (its environment_steps = kk) from the rows in buffer `buf` -
+        // the rows the driver's controller of that step reads; a slot without a route gets a value the driver ignores
+        auto publish_red_gaps = [&](int step, int buf, int kk) {
+            __builtin_amdgcn_s_setprio(3);                   // (the driver needs them at the end of its sweep: ahead of this role's own work)
+            const float4 ra = sh.a[buf][lane], rb = sh.b[buf][lane];
+            float rg = 1e30f;
+            const uint32_t red = red_mask_cached(w, cx.m, kk, redc);
+            if (red) {
+                Agent me{};
+                me.x = ra.x; me.y = ra.y; me.len = 2.0f * rb.z;      // (0.5f * len == hl exactly: the driver's own operand)
+                rg = red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, me, rb.x, rb.y);
+            }
+            sh.red_gap[step & 1][lane] = rg;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wavefront's LDS writes complete in order: gaps, then the step)
+            if (lane == 0) *reinterpret_cast<volatile int *>(&sh.red_seq) = step;
+            __builtin_amdgcn_s_setprio(TDE_PRIO_C);
+        };
+        if (lights) fill_stop_cache<A>(sh, w, cx.m, lane, a);
+        lds_barrier();                                       // rows of the launch state are in buffer 1
+        if (lights) publish_red_gaps(0, 1, er.steps + 1);
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1, q = p ^ 1;
             lds_barrier();                                   // A: masks of step i-1 are complete
@@ -2560,11 +2595,13 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     if (batch) load_ego_ctx(cold, er, cx);
                     redc.invalidate();
+                    if (lights) fill_stop_cache<A>(sh, w, cx.m, lane, a);       // (the new map's lines: visible to judge O behind barrier B)
                 }
             }
             lds_barrier();                                   // B: rows of step i are in buffer p
             er.steps += 1;
             const int k = er.steps;
+            if (lights && i + 1 < ro.K) publish_red_gaps(i + 1, p, k + 1);      // the driver is computing step i + 1 from these rows now
             const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];
             if constexpr (A == 16 && TDE_COLLIDE_DPP)
                 hit = collide_rows_dpp16(&sh.a[p][base], &sh.b[p][base], a, rc.z != 0.0f, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, ra.z);
