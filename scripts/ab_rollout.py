@@ -33,12 +33,13 @@ ap.add_argument("--town", action="store_true", help="the 1 km x 1 km town map (s
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawns")
 ap.add_argument("--truncate-only", type=int, default=0, metavar="N",
                 help="no termination at infractions, truncation after N steps: every env re-spawns every N steps")
+ap.add_argument("--dark-world", action="store_true", help="a world WITHOUT stop lines / light cycles (with --lights: the LIGHTS kernel variant with nothing to do: what its code alone costs)")
 ap.add_argument("--coast", action="store_true", help="clear TDE_F_NPC_FIRST_STEP: the NPCs coast through an episode's first step (the rule of rounds 4 / 5)")
 args = ap.parse_args()
 
 B, A, K = args.envs, args.agents, args.steps
 dev = torch.device("cuda:0")
-world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell, n_signals=args.signals, signal_reach=args.signal_reach) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell)
+world = synthetic_town(n_scn=256, A=A, seed=0, cell=args.cell, n_signals=args.signals, signal_reach=args.signal_reach) if args.town else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4, cell=args.cell, lights=not args.dark_world)
 dw = world.to_device(dev)
 
 

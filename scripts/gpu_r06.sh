@@ -42,6 +42,8 @@ for what in "$@"; do
     robust) ( time TDE_FUZZ_CASES=120 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -n 8 ) > $O/fuzz360.txt 2>&1; tail -3 $O/fuzz360.txt
       timeout 900 python scripts/soak.py > $O/soak.txt 2>&1; grep -v amdgpu $O/soak.txt | tail -8
       timeout 900 python scripts/stress_step_forms.py 60 > $O/stress_step_forms.txt 2>&1; grep -v amdgpu $O/stress_step_forms.txt | tail -6;;
+    abdark:*) LIBS=$(echo "${what#abdark:}" | tr ':' ' ')
+      for opt in "" "--lights --dark-world" "--lights"; do echo "== rollout $opt" >> $O/ab_dark.txt; python scripts/ab_rollout.py $opt $LIBS 2>&1 | grep -v amdgpu.ids | tail -3 >> $O/ab_dark.txt; done; cat $O/ab_dark.txt;;
     bench) python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json;;
     *) echo "unknown phase $what";;
   esac

@@ -111,8 +111,8 @@ def patch_trio(s):
             "        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            const float2 act = sh.act[p][base];")
     k = sub(k, "                if (F & TDE_F_NPC) {\n                    // A second pass means that an env of this wavefront finished and its lanes were re-spawned: they are at the",
             "                tde_mark(&stl, 0);\n                if (F & TDE_F_NPC) {\n                    // A second pass means that an env of this wavefront finished and its lanes were re-spawned: they are at the")
-    k = sub(k, "                                      cx.g_far, red_gap, na, nb);\n                    }\n                    if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }",
-            "                                      cx.g_far, red_gap, na, nb, &stl);\n                    }\n                    if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }")
+    k = sub(k, "                        const float gap = npc_gap<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, bit_of_row<A>(a), ag, c0, s0, has_target, cx.g_far);\n                        float red_gap = 1e30f;\n                        if (lights) {\n                            if (pass == 0) {",
+            "                        const float gap = npc_gap<A>(cfg, &sh.a[q][base], &sh.b[q][base], a, bit_of_row<A>(a), ag, c0, s0, has_target, cx.g_far, &stl);\n                        tde_mark(&stl, 2);\n                        float red_gap = 1e30f;\n                        if (lights) {\n                            if (pass == 0) {")
     k = sub(k, "                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;\n", "                tde_mark(&stl, 3);\n                nx = ag.x; ny = ag.y; npsi = ag.psi; nv = ag.v;\n")
     k = sub(k, "                switched = false;\n                nwp = ag.route_wp;", "                tde_mark(&stl, 4);\n                switched = false;\n                nwp = ag.route_wp;")
     k = sub(k, "                sincos_f32(npsi, ns, nc);\n                TDE_PROBE(TDE_DUMMY_D, nx);\n                if (pass) break;\n                lds_barrier();                               // A: the judges' masks of step i-1 are published\n",
@@ -120,10 +120,10 @@ def patch_trio(s):
     k = sub(k, "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            if (switched) load_route_target(cold, ag, cx);\n        }\n",
             "            write_rows(sh, p, lane, live, ag, c0, s0, cfg.npc_lane_half);\n            tde_mark(&stl, 7);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 8);\n            if (switched) load_route_target(cold, ag, cx);\n            tde_mark(&stl, 9);\n        }\n        tde_flush(0, 10);\n")
     # ---- judge C
-    k = sub(k, "        lds_barrier();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
-            "        lds_barrier();\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 12);\n")
-    k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)",
-            "            tde_mark(&stl, 13);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 14);\n            er.steps += 1;\n            const int k = er.steps;\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)")
+    k = sub(k, "        if (lights) publish_red_gaps(0, 1, er.steps + 1);\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n",
+            "        if (lights) publish_red_gaps(0, 1, er.steps + 1);\n        unsigned long long stl = __builtin_amdgcn_s_memtime();\n        for (int i = 0; i < ro.K; ++i) {\n            const int p = i & 1, q = p ^ 1;\n            lds_barrier();                                   // A: masks of step i-1 are complete\n            tde_mark(&stl, 12);\n")
+    k = sub(k, "            lds_barrier();                                   // B: rows of step i are in buffer p\n            er.steps += 1;\n            const int k = er.steps;\n            if (lights && i + 1 < ro.K) publish_red_gaps(i + 1, p, k + 1);      // the driver is computing step i + 1 from these rows now\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)",
+            "            tde_mark(&stl, 13);\n            lds_barrier();                                   // B: rows of step i are in buffer p\n            tde_mark(&stl, 14);\n            er.steps += 1;\n            const int k = er.steps;\n            if (lights && i + 1 < ro.K) publish_red_gaps(i + 1, p, k + 1);      // the driver is computing step i + 1 from these rows now\n            const float4 ra = sh.a[p][lane], rb = sh.b[p][lane], rc = sh.c[p][lane];\n            if constexpr (A == 16 && TDE_COLLIDE_DPP)")
     k = sub(k, "            if (lane == 0) sh.hit_mask = m;\n", "            if (lane == 0) sh.hit_mask = m;\n            tde_mark(&stl, 15);\n")
     k = sub(k, "                ro.reward[(int64_t)i * LB + e] = 0.0f;\n            }\n        }\n        lds_barrier();                                       // A'",
             "                ro.reward[(int64_t)i * LB + e] = 0.0f;\n            }\n            tde_mark(&stl, 16);\n        }\n        tde_flush(12, 17);\n        lds_barrier();                                       // A'")

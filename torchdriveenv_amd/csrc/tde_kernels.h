@@ -1002,6 +1002,9 @@ TDE_DEV uint32_t red_mask_cached(const tde_world &w, const tde_map &m, int k, Re
 #define TDE_RED_GAP_LINES 4         // stop lines fetched and tested side by side per trip of the wide loops (2 x 4 registers each)
 #endif
 constexpr int kLinesPerTrip = TDE_RED_GAP_LINES;
+#ifndef TDE_JUDGE_GAP_LINES
+#define TDE_JUDGE_GAP_LINES 4       // ... in judge C's red-gap relay of the three-role rollout kernel (its registers, not the driver's chain)
+#endif
 // compute_traffic_lights_violations() > 0 for the ego box (gym_env.py:144,415,429): it overlaps a stop line whose light
 // is red.  Mirrors tde_tl_violation of the oracle.
 // `line(i, a, b)` fetches stop line i of the map: (x, y, cos, sin) and (hl, hw, light, -)
@@ -1070,10 +1073,11 @@ TDE_DEV bool tl_violation(const tde_world &w, const tde_map &m, uint32_t red, fl
 
 // gap to a red stop line ahead in the own lane (same travel direction), treated as a standing leader by the NPC
 // controller.  Mirrors the stop-line loop of the oracle's tde_npc_action.
-template <typename L>
+template <typename L, int kLinesPerTrip = TDE_RED_GAP_LINES>
 TDE_DEV float red_line_gap_of(const tde_config &cfg, const L &line, int n_stop, uint32_t red, const Agent &ag, float cp,
                               float sp)
 {
+    static_assert(L::kCached % kLinesPerTrip == 0, "a trip lies inside or outside the LDS cache");
     float gap = 1e30f;
 #if TDE_RED_GAP_WIDE
     // four lines per trip, all fetched first, the four tests side by side and branch-free (a minimum over the same values in
@@ -1488,6 +1492,7 @@ struct DuoShared {
     // from the rows the driver's controller reads (slot = step & 1), and the step they were published for (-1: none yet)
     float red_gap[2][kWave];
     int red_seq;
+    int4 lights2[2][8];                  // ... and per env (red mask at that step, -, stop_base, n_stop) for judge O's violation test
     // one-step three-role kernel: Philox blocks 0 and 1 of every env's NEXT episode (what a re-spawn at this step would draw),
     // written by the driver's lanes 0 and 1 of the env ahead of barrier A
     uint4 draw[8][2];
@@ -1551,6 +1556,18 @@ struct CachedLines {
     TDE_DEV void global(int i, float4 &a, float4 &b) const { a = reinterpret_cast<const float4 *>(base + i)[0]; b = reinterpret_cast<const float4 *>(base + i)[1]; }
 };
 
+
+// the same when ALL of the map's stop lines are in the LDS cache (n_stop <= kStopCache: the junction maps, a town's light groups): no
+// global path - whose 64-bit addresses for four lines per trip are a dozen registers of the loop - in the instantiation at all
+template <int A>
+struct CacheOnlyLines {
+    const DuoShared &sh;
+    int envw;
+    static constexpr int kCached = 1 << 20;
+    TDE_DEV void cached(int i, float4 &a, float4 &b) const { a = sh.stop[envw][i][0]; b = sh.stop[envw][i][1]; }
+    TDE_DEV void global(int i, float4 &a, float4 &b) const { cached(i, a, b); }
+    TDE_DEV void operator()(int i, float4 &a, float4 &b) const { cached(i, a, b); }
+};
 
 TDE_DEV void write_rows(DuoShared &sh, int buf, int lane, bool live, const Agent &ag, float c, float s, float lane_half)
 {
@@ -2416,7 +2433,8 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                                 // (the second pass of a re-spawn without cached first-step gaps: rare - from the tables, by this wavefront)
                                 const tde_map m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
                                 const uint32_t red = red_mask(w, m, k);
-                                if (red) red_gap = red_line_gap(cfg, w, m, red, ag, c0, s0);
+                                // (a line at a time: this path's registers are the hot loop's spills)
+                                if (red) red_gap = red_line_gap_of<GlobalLines, 1>(cfg, GlobalLines{w.stoplines + m.stop_base}, m.n_stop, red, ag, c0, s0);
                             }
                         }
                         npc_act_of_gap(cfg, ag, c0, s0, has_target, cx.tgx, cx.tgy, gap, has_target ? red_gap : 1e30f, na, nb);
@@ -2574,9 +2592,13 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             if (red) {
                 Agent me{};
                 me.x = ra.x; me.y = ra.y; me.len = 2.0f * rb.z;      // (0.5f * len == hl exactly: the driver's own operand)
-                rg = red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, me, rb.x, rb.y);
+                if (cx.m.n_stop <= kStopCache)               // (every line in the LDS cache: the form without a global path)
+                    rg = red_line_gap_of<CacheOnlyLines<A>, TDE_JUDGE_GAP_LINES>(cfg, CacheOnlyLines<A>{sh, lane / A}, cx.m.n_stop, red, me, rb.x, rb.y);
+                else
+                    rg = red_line_gap_of<CachedLines<A>, TDE_JUDGE_GAP_LINES>(cfg, CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red, me, rb.x, rb.y);
             }
             sh.red_gap[step & 1][lane] = rg;
+            if (a == 0) sh.lights2[step & 1][lane / A] = make_int4((int)red, 0, cx.m.stop_base, cx.m.n_stop);   // (judge O's, behind barrier B)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wavefront's LDS writes complete in order: gaps, then the step)
             if (lane == 0) *reinterpret_cast<volatile int *>(&sh.red_seq) = step;
             __builtin_amdgcn_s_setprio(TDE_PRIO_C);
@@ -2595,7 +2617,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
                     if (batch) load_ego_ctx(cold, er, cx);
                     redc.invalidate();
-                    if (lights) fill_stop_cache<A>(sh, w, cx.m, lane, a);       // (the new map's lines: visible to judge O behind barrier B)
+                    if (lights) {                            // (the new episode's map: visible to judge O behind barrier B)
+                        fill_stop_cache<A>(sh, w, cx.m, lane, a);
+                        if (a == 0) sh.lights2[p][lane / A] = make_int4((int)red_mask_cached(w, cx.m, 1, redc), 0, cx.m.stop_base, cx.m.n_stop);
+                    }
                 }
             }
             lds_barrier();                                   // B: rows of step i are in buffer p
@@ -2643,7 +2668,6 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
         // ===================== judge O: offroad, stop lines =====================
         __builtin_amdgcn_s_setprio(TDE_PRIO_O);
         TDE_ROLE_PROLOGUE
-        RedCache redc; redc.invalidate();
         const float thr2 = thr2_of(cfg);
         bool off = false, tl = false;
         // action relay: this wavefront (lowest priority, off the simulation's serial chain) fetches the ego actions two
@@ -2668,7 +2692,6 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
                 if (dn && mask_bit(dn, base) && valid) {
                     reset_lane<A>(cfg, cold, e, a, ag, er);
                     load_ctx<A>(cfg, cold, a, ag, er, cx);
-                    redc.invalidate();
                 }
             }
             er.steps += 1;
@@ -2678,8 +2701,11 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(6, 6)
             off = false;
             if (F & TDE_F_OFFROAD) off = box_offroad<false, BIG || TDE_ROLLOUT_CLS2>(w, cx.m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
             tl = false;
-            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-                tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + cx.m.stop_base, lane / A}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+            if (lights && a == 0 && valid) {
+                const int4 lw = sh.lights2[p][lane / A];     // judge C's: (red mask at this step, -, stop_base, n_stop) of the env's map
+                if (lw.w <= kStopCache) tl = tl_violation_of(CacheOnlyLines<A>{sh, lane / A}, lw.w, (uint32_t)lw.x, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+                else tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + lw.z, lane / A}, lw.w, (uint32_t)lw.x, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+            }
             TDE_PROBE(TDE_DUMMY_O, ra.x);
             const unsigned long long om = __ballot(off), tm = __ballot(tl);
             if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
