@@ -2910,11 +2910,14 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
                 if (early) {
                     const tde_map m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
                     const uint32_t red = red_mask(w, m, k);
-                    if (red && has_target) red_gap = red_line_gap(cfg, w, m, red, ag, c0, s0);
+                    // (a line at a time: this rare path's registers would be the launch's straight path's)
+                    if (red && has_target) red_gap = red_line_gap_of<GlobalLines, 1>(cfg, GlobalLines{w.stoplines + m.stop_base}, m.n_stop, red, ag, c0, s0);
                 } else {
                     const int4 lw = sh.lights[lane / A];
-                    if (lw.y && has_target)
-                        red_gap = red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + lw.z, lane / A}, lw.w, (uint32_t)lw.y, ag, c0, s0);
+                    if (lw.y && has_target) {                // (all of the map's lines in the LDS cache: the form without a global path)
+                        if (lw.w <= kStopCache) red_gap = red_line_gap_of(cfg, CacheOnlyLines<A>{sh, lane / A}, lw.w, (uint32_t)lw.y, ag, c0, s0);
+                        else red_gap = red_line_gap_of(cfg, CachedLines<A>{sh, w.stoplines + lw.z, lane / A}, lw.w, (uint32_t)lw.y, ag, c0, s0);
+                    }
                 }
             }
             return red_gap;
@@ -3244,8 +3247,10 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
                 off = box_offroad<true, TDE_STEP_CLS2 != 0>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, thr2);
             }
         }
-        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid)
-            tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + m.stop_base, lane / A}, m.n_stop, red_k, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+        if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0 && valid) {
+            if (m.n_stop <= kStopCache) tl = tl_violation_of(CacheOnlyLines<A>{sh, lane / A}, m.n_stop, red_k, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+            else tl = tl_violation_of(CachedLines<A>{sh, w.stoplines + m.stop_base, lane / A}, m.n_stop, red_k, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w);
+        }
         const unsigned long long om = __ballot(off), tm = __ballot(tl);
         if (lane == 0) { sh.off_mask = om; sh.tl_mask = tm; }
         // the ego's psi term for judge C (get_reward :403; ring_pre is the rollout kernel's, unused in a one-step launch)
