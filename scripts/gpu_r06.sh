@@ -44,6 +44,8 @@ for what in "$@"; do
       timeout 900 python scripts/stress_step_forms.py 60 > $O/stress_step_forms.txt 2>&1; grep -v amdgpu $O/stress_step_forms.txt | tail -6;;
     abdark:*) LIBS=$(echo "${what#abdark:}" | tr ':' ' ')
       for opt in "" "--lights --dark-world" "--lights"; do echo "== rollout $opt" >> $O/ab_dark.txt; python scripts/ab_rollout.py $opt $LIBS 2>&1 | grep -v amdgpu.ids | tail -3 >> $O/ab_dark.txt; done; cat $O/ab_dark.txt;;
+    smoke) ( time python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.txt 2>&1; tail -4 $O/smoke.txt;;
+    durations) ( time timeout 1800 python -m pytest tests -m gpu -q --durations=25 ) > $O/pytest_durations.txt 2>&1; tail -40 $O/pytest_durations.txt;;
     bench) python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json;;
     *) echo "unknown phase $what";;
   esac

@@ -37,6 +37,8 @@ def test_hip_step_tracks_a_pytorch_fp32_step(small_world, form):
     cfg = _abi.default_config(seed=4, distance_cutoff=0.25)
     B, A = 64, 16
     _lib.kernel_override(step=form)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, 4))                        # (64 x 16 tensors: a hundred host threads only fight over them)
     try:
         dw = small_world.to_device(DEV)
         ds, hs = EnvState(B, A, device=DEV), EnvState(B, A)
@@ -70,12 +72,13 @@ def test_hip_step_tracks_a_pytorch_fp32_step(small_world, form):
             obs.reward(d["reward"], hs["reward"])
             # masks: the torch side's post-step state (= the device's within 1e-5) gives every slot's decision margin
             obs.rec["slot_steps"] += int(live.sum())
-            bad_c = obs.mask("collided", d["collided"], hs["collided"], collision_margin(hs, B, A), live)
-            bad_o = obs.mask("offroad", d["offroad"], hs["offroad"], offroad_margin(hs, B, A, tw, scn_map, cfg.offroad_threshold), live)
+            cm, om = collision_margin(hs, B, A), offroad_margin(hs, B, A, tw, scn_map, cfg.offroad_threshold)
+            bad_c = obs.mask("collided", d["collided"], hs["collided"], cm, live)
+            bad_o = obs.mask("offroad", d["offroad"], hs["offroad"], om, live)
             assert bad_c == 0 and bad_o == 0, (t, bad_c, bad_o)
             # a finished env's flags: done must agree unless its ego sits inside a band (then the episode ends on one side only)
             t_done = (hs["terminated"] | hs["truncated"]).astype(bool)
-            ego_band = (np.minimum(collision_margin(hs, B, A), offroad_margin(hs, B, A, tw, scn_map, cfg.offroad_threshold)).reshape(B, A)[:, 0] <= BAND)
+            ego_band = np.minimum(cm, om).reshape(B, A)[:, 0] <= BAND
             assert (done == t_done)[~ego_band].all(), t
             ego_off, ego_col = (d["done_bits"] >> 2) & 1, (d["done_bits"] >> 3) & 1
             assert (ego_off == hs["offroad"].reshape(B, A)[:, 0])[~done & ~ego_band].all() and (ego_col == hs["collided"].reshape(B, A)[:, 0])[~done & ~ego_band].all()
@@ -86,6 +89,7 @@ def test_hip_step_tracks_a_pytorch_fp32_step(small_world, form):
                   what=f"tde_env_step ({form}) vs oracle/torch_step.py, 64 envs x 16 agents x 120 teacher-forced steps", n_collided=n_coll, n_offroad=n_off)
     finally:
         _lib.kernel_override()
+        torch.set_num_threads(nthr)
 
 
 def test_hip_kinematics_within_1e5_of_torch_fp32():

@@ -9,9 +9,6 @@ slot's decision is from flipping, so that the tests can demand EQUAL masks on ev
   offroad    margin_i = min over the four box corners of |distance to the mesh - threshold| (ref gym_env.py:142)
 """
 import numpy as np
-import torch
-
-from oracle.torch_step import point_mesh_d2
 
 BAND = 1e-4          # metres: the band around a mask's decision threshold inside which two fp32 evaluations may disagree
 
@@ -34,6 +31,26 @@ def collision_margin(st, B, A):
     return np.where(ok, np.abs(slack), np.inf).min(2).reshape(-1)
 
 
+def _seg_d2(px, py, ax, ay, bx, by):
+    abx, aby = bx - ax, by - ay
+    apx, apy = px[:, None] - ax, py[:, None] - ay
+    t = np.clip((apx * abx + apy * aby) / np.maximum(abx * abx + aby * aby, 1e-300), 0.0, 1.0)
+    qx, qy = apx - t * abx, apy - t * aby
+    return qx * qx + qy * qy
+
+
+def _mesh_dist(px, py, tri):
+    """distance of points (float64 [n]) to a triangle soup [T, 3, 2] (0 inside), brute force in numpy"""
+    ax, ay, bx, by, cx, cy = (tri[None, :, i, j] for i in range(3) for j in range(2))
+    x, y = px[:, None], py[:, None]
+    e0 = (bx - ax) * (y - ay) - (by - ay) * (x - ax)
+    e1 = (cx - bx) * (y - by) - (cy - by) * (x - bx)
+    e2 = (ax - cx) * (y - cy) - (ay - cy) * (x - cx)
+    inside = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+    d2 = np.minimum(np.minimum(_seg_d2(px, py, ax, ay, bx, by), _seg_d2(px, py, bx, by, cx, cy)), _seg_d2(px, py, cx, cy, ax, ay))
+    return np.sqrt(np.where(inside, 0.0, d2).min(1))
+
+
 def offroad_margin(st, B, A, tw, scn_map, thr):
     x, y, psi = (np.asarray(st[k], np.float64).reshape(B, A) for k in ("x", "y", "psi"))
     hl, hw = 0.5 * np.asarray(st["len"], np.float64).reshape(B, A), 0.5 * np.asarray(st["wid"], np.float64).reshape(B, A)
@@ -42,12 +59,12 @@ def offroad_margin(st, B, A, tw, scn_map, thr):
     maps = scn_map[np.asarray(st["scn"]).astype(np.int64)]
     for m in np.unique(maps):
         e = np.flatnonzero(maps == m)
-        tri = tw.tris[int(m)].to(torch.float64)
+        tri = tw.tris[int(m)].numpy().astype(np.float64)
         best = np.full((len(e), A), np.inf)
         for sl, sw in ((1, 1), (1, -1), (-1, -1), (-1, 1)):
             px = x[e] + sl * hl[e] * c[e] - sw * hw[e] * s[e]
             py = y[e] + sl * hl[e] * s[e] + sw * hw[e] * c[e]
-            d = np.sqrt(point_mesh_d2(torch.from_numpy(np.stack([px.reshape(-1), py.reshape(-1)], -1)), tri).numpy()).reshape(len(e), A)
+            d = _mesh_dist(px.reshape(-1), py.reshape(-1), tri).reshape(len(e), A)
             best = np.minimum(best, np.abs(d - thr))
         out[e] = best
     return out.reshape(-1)
