@@ -494,3 +494,46 @@ def test_make_with_traffic_lights_terminates_at_a_red_line_and_reports_the_viola
     t_red, term_red, tl_red = results["red"]
     assert term_red and tl_red > 0 and t_red < 79                                   # stopped by the red line
     assert results["green"][2] == 0.0 and results["green"][0] > t_red              # the same drive passes it on green
+
+
+def test_batched_and_vec_env_report_red_line_violations(tmp_path):
+    """BatchedWaypointEnv / WaypointVecEnv on a WaypointSuite WITH `traffic_lights=`: the world carries light groups, the env steps with
+    TDE_F_TRAFFIC_LIGHTS (nobody has to ask), the device-side info and the SB3-shaped per-env infos both report the ego's red-line
+    violations, and they are the oracle's"""
+    from tests.golden_util import write_validation_suite_yaml
+    from torchdriveenv_amd.env import world_from_waypoint_suite
+    from torchdriveenv_amd.loaders import load_waypoint_suite_data
+
+    val = load_waypoint_suite_data(write_validation_suite_yaml(str(tmp_path / "validation_cases.yml")))
+    lights, field = _validation_lights_and_headings(val)
+    B = 96
+    ecfg = EnvConfig(seed=31, distance_cutoff=0.25, use_background_traffic=False, max_environment_steps=60, device="cuda:0")
+    env = BatchedWaypointEnv(ecfg, val, num_envs=B, agents_per_env=8, obs_mode="state", traffic_lights=lights, start_headings=field)
+    assert env.world.has_lights and (env.tde_cfg.flags & _abi.F_TRAFFIC_LIGHTS) and env.world.ints["NH"] == 16
+    world = world_from_waypoint_suite(val, agents_per_env=8, traffic_lights=lights, start_headings=field)
+    hs = EnvState(B, 8)
+    oracle.env_reset(env.tde_cfg, world, hs)
+    env.reset()
+    rng = np.random.default_rng(5)
+    seen = 0
+    for t in range(120):
+        act = np.stack([rng.uniform(0.2, 1.0, B), rng.normal(0.0, 0.03, B).clip(-0.3, 0.3)], -1).astype(np.float32)
+        hs["action"][...] = act
+        oracle.env_step(env.tde_cfg, world, hs)
+        _, rew, term, trunc, info = env.step(torch.from_numpy(act).to("cuda:0"))
+        tl = info["traffic_light_violation"].cpu().numpy()
+        assert np.array_equal(tl, hs["tl_violation"].astype(np.float32)) and np.array_equal(rew.cpu().numpy().view(np.uint32), hs["reward"].view(np.uint32))
+        seen += int(tl.sum())
+    assert seen > 0 and int(hs["episode"].max()) >= 2
+    # the SB3-shaped path: the column is there and carries violations too
+    venv = BatchedWaypointEnv(ecfg, val, num_envs=B, agents_per_env=8, obs_mode="state", traffic_lights=lights, start_headings=field).as_vec_env()
+    venv.reset()
+    n = 0
+    for t in range(120):
+        act = np.stack([rng.uniform(0.2, 1.0, B), np.zeros(B)], -1).astype(np.float32)
+        _, _, dones, infos = venv.step(act)
+        n += int(np.asarray(infos.column("traffic_light_violation")).sum())
+        if dones.any():
+            i = int(np.flatnonzero(dones)[0])
+            assert "terminal_observation" in infos[i] and "traffic_light_violation" in infos[i]
+    assert n > 0
