@@ -30,6 +30,7 @@ ap.add_argument("--lights", action="store_true", help="with TDE_F_TRAFFIC_LIGHTS
 ap.add_argument("--kernel", default=None, choices=["solo", "trio"])
 ap.add_argument("--endless", action="store_true", help="episodes never end (no termination, no truncation): no re-spawn tail")
 ap.add_argument("--outputs", action="store_true", help="with info / done bits / episode statistics / compact observation")
+ap.add_argument("--plain", action="store_true", help="time plain launches (K per block, through ctypes) instead of graph replays: the kernarg path of a real closed loop")
 ap.add_argument("--coast", action="store_true", help="clear TDE_F_NPC_FIRST_STEP: the NPCs coast through an episode's first step (the rule of rounds 4 / 5)")
 args = ap.parse_args()
 B, A, K = args.envs, args.agents, args.steps
@@ -81,11 +82,16 @@ for r in range(args.replays):
     for path, L, st, graph, ts, _ in handles:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        graph.replay()
+        if args.plain:
+            s0 = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            for s in _:
+                L.tde_env_step(C.byref(cfg), C.byref(dw.struct), C.byref(s), s0)
+        else:
+            graph.replay()
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / K)
-print(f"closed loop, {B} envs x {A} agents, {'town' if args.town else 'junction maps'}, {K} launches per graph, {args.replays} "
+print(("PLAIN LAUNCHES; " if args.plain else "") + f"closed loop, {B} envs x {A} agents, {'town' if args.town else 'junction maps'}, {K} launches per graph, {args.replays} "
       f"interleaved replays per library, kernel={args.kernel or 'auto'}, outputs={int(args.outputs)}, endless={int(args.endless)}")
 for path, L, st, graph, ts, _ in handles:
     print(f"  {path:40s} median {statistics.median(ts):6.3f}  min {min(ts):6.3f}  mean {statistics.mean(ts):6.3f} us/step")

@@ -57,6 +57,12 @@ extern "C" __attribute__((visibility("default"))) int tde_debug_stamps(unsigned 
     }
     return (int)e;
 }
+// the raw per-workgroup slots (wide patch: slots 20 / 21 / 22 = s_memrealtime, 100 MHz, at the workgroup's entry / the drive wavefront's end /
+// the judge wavefront's end of the LAST launch)
+extern "C" __attribute__((visibility("default"))) int tde_debug_wg(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tde::g_wg), sizeof(unsigned long long) * 4096 * 24);
+}
 '''
 ANCHOR = "template <int A> struct MaskOf { using type = uint32_t; };"
 
@@ -147,8 +153,8 @@ def patch_step3(s):
     """milestones of env_step_trio_kernel per role (ticks between marks): drive 0-5, C 8-12, O 16-19"""
     a, b = kernel_span(s, "env_step_trio_kernel")
     k = s[a:b]
-    k = sub(k, "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n    if (threadIdx.x == 0) {\n        fill_cold(cold, cfg, w); sh.hit_mask = 0ull;",
-            "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) {\n        fill_cold(cold, cfg, w); sh.hit_mask = 0ull;")
+    k = sub(k, "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n",
+            "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n")
     # drive
     k = sub(k, "        float c0, s0;\n        const bool live = valid && ag.present;\n        const int k = er.steps + 1;",
             "        tde_mark(&stl, 0);\n        float c0, s0;\n        const bool live = valid && ag.present;\n        const int k = er.steps + 1;")
@@ -194,7 +200,45 @@ def patch_trips(s):
     return s
 
 
-PATCHES = {"duo": patch_duo, "trio": patch_trio, "step3": patch_step3, "trips": patch_trips}
+def patch_wide(s):
+    """milestones of env_step_wide_kernel (128 slots, two roles), wavefronts 0 (drive) and 2 (judge) only: drive 0-7, judge 8-15"""
+    a, b = kernel_span(s, "env_step_wide_kernel")
+    k = s[a:b]
+    k = sub(k, "    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot\n",
+            "    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n"
+            "    unsigned long long *sp = (wv & 1) ? nullptr : &stl;\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n"
+            "    if (threadIdx.x == 0) g_wg[blockIdx.x & 4095][20] = __builtin_amdgcn_s_memrealtime();\n")
+    k = sub(k, "    if (wv == 2 && lane == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }\n",
+            "    if (wv == 2 && lane == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }\n    if (wv == 2) { asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); tde_mark(sp, 16); }\n")
+    k = sub(k, "        if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }\n",
+            "        if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }\n        tde_mark(sp, 17);\n")
+    # drive
+    k = sub(k, "        lds_barrier();                                       // cold is published\n        Ctx cx;\n        bool rebuilt;\n",
+            "        lds_barrier();                                       // cold is published\n        tde_mark(sp, 0);\n        Ctx cx;\n        bool rebuilt;\n")
+    k = sub(k, "        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n",
+            "        tde_mark(sp, 1);\n        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n        tde_mark(sp, 2);\n")
+    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(0);",
+            "        tde_mark(sp, 3);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 4);\n        __builtin_amdgcn_s_setprio(0);")
+    k = sub(k, "        lds_barrier();                                       // A: the env's done flag is published\n",
+            "        tde_mark(sp, 5);\n        lds_barrier();                                       // A: the env's done flag is published\n        tde_mark(sp, 6);\n")
+    k = sub(k, "            if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));\n        }\n",
+            "            if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));\n        }\n"
+            "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        tde_mark(sp, 7);\n        if (sp) { tde_flush(0, 8); tde_flush(17, 18); }\n        if (wv == 0 && lane == 0) g_wg[blockIdx.x & 4095][21] = __builtin_amdgcn_s_memrealtime();\n")
+    # judge
+    k = sub(k, "        lds_barrier();                                       // E\n        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2\n",
+            "        tde_mark(sp, 8);\n        lds_barrier();                                       // E\n        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2\n")
+    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(2);\n",
+            "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 9);\n        __builtin_amdgcn_s_setprio(2);\n")
+    k = sub(k, "        wide_sym_publish(sh, wv & 1, lane, 1);\n", "        wide_sym_publish(sh, wv & 1, lane, 1);\n        tde_mark(sp, 10);\n")
+    k = sub(k, "        hit |= wide_sym_joined(sh, wv & 1, a, 1);\n", "        tde_mark(sp, 11);\n        hit |= wide_sym_joined(sh, wv & 1, a, 1);\n        tde_mark(sp, 12);\n")
+    k = sub(k, "        lds_barrier();                                       // A\n        const bool respawned = sh.done != 0;\n        st.collided[g]",
+            "        tde_mark(sp, 13);\n        lds_barrier();                                       // A\n        tde_mark(sp, 14);\n        const bool respawned = sh.done != 0;\n        st.collided[g]")
+    k = sub(k, "        if constexpr (MAG) {\n            // tde_state.magnitudes for a flagged ego (get_info's \"collision\" / \"offroad\", :427-428), by the ego's wavefront from the\n",
+            "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        tde_mark(sp, 15);\n        if (sp) tde_flush(8, 17);\n        if (wv == 2 && lane == 0) g_wg[blockIdx.x & 4095][22] = __builtin_amdgcn_s_memrealtime();\n        if constexpr (MAG) {\n            // tde_state.magnitudes for a flagged ego (get_info's \"collision\" / \"offroad\", :427-428), by the ego's wavefront from the\n")
+    return s[:a] + k + s[b:]
+
+
+PATCHES = {"duo": patch_duo, "trio": patch_trio, "step3": patch_step3, "trips": patch_trips, "wide": patch_wide}
 
 
 def patched_source(mode):

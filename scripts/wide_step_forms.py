@@ -10,12 +10,12 @@ dev = torch.device("cuda:0")
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
 world = synthetic_town(n_scn=32, A=128, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4)
 dw = world.to_device(dev)
-for B in (1, 16, 64, 256, 512, 768, 1024, 2048):
+for B in (1, 16, 64, 256, 512, 768, 1024, 1536, 2048):
     g = torch.Generator().manual_seed(0)
     actions = torch.stack([torch.rand(250, B, generator=g) * 2 - 1, torch.rand(250, B, generator=g) * 0.6 - 0.3], -1).float().contiguous().to(dev)
     rows = [actions[i] for i in range(250)]
     out = []
-    for form in ("solo", None):
+    for form in ("solo", "duo", None):
         _lib.kernel_override(step=form)
         st = EnvState(B, 128, device=dev, with_info=False)
         ops.env_reset(cfg, dw, st)
@@ -26,4 +26,4 @@ for B in (1, 16, 64, 256, 512, 768, 1024, 2048):
         e1.record(); torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1))
     _lib.kernel_override()
-    print(f"B={B:5d} x 128 slots: one role {out[0]:7.2f} us, two roles {out[1]:7.2f} us per step", flush=True)
+    print(f"B={B:5d} x 128 slots: one role {out[0]:7.2f} us, two roles {out[1]:7.2f} us, the library's choice {out[2]:7.2f} us per step", flush=True)

@@ -168,6 +168,99 @@ def test_step_128_slots_above_one_residency_round():
     assert torch.equal(ds["obs"], ops.state_obs(dw, ds)) and int(hs["episode"].max()) >= 3
 
 
+def test_wide_step_argument_blocks_across_states_streams_and_graph_capture(crowded_town):
+    """The two-role 128-slot step kernel takes its arguments from an immutable block in device memory (tde_api.hip: step_args), one per
+    distinct argument set, uploaded once per stream.  Two batches stepped alternately on two streams, then a HIP graph that captured
+    three launches (after a warm-up on the capturing stream: blocks in place) and is replayed, then a THIRD batch whose first step
+    ever falls inside a capture (no block can be made there: the library launches the one-role kernel): all == the oracle."""
+    world = crowded_town
+    cfg = _abi.default_config(seed=47, distance_cutoff=0.25, max_steps=12)
+    dw = world.to_device(DEV)
+    A = 128
+    rng = np.random.default_rng(5)
+    sizes = (3, 5, 2)
+    hosts = [EnvState(B, A) for B in sizes]
+    devs = [EnvState(B, A, device=DEV) for B in sizes]
+    for h, d in zip(hosts, devs):
+        oracle.env_reset(cfg, world, h)
+        ops.env_reset(cfg, dw, d)
+    torch.cuda.synchronize()
+
+    def host_step(i, act):
+        hosts[i]["action"][...] = act
+        oracle.env_step(cfg, world, hosts[i])
+
+    streams = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+    for t in range(20):                                           # two states, two streams, alternating
+        for i in (0, 1):
+            act = np.stack([rng.uniform(-0.3, 1, sizes[i]), rng.uniform(-0.25, 0.25, sizes[i])], -1).astype(np.float32)
+            host_step(i, act)
+            with torch.cuda.stream(streams[(i + t) & 1]):
+                devs[i]["action"].copy_(dev(act))
+                ops.env_step(cfg, dw, devs[i])
+            torch.cuda.synchronize()
+    for i in (0, 1):
+        assert_state_equal(hosts[i].host(), devs[i].host(), f"batch {i} on alternating streams")
+    # a captured graph of three launches, replayed four times (the action buffer is the state's own: refilled between replays)
+    side = torch.cuda.Stream(device=DEV)
+    acts = [np.stack([rng.uniform(-0.3, 1, sizes[0]), rng.uniform(-0.25, 0.25, sizes[0])], -1).astype(np.float32) for _ in range(3)]
+    abuf = [dev(a) for a in acts]
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k in range(2):                                        # warm-up on the capturing stream
+            host_step(0, acts[k]); ops.env_step(cfg, dw, devs[0], action=abuf[k])
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for k in range(3):
+                ops.env_step(cfg, dw, devs[0], action=abuf[k])
+    torch.cuda.synchronize()
+    for r in range(4):
+        graph.replay()
+        for k in range(3):
+            host_step(0, acts[k])
+    torch.cuda.synchronize()
+    assert_state_equal(hosts[0].host(), devs[0].host(), "captured two-role launches, replayed")
+    # first use of an argument set inside a capture
+    g2 = torch.cuda.CUDAGraph()
+    a2 = np.stack([rng.uniform(-0.3, 1, sizes[2]), rng.uniform(-0.25, 0.25, sizes[2])], -1).astype(np.float32)
+    b2 = dev(a2)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g2, stream=side):
+            ops.env_step(cfg, dw, devs[2], action=b2)
+    for r in range(15):
+        g2.replay()
+        host_step(2, a2)
+    torch.cuda.synchronize()
+    assert_state_equal(hosts[2].host(), devs[2].host(), "first step of a batch inside a capture")
+    assert int(hosts[2]["episode"].max()) >= 2
+
+
+def test_two_role_step_kernel_forced_at_a_full_residency_round(crowded_town):
+    """tde_kernel_override(0, 2): the two-role step kernel at 1100 envs (above the 4 x CUs the library itself would give it) == oracle"""
+    from torchdriveenv_amd import _lib
+
+    cfg = _abi.default_config(seed=9, distance_cutoff=0.25, max_steps=4)
+    B, A = 1100, 128
+    hs, ds = EnvState(B, A), EnvState(B, A, device=DEV)
+    dw = crowded_town.to_device(DEV)
+    oracle.env_reset(cfg, crowded_town, hs)
+    ops.env_reset(cfg, dw, ds)
+    rng = np.random.default_rng(3)
+    _lib.kernel_override(step="duo")
+    try:
+        for t in range(9):
+            act = np.stack([rng.uniform(-0.3, 1, B), rng.uniform(-0.2, 0.2, B)], -1).astype(np.float32)
+            hs["action"][...] = act
+            oracle.env_step(cfg, crowded_town, hs)
+            ops.env_step(cfg, dw, ds, action=dev(act))
+    finally:
+        _lib.kernel_override()
+    assert_state_equal(hs.host(), ds.host(), "1100 envs x 128 slots, two roles")
+    assert int(hs["episode"].max()) >= 3
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_rollout_fuzz_128_slots(seed, crowded_town):
     """the two-role 128-slot rollout kernel over random flags (lights, no auto-reset, no offroad, no reward), launch lengths and

@@ -3,6 +3,8 @@
 // units (tde_step_*.hip, tde_rollout_*.hip: tde_host.h lists their launchers).  No torch types anywhere: plain device pointers,
 // sizes and a hipStream_t.
 #define TDE_TU_API 1
+#include <mutex>
+#include <vector>
 #include "tde_kernels.h"
 #include "tde_host.h"
 
@@ -33,8 +35,8 @@ int tde_abi_version(void) { return TDE_ABI_VERSION; }
 
 int tde_kernel_override(int rollout_team, int step_team)
 {
-    if (rollout_team < 0 || rollout_team > 3 || !(step_team == 0 || step_team == 1 || step_team == 3))
-        return bad("tde_kernel_override: rollout_team in {0, 1, 2, 3}, step_team in {0, 1, 3}");
+    if (rollout_team < 0 || rollout_team > 3 || step_team < 0 || step_team > 3)
+        return bad("tde_kernel_override: rollout_team in {0, 1, 2, 3}, step_team in {0, 1, 2, 3}");
     g_force_rollout = rollout_team;
     g_force_step = step_team;
     return 0;
@@ -154,7 +156,7 @@ static uint64_t fg_memo_word(const tde_world &w, uint32_t hash)
 
 static int first_gaps_launch(const tde_config *cfg, const tde_world *world, void *stream, bool use_memo)
 {
-    if (!world->first_gap || world->A > tde::kWave || world->n_scn <= 0) return 0;
+    if (!world->first_gap || world->A > 2 * tde::kWave || world->n_scn <= 0) return 0;
     if (!(cfg->flags & TDE_F_NPC) || !(cfg->flags & TDE_F_NPC_FIRST_STEP)) return 0;
     const uint32_t hash = tde_host::act_cfg_hash(*cfg, *world);
     const uint64_t word = fg_memo_word(*world, hash);
@@ -162,11 +164,66 @@ static int first_gaps_launch(const tde_config *cfg, const tde_world *world, void
         for (auto &m : g_fg_memo)
             if (m.load(std::memory_order_relaxed) == word) return 0;
     const unsigned nb = blocks_for((int64_t)world->n_scn * world->A);
-    TDE_DISPATCH_A(world->A, tde::first_gap_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, hash | 1u));
+    TDE_DISPATCH_A128(world->A, tde::first_gap_kernel<kA><<<nb, tde::kBlock, 0, (hipStream_t)stream>>>(*cfg, *world, hash | 1u));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("tde_first_gaps", e);
     g_fg_memo[g_fg_next.fetch_add(1, std::memory_order_relaxed) % 16].store(word, std::memory_order_relaxed);
     return 0;
+}
+
+// ---- argument blocks of the 128-slot two-role one-step kernel (tde::StepArgs, tde_kernels.h) -----------------------------------------
+// One IMMUTABLE block per distinct (configuration, world, state without its action pointer, controller hash) and device: a pinned
+// host copy and its device twin, slots of two pools allocated on first use and never freed or rewritten - a HIP graph that captured a
+// launch (or the block's upload) keeps reading valid memory for the life of the process.  A block is uploaded once per stream
+// that uses it, ahead of the first launch on that stream (identical bytes: concurrent uploads are benign).  No block - the pools are
+// full (kArgBlocks distinct argument sets), or the first use of an argument set (or of a stream) falls inside a stream capture, where
+// neither an allocation nor an un-replayed upload can be relied on - means nullptr: the caller launches the one-role kernel, which
+// takes its arguments by value.
+namespace {
+constexpr int kArgBlocks = 2048;
+struct ArgEntry { int device; int slot; std::vector<void *> streams; };
+struct ArgPool { tde::StepArgs *host = nullptr, *dev = nullptr; int used = 0; };
+std::mutex g_arg_mu;
+std::vector<ArgEntry> g_arg_entries;
+ArgPool g_arg_pool[16];
+}  // namespace
+
+static const tde::StepArgs *step_args(const tde_config *cfg, const tde_world *world, const tde_state *st, uint32_t act_hash, void *stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    tde::StepArgs now;
+    memset(&now, 0, sizeof(now));
+    now.cfg = *cfg; now.w = *world; now.st = *st; now.st.action = nullptr; now.act_hash = act_hash;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_arg_mu);
+    ArgPool &pool = g_arg_pool[dev];
+    ArgEntry *ent = nullptr;
+    for (auto &e : g_arg_entries)
+        if (e.device == dev && memcmp(&pool.host[e.slot], &now, sizeof(now)) == 0) { ent = &e; break; }
+    if (!ent) {
+        if (capturing) return nullptr;
+        if (!pool.host) {
+            if (hipHostMalloc((void **)&pool.host, sizeof(tde::StepArgs) * kArgBlocks, hipHostMallocDefault) != hipSuccess) { pool.host = nullptr; (void)hipGetLastError(); return nullptr; }
+            if (hipMalloc((void **)&pool.dev, sizeof(tde::StepArgs) * kArgBlocks) != hipSuccess) { (void)hipHostFree(pool.host); pool.host = nullptr; (void)hipGetLastError(); return nullptr; }
+        }
+        if (pool.used >= kArgBlocks) return nullptr;
+        memcpy(&pool.host[pool.used], &now, sizeof(now));
+        g_arg_entries.push_back(ArgEntry{dev, pool.used++, {}});
+        ent = &g_arg_entries.back();
+    }
+    bool uploaded = false;
+    for (void *s : ent->streams) uploaded = uploaded || s == stream;
+    if (!uploaded) {
+        if (capturing) return nullptr;
+        if (hipMemcpyAsync(&pool.dev[ent->slot], &pool.host[ent->slot], sizeof(tde::StepArgs), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        ent->streams.push_back(stream);
+    }
+    return &pool.dev[ent->slot];
 }
 
 static int env_step_launch(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream, int64_t load_slots)
@@ -198,14 +255,22 @@ static int env_step_launch(const tde_config *cfg, const tde_world *world, const 
     // per env, one role / two roles (profiles/r06_p_wide_step_forms.txt): 1 env 13.4 / 8.9 (the reference's own operating point),
     // 64 envs 15.5 / 13.1, 256 16.1 / 14.4, 512 16.4 / 15.5, 1024 19.1 / 18.8 through ctypes but 17.8 / 18.5 through the extension (the sweeps' VALU
     // work fills the chip either way), 2048 29.1 / 31.9.
-    // tde_kernel_override(0, 1) forces the one-role kernel.
-    if (st->A == 128 && st->act_cache && force != 1 && st->B <= 2 * cu_count())
-        return tde_host::launch_step_wide(cfg, world, st, tde_host::act_cfg_hash(*cfg, *world), stream);
+    // tde_kernel_override(0, 1) forces the one-role kernel, (0, 2) the two-role one at any batch size.
+    if (st->A == 128 && st->act_cache && (force == 2 || (force != 1 && st->B <= 4 * cu_count()))) {
+        tde_state local = *st;
+        if (!packable) local.slot_cache = nullptr;                           // (the kernel then walks the table chain)
+        const uint32_t hash = tde_host::act_cfg_hash(*cfg, *world);
+        if (const tde::StepArgs *args = step_args(cfg, world, &local, hash, stream)) {
+            rc = first_gaps_launch(cfg, world, stream, true);                // (first use of this world with this configuration)
+            if (rc) return rc;
+            return tde_host::launch_step_wide(args, cfg, st, stream);
+        }
+    }
     if (trio_ok && want_trio) {
         rc = first_gaps_launch(cfg, world, stream, true);                    // (first use of this world with this configuration)
         if (rc) return rc;
+        return tde_host::launch_step_trio(cfg, world, st, tde_host::act_cfg_hash(*cfg, *world), stream);
     }
-    if (trio_ok && want_trio) return tde_host::launch_step_trio(cfg, world, st, tde_host::act_cfg_hash(*cfg, *world), stream);
     // the one-role kernel (its forms - the class map on large grids, four wavefronts per SIMD for big 128-slot batches - are chosen
     // by the launcher); with / without tde_state.magnitudes are two translation units
     return st->magnitudes ? tde_host::launch_step_solo_mag(cfg, world, st, stream) : tde_host::launch_step_solo(cfg, world, st, stream);

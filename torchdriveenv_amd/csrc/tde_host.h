@@ -9,6 +9,8 @@
 
 #include "../../include/tde_hip.h"
 
+namespace tde { struct StepArgs; }
+
 namespace tde_host {
 
 // the calling thread's error slot (256 bytes), defined in tde_api.hip
@@ -79,7 +81,8 @@ inline uint32_t act_cfg_hash(const tde_config &cfg, const tde_world &w)
 // tde_step_trio.hip: env_step_trio_kernel<A in {8, 16, 32}, LIGHTS, OBS, MAG>
 int launch_step_trio(const tde_config *cfg, const tde_world *world, const tde_state *st, uint32_t act_hash, void *stream);
 // tde_step_wide.hip: env_step_wide_kernel<LIGHTS, OBS, MAG> (128 agent slots per env, two roles)
-int launch_step_wide(const tde_config *cfg, const tde_world *world, const tde_state *st, uint32_t act_hash, void *stream);
+// (`args` = the launch's argument block in device memory, tde_api.hip: step_args; `st` = the caller's struct - shape, optional outputs, action)
+int launch_step_wide(const tde::StepArgs *args, const tde_config *cfg, const tde_state *st, void *stream);
 // tde_step_solo.hip / tde_step_solo_mag.hip: env_step_kernel<A, LIGHTS, OBS, BIG, WAVES, MAG = false / true>
 int launch_step_solo(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream);
 int launch_step_solo_mag(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream);

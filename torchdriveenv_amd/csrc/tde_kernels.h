@@ -877,6 +877,59 @@ TDE_DEV bool collide_rows_wide(const float4 *ra, const float4 *rb, int a, bool l
     return h0 | h1;
 }
 
+// The two-role 128-slot kernels (one judge wavefront per half of the slots): every PAIR once.  Overlap is symmetric bit for bit -
+// swapping the boxes negates (dx, dy) and s = ci*sj - si*cj exactly and permutes the four axis tests of obb_overlap, and the
+// circumradius verdict squares the same differences - so slot a tests only the 64 slots AHEAD of it (a+1 .. a+64 modulo 128: each
+// unordered pair once, the opposite pairs (a, a+64) twice) and a hit is credited to BOTH slots: the tester keeps it, the partner
+// finds the step's stamp in `flag[partner]` (LDS) once the other judge wavefront has published its own (TDE_WIDE_SYM_JOIN below).
+// The lane's rows start at a different address per lane but at compile-time offsets from it: `ra` has 192 rows, rows 128..191
+// mirror rows 0..63 (write_rows_wide).  64 x 7 VALU instead of 128 x 7 per judge wavefront and step, half the exact tests.
+#ifndef TDE_WIDE_SYM
+#define TDE_WIDE_SYM 1              // 0: every slot sweeps all 128 rows (A/B)
+#endif
+TDE_DEV bool collide_rows_wide_sym(const float4 *ra, const float4 *rb, int a, bool live, float x, float y, float c, float s, float hl,
+                                   float hw, float ri, int *flag, int stamp)
+{
+    constexpr int C = kSweepBlock;
+    unsigned long long cand = 0;
+    if (live) {
+        cand = sweep_blocks<64>(ra + (a + 1), [&](float4 (&r)[C], float (&v)[C], auto &&prefetch) {
+            float dx[C], dy[C], rr[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) { dx[j] = r[j].x - x; dy[j] = r[j].y - y; rr[j] = ri + r[j].z; }
+#pragma unroll
+            for (int j = 0; j < C; ++j) asm volatile("" :: "v"(r[j].w));       // (keep the row a 16-byte read: collide_part)
+            pin(dx, dy);
+            pin(rr);
+            pin_memory();
+            prefetch();
+            pin_memory();
+#pragma unroll
+            for (int j = 0; j < C; ++j) dy[j] = dy[j] * dy[j];
+            pin(dy);
+#pragma unroll
+            for (int j = 0; j < C; ++j) dx[j] = __builtin_fmaf(dx[j], dx[j], dy[j]);
+            pin(dx);
+#pragma unroll
+            for (int j = 0; j < C; ++j) v[j] = __builtin_fmaf(-rr[j], rr[j], dx[j]);
+            pin(v);
+        });
+    }
+    bool hit = false;
+    while (__ballot(cand != 0)) {
+        if (cand) {
+            const int j = (a + 1 + row_of_bit<64>(lowest_bit(cand))) & 127;
+            cand &= cand - 1;
+            const float4 pj = ra[j], qj = rb[j];
+            if (obb_overlap(x, y, c, s, hl, hw, pj.x, pj.y, qj.x, qj.y, qj.z, qj.w)) {
+                hit = true;
+                *reinterpret_cast<volatile int *>(flag + j) = stamp;
+            }
+        }
+    }
+    return hit;
+}
+
 // The same for 16 slots per env when the wavefront's lane l holds slot l % 16 of its env, i.e. an env is one 16-lane DPP
 // row (three-role kernels).  The circumradius test of a pair is symmetric - both lanes would compute the same bits - so
 // each lane tests only the eight slots AHEAD of it in the row (offsets 1..8, slot index mod 16) and hands the verdict to
@@ -1815,8 +1868,10 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 // judges also do their own re-spawn bookkeeping).  Same per-agent arithmetic in the same order: same bits.
 // ------------------------------------------------------------------------------------------------------------------
 struct WideShared {
-    float4 a[2][128], b[2][128], c[2][128];
+    float4 a[2][192], b[2][128], c[2][128];   // (a: rows 128..191 mirror rows 0..63, for collide_rows_wide_sym)
     int done;                            // the env finished at the last judged step (and auto-reset is on)
+    int coll[128];                       // collide_rows_wide_sym: the stamp of the last step at which a partner credited the slot a hit
+    int coll_seq[2];                     // ... the stamp up to which a judge wavefront's credits are written
     float4 stop[kStopCache][2];          // the first kStopCache stop lines of the env's map
 };
 struct WideLines {
@@ -1837,10 +1892,36 @@ TDE_DEV void fill_stop_cache_wide(WideShared &sh, const tde_world &w, const tde_
 }
 TDE_DEV void write_rows_wide(WideShared &sh, int buf, int a, bool live, const Agent &ag, float c, float s, float lane_half)
 {
-    write_tile_slot(sh.a[buf][a], sh.b[buf][a], live, ag, c, s, lane_half);
+    float4 ta, tb;
+    write_tile_slot(ta, tb, live, ag, c, s, lane_half);
+    sh.a[buf][a] = ta; sh.b[buf][a] = tb;
+    if (TDE_WIDE_SYM && a < 64) sh.a[buf][a + 128] = ta;
     sh.c[buf][a] = make_float4(ag.psi, ag.v, live ? 1.0f : 0.0f, 0.0f);
 }
+// the two judge wavefronts of an env exchange their credits: publish() once a wavefront's exact tests are done, joined() where the
+// slot's flag is needed (the other wavefront has had the offroad section's time to get there)
+TDE_DEV void wide_sym_publish(WideShared &sh, int half, int lane, int stamp)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wavefront's LDS writes complete in order: credits, then the stamp)
+    if (lane == 0) *reinterpret_cast<volatile int *>(&sh.coll_seq[half]) = stamp;
+}
+TDE_DEV bool wide_sym_joined(WideShared &sh, int half, int a, int stamp)
+{
+    while (*reinterpret_cast<volatile int *>(&sh.coll_seq[half ^ 1]) != stamp) __builtin_amdgcn_s_sleep(1);
+    return *reinterpret_cast<volatile int *>(&sh.coll[a]) == stamp;
+}
 
+// The role of a wavefront in the 128-slot two-role kernels: its index in the workgroup -> drive 0, drive 1, judge 0, judge 1.
+// (TDE_WIDE_ROTATE=1 rotates the roles by the workgroup index, in case the hardware placed a workgroup's wavefronts on the CU's
+//  SIMDs in order - every drive wavefront on SIMDs 0 / 1: it does not; same times, profiles/r06_z_wide_128.txt)
+#ifndef TDE_WIDE_ROTATE
+#define TDE_WIDE_ROTATE 0
+#endif
+TDE_DEV int wide_role_wave()
+{
+    const int w0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    return TDE_WIDE_ROTATE ? ((w0 + (int)(blockIdx.x & 3u)) & 3) : w0;
+}
 #ifndef TDE_WIDE2_WAVES
 #define TDE_WIDE2_WAVES 4
 #endif
@@ -1852,7 +1933,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
     __shared__ WideShared sh;
     __shared__ Cold cold;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wv = wide_role_wave();
     const int role = wv >> 1;                               // 0 = drive, 1 = judge
     const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
     if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0; }
@@ -1952,6 +2033,8 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
         StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
         const float thr2 = thr2_of(cfg);
         RewardOut rw{};
+        sh.coll[a] = 0;
+        if (lane == 0) sh.coll_seq[wv & 1] = 0;
         lds_barrier();
         for (int i = 0; i < ro.K; ++i) {
             const int p = i & 1, q = p ^ 1;
@@ -1970,9 +2053,17 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
             const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
             Corners corners;
             if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+#if TDE_WIDE_SYM
+            bool hit = collide_rows_wide_sym(&sh.a[p][0], &sh.b[p][0], a, live, x, y, c0, s0, hl, hw, ra.z, sh.coll, i + 1);
+            wide_sym_publish(sh, wv & 1, lane, i + 1);
+#else
             const bool hit = collide_rows_wide<A>(&sh.a[p][0], &sh.b[p][0], a, live, x, y, c0, s0, hl, hw, ra.z);
+#endif
             bool off = false;
             if (F & TDE_F_OFFROAD) off = offroad_resolve<false, false>(w, corners, thr2, cx.m.rec_base);
+#if TDE_WIDE_SYM
+            hit |= wide_sym_joined(sh, wv & 1, a, i + 1);
+#endif
             bool tl = false;
             if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0)
                 tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
@@ -2025,229 +2116,6 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
     }
 }
 #undef TDE_WIDE_PROLOGUE
-
-// ------------------------------------------------------------------------------------------------------------------
-// Closed-loop step for 128 agent slots per env, two roles (tde_env_step with the action cache; round 6).  The one-role kernel runs
-// the whole step as ONE chain per wavefront: controller sweep over the env's 128 rows -> bicycle -> collision sweep over 128 rows ->
-// offroad -> reward (17.8 us per step at 1024 envs of ~122 agents, two wavefronts per SIMD).  Here, as in env_step_trio_kernel, the
-// controller's actions for THIS step were computed by the previous launch (tde_act_cache) and the next step's are computed by the
-// drive wavefronts BESIDE the judges' sweeps:
-//   drive (slots 0-63), drive (64-127): stored action -> bicycle -> replay -> route switch -> rows; then the next step's controller
-//   judge (0-63), judge (64-127)      : collision, offroad, stop lines; the ego lane: reward, termination, outputs, statistics
-// One env per workgroup of four wavefronts (4 per SIMD, 128 VGPRs: the 128-row sweeps fit without the squeeze of the 80-VGPR forms).
-// Barriers (LDS-only): E = do the drivers hold stored actions (else E2 + the controller on the pre-step rows, in the prologue: the first
-// launch, a re-spawned env's first step, a state edited from outside), B = the rows of the step are committed, A = the env's done
-// flag is published.  Same per-agent arithmetic in the same order as step_lane: the oracle's bits.
-// ------------------------------------------------------------------------------------------------------------------
-TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps);       // (the action cache's key word: defined with env_step_trio_kernel below)
-
-struct WideStepShared : WideShared {
-    int early[2];                        // a drive wavefront has a slot without a stored action
-    float poly[32];                      // MAG: box_iou_wave's vertex lists
-};
-
-template <bool LIGHTS, bool OBS, bool MAG>
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_step_wide_kernel(tde_config cfg, tde_world w, tde_state st,
-                                                                                                           uint32_t act_hash)
-{
-    constexpr int A = 128;
-    __shared__ WideStepShared sh;
-    __shared__ Cold cold;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int role = wv >> 1;                               // 0 = drive, 1 = judge
-    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
-    if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }
-    const uint32_t F = cfg.flags;
-    const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;
-    const bool lights = LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS);
-    const int e = (int)blockIdx.x;                          // (the grid is B workgroups: every env is valid)
-    const int64_t g = (int64_t)e * A + a;
-    __syncthreads();                                         // cold is filled
-    if (role == 0) {
-        // ================================ drive ================================
-        __builtin_amdgcn_s_setprio(2);
-        Agent ag;
-        load_agent(st, g, ag);
-        EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
-        const float2 act = reinterpret_cast<const float2 *>(st.action)[e];
-        float2 ac = make_float2(0.0f, 0.0f);
-        int2 akey = make_int2(-1, 0);                        // episode, steps (tde_act_cache: A + 1 entries per env)
-        float2 *ap = st.act_cache ? reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1) : nullptr;
-        if (ap) { ac = ap[a]; akey = reinterpret_cast<const int2 *>(ap)[A]; }
-        Ctx cx;
-        load_ctx<A>(cfg, cold, a, ag, er, cx);
-        const bool live = ag.present;
-        const int k = er.steps + 1;                          // :116
-        const bool npc = (F & TDE_F_NPC) && a > 0 && live;
-        const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
-        float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
-        bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-        float acc = 0.0f, beta = 0.0f;
-        if (a == 0) { acc = act.x; beta = act.y; }
-        float c0, s0;
-        auto controller = [&](int buf, int kk, float &na, float &nb) {
-            const uint32_t red = lights ? red_mask(w, cx.m, kk) : 0u;
-            const float red_gap = (lights && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-            npc_action_wide<A>(cfg, &sh.a[buf][0], &sh.b[buf][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
-        };
-        if (lights) fill_stop_cache_wide(sh, w, cx.m, a);
-        if (F & TDE_F_NPC) {
-            const bool stored = !npc || (k == 1 && !first_acts) || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
-            if (__ballot(!stored) && lane == 0) sh.early[wv] = 1;
-        }
-        lds_barrier();                                       // E: does a drive wavefront lack stored actions?
-        if (sh.early[0] | sh.early[1]) {
-            sincos_f32(ag.psi, s0, c0);
-            write_rows_wide(sh, 1, a, live, ag, c0, s0, cfg.npc_lane_half);      // pre-step rows: what the controller reads
-            lds_barrier();                                   // E2: both halves' rows (and the stop lines) are in
-            float na, nb;
-            controller(1, k, na, nb);
-            if (npc) { acc = na; beta = nb; }
-        } else if (npc) {
-            acc = ac.x; beta = ac.y;
-        }
-        if (npc && k == 1 && !first_acts) acc = beta = 0.0f;
-        if (live) {
-            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117
-            if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
-        }
-        bool switched = false;
-        if (has_target) {
-            const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
-            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { ag.route_wp += 1; switched = true; }
-        }
-        sincos_f32(ag.psi, s0, c0);
-        er.steps = k;
-        write_rows_wide(sh, 0, a, live, ag, c0, s0, cfg.npc_lane_half);
-        lds_barrier();                                       // B: rows of this step are in buffer 0
-        __builtin_amdgcn_s_setprio(0);                       // behind B the judges' sweeps are the critical path
-        if (switched) load_route_target(cold, ag, cx);
-        // the controller of the NEXT step, beside the judges of this one (speculative: a re-spawn below discards it)
-        float na2 = 0.0f, nb2 = 0.0f;
-        has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-        if ((F & TDE_F_NPC) && ap) controller(0, k + 1, na2, nb2);
-        lds_barrier();                                       // A: the env's done flag is published
-        __builtin_amdgcn_s_setprio(3);
-        const bool respawned = sh.done != 0;
-        if (respawned) reset_lane<A>(cfg, cold, e, a, ag, er);
-        store_agent_dynamic(st, g, ag);
-        if (respawned) store_agent_static(st, g, ag);
-        if (ap) {
-            ap[a] = make_float2(na2, nb2);
-            // (a re-spawned env's first actions are the next launch's: its key is stored invalid - the prologue above computes them)
-            if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));
-        }
-    } else {
-        // ================================ judge ================================
-        __builtin_amdgcn_s_setprio(1);
-        Agent ag;
-        load_agent(st, g, ag);                               // (the pose BEFORE the step: :371-375 for the ego lane)
-        EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
-        double ep_ret = 0.0;
-        if (a == 0 && st.ep_return) ep_ret = st.ep_return[e];
-        Ctx cx;
-        load_ctx<A>(cfg, cold, a, ag, er, cx);
-        const float lx = ag.x, ly = ag.y, lpsi = ag.psi, lv = ag.v;
-        const float thr2 = thr2_of(cfg);
-        lds_barrier();                                       // E
-        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2
-        lds_barrier();                                       // B: rows of this step are in buffer 0
-        __builtin_amdgcn_s_setprio(2);
-        er.steps += 1;
-        const int k = er.steps;
-        const float4 ra = sh.a[0][a], rb = sh.b[0][a], rc = sh.c[0][a];
-        const bool live = rc.z != 0.0f;
-        const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
-        Corners corners;
-        if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
-        const bool hit = collide_rows_wide<A>(&sh.a[0][0], &sh.b[0][0], a, live, x, y, c0, s0, hl, hw, ra.z);
-        bool off = false;
-        if (F & TDE_F_OFFROAD) off = offroad_resolve<true, false>(w, corners, thr2, cx.m.rec_base);
-        bool tl = false;
-        if (lights && a == 0) tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
-        StepOut o{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
-        const int ti0 = er.target_idx;
-        if (a == 0) {
-            int done = 0;
-            if (F & TDE_F_REWARD) {
-                RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, x, y, rc.x, rc.y, off, hit, tl, k, er.target_idx, er.reached,
-                                          st.info != nullptr);
-                o.reward = r.reward; o.terminated = r.terminated; o.truncated = r.truncated;
-                if (st.info) {
-                    double *inf = st.info + 4 * (int64_t)e;
-                    inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
-                }
-                if (st.info_reached) st.info_reached[e] = er.reached;
-                done = (r.terminated | r.truncated) ? 1 : 0;
-            }
-            sh.done = ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? done : 0;
-        }
-        const unsigned long long hit_m = MAG ? __ballot(hit) : 0ull, off_m = MAG ? __ballot(off) : 0ull;
-        lds_barrier();                                       // A
-        const bool respawned = sh.done != 0;
-        st.collided[g] = respawned ? 0 : o.collided;
-        st.offroad[g] = respawned ? 0 : o.offroad;
-        const tde_map map0 = cx.m;                           // (MAG: the map of the episode that was stepped; a re-spawn replaces cx)
-        if (a == 0) {
-            ag.x = x; ag.y = y; ag.psi = rc.x; ag.v = rc.y;  // the ego after the step (the compact observation)
-            float oc = c0, os = s0;
-            if (respawned) {
-                respawn_lane<A>(cfg, cold, e, a, ag, er, cx, false);             // (per-lane draws at 128 slots: no cross-lane traffic)
-                if (OBS) sincos_f32(ag.psi, os, oc);
-            } else if ((F & TDE_F_REWARD) && er.target_idx != ti0) {
-                load_ego_target(cold, er, cx);
-            }
-            st.steps[e] = er.steps;
-            st.target_idx[e] = er.target_idx;
-            st.reached[e] = er.reached;
-            st.reward[e] = o.reward;
-            st.terminated[e] = o.terminated;
-            st.truncated[e] = o.truncated;
-            if (st.tl_violation) st.tl_violation[e] = o.tl;
-            if (respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
-            if (st.done_bits) st.done_bits[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
-            if (st.ep_return) {
-                double ret = ep_ret + (double)o.reward;
-                if (o.terminated | o.truncated) {
-                    if (st.ep_final) st.ep_final[e] = ret;
-                    if (st.ep_final_len) st.ep_final_len[e] = k;
-                    if (respawned) ret = 0.0;
-                }
-                st.ep_return[e] = ret;
-            }
-            if (OBS && st.obs) {
-                // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it
-                const bool ended = (o.terminated | o.truncated) && !respawned;
-                bool has = er.target_idx < cx.n_wp;
-                double tx = cx.wtx, ty = cx.wty;
-                asm volatile("" : "+v"(tx), "+v"(ty));
-                if (!(F & TDE_F_REWARD) || ended) {
-                    has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
-                    const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
-                    tx = t2.x; ty = t2.y;
-                }
-                float fwd = 0.0f, lat = 0.0f;
-                if (has) {
-                    const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
-                    fwd = dx * oc + dy * os;
-                    lat = dy * oc - dx * os;
-                }
-                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
-                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
-                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
-            }
-        }
-        if constexpr (MAG) {
-            // tde_state.magnitudes for a flagged ego (get_info's "collision" / "offroad", :427-428), by the ego's wavefront from the
-            // rows of THIS step (a re-spawn does not rewrite them) - behind the stores, as in the one-role kernel
-            if ((wv & 1) == 0)
-                ego_magnitudes_of_wave<A, true>(cfg, w, [&](int) { return map0; }, __ballot(a == 0), hit_m, off_m, &sh.a[0][0], &sh.b[0][0], lane, sh.poly,
-                                                a == 0 ? reinterpret_cast<float4 *>(st.magnitudes) + e : nullptr);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Three roles per group: the same loop with the judge split in two wavefronts, six wavefronts per SIMD (80 VGPRs each):
@@ -2810,6 +2678,285 @@ TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, c
 //  counters of one configuration never share a word and two configurations collide with probability 2^-32; ABI 9 kept 12 bits)
 TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash ^ ((uint32_t)steps * 0x9E3779B1u)); }
 
+// The arguments of env_step_wide_kernel's launch as ONE block in device memory instead of ~900 bytes of by-value arguments: every field
+// is then a scalar load where it is used, not a scalar register held from the kernel's top - 58 SGPRs instead of 106 with 4 - 24 of
+// them spilled, and with that 124 VGPRs WITHOUT the 6 - 43 spilled ones: no private segment, whose set-up costs a launch more than a
+// microsecond (1024 envs x 128 slots: 16.0 -> 13.8 us per step; the first loads also issue 1 400 cycles sooner, which by itself
+// changes nothing: profiles/r06_z_wide_128.txt).  Blocks are immutable, one per distinct argument set (tde_api.hip: step_args); the action
+// pointer - the one field a closed loop changes from call to call - stays a by-value argument.  (The three-role kernels keep by-value
+// arguments: at 6 wavefronts per SIMD the block's extra hop costs them 0.2 - 0.4 us, same file.)
+struct StepArgs { tde_config cfg; tde_world w; tde_state st; uint32_t act_hash; uint32_t pad; };
+
+// ------------------------------------------------------------------------------------------------------------------
+// Closed-loop step for 128 agent slots per env, two roles (tde_env_step with the action cache; round 6).  The one-role kernel runs
+// the whole step as ONE chain per wavefront: controller sweep over the env's 128 rows -> bicycle -> collision sweep over 128 rows ->
+// offroad -> reward (17.8 us per step at 1024 envs of ~122 agents, two wavefronts per SIMD).  Here, as in env_step_trio_kernel, the
+// controller's actions for THIS step were computed by the previous launch (tde_act_cache) and the next step's are computed by the
+// drive wavefronts BESIDE the judges' sweeps:
+//   drive (slots 0-63), drive (64-127): stored action -> bicycle -> replay -> route switch -> rows; then the next step's controller
+//   judge (0-63), judge (64-127)      : collision, offroad, stop lines; the ego lane: reward, termination, outputs, statistics
+// One env per workgroup of four wavefronts (4 per SIMD, 128 VGPRs: the 128-row sweeps fit without the squeeze of the 80-VGPR forms).
+// Barriers (LDS-only): E = do the drivers hold stored actions (else E2 + the controller on the pre-step rows, in the prologue: the first
+// launch, a re-spawned env's first step, a state edited from outside), B = the rows of the step are committed, A = the env's done
+// flag is published.  Same per-agent arithmetic in the same order as step_lane: the oracle's bits.
+// ------------------------------------------------------------------------------------------------------------------
+struct WideStepShared : WideShared {
+    int early[2];                        // a drive wavefront has a slot without a stored action
+    float poly[32];                      // MAG: box_iou_wave's vertex lists
+};
+
+template <bool LIGHTS, bool OBS, bool MAG>
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_step_wide_kernel(const StepArgs *__restrict__ args,
+                                                                                                           const float *__restrict__ action)
+{
+    const tde_config &cfg = args->cfg;
+    const tde_world &w = args->w;
+    const tde_state &st = args->st;
+    const uint32_t act_hash = args->act_hash;
+    constexpr int A = 128;
+    __shared__ WideStepShared sh;
+    __shared__ Cold cold;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wv = wide_role_wave();
+    const int role = wv >> 1;                               // 0 = drive, 1 = judge
+    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
+    // (the cold block is filled by a JUDGE lane - the drivers' loads are the launch's first instructions - and published by an
+    //  LDS-only barrier that every role reaches with its loads in flight)
+    if (wv == 2 && lane == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }
+    const uint32_t F = cfg.flags;
+    const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;
+    const bool lights = LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS);
+    const int e = (int)blockIdx.x;                          // (the grid is B workgroups: every env is valid)
+    const int64_t g = (int64_t)e * A + a;
+    if (role == 0) {
+        // ================================ drive ================================
+        __builtin_amdgcn_s_setprio(2);
+        Agent ag;
+        load_agent(st, g, ag);
+        EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
+        const float2 act = reinterpret_cast<const float2 *>(action)[e];
+        float2 ac = make_float2(0.0f, 0.0f);
+        int2 akey = make_int2(-1, 0);                        // episode, steps (tde_act_cache: A + 1 entries per env)
+        float2 *ap = st.act_cache ? reinterpret_cast<float2 *>(st.act_cache) + (int64_t)e * (A + 1) : nullptr;
+        if (ap) { ac = ap[a]; akey = reinterpret_cast<const int2 *>(ap)[A]; }
+        // the slot's table entries from its cache entry, fetched beside the state (one round of independent loads); a missing or
+        // stale entry falls back to the chain scenario -> spawn record -> route table and is rewritten (load_ctx_cached)
+        int4 sc0 = make_int4(0, 0, 0, 0), sc1 = sc0;
+        if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }
+        lds_barrier();                                       // cold is published
+        Ctx cx;
+        bool rebuilt;
+        load_ctx_cached<A>(cfg, cold, st, g, a, true, sc0, sc1, ag, er, cx, false, rebuilt);
+        if (!rebuilt && lights) cx.m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];    // (a rebuilt entry fetched it)
+        const bool need_tg2 = !rebuilt && (sc0.y & kSlotTg2Later) != 0;      // (left by a re-spawn of the three-role kernel)
+        const bool live = ag.present;
+        const int k = er.steps + 1;                          // :116
+        const bool npc = (F & TDE_F_NPC) && a > 0 && live;
+        const bool replayed = (F & TDE_F_REPLAY) && a > 0 && live && k < cx.replay_len;
+        float4 rep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (replayed) rep = reinterpret_cast<const float4 *>(w.replay_states)[(int64_t)ag.replay * w.RT + k];
+        bool has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+        float acc = 0.0f, beta = 0.0f;
+        if (a == 0) { acc = act.x; beta = act.y; }
+        float c0, s0;
+        auto controller = [&](int buf, int kk, float &na, float &nb) {
+            const uint32_t red = lights ? red_mask(w, cx.m, kk) : 0u;
+            const float red_gap = (lights && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+            npc_action_wide<A>(cfg, &sh.a[buf][0], &sh.b[buf][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+        };
+        if (lights) fill_stop_cache_wide(sh, w, cx.m, a);
+        if (F & TDE_F_NPC) {
+            const bool stored = !npc || (k == 1 && !first_acts) || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
+            if (__ballot(!stored) && lane == 0) sh.early[wv] = 1;
+        }
+        lds_barrier();                                       // E: does a drive wavefront lack stored actions?
+        if (sh.early[0] | sh.early[1]) {
+            sincos_f32(ag.psi, s0, c0);
+            write_rows_wide(sh, 1, a, live, ag, c0, s0, cfg.npc_lane_half);      // pre-step rows: what the controller reads
+            lds_barrier();                                   // E2: both halves' rows (and the stop lines) are in
+            float na = ac.x, nb = ac.y;
+            // a re-spawned env's first step (the usual reason to be here: ~2 % of the envs per launch, and the launch waits for its
+            // slowest workgroup): min(the scenario's first-step gap, the exact test against the ego's row) instead of the 128-row
+            // sweep and the stop-line loop (npc_first_step; the ego's row is in the first half).  k is the env's: uniform.
+            bool have = false;
+            if (TDE_FIRST_GAP && first_acts && k == 1 && w.first_gap) {
+                uint2 fe = make_uint2(0u, 0u);
+                if (npc) fe = *reinterpret_cast<const uint2 *>(w.first_gap + ((int64_t)er.scn * A + a));
+                have = npc_first_step<64>(cfg, fe, first_gap_key(act_hash), &sh.a[1][0], &sh.b[1][0], a, ag, c0, s0, npc, has_target, cx.tgx, cx.tgy, na, nb);
+            }
+            if (!have) controller(1, k, na, nb);
+            if (npc) { acc = na; beta = nb; }
+        } else if (npc) {
+            acc = ac.x; beta = ac.y;
+        }
+        if (npc && k == 1 && !first_acts) acc = beta = 0.0f;
+        if (live) {
+            bicycle(ag.x, ag.y, ag.psi, ag.v, ag.inv_lr, acc, beta, cfg.dt);     // :117
+            if (replayed) { ag.x = rep.x; ag.y = rep.y; ag.psi = rep.z; ag.v = rep.w; }
+        }
+        bool switched = false;
+        if (has_target) {
+            const float dx = cx.tgx - ag.x, dy = cx.tgy - ag.y;
+            if (dx * dx + dy * dy < cfg.npc_reach * cfg.npc_reach) { ag.route_wp += 1; switched = true; cx.tgx = cx.tgx2; cx.tgy = cx.tgy2; }   // (the look-ahead entry)
+        }
+        sincos_f32(ag.psi, s0, c0);
+        er.steps = k;
+        write_rows_wide(sh, 0, a, live, ag, c0, s0, cfg.npc_lane_half);
+        lds_barrier();                                       // B: rows of this step are in buffer 0
+        __builtin_amdgcn_s_setprio(0);                       // behind B the judges' sweeps are the critical path
+        if (switched && need_tg2) load_route_target(cold, ag, cx);               // (the look-ahead entry was not there yet: rare)
+        if (switched || need_tg2) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);       // (only stored)
+        // the controller of the NEXT step, beside the judges of this one (speculative: a re-spawn below discards it)
+        float na2 = 0.0f, nb2 = 0.0f;
+        has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
+        if ((F & TDE_F_NPC) && ap) controller(0, k + 1, na2, nb2);
+        lds_barrier();                                       // A: the env's done flag is published
+        __builtin_amdgcn_s_setprio(3);
+        const bool respawned = sh.done != 0;
+        // (an entry is a function of (scenario, slot, route_wp, flags) - its key: a re-spawned slot's old entry is either right for the
+        //  new episode too or rebuilt by the next launch; nothing to fetch on this launch's tail)
+        if (st.slot_cache && !respawned && (switched || rebuilt || need_tg2)) store_slot_cache(st, g, ag, er, cx, cfg.flags);
+        if (respawned) reset_lane<A>(cfg, cold, e, a, ag, er);
+        store_agent_dynamic(st, g, ag);
+        if (respawned) store_agent_static(st, g, ag);
+        if (ap) {
+            ap[a] = make_float2(na2, nb2);
+            // (a re-spawned env's first actions are the next launch's: its key is stored invalid - the prologue above computes them)
+            if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));
+        }
+    } else {
+        // ================================ judge ================================
+        __builtin_amdgcn_s_setprio(1);
+        // A judge lane's own slot state comes from the rows behind barrier B: only the EGO lane reads the state arrays (its pose
+        // before the step, :371-375, and what a re-spawn overwrites), and the per-slot half of load_ctx (spawn record, route target)
+        // is the drivers'.  (With load_agent + load_ctx on all 128 lanes of both judges the launch's opening burst was twice the
+        // drivers' bytes, and at one residency round - every workgroup of the grid in the same phase - nothing hides it.)
+        Agent ag{};
+        ag.route = -1; ag.replay = -1;
+        if (a == 0) load_agent(st, g, ag);
+        EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
+        double ep_ret = 0.0;
+        if (a == 0 && st.ep_return) ep_ret = st.ep_return[e];
+        lds_barrier();                                       // cold is published
+        Ctx cx;
+        cx.tgx = cx.tgy = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0; cx.g_far = 0.0f;
+        {
+            const int4 sc = reinterpret_cast<const int4 *>(cold.scn)[er.scn];      // map, wp_n, start_heading, pad
+            cx.map_id = sc.x;
+            if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) cx.m = cold.maps[sc.x];
+            if (a == 0 && (F & TDE_F_REWARD)) { cx.n_wp = sc.y; load_ego_target(cold, er, cx); }
+        }
+        const float lx = ag.x, ly = ag.y, lpsi = ag.psi, lv = ag.v;
+        const float thr2 = thr2_of(cfg);
+        sh.coll[a] = 0;
+        if (lane == 0) sh.coll_seq[wv & 1] = 0;
+        lds_barrier();                                       // E
+        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2
+        lds_barrier();                                       // B: rows of this step are in buffer 0
+        __builtin_amdgcn_s_setprio(2);
+        er.steps += 1;
+        const int k = er.steps;
+        const float4 ra = sh.a[0][a], rb = sh.b[0][a], rc = sh.c[0][a];
+        const bool live = rc.z != 0.0f;
+        const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
+        Corners corners;
+        if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+#if TDE_WIDE_SYM
+        bool hit = collide_rows_wide_sym(&sh.a[0][0], &sh.b[0][0], a, live, x, y, c0, s0, hl, hw, ra.z, sh.coll, 1);
+        wide_sym_publish(sh, wv & 1, lane, 1);
+#else
+        const bool hit = collide_rows_wide<A>(&sh.a[0][0], &sh.b[0][0], a, live, x, y, c0, s0, hl, hw, ra.z);
+#endif
+        bool off = false;
+        if (F & TDE_F_OFFROAD) off = offroad_resolve<true, false>(w, corners, thr2, cx.m.rec_base);
+#if TDE_WIDE_SYM
+        hit |= wide_sym_joined(sh, wv & 1, a, 1);
+#endif
+        bool tl = false;
+        if (lights && a == 0) tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
+        StepOut o{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
+        const int ti0 = er.target_idx;
+        if (a == 0) {
+            int done = 0;
+            if (F & TDE_F_REWARD) {
+                RewardOut r = reward_core(cold, cx.n_wp, cx.wtx, cx.wty, lx, ly, lpsi, lv, x, y, rc.x, rc.y, off, hit, tl, k, er.target_idx, er.reached,
+                                          st.info != nullptr);
+                o.reward = r.reward; o.terminated = r.terminated; o.truncated = r.truncated;
+                if (st.info) {
+                    double *inf = st.info + 4 * (int64_t)e;
+                    inf[0] = r.psi_smooth; inf[1] = r.speed_smooth; inf[2] = r.psi_r; inf[3] = r.dist_r;
+                }
+                if (st.info_reached) st.info_reached[e] = er.reached;
+                done = (r.terminated | r.truncated) ? 1 : 0;
+            }
+            sh.done = ((F & TDE_F_REWARD) && (F & TDE_F_AUTORESET)) ? done : 0;
+        }
+        const unsigned long long hit_m = MAG ? __ballot(hit) : 0ull, off_m = MAG ? __ballot(off) : 0ull;
+        lds_barrier();                                       // A
+        const bool respawned = sh.done != 0;
+        st.collided[g] = respawned ? 0 : o.collided;
+        st.offroad[g] = respawned ? 0 : o.offroad;
+        const tde_map map0 = cx.m;                           // (MAG: the map of the episode that was stepped; a re-spawn replaces cx)
+        if (a == 0) {
+            ag.x = x; ag.y = y; ag.psi = rc.x; ag.v = rc.y;  // the ego after the step (the compact observation)
+            float oc = c0, os = s0;
+            if (respawned) {
+                respawn_lane<A>(cfg, cold, e, a, ag, er, cx, false);             // (per-lane draws at 128 slots: no cross-lane traffic)
+                if (OBS) sincos_f32(ag.psi, os, oc);
+            } else if ((F & TDE_F_REWARD) && er.target_idx != ti0) {
+                load_ego_target(cold, er, cx);
+            }
+            st.steps[e] = er.steps;
+            st.target_idx[e] = er.target_idx;
+            st.reached[e] = er.reached;
+            st.reward[e] = o.reward;
+            st.terminated[e] = o.terminated;
+            st.truncated[e] = o.truncated;
+            if (st.tl_violation) st.tl_violation[e] = o.tl;
+            if (respawned) { st.scn[e] = er.scn; st.episode[e] = er.episode; }
+            if (st.done_bits) st.done_bits[e] = (uint8_t)(o.terminated | (o.truncated << 1) | (o.offroad << 2) | (o.collided << 3) | (o.tl << 4));
+            if (st.ep_return) {
+                double ret = ep_ret + (double)o.reward;
+                if (o.terminated | o.truncated) {
+                    if (st.ep_final) st.ep_final[e] = ret;
+                    if (st.ep_final_len) st.ep_final_len[e] = k;
+                    if (respawned) ret = 0.0;
+                }
+                st.ep_return[e] = ret;
+            }
+            if (OBS && st.obs) {
+                // compact observation of the state after the step (and re-spawn), as state_obs_kernel forms it
+                const bool ended = (o.terminated | o.truncated) && !respawned;
+                bool has = er.target_idx < cx.n_wp;
+                double tx = cx.wtx, ty = cx.wty;
+                asm volatile("" : "+v"(tx), "+v"(ty));
+                if (!(F & TDE_F_REWARD) || ended) {
+                    has = er.target_idx < reinterpret_cast<const int4 *>(w.scn)[er.scn].y;
+                    const double2 t2 = reinterpret_cast<const double2 *>(w.wp_xy)[(int64_t)er.scn * w.NW + (has ? er.target_idx : 0)];
+                    tx = t2.x; ty = t2.y;
+                }
+                float fwd = 0.0f, lat = 0.0f;
+                if (has) {
+                    const float dx = (float)tx - ag.x, dy = (float)ty - ag.y;
+                    fwd = dx * oc + dy * os;
+                    lat = dy * oc - dx * os;
+                }
+                float4 *ob = reinterpret_cast<float4 *>(st.obs) + 2 * (int64_t)e;
+                ob[0] = make_float4(ag.x, ag.y, ag.psi, ag.v);
+                ob[1] = make_float4(fwd, lat, has ? 1.0f : 0.0f, (float)er.steps);
+            }
+        }
+        if constexpr (MAG) {
+            // tde_state.magnitudes for a flagged ego (get_info's "collision" / "offroad", :427-428), by the ego's wavefront from the
+            // rows of THIS step (a re-spawn does not rewrite them) - behind the stores, as in the one-role kernel
+            if ((wv & 1) == 0)
+                ego_magnitudes_of_wave<A, true>(cfg, w, [&](int) { return map0; }, __ballot(a == 0), hit_m, off_m, &sh.a[0][0], &sh.b[0][0], lane, sh.poly,
+                                                a == 0 ? reinterpret_cast<float4 *>(st.magnitudes) + e : nullptr);
+        }
+    }
+}
+
+
 // MAG: also writes tde_state.magnitudes (judge O, behind barrier A); a template flag because the code, taken or not, costs the
 // plain kernel its registers: 73 -> 80 VGPRs + 40 spilled, and a launch with a private segment takes 1.3 us longer to dispatch
 #ifndef TDE_TRIO_STEP_WPE
@@ -2833,7 +2980,12 @@ __global__ __launch_bounds__(3 * kWave) __attribute__((amdgpu_waves_per_eu(trio_
     __shared__ Cold cold;
     const int lane = threadIdx.x & (kWave - 1);
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x == 0) {
+    // (the cold block is filled by a lane of judge O, the role with slack ahead of barrier B: on the driver's wavefront its ~100
+    //  scalar loads, float64 products and LDS writes stood in front of the launch's first loads - TDE_COLD_FILL_LANE=0 for the A/B)
+#ifndef TDE_COLD_FILL_LANE
+#define TDE_COLD_FILL_LANE (2 * kWave)
+#endif
+    if (threadIdx.x == TDE_COLD_FILL_LANE) {
         fill_cold(cold, cfg, w); sh.hit_mask = 0ull; sh.off_mask = 0ull; sh.tl_mask = 0ull;
         sh.max_steps_w = cfg.max_steps; sh.term_at_infraction_w = cfg.terminated_at_infraction;
     }
@@ -3367,7 +3519,7 @@ __global__ __launch_bounds__(kBlock) void env_reset_kernel(tde_config cfg, tde_w
 template <int A>
 __global__ __launch_bounds__(kBlock) void first_gap_kernel(tde_config cfg, tde_world w, uint32_t key)
 {
-    static_assert(A <= kWave, "a scenario's slots inside one wavefront");
+    static_assert(A <= 2 * kWave, "a scenario's slots inside one or two wavefronts of the workgroup");
     __shared__ Tiles<kBlock> t;
     const uint32_t F = cfg.flags;
     const int tid = threadIdx.x;
@@ -3389,7 +3541,14 @@ __global__ __launch_bounds__(kBlock) void first_gap_kernel(tde_config cfg, tde_w
     const bool has_target = (F & TDE_F_NPC) && ag.present && ag.route >= 0 && ag.route_wp < si.z;
     const float g_far = (ag.vdes * ag.vdes / cfg.npc_max_accel) * 1.01f + cfg.npc_gap_s0 + 0.1f;        // (load_ctx)
     const int base = tid - a;
-    float gap = npc_gap<A>(cfg, &t.a[base], &t.b[base], a, bit_of_row<A>(a), ag, c0, s0, has_target, g_far);
+    float gap;
+    if constexpr (A > 64) {     // two halves of 64 rows, as npc_action_wide
+        const unsigned long long own = one_bit64(63 - (a & 63));
+        gap = fminf(npc_gap<64>(cfg, &t.a[base], &t.b[base], a, a < 64 ? own : 0ull, ag, c0, s0, has_target, g_far),
+                    npc_gap<64>(cfg, &t.a[base + 64], &t.b[base + 64], a - 64, a < 64 ? 0ull : own, ag, c0, s0, has_target, g_far));
+    } else {
+        gap = npc_gap<A>(cfg, &t.a[base], &t.b[base], a, bit_of_row<A>(a), ag, c0, s0, has_target, g_far);
+    }
     if ((F & TDE_F_TRAFFIC_LIGHTS) && has_target) {
         const tde_map m = w.maps[reinterpret_cast<const int4 *>(w.scn)[scn].x];
         const uint32_t red = red_mask(w, m, 1);
