@@ -154,7 +154,7 @@ def patch_step3(s):
     a, b = kernel_span(s, "env_step_trio_kernel")
     k = s[a:b]
     k = sub(k, "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n",
-            "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n")
+            "    const int lane = threadIdx.x & (kWave - 1);\n    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n    if (threadIdx.x == 0) g_wg[blockIdx.x & 4095][22] = __builtin_amdgcn_s_memrealtime();\n")
     # drive
     k = sub(k, "        float c0, s0;\n        const bool live = valid && ag.present;\n        const int k = er.steps + 1;",
             "        tde_mark(&stl, 0);\n        float c0, s0;\n        const bool live = valid && ag.present;\n        const int k = er.steps + 1;")
@@ -165,7 +165,7 @@ def patch_step3(s):
     k = sub(k, "        lds_barrier();                                       // A: the judges' masks are published\n",
             "        tde_mark(&stl, 6);\n        lds_barrier();                                       // A: the judges' masks are published\n        tde_mark(&stl, 4);\n")
     k = sub(k, "        if (respawned || switched || rebuilt || need_tg2) store_slot_cache(st, g, ag, er, cx, cfg.flags, respawned);\n",
-            "        if (respawned || switched || rebuilt || need_tg2) store_slot_cache(st, g, ag, er, cx, cfg.flags, respawned);\n        tde_mark(&stl, 5);\n        tde_flush(0, 7);\n")
+            "        if (respawned || switched || rebuilt || need_tg2) store_slot_cache(st, g, ag, er, cx, cfg.flags, respawned);\n        tde_mark(&stl, 5);\n        tde_flush(0, 7);\n        if (lane == 0) { g_wg[blockIdx.x & 4095][23] = __builtin_amdgcn_s_memrealtime(); g_wg[blockIdx.x & 4095][7] = dn ? 1ull : 0ull; }\n")
     # judge C
     k = sub(k, "        lds_barrier();                                       // B\n        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_C2);",
             "        tde_mark(&stl, 8);\n        lds_barrier();                                       // B\n        tde_mark(&stl, 9);\n        if (TDE_STEP_PRIO_SWITCH) __builtin_amdgcn_s_setprio(TDE_STEP_PRIO_C2);")

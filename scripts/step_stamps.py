@@ -47,3 +47,17 @@ names = {0: "D: entry -> state + cache loaded", 1: "D: controller", 2: "D: bicyc
          19: "O: wait A"}
 for i, nm in names.items():
     print(f"  {nm:42s} {out[i] / n:8.0f} ticks")
+
+# the last launch's workgroups on the 100 MHz counter (slots 22 / 23: entry / the drive wavefront's last store issued; 7: held a finished env)
+import numpy as np
+raw = np.zeros((4096, 24), dtype=np.uint64)
+lib.tde_debug_wg(raw.ctypes.data_as(C.c_void_p))
+nwg = min(B * A // 64, 4096)
+t0, t1, dn = raw[:nwg, 22].astype(np.int64), raw[:nwg, 23].astype(np.int64), raw[:nwg, 7] != 0
+z = t0.min()
+q = lambda v: " / ".join(f"{x * 0.01:6.2f}" for x in np.percentile(v, [0, 25, 50, 75, 95, 100]))
+print(f"  workgroup start, us after the first (min / 25 % / median / 75 % / 95 % / max): {q(t0 - z)}")
+print(f"  drive wavefront's end                                                      : {q(t1 - z)}")
+print(f"  lifetime, workgroups without a finished env ({int((~dn).sum())})                      : {q((t1 - t0)[~dn])}")
+if dn.any():
+    print(f"  lifetime, workgroups that re-spawned an env ({int(dn.sum())})                        : {q((t1 - t0)[dn])}")

@@ -181,7 +181,7 @@ static int first_gaps_launch(const tde_config *cfg, const tde_world *world, void
 // takes its arguments by value.
 namespace {
 constexpr int kArgBlocks = 2048;
-struct ArgEntry { int device; int slot; std::vector<void *> streams; };
+struct ArgEntry { int device; int slot; uint64_t hash; std::vector<void *> streams; };
 struct ArgPool { tde::StepArgs *host = nullptr, *dev = nullptr; int used = 0; };
 std::mutex g_arg_mu;
 std::vector<ArgEntry> g_arg_entries;
@@ -197,11 +197,18 @@ static const tde::StepArgs *step_args(const tde_config *cfg, const tde_world *wo
     now.cfg = *cfg; now.w = *world; now.st = *st; now.st.action = nullptr; now.act_hash = act_hash;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    uint64_t hash = 0xcbf29ce484222325ull;                                   // (a filter in front of the byte comparison)
+    {
+        uint64_t words[sizeof(now) / 8];
+        static_assert(sizeof(now) % 8 == 0, "StepArgs is a whole number of 8-byte words");
+        memcpy(words, &now, sizeof(now));
+        for (uint64_t x : words) hash = (hash ^ x) * 0x100000001b3ull;
+    }
     std::lock_guard<std::mutex> lock(g_arg_mu);
     ArgPool &pool = g_arg_pool[dev];
     ArgEntry *ent = nullptr;
     for (auto &e : g_arg_entries)
-        if (e.device == dev && memcmp(&pool.host[e.slot], &now, sizeof(now)) == 0) { ent = &e; break; }
+        if (e.device == dev && e.hash == hash && memcmp(&pool.host[e.slot], &now, sizeof(now)) == 0) { ent = &e; break; }
     if (!ent) {
         if (capturing) return nullptr;
         if (!pool.host) {
@@ -210,7 +217,7 @@ static const tde::StepArgs *step_args(const tde_config *cfg, const tde_world *wo
         }
         if (pool.used >= kArgBlocks) return nullptr;
         memcpy(&pool.host[pool.used], &now, sizeof(now));
-        g_arg_entries.push_back(ArgEntry{dev, pool.used++, {}});
+        g_arg_entries.push_back(ArgEntry{dev, pool.used++, hash, {}});
         ent = &g_arg_entries.back();
     }
     bool uploaded = false;
@@ -327,8 +334,13 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
         // Two roles (four wavefronts per env) at every batch size - us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs:
         // two roles 6.2 / 8.9 / 18.0 / 34.7, one role 10.6 / 11.4 / 23.3 / 38.9 (profiles/r04_z_wide2_waves.txt).
         // tde_kernel_override(1, 0) forces the one-role kernel.
-        const bool one_role = g_force_rollout == 1;
-        return one_role ? tde_host::launch_rollout_solo(cfg, world, st, &r128, stream) : tde_host::launch_rollout_wide(cfg, world, st, &r128, stream);
+        if (g_force_rollout == 1) return tde_host::launch_rollout_solo(cfg, world, st, &r128, stream);
+        const tde::StepArgs *args = nullptr;
+#if TDE_WIDE_ROLLOUT_BLOCK       // (A/B: the arguments from a block in device memory, as the one-step kernel's)
+        args = step_args(cfg, world, st, 0u, stream);
+        if (!args) return tde_host::launch_rollout_solo(cfg, world, st, &r128, stream);
+#endif
+        return tde_host::launch_rollout_wide(args, cfg, world, st, &r128, stream);
     }
     // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
     // forces one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median

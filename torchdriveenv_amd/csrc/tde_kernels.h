@@ -1857,6 +1857,15 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 
 #undef TDE_ROLE_PROLOGUE
 
+// The arguments of env_step_wide_kernel's launch as ONE block in device memory instead of ~900 bytes of by-value arguments: every field
+// is then a scalar load where it is used, not a scalar register held from the kernel's top - 58 SGPRs instead of 106 with 4 - 24 of
+// them spilled, and with that 124 VGPRs WITHOUT the 6 - 43 spilled ones: no private segment, whose set-up costs a launch more than a
+// microsecond (1024 envs x 128 slots: 16.0 -> 13.8 us per step; the first loads also issue 1 400 cycles sooner, which by itself
+// changes nothing: profiles/r06_z_wide_128.txt).  Blocks are immutable, one per distinct argument set (tde_api.hip: step_args); the action
+// pointer - the one field a closed loop changes from call to call - stays a by-value argument.  (The three-role kernels keep by-value
+// arguments: at 6 wavefronts per SIMD the block's extra hop costs them 0.2 - 0.4 us, same file.)
+struct StepArgs { tde_config cfg; tde_world w; tde_state st; uint32_t act_hash; uint32_t pad; };
+
 // ------------------------------------------------------------------------------------------------------------------
 // The two-role rollout for 128 agent slots per env (the reference's ~100-agent scenes): ONE env per workgroup of four
 // wavefronts - drive (slots 0-63), drive (64-127), judge (0-63), judge (64-127).  The one-role kernel runs both 128-row
@@ -1925,10 +1934,23 @@ TDE_DEV int wide_role_wave()
 #ifndef TDE_WIDE2_WAVES
 #define TDE_WIDE2_WAVES 4
 #endif
+#ifndef TDE_WIDE_ROLLOUT_BLOCK
+#define TDE_WIDE_ROLLOUT_BLOCK 0         // 1: the persistent kernel's arguments from the block too (A/B: 16 instead of 34 spilled VGPRs, and SLOWER -
+                                         // 1024 envs 5.25 -> 6.13 us per step: scalar loads inside the step loop; profiles/r06_z_wide_128.txt)
+#endif
 template <bool LIGHTS>
+#if TDE_WIDE_ROLLOUT_BLOCK
+__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(const StepArgs *__restrict__ args,
+                                                                     tde_rollout ro)
+{
+    const tde_config &cfg = args->cfg;
+    const tde_world &w = args->w;
+    const tde_state &st = args->st;
+#else
 __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(tde_config cfg, tde_world w, tde_state st,
                                                                      tde_rollout ro)
 {
+#endif
     constexpr int A = 128;
     __shared__ WideShared sh;
     __shared__ Cold cold;
@@ -2678,14 +2700,6 @@ TDE_DEV void store_slot_cache(const tde_state &st, int64_t g, const Agent &ag, c
 //  counters of one configuration never share a word and two configurations collide with probability 2^-32; ABI 9 kept 12 bits)
 TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash ^ ((uint32_t)steps * 0x9E3779B1u)); }
 
-// The arguments of env_step_wide_kernel's launch as ONE block in device memory instead of ~900 bytes of by-value arguments: every field
-// is then a scalar load where it is used, not a scalar register held from the kernel's top - 58 SGPRs instead of 106 with 4 - 24 of
-// them spilled, and with that 124 VGPRs WITHOUT the 6 - 43 spilled ones: no private segment, whose set-up costs a launch more than a
-// microsecond (1024 envs x 128 slots: 16.0 -> 13.8 us per step; the first loads also issue 1 400 cycles sooner, which by itself
-// changes nothing: profiles/r06_z_wide_128.txt).  Blocks are immutable, one per distinct argument set (tde_api.hip: step_args); the action
-// pointer - the one field a closed loop changes from call to call - stays a by-value argument.  (The three-role kernels keep by-value
-// arguments: at 6 wavefronts per SIMD the block's extra hop costs them 0.2 - 0.4 us, same file.)
-struct StepArgs { tde_config cfg; tde_world w; tde_state st; uint32_t act_hash; uint32_t pad; };
 
 // ------------------------------------------------------------------------------------------------------------------
 // Closed-loop step for 128 agent slots per env, two roles (tde_env_step with the action cache; round 6).  The one-role kernel runs

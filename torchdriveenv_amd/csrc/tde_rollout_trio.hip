@@ -32,11 +32,18 @@ int launch_rollout_trio(const tde_config *cfg, const tde_world *world, const tde
     return launch_status("tde_env_rollout");
 }
 
-int launch_rollout_wide(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, void *stream)
+int launch_rollout_wide(const tde::StepArgs *args, const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, void *stream)
 {
     // two roles, four wavefronts per env of 128 slots: one env per workgroup
+#if TDE_WIDE_ROLLOUT_BLOCK
+    (void)world;
+    if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) tde::env_rollout_wide_kernel<true><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(args, *ro);
+    else tde::env_rollout_wide_kernel<false><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(args, *ro);
+#else
+    (void)args;
     if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) tde::env_rollout_wide_kernel<true><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
     else tde::env_rollout_wide_kernel<false><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
+#endif
     return launch_status("tde_env_rollout");
 }
 
