@@ -208,8 +208,8 @@ def patch_wide(s):
             "    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n"
             "    unsigned long long *sp = (wv & 1) ? nullptr : &stl;\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n"
             "    if (threadIdx.x == 0) g_wg[blockIdx.x & 4095][20] = __builtin_amdgcn_s_memrealtime();\n")
-    k = sub(k, "    if (wv == 2 && lane == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }\n",
-            "    if (wv == 2 && lane == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }\n    if (wv == 2) { asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); tde_mark(sp, 16); }\n")
+    k = sub(k, "        sh.help_seq[0] = sh.help_seq[1] = sh.off_seq[0] = sh.off_seq[1] = 0;\n    }\n",
+            "        sh.help_seq[0] = sh.help_seq[1] = sh.off_seq[0] = sh.off_seq[1] = 0;\n    }\n    if (wv == 2) { asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); tde_mark(sp, 16); }\n")
     k = sub(k, "        if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }\n",
             "        if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }\n        tde_mark(sp, 17);\n")
     # drive
@@ -217,8 +217,8 @@ def patch_wide(s):
             "        lds_barrier();                                       // cold is published\n        tde_mark(sp, 0);\n        Ctx cx;\n        bool rebuilt;\n")
     k = sub(k, "        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n",
             "        tde_mark(sp, 1);\n        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n        tde_mark(sp, 2);\n")
-    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(0);",
-            "        tde_mark(sp, 3);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 4);\n        __builtin_amdgcn_s_setprio(0);")
+    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : 0);",
+            "        tde_mark(sp, 3);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 4);\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : 0);")
     k = sub(k, "        lds_barrier();                                       // A: the env's done flag is published\n",
             "        tde_mark(sp, 5);\n        lds_barrier();                                       // A: the env's done flag is published\n        tde_mark(sp, 6);\n")
     k = sub(k, "            if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));\n        }\n",

@@ -89,10 +89,12 @@ def test_env_step_rollout_and_birdview_128_slots(crowded_town, lights):
 
 
 @pytest.mark.parametrize("lights", [False, True])
-@pytest.mark.parametrize("form", [None, "solo"])
+@pytest.mark.parametrize("form", [None, "duo", "solo"])
 def test_both_step_forms_at_128_slots_with_every_output(crowded_town, lights, form):
     """tde_env_step at 128 agent slots: the two-role kernel (round 6: drive / judge wavefronts for each half of the env's slots, the next
-    step's controller beside the judges, actions through tde_act_cache) and the one-role kernel (tde_kernel_override(0, 1); also what a
+    step's controller beside the judges, actions through tde_act_cache) in its eight-wavefront form (None: what the library picks for a
+    small batch - sweep and offroad helpers beside the drivers and judges) and its four-wavefront form ("duo"), and the one-role kernel
+    (tde_kernel_override(0, 1); also what a
     state without the action cache gets), with info terms, done bits, episode statistics, the compact observation and the infraction
     magnitudes: 60 steps with re-spawns == the oracle, every array bit for bit; a state edit behind the cache's back (load) is survived"""
     from torchdriveenv_amd import _lib

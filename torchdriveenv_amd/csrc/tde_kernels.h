@@ -2714,13 +2714,28 @@ TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash 
 // launch, a re-spawned env's first step, a state edited from outside), B = the rows of the step are committed, A = the env's done
 // flag is published.  Same per-agent arithmetic in the same order as step_lane: the oracle's bits.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef TDE_WIDE_STEP_WAVES8
+#define TDE_WIDE_STEP_WAVES8 1       // 0: the library never launches the eight-wavefront form (A/B)
+#endif
 struct WideStepShared : WideShared {
     int early[2];                        // a drive wavefront has a slot without a stored action
     float poly[32];                      // MAG: box_iou_wave's vertex lists
+    // the eight-wavefront form: what the helpers take from / hand to the drivers and judges
+    float ctl[128];                      // drive -> sweep helper: the slot's g_far for the NEXT step's controller, < 0 = no target
+    float gap_part[128];                 // sweep helper -> drive: the leader gap over rows 64-127
+    int offw[128];                       // offroad helper -> judge: the slot's offroad flag
+    int tlw;                             // ... and the ego's stop-line violation
+    int help_seq[2], off_seq[2];         // 1 = a helper wavefront's results are written
 };
 
-template <bool LIGHTS, bool OBS, bool MAG>
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_step_wide_kernel(const StepArgs *__restrict__ args,
+// NW = 8 (batches up to half a residency round, where the CUs have issue slots to spare): four more wavefronts per env take work off the
+// two chains that bound the launch behind barrier B -
+//   sweep helper (0-63), (64-127) : the next step's controller sweep over rows 64-127 for the drivers' slots (the drivers keep rows 0-63,
+//                                   the exact tests' minimum over both and the action: npc_action_wide's two halves on two wavefronts)
+//   offroad helper (0-63), (64-127): offroad of all slots and the ego's stop-line violation (the judges keep collision, reward, outputs)
+// handed over through LDS with a flag per wavefront pair, as the judges' collision credits.  Same values, same order of the minima.
+template <bool LIGHTS, bool OBS, bool MAG, int NW = 4>
+__global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4))) void env_step_wide_kernel(const StepArgs *__restrict__ args,
                                                                                                            const float *__restrict__ action)
 {
     const tde_config &cfg = args->cfg;
@@ -2732,11 +2747,14 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
     __shared__ Cold cold;
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = wide_role_wave();
-    const int role = wv >> 1;                               // 0 = drive, 1 = judge
+    const int role = wv >> 1;                               // 0 = drive, 1 = judge; NW = 8: 2 = sweep helper, 3 = offroad helper
     const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
     // (the cold block is filled by a JUDGE lane - the drivers' loads are the launch's first instructions - and published by an
     //  LDS-only barrier that every role reaches with its loads in flight)
-    if (wv == 2 && lane == 0) { fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0; }
+    if (wv == (NW == 8 ? 4 : 2) && lane == 0) {
+        fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0;
+        sh.help_seq[0] = sh.help_seq[1] = sh.off_seq[0] = sh.off_seq[1] = 0;
+    }
     const uint32_t F = cfg.flags;
     const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;
     const bool lights = LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS);
@@ -2816,14 +2834,27 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         sincos_f32(ag.psi, s0, c0);
         er.steps = k;
         write_rows_wide(sh, 0, a, live, ag, c0, s0, cfg.npc_lane_half);
+        has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;          // of the NEXT step's controller
+        if constexpr (NW == 8) sh.ctl[a] = has_target ? cx.g_far : -1.0f;
         lds_barrier();                                       // B: rows of this step are in buffer 0
-        __builtin_amdgcn_s_setprio(0);                       // behind B the judges' sweeps are the critical path
+        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : 0);         // behind B the judges' sweeps are the critical path (four wavefronts)
         if (switched && need_tg2) load_route_target(cold, ag, cx);               // (the look-ahead entry was not there yet: rare)
         if (switched || need_tg2) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);       // (only stored)
         // the controller of the NEXT step, beside the judges of this one (speculative: a re-spawn below discards it)
         float na2 = 0.0f, nb2 = 0.0f;
-        has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;
-        if ((F & TDE_F_NPC) && ap) controller(0, k + 1, na2, nb2);
+        if ((F & TDE_F_NPC) && ap) {
+            if constexpr (NW == 8) {
+                const uint32_t red = lights ? red_mask(w, cx.m, k + 1) : 0u;
+                const float red_gap = (lights && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
+                const unsigned long long own = one_bit64(63 - (a & 63));
+                const float g0 = npc_gap<64>(cfg, &sh.a[0][0], &sh.b[0][0], a, a < 64 ? own : 0ull, ag, c0, s0, has_target, cx.g_far);
+                while (*reinterpret_cast<volatile int *>(&sh.help_seq[wv & 1]) != 1) __builtin_amdgcn_s_sleep(1);
+                const float g1 = *reinterpret_cast<volatile float *>(&sh.gap_part[a]);
+                npc_act_of_gap(cfg, ag, c0, s0, has_target, cx.tgx, cx.tgy, fminf(g0, g1), red_gap, na2, nb2);
+            } else {
+                controller(0, k + 1, na2, nb2);
+            }
+        }
         lds_barrier();                                       // A: the env's done flag is published
         __builtin_amdgcn_s_setprio(3);
         const bool respawned = sh.done != 0;
@@ -2838,7 +2869,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
             // (a re-spawned env's first actions are the next launch's: its key is stored invalid - the prologue above computes them)
             if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));
         }
-    } else {
+    } else if (role == 1) {
         // ================================ judge ================================
         __builtin_amdgcn_s_setprio(1);
         // A judge lane's own slot state comes from the rows behind barrier B: only the EGO lane reads the state arrays (its pose
@@ -2874,7 +2905,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         const bool live = rc.z != 0.0f;
         const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
         Corners corners;
-        if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+        if (NW != 8 && (F & TDE_F_OFFROAD)) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
 #if TDE_WIDE_SYM
         bool hit = collide_rows_wide_sym(&sh.a[0][0], &sh.b[0][0], a, live, x, y, c0, s0, hl, hw, ra.z, sh.coll, 1);
         wide_sym_publish(sh, wv & 1, lane, 1);
@@ -2882,12 +2913,18 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
         const bool hit = collide_rows_wide<A>(&sh.a[0][0], &sh.b[0][0], a, live, x, y, c0, s0, hl, hw, ra.z);
 #endif
         bool off = false;
-        if (F & TDE_F_OFFROAD) off = offroad_resolve<true, false>(w, corners, thr2, cx.m.rec_base);
+        if (NW != 8 && (F & TDE_F_OFFROAD)) off = offroad_resolve<true, false>(w, corners, thr2, cx.m.rec_base);
 #if TDE_WIDE_SYM
         hit |= wide_sym_joined(sh, wv & 1, a, 1);
 #endif
         bool tl = false;
-        if (lights && a == 0) tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
+        if constexpr (NW == 8) {                             // (the offroad helper's flags for this half of the slots)
+            while (*reinterpret_cast<volatile int *>(&sh.off_seq[wv & 1]) != 1) __builtin_amdgcn_s_sleep(1);
+            off = *reinterpret_cast<volatile int *>(&sh.offw[a]) != 0;
+            if (lights && a == 0) tl = *reinterpret_cast<volatile int *>(&sh.tlw) != 0;
+        } else if (lights && a == 0) {
+            tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask(w, cx.m, k), x, y, c0, s0, hl, hw);
+        }
         StepOut o{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
         const int ti0 = er.target_idx;
         if (a == 0) {
@@ -2967,6 +3004,50 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
                 ego_magnitudes_of_wave<A, true>(cfg, w, [&](int) { return map0; }, __ballot(a == 0), hit_m, off_m, &sh.a[0][0], &sh.b[0][0], lane, sh.poly,
                                                 a == 0 ? reinterpret_cast<float4 *>(st.magnitudes) + e : nullptr);
         }
+    }
+    else if (NW == 8 && role == 2) {
+        // ================================ sweep helper (NW = 8) ================================
+        __builtin_amdgcn_s_setprio(2);
+        lds_barrier();                                       // cold
+        lds_barrier();                                       // E
+        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2
+        lds_barrier();                                       // B: rows of this step are in buffer 0, the drivers' ctl words beside them
+        if ((F & TDE_F_NPC) && st.act_cache) {
+            const float4 ra = sh.a[0][a], rb = sh.b[0][a];
+            const float gf = sh.ctl[a];
+            Agent me{};
+            me.x = ra.x; me.y = ra.y; me.len = 2.0f * rb.z;  // (0.5f * len == hl exactly: the driver's own operand)
+            const unsigned long long own = one_bit64(63 - (a & 63));
+            sh.gap_part[a] = npc_gap<64>(cfg, &sh.a[0][64], &sh.b[0][64], a - 64, a < 64 ? 0ull : own, me, rb.x, rb.y, gf >= 0.0f, gf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *reinterpret_cast<volatile int *>(&sh.help_seq[wv & 1]) = 1;
+        }
+        lds_barrier();                                       // A
+    } else if (NW == 8 && role == 3) {
+        // ================================ offroad helper (NW = 8) ================================
+        __builtin_amdgcn_s_setprio(1);
+        const int scn = st.scn[e], k = st.steps[e] + 1;
+        lds_barrier();                                       // cold
+        tde_map m{};
+        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[scn].x];
+        const float thr2 = thr2_of(cfg);
+        lds_barrier();                                       // E
+        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2
+        lds_barrier();                                       // B
+        const float4 ra = sh.a[0][a], rb = sh.b[0][a], rc = sh.c[0][a];
+        const bool live = rc.z != 0.0f;
+        bool off = false;
+        if (F & TDE_F_OFFROAD) {
+            Corners corners;
+            offroad_issue<false>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, corners);
+            off = offroad_resolve<true, false>(w, corners, thr2, m.rec_base);
+        }
+        sh.offw[a] = off ? 1 : 0;
+        if (lights && a == 0)
+            sh.tlw = tl_violation_of(WideLines{sh, w.stoplines + m.stop_base}, m.n_stop, red_mask(w, m, k), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w) ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *reinterpret_cast<volatile int *>(&sh.off_seq[wv & 1]) = 1;
+        lds_barrier();                                       // A
     }
 }
 
