@@ -15,15 +15,15 @@ from torchdriveenv_amd.synth import synthetic_world
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 SKIP = ("action", "env_cache", "slot_cache", "act_cache", "obs")
 bad = 0
-for A in (8, 16, 32, 64):
+for A in (8, 16, 32, 64, 128):
     for lights in (False, True):
         world = synthetic_world(n_scn=16, A=A, seed=2 + A, n_maps=2)
         flags = _abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0)
         cfg = _abi.default_config(seed=21, flags=flags, max_steps=40, distance_cutoff=0.25)
         dw = world.to_device("cuda:0")
-        for B in (512, 1024, 1536, 4096):
+        for B in ((48, 600) if A == 128 else (512, 1024, 1536, 4096)):      # (128 slots: eight wavefronts per env / four / one role)
             for mag in (True, False):
-                forms = ("trio", "solo") if A in (8, 16, 32) else ("solo",)
+                forms = ("trio", "solo") if A in (8, 16, 32) else ("auto", "duo", "solo") if A == 128 else ("solo",)
                 hs = EnvState(B, A, with_magnitudes=mag)
                 oracle.env_reset(cfg, world, hs)
                 ds = [EnvState(B, A, device="cuda:0", with_obs=True, with_magnitudes=mag) for _ in forms]

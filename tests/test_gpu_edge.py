@@ -386,18 +386,18 @@ def test_configs3_partitioning_at_full_size_on_one_gpu():
     assert (fd & 1).sum() > 0 and fep.max() >= 2
 
 
-@pytest.mark.parametrize("A,lights", [(16, True), (8, False), (32, True)])
+@pytest.mark.parametrize("A,lights", [(16, True), (8, False), (32, True), (128, True), (128, False)])
 def test_first_step_gap_cache_filled_and_missing_give_the_oracles_results(A, lights):
     """tde_world.first_gap (ABI 11): with the cache filled (tde_first_gaps; tde_env_step / tde_env_rollout fill it on first use) a
     re-spawned env's first NPC actions come from min(cached gap, exact test against the ego) - with its entries missing (zeroed behind
     the library's back, or never filled: another configuration's keys) from the whole controller.  Both equal the oracle bit for bit,
-    in the three-role step kernel and the two- / three-role rollout kernels; the table itself: a keyed entry per NPC slot, 1e30 for a
-    slot without a route."""
+    in the three-role step kernel and the two- / three-role rollout kernels (128 slots: the two-role step kernel's `early` path, eight
+    wavefronts per env at this batch size); the table itself: a keyed entry per NPC slot, 1e30 for a slot without a route."""
     from tests.test_gpu_parity import assert_state_equal, dev
 
     world = synthetic_world(n_scn=8, A=A, seed=5, n_maps=2)
     dw = world.to_device(DEV)
-    B, K = 128, 70
+    B, K = (128 if A < 128 else 20), 70
     cfg = _abi.default_config(seed=21, flags=_abi.F_ALL | (_abi.F_TRAFFIC_LIGHTS if lights else 0), max_steps=25, distance_cutoff=0.25)
     rng = np.random.default_rng(2)
     acts = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
