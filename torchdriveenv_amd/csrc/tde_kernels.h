@@ -2837,7 +2837,13 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;          // of the NEXT step's controller
         if constexpr (NW == 8) sh.ctl[a] = has_target ? cx.g_far : -1.0f;
         lds_barrier();                                       // B: rows of this step are in buffer 0
-        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : 0);         // behind B the judges' sweeps are the critical path (four wavefronts)
+#ifndef TDE_WIDE_PRIO_D2
+#define TDE_WIDE_PRIO_D2 3           // the drivers' issue priority behind barrier B (four wavefronts per env), the judges' below: since the
+#endif                               // judges sweep every pair once the drivers' controller is the longer chain - (3, 1) 11.99 us per step at
+#ifndef TDE_WIDE_PRIO_J2             // 1024 envs against 12.16 for the (0, 2) of the 128-row collision sweep, (2, 2) 12.14
+#define TDE_WIDE_PRIO_J2 1
+#endif
+        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_D2);
         if (switched && need_tg2) load_route_target(cold, ag, cx);               // (the look-ahead entry was not there yet: rare)
         if (switched || need_tg2) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);       // (only stored)
         // the controller of the NEXT step, beside the judges of this one (speculative: a re-spawn below discards it)
@@ -2898,7 +2904,7 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         lds_barrier();                                       // E
         if (sh.early[0] | sh.early[1]) lds_barrier();        // E2
         lds_barrier();                                       // B: rows of this step are in buffer 0
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_J2);
         er.steps += 1;
         const int k = er.steps;
         const float4 ra = sh.a[0][a], rb = sh.b[0][a], rc = sh.c[0][a];
