@@ -88,7 +88,9 @@ TDE_API int tde_env_reset(const tde_config *cfg, const tde_world *world, const t
  * (gym_env.py:453-461, 369-389, 115-120): bicycle kinematics, heuristic NPC controller (in place of the IAI call,
  * :285-294), replay override (:275-283), all-pairs OBB collision, drivable-mesh offroad, WaypointSuite reward,
  * termination/truncation, info, waypoint advance, and (TDE_F_AUTORESET) in-place re-spawn of finished envs.
- * Reads state->action [B][2]; writes state in place. */
+ * Reads state->action [B][2]; writes state in place.
+ * (At 128 agent slots the kernel reads (cfg, world, state) from an immutable argument block the library keeps in device memory, one
+ *  per distinct argument set, uploaded on `stream` at first use; every other form takes them by value.  INTEGRATION.md, section 1.) */
 TDE_API int tde_env_step(const tde_config *cfg, const tde_world *world, const tde_state *state, void *stream);
 
 /* K consecutive timesteps with the ego actions taken from a resident [K][B][2] buffer (open-loop / action-repeat

@@ -217,8 +217,8 @@ def patch_wide(s):
             "        lds_barrier();                                       // cold is published\n        tde_mark(sp, 0);\n        Ctx cx;\n        bool rebuilt;\n")
     k = sub(k, "        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n",
             "        tde_mark(sp, 1);\n        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n        tde_mark(sp, 2);\n")
-    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : 0);",
-            "        tde_mark(sp, 3);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 4);\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : 0);")
+    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_D2);",
+            "        tde_mark(sp, 3);\n        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 4);\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_D2);")
     k = sub(k, "        lds_barrier();                                       // A: the env's done flag is published\n",
             "        tde_mark(sp, 5);\n        lds_barrier();                                       // A: the env's done flag is published\n        tde_mark(sp, 6);\n")
     k = sub(k, "            if (a == 0) reinterpret_cast<int2 *>(ap)[A] = make_int2(((F & TDE_F_NPC) && !respawned) ? er.episode : -1, act_key_steps(act_hash, er.steps));\n        }\n",
@@ -227,8 +227,8 @@ def patch_wide(s):
     # judge
     k = sub(k, "        lds_barrier();                                       // E\n        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2\n",
             "        tde_mark(sp, 8);\n        lds_barrier();                                       // E\n        if (sh.early[0] | sh.early[1]) lds_barrier();        // E2\n")
-    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(2);\n",
-            "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 9);\n        __builtin_amdgcn_s_setprio(2);\n")
+    k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_J2);\n",
+            "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        tde_mark(sp, 9);\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_J2);\n")
     k = sub(k, "        wide_sym_publish(sh, wv & 1, lane, 1);\n", "        wide_sym_publish(sh, wv & 1, lane, 1);\n        tde_mark(sp, 10);\n")
     k = sub(k, "        hit |= wide_sym_joined(sh, wv & 1, a, 1);\n", "        tde_mark(sp, 11);\n        hit |= wide_sym_joined(sh, wv & 1, a, 1);\n        tde_mark(sp, 12);\n")
     k = sub(k, "        lds_barrier();                                       // A\n        const bool respawned = sh.done != 0;\n        st.collided[g]",

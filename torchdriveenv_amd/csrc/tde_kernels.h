@@ -2714,6 +2714,12 @@ TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash 
 // launch, a re-spawned env's first step, a state edited from outside), B = the rows of the step are committed, A = the env's done
 // flag is published.  Same per-agent arithmetic in the same order as step_lane: the oracle's bits.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef TDE_WIDE_PRIO_D2
+#define TDE_WIDE_PRIO_D2 3           // the drivers' issue priority behind barrier B (four wavefronts per env), the judges' below: since the
+#endif                               // judges sweep every pair once the drivers' controller is the longer chain - (3, 1) 11.99 us per step at
+#ifndef TDE_WIDE_PRIO_J2             // 1024 envs against 12.16 for the (0, 2) of the 128-row collision sweep, (2, 2) 12.14
+#define TDE_WIDE_PRIO_J2 1
+#endif
 #ifndef TDE_WIDE_STEP_WAVES8
 #define TDE_WIDE_STEP_WAVES8 1       // 0: the library never launches the eight-wavefront form (A/B)
 #endif
@@ -2837,12 +2843,6 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         has_target = npc && ag.route >= 0 && ag.route_wp < cx.route_n;          // of the NEXT step's controller
         if constexpr (NW == 8) sh.ctl[a] = has_target ? cx.g_far : -1.0f;
         lds_barrier();                                       // B: rows of this step are in buffer 0
-#ifndef TDE_WIDE_PRIO_D2
-#define TDE_WIDE_PRIO_D2 3           // the drivers' issue priority behind barrier B (four wavefronts per env), the judges' below: since the
-#endif                               // judges sweep every pair once the drivers' controller is the longer chain - (3, 1) 11.99 us per step at
-#ifndef TDE_WIDE_PRIO_J2             // 1024 envs against 12.16 for the (0, 2) of the 128-row collision sweep, (2, 2) 12.14
-#define TDE_WIDE_PRIO_J2 1
-#endif
         __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_D2);
         if (switched && need_tg2) load_route_target(cold, ag, cx);               // (the look-ahead entry was not there yet: rare)
         if (switched || need_tg2) load_next_target(cold, ag, cx.route_n, cx.tgx2, cx.tgy2);       // (only stored)
