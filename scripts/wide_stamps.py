@@ -1,4 +1,4 @@
-"""Milestones of the two-role 128-slot one-step kernel (make_stamped_build.py wide): 10-ns ticks between marks, wavefronts 0 (drive) and 2 (judge).
+"""Milestones of the two-role 128-slot one-step kernel (make_stamped_build.py wide): shader cycles between marks on wavefronts 0 (drive) and 2 (judge), workgroup start / end on the 100 MHz counter.
 usage: python scripts/make_stamped_build.py wide && TDE_HIP_LIB=$PWD/ab/libS.so python scripts/wide_stamps.py [B ...]"""
 import ctypes as C
 import os
