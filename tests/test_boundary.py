@@ -28,6 +28,23 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load() is not None     # full loader: argtypes + ABI version check
 
 
+def test_kernel_override_accepts_the_documented_teams_only():
+    """tde_kernel_override (no GPU involved: two atomics): rollout team 0..3, step team 0..3 (2 = the four-wavefront 128-slot step kernel
+    at any batch size); anything else is an argument error with a message, and the choice is left as it was"""
+    from torchdriveenv_amd import _lib
+
+    L = _lib.load()
+    try:
+        for r in range(4):
+            for s in range(4):
+                assert L.tde_kernel_override(r, s) == 0
+        for bad in ((4, 0), (-1, 0), (0, 4), (0, -1)):
+            assert L.tde_kernel_override(*bad) != 0
+            assert b"tde_kernel_override" in L.tde_last_error()
+    finally:
+        assert L.tde_kernel_override(0, 0) == 0
+
+
 def test_abi_struct_sizes_match_header():
     """compile a tiny C program against include/tde_abi.h and compare sizeof/offsetof with the ctypes mirror"""
     import subprocess
