@@ -171,7 +171,10 @@ TDE_DEV int lowest_bit(unsigned long long m) { return __ffsll((long long)m) - 1;
 //   * the row's verdict is formed as a float whose SIGN bit says "candidate" and shifted into the mask with one
 //     v_alignbit_b32 (mask = mask << 1 | sign): no compare, no select, no VCC.
 // Bit order: row r of the env lands in bit A-1-r (row_of_bit / bit_of_row below).
-constexpr int kSweepBlock = 2;
+#ifndef TDE_SWEEP_BLOCK
+#define TDE_SWEEP_BLOCK 2
+#endif
+constexpr int kSweepBlock = TDE_SWEEP_BLOCK;
 // Stage pins.  sched_barrier only constrains the machine scheduler, and instruction selection is free to place pure
 // arithmetic on either side of it; an empty asm that takes the stage's values as read-write operands is a real data
 // dependency: everything that produces them is issued before it, everything that consumes them after it.  The
@@ -244,9 +247,9 @@ template <int A, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks(const
 // The same sweep with every row fetched as two 8-byte halves (.xy / .zw) that are consumed - and therefore re-fetched for
 // the next block - at different stages: `stage(xy, zw, verdicts, prefetch_xy, prefetch_zw)`.  The halves of the two rows
 // of a block travel in one ds_read2_b64 each, so the number of LDS instructions is that of the 16-byte form.
-template <int A, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks_halves(const float4 *rows, S &&stage)
+template <int A, int SB = kSweepBlock, typename S> TDE_DEV typename MaskOf<A>::type sweep_blocks_halves(const float4 *rows, S &&stage)
 {
-    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
+    constexpr int C = A < SB ? A : SB;                      // (SB: rows per block; the 128-slot step kernel's plain form takes four)
     constexpr int NB = A / C;
     uint32_t word = 0, hi = 0;
     const float2 *h = reinterpret_cast<const float2 *>(rows);
@@ -615,12 +618,12 @@ TDE_DEV float npc_gap_exact(const tde_config &cfg, const float4 *ra, const float
 
 // (the hot path's form: sweep and exact tests in ONE function - split in two calls the same code costs the three-role kernels
 //  registers: 13 -> 18 spilled VGPRs in the rollout kernel, +0.5 us per closed-loop launch)
-template <int A>
+template <int A, int SB = kSweepBlock>
 TDE_DEV float npc_gap(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, typename MaskOf<A>::type own_bit, const Agent &ag,
                       float cp, float sp, bool has_target, float g_far)
 {
     using mask_t = typename MaskOf<A>::type;
-    constexpr int C = A < kSweepBlock ? A : kSweepBlock;
+    constexpr int C = A < SB ? A : SB;
     mask_t cand = 0;
     const float hl_i = 0.5f * ag.len;
     if (has_target) {
@@ -637,7 +640,7 @@ TDE_DEV float npc_gap(const tde_config &cfg, const float4 *ra, const float4 *rb,
         const float kc = fmaxf(cfg.npc_cone_k, 0.0f);
         // (the rows as two 8-byte halves fetched at different stages: 3.63 vs 3.67 us; with 16-byte reads like the
         //  collision sweep 3.25 vs 3.19, profiles/r02_d_ab_diet_steps.txt H1 / Q2)
-        cand = sweep_blocks_halves<A>(ra, [&](float2 (&xy)[C], float2 (&zw)[C], float (&v)[C], auto &&prefetch_xy, auto &&prefetch_zw) {
+        cand = sweep_blocks_halves<A, SB>(ra, [&](float2 (&xy)[C], float2 (&zw)[C], float (&v)[C], auto &&prefetch_xy, auto &&prefetch_zw) {
             float f[C], l[C], n[C], w[C];
 #pragma unroll
             for (int j = 0; j < C; ++j) { f[j] = __builtin_fmaf(xy[j].y, sp, nP); l[j] = __builtin_fmaf(-xy[j].x, sp, nQ); }
@@ -855,14 +858,14 @@ TDE_DEV bool collide_rows(const float4 *ra, const float4 *rb, int a, bool live, 
 // is the minimum over both (a minimum of the same values in another order: same bits), the collision flag their OR.
 // (round 4's first form walked every row with the exact tests: 43 us per step at ~ 120 agents per env against the masks' 11,
 //  profiles/r04_y_wide_times.txt)
-template <int A>
+template <int A, int SB = kSweepBlock>
 TDE_DEV void npc_action_wide(const tde_config &cfg, const float4 *ra, const float4 *rb, int i, const Agent &ag, float cp, float sp,
                              bool has_target, float tgx, float tgy, float g_far, float red_gap, float &acc, float &beta)
 {
     static_assert(A == 128, "two halves of 64 rows");
     const unsigned long long own = one_bit64(63 - (i & 63));
-    const float g0 = npc_gap<64>(cfg, ra, rb, i, i < 64 ? own : 0ull, ag, cp, sp, has_target, g_far);
-    const float g1 = npc_gap<64>(cfg, ra + 64, rb + 64, i - 64, i < 64 ? 0ull : own, ag, cp, sp, has_target, g_far);
+    const float g0 = npc_gap<64, SB>(cfg, ra, rb, i, i < 64 ? own : 0ull, ag, cp, sp, has_target, g_far);
+    const float g1 = npc_gap<64, SB>(cfg, ra + 64, rb + 64, i - 64, i < 64 ? 0ull : own, ag, cp, sp, has_target, g_far);
     npc_act_of_gap(cfg, ag, cp, sp, has_target, tgx, tgy, fminf(g0, g1), red_gap, acc, beta);
 }
 
@@ -2720,6 +2723,9 @@ TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash 
 #ifndef TDE_WIDE_PRIO_J2             // 1024 envs against 12.16 for the (0, 2) of the 128-row collision sweep, (2, 2) 12.14
 #define TDE_WIDE_PRIO_J2 1
 #endif
+#ifndef TDE_WIDE4_SWEEP_BLOCK
+#define TDE_WIDE4_SWEEP_BLOCK 4
+#endif
 #ifndef TDE_WIDE_STEP_WAVES8
 #define TDE_WIDE_STEP_WAVES8 1       // 0: the library never launches the eight-wavefront form (A/B)
 #endif
@@ -2800,7 +2806,12 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         auto controller = [&](int buf, int kk, float &na, float &nb) {
             const uint32_t red = lights ? red_mask(w, cx.m, kk) : 0u;
             const float red_gap = (lights && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-            npc_action_wide<A>(cfg, &sh.a[buf][0], &sh.b[buf][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+            // (four rows per block of the controller sweep in the plain four-wavefront variants: at one residency round the launch is
+            //  bound by dependent-issue latency at four wavefronts per SIMD - 1024 envs 12.05 -> 11.58 us per step, 768 envs 11.34 -> 10.55
+            //  with 14 spilled VGPRs; the variants with the magnitudes section gain nothing (14.45 / 14.51), those with the stop-line
+            //  loops lose - 16.9 -> 19.1 - and the eight-wavefront form too, 8.36 -> 8.72: they keep two.  profiles/r06_z_wide_128.txt)
+            npc_action_wide<A, (NW == 4 && !LIGHTS && !MAG) ? TDE_WIDE4_SWEEP_BLOCK : kSweepBlock>(cfg, &sh.a[buf][0], &sh.b[buf][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy,
+                                                                                          cx.g_far, red_gap, na, nb);
         };
         if (lights) fill_stop_cache_wide(sh, w, cx.m, a);
         if (F & TDE_F_NPC) {
