@@ -104,8 +104,8 @@ def patch_trio(s):
     # npc_action gets an optional stamp cursor
     s = sub(s, "float g_far, float red_gap, float &acc,\n                        float &beta)\n{\n    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far);\n",
             "float g_far, float red_gap, float &acc,\n                        float &beta, unsigned long long *stl = nullptr)\n{\n    const float gap = npc_gap<A>(cfg, ra, rb, i, bit_of_row<A>(i), ag, cp, sp, has_target, g_far, stl);\n    tde_mark(stl, 2);\n")
-    s = sub(s, "                      float cp, float sp, bool has_target, float g_far)\n{\n    using mask_t = typename MaskOf<A>::type;\n    constexpr int C = A < kSweepBlock ? A : kSweepBlock;\n    mask_t cand = 0;\n    const float hl_i = 0.5f * ag.len;\n    if (has_target) {",
-            "                      float cp, float sp, bool has_target, float g_far, unsigned long long *stl = nullptr)\n{\n    using mask_t = typename MaskOf<A>::type;\n    constexpr int C = A < kSweepBlock ? A : kSweepBlock;\n    mask_t cand = 0;\n    const float hl_i = 0.5f * ag.len;\n    if (has_target) {")
+    s = sub(s, "                      float cp, float sp, bool has_target, float g_far)\n{\n    using mask_t = typename MaskOf<A>::type;\n    constexpr int C = A < SB ? A : SB;\n    mask_t cand = 0;\n    const float hl_i = 0.5f * ag.len;\n    if (has_target) {",
+            "                      float cp, float sp, bool has_target, float g_far, unsigned long long *stl = nullptr)\n{\n    using mask_t = typename MaskOf<A>::type;\n    constexpr int C = A < SB ? A : SB;\n    mask_t cand = 0;\n    const float hl_i = 0.5f * ag.len;\n    if (has_target) {")
     s = sub(s, "        cand &= ~own_bit;\n    }\n    float gap = 1e30f;\n",
             "        cand &= ~own_bit;\n    }\n    tde_mark(stl, 1);\n    float gap = 1e30f;\n")
     a, b = kernel_span(s, "env_rollout_trio_kernel")
