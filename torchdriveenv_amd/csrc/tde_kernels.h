@@ -1862,8 +1862,9 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 
 // The arguments of env_step_wide_kernel's launch as ONE block in device memory instead of ~900 bytes of by-value arguments: every field
 // is then a scalar load where it is used, not a scalar register held from the kernel's top - 58 - 83 SGPRs instead of 106 with 4 - 24 of
-// them spilled, and with that 0 - 14 spilled VGPRs instead of 6 - 43.  The plain variants have none: no private segment, whose set-up
-// costs a launch more than a microsecond.  1024 envs x 128 slots: 16.0 -> 13.8 us per step (the first loads also issue 1 400 cycles
+// them spilled, and with that 0 - 14 spilled VGPRs instead of 6 - 43.  The eight-wavefront variants without lights have none (nor had
+// the plain four-wavefront ones before they traded 14 for wider sweep blocks): no private segment, whose set-up costs a launch more
+// than a microsecond.  1024 envs x 128 slots: 16.0 -> 13.8 us per step (the first loads also issue 1 400 cycles
 // sooner, which by itself changes nothing: profiles/r06_z_wide_128.txt).  Blocks are immutable, one per distinct argument set
 // (tde_api.hip: step_args); the action pointer - the one field a closed loop changes from call to call - stays a by-value argument.
 // (The three-role kernels keep by-value arguments: at 6 wavefronts per SIMD the block's extra hop costs them 0.2 - 0.4 us, same file.)
