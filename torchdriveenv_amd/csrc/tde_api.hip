@@ -195,6 +195,7 @@ static const tde::StepArgs *step_args(const tde_config *cfg, const tde_world *wo
     tde::StepArgs now;
     memset(&now, 0, sizeof(now));
     now.cfg = *cfg; now.w = *world; now.st = *st; now.st.action = nullptr; now.act_hash = act_hash;
+    tde::fill_cold(now.cold, *cfg, *world);                              // (host-filled: the kernel reads it from the block)
     std::lock_guard<std::mutex> lock(g_arg_mu);
     ArgPool &pool = g_arg_pool[dev];
     ArgEntry *ent = nullptr;

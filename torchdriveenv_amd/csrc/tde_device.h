@@ -426,7 +426,7 @@ TDE_DEV double u01(uint32_t r) { return (double)(r >> 8) * (1.0 / 16777216.0); }
 // `math.dist(..) > cutoff` / `math.dist(..) < 3` (gym_env.py:394,402) at a fraction of the instructions.
 // `lo` / `hi` = r*r*(1 -+ 1e-12): the sliver, formed once (Cold) instead of with three float64 multiplies per call
 struct Sliver { double lo, hi; };
-TDE_DEV Sliver sliver_of(double r) { const double r2 = r * r; return Sliver{r2 * (1.0 - 1e-12), r2 * (1.0 + 1e-12)}; }
+__host__ TDE_DEV Sliver sliver_of(double r) { const double r2 = r * r; return Sliver{r2 * (1.0 - 1e-12), r2 * (1.0 + 1e-12)}; }
 TDE_DEV bool sqrt_gt(double s, double r, const Sliver &v)
 {
     if (s > v.hi) return true;
@@ -478,7 +478,7 @@ TDE_DEV double cos_heading_f64(double x)
 
 // fp32 bounds of reward_core's pre-test: r^2 * (1 -+ 1e-6); a cut-off whose square leaves the normal fp32 range (or a NaN)
 // gets (0, +inf), which sends every step to the float64 path
-TDE_DEV void cut2f_bounds(double r, float &lo, float &hi)
+__host__ TDE_DEV void cut2f_bounds(double r, float &lo, float &hi)
 {
     const double r2 = r * r;
     lo = 0.0f; hi = __builtin_inff();
@@ -503,7 +503,7 @@ struct Cold {
     int n_scn, NW, RW, max_steps, terminated_at_infraction, NH;
 };
 
-TDE_DEV void fill_cold(Cold &c, const tde_config &cfg, const tde_world &w)
+__host__ TDE_DEV void fill_cold(Cold &c, const tde_config &cfg, const tde_world &w)
 {
     c.waypoint_bonus = cfg.waypoint_bonus; c.heading_penalty = cfg.heading_penalty;
     c.distance_bonus = cfg.distance_bonus; c.distance_cutoff = cfg.distance_cutoff;

@@ -1868,7 +1868,12 @@ __global__ __launch_bounds__(2 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)
 // sooner, which by itself changes nothing: profiles/r06_z_wide_128.txt).  Blocks are immutable, one per distinct argument set
 // (tde_api.hip: step_args); the action pointer - the one field a closed loop changes from call to call - stays a by-value argument.
 // (The three-role kernels keep by-value arguments: at 6 wavefronts per SIMD the block's extra hop costs them 0.2 - 0.4 us, same file.)
-struct StepArgs { tde_config cfg; tde_world w; tde_state st; uint32_t act_hash; uint32_t pad; };
+// `cold`: the block of rarely read arguments the other kernels park in LDS at their start (tde_device.h: Cold), here filled by the HOST with
+// the block: no fill on a lane, no barrier that publishes it (TDE_WIDE_COLD_IN_BLOCK=0: the LDS form, for the A/B).
+struct StepArgs { tde_config cfg; tde_world w; tde_state st; uint32_t act_hash; uint32_t pad; Cold cold; };
+#ifndef TDE_WIDE_COLD_IN_BLOCK
+#define TDE_WIDE_COLD_IN_BLOCK 1
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // The two-role rollout for 128 agent slots per env (the reference's ~100-agent scenes): ONE env per workgroup of four
@@ -2757,17 +2762,24 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
     const uint32_t act_hash = args->act_hash;
     constexpr int A = 128;
     __shared__ WideStepShared sh;
+#if TDE_WIDE_COLD_IN_BLOCK
+    const Cold &cold = args->cold;
+#define TDE_WIDE_COLD_BARRIER() ((void)0)
+#else
     __shared__ Cold cold;
+#define TDE_WIDE_COLD_BARRIER() lds_barrier()
+#endif
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = wide_role_wave();
     const int role = wv >> 1;                               // 0 = drive, 1 = judge; NW = 8: 2 = sweep helper, 3 = offroad helper
     const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
     // (the cold block is filled by a JUDGE lane - the drivers' loads are the launch's first instructions - and published by an
     //  LDS-only barrier that every role reaches with its loads in flight)
-    if (wv == (NW == 8 ? 4 : 2) && lane == 0) {
-        fill_cold(cold, cfg, w); sh.done = 0; sh.early[0] = 0; sh.early[1] = 0;
-        sh.help_seq[0] = sh.help_seq[1] = sh.off_seq[0] = sh.off_seq[1] = 0;
-    }
+    // (every flag word in LDS is initialised by the wavefront that later sets it - program order - and read by the others behind a
+    //  barrier that follows the initialisation: no barrier of its own)
+#if !TDE_WIDE_COLD_IN_BLOCK
+    if (wv == (NW == 8 ? 4 : 2) && lane == 0) fill_cold(cold, cfg, w);
+#endif
     const uint32_t F = cfg.flags;
     const bool first_acts = (F & TDE_F_NPC_FIRST_STEP) != 0;
     const bool lights = LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS);
@@ -2788,7 +2800,7 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         // stale entry falls back to the chain scenario -> spawn record -> route table and is rewritten (load_ctx_cached)
         int4 sc0 = make_int4(0, 0, 0, 0), sc1 = sc0;
         if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }
-        lds_barrier();                                       // cold is published
+        TDE_WIDE_COLD_BARRIER();                             // cold is published
         Ctx cx;
         bool rebuilt;
         load_ctx_cached<A>(cfg, cold, st, g, a, true, sc0, sc1, ag, er, cx, false, rebuilt);
@@ -2817,7 +2829,10 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         if (lights) fill_stop_cache_wide(sh, w, cx.m, a);
         if (F & TDE_F_NPC) {
             const bool stored = !npc || (k == 1 && !first_acts) || (akey.x == er.episode && akey.y == act_key_steps(act_hash, er.steps));
-            if (__ballot(!stored) && lane == 0) sh.early[wv] = 1;
+            const bool any_missing = __ballot(!stored) != 0ull;          // (every lane votes: ahead of the one-lane store)
+            if (lane == 0) sh.early[wv] = any_missing ? 1 : 0;
+        } else if (lane == 0) {
+            sh.early[wv] = 0;
         }
         lds_barrier();                                       // E: does a drive wavefront lack stored actions?
         if (sh.early[0] | sh.early[1]) {
@@ -2900,7 +2915,7 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
         double ep_ret = 0.0;
         if (a == 0 && st.ep_return) ep_ret = st.ep_return[e];
-        lds_barrier();                                       // cold is published
+        TDE_WIDE_COLD_BARRIER();                             // cold is published
         Ctx cx;
         cx.tgx = cx.tgy = 0.0f; cx.route_n = 0; cx.replay_len = 0; cx.wtx = cx.wty = 0.0; cx.n_wp = 0; cx.g_far = 0.0f;
         {
@@ -3026,7 +3041,8 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
     else if (NW == 8 && role == 2) {
         // ================================ sweep helper (NW = 8) ================================
         __builtin_amdgcn_s_setprio(2);
-        lds_barrier();                                       // cold
+        if (lane == 0) sh.help_seq[wv & 1] = 0;
+        TDE_WIDE_COLD_BARRIER();                             // cold
         lds_barrier();                                       // E
         if (sh.early[0] | sh.early[1]) lds_barrier();        // E2
         lds_barrier();                                       // B: rows of this step are in buffer 0, the drivers' ctl words beside them
@@ -3044,8 +3060,9 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
     } else if (NW == 8 && role == 3) {
         // ================================ offroad helper (NW = 8) ================================
         __builtin_amdgcn_s_setprio(1);
+        if (lane == 0) sh.off_seq[wv & 1] = 0;
         const int scn = st.scn[e], k = st.steps[e] + 1;
-        lds_barrier();                                       // cold
+        TDE_WIDE_COLD_BARRIER();                             // cold
         tde_map m{};
         if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[scn].x];
         const float thr2 = thr2_of(cfg);
@@ -3068,6 +3085,7 @@ __global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4
         lds_barrier();                                       // A
     }
 }
+#undef TDE_WIDE_COLD_BARRIER
 
 
 // MAG: also writes tde_state.magnitudes (judge O, behind barrier A); a template flag because the code, taken or not, costs the
