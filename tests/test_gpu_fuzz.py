@@ -90,7 +90,7 @@ def test_render_and_streams_fuzz(seed):
     from torchdriveenv_amd.synth import synthetic_world
 
     rng = np.random.default_rng(9000 + seed)
-    A = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+    A = int(rng.choice([1, 2, 4, 8, 16, 32, 64, 128]))            # (128: the two-role step kernel's argument blocks, one per sub-batch and stream)
     from torchdriveenv_amd.world import effective_offroad_distance
 
     squared = bool(rng.random() < 0.3)              # (the grid index is built for the effective distance of the reading)
@@ -113,7 +113,7 @@ def test_render_and_streams_fuzz(seed):
     img = torch.zeros((B, 3, H, W), dtype=torch.uint8, device=DEV)
     tag = f"seed {seed} A={A} B={B} {H}x{W} fov={fov} rflags={rflags} flags={flags:#x} streams={n_streams}"
     try:
-        _lib.kernel_override(step=[None, "solo", "trio"][int(rng.integers(0, 3))])
+        _lib.kernel_override(step=[None, "solo", "trio", "duo"][int(rng.integers(0, 4))])
         for t in range(24):
             act = np.stack([rng.uniform(-1, 1, B), rng.uniform(-0.3, 0.3, B)], -1).astype(np.float32)
             hs["action"][...] = act
