@@ -208,13 +208,11 @@ def patch_wide(s):
             "    const int a = ((wv & 1) << 6) | lane;                   // the lane's slot\n    unsigned long long stl = __builtin_amdgcn_s_memtime();\n"
             "    unsigned long long *sp = (wv & 1) ? nullptr : &stl;\n    if (threadIdx.x < 24) s_acc[threadIdx.x] = 0ull;\n"
             "    if (threadIdx.x == 0) g_wg[blockIdx.x & 4095][20] = __builtin_amdgcn_s_memrealtime();\n")
-    k = sub(k, "        sh.help_seq[0] = sh.help_seq[1] = sh.off_seq[0] = sh.off_seq[1] = 0;\n    }\n",
-            "        sh.help_seq[0] = sh.help_seq[1] = sh.off_seq[0] = sh.off_seq[1] = 0;\n    }\n    if (wv == 2) { asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); tde_mark(sp, 16); }\n")
     k = sub(k, "        if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }\n",
             "        if (st.slot_cache) { sc0 = reinterpret_cast<const int4 *>(st.slot_cache + g)[0]; sc1 = reinterpret_cast<const int4 *>(st.slot_cache + g)[1]; }\n        tde_mark(sp, 17);\n")
     # drive
-    k = sub(k, "        lds_barrier();                                       // cold is published\n        Ctx cx;\n        bool rebuilt;\n",
-            "        lds_barrier();                                       // cold is published\n        tde_mark(sp, 0);\n        Ctx cx;\n        bool rebuilt;\n")
+    k = sub(k, "        TDE_WIDE_COLD_BARRIER();                             // cold is published\n        Ctx cx;\n        bool rebuilt;\n",
+            "        TDE_WIDE_COLD_BARRIER();                             // cold is published\n        tde_mark(sp, 0);\n        Ctx cx;\n        bool rebuilt;\n")
     k = sub(k, "        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n",
             "        tde_mark(sp, 1);\n        lds_barrier();                                       // E: does a drive wavefront lack stored actions?\n        tde_mark(sp, 2);\n")
     k = sub(k, "        lds_barrier();                                       // B: rows of this step are in buffer 0\n        __builtin_amdgcn_s_setprio(NW == 8 ? 2 : TDE_WIDE_PRIO_D2);",

@@ -17,9 +17,9 @@ lib = _lib.load()
 world = synthetic_town(n_scn=32, A=128, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4)
 dw = world.to_device(dev)
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
-names = {17: "D: entry -> loads issued", 0: "D: -> cold published", 1: "D: state + cache entries landed, ctx, stored?", 2: "D: wait E",
+names = {17: "D: entry -> loads issued", 0: "D: -> (cold barrier: none since the cold block travels in the argument block)", 1: "D: state + cache entries landed, ctx, stored?", 2: "D: wait E",
          3: "D: bicycle, route switch, sincos, rows", 4: "D: wait B", 5: "D: next step's controller", 6: "D: wait A", 7: "D: re-spawn, stores (drained)",
-         16: "J: entry -> cold block filled", 8: "J: -> prologue done", 9: "J: wait E + B", 10: "J: collision sweep, exact tests, publish", 11: "J: offroad", 12: "J: join the other judge",
+         8: "J: entry -> prologue done", 9: "J: wait E + B", 10: "J: collision sweep, exact tests, publish", 11: "J: offroad", 12: "J: join the other judge",
          13: "J: reward, done flag", 14: "J: wait A", 15: "J: stores (drained)"}
 for B in [int(x) for x in sys.argv[1:] if x.isdigit()] or [1, 256, 1024]:
     _lib.kernel_override(step="duo")
