@@ -12,7 +12,9 @@ kern = sys.argv[2] if len(sys.argv) > 2 else None
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 8192
 dev = torch.device("cuda:0")
-world = synthetic_town(n_scn=256, A=A, seed=0) if TOWN else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4)
+CROWDED = os.environ.get("TDE_WORLD") == "crowded"      # TDE_WORLD=crowded: bench.py's 128-slot town (~122 agents present per env)
+world = (synthetic_town(n_scn=32, A=A, seed=5, n_streets=4, spacing=100.0, ext=160.0, min_gap=3.4) if CROWDED else
+         synthetic_town(n_scn=256, A=A, seed=0) if TOWN else synthetic_world(n_scn=64, A=A, seed=0, n_maps=4))
 dw = world.to_device(dev)
 cfg = _abi.default_config(seed=1000, distance_cutoff=0.25)
 if os.environ.get("TDE_COAST") == "1":                  # the opt-out of TDE_F_NPC_FIRST_STEP: the NPCs coast through an episode's first step
