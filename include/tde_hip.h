@@ -31,9 +31,9 @@ TDE_API const char *tde_last_error(void);
 /* Test / tuning hook (no reference counterpart): tde_env_rollout and tde_env_step each have several kernel forms (one, two
  * or three wavefronts per 64 agent slots) and pick one by group shape and batch size; this forces a form for the calling
  * process - 0 = automatic (default), rollout_team 1 | 2 | 3, step_team 1 | 3 (2 at 128 slots) - so that every form can be held against the
- * oracle and A/B-timed.  A forced three-wavefront form still needs 8, 16 or 32 agents per env; at 128 agent slots per env only
- * rollout_team 1 has an effect (the one-role persistent kernel instead of the two-role wide one): 2 and 3 leave the choice as it
- * is; step_team 1 = the one-role step kernel, 2 = the two-role wide step kernel at any batch size.  The two values are atomics: a call from one thread while another launches is a race on the choice, not on memory. */
+ * oracle and A/B-timed.  A forced three-wavefront form still needs 8, 16 or 32 agents per env; at 128 agent slots per env
+ * rollout_team / step_team 1 = the one-role kernel, 2 = the two-role kernel in its four-wavefront form at any batch size (the
+ * library itself takes the eight-wavefront form up to half a residency round), 3 leaves the choice as it is.  The two values are atomics: a call from one thread while another launches is a race on the choice, not on memory. */
 TDE_API int tde_kernel_override(int rollout_team, int step_team);
 
 /* ---- operator level: the SimulatorInterface methods GymEnv calls ------------------------------------ */

@@ -263,10 +263,13 @@ def test_two_role_step_kernel_forced_at_a_full_residency_round(crowded_town):
     assert int(hs["episode"].max()) >= 3
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(8))
 def test_rollout_fuzz_128_slots(seed, crowded_town):
-    """the two-role 128-slot rollout kernel over random flags (lights, no auto-reset, no offroad, no reward), launch lengths and
-    episode lengths, consecutive launches: rewards, done bits and the whole state equal the oracle's after every launch"""
+    """the two-role 128-slot rollout kernel - eight wavefronts per env (what the library picks for these batches: sweep and offroad
+    helpers beside drivers and judges), four (tde_kernel_override(2, 0)) and the one-role kernel (1, 0), by seed - over random flags
+    (lights, no auto-reset, no offroad, no reward), launch lengths and episode lengths, consecutive launches: rewards, done bits and the
+    whole state equal the oracle's after every launch"""
+    from torchdriveenv_amd import _lib
     from torchdriveenv_amd.synth import synthetic_world
 
     rng = np.random.default_rng(700 + seed)
@@ -286,12 +289,17 @@ def test_rollout_fuzz_128_slots(seed, crowded_town):
     dw = world.to_device(DEV)
     oracle.env_reset(cfg, world, hs)
     ops.env_reset(cfg, dw, ds)
-    for launch in range(3):
-        K = int(rng.choice([1, 2, 9, 33]))
-        actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
-        hr, hd = oracle.env_rollout(cfg, world, hs, actions)
-        dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
-        tag = f"seed {seed} B={B} K={K} flags={flags:#x} max_steps={cfg.max_steps} launch {launch}"
-        assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)), tag
-        assert np.array_equal(dd.cpu().numpy(), hd), tag
-        assert_state_equal(hs.host(), ds.host(), tag)
+    form = [None, "duo", None, "duo", None, "duo", "solo", None][seed]
+    _lib.kernel_override(rollout=form)
+    try:
+        for launch in range(3):
+            K = int(rng.choice([1, 2, 9, 33]))
+            actions = np.stack([rng.uniform(-1, 1, (K, B)), rng.uniform(-0.3, 0.3, (K, B))], -1).astype(np.float32)
+            hr, hd = oracle.env_rollout(cfg, world, hs, actions)
+            dr, dd = ops.env_rollout(cfg, dw, ds, dev(actions))
+            tag = f"seed {seed} form {form} B={B} K={K} flags={flags:#x} max_steps={cfg.max_steps} launch {launch}"
+            assert np.array_equal(dr.cpu().numpy().view(np.uint32), hr.view(np.uint32)), tag
+            assert np.array_equal(dd.cpu().numpy(), hd), tag
+            assert_state_equal(hs.host(), ds.host(), tag)
+    finally:
+        _lib.kernel_override()

@@ -342,8 +342,8 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
         // keep an env inside one wavefront)
         tde_rollout r128 = *ro;
         if (r128.ldb == 0) r128.ldb = st->B;
-        // Two roles (four wavefronts per env) at every batch size - us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs:
-        // two roles 6.2 / 8.9 / 18.0 / 34.7, one role 10.6 / 11.4 / 23.3 / 38.9 (profiles/r04_z_wide2_waves.txt).
+        // Two roles at every batch size - us per step at ~122 agents per env, 256 / 1024 / 2048 / 4096 envs: two roles (four wavefronts
+        // per env) 6.2 / 8.9 / 18.0 / 34.7, one role 10.6 / 11.4 / 23.3 / 38.9 (profiles/r04_z_wide2_waves.txt; round 6: 7.3 at 1024 envs).
         // tde_kernel_override(1, 0) forces the one-role kernel.
         if (g_force_rollout == 1) return tde_host::launch_rollout_solo(cfg, world, st, &r128, stream);
         const tde::StepArgs *args = nullptr;
@@ -351,7 +351,11 @@ int tde_env_rollout(const tde_config *cfg, const tde_world *world, const tde_sta
         args = step_args(cfg, world, st, 0u, stream);
         if (!args) return tde_host::launch_rollout_solo(cfg, world, st, &r128, stream);
 #endif
-        return tde_host::launch_rollout_wide(args, cfg, world, st, &r128, stream);
+        // eight wavefronts per env while the batch leaves the CUs issue slots to spare (half a residency round), four above - us per
+        // step, four / eight: 1 env 5.05 / 3.49, 64 envs 5.22 / 3.69, 256 envs 5.35 / 3.81, 512 envs 5.42 / 4.01, 256 envs with lights
+        // 6.61 / 5.01 (profiles/r06_z_wide_128.txt); tde_kernel_override(2, 0) = the four-wavefront form at any batch size
+        const int waves = (g_force_rollout != 2 && TDE_WIDE_ROLLOUT_WAVES8 && st->B <= 2 * cu_count()) ? 8 : 4;
+        return tde_host::launch_rollout_wide(args, cfg, world, st, &r128, waves, stream);
     }
     // Which persistent kernel: one, two or three wavefronts per group of 64 agent slots (tde_kernel_override(1 | 2 | 3, 0)
     // forces one; a forced trio still needs 8, 16 or 32 agents per env).  Interleaved same-process A/B, 40 launches each, median

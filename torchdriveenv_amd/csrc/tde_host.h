@@ -88,7 +88,7 @@ int launch_step_solo(const tde_config *cfg, const tde_world *world, const tde_st
 int launch_step_solo_mag(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream);
 // tde_rollout_trio.hip: env_rollout_trio_kernel<A in {8, 16, 32}, LIGHTS, BIG>; env_rollout_wide_kernel<LIGHTS> (128 slots)
 int launch_rollout_trio(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, void *stream);
-int launch_rollout_wide(const tde::StepArgs *args, const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, void *stream);
+int launch_rollout_wide(const tde::StepArgs *args, const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, int waves, void *stream);
 // tde_rollout_duo.hip: env_rollout_duo_kernel<A <= 64, LIGHTS, BIG>
 int launch_rollout_duo(const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, void *stream);
 // tde_rollout_solo.hip: env_rollout_kernel<A <= 128, LIGHTS>

@@ -1890,6 +1890,12 @@ struct WideShared {
     int done;                            // the env finished at the last judged step (and auto-reset is on)
     int coll[128];                       // collide_rows_wide_sym: the stamp of the last step at which a partner credited the slot a hit
     int coll_seq[2];                     // ... the stamp up to which a judge wavefront's credits are written
+    // the eight-wavefront forms: what the helpers take from / hand to the drivers and judges
+    float ctl[128];                      // drive -> sweep helper: the slot's g_far for the NEXT step's controller, < 0 = no target
+    float gap_part[128];                 // sweep helper -> drive: the leader gap over rows 64-127
+    int offw[128];                       // offroad helper -> judge: the slot's offroad flag
+    int tlw;                             // ... and the ego's stop-line violation
+    int help_seq[2], off_seq[2];         // the stamp of the step a helper wavefront's results are written for
     float4 stop[kStopCache][2];          // the first kStopCache stop lines of the env's map
 };
 struct WideLines {
@@ -1943,20 +1949,26 @@ TDE_DEV int wide_role_wave()
 #ifndef TDE_WIDE2_WAVES
 #define TDE_WIDE2_WAVES 4
 #endif
+#ifndef TDE_WIDE_ROLLOUT_WAVES8
+#define TDE_WIDE_ROLLOUT_WAVES8 1     // 0: the library never launches the eight-wavefront rollout form (A/B)
+#endif
 #ifndef TDE_WIDE_ROLLOUT_BLOCK
 #define TDE_WIDE_ROLLOUT_BLOCK 0         // 1: the persistent kernel's arguments from the block too (A/B: 16 instead of 34 spilled VGPRs, and SLOWER -
                                          // 1024 envs 5.25 -> 6.13 us per step: scalar loads inside the step loop; profiles/r06_z_wide_128.txt)
 #endif
-template <bool LIGHTS>
+// NW = 8 (batches up to half a residency round): the eight-wavefront form of env_step_wide_kernel in the persistent loop - two sweep
+// helpers take rows 64-127 of the controller sweep of the drivers' slots (first pass only: a re-spawn's second pass is the drivers' own),
+// two offroad helpers take offroad and the ego's stop-line test; stamps instead of flags (the step number + 1).
+template <bool LIGHTS, int NW = 4>
 #if TDE_WIDE_ROLLOUT_BLOCK
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(const StepArgs *__restrict__ args,
+__global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(const StepArgs *__restrict__ args,
                                                                      tde_rollout ro)
 {
     const tde_config &cfg = args->cfg;
     const tde_world &w = args->w;
     const tde_state &st = args->st;
 #else
-__global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(tde_config cfg, tde_world w, tde_state st,
+__global__ __launch_bounds__(NW * kWave) __attribute__((amdgpu_waves_per_eu(TDE_WIDE2_WAVES, TDE_WIDE2_WAVES))) void env_rollout_wide_kernel(tde_config cfg, tde_world w, tde_state st,
                                                                      tde_rollout ro)
 {
 #endif
@@ -1965,7 +1977,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
     __shared__ Cold cold;
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = wide_role_wave();
-    const int role = wv >> 1;                               // 0 = drive, 1 = judge
+    const int role = wv >> 1;                               // 0 = drive, 1 = judge; NW = 8: 2 = sweep helper, 3 = offroad helper
     const int a = ((wv & 1) << 6) | lane;                   // the lane's slot
     if (threadIdx.x == 0) { fill_cold(cold, cfg, w); sh.done = 0; }
     const uint32_t F = cfg.flags;
@@ -1989,6 +2001,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
         float c0, s0;
         sincos_f32(ag.psi, s0, c0);
         write_rows_wide(sh, 1, a, ag.present, ag, c0, s0, cfg.npc_lane_half);
+        if constexpr (NW == 8) sh.ctl[a] = ((F & TDE_F_NPC) && a > 0 && ag.present && ag.route >= 0 && ag.route_wp < cx.route_n) ? cx.g_far : -1.0f;
         if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) fill_stop_cache_wide(sh, w, cx.m, a);
         lds_barrier();                                       // rows of the launch state are in buffer 1
         const float2 *acts = reinterpret_cast<const float2 *>(ro.actions);
@@ -2016,7 +2029,15 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
                         const uint32_t red = (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS)) ? red_mask_cached(w, cx.m, k, redc) : 0u;
                         const float red_gap =
                             (LIGHTS && red && has_target) ? red_line_gap_of(cfg, WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red, ag, c0, s0) : 1e30f;
-                        npc_action_wide<A>(cfg, &sh.a[q][0], &sh.b[q][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+                        if (NW == 8 && pass == 0) {         // rows 64-127 are a sweep helper's (stamp = this step's number + 1)
+                            const unsigned long long own = one_bit64(63 - (a & 63));
+                            const float g0 = npc_gap<64>(cfg, &sh.a[q][0], &sh.b[q][0], a, a < 64 ? own : 0ull, ag, c0, s0, has_target, cx.g_far);
+                            while (*reinterpret_cast<volatile int *>(&sh.help_seq[wv & 1]) != i + 1) __builtin_amdgcn_s_sleep(1);
+                            const float g1 = *reinterpret_cast<volatile float *>(&sh.gap_part[a]);
+                            npc_act_of_gap(cfg, ag, c0, s0, has_target, cx.tgx, cx.tgy, fminf(g0, g1), red_gap, na, nb);
+                        } else {
+                            npc_action_wide<A>(cfg, &sh.a[q][0], &sh.b[q][0], a, ag, c0, s0, has_target, cx.tgx, cx.tgy, cx.g_far, red_gap, na, nb);
+                        }
                     }
                     if (npc && (k > 1 || first_acts)) { acc = na; beta = nb; }
                 }
@@ -2050,6 +2071,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
             c0 = nc; s0 = ns;
             er.steps = k;
             write_rows_wide(sh, p, a, live, ag, c0, s0, cfg.npc_lane_half);
+            if constexpr (NW == 8) sh.ctl[a] = ((F & TDE_F_NPC) && a > 0 && live && ag.route >= 0 && ag.route_wp < cx.route_n) ? cx.g_far : -1.0f;   // of step i + 1
             lds_barrier();                                   // B: rows of step i are in buffer p
             if (switched) load_route_target(cold, ag, cx);
             act = act_next;
@@ -2058,7 +2080,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
         if (sh.done) reset_lane<A>(cfg, cold, e, a, ag, er);
         store_agent_dynamic(st, g, ag);
         store_agent_static(st, g, ag);
-    } else {
+    } else if (role == 1) {
         // ================================ judge ================================
         TDE_WIDE_PROLOGUE
         StepOut o{0.0f, 0, 0, 0, 0, 0, false, 0};
@@ -2083,7 +2105,7 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
             const bool live = rc.z != 0.0f;
             const float x = ra.x, y = ra.y, c0 = rb.x, s0 = rb.y, hl = rb.z, hw = rb.w;
             Corners corners;
-            if (F & TDE_F_OFFROAD) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
+            if (NW != 8 && (F & TDE_F_OFFROAD)) offroad_issue<false>(w, cx.m, live, x, y, c0, s0, hl, hw, corners);
 #if TDE_WIDE_SYM
             bool hit = collide_rows_wide_sym(&sh.a[p][0], &sh.b[p][0], a, live, x, y, c0, s0, hl, hw, ra.z, sh.coll, i + 1);
             wide_sym_publish(sh, wv & 1, lane, i + 1);
@@ -2091,13 +2113,18 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
             const bool hit = collide_rows_wide<A>(&sh.a[p][0], &sh.b[p][0], a, live, x, y, c0, s0, hl, hw, ra.z);
 #endif
             bool off = false;
-            if (F & TDE_F_OFFROAD) off = offroad_resolve<false, false>(w, corners, thr2, cx.m.rec_base);
+            if (NW != 8 && (F & TDE_F_OFFROAD)) off = offroad_resolve<false, false>(w, corners, thr2, cx.m.rec_base);
 #if TDE_WIDE_SYM
             hit |= wide_sym_joined(sh, wv & 1, a, i + 1);
 #endif
             bool tl = false;
-            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0)
+            if constexpr (NW == 8) {                         // (the offroad helper's flags for this half of the slots at this step)
+                while (*reinterpret_cast<volatile int *>(&sh.off_seq[wv & 1]) != i + 1) __builtin_amdgcn_s_sleep(1);
+                off = *reinterpret_cast<volatile int *>(&sh.offw[a]) != 0;
+                if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0) tl = *reinterpret_cast<volatile int *>(&sh.tlw) != 0;
+            } else if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0) {
                 tl = tl_violation_of(WideLines{sh, w.stoplines + cx.m.stop_base}, cx.m.n_stop, red_mask_cached(w, cx.m, k, redc), x, y, c0, s0, hl, hw);
+            }
             o = StepOut{0.0f, 0, 0, (uint8_t)(hit ? 1 : 0), (uint8_t)(off ? 1 : 0), (uint8_t)(tl ? 1 : 0), false, k};
             if (a == 0) {
                 int done = 0;
@@ -2144,6 +2171,65 @@ __global__ __launch_bounds__(4 * kWave) __attribute__((amdgpu_waves_per_eu(TDE_W
             st.truncated[e] = o.truncated;
             if (st.tl_violation) st.tl_violation[e] = o.tl;
         }
+    } else if (NW == 8 && role == 2) {
+        // ================================ sweep helper (NW = 8) ================================
+        __builtin_amdgcn_s_setprio(3);
+        if (lane == 0) sh.help_seq[wv & 1] = 0;
+        lds_barrier();                                       // rows of the launch state are in buffer 1, the drivers' ctl words beside them
+        for (int i = 0; i < ro.K; ++i) {
+            const int q = (i & 1) ^ 1;
+            if (F & TDE_F_NPC) {
+                const float4 ra = sh.a[q][a], rb = sh.b[q][a];
+                const float gf = sh.ctl[a];
+                Agent me{};
+                me.x = ra.x; me.y = ra.y; me.len = 2.0f * rb.z;  // (0.5f * len == hl exactly: the driver's own operand)
+                const unsigned long long own = one_bit64(63 - (a & 63));
+                sh.gap_part[a] = npc_gap<64>(cfg, &sh.a[q][64], &sh.b[q][64], a - 64, a < 64 ? 0ull : own, me, rb.x, rb.y, gf >= 0.0f, gf);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *reinterpret_cast<volatile int *>(&sh.help_seq[wv & 1]) = i + 1;
+            }
+            lds_barrier();                                   // A
+            if (sh.done && first_acts) lds_barrier();        // (the drivers' barrier between the spawn rows and their second pass)
+            lds_barrier();                                   // B
+        }
+        lds_barrier();                                       // done(K-1)
+    } else if (NW == 8 && role == 3) {
+        // ================================ offroad helper (NW = 8) ================================
+        __builtin_amdgcn_s_setprio(1);
+        Agent ag{};                                          // (only the episode bookkeeping of a re-spawn touches it)
+        EnvRegs er{st.scn[e], st.steps[e], st.target_idx[e], st.reached[e], st.episode[e]};
+        RedCache redc; redc.invalidate();
+        tde_map m{};
+        if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
+        const float thr2 = thr2_of(cfg);
+        if (lane == 0) sh.off_seq[wv & 1] = 0;
+        lds_barrier();
+        for (int i = 0; i < ro.K; ++i) {
+            const int p = i & 1;
+            lds_barrier();                                   // A
+            if (sh.done) {                                   // (sh.done is 0 until the first judged step)
+                reset_lane<A>(cfg, cold, e, a, ag, er);
+                if (F & (TDE_F_OFFROAD | TDE_F_TRAFFIC_LIGHTS)) m = cold.maps[reinterpret_cast<const int4 *>(cold.scn)[er.scn].x];
+                redc.invalidate();
+                if (first_acts) lds_barrier();
+            }
+            lds_barrier();                                   // B: rows of step i are in buffer p
+            er.steps += 1;
+            const float4 ra = sh.a[p][a], rb = sh.b[p][a], rc = sh.c[p][a];
+            const bool live = rc.z != 0.0f;
+            bool off = false;
+            if (F & TDE_F_OFFROAD) {
+                Corners corners;
+                offroad_issue<false>(w, m, live, ra.x, ra.y, rb.x, rb.y, rb.z, rb.w, corners);
+                off = offroad_resolve<false, false>(w, corners, thr2, m.rec_base);
+            }
+            sh.offw[a] = off ? 1 : 0;
+            if (LIGHTS && (F & TDE_F_TRAFFIC_LIGHTS) && a == 0)
+                sh.tlw = tl_violation_of(WideLines{sh, w.stoplines + m.stop_base}, m.n_stop, red_mask_cached(w, m, er.steps, redc), ra.x, ra.y, rb.x, rb.y, rb.z, rb.w) ? 1 : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *reinterpret_cast<volatile int *>(&sh.off_seq[wv & 1]) = i + 1;
+        }
+        lds_barrier();                                       // done(K-1)
     }
 }
 #undef TDE_WIDE_PROLOGUE
@@ -2738,12 +2824,6 @@ TDE_DEV int act_key_steps(uint32_t cfg_hash, int steps) { return (int)(cfg_hash 
 struct WideStepShared : WideShared {
     int early[2];                        // a drive wavefront has a slot without a stored action
     float poly[32];                      // MAG: box_iou_wave's vertex lists
-    // the eight-wavefront form: what the helpers take from / hand to the drivers and judges
-    float ctl[128];                      // drive -> sweep helper: the slot's g_far for the NEXT step's controller, < 0 = no target
-    float gap_part[128];                 // sweep helper -> drive: the leader gap over rows 64-127
-    int offw[128];                       // offroad helper -> judge: the slot's offroad flag
-    int tlw;                             // ... and the ego's stop-line violation
-    int help_seq[2], off_seq[2];         // 1 = a helper wavefront's results are written
 };
 
 // NW = 8 (batches up to half a residency round, where the CUs have issue slots to spare): four more wavefronts per env take work off the

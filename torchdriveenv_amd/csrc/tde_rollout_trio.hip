@@ -32,18 +32,20 @@ int launch_rollout_trio(const tde_config *cfg, const tde_world *world, const tde
     return launch_status("tde_env_rollout");
 }
 
-int launch_rollout_wide(const tde::StepArgs *args, const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, void *stream)
+int launch_rollout_wide(const tde::StepArgs *args, const tde_config *cfg, const tde_world *world, const tde_state *st, const tde_rollout *ro, int waves, void *stream)
 {
-    // two roles, four wavefronts per env of 128 slots: one env per workgroup
+    // two roles, four wavefronts per env of 128 slots (waves = 8: + two sweep helpers and two offroad helpers): one env per workgroup
+    const bool lights = (cfg->flags & TDE_F_TRAFFIC_LIGHTS) != 0;
 #if TDE_WIDE_ROLLOUT_BLOCK
     (void)world;
-    if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) tde::env_rollout_wide_kernel<true><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(args, *ro);
-    else tde::env_rollout_wide_kernel<false><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(args, *ro);
+#define TDE_LAUNCH_RW(L, NW) tde::env_rollout_wide_kernel<L, NW><<<(unsigned)st->B, NW * tde::kWave, 0, (hipStream_t)stream>>>(args, *ro)
 #else
     (void)args;
-    if (cfg->flags & TDE_F_TRAFFIC_LIGHTS) tde::env_rollout_wide_kernel<true><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
-    else tde::env_rollout_wide_kernel<false><<<(unsigned)st->B, 4 * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro);
+#define TDE_LAUNCH_RW(L, NW) tde::env_rollout_wide_kernel<L, NW><<<(unsigned)st->B, NW * tde::kWave, 0, (hipStream_t)stream>>>(*cfg, *world, *st, *ro)
 #endif
+    if (waves == 8) { if (lights) TDE_LAUNCH_RW(true, 8); else TDE_LAUNCH_RW(false, 8); }
+    else { if (lights) TDE_LAUNCH_RW(true, 4); else TDE_LAUNCH_RW(false, 4); }
+#undef TDE_LAUNCH_RW
     return launch_status("tde_env_rollout");
 }
 
