@@ -263,6 +263,8 @@ def secondary(dev, region_s=0.3):
                             config=3, B=1024, A=128, stepwise=False, flags=F, town="crowded")),
         ("agents_128_closed_loop", dict(name="the same in closed loop: one tde_env_step launch per timestep",
                                         config=3, B=1024, A=128, stepwise=True, flags=F, town="crowded")),
+        ("agents_128_256", dict(name="256 envs x 128 agent slots, rollout (eight wavefronts per env up to half a residency round)",
+                                config=3, B=256, A=128, stepwise=False, flags=F, town="crowded")),
         ("agents_128_closed_loop_256", dict(name="256 envs x 128 agent slots in closed loop (half a residency round and below: eight wavefronts per env - "
                                                  "drive, judge, sweep helper, offroad helper for each half of the slots)",
                                             config=3, B=256, A=128, stepwise=True, flags=F, town="crowded")),
@@ -808,7 +810,7 @@ def main():
                 "reference_semantics": pt("lights_closed_loop"),          # closed loop, lights + first step: the reference's step()
                 "reference_semantics_full": pt("lights_closed_loop_full_outputs"),
                 "agents_128": pt("agents_128"), "agents_128_closed_loop": pt("agents_128_closed_loop"),
-                "agents_128_closed_loop_256_envs": pt("agents_128_closed_loop_256"),
+                "agents_128_256_envs": pt("agents_128_256"), "agents_128_closed_loop_256_envs": pt("agents_128_closed_loop_256"),
                 "note": "us per timestep / algorithmic bytes over the 8 TB/s peak; default flags = TDE_F_ALL (NPCs act from step one); "
                         "reference_semantics = traffic lights + first step, closed loop"}
             try:
