@@ -1,5 +1,5 @@
 """Builds libtde_hip.so in-tree with hipcc for gfx950: one translation unit per kernel family (csrc/tde_*.hip), compiled side by
-side on the host's cores (~35 s on 8 instead of the ~95 s of the single unit csrc/tde_kernels.hip), linked, and the linked code
+side on the host's cores (~40 s on 8 instead of the ~120 s of the single unit csrc/tde_kernels.hip), linked, and the linked code
 object audited (isa_audit.py) before the library is put in place."""
 import os
 import subprocess
@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 # the units, longest first (the pool starts them in this order)
-UNITS = ["tde_step_solo_mag.hip", "tde_step_solo.hip", "tde_step_trio.hip", "tde_rollout_duo.hip", "tde_rollout_trio.hip",
-         "tde_rollout_solo.hip", "tde_step_wide.hip", "tde_api.hip"]
+UNITS = ["tde_step_solo_mag.hip", "tde_step_wide.hip", "tde_step_wide8.hip", "tde_step_solo.hip", "tde_step_trio.hip", "tde_rollout_trio.hip",
+         "tde_rollout_duo.hip", "tde_rollout_solo.hip", "tde_api.hip"]
 SRC = [os.path.join(_CSRC, u) for u in UNITS]
 HEADERS = ["tde_kernels.h", "tde_host.h", "tde_device.h", "tde_raster.h", "tde_gridbuild.h", "tde_magnitudes.h", "tde_magnitudes_kernels.h"]
 DEPS = SRC + [os.path.join(_CSRC, h) for h in HEADERS] + [os.path.join(_PKG, "..", "include", "tde_abi.h"),

@@ -83,6 +83,8 @@ int launch_step_trio(const tde_config *cfg, const tde_world *world, const tde_st
 // tde_step_wide.hip: env_step_wide_kernel<LIGHTS, OBS, MAG> (128 agent slots per env, two roles)
 // (`args` = the launch's argument block in device memory, tde_api.hip: step_args; `st` = the caller's struct - shape, optional outputs, action)
 int launch_step_wide(const tde::StepArgs *args, const tde_config *cfg, const tde_state *st, int waves, void *stream);
+// tde_step_wide8.hip: the same kernel's eight-wavefront instantiations (launch_step_wide hands waves == 8 over)
+int launch_step_wide8(const tde::StepArgs *args, const tde_config *cfg, const tde_state *st, void *stream);
 // tde_step_solo.hip / tde_step_solo_mag.hip: env_step_kernel<A, LIGHTS, OBS, BIG, WAVES, MAG = false / true>
 int launch_step_solo(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream);
 int launch_step_solo_mag(const tde_config *cfg, const tde_world *world, const tde_state *st, void *stream);

@@ -14,6 +14,7 @@
 #include "tde_api.hip"
 #include "tde_step_trio.hip"
 #include "tde_step_wide.hip"
+#include "tde_step_wide8.hip"
 #include "tde_step_solo.hip"
 #include "tde_step_solo_mag.hip"
 #include "tde_rollout_trio.hip"
